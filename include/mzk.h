@@ -1,0 +1,131 @@
+/* mzk.h -- C ABI of libmi355zk: the MI355X (gfx950) backend for the jf-plonk prover's
+ * arithmetic hot path (radix-2 NTT over Fr, Pippenger MSM on G1).
+ *
+ * The reference (renegade-fi/mpc-jellyfish) has no FFI of its own: the path sits behind two
+ * third-party Rust trait surfaces.  Each entry point below names the reference call it replaces
+ * (paths relative to the reference tree); INTEGRATION.md shows the Rust-side binding.
+ *
+ * Conventions
+ *   curve_id        0 = BLS12-381, 1 = BN254.
+ *   field elements  little-endian 64-bit limbs; Fr = 4 limbs; Fq = 6 limbs (BLS12-381) / 4 (BN254).
+ *                   "mont" = Montgomery form a*R mod p with R = 2^(64*limbs), fully reduced --
+ *                   the in-memory image of ark-ff's Fp<MontBackend<_,N>,N>.
+ *   affine points   packed x||y (mont), no flag word; (0,0) encodes the point at infinity.
+ *   Jacobian out    X||Y||Z (mont); Z = 0 encodes infinity (ark-ec `Projective::new_unchecked(X,Y,Z)`).
+ *   return value    0 on success, < 0 on error (mzk_strerror); never unwinds, never aborts.
+ *   threading       every entry point may be called concurrently (the reference calls commit and
+ *                   fft from Rayon workers: univariate_kzg/mod.rs:125-127, prover.rs:552-562);
+ *                   calls are serialised on an internal lock and run on one HIP stream.
+ *   memory          host buffers are borrowed for the duration of the call; the library owns all
+ *                   device memory it allocates, including the registered SRS copy.
+ *   "_dev" variants take device pointers (hipMalloc / torch tensors) and a hipStream_t passed as
+ *                   void* (NULL = the null stream); they do not synchronise unless stated.
+ */
+#ifndef MZK_H
+#define MZK_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#if defined(__GNUC__)
+#define MZK_API __attribute__((visibility("default")))
+#else
+#define MZK_API
+#endif
+
+#define MZK_OK 0
+#define MZK_ERR_INVALID_ARG (-1)
+#define MZK_ERR_HIP (-2)          /* a HIP runtime call failed; text via mzk_last_error() */
+#define MZK_ERR_NO_DEVICE (-3)
+#define MZK_ERR_BAD_HANDLE (-4)
+#define MZK_ERR_UNSUPPORTED (-5)
+#define MZK_ERR_OOM (-6)
+#define MZK_ERR_NOT_INIT (-7)
+
+#define MZK_CURVE_BLS12_381 0
+#define MZK_CURVE_BN254 1
+
+/* Bind the library to HIP device `device` (idempotent; -1 = current device).  Fails with
+ * MZK_ERR_NO_DEVICE when no GPU is visible: there is no CPU fallback. */
+MZK_API int32_t mzk_init(int32_t device);
+MZK_API int32_t mzk_shutdown(void);
+MZK_API const char* mzk_strerror(int32_t code);
+MZK_API const char* mzk_last_error(void);
+MZK_API const char* mzk_version(void);
+
+/* ---- SRS (CommitKey = UnivariateProverParam{powers_of_g}; primitives/src/pcs/univariate_kzg/srs.rs:36-40) ---- */
+
+/* Copy n_points affine bases to the device once; returns an opaque handle. */
+MZK_API int32_t mzk_srs_register(int32_t curve_id, const uint64_t* xy_mont, uint64_t n_points, uint64_t* out_handle);
+MZK_API int32_t mzk_srs_register_dev(int32_t curve_id, const void* d_xy_mont, uint64_t n_points, uint64_t* out_handle, void* stream);
+MZK_API int32_t mzk_srs_release(uint64_t handle);
+/* Testing SRS on the device: point i = beta^i * G (G = standard generator), beta canonical 4 limbs.
+ * Mirrors gen_srs_for_testing (srs.rs:118-153) with g fixed to the generator. */
+MZK_API int32_t mzk_srs_generate_for_testing(int32_t curve_id, const uint64_t* beta_canonical, uint64_t n_points, uint64_t* out_handle);
+MZK_API int32_t mzk_srs_download(uint64_t handle, uint64_t first, uint64_t n_points, uint64_t* out_xy_mont);
+MZK_API int32_t mzk_srs_len(uint64_t handle, uint64_t* out_n_points);
+
+/* ---- MSM: replaces <E::G1 as VariableBaseMSM>::msm_bigint(bases, bigints)
+ *      at univariate_kzg/mod.rs:109-111 (commit) and :151-155 (open).
+ * Computes sum_{i<n} scalars[i] * srs[base_offset + i]; base_offset = num_leading_zeros of
+ * skip_leading_zeros_and_convert_to_bigints (mod.rs:379-388).  scalars: n x 4 limbs, canonical
+ * integers (msm_bigint semantics) or, with scalars_are_mont != 0, Montgomery Fr as stored in a
+ * DensePolynomial (saves the CPU-side into_bigint pass, mod.rs:390-395).
+ * n = 0 yields infinity.  Fails with MZK_ERR_INVALID_ARG if base_offset + n exceeds the SRS
+ * (the reference's degree guard, mod.rs:98-104). */
+MZK_API int32_t mzk_msm(uint64_t srs_handle, uint64_t base_offset, const uint64_t* scalars, uint64_t n,
+                int32_t scalars_are_mont, uint64_t* out_xyz_mont);
+/* Device-resident scalars; the result lands in host memory (the call synchronises the stream). */
+MZK_API int32_t mzk_msm_dev(uint64_t srs_handle, uint64_t base_offset, const void* d_scalars, uint64_t n,
+                    int32_t scalars_are_mont, uint64_t* out_xyz_mont, void* stream);
+/* batch_commit (mod.rs:119-131) in one call: n_polys independent MSMs over one SRS. */
+MZK_API int32_t mzk_msm_batch(uint64_t srs_handle, uint32_t n_polys, const uint64_t* const* scalars, const uint64_t* lens,
+                      const uint64_t* base_offsets, int32_t scalars_are_mont, uint64_t* out_xyz_mont);
+/* Same point as mzk_msm but normalised on the host: x||y (mont), (0,0) for infinity
+ * (the `.into_affine()` of mod.rs:111 folded in). */
+MZK_API int32_t mzk_msm_affine(uint64_t srs_handle, uint64_t base_offset, const uint64_t* scalars, uint64_t n,
+                       int32_t scalars_are_mont, uint64_t* out_xy_mont);
+
+/* ---- NTT: replaces EvaluationDomain::{fft,ifft}_in_place on Radix2EvaluationDomain
+ *      forward coset: plonk/src/proof_system/prover.rs:554,557,561,566,567,579-591
+ *      inverse coset: plonk/src/proof_system/prover.rs:672
+ *      inverse plain: relation/src/constraint_system.rs:1172,1189,1221,1240,1257,1266-1287,1366,1414-1415
+ * data: 2^log_n x 4 limbs (mont), transformed in place, natural order in and out.  Elements at
+ * index >= in_len are treated as zero on input (the reference zero-pads short coefficient
+ * vectors).  coset_offset_mont = NULL means offset 1; otherwise one Fr (mont), e.g. Fr::GENERATOR
+ * for `quot_domain.get_coset(Fr::GENERATOR)` (prover.rs:545).
+ *   forward: out[i] = sum_j c[j] (h w^i)^j      inverse: c[j] = h^-j N^-1 sum_i e[i] w^(-ij) */
+MZK_API int32_t mzk_ntt(int32_t curve_id, uint64_t* data_mont, uint64_t in_len, uint32_t log_n, int32_t inverse,
+                const uint64_t* coset_offset_mont);
+MZK_API int32_t mzk_ntt_batch(int32_t curve_id, uint32_t n_polys, uint64_t* const* data_mont, const uint64_t* in_lens,
+                      uint32_t log_n, int32_t inverse, const uint64_t* coset_offset_mont);
+/* Device-resident: `batch` polynomials of 2^log_n elements each, `batch_stride` elements apart
+ * (>= 2^log_n), transformed in place.  in_len applies to every polynomial.  coset_offset_mont is
+ * a HOST pointer.  Asynchronous on `stream`. */
+MZK_API int32_t mzk_ntt_dev(int32_t curve_id, void* d_data_mont, uint64_t in_len, uint32_t log_n, int32_t inverse,
+                    const uint64_t* coset_offset_mont, uint32_t batch, uint64_t batch_stride, void* stream);
+
+/* ---- device memory helpers for bindings without HIP of their own ---- */
+MZK_API int32_t mzk_dev_alloc(uint64_t bytes, void** out_dptr);
+MZK_API int32_t mzk_dev_free(void* dptr);
+MZK_API int32_t mzk_dev_upload(void* dptr, const void* host, uint64_t bytes);
+MZK_API int32_t mzk_dev_download(void* host, const void* dptr, uint64_t bytes);
+MZK_API int32_t mzk_dev_sync(void);
+
+/* ---- measurement hooks (bench.py): HIP-event timing of the library's own kernels ---- */
+/* on != 0: every subsequent call brackets its dominant kernels with hipEvents on the launch stream. */
+MZK_API int32_t mzk_profile_enable(int32_t on);
+/* name: "msm_accumulate", "msm_total", "ntt_pass", "ntt_total".  Returns accumulated device
+ * milliseconds and launch count since the last reset (synchronises the recorded events). */
+MZK_API int32_t mzk_profile_get(const char* name, double* out_ms, uint64_t* out_count);
+MZK_API int32_t mzk_profile_reset(void);
+/* Last MSM's shape: window bits, windows, buckets per window (for DESIGN.md's op counts). */
+MZK_API int32_t mzk_msm_last_shape(uint32_t* out_window_bits, uint32_t* out_windows, uint32_t* out_buckets);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MZK_H */

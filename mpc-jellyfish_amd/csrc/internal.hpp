@@ -1,0 +1,82 @@
+// internal.hpp -- state and helpers shared by the translation units of libmi355zk.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdint>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "../../include/mzk.h"
+
+namespace mzk {
+
+void set_error(const std::string& s);
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            ::mzk::set_error(std::string(#expr) + ": " + hipGetErrorString(_e));              \
+            return _e == hipErrorOutOfMemory ? MZK_ERR_OOM : MZK_ERR_HIP;                     \
+        }                                                                                     \
+    } while (0)
+
+#define MZK_TRY(expr)                \
+    do {                             \
+        int32_t _r = (expr);         \
+        if (_r != MZK_OK) return _r; \
+    } while (0)
+
+// grow-only device buffer
+struct DevBuf {
+    void* p = nullptr;
+    size_t cap = 0;
+    int32_t reserve(size_t bytes);
+    void release();
+    template <class T> T* as() { return reinterpret_cast<T*>(p); }
+};
+
+struct Workspace {
+    DevBuf ntt_scratch, scalars, hist, offs, cursor, sorted, buckets, collect, io, misc;
+    void* h_collect = nullptr;
+    size_t h_collect_cap = 0;
+    hipEvent_t last_use = nullptr;
+    void release();
+};
+extern Workspace g_ws;
+
+// a call on `st` must not start before the previous user of the shared workspace is done
+int32_t ws_acquire(hipStream_t st);
+int32_t ws_release(hipStream_t st);
+
+// HIP-event timing of named regions (mzk_profile_*)
+extern bool g_prof;
+struct ProfRec { std::string name; hipEvent_t a, b; };
+extern std::vector<ProfRec> g_prof_recs;
+struct ProfScope {
+    hipEvent_t a = nullptr, b = nullptr;
+    hipStream_t st;
+    const char* name;
+    ProfScope(const char* n, hipStream_t s);
+    ~ProfScope();
+};
+extern uint32_t g_last_c, g_last_w, g_last_m;
+
+struct Srs {
+    int curve;
+    uint64_t n;
+    uint32_t* d_xy;   // n * 2 * fq words
+};
+inline int fq_words(int curve) { return curve == MZK_CURVE_BLS12_381 ? 12 : 8; }
+
+// ntt.hip
+int32_t ntt_dispatch(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool inverse, const uint32_t* coset,
+                     uint32_t batch, uint64_t stride, hipStream_t st);
+void ntt_release_plans();
+// msm.hip
+int32_t msm_dispatch(const Srs& s, uint64_t base_offset, const uint32_t* d_scalars, uint64_t n, int is_mont, uint32_t* out, hipStream_t st);
+int32_t srs_generate_dispatch(int curve, const uint32_t* beta_canon, uint64_t n, uint32_t* d_out);
+void jac_to_affine_host_dispatch(int curve, const uint64_t* xyz, uint64_t* xy);
+
+}  // namespace mzk

@@ -1,0 +1,267 @@
+// msm.cuh -- Pippenger multi-scalar multiplication on G1 for gfx950.
+//
+// Replaces ark-ec's VariableBaseMSM::msm_bigint at the reference call sites
+//   primitives/src/pcs/univariate_kzg/mod.rs:109-111 (commit) and :151-155 (open).
+// Contract: result = sum_i k_i * P_i as a Jacobian point; only the group
+// element is pinned, not the algorithm.  Pipeline (all on one stream):
+//   1. msm_hist      signed base-2^c digits of every scalar, per-(window,bucket) histogram
+//   2. msm_scan      exclusive scan of each window's histogram -> bucket offsets
+//   3. msm_scatter   counting sort: point indices grouped by (window, bucket)
+//   4. msm_accumulate  one thread per (window,bucket): XYZZ += +-P (mixed add, all in VGPRs)
+//   5. msm_fold x log2(M)  in-place recursive halving: after level l the main array keeps
+//                    sum_i B_i folded to M/2^l entries and T_j (at offset M/2^j) the partial sums
+//                    of the buckets whose index bit (log2 M - j) is set, so that
+//                    S_w = X[0] + sum_j 2^(log2 M - j) X[M/2^j]     (weights i+1 for bucket i)
+//   6. msm_collect + host Horner over the (1 + log2 M) points per window (hostfp.hpp).
+// Algorithmic bytes: N * (2*|Fq| + 32) per MSM.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "ec.cuh"
+
+namespace mzk {
+
+constexpr int MSM_THREADS = 256;
+constexpr int MSM_ACC_THREADS = 128;
+
+// window size: ~log2(n) - 4, clamped; 16 divides 256 so the top signed digit always fits
+inline int msm_choose_window(unsigned long long n) {
+    int lg = 0;
+    while ((1ull << (lg + 1)) <= n) lg++;
+    int c = lg - 4;
+    if (c < 4) c = 4;
+    if (c > 16) c = 16;
+    return c;
+}
+inline int msm_num_windows(int scalar_bits, int c) { return (scalar_bits + 1 + c - 1) / c; }
+
+// Signed digit of window w: returns magnitude (0..2^(c-1)) and sign.  The recoding carries
+// upward, so digits are produced low to high by one thread per scalar.
+struct DigitIter {
+    uint32_t k[8];
+    uint32_t carry;
+    __device__ __forceinline__ void next(int w, int c, uint32_t& mag, uint32_t& negative) {
+        const int off = w * c, word = off >> 5, bit = off & 31;
+        uint32_t buf = 0;
+        if (word < 8) {
+            uint64_t two = k[word];
+            if (word + 1 < 8) two |= (uint64_t)k[word + 1] << 32;
+            buf = (uint32_t)(two >> bit);
+        }
+        uint32_t coef = (buf & ((1u << c) - 1)) + carry;
+        carry = coef > (1u << (c - 1)) ? 1u : 0u;          // digit in (-2^(c-1), 2^(c-1)]
+        negative = carry;
+        mag = carry ? (1u << c) - coef : coef;
+    }
+};
+
+template <class FR>
+__device__ __forceinline__ void load_scalar(DigitIter& it, const uint32_t* __restrict__ scalars, unsigned long long i, int is_mont) {
+    Fp<FR> s = load_fp<FR>(scalars + i * 8);
+    if (is_mont) s = from_mont(s);
+#pragma unroll
+    for (int q = 0; q < 8; q++) it.k[q] = s.l[q];
+    it.carry = 0;
+}
+
+// hist[w*M + b] += 1 for every non-zero digit
+template <class FR>
+__global__ __launch_bounds__(MSM_THREADS) void msm_hist_kernel(const uint32_t* __restrict__ scalars, unsigned long long n, int is_mont,
+                                                                int c, int n_win, uint32_t* __restrict__ hist) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * MSM_THREADS + threadIdx.x;
+    if (i >= n) return;
+    DigitIter it;
+    load_scalar<FR>(it, scalars, i, is_mont);
+    const uint32_t M = 1u << (c - 1);
+    for (int w = 0; w < n_win; w++) {
+        uint32_t mag, ng;
+        it.next(w, c, mag, ng);
+        if (mag) atomicAdd(&hist[(size_t)w * M + (mag - 1)], 1u);
+    }
+}
+
+// per-window exclusive scan; one 1024-thread workgroup per window
+__global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restrict__ hist, uint32_t* __restrict__ offs,
+                                                        uint32_t* __restrict__ cursor, uint32_t M) {
+    __shared__ uint32_t part[1024];
+    const int w = blockIdx.x, t = threadIdx.x;
+    const uint32_t per = (M + 1023) / 1024;
+    const uint32_t lo = t * per, hi = min(M, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t b = lo; b < hi; b++) sum += hist[(size_t)w * M + b];
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {            // Hillis-Steele inclusive scan of the partials
+        uint32_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t run = part[t] - sum;
+    for (uint32_t b = lo; b < hi; b++) {
+        offs[(size_t)w * M + b] = run;
+        cursor[(size_t)w * M + b] = run;
+        run += hist[(size_t)w * M + b];
+    }
+}
+
+// sorted[w*n + pos] = i | sign<<31, grouped by bucket
+template <class FR>
+__global__ __launch_bounds__(MSM_THREADS) void msm_scatter_kernel(const uint32_t* __restrict__ scalars, unsigned long long n, int is_mont,
+                                                                   int c, int n_win, uint32_t* __restrict__ cursor,
+                                                                   uint32_t* __restrict__ sorted) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * MSM_THREADS + threadIdx.x;
+    if (i >= n) return;
+    DigitIter it;
+    load_scalar<FR>(it, scalars, i, is_mont);
+    const uint32_t M = 1u << (c - 1);
+    for (int w = 0; w < n_win; w++) {
+        uint32_t mag, ng;
+        it.next(w, c, mag, ng);
+        if (mag) {
+            uint32_t pos = atomicAdd(&cursor[(size_t)w * M + (mag - 1)], 1u);
+            sorted[(size_t)w * n + pos] = (uint32_t)i | (ng << 31);
+        }
+    }
+}
+
+template <class FQ>
+__device__ __forceinline__ Affine<Fp<FQ>> load_affine(const uint32_t* __restrict__ bases, unsigned long long idx) {
+    Affine<Fp<FQ>> p;
+    const uint32_t* src = bases + idx * (2 * FQ::N);
+    p.x = load_fp<FQ>(src);
+    p.y = load_fp<FQ>(src + FQ::N);
+    return p;
+}
+template <class FQ>
+__device__ __forceinline__ XYZZ<Fp<FQ>> load_xyzz(const uint32_t* __restrict__ buf, unsigned long long idx) {
+    XYZZ<Fp<FQ>> p;
+    const uint32_t* src = buf + idx * (4 * FQ::N);
+    p.x = load_fp<FQ>(src);
+    p.y = load_fp<FQ>(src + FQ::N);
+    p.zz = load_fp<FQ>(src + 2 * FQ::N);
+    p.zzz = load_fp<FQ>(src + 3 * FQ::N);
+    return p;
+}
+template <class FQ>
+__device__ __forceinline__ void store_xyzz(uint32_t* __restrict__ buf, unsigned long long idx, const XYZZ<Fp<FQ>>& p) {
+    uint32_t* dst = buf + idx * (4 * FQ::N);
+    store_fp<FQ>(dst, p.x);
+    store_fp<FQ>(dst + FQ::N, p.y);
+    store_fp<FQ>(dst + 2 * FQ::N, p.zz);
+    store_fp<FQ>(dst + 3 * FQ::N, p.zzz);
+}
+
+// one thread per (window, bucket): sum of +-P over the bucket's sorted run
+template <class FQ>
+__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(const uint32_t* __restrict__ bases, unsigned long long n,
+                                                                          const uint32_t* __restrict__ offs, const uint32_t* __restrict__ hist,
+                                                                          const uint32_t* __restrict__ sorted, uint32_t M, int n_win,
+                                                                          uint32_t* __restrict__ buckets) {
+    const unsigned long long t = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
+    if (t >= (unsigned long long)n_win * M) return;
+    const unsigned long long w = t / M;
+    const uint32_t start = offs[t], cnt = hist[t];
+    const uint32_t* list = sorted + w * n + start;
+    XYZZ<Fp<FQ>> acc = XYZZ<Fp<FQ>>::inf();
+    for (uint32_t k = 0; k < cnt; k++) {
+        const uint32_t e = list[k];
+        Affine<Fp<FQ>> p = load_affine<FQ>(bases, e & 0x7fffffffu);
+        if (e >> 31) p.y = neg(p.y);
+        acc = xyzz_madd(acc, p);
+    }
+    store_xyzz<FQ>(buckets, t, acc);
+}
+
+// level with half-size h: segment 0 is the main array (base 0), segment j >= 1 is T_j (base M>>j);
+// X[base+i] += X[base+h+i].  grid covers n_win * nseg * h threads.
+template <class FQ>
+__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_fold_kernel(uint32_t* __restrict__ buckets, uint32_t M, uint32_t h, int nseg, int n_win) {
+    const unsigned long long t = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
+    const unsigned long long per_win = (unsigned long long)nseg * h;
+    if (t >= per_win * n_win) return;
+    const unsigned long long w = t / per_win, r = t % per_win;
+    const uint32_t seg = (uint32_t)(r / h), i = (uint32_t)(r % h);
+    const unsigned long long base = w * M + (seg ? (M >> seg) : 0u);
+    XYZZ<Fp<FQ>> a = load_xyzz<FQ>(buckets, base + i);
+    XYZZ<Fp<FQ>> b = load_xyzz<FQ>(buckets, base + h + i);
+    store_xyzz<FQ>(buckets, base + i, xyzz_add(a, b));
+}
+
+// out[w][0] = X[w*M], out[w][j] = X[w*M + (M>>j)], j = 1..log2 M
+template <class FQ>
+__global__ void msm_collect_kernel(const uint32_t* __restrict__ buckets, uint32_t M, int log_m, int n_win, uint32_t* __restrict__ out) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    const int per = log_m + 1;
+    if (t >= n_win * per) return;
+    const int w = t / per, j = t % per;
+    XYZZ<Fp<FQ>> p = load_xyzz<FQ>(buckets, (unsigned long long)w * M + (j ? (M >> j) : 0u));
+    store_xyzz<FQ>(out, t, p);
+}
+
+// ------------------------------------------------------------------------------------------------
+// fixed-base powers: out[i] = beta^i * G as affine points (testing SRS, srs.rs:118-153 with g = G)
+// ------------------------------------------------------------------------------------------------
+// table[k] = 2^k * G, k < 256: one thread walks the doublings (XYZZ), then 256 threads normalise
+template <class FQ>
+__global__ void g1_pow2_table_kernel(uint32_t* __restrict__ table_xyzz) {
+    if (threadIdx.x != 0 || blockIdx.x != 0) return;
+    using F = Fp<FQ>;
+    Affine<F> g;
+    g.x = F::from_const(FQ::GEN_X);
+    g.y = F::from_const(FQ::GEN_Y);
+    XYZZ<F> cur = XYZZ<F>::from_affine(g);
+    for (int k = 0; k < 256; k++) {
+        store_xyzz<FQ>(table_xyzz, k, cur);
+        cur = xyzz_dbl(cur);
+    }
+}
+template <class FQ>
+__global__ void g1_table_to_affine_kernel(const uint32_t* __restrict__ table_xyzz, uint32_t* __restrict__ table_xy, int n) {
+    const int k = blockIdx.x * blockDim.x + threadIdx.x;
+    if (k >= n) return;
+    Affine<Fp<FQ>> a = xyzz_to_affine(load_xyzz<FQ>(table_xyzz, k));
+    store_fp<FQ>(table_xy + (size_t)k * 2 * FQ::N, a.x);
+    store_fp<FQ>(table_xy + (size_t)k * 2 * FQ::N + FQ::N, a.y);
+}
+
+// scalars: canonical 8-word little-endian; out affine
+template <class FQ>
+__global__ __launch_bounds__(MSM_ACC_THREADS) void g1_fixed_base_kernel(const uint32_t* __restrict__ table, const uint32_t* __restrict__ scalars,
+                                                                         unsigned long long n, uint32_t* __restrict__ out_xy) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
+    if (i >= n) return;
+    using F = Fp<FQ>;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int wd = 0; wd < 8; wd++) {
+        uint32_t bits = scalars[i * 8 + wd];
+        for (int b = 0; b < 32; b++) {
+            if ((bits >> b) & 1) acc = xyzz_madd(acc, load_affine<FQ>(table, (unsigned long long)(wd * 32 + b)));
+        }
+    }
+    Affine<F> a = xyzz_to_affine(acc);
+    store_fp<FQ>(out_xy + i * 2 * FQ::N, a.x);
+    store_fp<FQ>(out_xy + i * 2 * FQ::N + FQ::N, a.y);
+}
+
+// out[i] = beta^i (canonical), i < n: chunked so threads are independent
+template <class FR>
+__global__ __launch_bounds__(MSM_THREADS) void fr_powers_kernel(const uint32_t* __restrict__ beta_canon, unsigned long long n, uint32_t* __restrict__ out_canon) {
+    const unsigned long long CH = 64;
+    const unsigned long long t = (unsigned long long)blockIdx.x * MSM_THREADS + threadIdx.x;
+    const unsigned long long start = t * CH;
+    if (start >= n) return;
+    using F = Fp<FR>;
+    F b;
+#pragma unroll
+    for (int q = 0; q < 8; q++) b.l[q] = beta_canon[q];
+    b = to_mont(b);
+    F p = pow_u64(b, start);
+    const unsigned long long end = start + CH < n ? start + CH : n;
+    for (unsigned long long i = start; i < end; i++) {
+        store_fp<FR>(out_canon + i * 8, from_mont(p));
+        p = p * b;
+    }
+}
+
+}  // namespace mzk

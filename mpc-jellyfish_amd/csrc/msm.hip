@@ -1,0 +1,176 @@
+// msm.hip -- host side of the MSM: pipeline launches, the host Horner tail, testing SRS.
+#include "internal.hpp"
+#include "hostfp.hpp"
+#include "msm.cuh"
+
+namespace mzk {
+namespace {
+
+// ---- MSM ------------------------------------------------------------------------------------------
+template <class FQ>
+void host_horner(const uint32_t* pts, int n_win, int c, uint32_t* out_xyz) {
+    using F = Fp64<FQ>;
+    const int log_m = c - 1, per = log_m + 1, W4 = 4 * FQ::N;
+    auto load = [&](int w, int j) {
+        XYZZ<F> p;
+        const uint32_t* s = pts + ((size_t)w * per + j) * W4;
+        p.x = F::from_words(s); p.y = F::from_words(s + FQ::N);
+        p.zz = F::from_words(s + 2 * FQ::N); p.zzz = F::from_words(s + 3 * FQ::N);
+        return p;
+    };
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (int w = n_win - 1; w >= 0; w--) {
+        for (int k = c - 1; k >= 0; k--) {
+            if (!acc.is_inf()) acc = xyzz_dbl(acc);
+            if (k <= c - 2) {
+                XYZZ<F> t = load(w, log_m - k);          // buckets whose index has bit k set
+                if (!t.is_inf()) acc = xyzz_add(acc, t);
+            }
+        }
+        XYZZ<F> t0 = load(w, 0);                          // sum of all buckets (weights are index+1)
+        if (!t0.is_inf()) acc = xyzz_add(acc, t0);
+    }
+    F X, Y, Z;
+    xyzz_to_jacobian(acc, X, Y, Z);
+    X.to_words(out_xyz); Y.to_words(out_xyz + FQ::N); Z.to_words(out_xyz + 2 * FQ::N);
+}
+
+template <class FR, class FQ>
+int32_t msm_dev(const uint32_t* d_bases, const uint32_t* d_scalars, uint64_t n, int is_mont, uint32_t* out_xyz, hipStream_t st) {
+    using F64 = Fp64<FQ>;
+    if (n == 0) {
+        F64 one = F64::one(), z = F64::zero();
+        one.to_words(out_xyz); one.to_words(out_xyz + FQ::N); z.to_words(out_xyz + 2 * FQ::N);
+        return MZK_OK;
+    }
+    if (n >= (1ull << 31)) { set_error("MSM size must be < 2^31"); return MZK_ERR_INVALID_ARG; }
+    const int c = msm_choose_window(n);
+    const uint32_t M = 1u << (c - 1);
+    const int log_m = c - 1;
+    const int n_win = msm_num_windows(is_mont ? FR::BITS : 256, c);
+    g_last_c = c; g_last_w = n_win; g_last_m = M;
+    const size_t wm = (size_t)n_win * M;
+    MZK_TRY(ws_acquire(st));
+    MZK_TRY(g_ws.hist.reserve(wm * 4));
+    MZK_TRY(g_ws.offs.reserve(wm * 4));
+    MZK_TRY(g_ws.cursor.reserve(wm * 4));
+    MZK_TRY(g_ws.sorted.reserve((size_t)n_win * n * 4));
+    MZK_TRY(g_ws.buckets.reserve(wm * 4 * FQ::N * 4));
+    const int n_out = n_win * (log_m + 1);
+    const size_t out_bytes = (size_t)n_out * 4 * FQ::N * 4;
+    MZK_TRY(g_ws.collect.reserve(out_bytes));
+    if (g_ws.h_collect_cap < out_bytes) {
+        if (g_ws.h_collect) HIP_TRY(hipHostFree(g_ws.h_collect));
+        g_ws.h_collect = nullptr;
+        HIP_TRY(hipHostMalloc(&g_ws.h_collect, out_bytes, hipHostMallocDefault));
+        g_ws.h_collect_cap = out_bytes;
+    }
+    uint32_t* hist = g_ws.hist.as<uint32_t>();
+    uint32_t* offs = g_ws.offs.as<uint32_t>();
+    uint32_t* cursor = g_ws.cursor.as<uint32_t>();
+    uint32_t* sorted = g_ws.sorted.as<uint32_t>();
+    uint32_t* buckets = g_ws.buckets.as<uint32_t>();
+    uint32_t* collect = g_ws.collect.as<uint32_t>();
+    {
+        ProfScope total("msm_total", st);
+        HIP_TRY(hipMemsetAsync(hist, 0, wm * 4, st));
+        const unsigned gs = (unsigned)((n + MSM_THREADS - 1) / MSM_THREADS);
+        {
+            ProfScope ps("msm_sort", st);
+            hipLaunchKernelGGL((msm_hist_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, st, d_scalars, n, is_mont, c, n_win, hist);
+            hipLaunchKernelGGL(msm_scan_kernel, dim3(n_win), dim3(1024), 0, st, hist, offs, cursor, M);
+            hipLaunchKernelGGL((msm_scatter_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, st, d_scalars, n, is_mont, c, n_win, cursor, sorted);
+        }
+        {
+            ProfScope ps("msm_accumulate", st);
+            hipLaunchKernelGGL((msm_accumulate_kernel<FQ>), dim3((unsigned)((wm + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
+                               d_bases, n, offs, hist, sorted, M, n_win, buckets);
+        }
+        {
+            ProfScope ps("msm_reduce", st);
+            for (int lvl = 1; lvl <= log_m; lvl++) {
+                const uint32_t h = M >> lvl;
+                const size_t threads = (size_t)n_win * lvl * h;
+                hipLaunchKernelGGL((msm_fold_kernel<FQ>), dim3((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
+                                   buckets, M, h, lvl, n_win);
+            }
+            hipLaunchKernelGGL((msm_collect_kernel<FQ>), dim3((n_out + 63) / 64), dim3(64), 0, st, buckets, M, log_m, n_win, collect);
+        }
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(g_ws.h_collect, collect, out_bytes, hipMemcpyDeviceToHost, st));
+    }
+    MZK_TRY(ws_release(st));
+    HIP_TRY(hipStreamSynchronize(st));
+    host_horner<FQ>(reinterpret_cast<const uint32_t*>(g_ws.h_collect), n_win, c, out_xyz);
+    return MZK_OK;
+}
+
+}  // namespace
+
+int32_t msm_dispatch(const Srs& s, uint64_t base_offset, const uint32_t* d_scalars, uint64_t n, int is_mont, uint32_t* out, hipStream_t st) {
+    if (base_offset > s.n || n > s.n - base_offset) {
+        set_error("MSM longer than the registered SRS (poly degree larger than allowed)");
+        return MZK_ERR_INVALID_ARG;
+    }
+    const uint32_t* bases = s.d_xy + base_offset * 2 * fq_words(s.curve);
+    if (s.curve == MZK_CURVE_BLS12_381) return msm_dev<BlsFr, BlsFq>(bases, d_scalars, n, is_mont, out, st);
+    return msm_dev<BnFr, BnFq>(bases, d_scalars, n, is_mont, out, st);
+}
+
+namespace {
+template <class FR, class FQ>
+int32_t srs_generate(const uint32_t* beta_canon, uint64_t n, uint32_t* d_out) {
+    hipStream_t st = nullptr;
+    MZK_TRY(ws_acquire(st));
+    MZK_TRY(g_ws.scalars.reserve((n ? n : 1) * 32));
+    MZK_TRY(g_ws.misc.reserve(32 + 256 * 4 * FQ::N * 4 + 256 * 2 * FQ::N * 4));
+    uint32_t* d_beta = g_ws.misc.as<uint32_t>();
+    uint32_t* d_tab_xyzz = d_beta + 8;
+    uint32_t* d_tab = d_tab_xyzz + 256 * 4 * FQ::N;
+    HIP_TRY(hipMemcpyAsync(d_beta, beta_canon, 32, hipMemcpyHostToDevice, st));
+    const unsigned long long chunks = (n + 63) / 64;
+    hipLaunchKernelGGL((fr_powers_kernel<FR>), dim3((unsigned)((chunks + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0, st,
+                       d_beta, n, g_ws.scalars.as<uint32_t>());
+    hipLaunchKernelGGL((g1_pow2_table_kernel<FQ>), dim3(1), dim3(64), 0, st, d_tab_xyzz);
+    hipLaunchKernelGGL((g1_table_to_affine_kernel<FQ>), dim3(4), dim3(64), 0, st, d_tab_xyzz, d_tab, 256);
+    hipLaunchKernelGGL((g1_fixed_base_kernel<FQ>), dim3((unsigned)((n + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
+                       d_tab, g_ws.scalars.as<uint32_t>(), n, d_out);
+    HIP_TRY(hipGetLastError());
+    MZK_TRY(ws_release(st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return MZK_OK;
+}
+
+template <class FQ>
+void jac_to_affine_host(const uint64_t* xyz, uint64_t* xy) {
+    using F = Fp64<FQ>;
+    constexpr int L = FQ::N / 2;
+    F X = F::from_words((const uint32_t*)xyz), Y = F::from_words((const uint32_t*)(xyz + L)), Z = F::from_words((const uint32_t*)(xyz + 2 * L));
+    if (Z.is_zero()) { std::memset(xy, 0, 2 * L * 8); return; }
+    // Z^-1 by Fermat on the host
+    F e = Z, acc = F::one();
+    uint64_t ex[L];
+    for (int i = 0; i < L; i++) ex[i] = F::mod(i);
+    ex[0] -= 2;                                   // p - 2 (p odd and > 2: no borrow)
+    for (int i = 0; i < L; i++)
+        for (int b = 0; b < 64; b++) {
+            if ((ex[i] >> b) & 1) acc = acc * e;
+            e = e * e;
+        }
+    F zi2 = acc * acc;
+    F x = X * zi2, y = Y * zi2 * acc;
+    x.to_words((uint32_t*)xy);
+    y.to_words((uint32_t*)(xy + L));
+}
+
+}  // namespace
+
+int32_t srs_generate_dispatch(int curve, const uint32_t* beta_canon, uint64_t n, uint32_t* d_out) {
+    return curve == 0 ? srs_generate<BlsFr, BlsFq>(beta_canon, n, d_out) : srs_generate<BnFr, BnFq>(beta_canon, n, d_out);
+}
+void jac_to_affine_host_dispatch(int curve, const uint64_t* xyz, uint64_t* xy) {
+    if (curve == 0) jac_to_affine_host<BlsFq>(xyz, xy);
+    else jac_to_affine_host<BnFq>(xyz, xy);
+}
+
+}  // namespace mzk

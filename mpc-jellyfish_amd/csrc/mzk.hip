@@ -1,0 +1,392 @@
+// mzk.hip -- libmi355zk: the C ABI (include/mzk.h) and the state shared by ntt.hip / msm.hip.
+// One process drives one GPU; entry points are serialised on a lock and enqueue on one stream.
+#include <map>
+#include <mutex>
+
+#include "internal.hpp"
+
+namespace mzk {
+
+thread_local std::string g_last_error;
+std::string g_last_error_global;
+void set_error(const std::string& s) {
+    g_last_error = s;
+    g_last_error_global = s;
+}
+
+int32_t DevBuf::reserve(size_t bytes) {
+    if (bytes <= cap) return MZK_OK;
+    if (p) HIP_TRY(hipFree(p));
+    p = nullptr;
+    cap = 0;
+    HIP_TRY(hipMalloc(&p, bytes));
+    cap = bytes;
+    return MZK_OK;
+}
+void DevBuf::release() {
+    if (p) (void)hipFree(p);
+    p = nullptr;
+    cap = 0;
+}
+void Workspace::release() {
+    for (DevBuf* b : {&ntt_scratch, &scalars, &hist, &offs, &cursor, &sorted, &buckets, &collect, &io, &misc}) b->release();
+    if (h_collect) (void)hipHostFree(h_collect);
+    h_collect = nullptr;
+    h_collect_cap = 0;
+    if (last_use) (void)hipEventDestroy(last_use);
+    last_use = nullptr;
+}
+Workspace g_ws;
+
+int32_t ws_acquire(hipStream_t st) {
+    if (!g_ws.last_use) HIP_TRY(hipEventCreateWithFlags(&g_ws.last_use, hipEventDisableTiming));
+    else HIP_TRY(hipStreamWaitEvent(st, g_ws.last_use, 0));
+    return MZK_OK;
+}
+int32_t ws_release(hipStream_t st) {
+    HIP_TRY(hipEventRecord(g_ws.last_use, st));
+    return MZK_OK;
+}
+
+bool g_prof = false;
+std::vector<ProfRec> g_prof_recs;
+ProfScope::ProfScope(const char* n, hipStream_t s) : st(s), name(n) {
+    if (!g_prof) return;
+    if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
+    (void)hipEventRecord(a, st);
+}
+ProfScope::~ProfScope() {
+    if (!a) return;
+    (void)hipEventRecord(b, st);
+    g_prof_recs.push_back({name, a, b});
+}
+uint32_t g_last_c = 0, g_last_w = 0, g_last_m = 0;
+
+}  // namespace mzk
+
+using namespace mzk;
+
+namespace {
+
+std::mutex g_lock;
+bool g_init = false;
+int g_device = -1;
+std::map<uint64_t, Srs> g_srs;
+uint64_t g_next_handle = 1;
+
+int32_t msm_host_locked(const Srs& s, uint64_t base_offset, const uint64_t* scalars, uint64_t n, int32_t is_mont, uint64_t* out) {
+    if (!out || (!scalars && n)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    if (base_offset > s.n || n > s.n - base_offset) {
+        set_error("MSM longer than the registered SRS (poly degree larger than allowed)");
+        return MZK_ERR_INVALID_ARG;
+    }
+    hipStream_t st = nullptr;
+    if (n) {
+        // the upload buffer is private to host-pointer calls; it is consumed before ws_release
+        MZK_TRY(ws_acquire(st));
+        MZK_TRY(g_ws.scalars.reserve(n * 32));
+        HIP_TRY(hipMemcpyAsync(g_ws.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, st));
+        MZK_TRY(ws_release(st));
+    }
+    return msm_dispatch(s, base_offset, g_ws.scalars.as<uint32_t>(), n, is_mont != 0, reinterpret_cast<uint32_t*>(out), st);
+}
+
+int32_t require_init() {
+    if (!g_init) { set_error("mzk_init has not been called"); return MZK_ERR_NOT_INIT; }
+    HIP_TRY(hipSetDevice(g_device));
+    return MZK_OK;
+}
+
+}  // namespace
+
+// =================================================================================================
+extern "C" {
+
+int32_t mzk_init(int32_t device) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        set_error("no HIP device visible (libmi355zk has no CPU fallback)");
+        return MZK_ERR_NO_DEVICE;
+    }
+    if (device < 0) {
+        if (g_init) return MZK_OK;
+        int cur = 0;
+        HIP_TRY(hipGetDevice(&cur));
+        device = cur;
+    }
+    if (device >= count) { set_error("device index out of range"); return MZK_ERR_INVALID_ARG; }
+    if (g_init && device != g_device) { set_error("already bound to another device (one process per GPU)"); return MZK_ERR_INVALID_ARG; }
+    HIP_TRY(hipSetDevice(device));
+    g_device = device;
+    g_init = true;
+    return MZK_OK;
+}
+
+int32_t mzk_shutdown(void) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    if (!g_init) return MZK_OK;
+    (void)hipSetDevice(g_device);
+    (void)hipDeviceSynchronize();
+    for (auto& kv : g_srs) (void)hipFree(kv.second.d_xy);
+    g_srs.clear();
+    ntt_release_plans();
+    for (auto& r : g_prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof_recs.clear();
+    g_ws.release();
+    g_init = false;
+    return MZK_OK;
+}
+
+const char* mzk_strerror(int32_t code) {
+    switch (code) {
+        case MZK_OK: return "ok";
+        case MZK_ERR_INVALID_ARG: return "invalid argument";
+        case MZK_ERR_HIP: return "HIP runtime error";
+        case MZK_ERR_NO_DEVICE: return "no HIP device";
+        case MZK_ERR_BAD_HANDLE: return "unknown handle";
+        case MZK_ERR_UNSUPPORTED: return "unsupported";
+        case MZK_ERR_OOM: return "out of device memory";
+        case MZK_ERR_NOT_INIT: return "mzk_init not called";
+        default: return "unknown error";
+    }
+}
+const char* mzk_last_error(void) { return mzk::g_last_error.empty() ? mzk::g_last_error_global.c_str() : mzk::g_last_error.c_str(); }
+const char* mzk_version(void) { return "libmi355zk 0.1 (gfx950)"; }
+
+// ---- SRS -----------------------------------------------------------------------------------------
+int32_t mzk_srs_register(int32_t curve_id, const uint64_t* xy_mont, uint64_t n_points, uint64_t* out_handle) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    if ((curve_id != 0 && curve_id != 1) || !out_handle || (!xy_mont && n_points)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
+    Srs s{curve_id, n_points, nullptr};
+    const size_t bytes = (size_t)n_points * 2 * fq_words(curve_id) * 4;
+    HIP_TRY(hipMalloc((void**)&s.d_xy, bytes ? bytes : 4));
+    if (bytes) HIP_TRY(hipMemcpy(s.d_xy, xy_mont, bytes, hipMemcpyHostToDevice));
+    *out_handle = g_next_handle++;
+    g_srs[*out_handle] = s;
+    return MZK_OK;
+}
+int32_t mzk_srs_register_dev(int32_t curve_id, const void* d_xy_mont, uint64_t n_points, uint64_t* out_handle, void* stream) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    if ((curve_id != 0 && curve_id != 1) || !out_handle || (!d_xy_mont && n_points)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
+    Srs s{curve_id, n_points, nullptr};
+    const size_t bytes = (size_t)n_points * 2 * fq_words(curve_id) * 4;
+    HIP_TRY(hipMalloc((void**)&s.d_xy, bytes ? bytes : 4));
+    if (bytes) {
+        HIP_TRY(hipMemcpyAsync(s.d_xy, d_xy_mont, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+        HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    }
+    *out_handle = g_next_handle++;
+    g_srs[*out_handle] = s;
+    return MZK_OK;
+}
+int32_t mzk_srs_release(uint64_t handle) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    auto it = g_srs.find(handle);
+    if (it == g_srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipFree(it->second.d_xy));
+    g_srs.erase(it);
+    return MZK_OK;
+}
+int32_t mzk_srs_generate_for_testing(int32_t curve_id, const uint64_t* beta_canonical, uint64_t n_points, uint64_t* out_handle) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    if ((curve_id != 0 && curve_id != 1) || !out_handle || !beta_canonical) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
+    Srs s{curve_id, n_points, nullptr};
+    const size_t bytes = (size_t)n_points * 2 * fq_words(curve_id) * 4;
+    HIP_TRY(hipMalloc((void**)&s.d_xy, bytes ? bytes : 4));
+    int32_t rc = MZK_OK;
+    if (n_points) {
+        const uint32_t* beta = reinterpret_cast<const uint32_t*>(beta_canonical);
+        rc = srs_generate_dispatch(curve_id, beta, n_points, s.d_xy);
+    }
+    if (rc != MZK_OK) { (void)hipFree(s.d_xy); return rc; }
+    *out_handle = g_next_handle++;
+    g_srs[*out_handle] = s;
+    return MZK_OK;
+}
+int32_t mzk_srs_download(uint64_t handle, uint64_t first, uint64_t n_points, uint64_t* out_xy_mont) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    auto it = g_srs.find(handle);
+    if (it == g_srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+    const Srs& s = it->second;
+    if (first > s.n || n_points > s.n - first) { set_error("range outside the SRS"); return MZK_ERR_INVALID_ARG; }
+    const size_t pw = (size_t)2 * fq_words(s.curve);
+    HIP_TRY(hipDeviceSynchronize());
+    if (n_points) HIP_TRY(hipMemcpy(out_xy_mont, s.d_xy + first * pw, n_points * pw * 4, hipMemcpyDeviceToHost));
+    return MZK_OK;
+}
+int32_t mzk_srs_len(uint64_t handle, uint64_t* out_n_points) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    auto it = g_srs.find(handle);
+    if (it == g_srs.end() || !out_n_points) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+    *out_n_points = it->second.n;
+    return MZK_OK;
+}
+
+// ---- MSM -----------------------------------------------------------------------------------------
+int32_t mzk_msm_dev(uint64_t srs_handle, uint64_t base_offset, const void* d_scalars, uint64_t n, int32_t scalars_are_mont,
+                    uint64_t* out_xyz_mont, void* stream) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    auto it = g_srs.find(srs_handle);
+    if (it == g_srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+    if (!out_xyz_mont || (!d_scalars && n)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    return msm_dispatch(it->second, base_offset, reinterpret_cast<const uint32_t*>(d_scalars), n, scalars_are_mont != 0,
+                        reinterpret_cast<uint32_t*>(out_xyz_mont), (hipStream_t)stream);
+}
+
+int32_t mzk_msm(uint64_t srs_handle, uint64_t base_offset, const uint64_t* scalars, uint64_t n, int32_t scalars_are_mont, uint64_t* out_xyz_mont) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    auto it = g_srs.find(srs_handle);
+    if (it == g_srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+    return msm_host_locked(it->second, base_offset, scalars, n, scalars_are_mont, out_xyz_mont);
+}
+
+int32_t mzk_msm_batch(uint64_t srs_handle, uint32_t n_polys, const uint64_t* const* scalars, const uint64_t* lens, const uint64_t* base_offsets,
+                      int32_t scalars_are_mont, uint64_t* out_xyz_mont) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    auto it = g_srs.find(srs_handle);
+    if (it == g_srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+    if (n_polys && (!scalars || !lens || !out_xyz_mont)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    const int pw = 3 * fq_words(it->second.curve) / 2;   // u64 words per Jacobian point
+    for (uint32_t i = 0; i < n_polys; i++)
+        MZK_TRY(msm_host_locked(it->second, base_offsets ? base_offsets[i] : 0, scalars[i], lens[i], scalars_are_mont, out_xyz_mont + (size_t)i * pw));
+    return MZK_OK;
+}
+
+int32_t mzk_msm_affine(uint64_t srs_handle, uint64_t base_offset, const uint64_t* scalars, uint64_t n, int32_t scalars_are_mont, uint64_t* out_xy_mont) {
+    uint64_t xyz[18];
+    int curve;
+    {
+        std::lock_guard<std::mutex> lk(g_lock);
+        MZK_TRY(require_init());
+        auto it = g_srs.find(srs_handle);
+        if (it == g_srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+        if (!out_xy_mont) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+        curve = it->second.curve;
+        MZK_TRY(msm_host_locked(it->second, base_offset, scalars, n, scalars_are_mont, xyz));
+    }
+    jac_to_affine_host_dispatch(curve, xyz, out_xy_mont);
+    return MZK_OK;
+}
+
+// ---- NTT -----------------------------------------------------------------------------------------
+int32_t mzk_ntt_dev(int32_t curve_id, void* d_data_mont, uint64_t in_len, uint32_t log_n, int32_t inverse, const uint64_t* coset_offset_mont,
+                    uint32_t batch, uint64_t batch_stride, void* stream) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    if (!d_data_mont) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    return ntt_dispatch(curve_id, reinterpret_cast<uint32_t*>(d_data_mont), in_len, (int)log_n, inverse != 0,
+                        reinterpret_cast<const uint32_t*>(coset_offset_mont), batch, batch_stride, (hipStream_t)stream);
+}
+
+int32_t mzk_ntt_batch(int32_t curve_id, uint32_t n_polys, uint64_t* const* data_mont, const uint64_t* in_lens, uint32_t log_n, int32_t inverse,
+                      const uint64_t* coset_offset_mont) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    if (log_n > 30) { set_error("log_n out of range"); return MZK_ERR_INVALID_ARG; }
+    if (n_polys && (!data_mont || !in_lens)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    const uint64_t N = 1ull << log_n;
+    hipStream_t st = nullptr;
+    for (uint32_t i = 0; i < n_polys; i++) {
+        const uint64_t len = in_lens[i] < N ? in_lens[i] : N;
+        MZK_TRY(ws_acquire(st));
+        MZK_TRY(g_ws.io.reserve(N * 32));
+        if (len) HIP_TRY(hipMemcpyAsync(g_ws.io.p, data_mont[i], len * 32, hipMemcpyHostToDevice, st));
+        MZK_TRY(ws_release(st));
+        MZK_TRY(ntt_dispatch(curve_id, g_ws.io.as<uint32_t>(), len, (int)log_n, inverse != 0,
+                             reinterpret_cast<const uint32_t*>(coset_offset_mont), 1, N, st));
+        HIP_TRY(hipMemcpyAsync(data_mont[i], g_ws.io.p, N * 32, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return MZK_OK;
+}
+
+int32_t mzk_ntt(int32_t curve_id, uint64_t* data_mont, uint64_t in_len, uint32_t log_n, int32_t inverse, const uint64_t* coset_offset_mont) {
+    uint64_t* ptrs[1] = {data_mont};
+    uint64_t lens[1] = {in_len};
+    if (!data_mont) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    return mzk_ntt_batch(curve_id, 1, ptrs, lens, log_n, inverse, coset_offset_mont);
+}
+
+// ---- device memory helpers --------------------------------------------------------------------------
+int32_t mzk_dev_alloc(uint64_t bytes, void** out_dptr) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    if (!out_dptr) return MZK_ERR_INVALID_ARG;
+    HIP_TRY(hipMalloc(out_dptr, bytes ? bytes : 4));
+    return MZK_OK;
+}
+int32_t mzk_dev_free(void* dptr) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    HIP_TRY(hipFree(dptr));
+    return MZK_OK;
+}
+int32_t mzk_dev_upload(void* dptr, const void* host, uint64_t bytes) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    HIP_TRY(hipMemcpy(dptr, host, bytes, hipMemcpyHostToDevice));
+    return MZK_OK;
+}
+int32_t mzk_dev_download(void* host, const void* dptr, uint64_t bytes) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    HIP_TRY(hipMemcpy(host, dptr, bytes, hipMemcpyDeviceToHost));
+    return MZK_OK;
+}
+int32_t mzk_dev_sync(void) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    HIP_TRY(hipDeviceSynchronize());
+    return MZK_OK;
+}
+
+// ---- profiling ---------------------------------------------------------------------------------------
+int32_t mzk_profile_enable(int32_t on) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    g_prof = on != 0;
+    return MZK_OK;
+}
+int32_t mzk_profile_get(const char* name, double* out_ms, uint64_t* out_count) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    if (!name || !out_ms || !out_count) return MZK_ERR_INVALID_ARG;
+    double ms = 0;
+    uint64_t cnt = 0;
+    for (auto& r : g_prof_recs) {
+        if (r.name != name) continue;
+        HIP_TRY(hipEventSynchronize(r.b));
+        float t = 0;
+        HIP_TRY(hipEventElapsedTime(&t, r.a, r.b));
+        ms += t;
+        cnt++;
+    }
+    *out_ms = ms;
+    *out_count = cnt;
+    return MZK_OK;
+}
+int32_t mzk_profile_reset(void) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    for (auto& r : g_prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+    g_prof_recs.clear();
+    return MZK_OK;
+}
+int32_t mzk_msm_last_shape(uint32_t* out_window_bits, uint32_t* out_windows, uint32_t* out_buckets) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    if (out_window_bits) *out_window_bits = g_last_c;
+    if (out_windows) *out_windows = g_last_w;
+    if (out_buckets) *out_buckets = g_last_m;
+    return MZK_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,145 @@
+"""UnivariateKzgPCS -- mirror of primitives/src/pcs/univariate_kzg/{mod,srs}.rs for the commit path:
+
+    UnivariateProverParam{powers_of_g}      srs.rs:36-40   -> an SRS resident in HBM (handle)
+    gen_srs_for_testing                     srs.rs:118-153 -> UnivariateProverParam.gen_srs_for_testing
+    trim                                    srs.rs:77-93   -> UnivariateProverParam.trim
+    commit / batch_commit                   mod.rs:90-131  -> UnivariateKzgPCS.commit / batch_commit
+    <G1 as VariableBaseMSM>::msm_bigint     mod.rs:109-111 -> msm_bigint
+
+Polynomials are (len,4) uint64 Montgomery coefficient arrays, low order first (DensePolynomial);
+commitments are affine points x||y (Montgomery limbs), (0,0) = infinity.  Error behaviour follows
+the reference: commit raises PCSError (InvalidParameters) when the degree exceeds the key.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+from .params import CurveParams, curve as _curve, int_to_limbs
+
+
+class PCSError(Exception):
+    """primitives/src/pcs/errors.rs:16-33 (InvalidParameters is the only variant raised here)."""
+
+
+class Commitment:
+    """pcs/structs.rs:16-19: a G1 affine point; .xy is (2, fq_limbs) uint64 Montgomery."""
+
+    def __init__(self, curve: CurveParams, xy: np.ndarray):
+        self.curve = curve
+        self.xy = np.ascontiguousarray(xy, dtype=np.uint64).reshape(2, curve.fq_limbs)
+
+    def is_infinity(self) -> bool:
+        return not self.xy.any()
+
+    def __eq__(self, other):
+        return isinstance(other, Commitment) and self.curve is other.curve and np.array_equal(self.xy, other.xy)
+
+    def __repr__(self):
+        return f"Commitment({self.curve.name}, x[0]=0x{int(self.xy[0, 0]):016x})"
+
+
+class UnivariateProverParam:
+    """powers_of_g held on the GPU.  `offset`/`length` give a trimmed view of one registration."""
+
+    def __init__(self, curve: CurveParams, handle: int, length: int, offset: int = 0, owner: bool = True):
+        self.curve, self.handle, self.length, self.offset, self._owner = curve, handle, length, offset, owner
+
+    @classmethod
+    def from_affine(cls, curve, powers_of_g: np.ndarray) -> "UnivariateProverParam":
+        c = _curve(curve)
+        a = np.ascontiguousarray(powers_of_g, dtype=np.uint64).reshape(-1, 2, c.fq_limbs)
+        L = _lib.ensure_init()
+        h = C.c_uint64()
+        _lib.check(L.mzk_srs_register(c.curve_id, a.ctypes.data_as(C.c_void_p), a.shape[0], C.byref(h)), "mzk_srs_register")
+        return cls(c, h.value, a.shape[0])
+
+    @classmethod
+    def gen_srs_for_testing(cls, curve, beta: int, max_degree: int) -> "UnivariateProverParam":
+        """powers_of_g = [beta^i * G] for i <= max_degree (srs.rs:118-153), built on the GPU."""
+        c = _curve(curve)
+        L = _lib.ensure_init()
+        h = C.c_uint64()
+        b = int_to_limbs(beta % c.r, 4)
+        _lib.check(L.mzk_srs_generate_for_testing(c.curve_id, b.ctypes.data_as(C.c_void_p), max_degree + 1, C.byref(h)),
+                   "mzk_srs_generate_for_testing")
+        return cls(c, h.value, max_degree + 1)
+
+    def trim(self, supported_degree: int) -> "UnivariateProverParam":
+        """srs.rs:77-93: keep powers_of_g[..=supported_degree]."""
+        if supported_degree + 1 > self.length:
+            raise PCSError("InvalidParameters: supported degree larger than the SRS")
+        return UnivariateProverParam(self.curve, self.handle, supported_degree + 1, self.offset, owner=False)
+
+    def powers_of_g(self, first: int = 0, count: int | None = None) -> np.ndarray:
+        count = self.length - first if count is None else count
+        out = np.empty((count, 2, self.curve.fq_limbs), dtype=np.uint64)
+        _lib.check(_lib.ensure_init().mzk_srs_download(self.handle, self.offset + first, count, out.ctypes.data_as(C.c_void_p)),
+                   "mzk_srs_download")
+        return out
+
+    def release(self):
+        if self._owner and self.handle:
+            _lib.check(_lib.load().mzk_srs_release(self.handle), "mzk_srs_release")
+            self.handle = 0
+
+
+def _is_torch(x) -> bool:
+    return type(x).__module__.startswith("torch")
+
+
+def _degree_and_leading_zeros(coeffs: np.ndarray):
+    """(degree, num_leading_zeros) of a coefficient array; degree of the zero polynomial is 0."""
+    nz = np.flatnonzero(coeffs.any(axis=1))
+    if nz.size == 0:
+        return 0, coeffs.shape[0]
+    return int(nz[-1]), int(nz[0])
+
+
+def msm_bigint(pp: UnivariateProverParam, bigints, base_offset: int = 0, scalars_are_mont: bool = False) -> np.ndarray:
+    """sum_i bigints[i] * powers_of_g[base_offset + i] as a Jacobian point (3, fq_limbs), Montgomery.
+    Uses min(len) of the two sides like ark-ec.  bigints: (n,4) uint64 host array or int64 CUDA tensor."""
+    L = _lib.ensure_init()
+    out = np.empty((3, pp.curve.fq_limbs), dtype=np.uint64)
+    avail = max(0, pp.length - base_offset)
+    if _is_torch(bigints):
+        import torch
+        if bigints.dtype != torch.int64 or not bigints.is_cuda or not bigints.is_contiguous() or bigints.shape[-1] != 4:
+            raise ValueError("expected a contiguous int64 CUDA tensor of shape (n, 4)")
+        n = min(bigints.shape[0], avail)
+        st = torch.cuda.current_stream(bigints.device).cuda_stream
+        _lib.check(L.mzk_msm_dev(pp.handle, pp.offset + base_offset, bigints.data_ptr(), n, int(scalars_are_mont),
+                                 out.ctypes.data_as(C.c_void_p), st), "mzk_msm_dev")
+        return out
+    s = np.ascontiguousarray(bigints, dtype=np.uint64).reshape(-1, 4)
+    n = min(s.shape[0], avail)
+    _lib.check(L.mzk_msm(pp.handle, pp.offset + base_offset, s.ctypes.data_as(C.c_void_p), n, int(scalars_are_mont),
+                         out.ctypes.data_as(C.c_void_p)), "mzk_msm")
+    return out
+
+
+class UnivariateKzgPCS:
+    @staticmethod
+    def commit(prover_param: UnivariateProverParam, poly: np.ndarray) -> Commitment:
+        """mod.rs:90-116: degree guard, skip low-order zero coefficients, MSM, into_affine."""
+        pp = prover_param
+        coeffs = np.ascontiguousarray(poly, dtype=np.uint64).reshape(-1, 4)
+        degree, lead = _degree_and_leading_zeros(coeffs)
+        if degree > pp.length:                                             # mod.rs:98
+            raise PCSError(f"InvalidParameters: poly degree {degree} is larger than allowed {pp.length}")
+        body = coeffs[lead:degree + 1] if lead <= degree else coeffs[:0]
+        if lead + body.shape[0] > pp.length:
+            # degree == powers_of_g.len(): passes the reference's guard, then ark-ec truncates to min(len)
+            body = body[:pp.length - lead]
+        L = _lib.ensure_init()
+        out = np.empty((2, pp.curve.fq_limbs), dtype=np.uint64)
+        _lib.check(L.mzk_msm_affine(pp.handle, pp.offset + lead, body.ctypes.data_as(C.c_void_p) if body.size else None,
+                                    body.shape[0], 1, out.ctypes.data_as(C.c_void_p)), "mzk_msm_affine")
+        return Commitment(pp.curve, out)
+
+    @staticmethod
+    def batch_commit(prover_param: UnivariateProverParam, polys) -> list[Commitment]:
+        """mod.rs:119-131."""
+        return [UnivariateKzgPCS.commit(prover_param, p) for p in polys]

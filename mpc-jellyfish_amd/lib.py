@@ -1,0 +1,105 @@
+"""ctypes binding of libmi355zk.so (C ABI: include/mzk.h).  There is no CPU fallback: if the HIP
+library is missing or no GPU is visible the calls raise."""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+class MzkError(RuntimeError):
+    def __init__(self, code: int, where: str, detail: str):
+        super().__init__(f"{where}: {detail} (code {code})")
+        self.code = code
+
+
+def lib_path() -> str:
+    return os.path.join(_HERE, "libmi355zk.so")
+
+
+_SIGS = {
+    "mzk_init": [C.c_int32],
+    "mzk_shutdown": [],
+    "mzk_srs_register": [C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)],
+    "mzk_srs_register_dev": [C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p],
+    "mzk_srs_release": [C.c_uint64],
+    "mzk_srs_generate_for_testing": [C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)],
+    "mzk_srs_download": [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p],
+    "mzk_srs_len": [C.c_uint64, C.POINTER(C.c_uint64)],
+    "mzk_msm": [C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p],
+    "mzk_msm_dev": [C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p],
+    "mzk_msm_batch": [C.c_uint64, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32, C.c_void_p],
+    "mzk_msm_affine": [C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p],
+    "mzk_ntt": [C.c_int32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_void_p],
+    "mzk_ntt_batch": [C.c_int32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_uint32, C.c_int32, C.c_void_p],
+    "mzk_ntt_dev": [C.c_int32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p],
+    "mzk_dev_alloc": [C.c_uint64, C.POINTER(C.c_void_p)],
+    "mzk_dev_free": [C.c_void_p],
+    "mzk_dev_upload": [C.c_void_p, C.c_void_p, C.c_uint64],
+    "mzk_dev_download": [C.c_void_p, C.c_void_p, C.c_uint64],
+    "mzk_dev_sync": [],
+    "mzk_profile_enable": [C.c_int32],
+    "mzk_profile_get": [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
+    "mzk_profile_reset": [],
+    "mzk_msm_last_shape": [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
+}
+_STR_FUNCS = ("mzk_strerror", "mzk_last_error", "mzk_version")
+EXPORTS = tuple(_SIGS) + _STR_FUNCS
+
+
+def load():
+    """dlopen the library (does not touch the GPU).  Raises FileNotFoundError if it was not built."""
+    global _LIB
+    if _LIB is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                                    "(hipcc, gfx950). There is no CPU fallback.")
+        L = C.CDLL(path)
+        for name, args in _SIGS.items():
+            f = getattr(L, name)
+            f.argtypes = args
+            f.restype = C.c_int32
+        L.mzk_strerror.argtypes = [C.c_int32]
+        for name in _STR_FUNCS:
+            getattr(L, name).restype = C.c_char_p
+        _LIB = L
+    return _LIB
+
+
+def check(rc: int, where: str):
+    if rc != 0:
+        L = load()
+        raise MzkError(rc, where, f"{L.mzk_strerror(rc).decode()}: {L.mzk_last_error().decode()}")
+
+
+_INIT_DEV = None
+
+
+def init(device: int = -1):
+    """mzk_init: bind this process to one GPU (idempotent)."""
+    global _INIT_DEV
+    L = load()
+    check(L.mzk_init(device), "mzk_init")
+    _INIT_DEV = device
+    return L
+
+
+def ensure_init():
+    return load() if _INIT_DEV is not None else init(-1)
+
+
+def profile_get(name: str):
+    L = ensure_init()
+    ms, cnt = C.c_double(), C.c_uint64()
+    check(L.mzk_profile_get(name.encode(), C.byref(ms), C.byref(cnt)), "mzk_profile_get")
+    return ms.value, cnt.value
+
+
+def msm_last_shape():
+    L = load()
+    a, b, c = C.c_uint32(), C.c_uint32(), C.c_uint32()
+    L.mzk_msm_last_shape(C.byref(a), C.byref(b), C.byref(c))
+    return a.value, b.value, c.value

@@ -1,0 +1,142 @@
+"""GPU parity: the HIP Pippenger MSM / KZG commit (through the C ABI) against the committed
+vectors, the C oracle on seeded inputs, and the trapdoor identity at the benchmark size."""
+import numpy as np
+import pytest
+
+from conftest import (affine_from_limbs, affine_limbs, fr_mont_limbs, golden_pt, jacobian_to_affine_ints, load_golden)
+
+pytestmark = pytest.mark.gpu
+
+
+def _bigints(scalars):
+    return np.array([[(s >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)] for s in scalars], dtype=np.uint64).reshape(-1, 4)
+
+
+def test_msm_matches_golden_vectors(gpu, mj, pyref):
+    for case in load_golden("msm_vectors"):
+        c = pyref.CURVES[case["curve"]]
+        pp = mj.UnivariateProverParam.from_affine(c.curve_id, affine_limbs(c, [golden_pt(p) for p in case["bases"]]))
+        scalars = [int(s, 16) for s in case["scalars"]]
+        jac = mj.msm_bigint(pp, _bigints(scalars))
+        assert jacobian_to_affine_ints(c, jac) == golden_pt(case["result"]), (c.name, len(scalars))
+        if max(scalars) < c.r:
+            jac = mj.msm_bigint(pp, fr_mont_limbs(c, scalars), scalars_are_mont=True)
+            assert jacobian_to_affine_ints(c, jac) == golden_pt(case["result"]), (c.name, len(scalars), "mont")
+        pp.release()
+
+
+def test_commit_matches_golden_trapdoor_vectors(gpu, mj, pyref):
+    for case in load_golden("kzg_vectors"):
+        c = pyref.CURVES[case["curve"]]
+        pp = mj.UnivariateProverParam.gen_srs_for_testing(c.curve_id, int(case["beta"], 16), len(case["srs"]) - 1)
+        srs = pp.powers_of_g()
+        for i, p in enumerate(case["srs"]):
+            assert affine_from_limbs(c, srs[i]) == golden_pt(p), ("srs", c.name, i)
+        com = mj.UnivariateKzgPCS.commit(pp, fr_mont_limbs(c, [int(v, 16) for v in case["coeffs"]]))
+        assert affine_from_limbs(c, com.xy) == golden_pt(case["commitment"]), (c.name, len(case["coeffs"]))
+        pp.release()
+
+
+@pytest.mark.parametrize("curve_id", [0, 1])
+@pytest.mark.parametrize("n", [1, 2, 3, 31, 32, 33, 1000, 1 << 12, (1 << 14) + 3, 1 << 16])
+def test_msm_matches_c_oracle(gpu, mj, cref, curve_id, n):
+    c = mj.params.CURVES[curve_id]
+    bases = cref.g1_arith_bases(curve_id, 0xabcdef12345 + n, 0x777, n)
+    scalars = mj.params.random_fr_mont(c, n, seed=n)
+    edge = [0, 1, 2, c.r - 1, (1 << 15) - 1, 1 << 15, (1 << 16) - 1, 1 << 16, (1 << 16) + 1, (1 << 240) - 1, c.r >> 1]
+    for i, e in enumerate(edge):
+        if i * 2 < n:
+            scalars[i * 2] = _bigints([e])[0]
+    if n >= 8:
+        bases[7] = bases[6]                       # equal points with different scalars
+    if n >= 40:
+        bases[33] = 0                             # infinity in the base table
+        scalars[35] = scalars[34]
+        bases[35, 0] = bases[34, 0]               # P and -P under the same scalar
+        neg = cref.g1_mul(curve_id, bases[34], c.r - 1)
+        bases[35] = neg
+    pp = mj.UnivariateProverParam.from_affine(curve_id, bases)
+    want = cref.jac_to_affine(curve_id, cref.msm(curve_id, bases, scalars, threads=8))[0]
+    got = cref.jac_to_affine(curve_id, mj.msm_bigint(pp, scalars))[0]
+    assert np.array_equal(got, want)
+    # Montgomery-form scalars (what a DensePolynomial holds) give the same point
+    got = cref.jac_to_affine(curve_id, mj.msm_bigint(pp, cref.fr_convert(curve_id, scalars, True), scalars_are_mont=True))[0]
+    assert np.array_equal(got, want)
+    # base_offset = num_leading_zeros: a suffix of the SRS
+    if n > 5:
+        want = cref.jac_to_affine(curve_id, cref.msm(curve_id, bases[5:], scalars[5:], threads=8))[0]
+        got = cref.jac_to_affine(curve_id, mj.msm_bigint(pp, scalars[5:], base_offset=5))[0]
+        assert np.array_equal(got, want)
+    pp.release()
+
+
+def test_msm_skewed_and_degenerate_scalars(gpu, mj, cref):
+    """All points in one bucket per window; all-zero scalars; a single non-zero scalar."""
+    curve_id, n = 0, 5000
+    c = mj.params.CURVES[curve_id]
+    bases = cref.g1_arith_bases(curve_id, 99, 3, n)
+    pp = mj.UnivariateProverParam.from_affine(curve_id, bases)
+    same = np.repeat(_bigints([0x1234567890abcdef1234567890abcdef1234567890abcdef]), n, axis=0)
+    want = cref.jac_to_affine(curve_id, cref.msm(curve_id, bases, same, threads=8))[0]
+    assert np.array_equal(cref.jac_to_affine(curve_id, mj.msm_bigint(pp, same))[0], want)
+    zeros = np.zeros((n, 4), dtype=np.uint64)
+    assert not cref.jac_to_affine(curve_id, mj.msm_bigint(pp, zeros))[0].any()
+    assert not mj.msm_bigint(pp, zeros[:0])[2].any()                     # n = 0 -> Z = 0
+    one = zeros.copy()
+    one[n - 1] = _bigints([c.r - 1])[0]
+    want = cref.g1_mul(curve_id, bases[n - 1], c.r - 1)
+    assert np.array_equal(cref.jac_to_affine(curve_id, mj.msm_bigint(pp, one))[0], want)
+    pp.release()
+
+
+def test_commit_api_behaviour(gpu, mj, cref):
+    """Degree guard (mod.rs:98-104), leading/trailing zero handling, batch_commit, device scalars."""
+    import torch
+    curve_id = 1
+    c = mj.params.CURVES[curve_id]
+    pp_full = mj.UnivariateProverParam.gen_srs_for_testing(curve_id, 0xdeadbeef, 40)
+    pp = pp_full.trim(20)                                                  # 21 powers
+    srs = pp_full.powers_of_g()
+    assert cref.count_off_curve(curve_id, srs) == 0
+    polys = [mj.params.random_fr_mont(c, k, seed=k) for k in (1, 7, 21)]
+    polys[1][:3] = 0
+    coms = mj.UnivariateKzgPCS.batch_commit(pp, polys)
+    for p, com in zip(polys, coms):
+        want = cref.jac_to_affine(curve_id, cref.msm(curve_id, srs[:len(p)], p, scalars_are_mont=True))[0]
+        assert np.array_equal(com.xy, want)
+    too_long = np.zeros((23, 4), dtype=np.uint64)
+    too_long[22] = 1
+    with pytest.raises(mj.PCSError):
+        mj.UnivariateKzgPCS.commit(pp, too_long)                           # degree 22 > 21
+    assert mj.UnivariateKzgPCS.commit(pp, np.zeros((5, 4), dtype=np.uint64)).is_infinity()
+    with pytest.raises(mj.PCSError):
+        pp.trim(30)
+    with pytest.raises(mj.MzkError):
+        mj.msm_bigint(mj.UnivariateProverParam(c, 999999, 4, owner=False), polys[1])   # unknown handle
+    t = torch.from_numpy(polys[2].view(np.int64)).cuda()
+    jac = mj.msm_bigint(pp, t, scalars_are_mont=True)
+    assert np.array_equal(cref.jac_to_affine(curve_id, jac)[0], coms[2].xy)
+    pp_full.release()
+
+
+def test_msm_full_size_trapdoor(gpu, mj, cref):
+    """BASELINE config C2 (2^20 pairs, BLS12-381): commit(p) over [beta^i]G equals [p(beta)]G --
+    one oracle scalar multiplication pins an MSM of any size."""
+    import torch
+    curve_id, n = 0, 1 << 20
+    c = mj.params.CURVES[curve_id]
+    beta = 0x1f3a5c7e9b2d4f6081a3c5e7092b4d6f8091a2b3c4d5e6f708192a3b4c5d6e7f % c.r
+    pp = mj.UnivariateProverParam.gen_srs_for_testing(curve_id, beta, n - 1)
+    srs_sample = pp.powers_of_g(n - 3, 3)
+    assert cref.count_off_curve(curve_id, srs_sample) == 0
+    coeffs = mj.params.random_fr_mont(c, n, seed=2020)
+    t = torch.from_numpy(coeffs.view(np.int64)).cuda()
+    jac = mj.msm_bigint(pp, t, scalars_are_mont=True)
+    p_beta = cref.poly_eval(curve_id, coeffs, mj.params.fr_to_mont(c, [beta])[0])
+    k = mj.params.limbs_to_int(cref.fr_convert(curve_id, p_beta.reshape(1, 4), False)[0])
+    assert np.array_equal(cref.jac_to_affine(curve_id, jac)[0], cref.g1_mul_gen(curve_id, k))
+    # linearity: MSM(2x) = 2 MSM(x)
+    doubled = cref.fr_mul(curve_id, coeffs, np.repeat(mj.params.fr_to_mont(c, [2]), n, axis=0))
+    jac2 = mj.msm_bigint(pp, doubled, scalars_are_mont=True)
+    assert np.array_equal(cref.jac_to_affine(curve_id, jac2)[0], cref.g1_mul_gen(curve_id, 2 * k % c.r))
+    pp.release()

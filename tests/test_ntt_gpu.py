@@ -1,0 +1,123 @@
+"""GPU parity: the HIP NTT (through the C ABI) against the committed definition-level vectors,
+the C oracle on seeded inputs, and size-independent properties at the benchmark sizes."""
+import numpy as np
+import pytest
+
+from conftest import fr_from_mont_limbs, fr_mont_limbs, load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+def _dom(mj, c, log_n, offset):
+    d = mj.Radix2EvaluationDomain(c.curve_id, log_n)
+    return d if offset == 1 else d.get_coset(offset)
+
+
+def test_ntt_matches_golden_vectors(gpu, mj, pyref):
+    for case in load_golden("ntt_vectors"):
+        c = pyref.CURVES[case["curve"]]
+        log_n, offset = case["log_n"], int(case["offset"], 16)
+        inp = fr_mont_limbs(c, [int(v, 16) for v in case["input"]])
+        d = _dom(mj, c, log_n, offset)
+        assert fr_from_mont_limbs(c, d.fft(inp)) == [int(v, 16) for v in case["forward"]], (c.name, log_n, len(inp), offset)
+        assert fr_from_mont_limbs(c, d.ifft(inp)) == [int(v, 16) for v in case["inverse"]], (c.name, log_n, len(inp), offset, "inv")
+
+
+@pytest.mark.parametrize("curve_id", [0, 1])
+@pytest.mark.parametrize("log_n", [1, 5, 9, 10, 11, 13, 16, 17, 18, 20])
+def test_ntt_matches_c_oracle(gpu, mj, cref, curve_id, log_n):
+    """Seeded inputs, every pass-count regime (1, 2 and 3 passes), plain and coset, ragged inputs."""
+    c = mj.params.CURVES[curve_id]
+    n = 1 << log_n
+    a = mj.params.random_fr_mont(c, n, seed=100 + log_n)
+    g = mj.params.fr_to_mont(c, [c.fr_generator])[0]
+    odd = mj.params.fr_to_mont(c, [0x123456789abcdef123])[0]
+    for offset, off_limbs in ((1, None), (c.fr_generator, g), (0x123456789abcdef123, odd)):
+        d = _dom(mj, c, log_n, offset)
+        for in_len in (n, n // 8 + 3 if n >= 8 else n):
+            x = a[:in_len]
+            padded = np.zeros((n, 4), dtype=np.uint64)
+            padded[:in_len] = x
+            assert np.array_equal(d.fft(x), cref.ntt(curve_id, padded, log_n, False, off_limbs, threads=8)), (log_n, offset, in_len, "fwd")
+            assert np.array_equal(d.ifft(x), cref.ntt(curve_id, padded, log_n, True, off_limbs, threads=8)), (log_n, offset, in_len, "inv")
+        if log_n >= 17 and offset != 1:
+            break                               # one coset is enough at the slow-oracle sizes
+
+
+def test_ntt_edge_sizes(gpu, mj):
+    c = mj.params.BLS12_381
+    one = mj.params.fr_to_mont(c, [5])
+    d0 = mj.Radix2EvaluationDomain(0, 0)
+    assert np.array_equal(d0.fft(one), one) and np.array_equal(d0.ifft(one), one)
+    assert np.array_equal(d0.get_coset(7).fft(one), one)
+    d = mj.Radix2EvaluationDomain(0, 6)
+    z = np.zeros((64, 4), dtype=np.uint64)
+    assert not d.fft(z).any() and not d.ifft(z[:0]).any()
+    const = d.fft(one)                          # constant polynomial evaluates to itself everywhere
+    assert np.array_equal(const, np.repeat(one, 64, axis=0))
+    with pytest.raises(ValueError):
+        d.fft(np.zeros((65, 4), dtype=np.uint64))
+    with pytest.raises(mj.MzkError):
+        mj.lib.check(mj.load().mzk_ntt(7, z.ctypes.data, 64, 6, 0, None), "mzk_ntt")
+
+
+def test_ntt_device_resident_batch_and_stream(gpu, mj, cref):
+    """(batch, size, 4) CUDA tensor transformed in place on the current torch stream."""
+    import torch
+    c = mj.params.BN254
+    log_n, n, batch = 12, 1 << 12, 5
+    host = mj.params.random_fr_mont(c, batch * n, seed=7).reshape(batch, n, 4)
+    t = torch.from_numpy(host.view(np.int64)).cuda()
+    d = mj.Radix2EvaluationDomain(1, log_n).get_coset(c.fr_generator)
+    g = mj.params.fr_to_mont(c, [c.fr_generator])[0]
+    s = torch.cuda.Stream()
+    with torch.cuda.stream(s):
+        d.fft_in_place(t, in_len=n // 2 + 1)
+    s.synchronize()
+    got = t.cpu().numpy().view(np.uint64)
+    for b in range(batch):
+        padded = host[b].copy()
+        padded[n // 2 + 1:] = 0
+        assert np.array_equal(got[b], cref.ntt(1, padded, log_n, False, g, threads=4)), b
+    d.ifft_in_place(t)
+    torch.cuda.synchronize()
+    back = t.cpu().numpy().view(np.uint64)
+    for b in range(batch):
+        padded = host[b].copy()
+        padded[n // 2 + 1:] = 0
+        assert np.array_equal(back[b], padded)
+
+
+@pytest.mark.parametrize("curve_id,log_n", [(0, 22), (0, 23), (1, 25)])
+def test_ntt_full_size_properties(gpu, mj, cref, curve_id, log_n):
+    """BASELINE sizes (C3: 2^22; C4 quotient domain 2^23; C5 quotient domain 2^25, BN254):
+    inverse(forward(x)) == x bit-exactly on the Fr::GENERATOR coset, linearity, and spot
+    evaluations against Horner's rule on the oracle."""
+    import torch
+    c = mj.params.CURVES[curve_id]
+    n = 1 << log_n
+    x = mj.params.random_fr_mont(c, n, seed=log_n)
+    g = mj.params.fr_to_mont(c, [c.fr_generator])[0]
+    d = mj.Radix2EvaluationDomain(curve_id, log_n).get_coset(c.fr_generator)
+    t = torch.from_numpy(x.view(np.int64)).cuda()
+    d.fft_in_place(t)
+    ev = t.cpu().numpy().view(np.uint64)
+    if log_n <= 23:
+        for i in (0, 1, 12345, n // 2 + 7, n - 1):
+            pt = cref.domain_element(curve_id, log_n, i, g)
+            assert np.array_equal(ev[i], cref.poly_eval(curve_id, x, pt)), i
+    d.ifft_in_place(t)
+    assert np.array_equal(t.cpu().numpy().view(np.uint64), x)
+    # linearity on a sparse second input: NTT(x + y) - NTT(x) == NTT(y), y = e_k  => column of powers
+    k = 5
+    y = np.zeros((n, 4), dtype=np.uint64)
+    y[k] = mj.params.fr_to_mont(c, [1])[0]
+    ty = torch.from_numpy(y.view(np.int64)).cuda()
+    d.fft_in_place(ty)
+    evy = ty.cpu().numpy().view(np.uint64)
+    for i in (0, 3, n - 2):
+        pt = cref.domain_element(curve_id, log_n, i, g)             # (g w^i)
+        pk = pt
+        for _ in range(k - 1):
+            pk = cref.fr_mul(curve_id, pk.reshape(1, 4), pt.reshape(1, 4))[0]
+        assert np.array_equal(evy[i], pk), i

@@ -1,0 +1,93 @@
+"""CPU suite: pins the C oracle (oracle/cpu_ref.c) to the committed definition-level vectors
+(tests/golden, generated from oracle/pyref.py) and to algebraic properties."""
+import random
+
+import numpy as np
+
+from conftest import (affine_from_limbs, affine_limbs, fr_from_mont_limbs, fr_mont_limbs, golden_pt,
+                      jacobian_to_affine_ints, limbs_ints, load_golden)
+
+
+def test_pyref_self_check(pyref):
+    assert pyref.self_check()
+
+
+def test_c_oracle_ntt_matches_golden(pyref, cref):
+    for case in load_golden("ntt_vectors"):
+        c = pyref.CURVES[case["curve"]]
+        log_n, n = case["log_n"], 1 << case["log_n"]
+        offset = int(case["offset"], 16)
+        inp = [int(v, 16) for v in case["input"]]
+        padded = inp + [0] * (n - len(inp))
+        off = None if offset == 1 else fr_mont_limbs(c, [offset])[0]
+        got = cref.ntt(c.curve_id, fr_mont_limbs(c, padded), log_n, False, off, threads=2)
+        assert fr_from_mont_limbs(c, got) == [int(v, 16) for v in case["forward"]], (c.name, log_n, len(inp), offset)
+        got = cref.ntt(c.curve_id, fr_mont_limbs(c, padded), log_n, True, off)
+        assert fr_from_mont_limbs(c, got) == [int(v, 16) for v in case["inverse"]], (c.name, log_n, len(inp), offset, "inv")
+
+
+def test_c_oracle_msm_matches_golden(pyref, cref):
+    for case in load_golden("msm_vectors"):
+        c = pyref.CURVES[case["curve"]]
+        bases = affine_limbs(c, [golden_pt(p) for p in case["bases"]])
+        scalars = [int(s, 16) for s in case["scalars"]]
+        lim = np.array([[(s >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)] for s in scalars], dtype=np.uint64)
+        # the oracle's digit recoding covers r.bit_length()+1 bits; wider plain integers are reduced first
+        if max(scalars) >= (1 << c.r.bit_length()):
+            lim = np.array([[(s % c.r >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for j in range(4)] for s in scalars], dtype=np.uint64)
+        for threads, wb in ((1, 0), (3, 0), (2, 7)):
+            jac = cref.msm(c.curve_id, bases, lim, threads=threads, window_bits=wb)
+            assert jacobian_to_affine_ints(c, jac) == golden_pt(case["result"])
+            assert affine_from_limbs(c, cref.jac_to_affine(c.curve_id, jac)[0]) == golden_pt(case["result"])
+
+
+def test_c_oracle_kzg_trapdoor(pyref, cref):
+    for case in load_golden("kzg_vectors"):
+        c = pyref.CURVES[case["curve"]]
+        beta = int(case["beta"], 16)
+        srs = cref.srs_powers(c.curve_id, beta, len(case["srs"]), threads=2)
+        for i, p in enumerate(case["srs"]):
+            assert affine_from_limbs(c, srs[i]) == golden_pt(p)
+        coeffs = [int(v, 16) for v in case["coeffs"]]
+        jac = cref.msm(c.curve_id, srs, fr_mont_limbs(c, coeffs), scalars_are_mont=True)
+        assert jacobian_to_affine_ints(c, jac) == golden_pt(case["commitment"])
+
+
+def test_c_oracle_ntt_properties_mid_size(pyref, cref):
+    """2^14: inverse(forward) = id, spot evaluations by Horner, vs the big-int recursive NTT at 2^10."""
+    rng = random.Random(5)
+    for c in (pyref.BLS12_381, pyref.BN254):
+        log_n = 14
+        n = 1 << log_n
+        coeffs = [rng.randrange(c.r) for _ in range(n)]
+        a = fr_mont_limbs(c, coeffs)
+        g = fr_mont_limbs(c, [c.fr_gen])[0]
+        ev = cref.ntt(c.curve_id, a, log_n, False, g, threads=4)
+        back = cref.ntt(c.curve_id, ev, log_n, True, g, threads=4)
+        assert np.array_equal(back, a)
+        w = c.root_of_unity(log_n)
+        evi = fr_from_mont_limbs(c, ev[[0, 1, 77, n - 1]])
+        for k, i in enumerate((0, 1, 77, n - 1)):
+            assert evi[k] == pyref.poly_eval(c, coeffs, c.fr_gen * pow(w, i, c.r) % c.r)
+            x = cref.domain_element(c.curve_id, log_n, i, g)
+            assert fr_from_mont_limbs(c, cref.poly_eval(c.curve_id, a, x)) == [evi[k]]
+        small = coeffs[:1 << 10]
+        got = cref.ntt(c.curve_id, fr_mont_limbs(c, small), 10, False, None)
+        assert fr_from_mont_limbs(c, got) == pyref.ntt_fast(c, small, 10)
+
+
+def test_c_oracle_field_and_group_helpers(pyref, cref):
+    rng = random.Random(9)
+    for c in (pyref.BLS12_381, pyref.BN254):
+        vals = [rng.randrange(c.r) for _ in range(8)] + [0, 1, c.r - 1]
+        m = fr_mont_limbs(c, vals)
+        assert limbs_ints(cref.fr_convert(c.curve_id, m, False)) == vals
+        assert np.array_equal(cref.fr_convert(c.curve_id, cref.fr_convert(c.curve_id, m, False), True), m)
+        prod = cref.fr_mul(c.curve_id, m, m[::-1].copy())
+        assert fr_from_mont_limbs(c, prod) == [a * b % c.r for a, b in zip(vals, vals[::-1])]
+        k = rng.randrange(c.r)
+        assert affine_from_limbs(c, cref.g1_mul_gen(c.curve_id, k)) == pyref.g1_mul(c, k, pyref.g1_gen(c))
+        bases = cref.g1_arith_bases(c.curve_id, 11, 5, 9)
+        assert cref.count_off_curve(c.curve_id, bases) == 0
+        assert affine_from_limbs(c, bases[8]) == pyref.g1_mul(c, 11 + 5 * 8, pyref.g1_gen(c))
+        assert affine_from_limbs(c, cref.g1_mul(c.curve_id, bases[2], c.r - 1)) == pyref.g1_neg(c, pyref.g1_mul(c, 21, pyref.g1_gen(c)))
