@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the jf-plonk hot path on MI355X.
+
+Workload (BASELINE.json configs[1], "Standalone MSM"): 2^20 G1 points x Fr scalars on BLS12-381,
+SRS and scalars resident in HBM when the timed region starts; one step = one MSM of 2^20 pairs
+per GPU through the C ABI (mzk_msm_dev).  With N > 1 ranks the N*2^20 pairs are sharded by point
+range (one shard per GPU, weak scaling) and each step ends with the all-gather + local EC sum of
+the N partial points (mpc-jellyfish_amd/sharding.py).  Alongside, untimed by `value`, the same
+process measures BASELINE.json configs[2] (NTT 2^22 forward + inverse) and reports it under
+"ntt".
+
+    python bench.py [--gpus N --steps K --warmup W] [--log-n 20] [--no-cpu-baseline]
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+Prints ONE JSON line on rank 0.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--log-n", type=int, default=20, help="log2 of the MSM size per GPU (default 2^20 = config C2)")
+    ap.add_argument("--ntt-log-n", type=int, default=22, help="log2 of the NTT size for the secondary measurement")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-ntt", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (libmi355zk has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=dev)
+
+    import mpc_jellyfish_amd as mj
+    from importlib import import_module
+    mlib = import_module("mpc-jellyfish_amd.lib")
+    L = mlib.init(local_rank)
+
+    curve = mj.params.BLS12_381
+    n = 1 << args.log_n
+    # ---- synthetic inputs, generated on the device side of the boundary (no oracle involved) --------
+    # bases: a testing SRS [beta^i]G (srs.rs:118-153) -- distinct, on-curve, in-subgroup points.
+    # Each rank builds the n bases of its own point-range shard from its own trapdoor.
+    beta = 0x1f3a5c7e9b2d4f6081a3c5e7092b4d6f8091a2b3c4d5e6f708192a3b4c5d6e7f % curve.r
+    shard_beta = beta * pow(3, rank, curve.r) % curve.r
+    t0 = time.time()
+    pp = mj.UnivariateProverParam.gen_srs_for_testing(curve, shard_beta, n - 1)
+    t_srs = time.time() - t0
+    scalars = mj.params.random_fr_mont(curve, n, seed=0x6d7a6b5f + rank)      # uniform in [0, r)
+    d_scalars = torch.from_numpy(scalars.view(np.int64)).to(dev)
+    torch.cuda.synchronize()
+
+    def step():
+        jac = mj.msm_bigint(pp, d_scalars, scalars_are_mont=True)            # one Pippenger MSM, result on host
+        if world > 1:
+            jac = mj.sharding.all_gather_sum(curve, jac, device=dev)
+        return jac
+
+    for _ in range(args.warmup):
+        step()
+    L.mzk_profile_reset()
+    L.mzk_profile_enable(1)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        result = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    L.mzk_profile_enable(0)
+    if world > 1:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+    acc_ms, acc_cnt = mlib.profile_get("msm_accumulate")
+    tot_ms, tot_cnt = mlib.profile_get("msm_total")
+    sort_ms, _ = mlib.profile_get("msm_sort")
+    red_ms, _ = mlib.profile_get("msm_reduce")
+    c_bits, n_win, n_buckets = mlib.msm_last_shape()
+
+    # ---- secondary: NTT 2^22 forward + inverse on the Fr::GENERATOR coset (config C3) ---------------
+    ntt = None
+    if not args.no_ntt and rank == 0:
+        nl = args.ntt_log_n
+        N = 1 << nl
+        x = torch.from_numpy(mj.params.random_fr_mont(curve, N, seed=22).view(np.int64)).to(dev)
+        d = mj.Radix2EvaluationDomain(curve, nl).get_coset(curve.fr_generator)
+        for _ in range(2):
+            d.fft_in_place(x)
+            d.ifft_in_place(x)
+        torch.cuda.synchronize()
+        L.mzk_profile_reset()
+        L.mzk_profile_enable(1)
+        reps = 10
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            d.fft_in_place(x)
+            d.ifft_in_place(x)
+        torch.cuda.synchronize()
+        ntt_wall = (time.perf_counter() - t1) / reps
+        L.mzk_profile_enable(0)
+        pass_ms, pass_cnt = mlib.profile_get("ntt_pass")
+        nt_ms, nt_cnt = mlib.profile_get("ntt_total")
+        L.mzk_profile_reset()
+        per_transform_ms = nt_ms / max(nt_cnt, 1)
+        ntt = {"log_n": nl, "fwd_plus_inv_ms": round(ntt_wall * 1e3, 4), "transform_ms": round(per_transform_ms, 4),
+               "passes_per_transform": pass_cnt // max(nt_cnt, 1),
+               "butterflies_per_s": (N // 2 * nl) / (per_transform_ms * 1e-3),
+               "roofline": {"bound": "hbm", "achieved": round(64.0 * N / (per_transform_ms * 1e-3) / 1e9, 2),
+                            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                            "frac": round(64.0 * N / (per_transform_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None}}
+
+    # ---- CPU baseline: the C oracle ("port" of the ark-ec algorithm) on this host, rank 0 only -------
+    cpu = None
+    if not args.no_cpu_baseline and rank == 0 and world == 1:
+        sys.path.insert(0, os.path.join(ROOT, "oracle"))
+        import cref
+        threads = max(1, min(16, os.cpu_count() or 1))
+        bases = pp.powers_of_g()
+        canon = cref.fr_convert(0, scalars, False)
+        t1 = time.perf_counter()
+        want = cref.msm(0, bases, canon, threads=threads)
+        cpu_s = time.perf_counter() - t1
+        same = np.array_equal(cref.jac_to_affine(0, want)[0], cref.jac_to_affine(0, result)[0])
+        cpu = {"value": n / cpu_s, "unit": "pairs/s", "cores": threads, "kind": "port",
+               "sample": f"one full 2^{args.log_n}-pair MSM (same bases and scalars as the GPU step), oracle/cpu_ref.c "
+                         f"Pippenger with the ark-ec window rule, {threads} threads; restatement of ark-ec, not the Rust binary",
+               "seconds": round(cpu_s, 3), "matches_gpu": bool(same)}
+
+    if rank == 0:
+        acc_avg_ms = acc_ms / max(acc_cnt, 1)
+        alg_bytes = 128.0 * n                      # N * (2*|Fq| + 32) bytes per BLS12-381 MSM
+        achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9
+        traffic = None
+        tp = os.path.join(ROOT, "profiles", "r01_msm_traffic.json")
+        if os.path.exists(tp):
+            try:
+                traffic = json.load(open(tp)).get("msm_accumulate_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        out = {
+            "metric": "msm_g1_scalar_pairs_per_s", "value": world * n * args.steps / elapsed, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x12 (384-bit Fq Montgomery)",
+            "data": "synthetic",
+            "config": {"workload": f"standalone MSM, 2^{args.log_n} G1 x Fr pairs per GPU, BLS12-381 (BASELINE configs[1])",
+                       "curve": "bls12-381", "pairs_per_gpu": n, "window_bits": c_bits, "windows": n_win,
+                       "buckets_per_window": n_buckets, "sharding": "point-range" if world > 1 else "none",
+                       "srs_gen_s": round(t_srs, 3)},
+            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel<BlsFq>", "achieved": round(achieved, 3),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(acc_avg_ms, 4),
+                         "note": "integer-ALU bound (384-bit Montgomery mixed adds), not HBM bound: see DESIGN.md"},
+            "phases_ms": {"sort": round(sort_ms / max(tot_cnt, 1), 4), "accumulate": round(acc_avg_ms, 4),
+                          "reduce": round(red_ms / max(tot_cnt, 1), 4), "device_total": round(tot_ms / max(tot_cnt, 1), 4)},
+            "cpu_baseline": cpu, "ntt": ntt,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -89,6 +89,11 @@ MZK_API int32_t mzk_msm_batch(uint64_t srs_handle, uint32_t n_polys, const uint6
 MZK_API int32_t mzk_msm_affine(uint64_t srs_handle, uint64_t base_offset, const uint64_t* scalars, uint64_t n,
                        int32_t scalars_are_mont, uint64_t* out_xy_mont);
 
+/* Host-only (no GPU needed): out = sum of n Jacobian points (X||Y||Z mont each).  Used to combine the
+ * per-GPU partial sums of a point-range-sharded MSM after an all-gather; RCCL has
+ * no EC-add reduction, so the "all-reduce of partial EC sums" is all-gather + this local sum. */
+MZK_API int32_t mzk_g1_sum_jacobian(int32_t curve_id, const uint64_t* xyz_mont, uint64_t n, uint64_t* out_xyz_mont);
+
 /* ---- NTT: replaces EvaluationDomain::{fft,ifft}_in_place on Radix2EvaluationDomain
  *      forward coset: plonk/src/proof_system/prover.rs:554,557,561,566,567,579-591
  *      inverse coset: plonk/src/proof_system/prover.rs:672

@@ -13,5 +13,6 @@ The directory name carries a hyphen, so import it with
 from . import params  # noqa: F401
 from .lib import MzkError, lib_path, load  # noqa: F401
 from .domain import Radix2EvaluationDomain  # noqa: F401
+from . import sharding  # noqa: F401
 from .kzg import (Commitment, PCSError, UnivariateKzgPCS, UnivariateProverParam,  # noqa: F401
                   msm_bigint)

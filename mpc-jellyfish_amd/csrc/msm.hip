@@ -165,6 +165,31 @@ void jac_to_affine_host(const uint64_t* xyz, uint64_t* xy) {
 
 }  // namespace
 
+namespace {
+template <class FQ>
+void jac_sum_host(const uint64_t* xyz, uint64_t n, uint64_t* out) {
+    using F = Fp64<FQ>;
+    constexpr int L = FQ::N / 2;
+    XYZZ<F> acc = XYZZ<F>::inf();
+    for (uint64_t i = 0; i < n; i++) {
+        const uint64_t* p = xyz + i * 3 * L;
+        F X = F::from_words((const uint32_t*)p), Y = F::from_words((const uint32_t*)(p + L)), Z = F::from_words((const uint32_t*)(p + 2 * L));
+        if (Z.is_zero()) continue;
+        XYZZ<F> q;                                   // Jacobian (X,Y,Z) == XYZZ (X, Y, Z^2, Z^3)
+        q.x = X; q.y = Y; q.zz = Z * Z; q.zzz = q.zz * Z;
+        acc = xyzz_add(acc, q);
+    }
+    F X, Y, Z;
+    xyzz_to_jacobian(acc, X, Y, Z);
+    X.to_words((uint32_t*)out); Y.to_words((uint32_t*)(out + L)); Z.to_words((uint32_t*)(out + 2 * L));
+}
+}  // namespace
+
+void jac_sum_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uint64_t* out) {
+    if (curve == 0) jac_sum_host<BlsFq>(xyz, n, out);
+    else jac_sum_host<BnFq>(xyz, n, out);
+}
+
 int32_t srs_generate_dispatch(int curve, const uint32_t* beta_canon, uint64_t n, uint32_t* d_out) {
     return curve == 0 ? srs_generate<BlsFr, BlsFq>(beta_canon, n, d_out) : srs_generate<BnFr, BnFq>(beta_canon, n, d_out);
 }

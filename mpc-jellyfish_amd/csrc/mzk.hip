@@ -279,6 +279,12 @@ int32_t mzk_msm_affine(uint64_t srs_handle, uint64_t base_offset, const uint64_t
     return MZK_OK;
 }
 
+int32_t mzk_g1_sum_jacobian(int32_t curve_id, const uint64_t* xyz_mont, uint64_t n, uint64_t* out_xyz_mont) {
+    if ((curve_id != 0 && curve_id != 1) || !out_xyz_mont || (!xyz_mont && n)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
+    jac_sum_host_dispatch(curve_id, xyz_mont, n, out_xyz_mont);
+    return MZK_OK;
+}
+
 // ---- NTT -----------------------------------------------------------------------------------------
 int32_t mzk_ntt_dev(int32_t curve_id, void* d_data_mont, uint64_t in_len, uint32_t log_n, int32_t inverse, const uint64_t* coset_offset_mont,
                     uint32_t batch, uint64_t batch_stride, void* stream) {

@@ -1,0 +1,54 @@
+"""Multi-GPU sharding of the commit path; one process per GPU, torch.distributed.
+
+  * independent MSMs (batch_commit, mod.rs:125-127): polynomial i goes to rank i % world -- no
+    collective on the data path; the W affine results are gathered as plain bytes at the end.
+  * one large MSM sharded by point range: rank g owns bases/scalars [g*N/G, (g+1)*N/G), computes a
+    full Pippenger over its range and emits one Jacobian partial; the partials (<= 8 x 144 B) are
+    all-gathered and summed locally on every rank (RCCL has no EC-add reduction op).
+The collective is latency-bound (<= 1152 B); link bandwidth is irrelevant.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+from .params import curve as _curve
+
+
+def shard_range(n: int, rank: int, world: int) -> tuple[int, int]:
+    """Contiguous [lo, hi) of rank's share of n points (the first n % world ranks take one extra)."""
+    base, extra = divmod(n, world)
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def poly_owner(i: int, world: int) -> int:
+    return i % world
+
+
+def sum_jacobian(curve, points: np.ndarray) -> np.ndarray:
+    """Host-side sum of Jacobian points (n, 3, fq_limbs) -> (3, fq_limbs); needs no GPU."""
+    c = _curve(curve)
+    pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 3, c.fq_limbs)
+    out = np.empty((3, c.fq_limbs), dtype=np.uint64)
+    _lib.check(_lib.load().mzk_g1_sum_jacobian(c.curve_id, pts.ctypes.data_as(C.c_void_p), pts.shape[0],
+                                                out.ctypes.data_as(C.c_void_p)), "mzk_g1_sum_jacobian")
+    return out
+
+
+def all_gather_sum(curve, partial_xyz: np.ndarray, group=None, device=None) -> np.ndarray:
+    """All-gather every rank's Jacobian partial and add them up locally ("all-reduce" of EC sums).
+    With backend nccl (= RCCL) the 144-byte payload travels in a CUDA tensor; gloo uses host tensors."""
+    import torch
+    import torch.distributed as dist
+    c = _curve(curve)
+    world = dist.get_world_size(group)
+    t = torch.from_numpy(np.ascontiguousarray(partial_xyz, dtype=np.uint64).view(np.int64).reshape(-1))
+    if device is not None:
+        t = t.to(device)
+    parts = [torch.empty_like(t) for _ in range(world)]
+    dist.all_gather(parts, t, group=group)
+    stacked = torch.stack(parts).cpu().numpy().view(np.uint64).reshape(world, 3, c.fq_limbs)
+    return sum_jacobian(c, stacked)
