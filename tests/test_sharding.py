@@ -1,0 +1,77 @@
+"""CPU suite: the N > 1 path.  Two gloo ranks shard one MSM by point range, all-gather their
+Jacobian partials and add them up with the library's host-side EC sum (no GPU involved: the
+per-rank partial MSM comes from the oracle here, exactly where the HIP MSM sits on a GPU box)."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, curve_id, n, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import cref
+    import mpc_jellyfish_amd as mj
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c = mj.params.CURVES[curve_id]
+        bases = cref.g1_arith_bases(curve_id, 4242, 17, n)                 # same on every rank (seeded)
+        scalars = mj.params.random_fr_mont(c, n, seed=77)
+        lo, hi = mj.sharding.shard_range(n, rank, world)
+        partial = cref.msm(curve_id, bases[lo:hi], scalars[lo:hi]) if hi > lo else cref.msm(curve_id, bases[:0], scalars[:0])
+        total = mj.sharding.all_gather_sum(c, partial)
+        np.save(os.path.join(out_dir, f"total_{rank}.npy"), total)
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("curve_id,n", [(0, 257), (1, 64), (0, 1)])
+def test_point_range_sharded_msm_two_ranks(tmp_path, cref, mj, curve_id, n):
+    import torch.multiprocessing as mp
+    world = 2
+    port = 29500 + (os.getpid() + n) % 2000
+    mp.spawn(_worker, args=(world, port, curve_id, n, str(tmp_path)), nprocs=world, join=True)
+    c = mj.params.CURVES[curve_id]
+    bases = cref.g1_arith_bases(curve_id, 4242, 17, n)
+    scalars = mj.params.random_fr_mont(c, n, seed=77)
+    want = cref.jac_to_affine(curve_id, cref.msm(curve_id, bases, scalars))[0]
+    for rank in range(world):
+        total = np.load(tmp_path / f"total_{rank}.npy")
+        assert np.array_equal(cref.jac_to_affine(curve_id, total)[0], want), rank
+
+
+def test_shard_ranges_cover_exactly(mj):
+    for n in (0, 1, 7, 8, 1 << 20, (1 << 20) + 3):
+        for world in (1, 2, 3, 4, 8):
+            spans = [mj.sharding.shard_range(n, r, world) for r in range(world)]
+            assert spans[0][0] == 0 and spans[-1][1] == n
+            assert all(spans[i][1] == spans[i + 1][0] for i in range(world - 1))
+            sizes = [b - a for a, b in spans]
+            assert max(sizes) - min(sizes) <= 1
+    assert [mj.sharding.poly_owner(i, 4) for i in range(6)] == [0, 1, 2, 3, 0, 1]
+
+
+def test_host_ec_sum_edge_cases(mj, cref):
+    """infinity operands, P + P (doubling branch), P + (-P)."""
+    for curve_id in (0, 1):
+        c = mj.params.CURVES[curve_id]
+        L = c.fq_limbs
+        P = cref.g1_mul_gen(curve_id, 5)
+        one = cref.fq_convert(curve_id, np.array([[1] + [0] * (L - 1)], dtype=np.uint64), True)[0]
+        jacP = np.stack([P[0], P[1], one])
+        negP = cref.g1_mul_gen(curve_id, c.r - 5)
+        jacN = np.stack([negP[0], negP[1], one])
+        inf = np.stack([one, one, np.zeros(L, dtype=np.uint64)])
+        s = mj.sharding.sum_jacobian(c, np.stack([inf, jacP, inf]))
+        assert np.array_equal(cref.jac_to_affine(curve_id, s)[0], P)
+        s = mj.sharding.sum_jacobian(c, np.stack([jacP, jacP]))
+        assert np.array_equal(cref.jac_to_affine(curve_id, s)[0], cref.g1_mul_gen(curve_id, 10))
+        s = mj.sharding.sum_jacobian(c, np.stack([jacP, jacN]))
+        assert not s[2].any()
+        s = mj.sharding.sum_jacobian(c, np.zeros((0, 3, L), dtype=np.uint64))
+        assert not s[2].any()
