@@ -131,7 +131,7 @@ MZK_HD Fp<P> dbl(const Fp<P>& a) {
 // Montgomery product a*b/R mod p: CIOS, multiplication and reduction chains interleaved
 // ("no-carry" variant, valid because the top bit of every modulus is clear).
 template <class P>
-MZK_HD Fp<P> operator*(const Fp<P>& x, const Fp<P>& y) {
+MZK_HD Fp<P> mont_mul_cios(const Fp<P>& x, const Fp<P>& y) {
     constexpr int N = P::N;
     uint32_t t[N];
 #pragma unroll
@@ -155,8 +155,28 @@ MZK_HD Fp<P> operator*(const Fp<P>& x, const Fp<P>& y) {
     for (int j = 0; j < N; j++) r.l[j] = t[j];
     return r;
 }
+}  // namespace mzk
+#if defined(__HIP_DEVICE_COMPILE__)
+#include "fp_mul_gen.cuh"     // mont_mul_fips{8,12}, mont_sqr_fips{8,12}: one asm block per column
+#endif
+namespace mzk {
+
+// Device: FIPS in inline asm -- 2*N^2 (v_mad_u64_u32 + v_addc_co_u32) pairs and nothing else;
+// hipcc's lowering of the portable CIOS form spends ~55 % of its instructions on v_mov and
+// 64-bit adds (profiles/r01_fp_bench.txt).  Host: the portable form.
+template <class P>
+MZK_HD Fp<P> operator*(const Fp<P>& x, const Fp<P>& y) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    if constexpr (P::N == 8) return mont_mul_fips8(x, y);
+    else return mont_mul_fips12(x, y);
+#else
+    return mont_mul_cios(x, y);
+#endif
+}
 template <class P>
 MZK_HD Fp<P> sqr(const Fp<P>& x) {
+    // a dedicated FIPS squaring (mont_sqr_fips*, 23 % fewer multiply-adds) measured no faster than
+    // the product on gfx950: the per-column doubling eats the saving (profiles/r01_fp_bench.txt)
     return x * x;
 }
 
