@@ -38,7 +38,7 @@ struct DevBuf {
 };
 
 struct Workspace {
-    DevBuf ntt_scratch, scalars, hist, offs, cursor, sorted, buckets, collect, io, misc;
+    DevBuf ntt_scratch, scalars, hist, offs, cursor, sorted, buckets, collect, io, misc, digits;
     void* h_collect = nullptr;
     size_t h_collect_cap = 0;
     hipEvent_t last_use = nullptr;

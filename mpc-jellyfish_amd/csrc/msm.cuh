@@ -4,9 +4,10 @@
 //   primitives/src/pcs/univariate_kzg/mod.rs:109-111 (commit) and :151-155 (open).
 // Contract: result = sum_i k_i * P_i as a Jacobian point; only the group
 // element is pinned, not the algorithm.  Pipeline (all on one stream):
-//   1. msm_hist      signed base-2^c digits of every scalar, per-(window,bucket) histogram
-//   2. msm_scan      exclusive scan of each window's histogram -> bucket offsets
-//   3. msm_scatter   counting sort: point indices grouped by (window, bucket)
+//   1. msm_digits    signed base-2^c digits of every scalar (16-bit, window-major)
+//   2. msm_sort<COUNT> / msm_scan / msm_sort<SCATTER>   counting sort of point indices by (window,
+//                    bucket); one workgroup per (2048-bucket range, window), LDS atomics only
+//   3. msm_order     buckets of each window ranked by load (equal-length loops within a wave)
 //   4. msm_accumulate  one thread per (window,bucket): XYZZ += +-P (mixed add, all in VGPRs)
 //   5. msm_fold x log2(M)  in-place recursive halving: after level l the main array keeps
 //                    sum_i B_i folded to M/2^l entries and T_j (at offset M/2^j) the partial sums
@@ -64,25 +65,72 @@ __device__ __forceinline__ void load_scalar(DigitIter& it, const uint32_t* __res
     it.carry = 0;
 }
 
-// hist[w*M + b] += 1 for every non-zero digit
+// ---- bucket sort without global atomics ----------------------------------------------------------
+// digits[w*n + i] = sign<<15 | (magnitude-1), MSM_EMPTY for a zero digit.  (sign=1, magnitude=2^15)
+// cannot occur because negative digits have magnitude < 2^(c-1), so 0xFFFF is free.
+constexpr uint32_t MSM_EMPTY = 0xFFFFu;
+constexpr int MSM_RANGE_LOG = 11;            // buckets per sorting workgroup (LDS histogram of 2048 bins)
+constexpr int MSM_SORT_THREADS = 1024;
+
 template <class FR>
-__global__ __launch_bounds__(MSM_THREADS) void msm_hist_kernel(const uint32_t* __restrict__ scalars, unsigned long long n, int is_mont,
-                                                                int c, int n_win, uint32_t* __restrict__ hist) {
+__global__ __launch_bounds__(MSM_THREADS) void msm_digits_kernel(const uint32_t* __restrict__ scalars, unsigned long long n, int is_mont,
+                                                                  int c, int n_win, uint16_t* __restrict__ digits, unsigned long long stride) {
     const unsigned long long i = (unsigned long long)blockIdx.x * MSM_THREADS + threadIdx.x;
     if (i >= n) return;
     DigitIter it;
     load_scalar<FR>(it, scalars, i, is_mont);
-    const uint32_t M = 1u << (c - 1);
     for (int w = 0; w < n_win; w++) {
         uint32_t mag, ng;
         it.next(w, c, mag, ng);
-        if (mag) atomicAdd(&hist[(size_t)w * M + (mag - 1)], 1u);
+        digits[(size_t)w * stride + i] = (uint16_t)(mag ? ((ng << 15) | (mag - 1)) : MSM_EMPTY);
+    }
+}
+
+// One workgroup per (bucket range, window): it scans the window's n digits and keeps those whose
+// bucket lies in its range -- counts them in LDS (pass COUNT) or hands out positions from LDS
+// cursors (pass SCATTER).  All atomics are LDS atomics; global writes go to the range's own segment.
+template <bool SCATTER>
+__global__ __launch_bounds__(MSM_SORT_THREADS) void msm_sort_kernel(const uint16_t* __restrict__ digits, unsigned long long n, unsigned long long stride, uint32_t M,
+                                                                     uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs,
+                                                                     uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t bins[1 << MSM_RANGE_LOG];
+    const uint32_t range = blockIdx.x, w = blockIdx.y, tid = threadIdx.x;
+    const uint32_t rsize = M < (1u << MSM_RANGE_LOG) ? M : (1u << MSM_RANGE_LOG);
+    const uint32_t rbase = range * rsize;
+    for (uint32_t j = tid; j < rsize; j += MSM_SORT_THREADS) bins[j] = SCATTER ? offs[(size_t)w * M + rbase + j] : 0u;
+    __syncthreads();
+    const uint16_t* dw = digits + (size_t)w * stride;      // stride is a multiple of 8: 16-B aligned rows
+    uint32_t* out = sorted + (size_t)w * n;
+    // 8 digits (16 B) per thread per step
+    const unsigned long long n8 = n >> 3;
+    for (unsigned long long q = tid; q < n8; q += MSM_SORT_THREADS) {
+        const uint4 v = reinterpret_cast<const uint4*>(dw)[q];
+        const uint32_t wd[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const uint32_t d = (wd[k >> 1] >> ((k & 1) * 16)) & 0xFFFFu;
+            const uint32_t b = d & 0x7FFFu;
+            if (d != MSM_EMPTY && b - rbase < rsize) {
+                if (SCATTER) out[atomicAdd(&bins[b - rbase], 1u)] = (uint32_t)(q * 8 + k) | ((d >> 15) << 31);
+                else atomicAdd(&bins[b - rbase], 1u);
+            }
+        }
+    }
+    for (unsigned long long i = (n8 << 3) + tid; i < n; i += MSM_SORT_THREADS) {
+        const uint32_t d = dw[i], b = d & 0x7FFFu;
+        if (d != MSM_EMPTY && b - rbase < rsize) {
+            if (SCATTER) out[atomicAdd(&bins[b - rbase], 1u)] = (uint32_t)i | ((d >> 15) << 31);
+            else atomicAdd(&bins[b - rbase], 1u);
+        }
+    }
+    if (!SCATTER) {
+        __syncthreads();
+        for (uint32_t j = tid; j < rsize; j += MSM_SORT_THREADS) hist[(size_t)w * M + rbase + j] = bins[j];
     }
 }
 
 // per-window exclusive scan; one 1024-thread workgroup per window
-__global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restrict__ hist, uint32_t* __restrict__ offs,
-                                                        uint32_t* __restrict__ cursor, uint32_t M) {
+__global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restrict__ hist, uint32_t* __restrict__ offs, uint32_t M) {
     __shared__ uint32_t part[1024];
     const int w = blockIdx.x, t = threadIdx.x;
     const uint32_t per = (M + 1023) / 1024;
@@ -100,28 +148,34 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
     uint32_t run = part[t] - sum;
     for (uint32_t b = lo; b < hi; b++) {
         offs[(size_t)w * M + b] = run;
-        cursor[(size_t)w * M + b] = run;
         run += hist[(size_t)w * M + b];
     }
 }
 
-// sorted[w*n + pos] = i | sign<<31, grouped by bucket
-template <class FR>
-__global__ __launch_bounds__(MSM_THREADS) void msm_scatter_kernel(const uint32_t* __restrict__ scalars, unsigned long long n, int is_mont,
-                                                                   int c, int n_win, uint32_t* __restrict__ cursor,
-                                                                   uint32_t* __restrict__ sorted) {
-    const unsigned long long i = (unsigned long long)blockIdx.x * MSM_THREADS + threadIdx.x;
-    if (i >= n) return;
-    DigitIter it;
-    load_scalar<FR>(it, scalars, i, is_mont);
-    const uint32_t M = 1u << (c - 1);
-    for (int w = 0; w < n_win; w++) {
-        uint32_t mag, ng;
-        it.next(w, c, mag, ng);
-        if (mag) {
-            uint32_t pos = atomicAdd(&cursor[(size_t)w * M + (mag - 1)], 1u);
-            sorted[(size_t)w * n + pos] = (uint32_t)i | (ng << 31);
-        }
+// order[w*M + rank] = bucket, buckets of a window listed by descending point count (counting sort on
+// the count, clamped to 1023), so the 64 lanes of an accumulation wave run loops of equal length.
+__global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t* __restrict__ hist, uint32_t* __restrict__ order, uint32_t M) {
+    __shared__ uint32_t cnt[1024];
+    __shared__ uint32_t part[1024];
+    const int w = blockIdx.x, t = threadIdx.x;
+    cnt[t] = 0;
+    __syncthreads();
+    for (uint32_t b = t; b < M; b += 1024) atomicAdd(&cnt[1023 - min(hist[(size_t)w * M + b], 1023u)], 1u);
+    __syncthreads();
+    const uint32_t mine = cnt[t];
+    part[t] = mine;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        uint32_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    cnt[t] = part[t] - mine;                         // exclusive start of key t (key = 1023 - count)
+    __syncthreads();
+    for (uint32_t b = t; b < M; b += 1024) {
+        const uint32_t pos = atomicAdd(&cnt[1023 - min(hist[(size_t)w * M + b], 1023u)], 1u);
+        order[(size_t)w * M + pos] = b;
     }
 }
 
@@ -156,11 +210,12 @@ __device__ __forceinline__ void store_xyzz(uint32_t* __restrict__ buf, unsigned 
 template <class FQ>
 __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(const uint32_t* __restrict__ bases, unsigned long long n,
                                                                           const uint32_t* __restrict__ offs, const uint32_t* __restrict__ hist,
-                                                                          const uint32_t* __restrict__ sorted, uint32_t M, int n_win,
-                                                                          uint32_t* __restrict__ buckets) {
-    const unsigned long long t = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
-    if (t >= (unsigned long long)n_win * M) return;
-    const unsigned long long w = t / M;
+                                                                          const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ order,
+                                                                          uint32_t M, int n_win, uint32_t* __restrict__ buckets) {
+    const unsigned long long t0 = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
+    if (t0 >= (unsigned long long)n_win * M) return;
+    const unsigned long long w = t0 / M;
+    const unsigned long long t = w * M + order[t0];            // lanes of a wave take buckets of equal load
     const uint32_t start = offs[t], cnt = hist[t];
     const uint32_t* list = sorted + w * n + start;
     XYZZ<Fp<FQ>> acc = XYZZ<Fp<FQ>>::inf();

@@ -53,7 +53,9 @@ int32_t msm_dev(const uint32_t* d_bases, const uint32_t* d_scalars, uint64_t n, 
     MZK_TRY(ws_acquire(st));
     MZK_TRY(g_ws.hist.reserve(wm * 4));
     MZK_TRY(g_ws.offs.reserve(wm * 4));
-    MZK_TRY(g_ws.cursor.reserve(wm * 4));
+    MZK_TRY(g_ws.cursor.reserve(wm * 4));                       // bucket order by load
+    const unsigned long long dstride = (n + 7) & ~7ull;
+    MZK_TRY(g_ws.digits.reserve((size_t)n_win * dstride * 2));
     MZK_TRY(g_ws.sorted.reserve((size_t)n_win * n * 4));
     MZK_TRY(g_ws.buckets.reserve(wm * 4 * FQ::N * 4));
     const int n_out = n_win * (log_m + 1);
@@ -67,24 +69,27 @@ int32_t msm_dev(const uint32_t* d_bases, const uint32_t* d_scalars, uint64_t n, 
     }
     uint32_t* hist = g_ws.hist.as<uint32_t>();
     uint32_t* offs = g_ws.offs.as<uint32_t>();
-    uint32_t* cursor = g_ws.cursor.as<uint32_t>();
+    uint32_t* order = g_ws.cursor.as<uint32_t>();
+    uint16_t* digits = g_ws.digits.as<uint16_t>();
     uint32_t* sorted = g_ws.sorted.as<uint32_t>();
     uint32_t* buckets = g_ws.buckets.as<uint32_t>();
     uint32_t* collect = g_ws.collect.as<uint32_t>();
     {
         ProfScope total("msm_total", st);
-        HIP_TRY(hipMemsetAsync(hist, 0, wm * 4, st));
         const unsigned gs = (unsigned)((n + MSM_THREADS - 1) / MSM_THREADS);
+        const unsigned n_ranges = M >> MSM_RANGE_LOG ? M >> MSM_RANGE_LOG : 1u;
         {
             ProfScope ps("msm_sort", st);
-            hipLaunchKernelGGL((msm_hist_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, st, d_scalars, n, is_mont, c, n_win, hist);
-            hipLaunchKernelGGL(msm_scan_kernel, dim3(n_win), dim3(1024), 0, st, hist, offs, cursor, M);
-            hipLaunchKernelGGL((msm_scatter_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, st, d_scalars, n, is_mont, c, n_win, cursor, sorted);
+            hipLaunchKernelGGL((msm_digits_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, st, d_scalars, n, is_mont, c, n_win, digits, dstride);
+            hipLaunchKernelGGL((msm_sort_kernel<false>), dim3(n_ranges, n_win), dim3(MSM_SORT_THREADS), 0, st, digits, n, dstride, M, hist, offs, sorted);
+            hipLaunchKernelGGL(msm_scan_kernel, dim3(n_win), dim3(1024), 0, st, hist, offs, M);
+            hipLaunchKernelGGL((msm_sort_kernel<true>), dim3(n_ranges, n_win), dim3(MSM_SORT_THREADS), 0, st, digits, n, dstride, M, hist, offs, sorted);
+            hipLaunchKernelGGL(msm_order_kernel, dim3(n_win), dim3(1024), 0, st, hist, order, M);
         }
         {
             ProfScope ps("msm_accumulate", st);
             hipLaunchKernelGGL((msm_accumulate_kernel<FQ>), dim3((unsigned)((wm + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
-                               d_bases, n, offs, hist, sorted, M, n_win, buckets);
+                               d_bases, n, offs, hist, sorted, order, M, n_win, buckets);
         }
         {
             ProfScope ps("msm_reduce", st);
