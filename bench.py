@@ -28,6 +28,16 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
 
 
+def _profile_value(key):
+    """HBM bytes per launch from the committed PMC passes (profiles/r01_msm_traffic.json, collected
+    with tools/pmc_passes.sh: PMC counters cannot be read inside the timed run)."""
+    tp = os.path.join(ROOT, "profiles", "r01_msm_traffic.json")
+    try:
+        return json.load(open(tp)).get(key)
+    except Exception:
+        return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -135,7 +145,8 @@ def main():
                "butterflies_per_s": (N // 2 * nl) / (per_transform_ms * 1e-3),
                "roofline": {"bound": "hbm", "achieved": round(64.0 * N / (per_transform_ms * 1e-3) / 1e9, 2),
                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                            "frac": round(64.0 * N / (per_transform_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5), "traffic": None}}
+                            "frac": round(64.0 * N / (per_transform_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
+                            "traffic": _profile_value("ntt_pass_hbm_bytes_per_launch")}}
 
     # ---- CPU baseline: the C oracle ("port" of the ark-ec algorithm) on this host, rank 0 only -------
     cpu = None
@@ -158,13 +169,7 @@ def main():
         acc_avg_ms = acc_ms / max(acc_cnt, 1)
         alg_bytes = 128.0 * n                      # N * (2*|Fq| + 32) bytes per BLS12-381 MSM
         achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9
-        traffic = None
-        tp = os.path.join(ROOT, "profiles", "r01_msm_traffic.json")
-        if os.path.exists(tp):
-            try:
-                traffic = json.load(open(tp)).get("msm_accumulate_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
+        traffic = _profile_value("msm_accumulate_hbm_bytes_per_launch")
         out = {
             "metric": "msm_g1_scalar_pairs_per_s", "value": world * n * args.steps / elapsed, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,

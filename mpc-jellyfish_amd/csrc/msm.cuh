@@ -211,21 +211,132 @@ template <class FQ>
 __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(const uint32_t* __restrict__ bases, unsigned long long n,
                                                                           const uint32_t* __restrict__ offs, const uint32_t* __restrict__ hist,
                                                                           const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ order,
-                                                                          uint32_t M, int n_win, uint32_t* __restrict__ buckets) {
+                                                                          uint32_t M, int n_win, uint32_t cap, uint32_t* __restrict__ buckets) {
     const unsigned long long t0 = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
     if (t0 >= (unsigned long long)n_win * M) return;
     const unsigned long long w = t0 / M;
     const unsigned long long t = w * M + order[t0];            // lanes of a wave take buckets of equal load
-    const uint32_t start = offs[t], cnt = hist[t];
+    const uint32_t start = offs[t];
+    const uint32_t cnt = min(hist[t], cap);                    // the rest of an over-long bucket: msm_long_* kernels
     const uint32_t* list = sorted + w * n + start;
     XYZZ<Fp<FQ>> acc = XYZZ<Fp<FQ>>::inf();
-    for (uint32_t k = 0; k < cnt; k++) {
+    if (cnt) {
+        // software pipeline: the gather of point k+1 is in flight while point k is being added
+        uint32_t e = list[0];
+        Affine<Fp<FQ>> p = load_affine<FQ>(bases, e & 0x7fffffffu);
+        for (uint32_t k = 0; k < cnt; k++) {
+            const uint32_t e_next = list[k + 1 < cnt ? k + 1 : k];
+            Affine<Fp<FQ>> p_next = load_affine<FQ>(bases, e_next & 0x7fffffffu);
+            if (e >> 31) p.y = neg(p.y);
+            acc = xyzz_madd(acc, p);
+            p = p_next;
+            e = e_next;
+        }
+    }
+    store_xyzz<FQ>(buckets, t, acc);
+}
+
+// ---- over-long buckets (skewed scalars) ------------------------------------------------------------
+// A bucket with more than `cap` points would serialise one thread for its whole run (all-equal
+// scalars put n points into one bucket per window).  Its first `cap` points stay with the regular
+// accumulation; the remainder is cut into chunks of `cap`, each summed by its own thread, and the
+// chunk sums are tree-reduced per bucket.  With uniformly random scalars no bucket is long and the
+// three kernels below exit at once.
+struct LongDesc { uint32_t bucket, start, len, idx_in_run, run_len; };
+
+// one 1024-thread workgroup per window: descriptors in bucket order, at most n/cap per window
+__global__ __launch_bounds__(1024) void msm_long_find_kernel(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs, uint32_t M,
+                                                             uint32_t cap, uint32_t desc_cap, LongDesc* __restrict__ desc,
+                                                             uint32_t* __restrict__ desc_count) {
+    __shared__ uint32_t part[1024];
+    const int w = blockIdx.x, t = threadIdx.x;
+    const uint32_t per = (M + 1023) / 1024;
+    const uint32_t lo = t * per, hi = min(M, lo + per);
+    uint32_t sum = 0;
+    for (uint32_t b = lo; b < hi; b++) {
+        const uint32_t c = hist[(size_t)w * M + b];
+        if (c > cap) sum += (c - cap + cap - 1) / cap;
+    }
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        uint32_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    uint32_t pos = part[t] - sum;
+    if (t == 1023) desc_count[w] = min(part[1023], desc_cap);
+    for (uint32_t b = lo; b < hi; b++) {
+        const uint32_t c = hist[(size_t)w * M + b];
+        if (c <= cap) continue;
+        const uint32_t nch = (c - cap + cap - 1) / cap;
+        for (uint32_t j = 0; j < nch; j++) {
+            if (pos + j >= desc_cap) break;                  // cannot happen: sum of (c-cap)/cap <= n/cap
+            LongDesc d;
+            d.bucket = b;
+            d.start = offs[(size_t)w * M + b] + cap * (j + 1);
+            d.len = min(cap, c - cap * (j + 1));
+            d.idx_in_run = j;
+            d.run_len = nch;
+            desc[(size_t)w * desc_cap + pos + j] = d;
+        }
+        pos += nch;
+    }
+}
+
+// one thread per chunk descriptor
+template <class FQ>
+__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_long_chunk_kernel(const uint32_t* __restrict__ bases, unsigned long long n,
+                                                                          const uint32_t* __restrict__ sorted, const LongDesc* __restrict__ desc,
+                                                                          const uint32_t* __restrict__ desc_count, uint32_t desc_cap,
+                                                                          uint32_t* __restrict__ parts) {
+    const uint32_t w = blockIdx.y;
+    const uint32_t i = blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
+    if (i >= desc_count[w]) return;
+    const LongDesc d = desc[(size_t)w * desc_cap + i];
+    const uint32_t* list = sorted + (size_t)w * n + d.start;
+    XYZZ<Fp<FQ>> acc = XYZZ<Fp<FQ>>::inf();
+    for (uint32_t k = 0; k < d.len; k++) {
         const uint32_t e = list[k];
         Affine<Fp<FQ>> p = load_affine<FQ>(bases, e & 0x7fffffffu);
         if (e >> 31) p.y = neg(p.y);
         acc = xyzz_madd(acc, p);
     }
-    store_xyzz<FQ>(buckets, t, acc);
+    store_xyzz<FQ>(parts, (size_t)w * desc_cap + i, acc);
+}
+
+// one 1024-thread workgroup per window: pairwise tree over each bucket's run of chunk sums, then
+// bucket += run total.  Chunk sums live in global memory; a workgroup barrier plus a workgroup-scope
+// fence orders the passes (all traffic stays on one CU).
+template <class FQ>
+__global__ __launch_bounds__(1024) void msm_long_combine_kernel(const LongDesc* __restrict__ desc, const uint32_t* __restrict__ desc_count,
+                                                                uint32_t desc_cap, uint32_t M, uint32_t* __restrict__ parts,
+                                                                uint32_t* __restrict__ buckets) {
+    const uint32_t w = blockIdx.x, t = threadIdx.x;
+    const uint32_t cnt = desc_count[w];
+    if (cnt == 0) return;
+    const LongDesc* dw = desc + (size_t)w * desc_cap;
+    const size_t pbase = (size_t)w * desc_cap;
+    for (uint32_t s = 1; s < cnt; s <<= 1) {
+        for (uint32_t i = t; i < cnt; i += 1024) {
+            const LongDesc d = dw[i];
+            if ((d.idx_in_run & (2 * s - 1)) == 0 && d.idx_in_run + s < d.run_len) {
+                XYZZ<Fp<FQ>> a = load_xyzz<FQ>(parts, pbase + i), b = load_xyzz<FQ>(parts, pbase + i + s);
+                store_xyzz<FQ>(parts, pbase + i, xyzz_add(a, b));
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+    for (uint32_t i = t; i < cnt; i += 1024) {
+        const LongDesc d = dw[i];
+        if (d.idx_in_run == 0) {
+            const size_t bi = (size_t)w * M + d.bucket;
+            XYZZ<Fp<FQ>> a = load_xyzz<FQ>(buckets, bi), b = load_xyzz<FQ>(parts, pbase + i);
+            store_xyzz<FQ>(buckets, bi, xyzz_add(a, b));
+        }
+    }
 }
 
 // level with half-size h: segment 0 is the main array (base 0), segment j >= 1 is T_j (base M>>j);

@@ -1,4 +1,6 @@
 // msm.hip -- host side of the MSM: pipeline launches, the host Horner tail, testing SRS.
+#include <algorithm>
+
 #include "internal.hpp"
 #include "hostfp.hpp"
 #include "msm.cuh"
@@ -54,6 +56,14 @@ int32_t msm_dev(const uint32_t* d_bases, const uint32_t* d_scalars, uint64_t n, 
     MZK_TRY(g_ws.hist.reserve(wm * 4));
     MZK_TRY(g_ws.offs.reserve(wm * 4));
     MZK_TRY(g_ws.cursor.reserve(wm * 4));                       // bucket order by load
+    // per-thread cap on a bucket's run: 8x the mean load, at least 256
+    const uint32_t cap = (uint32_t)std::max<unsigned long long>(256ull, 8ull * (n / M + 1));
+    const uint32_t desc_cap = (uint32_t)(n / cap + 1);
+    MZK_TRY(g_ws.long_desc.reserve((size_t)n_win * desc_cap * sizeof(LongDesc) + (size_t)n_win * 4));
+    MZK_TRY(g_ws.long_parts.reserve((size_t)n_win * desc_cap * 4 * FQ::N * 4));
+    LongDesc* desc = g_ws.long_desc.as<LongDesc>();
+    uint32_t* desc_count = reinterpret_cast<uint32_t*>(desc + (size_t)n_win * desc_cap);
+    uint32_t* parts = g_ws.long_parts.as<uint32_t>();
     const unsigned long long dstride = (n + 7) & ~7ull;
     MZK_TRY(g_ws.digits.reserve((size_t)n_win * dstride * 2));
     MZK_TRY(g_ws.sorted.reserve((size_t)n_win * n * 4));
@@ -89,7 +99,15 @@ int32_t msm_dev(const uint32_t* d_bases, const uint32_t* d_scalars, uint64_t n, 
         {
             ProfScope ps("msm_accumulate", st);
             hipLaunchKernelGGL((msm_accumulate_kernel<FQ>), dim3((unsigned)((wm + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
-                               d_bases, n, offs, hist, sorted, order, M, n_win, buckets);
+                               d_bases, n, offs, hist, sorted, order, M, n_win, cap, buckets);
+        }
+        {
+            // over-long buckets (skewed scalars); no-ops for uniformly random scalars
+            ProfScope ps("msm_long", st);
+            hipLaunchKernelGGL(msm_long_find_kernel, dim3(n_win), dim3(1024), 0, st, hist, offs, M, cap, desc_cap, desc, desc_count);
+            hipLaunchKernelGGL((msm_long_chunk_kernel<FQ>), dim3((desc_cap + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, n_win), dim3(MSM_ACC_THREADS), 0, st,
+                               d_bases, n, sorted, desc, desc_count, desc_cap, parts);
+            hipLaunchKernelGGL((msm_long_combine_kernel<FQ>), dim3(n_win), dim3(1024), 0, st, desc, desc_count, desc_cap, M, parts, buckets);
         }
         {
             ProfScope ps("msm_reduce", st);

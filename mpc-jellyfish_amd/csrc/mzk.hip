@@ -29,7 +29,7 @@ void DevBuf::release() {
     cap = 0;
 }
 void Workspace::release() {
-    for (DevBuf* b : {&ntt_scratch, &scalars, &hist, &offs, &cursor, &sorted, &buckets, &collect, &io, &misc, &digits}) b->release();
+    for (DevBuf* b : {&ntt_scratch, &scalars, &hist, &offs, &cursor, &sorted, &buckets, &collect, &io, &misc, &digits, &long_desc, &long_parts}) b->release();
     if (h_collect) (void)hipHostFree(h_collect);
     h_collect = nullptr;
     h_collect_cap = 0;

@@ -89,6 +89,34 @@ def test_msm_skewed_and_degenerate_scalars(gpu, mj, cref):
     pp.release()
 
 
+@pytest.mark.parametrize("mode", ["all_equal", "half_equal", "small", "two_values"])
+def test_msm_skewed_large(gpu, mj, cref, mode):
+    """Adversarial scalar mixes at 2^18: over-long buckets take the chunked path (msm_long_* kernels);
+    small scalars leave the high windows empty (the bench circuit's witness is 0..2^20)."""
+    import time
+    curve_id, n = 0, 1 << 18
+    c = mj.params.CURVES[curve_id]
+    bases = cref.g1_arith_bases(curve_id, 31337, 11, n)
+    pp = mj.UnivariateProverParam.from_affine(curve_id, bases)
+    rnd = mj.params.random_fr_mont(c, n, seed=5)
+    if mode == "all_equal":
+        scalars = np.repeat(_bigints([0x5a5a5a5a1234567890abcdef0fedcba987654321deadbeefcafef00d12345678 % c.r]), n, axis=0)
+    elif mode == "half_equal":
+        scalars = rnd.copy()
+        scalars[::2] = _bigints([c.r - 2])[0]
+    elif mode == "small":
+        scalars = np.zeros((n, 4), dtype=np.uint64)
+        scalars[:, 0] = np.arange(n, dtype=np.uint64)
+    else:
+        scalars = np.where((np.arange(n) % 3 == 0)[:, None], _bigints([(1 << 200) + 12345])[0], _bigints([c.r >> 3])[0]).astype(np.uint64)
+    t0 = time.time()
+    got = mj.msm_bigint(pp, scalars)
+    assert time.time() - t0 < 5.0, "skewed MSM fell off a performance cliff"
+    want = cref.msm(curve_id, bases, scalars, threads=8)
+    assert np.array_equal(cref.jac_to_affine(curve_id, got)[0], cref.jac_to_affine(curve_id, want)[0])
+    pp.release()
+
+
 def test_commit_api_behaviour(gpu, mj, cref):
     """Degree guard (mod.rs:98-104), leading/trailing zero handling, batch_commit, device scalars."""
     import torch

@@ -36,6 +36,38 @@ __global__ void ksqrcheck(const uint32_t* in, uint32_t* out) {
     out[t] = bad;
 }
 
+// same work, loop body unrolled UNR times: code size UNR x larger (instruction-cache pressure test)
+template <class P, int UNR, int ITERS>
+__global__ __launch_bounds__(256) void kbench_unr(const uint32_t* in, uint32_t* out) {
+    const size_t t = (size_t)blockIdx.x * 256 + threadIdx.x;
+    Fp<P> a = load_fp<P>(in + (t % 4096) * 2 * P::N), b = load_fp<P>(in + (t % 4096) * 2 * P::N + P::N);
+#pragma unroll 1
+    for (int i = 0; i < ITERS / UNR; i++) {
+#pragma unroll
+        for (int u = 0; u < UNR; u++) {
+            a = a * b;
+            b = b * a;
+        }
+    }
+    store_fp<P>(out + t * P::N, a + b);
+}
+template <class P, int UNR>
+void run_unr(const uint32_t* d_in, uint32_t* d_out, int blocks) {
+    constexpr int ITERS = 256;
+    hipEvent_t e0, e1;
+    (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+    kbench_unr<P, UNR, ITERS><<<blocks, 256>>>(d_in, d_out);
+    (void)hipDeviceSynchronize();
+    (void)hipEventRecord(e0);
+    kbench_unr<P, UNR, ITERS><<<blocks, 256>>>(d_in, d_out);
+    (void)hipEventRecord(e1);
+    (void)hipEventSynchronize(e1);
+    float ms;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    printf("  unroll %2d muls/iter (%3d KB of code) blocks=%5d  %8.3f ms  %8.2f Gmul/s\n", 2 * UNR, 2 * UNR * (P::N == 12 ? 844 : 427) * 8 / 1024, blocks, ms,
+           (double)blocks * 256 * ITERS * 2 / ms * 1e-6);
+}
+
 template <class P, int VARIANT>
 double run(const char* name, const uint32_t* d_in, uint32_t* d_out, int blocks, std::vector<uint32_t>* result) {
     constexpr int ITERS = 256;
@@ -80,6 +112,12 @@ void suite(const char* tag) {
         run<P, 2>(name, d_in, d_out, blocks, nullptr);
     }
     printf("%s mul bit-exact vs CIOS: %s\n", tag, r0 == r1 ? "YES" : "NO");
+    for (int blocks : {768, 2048}) {
+        run_unr<P, 1>(d_in, d_out, blocks);
+        run_unr<P, 2>(d_in, d_out, blocks);
+        run_unr<P, 4>(d_in, d_out, blocks);
+        run_unr<P, 8>(d_in, d_out, blocks);
+    }
     ksqrcheck<P><<<32, 256>>>(d_in, d_out);
     std::vector<uint32_t> bad(32 * 256);
     (void)hipMemcpy(bad.data(), d_out, bad.size() * 4, hipMemcpyDeviceToHost);
