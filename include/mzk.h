@@ -113,6 +113,29 @@ MZK_API int32_t mzk_ntt_batch(int32_t curve_id, uint32_t n_polys, uint64_t* cons
 MZK_API int32_t mzk_ntt_dev(int32_t curve_id, void* d_data_mont, uint64_t in_len, uint32_t log_n, int32_t inverse,
                     const uint64_t* coset_offset_mont, uint32_t batch, uint64_t batch_stride, void* stream);
 
+/* ---- TurboPlonk quotient round on the device: replaces the body of
+ *      Prover::compute_quotient_polynomial, plonk/src/proof_system/prover.rs:512-673 (one instance, no Plookup).
+ * mzk_plonk_pk_register keeps, per proving key, the coset evaluations of the 13 selector and 5 sigma
+ * polynomials (`ProvingKey{selectors, sigmas}`, plonk/src/proof_system/structs.rs:575-590) on the
+ * 8n-point quotient domain -- the reference recomputes those 18 FFTs in every proof (prover.rs:552-558).
+ * selector_coeffs: 13 x poly_len, sigma_coeffs: 5 x poly_len Montgomery coefficients (low order first,
+ * selector order q_lc[4], q_mul[2], q_hash[4], q_o, q_c, q_ecc); k_mont: the 5 coset representatives
+ * `vk.k` (relation/src/constants.rs:30-80). */
+MZK_API int32_t mzk_plonk_pk_register(int32_t curve_id, uint32_t log_n, uint32_t num_wire_types, const uint64_t* selector_coeffs,
+                                      const uint64_t* sigma_coeffs, uint64_t poly_len, const uint64_t* k_mont, uint64_t* out_handle);
+MZK_API int32_t mzk_plonk_pk_release(uint64_t pk_handle);
+/* d_polys: device buffer of (5 + 2) x 8n elements: wire polynomials, then the permutation product z,
+ * then the public-input polynomial, each as coefficients in its first in_len slots (the rest is
+ * ignored).  The buffer is overwritten with the coset evaluations.  alpha/beta/gamma: host, Montgomery.
+ * d_out: 8n elements, the coefficients of the quotient polynomial (what `coset.ifft` returns at
+ * prover.rs:672; the caller strips trailing zeros as DensePolynomial::from_coefficients_vec does).
+ * Asynchronous on `stream`. */
+MZK_API int32_t mzk_plonk_quotient_dev(uint64_t pk_handle, void* d_polys, uint64_t in_len, const uint64_t* alpha_mont,
+                                       const uint64_t* beta_mont, const uint64_t* gamma_mont, void* d_out, void* stream);
+/* Host-pointer form: polys = 7 x in_len coefficients (wires, z, pi), out = 8n coefficients. */
+MZK_API int32_t mzk_plonk_quotient(uint64_t pk_handle, const uint64_t* polys, uint64_t in_len, const uint64_t* alpha_mont,
+                                   const uint64_t* beta_mont, const uint64_t* gamma_mont, uint64_t* out);
+
 /* ---- device memory helpers for bindings without HIP of their own ---- */
 MZK_API int32_t mzk_dev_alloc(uint64_t bytes, void** out_dptr);
 MZK_API int32_t mzk_dev_free(void* dptr);

@@ -6,6 +6,8 @@ The package is a thin Python layer over libmi355zk.so (HIP, gfx950; C ABI in inc
     lib      ctypes binding of the C ABI; raises if the HIP library is missing (no CPU fallback)
     domain   Radix2EvaluationDomain mirror  (ark-poly surface used at prover.rs:54-62,545-567,672)
     kzg      UnivariateKzgPCS mirror        (primitives/src/pcs/univariate_kzg/mod.rs:90-161, srs.rs)
+    plonk    TurboPlonk quotient round      (plonk/src/proof_system/prover.rs:512-759)
+    sharding multi-GPU split of the commit path
 
 The directory name carries a hyphen, so import it with
     importlib.import_module("mpc-jellyfish_amd")      or      import mpc_jellyfish_amd   (shim at the repo root).
@@ -13,6 +15,6 @@ The directory name carries a hyphen, so import it with
 from . import params  # noqa: F401
 from .lib import MzkError, lib_path, load  # noqa: F401
 from .domain import Radix2EvaluationDomain  # noqa: F401
-from . import sharding  # noqa: F401
+from . import plonk, sharding  # noqa: F401
 from .kzg import (Commitment, PCSError, UnivariateKzgPCS, UnivariateProverParam,  # noqa: F401
                   msm_bigint)

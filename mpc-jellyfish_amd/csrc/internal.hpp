@@ -38,7 +38,7 @@ struct DevBuf {
 };
 
 struct Workspace {
-    DevBuf ntt_scratch, scalars, hist, offs, cursor, sorted, buckets, collect, io, misc, digits, long_desc, long_parts;
+    DevBuf ntt_scratch, scalars, hist, offs, cursor, sorted, buckets, collect, io, misc, digits, long_desc, long_parts, plonk_polys, plonk_out;
     void* h_collect = nullptr;
     size_t h_collect_cap = 0;
     hipEvent_t last_use = nullptr;
@@ -79,5 +79,15 @@ int32_t msm_dispatch(const Srs& s, uint64_t base_offset, const uint32_t* d_scala
 int32_t srs_generate_dispatch(int curve, const uint32_t* beta_canon, uint64_t n, uint32_t* d_out);
 void jac_to_affine_host_dispatch(int curve, const uint64_t* xyz, uint64_t* xy);
 void jac_sum_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uint64_t* out);
+
+// plonk.hip
+int32_t plonk_pk_register(int curve, int log_n, int W, const uint32_t* sel, const uint32_t* sig, uint64_t poly_len, const uint32_t* k_mont,
+                          uint64_t* out_handle);
+int32_t plonk_pk_release(uint64_t handle);
+void plonk_release_all();
+int32_t plonk_quotient_dev(uint64_t handle, uint32_t* d_polys, uint64_t in_len, const uint32_t* alpha, const uint32_t* beta, const uint32_t* gamma,
+                           uint32_t* d_out, hipStream_t st);
+int plonk_pk_log_n(uint64_t handle);
+int plonk_pk_wires(uint64_t handle);
 
 }  // namespace mzk

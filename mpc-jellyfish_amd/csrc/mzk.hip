@@ -29,7 +29,7 @@ void DevBuf::release() {
     cap = 0;
 }
 void Workspace::release() {
-    for (DevBuf* b : {&ntt_scratch, &scalars, &hist, &offs, &cursor, &sorted, &buckets, &collect, &io, &misc, &digits, &long_desc, &long_parts}) b->release();
+    for (DevBuf* b : {&ntt_scratch, &scalars, &hist, &offs, &cursor, &sorted, &buckets, &collect, &io, &misc, &digits, &long_desc, &long_parts, &plonk_polys, &plonk_out}) b->release();
     if (h_collect) (void)hipHostFree(h_collect);
     h_collect = nullptr;
     h_collect_cap = 0;
@@ -132,6 +132,7 @@ int32_t mzk_shutdown(void) {
     for (auto& kv : g_srs) (void)hipFree(kv.second.d_xy);
     g_srs.clear();
     ntt_release_plans();
+    plonk_release_all();
     for (auto& r : g_prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof_recs.clear();
     g_ws.release();
@@ -322,6 +323,47 @@ int32_t mzk_ntt(int32_t curve_id, uint64_t* data_mont, uint64_t in_len, uint32_t
     uint64_t lens[1] = {in_len};
     if (!data_mont) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     return mzk_ntt_batch(curve_id, 1, ptrs, lens, log_n, inverse, coset_offset_mont);
+}
+
+// ---- TurboPlonk quotient round ------------------------------------------------------------------------
+int32_t mzk_plonk_pk_register(int32_t curve_id, uint32_t log_n, uint32_t num_wire_types, const uint64_t* selector_coeffs,
+                              const uint64_t* sigma_coeffs, uint64_t poly_len, const uint64_t* k_mont, uint64_t* out_handle) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    return plonk_pk_register(curve_id, (int)log_n, (int)num_wire_types, reinterpret_cast<const uint32_t*>(selector_coeffs),
+                             reinterpret_cast<const uint32_t*>(sigma_coeffs), poly_len, reinterpret_cast<const uint32_t*>(k_mont), out_handle);
+}
+int32_t mzk_plonk_pk_release(uint64_t pk_handle) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    return plonk_pk_release(pk_handle);
+}
+int32_t mzk_plonk_quotient_dev(uint64_t pk_handle, void* d_polys, uint64_t in_len, const uint64_t* alpha_mont, const uint64_t* beta_mont,
+                               const uint64_t* gamma_mont, void* d_out, void* stream) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    return plonk_quotient_dev(pk_handle, reinterpret_cast<uint32_t*>(d_polys), in_len, reinterpret_cast<const uint32_t*>(alpha_mont),
+                              reinterpret_cast<const uint32_t*>(beta_mont), reinterpret_cast<const uint32_t*>(gamma_mont),
+                              reinterpret_cast<uint32_t*>(d_out), (hipStream_t)stream);
+}
+int32_t mzk_plonk_quotient(uint64_t pk_handle, const uint64_t* polys, uint64_t in_len, const uint64_t* alpha_mont, const uint64_t* beta_mont,
+                           const uint64_t* gamma_mont, uint64_t* out) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    const int log_n = plonk_pk_log_n(pk_handle), W = plonk_pk_wires(pk_handle);
+    if (log_n < 0) { set_error("unknown proving-key handle"); return MZK_ERR_BAD_HANDLE; }
+    if (!polys || !out || in_len == 0 || in_len > (8ull << log_n)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
+    const uint64_t m = 8ull << log_n;
+    hipStream_t st = nullptr;
+    MZK_TRY(g_ws.plonk_polys.reserve((size_t)(W + 2) * m * 32));
+    MZK_TRY(g_ws.plonk_out.reserve(m * 32));
+    HIP_TRY(hipMemcpy2DAsync(g_ws.plonk_polys.p, m * 32, polys, in_len * 32, in_len * 32, W + 2, hipMemcpyHostToDevice, st));
+    MZK_TRY(plonk_quotient_dev(pk_handle, g_ws.plonk_polys.as<uint32_t>(), in_len, reinterpret_cast<const uint32_t*>(alpha_mont),
+                               reinterpret_cast<const uint32_t*>(beta_mont), reinterpret_cast<const uint32_t*>(gamma_mont),
+                               g_ws.plonk_out.as<uint32_t>(), st));
+    HIP_TRY(hipMemcpyAsync(out, g_ws.plonk_out.p, m * 32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return MZK_OK;
 }
 
 // ---- device memory helpers --------------------------------------------------------------------------

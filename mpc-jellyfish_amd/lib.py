@@ -36,6 +36,10 @@ _SIGS = {
     "mzk_ntt": [C.c_int32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_void_p],
     "mzk_ntt_batch": [C.c_int32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_uint32, C.c_int32, C.c_void_p],
     "mzk_ntt_dev": [C.c_int32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_void_p, C.c_uint32, C.c_uint64, C.c_void_p],
+    "mzk_plonk_pk_register": [C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)],
+    "mzk_plonk_pk_release": [C.c_uint64],
+    "mzk_plonk_quotient_dev": [C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "mzk_plonk_quotient": [C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "mzk_dev_alloc": [C.c_uint64, C.POINTER(C.c_void_p)],
     "mzk_dev_free": [C.c_void_p],
     "mzk_dev_upload": [C.c_void_p, C.c_void_p, C.c_uint64],

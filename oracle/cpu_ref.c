@@ -94,6 +94,27 @@ typedef unsigned __int128 u128;
 #undef NTT_ROOT
 #undef NTT_TWO_ADICITY
 
+/* ---- TurboPlonk quotient instantiations -------------------------------------------------------- */
+#define PLK(n) blsplk_##n
+#define FR(n) blsfr_##n
+#define NTT(n) blsntt_##n
+#define PLK_GEN BLS_FR_GENERATOR
+#include "plonk_impl.inc"
+#undef PLK
+#undef FR
+#undef NTT
+#undef PLK_GEN
+
+#define PLK(n) bnplk_##n
+#define FR(n) bnfr_##n
+#define NTT(n) bnntt_##n
+#define PLK_GEN BN_FR_GENERATOR
+#include "plonk_impl.inc"
+#undef PLK
+#undef FR
+#undef NTT
+#undef PLK_GEN
+
 /* ---- G1 instantiations ---------------------------------------------------------------- */
 #define G1(n) blsg1_##n
 #define FQ(n) blsfq_##n
@@ -189,6 +210,15 @@ EXPORT int orc_domain_element(int curve, int log_n, u64 k, const u64 *coset_mont
         memcpy(out_mont, &w, 32);
     } else return -2;
     return 0;
+}
+
+/* TurboPlonk quotient polynomial (one instance); see plonk_impl.inc for the layout */
+EXPORT int orc_plonk_quotient(int curve, int log_n, int num_wire_types, const u64 *polys, size_t poly_len, const u64 *k_mont,
+                              const u64 *alpha, const u64 *beta, const u64 *gamma, u64 *out, int threads) {
+    if (threads < 1) threads = 1;
+    if (curve == 0) return blsplk_quotient(log_n, num_wire_types, polys, poly_len, k_mont, alpha, beta, gamma, out, threads);
+    if (curve == 1) return bnplk_quotient(log_n, num_wire_types, polys, poly_len, k_mont, alpha, beta, gamma, out, threads);
+    return -2;
 }
 
 /* MSM: bases packed x||y Montgomery ((0,0) = infinity), scalars 4 limbs each (canonical, or

@@ -39,6 +39,7 @@ def lib():
         L.orc_srs_powers.argtypes = [C.c_int, u64p, C.c_size_t, u64p, C.c_int]
         L.orc_g1_count_off_curve.argtypes = [C.c_int, u64p, C.c_size_t]
         L.orc_g1_count_off_curve.restype = C.c_long
+        L.orc_plonk_quotient.argtypes = [C.c_int, C.c_int, C.c_int, u64p, C.c_size_t, u64p, u64p, u64p, u64p, u64p, C.c_int]
         _LIB = L
     return _LIB
 
@@ -163,3 +164,14 @@ def srs_powers(curve: int, beta: int, n: int, threads: int = 1) -> np.ndarray:
 def count_off_curve(curve: int, xy: np.ndarray) -> int:
     a = np.ascontiguousarray(xy, dtype=np.uint64)
     return int(lib().orc_g1_count_off_curve(curve, _p(a), a.size // (2 * fq_limbs(curve))))
+
+
+def plonk_quotient(curve: int, log_n: int, polys: np.ndarray, k_mont: np.ndarray, alpha, beta, gamma, threads: int = 1) -> np.ndarray:
+    """polys: (13 + 2*5 + 2, poly_len, 4) Montgomery coefficients (selectors, sigmas, wires, z, pi);
+    returns the 8n quotient coefficients (prover.rs:512-673, one TurboPlonk instance)."""
+    p = np.ascontiguousarray(polys, dtype=np.uint64)
+    assert p.ndim == 3 and p.shape[0] == 25 and p.shape[2] == 4
+    out = np.empty((8 << log_n, 4), dtype=np.uint64)
+    args = [np.ascontiguousarray(a, dtype=np.uint64) for a in (k_mont, alpha, beta, gamma)]
+    _chk(lib().orc_plonk_quotient(curve, log_n, 5, _p(p), p.shape[1], _p(args[0]), _p(args[1]), _p(args[2]), _p(args[3]), _p(out), threads))
+    return out

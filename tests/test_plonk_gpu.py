@@ -1,0 +1,123 @@
+"""GPU parity for the device-resident TurboPlonk quotient round: against the C
+restatement of prover.rs:512-759 on random inputs, and -- independent of any oracle -- the degree and
+divisibility properties the reference's own tests check (snark.rs:1282-1408) on a satisfied circuit."""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import fr_from_mont_limbs, fr_mont_limbs
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("curve_id", [0, 1])
+@pytest.mark.parametrize("log_n", [1, 3, 6, 9])
+def test_quotient_matches_c_oracle(gpu, mj, cref, curve_id, log_n):
+    c = mj.params.CURVES[curve_id]
+    n = 1 << log_n
+    rng = random.Random(log_n * 7 + curve_id)
+    # wires carry one blinding coefficient pair (n+2), z three (n+3): prover.rs:79-83,133-138
+    polys = mj.params.random_fr_mont(c, 25 * (n + 3), seed=log_n).reshape(25, n + 3, 4)
+    polys[:18, n:] = 0          # selectors and sigmas have degree < n
+    polys[18:23, n + 2:] = 0
+    k = [rng.randrange(1, c.r) for _ in range(5)]
+    ch = mj.plonk.Challenges(rng.randrange(c.r), rng.randrange(c.r), rng.randrange(c.r))
+    pk = mj.plonk.ProvingKeyDevice.register(c, n, list(polys[:13, :n]), list(polys[13:18, :n]), k)
+    got = mj.plonk.compute_quotient_polynomial(pk, ch, list(polys[18:23, :n + 2]), polys[23], polys[24, :n])
+    pi_padded = polys.copy()
+    pi_padded[24, n:] = 0
+    want = cref.plonk_quotient(curve_id, log_n, pi_padded, mj.params.fr_to_mont(c, k), *mj.params.fr_to_mont(c, [ch.alpha, ch.beta, ch.gamma]),
+                               threads=8)
+    assert np.array_equal(got, want)
+    # a second proof against the same resident key (different witness polynomials and challenges)
+    polys2 = polys.copy()
+    polys2[18:] = mj.params.random_fr_mont(c, 7 * (n + 3), seed=99).reshape(7, n + 3, 4)
+    ch2 = mj.plonk.Challenges(5, 7, 11)
+    got2 = mj.plonk.compute_quotient_polynomial(pk, ch2, list(polys2[18:23]), polys2[23], polys2[24])
+    want2 = cref.plonk_quotient(curve_id, log_n, polys2, mj.params.fr_to_mont(c, k), *mj.params.fr_to_mont(c, [5, 7, 11]), threads=8)
+    assert np.array_equal(got2, want2)
+    pk.release()
+
+
+def _interpolate(mj, c, log_n, values):
+    return mj.Radix2EvaluationDomain(c, log_n).ifft(fr_mont_limbs(c, values))
+
+
+@pytest.mark.parametrize("curve_id", [0, 1])
+def test_quotient_of_a_satisfied_circuit_is_a_low_degree_polynomial(gpu, mj, cref, pyref, curve_id):
+    """Add / mul / x^5 / constant gates with the identity permutation (z = 1, sigma_j = k_j X): the gate
+    polynomial vanishes on H, so t = gate / Z_H has degree < 5n and t * Z_H == gate at a random point;
+    breaking one witness value makes the high coefficients non-zero."""
+    c = mj.params.CURVES[curve_id]
+    pc = pyref.CURVES[curve_id]
+    log_n, n = 6, 64
+    rng = random.Random(11 + curve_id)
+    r = c.r
+    w = [[rng.randrange(r) for _ in range(n)] for _ in range(5)]
+    sel = [[0] * n for _ in range(13)]
+    for i in range(n):
+        kind = i % 4
+        if kind == 0:      # w0 + w1 = w4
+            sel[0][i] = sel[1][i] = 1; sel[10][i] = 1
+            w[4][i] = (w[0][i] + w[1][i]) % r
+        elif kind == 1:    # 3*w0*w1 + w2*w3 = w4
+            sel[4][i] = 3; sel[5][i] = 1; sel[10][i] = 1
+            w[4][i] = (3 * w[0][i] * w[1][i] + w[2][i] * w[3][i]) % r
+        elif kind == 2:    # w0^5 + 2*w3^5 + w0*w1*w2*w3*w4' ... keep the ecc gate separate
+            sel[6][i] = 1; sel[9][i] = 2; sel[10][i] = 1
+            w[4][i] = (pow(w[0][i], 5, r) + 2 * pow(w[3][i], 5, r)) % r
+        else:              # q_ecc * w0 w1 w2 w3 w4 + q_c = 0 with w4 chosen, and a linear term on w2
+            sel[12][i] = 1
+            w[4][i] = rng.randrange(r)
+            prod = w[0][i] * w[1][i] % r * w[2][i] % r * w[3][i] % r * w[4][i] % r
+            sel[11][i] = (-prod) % r
+    k = [1, 7, 13, 17, 23]
+    sel_polys = [_interpolate(mj, c, log_n, s) for s in sel]
+    sigma_polys = [fr_mont_limbs(c, [0, kj] + [0] * (n - 2)) for kj in k]          # sigma_j(X) = k_j X
+    z_poly = fr_mont_limbs(c, [1])
+    pi_poly = fr_mont_limbs(c, [0])
+    pk = mj.plonk.ProvingKeyDevice.register(c, n, sel_polys, sigma_polys, k)
+    ch = mj.plonk.Challenges(rng.randrange(r), rng.randrange(r), rng.randrange(r))
+    wire_polys = [_interpolate(mj, c, log_n, col) for col in w]
+    t = mj.plonk.compute_quotient_polynomial(pk, ch, wire_polys, z_poly, pi_poly)
+    assert not t[5 * n:].any(), "quotient of a satisfied circuit must have degree < 5n"
+    # t(x) * Z_H(x) == gate(x) at a random point (big-int evaluation of every polynomial)
+    x = rng.randrange(r)
+    ev = lambda poly: pyref.poly_eval(pc, fr_from_mont_limbs(c, poly), x)
+    W = [ev(p) for p in wire_polys]
+    S = [ev(p) for p in sel_polys]
+    gate = (S[11] + sum(S[j] * W[j] for j in range(4)) + S[4] * W[0] * W[1] + S[5] * W[2] * W[3]
+            + S[12] * W[0] * W[1] * W[2] * W[3] * W[4] + sum(S[6 + j] * pow(W[j], 5, r) for j in range(4)) - S[10] * W[4]) % r
+    assert ev(t) * (pow(x, n, r) - 1) % r == gate
+    # an unsatisfied gate breaks divisibility
+    w[4][5] = (w[4][5] + 1) % r
+    bad = mj.plonk.compute_quotient_polynomial(pk, ch, [_interpolate(mj, c, log_n, col) for col in w], z_poly, pi_poly)
+    assert bad[5 * n:].any()
+    pk.release()
+
+
+def test_quotient_device_resident_and_errors(gpu, mj, cref):
+    import torch
+    c = mj.params.BLS12_381
+    log_n, n = 8, 256
+    m = 8 * n
+    polys = mj.params.random_fr_mont(c, 25 * n, seed=4).reshape(25, n, 4)
+    k = [1, 2, 3, 4, 5]
+    pk = mj.plonk.ProvingKeyDevice.register(c, n, list(polys[:13]), list(polys[13:18]), k)
+    slab = np.zeros((7, m, 4), dtype=np.uint64)
+    slab[:, :n] = polys[18:]
+    d = torch.from_numpy(slab.view(np.int64)).cuda()
+    out = torch.empty((m, 4), dtype=torch.int64, device="cuda")
+    ch = mj.plonk.Challenges(3, 5, 9)
+    mj.plonk.compute_quotient_polynomial_dev(pk, ch, d, n, out)
+    torch.cuda.synchronize()
+    want = cref.plonk_quotient(0, log_n, polys, mj.params.fr_to_mont(c, k), *mj.params.fr_to_mont(c, [3, 5, 9]), threads=8)
+    assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
+    with pytest.raises(mj.plonk.PlonkError):
+        mj.plonk.compute_quotient_polynomial(pk, ch, list(polys[18:22]), polys[23], polys[24])       # 4 wire polys
+    with pytest.raises(mj.plonk.PlonkError):
+        mj.plonk.ProvingKeyDevice.register(c, n, list(polys[:12]), list(polys[13:18]), k)
+    pk.release()
+    with pytest.raises(mj.MzkError):
+        mj.plonk.compute_quotient_polynomial(pk.__class__(c, 424242, n), ch, list(polys[18:23]), polys[23], polys[24])
