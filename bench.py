@@ -47,6 +47,8 @@ def main():
     ap.add_argument("--ntt-log-n", type=int, default=22, help="log2 of the NTT size for the secondary measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-ntt", action="store_true")
+    ap.add_argument("--no-plonk", action="store_true", help="skip the TurboPlonk round-3 (quotient) measurement")
+    ap.add_argument("--plonk-log-n", type=int, default=20)
     args = ap.parse_args()
 
     import torch
@@ -115,6 +117,21 @@ def main():
     red_ms, _ = mlib.profile_get("msm_reduce")
     c_bits, n_win, n_buckets = mlib.msm_last_shape()
 
+    # ---- secondary: batch_commit of 5 polynomials (round 1 / round 3 of a proof) in one fused call -----
+    batch = None
+    if rank == 0 and world == 1:
+        sets = [d_scalars] * 5
+        mj.msm_bigint_batch(pp, sets, scalars_are_mont=True)
+        torch.cuda.synchronize()
+        reps = 3
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            mj.msm_bigint_batch(pp, sets, scalars_are_mont=True)
+        torch.cuda.synchronize()
+        bt = (time.perf_counter() - t1) / reps
+        batch = {"what": "5 MSMs of 2^%d pairs in one mzk_msm_batch_dev call (shared bucket reduction, one sync)" % args.log_n,
+                 "ms_per_batch": round(bt * 1e3, 3), "pairs_per_s": 5 * n / bt}
+
     # ---- secondary: NTT 2^22 forward + inverse on the Fr::GENERATOR coset (config C3) ---------------
     ntt = None
     if not args.no_ntt and rank == 0:
@@ -147,6 +164,47 @@ def main():
                             "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(64.0 * N / (per_transform_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
                             "traffic": _profile_value("ntt_pass_hbm_bytes_per_launch")}}
+
+    # ---- secondary: TurboPlonk round 3 on the device at 2^20 gates (config C4's heaviest round) -------
+    plonk = None
+    if not args.no_plonk and rank == 0:
+        pl, pn = args.plonk_log_n, 1 << args.plonk_log_n
+        pm = 8 * pn
+        fixed = mj.params.random_fr_mont(curve, 18 * pn, seed=31).reshape(18, pn, 4)
+        t1 = time.perf_counter()
+        pk = mj.plonk.ProvingKeyDevice.register(curve, pn, list(fixed[:13]), list(fixed[13:]), [1, 2, 3, 4, 5])
+        t_pk = time.perf_counter() - t1
+        del fixed
+        wit = mj.params.random_fr_mont(curve, 7 * (pn + 3), seed=32).reshape(7, pn + 3, 4)
+        d_coeffs = torch.from_numpy(wit.view(np.int64)).to(dev)
+        d_polys = torch.zeros((7, pm, 4), dtype=torch.int64, device=dev)
+        d_out = torch.empty((pm, 4), dtype=torch.int64, device=dev)
+        ch = mj.plonk.Challenges(0x1234567, 0x89abcde, 0xf012345)
+        def round3():
+            d_polys[:, :pn + 3] = d_coeffs            # fresh coefficients (the call overwrites them)
+            mj.plonk.compute_quotient_polynomial_dev(pk, ch, d_polys, pn + 3, d_out)
+        round3()
+        torch.cuda.synchronize()
+        L.mzk_profile_reset()
+        L.mzk_profile_enable(1)
+        reps = 3
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            round3()
+        torch.cuda.synchronize()
+        r3_wall = (time.perf_counter() - t1) / reps
+        L.mzk_profile_enable(0)
+        qk_ms, qk_cnt = mlib.profile_get("plonk_quotient_kernel")
+        qt_ms, qt_cnt = mlib.profile_get("plonk_quotient_total")
+        L.mzk_profile_reset()
+        plonk = {"what": "TurboPlonk round 3 without commitments: 7 coset NTT(8n) + fused quotient kernel + coset iNTT(8n); "
+                         "selector/sigma coset evaluations resident per proving key",
+                 "log_n": pl, "quotient_domain_log": pl + 3, "round3_ms": round(r3_wall * 1e3, 3),
+                 "quotient_kernel_ms": round(qk_ms / max(qk_cnt, 1), 3), "device_ms": round(qt_ms / max(qt_cnt, 1), 3),
+                 "pk_register_s": round(t_pk, 3),
+                 "quotient_kernel_GBps": round(27 * 32.0 * pm / (qk_ms / max(qk_cnt, 1) * 1e-3) / 1e9, 1)}
+        pk.release()
+        del d_polys, d_out, d_coeffs
 
     # ---- CPU baseline: the C oracle ("port" of the ark-ec algorithm) on this host, rank 0 only -------
     cpu = None
@@ -185,7 +243,7 @@ def main():
                          "note": "integer-ALU bound (384-bit Montgomery mixed adds), not HBM bound: see DESIGN.md"},
             "phases_ms": {"sort": round(sort_ms / max(tot_cnt, 1), 4), "accumulate": round(acc_avg_ms, 4),
                           "reduce": round(red_ms / max(tot_cnt, 1), 4), "device_total": round(tot_ms / max(tot_cnt, 1), 4)},
-            "cpu_baseline": cpu, "ntt": ntt,
+            "cpu_baseline": cpu, "ntt": ntt, "plonk_round3": plonk, "batch_commit5": batch,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

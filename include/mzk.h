@@ -84,6 +84,10 @@ MZK_API int32_t mzk_msm_dev(uint64_t srs_handle, uint64_t base_offset, const voi
 /* batch_commit (mod.rs:119-131) in one call: n_polys independent MSMs over one SRS. */
 MZK_API int32_t mzk_msm_batch(uint64_t srs_handle, uint32_t n_polys, const uint64_t* const* scalars, const uint64_t* lens,
                       const uint64_t* base_offsets, int32_t scalars_are_mont, uint64_t* out_xyz_mont);
+/* Device-resident scalars: d_scalars[i] is a device pointer to lens[i] x 4 limbs.  The MSMs run back to back
+ * and share one bucket-reduction phase and one host synchronisation; base_offsets may be NULL (all 0). */
+MZK_API int32_t mzk_msm_batch_dev(uint64_t srs_handle, uint32_t n_polys, const void* const* d_scalars, const uint64_t* lens,
+                          const uint64_t* base_offsets, int32_t scalars_are_mont, uint64_t* out_xyz_mont, void* stream);
 /* Same point as mzk_msm but normalised on the host: x||y (mont), (0,0) for infinity
  * (the `.into_affine()` of mod.rs:111 folded in). */
 MZK_API int32_t mzk_msm_affine(uint64_t srs_handle, uint64_t base_offset, const uint64_t* scalars, uint64_t n,
@@ -93,6 +97,9 @@ MZK_API int32_t mzk_msm_affine(uint64_t srs_handle, uint64_t base_offset, const 
  * per-GPU partial sums of a point-range-sharded MSM after an all-gather; RCCL has
  * no EC-add reduction, so the "all-reduce of partial EC sums" is all-gather + this local sum. */
 MZK_API int32_t mzk_g1_sum_jacobian(int32_t curve_id, const uint64_t* xyz_mont, uint64_t n, uint64_t* out_xyz_mont);
+
+/* Host-only: n Jacobian points -> affine x||y ((0,0) for infinity): `.into_affine()` (mod.rs:111) / normalize_batch. */
+MZK_API int32_t mzk_g1_jacobian_to_affine(int32_t curve_id, const uint64_t* xyz_mont, uint64_t n, uint64_t* out_xy_mont);
 
 /* ---- NTT: replaces EvaluationDomain::{fft,ifft}_in_place on Radix2EvaluationDomain
  *      forward coset: plonk/src/proof_system/prover.rs:554,557,561,566,567,579-591

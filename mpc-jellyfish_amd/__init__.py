@@ -17,4 +17,4 @@ from .lib import MzkError, lib_path, load  # noqa: F401
 from .domain import Radix2EvaluationDomain  # noqa: F401
 from . import plonk, sharding  # noqa: F401
 from .kzg import (Commitment, PCSError, UnivariateKzgPCS, UnivariateProverParam,  # noqa: F401
-                  msm_bigint)
+                  jacobian_to_affine, msm_bigint, msm_bigint_batch)

@@ -76,6 +76,8 @@ int32_t ntt_dispatch(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bo
 void ntt_release_plans();
 // msm.hip
 int32_t msm_dispatch(const Srs& s, uint64_t base_offset, const uint32_t* d_scalars, uint64_t n, int is_mont, uint32_t* out, hipStream_t st);
+int32_t msm_batch_dispatch(const Srs& s, uint32_t n_polys, const uint32_t* const* d_scalars, const uint64_t* lens, const uint64_t* base_offsets,
+                           int is_mont, uint32_t* out_xyz, hipStream_t st);
 int32_t srs_generate_dispatch(int curve, const uint32_t* beta_canon, uint64_t n, uint32_t* d_out);
 void jac_to_affine_host_dispatch(int curve, const uint64_t* xyz, uint64_t* xy);
 void jac_sum_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uint64_t* out);

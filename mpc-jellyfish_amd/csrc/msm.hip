@@ -1,5 +1,7 @@
 // msm.hip -- host side of the MSM: pipeline launches, the host Horner tail, testing SRS.
 #include <algorithm>
+#include <thread>
+#include <vector>
 
 #include "internal.hpp"
 #include "hostfp.hpp"
@@ -37,38 +39,48 @@ void host_horner(const uint32_t* pts, int n_win, int c, uint32_t* out_xyz) {
     X.to_words(out_xyz); Y.to_words(out_xyz + FQ::N); Z.to_words(out_xyz + 2 * FQ::N);
 }
 
-template <class FR, class FQ>
-int32_t msm_dev(const uint32_t* d_bases, const uint32_t* d_scalars, uint64_t n, int is_mont, uint32_t* out_xyz, hipStream_t st) {
+struct MsmItem {
+    const uint32_t* d_bases;     // first base of this MSM
+    const uint32_t* d_scalars;
+    uint64_t n;
+    uint32_t* out_xyz;           // host, Jacobian
+};
+
+template <class FQ>
+void write_infinity(uint32_t* out_xyz) {
     using F64 = Fp64<FQ>;
-    if (n == 0) {
-        F64 one = F64::one(), z = F64::zero();
-        one.to_words(out_xyz); one.to_words(out_xyz + FQ::N); z.to_words(out_xyz + 2 * FQ::N);
-        return MZK_OK;
-    }
-    if (n >= (1ull << 31)) { set_error("MSM size must be < 2^31"); return MZK_ERR_INVALID_ARG; }
-    const int c = msm_choose_window(n);
+    F64 one = F64::one(), z = F64::zero();
+    one.to_words(out_xyz); one.to_words(out_xyz + FQ::N); z.to_words(out_xyz + 2 * FQ::N);
+}
+
+// `count` MSMs that share the window size: sort + accumulate run one after the other (they fill the
+// chip on their own), the latency-bound recursive halving runs ONCE over all count*n_win windows, one
+// copy brings every partial sum to the host, and the host Horner tails run on separate threads.
+template <class FR, class FQ>
+int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, hipStream_t st) {
     const uint32_t M = 1u << (c - 1);
     const int log_m = c - 1;
     const int n_win = msm_num_windows(is_mont ? FR::BITS : 256, c);
     g_last_c = c; g_last_w = n_win; g_last_m = M;
     const size_t wm = (size_t)n_win * M;
+    uint64_t n_max = 0;
+    for (int p = 0; p < count; p++) n_max = std::max<uint64_t>(n_max, items[p].n);
     MZK_TRY(ws_acquire(st));
     MZK_TRY(g_ws.hist.reserve(wm * 4));
     MZK_TRY(g_ws.offs.reserve(wm * 4));
     MZK_TRY(g_ws.cursor.reserve(wm * 4));                       // bucket order by load
     // per-thread cap on a bucket's run: 8x the mean load, at least 256
-    const uint32_t cap = (uint32_t)std::max<unsigned long long>(256ull, 8ull * (n / M + 1));
-    const uint32_t desc_cap = (uint32_t)(n / cap + 1);
-    MZK_TRY(g_ws.long_desc.reserve((size_t)n_win * desc_cap * sizeof(LongDesc) + (size_t)n_win * 4));
-    MZK_TRY(g_ws.long_parts.reserve((size_t)n_win * desc_cap * 4 * FQ::N * 4));
-    LongDesc* desc = g_ws.long_desc.as<LongDesc>();
-    uint32_t* desc_count = reinterpret_cast<uint32_t*>(desc + (size_t)n_win * desc_cap);
-    uint32_t* parts = g_ws.long_parts.as<uint32_t>();
-    const unsigned long long dstride = (n + 7) & ~7ull;
-    MZK_TRY(g_ws.digits.reserve((size_t)n_win * dstride * 2));
-    MZK_TRY(g_ws.sorted.reserve((size_t)n_win * n * 4));
-    MZK_TRY(g_ws.buckets.reserve(wm * 4 * FQ::N * 4));
-    const int n_out = n_win * (log_m + 1);
+    const uint32_t cap_max = (uint32_t)std::max<unsigned long long>(256ull, 8ull * (n_max / M + 1));
+    const uint32_t desc_cap_max = (uint32_t)(n_max / 256 + 1);
+    MZK_TRY(g_ws.long_desc.reserve((size_t)n_win * desc_cap_max * sizeof(LongDesc) + (size_t)n_win * 4));
+    MZK_TRY(g_ws.long_parts.reserve((size_t)n_win * desc_cap_max * 4 * FQ::N * 4));
+    (void)cap_max;
+    const unsigned long long dstride_max = (n_max + 7) & ~7ull;
+    MZK_TRY(g_ws.digits.reserve((size_t)n_win * dstride_max * 2));
+    MZK_TRY(g_ws.sorted.reserve((size_t)n_win * n_max * 4));
+    MZK_TRY(g_ws.buckets.reserve((size_t)count * wm * 4 * FQ::N * 4));
+    const int n_out_one = n_win * (log_m + 1);
+    const int n_out = n_out_one * count;
     const size_t out_bytes = (size_t)n_out * 4 * FQ::N * 4;
     MZK_TRY(g_ws.collect.reserve(out_bytes));
     if (g_ws.h_collect_cap < out_bytes) {
@@ -82,62 +94,110 @@ int32_t msm_dev(const uint32_t* d_bases, const uint32_t* d_scalars, uint64_t n, 
     uint32_t* order = g_ws.cursor.as<uint32_t>();
     uint16_t* digits = g_ws.digits.as<uint16_t>();
     uint32_t* sorted = g_ws.sorted.as<uint32_t>();
-    uint32_t* buckets = g_ws.buckets.as<uint32_t>();
     uint32_t* collect = g_ws.collect.as<uint32_t>();
+    LongDesc* desc = g_ws.long_desc.as<LongDesc>();
+    uint32_t* parts = g_ws.long_parts.as<uint32_t>();
     {
         ProfScope total("msm_total", st);
-        const unsigned gs = (unsigned)((n + MSM_THREADS - 1) / MSM_THREADS);
         const unsigned n_ranges = M >> MSM_RANGE_LOG ? M >> MSM_RANGE_LOG : 1u;
-        {
-            ProfScope ps("msm_sort", st);
-            hipLaunchKernelGGL((msm_digits_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, st, d_scalars, n, is_mont, c, n_win, digits, dstride);
-            hipLaunchKernelGGL((msm_sort_kernel<false>), dim3(n_ranges, n_win), dim3(MSM_SORT_THREADS), 0, st, digits, n, dstride, M, hist, offs, sorted);
-            hipLaunchKernelGGL(msm_scan_kernel, dim3(n_win), dim3(1024), 0, st, hist, offs, M);
-            hipLaunchKernelGGL((msm_sort_kernel<true>), dim3(n_ranges, n_win), dim3(MSM_SORT_THREADS), 0, st, digits, n, dstride, M, hist, offs, sorted);
-            hipLaunchKernelGGL(msm_order_kernel, dim3(n_win), dim3(1024), 0, st, hist, order, M);
-        }
-        {
-            ProfScope ps("msm_accumulate", st);
-            hipLaunchKernelGGL((msm_accumulate_kernel<FQ>), dim3((unsigned)((wm + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
-                               d_bases, n, offs, hist, sorted, order, M, n_win, cap, buckets);
-        }
-        {
-            // over-long buckets (skewed scalars); no-ops for uniformly random scalars
-            ProfScope ps("msm_long", st);
-            hipLaunchKernelGGL(msm_long_find_kernel, dim3(n_win), dim3(1024), 0, st, hist, offs, M, cap, desc_cap, desc, desc_count);
-            hipLaunchKernelGGL((msm_long_chunk_kernel<FQ>), dim3((desc_cap + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, n_win), dim3(MSM_ACC_THREADS), 0, st,
-                               d_bases, n, sorted, desc, desc_count, desc_cap, parts);
-            hipLaunchKernelGGL((msm_long_combine_kernel<FQ>), dim3(n_win), dim3(1024), 0, st, desc, desc_count, desc_cap, M, parts, buckets);
+        for (int p = 0; p < count; p++) {
+            const uint64_t n = items[p].n;
+            const uint32_t* d_scalars = items[p].d_scalars;
+            const uint32_t* d_bases = items[p].d_bases;
+            uint32_t* buckets = g_ws.buckets.as<uint32_t>() + (size_t)p * wm * 4 * FQ::N;
+            const uint32_t cap = (uint32_t)std::max<unsigned long long>(256ull, 8ull * (n / M + 1));
+            const uint32_t desc_cap = (uint32_t)(n / cap + 1);
+            uint32_t* desc_count = reinterpret_cast<uint32_t*>(desc + (size_t)n_win * desc_cap);
+            const unsigned long long dstride = (n + 7) & ~7ull;
+            const unsigned gs = (unsigned)((n + MSM_THREADS - 1) / MSM_THREADS);
+            {
+                ProfScope ps("msm_sort", st);
+                hipLaunchKernelGGL((msm_digits_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, st, d_scalars, n, is_mont, c, n_win, digits, dstride);
+                hipLaunchKernelGGL((msm_sort_kernel<false>), dim3(n_ranges, n_win), dim3(MSM_SORT_THREADS), 0, st, digits, n, dstride, M, hist, offs, sorted);
+                hipLaunchKernelGGL(msm_scan_kernel, dim3(n_win), dim3(1024), 0, st, hist, offs, M);
+                hipLaunchKernelGGL((msm_sort_kernel<true>), dim3(n_ranges, n_win), dim3(MSM_SORT_THREADS), 0, st, digits, n, dstride, M, hist, offs, sorted);
+                hipLaunchKernelGGL(msm_order_kernel, dim3(n_win), dim3(1024), 0, st, hist, order, M);
+            }
+            {
+                ProfScope ps("msm_accumulate", st);
+                hipLaunchKernelGGL((msm_accumulate_kernel<FQ>), dim3((unsigned)((wm + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
+                                   d_bases, n, offs, hist, sorted, order, M, n_win, cap, buckets);
+            }
+            {
+                // over-long buckets (skewed scalars); no-ops for uniformly random scalars
+                ProfScope ps("msm_long", st);
+                hipLaunchKernelGGL(msm_long_find_kernel, dim3(n_win), dim3(1024), 0, st, hist, offs, M, cap, desc_cap, desc, desc_count);
+                hipLaunchKernelGGL((msm_long_chunk_kernel<FQ>), dim3((desc_cap + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, n_win), dim3(MSM_ACC_THREADS), 0, st,
+                                   d_bases, n, sorted, desc, desc_count, desc_cap, parts);
+                hipLaunchKernelGGL((msm_long_combine_kernel<FQ>), dim3(n_win), dim3(1024), 0, st, desc, desc_count, desc_cap, M, parts, buckets);
+            }
         }
         {
             ProfScope ps("msm_reduce", st);
+            uint32_t* buckets = g_ws.buckets.as<uint32_t>();
+            const int nw_all = n_win * count;                   // every (MSM, window) pair folds independently
             for (int lvl = 1; lvl <= log_m; lvl++) {
                 const uint32_t h = M >> lvl;
-                const size_t threads = (size_t)n_win * lvl * h;
+                const size_t threads = (size_t)nw_all * lvl * h;
                 hipLaunchKernelGGL((msm_fold_kernel<FQ>), dim3((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
-                                   buckets, M, h, lvl, n_win);
+                                   buckets, M, h, lvl, nw_all);
             }
-            hipLaunchKernelGGL((msm_collect_kernel<FQ>), dim3((n_out + 63) / 64), dim3(64), 0, st, buckets, M, log_m, n_win, collect);
+            hipLaunchKernelGGL((msm_collect_kernel<FQ>), dim3((n_out + 63) / 64), dim3(64), 0, st, buckets, M, log_m, nw_all, collect);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(g_ws.h_collect, collect, out_bytes, hipMemcpyDeviceToHost, st));
     }
     MZK_TRY(ws_release(st));
     HIP_TRY(hipStreamSynchronize(st));
-    host_horner<FQ>(reinterpret_cast<const uint32_t*>(g_ws.h_collect), n_win, c, out_xyz);
+    const uint32_t* h = reinterpret_cast<const uint32_t*>(g_ws.h_collect);
+    const size_t per = (size_t)n_out_one * 4 * FQ::N;
+    if (count == 1) {
+        host_horner<FQ>(h, n_win, c, items[0].out_xyz);
+    } else {
+        std::vector<std::thread> th;
+        for (int p = 0; p < count; p++) th.emplace_back([=] { host_horner<FQ>(h + p * per, n_win, c, items[p].out_xyz); });
+        for (auto& t : th) t.join();
+    }
+    return MZK_OK;
+}
+
+template <class FR, class FQ>
+int32_t msm_batch_dev(const MsmItem* items, int count, int is_mont, hipStream_t st) {
+    // runs of consecutive non-empty MSMs with one window size share a fused reduction
+    int i = 0;
+    while (i < count) {
+        if (items[i].n == 0) { write_infinity<FQ>(items[i].out_xyz); i++; continue; }
+        if (items[i].n >= (1ull << 31)) { set_error("MSM size must be < 2^31"); return MZK_ERR_INVALID_ARG; }
+        const int c = msm_choose_window(items[i].n);
+        int j = i + 1;
+        while (j < count && j - i < 16 && items[j].n != 0 && items[j].n < (1ull << 31) && msm_choose_window(items[j].n) == c) j++;
+        MZK_TRY((msm_group_dev<FR, FQ>(items + i, j - i, c, is_mont, st)));
+        i = j;
+    }
     return MZK_OK;
 }
 
 }  // namespace
 
 int32_t msm_dispatch(const Srs& s, uint64_t base_offset, const uint32_t* d_scalars, uint64_t n, int is_mont, uint32_t* out, hipStream_t st) {
-    if (base_offset > s.n || n > s.n - base_offset) {
-        set_error("MSM longer than the registered SRS (poly degree larger than allowed)");
-        return MZK_ERR_INVALID_ARG;
+    const uint32_t* sc[1] = {d_scalars};
+    return msm_batch_dispatch(s, 1, sc, &n, &base_offset, is_mont, out, st);
+}
+
+int32_t msm_batch_dispatch(const Srs& s, uint32_t n_polys, const uint32_t* const* d_scalars, const uint64_t* lens, const uint64_t* base_offsets,
+                           int is_mont, uint32_t* out_xyz, hipStream_t st) {
+    const int fw = fq_words(s.curve);
+    std::vector<MsmItem> items(n_polys);
+    for (uint32_t i = 0; i < n_polys; i++) {
+        const uint64_t off = base_offsets ? base_offsets[i] : 0;
+        if (off > s.n || lens[i] > s.n - off) {
+            set_error("MSM longer than the registered SRS (poly degree larger than allowed)");
+            return MZK_ERR_INVALID_ARG;
+        }
+        items[i] = MsmItem{s.d_xy + off * 2 * fw, d_scalars[i], lens[i], out_xyz + (size_t)i * 3 * fw};
     }
-    const uint32_t* bases = s.d_xy + base_offset * 2 * fq_words(s.curve);
-    if (s.curve == MZK_CURVE_BLS12_381) return msm_dev<BlsFr, BlsFq>(bases, d_scalars, n, is_mont, out, st);
-    return msm_dev<BnFr, BnFq>(bases, d_scalars, n, is_mont, out, st);
+    if (s.curve == MZK_CURVE_BLS12_381) return msm_batch_dev<BlsFr, BlsFq>(items.data(), (int)n_polys, is_mont, st);
+    return msm_batch_dev<BnFr, BnFq>(items.data(), (int)n_polys, is_mont, st);
 }
 
 namespace {

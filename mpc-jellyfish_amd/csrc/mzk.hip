@@ -2,6 +2,7 @@
 // One process drives one GPU; entry points are serialised on a lock and enqueue on one stream.
 #include <map>
 #include <mutex>
+#include <vector>
 
 #include "internal.hpp"
 
@@ -251,6 +252,17 @@ int32_t mzk_msm(uint64_t srs_handle, uint64_t base_offset, const uint64_t* scala
     return msm_host_locked(it->second, base_offset, scalars, n, scalars_are_mont, out_xyz_mont);
 }
 
+int32_t mzk_msm_batch_dev(uint64_t srs_handle, uint32_t n_polys, const void* const* d_scalars, const uint64_t* lens, const uint64_t* base_offsets,
+                          int32_t scalars_are_mont, uint64_t* out_xyz_mont, void* stream) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    auto it = g_srs.find(srs_handle);
+    if (it == g_srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+    if (n_polys && (!d_scalars || !lens || !out_xyz_mont)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    return msm_batch_dispatch(it->second, n_polys, reinterpret_cast<const uint32_t* const*>(d_scalars), lens, base_offsets, scalars_are_mont != 0,
+                              reinterpret_cast<uint32_t*>(out_xyz_mont), (hipStream_t)stream);
+}
+
 int32_t mzk_msm_batch(uint64_t srs_handle, uint32_t n_polys, const uint64_t* const* scalars, const uint64_t* lens, const uint64_t* base_offsets,
                       int32_t scalars_are_mont, uint64_t* out_xyz_mont) {
     std::lock_guard<std::mutex> lk(g_lock);
@@ -258,10 +270,24 @@ int32_t mzk_msm_batch(uint64_t srs_handle, uint32_t n_polys, const uint64_t* con
     auto it = g_srs.find(srs_handle);
     if (it == g_srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
     if (n_polys && (!scalars || !lens || !out_xyz_mont)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
-    const int pw = 3 * fq_words(it->second.curve) / 2;   // u64 words per Jacobian point
-    for (uint32_t i = 0; i < n_polys; i++)
-        MZK_TRY(msm_host_locked(it->second, base_offsets ? base_offsets[i] : 0, scalars[i], lens[i], scalars_are_mont, out_xyz_mont + (size_t)i * pw));
-    return MZK_OK;
+    // one upload slab, then the fused batch
+    hipStream_t st = nullptr;
+    uint64_t total = 0;
+    for (uint32_t i = 0; i < n_polys; i++) {
+        if (lens[i] && !scalars[i]) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+        total += lens[i];
+    }
+    MZK_TRY(ws_acquire(st));
+    MZK_TRY(g_ws.scalars.reserve((total ? total : 1) * 32));
+    std::vector<const uint32_t*> dptr(n_polys);
+    uint64_t off = 0;
+    for (uint32_t i = 0; i < n_polys; i++) {
+        dptr[i] = g_ws.scalars.as<uint32_t>() + off * 8;
+        if (lens[i]) HIP_TRY(hipMemcpyAsync(const_cast<uint32_t*>(dptr[i]), scalars[i], lens[i] * 32, hipMemcpyHostToDevice, st));
+        off += lens[i];
+    }
+    MZK_TRY(ws_release(st));
+    return msm_batch_dispatch(it->second, n_polys, dptr.data(), lens, base_offsets, scalars_are_mont != 0, reinterpret_cast<uint32_t*>(out_xyz_mont), st);
 }
 
 int32_t mzk_msm_affine(uint64_t srs_handle, uint64_t base_offset, const uint64_t* scalars, uint64_t n, int32_t scalars_are_mont, uint64_t* out_xy_mont) {
@@ -283,6 +309,13 @@ int32_t mzk_msm_affine(uint64_t srs_handle, uint64_t base_offset, const uint64_t
 int32_t mzk_g1_sum_jacobian(int32_t curve_id, const uint64_t* xyz_mont, uint64_t n, uint64_t* out_xyz_mont) {
     if ((curve_id != 0 && curve_id != 1) || !out_xyz_mont || (!xyz_mont && n)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
     jac_sum_host_dispatch(curve_id, xyz_mont, n, out_xyz_mont);
+    return MZK_OK;
+}
+
+int32_t mzk_g1_jacobian_to_affine(int32_t curve_id, const uint64_t* xyz_mont, uint64_t n, uint64_t* out_xy_mont) {
+    if ((curve_id != 0 && curve_id != 1) || ((!xyz_mont || !out_xy_mont) && n)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
+    const int L = fq_words(curve_id) / 2;
+    for (uint64_t i = 0; i < n; i++) jac_to_affine_host_dispatch(curve_id, xyz_mont + i * 3 * L, out_xy_mont + i * 2 * L);
     return MZK_OK;
 }
 

@@ -141,5 +141,67 @@ class UnivariateKzgPCS:
 
     @staticmethod
     def batch_commit(prover_param: UnivariateProverParam, polys) -> list[Commitment]:
-        """mod.rs:119-131."""
-        return [UnivariateKzgPCS.commit(prover_param, p) for p in polys]
+        """mod.rs:119-131.  The reference maps `commit` over the polynomials on Rayon workers; here
+        the MSMs run back to back on the GPU and share one bucket-reduction phase (mzk_msm_batch)."""
+        pp = prover_param
+        bodies, offs = [], []
+        for poly in polys:
+            coeffs = np.ascontiguousarray(poly, dtype=np.uint64).reshape(-1, 4)
+            degree, lead = _degree_and_leading_zeros(coeffs)
+            if degree > pp.length:
+                raise PCSError(f"InvalidParameters: poly degree {degree} is larger than allowed {pp.length}")
+            body = coeffs[lead:degree + 1] if lead <= degree else coeffs[:0]
+            if lead + body.shape[0] > pp.length:
+                body = body[:pp.length - lead]
+            bodies.append(np.ascontiguousarray(body))
+            offs.append(pp.offset + lead)
+        jac = msm_bigint_batch(pp, bodies, offs, scalars_are_mont=True, absolute_offsets=True)
+        xy = jacobian_to_affine(pp.curve, jac)
+        return [Commitment(pp.curve, xy[i]) for i in range(len(bodies))]
+
+
+def jacobian_to_affine(curve, xyz: np.ndarray) -> np.ndarray:
+    """(n,3,fq_limbs) Jacobian -> (n,2,fq_limbs) affine on the host (`into_affine`, mod.rs:111)."""
+    c = _curve(curve)
+    a = np.ascontiguousarray(xyz, dtype=np.uint64).reshape(-1, 3, c.fq_limbs)
+    out = np.empty((a.shape[0], 2, c.fq_limbs), dtype=np.uint64)
+    _lib.check(_lib.load().mzk_g1_jacobian_to_affine(c.curve_id, a.ctypes.data_as(C.c_void_p), a.shape[0], out.ctypes.data_as(C.c_void_p)),
+               "mzk_g1_jacobian_to_affine")
+    return out
+
+
+def msm_bigint_batch(pp: UnivariateProverParam, scalar_sets, base_offsets=None, scalars_are_mont: bool = False,
+                     absolute_offsets: bool = False) -> np.ndarray:
+    """Several MSMs over one SRS in one call -> (k,3,fq_limbs) Jacobian.  scalar_sets: host (n_i,4) uint64
+    arrays, or int64 CUDA tensors (all of one kind)."""
+    L = _lib.ensure_init()
+    k = len(scalar_sets)
+    out = np.empty((k, 3, pp.curve.fq_limbs), dtype=np.uint64)
+    if k == 0:
+        return out
+    offs = [0] * k if base_offsets is None else list(base_offsets)
+    if not absolute_offsets:
+        offs = [pp.offset + o for o in offs]
+    limit = pp.offset + pp.length
+    lens = (C.c_uint64 * k)()
+    offa = (C.c_uint64 * k)(*offs)
+    ptrs = (C.c_void_p * k)()
+    if _is_torch(scalar_sets[0]):
+        import torch
+        for i, t in enumerate(scalar_sets):
+            if t.dtype != torch.int64 or not t.is_cuda or not t.is_contiguous() or t.shape[-1] != 4:
+                raise ValueError("expected contiguous int64 CUDA tensors of shape (n, 4)")
+            lens[i] = min(t.shape[0], max(0, limit - offs[i]))
+            ptrs[i] = t.data_ptr()
+        st = torch.cuda.current_stream(scalar_sets[0].device).cuda_stream
+        _lib.check(L.mzk_msm_batch_dev(pp.handle, k, ptrs, lens, offa, int(scalars_are_mont), out.ctypes.data_as(C.c_void_p), st),
+                   "mzk_msm_batch_dev")
+        return out
+    keep = []
+    for i, s in enumerate(scalar_sets):
+        a = np.ascontiguousarray(s, dtype=np.uint64).reshape(-1, 4)
+        keep.append(a)
+        lens[i] = min(a.shape[0], max(0, limit - offs[i]))
+        ptrs[i] = a.ctypes.data if a.size else None
+    _lib.check(L.mzk_msm_batch(pp.handle, k, ptrs, lens, offa, int(scalars_are_mont), out.ctypes.data_as(C.c_void_p)), "mzk_msm_batch")
+    return out

@@ -31,7 +31,9 @@ _SIGS = {
     "mzk_msm": [C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p],
     "mzk_msm_dev": [C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p, C.c_void_p],
     "mzk_msm_batch": [C.c_uint64, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32, C.c_void_p],
+    "mzk_msm_batch_dev": [C.c_uint64, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.c_int32, C.c_void_p, C.c_void_p],
     "mzk_msm_affine": [C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p],
+    "mzk_g1_jacobian_to_affine": [C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p],
     "mzk_g1_sum_jacobian": [C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p],
     "mzk_ntt": [C.c_int32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_int32, C.c_void_p],
     "mzk_ntt_batch": [C.c_int32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_uint32, C.c_int32, C.c_void_p],

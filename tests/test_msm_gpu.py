@@ -168,3 +168,27 @@ def test_msm_full_size_trapdoor(gpu, mj, cref):
     jac2 = mj.msm_bigint(pp, doubled, scalars_are_mont=True)
     assert np.array_equal(cref.jac_to_affine(curve_id, jac2)[0], cref.g1_mul_gen(curve_id, 2 * k % c.r))
     pp.release()
+
+
+def test_msm_batch_fused(gpu, mj, cref):
+    """mzk_msm_batch / mzk_msm_batch_dev: MSMs of different lengths (two window sizes, an empty one)
+    in one call equal the single calls and the oracle."""
+    import torch
+    curve_id = 0
+    c = mj.params.CURVES[curve_id]
+    nmax = (1 << 13) + 3
+    bases = cref.g1_arith_bases(curve_id, 777, 5, nmax)
+    pp = mj.UnivariateProverParam.from_affine(curve_id, bases)
+    lens = [nmax, 1 << 13, 0, 100, (1 << 13) + 2, 7, 1 << 12]
+    offs = [0, 3, 0, 50, 1, 0, 9]
+    sets = [mj.params.random_fr_mont(c, n, seed=40 + i) for i, n in enumerate(lens)]
+    jac = mj.msm_bigint_batch(pp, sets, offs, scalars_are_mont=True)
+    aff = mj.jacobian_to_affine(c, jac)
+    for i, (n, o) in enumerate(zip(lens, offs)):
+        want = cref.jac_to_affine(curve_id, cref.msm(curve_id, bases[o:o + n], sets[i], scalars_are_mont=True, threads=8))[0]
+        assert np.array_equal(aff[i], want), i
+        assert np.array_equal(cref.jac_to_affine(curve_id, jac[i])[0], want), i
+    dev_sets = [torch.from_numpy(s.view(np.int64)).cuda() for s in sets]
+    jac2 = mj.msm_bigint_batch(pp, dev_sets, offs, scalars_are_mont=True)
+    assert np.array_equal(mj.jacobian_to_affine(c, jac2), aff)
+    pp.release()
