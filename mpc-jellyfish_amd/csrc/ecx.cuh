@@ -1,0 +1,179 @@
+// ecx.cuh -- G1 bucket arithmetic on the reduced-radix field (fx.cuh) for curves whose base field
+// leaves plenty of head-room in 29-bit limbs (BLS12-381: 14 x 29 = 406 bits for a 381-bit p, so any
+// product of values below 2^12 p comes out below 1.5 p and value bounds never bind; only the 32-bit
+// limb capacity has to be tracked).  Same formulas as ec.cuh (EFD madd-2008-s / add-2008-s /
+// dbl-2008-s-1 / mdbl-2008-s-1), same exceptional cases.
+//
+// Limb classes:  M = every limb < 2^29 (an fx_mul result, or a canonical value)
+//                N = every limb < 2^29 + 8 (after fx_norm)
+// Invariant of an accumulator: X, Y in N with value < 64p; ZZ, ZZZ in M; infinity <=> ZZ == 0 (all limbs).
+#pragma once
+#include "ec.cuh"
+#include "fx.cuh"
+
+namespace mzk {
+
+template <class X>
+struct AffineX {               // x, y canonical in R'-form; (0,0) = infinity
+    Fx<X> x, y;
+    MZK_HD bool is_inf() const {
+        uint32_t a = 0;
+#pragma unroll
+        for (int i = 0; i < X::XN; i++) a |= x.l[i] | y.l[i];
+        return a == 0;
+    }
+};
+
+template <class X>
+struct XYZZX {
+    Fx<X> x, y, zz, zzz;
+    MZK_HD bool is_inf() const {
+        uint32_t a = 0;
+#pragma unroll
+        for (int i = 0; i < X::XN; i++) a |= zz.l[i];
+        return a == 0;
+    }
+    MZK_HD static XYZZX inf() {
+        XYZZX r;
+        r.x = Fx<X>::one(); r.y = Fx<X>::one(); r.zz = Fx<X>::zero(); r.zzz = Fx<X>::zero();
+        return r;
+    }
+    MZK_HD static XYZZX from_affine(const AffineX<X>& p) {
+        if (p.is_inf()) return inf();
+        XYZZX r;
+        r.x = p.x; r.y = p.y; r.zz = Fx<X>::one(); r.zzz = Fx<X>::one();
+        return r;
+    }
+};
+
+// -y for a canonical y: 2p - y, limbs < 2^30 (usable directly as a multiplicand)
+template <class X>
+MZK_HD Fx<X> fx_neg_m(const Fx<X>& y) {
+    Fx<X> r;
+#pragma unroll
+    for (int i = 0; i < X::XN; i++) r.l[i] = X::XSUB2[i] - y.l[i];
+    return r;
+}
+
+// 2*P for affine P (mdbl-2008-s-1); cold path
+template <class X>
+MZK_HD XYZZX<X> xyzzx_dbl_affine(const AffineX<X>& p) {
+    XYZZX<X> r;
+    const Fx<X> u = fx_norm(fx_add(p.y, p.y));                              // 2y, N
+    const Fx<X> v = fx_sqr(u);                                              // M
+    const Fx<X> w = fx_mul(u, v);                                           // M
+    const Fx<X> s = fx_mul(p.x, v);                                         // M
+    const Fx<X> x2 = fx_sqr(p.x);                                           // M
+    const Fx<X> m = fx_norm(fx_add(fx_add(x2, x2), x2));                    // 3x^2, N, < 6p
+    const Fx<X> mm = fx_sqr(m);                                             // M
+    r.x = fx_norm(fx_sub8(mm, fx_add(s, s)));                               // M + 8p - 2S: N, < 10p
+    const Fx<X> d = fx_norm(fx_sub_pad<X>(s, r.x, X::XSUB64));              // S - X3, N
+    r.y = fx_norm(fx_sub2(fx_mul(m, d), fx_mul(w, p.y)));                   // N, < 4p
+    r.zz = v;
+    r.zzz = w;
+    return r;
+}
+
+// 2*P (dbl-2008-s-1); cold path
+template <class X>
+MZK_HD XYZZX<X> xyzzx_dbl(const XYZZX<X>& p) {
+    if (p.is_inf()) return p;
+    XYZZX<X> r;
+    const Fx<X> u = fx_norm(fx_add(p.y, p.y));                              // N
+    const Fx<X> v = fx_sqr(u);
+    const Fx<X> w = fx_mul(u, v);
+    const Fx<X> s = fx_mul(p.x, v);
+    const Fx<X> x2 = fx_sqr(p.x);
+    const Fx<X> m = fx_norm(fx_add(fx_add(x2, x2), x2));
+    const Fx<X> mm = fx_sqr(m);
+    r.x = fx_norm(fx_sub8(mm, fx_add(s, s)));
+    const Fx<X> d = fx_norm(fx_sub_pad<X>(s, r.x, X::XSUB64));
+    r.y = fx_norm(fx_sub2(fx_mul(m, d), fx_mul(w, p.y)));
+    r.zz = fx_mul(v, p.zz);
+    r.zzz = fx_mul(w, p.zzz);
+    return r;
+}
+
+// P +- Q, Q affine and canonical; `negate` adds -Q.  10 products, 5 fx_norm.
+template <class X>
+MZK_HD XYZZX<X> xyzzx_madd(const XYZZX<X>& p, const AffineX<X>& q, bool negate) {
+    if (q.is_inf()) return p;
+    const Fx<X> qy = negate ? fx_neg_m(q.y) : q.y;                          // limbs < 2^30
+    if (p.is_inf()) {
+        XYZZX<X> r;
+        r.x = q.x; r.y = fx_norm(qy); r.zz = Fx<X>::one(); r.zzz = Fx<X>::one();
+        return r;
+    }
+    const Fx<X> u2 = fx_mul(q.x, p.zz);                                     // M
+    const Fx<X> s2 = fx_mul(qy, p.zzz);                                     // M
+    const Fx<X> pp_ = fx_norm(fx_sub_pad<X>(u2, p.x, X::XSUB64));           // U2 - X1, N
+    const Fx<X> rr_ = fx_norm(fx_sub_pad<X>(s2, p.y, X::XSUB64));           // S2 - Y1, N
+    const Fx<X> pp = fx_sqr(pp_);                                           // M
+    const Fx<X> rr2 = fx_sqr(rr_);                                          // M
+    if (fx_is_zero_m(pp)) {                                                 // U2 == X1 (mod p)
+        if (fx_is_zero_m(rr2)) {                                            // same point: double it
+            AffineX<X> qq;
+            qq.x = q.x;
+            qq.y = fx_norm(qy);
+            return xyzzx_dbl_affine(qq);
+        }
+        return XYZZX<X>::inf();                                             // P = -Q
+    }
+    XYZZX<X> r;
+    const Fx<X> ppp = fx_mul(pp_, pp);                                      // M
+    const Fx<X> qv = fx_mul(p.x, pp);                                       // M
+    r.x = fx_norm(fx_sub32(rr2, fx_add(ppp, fx_add(qv, qv))));              // R^2 - PPP - 2Q: N, < 34p
+    const Fx<X> d = fx_norm(fx_sub_pad<X>(qv, r.x, X::XSUB64));             // Q - X3, N
+    r.y = fx_norm(fx_sub2(fx_mul(rr_, d), fx_mul(p.y, ppp)));               // N, < 4p
+    r.zz = fx_mul(p.zz, pp);                                                // M
+    r.zzz = fx_mul(p.zzz, ppp);                                             // M
+    return r;
+}
+
+// P + Q, both accumulators.  14 products.
+template <class X>
+MZK_HD XYZZX<X> xyzzx_add(const XYZZX<X>& p, const XYZZX<X>& q) {
+    if (q.is_inf()) return p;
+    if (p.is_inf()) return q;
+    const Fx<X> u1 = fx_mul(p.x, q.zz), u2 = fx_mul(q.x, p.zz);             // M
+    const Fx<X> s1 = fx_mul(p.y, q.zzz), s2 = fx_mul(q.y, p.zzz);           // M
+    const Fx<X> pp_ = fx_norm(fx_sub2(u2, u1));                             // N, < 4p
+    const Fx<X> rr_ = fx_norm(fx_sub2(s2, s1));                             // N
+    const Fx<X> pp = fx_sqr(pp_);
+    const Fx<X> rr2 = fx_sqr(rr_);
+    if (fx_is_zero_m(pp)) {
+        if (fx_is_zero_m(rr2)) return xyzzx_dbl(p);
+        return XYZZX<X>::inf();
+    }
+    XYZZX<X> r;
+    const Fx<X> ppp = fx_mul(pp_, pp);
+    const Fx<X> qv = fx_mul(u1, pp);
+    r.x = fx_norm(fx_sub32(rr2, fx_add(ppp, fx_add(qv, qv))));
+    const Fx<X> d = fx_norm(fx_sub_pad<X>(qv, r.x, X::XSUB64));
+    r.y = fx_norm(fx_sub2(fx_mul(rr_, d), fx_mul(s1, ppp)));
+    r.zz = fx_mul(fx_mul(p.zz, q.zz), pp);
+    r.zzz = fx_mul(fx_mul(p.zzz, q.zzz), ppp);
+    return r;
+}
+
+// boundary <-> internal
+template <class X>
+MZK_HD Fx<X> fx_from_boundary(const Fp<X>& a) {                // x*R (packed) -> x*R' canonical
+    return fx_canonical(fx_mul(fx_unpack<X>(a.l), Fx<X>::from_const(X::XTO)));
+}
+template <class X>
+MZK_HD Fp<X> fx_to_boundary(const Fx<X>& a) {                  // lazy x*R' (limbs N) -> x*R canonical, packed
+    Fp<X> r;
+    fx_pack<X>(r.l, fx_canonical(fx_mul(a, Fx<X>::from_const(X::XFROM))));
+    return r;
+}
+template <class X>
+MZK_HD XYZZ<Fp<X>> xyzzx_to_boundary(const XYZZX<X>& p) {
+    XYZZ<Fp<X>> r;
+    if (p.is_inf()) return XYZZ<Fp<X>>::inf();
+    r.x = fx_to_boundary<X>(p.x); r.y = fx_to_boundary<X>(p.y);
+    r.zz = fx_to_boundary<X>(p.zz); r.zzz = fx_to_boundary<X>(p.zzz);
+    return r;
+}
+
+}  // namespace mzk

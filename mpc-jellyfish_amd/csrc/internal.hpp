@@ -66,7 +66,8 @@ extern uint32_t g_last_c, g_last_w, g_last_m;
 struct Srs {
     int curve;
     uint64_t n;
-    uint32_t* d_xy;   // n * 2 * fq words
+    uint32_t* d_xy;   // n * 2 * fq words, boundary form (what mzk_srs_download returns)
+    uint32_t* d_int;  // internal reduced-radix table used by the MSM (BLS12-381), else nullptr
 };
 inline int fq_words(int curve) { return curve == MZK_CURVE_BLS12_381 ? 12 : 8; }
 
@@ -78,6 +79,7 @@ void ntt_release_plans();
 int32_t msm_dispatch(const Srs& s, uint64_t base_offset, const uint32_t* d_scalars, uint64_t n, int is_mont, uint32_t* out, hipStream_t st);
 int32_t msm_batch_dispatch(const Srs& s, uint32_t n_polys, const uint32_t* const* d_scalars, const uint64_t* lens, const uint64_t* base_offsets,
                            int is_mont, uint32_t* out_xyz, hipStream_t st);
+int32_t srs_build_internal(Srs& s, hipStream_t st);
 int32_t srs_generate_dispatch(int curve, const uint32_t* beta_canon, uint64_t n, uint32_t* d_out);
 void jac_to_affine_host_dispatch(int curve, const uint64_t* xyz, uint64_t* xy);
 void jac_sum_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uint64_t* out);

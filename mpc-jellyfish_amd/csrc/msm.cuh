@@ -19,6 +19,7 @@
 #include <hip/hip_runtime.h>
 
 #include "ec.cuh"
+#include "ecx.cuh"
 
 namespace mzk {
 
@@ -206,8 +207,103 @@ __device__ __forceinline__ void store_xyzz(uint32_t* __restrict__ buf, unsigned 
     store_fp<FQ>(dst + 3 * FQ::N, p.zzz);
 }
 
-// one thread per (window, bucket): sum of +-P over the bucket's sorted run
+// ---- EC back ends -----------------------------------------------------------------------------------
+// The bucket kernels are written once against a small policy: EcFp keeps points in the boundary's
+// 32-bit-limb Montgomery form (BN254); EcFx keeps them in the reduced-radix form of fx.cuh / ecx.cuh
+// (BLS12-381: one v_mad_u64_u32 per partial product and carry-free additions), with the SRS
+// converted once at registration and results converted back when they are collected.
 template <class FQ>
+struct EcFp {
+    using Field = FQ;
+    using Aff = Affine<Fp<FQ>>;
+    using Pt = XYZZ<Fp<FQ>>;
+    static constexpr int AFF_WORDS = 2 * FQ::N, PT_WORDS = 4 * FQ::N;
+    static __device__ __forceinline__ Aff load_aff(const uint32_t* __restrict__ bases, unsigned long long idx) { return load_affine<FQ>(bases, idx); }
+    static __device__ __forceinline__ Pt load_pt(const uint32_t* __restrict__ buf, unsigned long long idx) { return load_xyzz<FQ>(buf, idx); }
+    static __device__ __forceinline__ void store_pt(uint32_t* __restrict__ buf, unsigned long long idx, const Pt& p) { store_xyzz<FQ>(buf, idx, p); }
+    static __device__ __forceinline__ Pt inf() { return Pt::inf(); }
+    static __device__ __forceinline__ Pt madd(const Pt& a, Aff q, bool negate) {
+        if (negate) q.y = neg(q.y);
+        return xyzz_madd(a, q);
+    }
+    static __device__ __forceinline__ Pt add(const Pt& a, const Pt& b) { return xyzz_add(a, b); }
+    static __device__ __forceinline__ XYZZ<Fp<FQ>> to_boundary(const Pt& p) { return p; }
+};
+
+template <class X>
+__device__ __forceinline__ void load_words(uint32_t* dst, const uint32_t* __restrict__ src, int n_words) {
+    // n_words is a multiple of 4 and src is 16-byte aligned
+    for (int i = 0; i < n_words / 4; i++) {
+        const uint4 v = reinterpret_cast<const uint4*>(src)[i];
+        dst[4 * i] = v.x; dst[4 * i + 1] = v.y; dst[4 * i + 2] = v.z; dst[4 * i + 3] = v.w;
+    }
+}
+
+template <class X>
+struct EcFx {
+    using Field = X;
+    using Aff = AffineX<X>;
+    using Pt = XYZZX<X>;
+    static constexpr int AFF_WORDS = 2 * X::XN, PT_WORDS = 4 * X::XN;      // 28 / 56 words: 16-byte multiples
+    static_assert((2 * X::XN) % 4 == 0, "affine point must be a whole number of 16-byte words");
+    static __device__ __forceinline__ Aff load_aff(const uint32_t* __restrict__ bases, unsigned long long idx) {
+        uint32_t w[AFF_WORDS];
+        const uint4* src = reinterpret_cast<const uint4*>(bases + idx * AFF_WORDS);
+#pragma unroll
+        for (int i = 0; i < AFF_WORDS / 4; i++) {
+            const uint4 v = src[i];
+            w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+        }
+        Aff p;
+#pragma unroll
+        for (int i = 0; i < X::XN; i++) { p.x.l[i] = w[i]; p.y.l[i] = w[X::XN + i]; }
+        return p;
+    }
+    static __device__ __forceinline__ Pt load_pt(const uint32_t* __restrict__ buf, unsigned long long idx) {
+        uint32_t w[PT_WORDS];
+        const uint4* src = reinterpret_cast<const uint4*>(buf + idx * PT_WORDS);
+#pragma unroll
+        for (int i = 0; i < PT_WORDS / 4; i++) {
+            const uint4 v = src[i];
+            w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+        }
+        Pt p;
+#pragma unroll
+        for (int i = 0; i < X::XN; i++) {
+            p.x.l[i] = w[i]; p.y.l[i] = w[X::XN + i]; p.zz.l[i] = w[2 * X::XN + i]; p.zzz.l[i] = w[3 * X::XN + i];
+        }
+        return p;
+    }
+    static __device__ __forceinline__ void store_pt(uint32_t* __restrict__ buf, unsigned long long idx, const Pt& p) {
+        uint32_t w[PT_WORDS];
+#pragma unroll
+        for (int i = 0; i < X::XN; i++) {
+            w[i] = p.x.l[i]; w[X::XN + i] = p.y.l[i]; w[2 * X::XN + i] = p.zz.l[i]; w[3 * X::XN + i] = p.zzz.l[i];
+        }
+        uint4* dst = reinterpret_cast<uint4*>(buf + idx * PT_WORDS);
+#pragma unroll
+        for (int i = 0; i < PT_WORDS / 4; i++) dst[i] = make_uint4(w[4 * i], w[4 * i + 1], w[4 * i + 2], w[4 * i + 3]);
+    }
+    static __device__ __forceinline__ Pt inf() { return Pt::inf(); }
+    static __device__ __forceinline__ Pt madd(const Pt& a, const Aff& q, bool negate) { return xyzzx_madd(a, q, negate); }
+    static __device__ __forceinline__ Pt add(const Pt& a, const Pt& b) { return xyzzx_add(a, b); }
+    static __device__ __forceinline__ XYZZ<Fp<X>> to_boundary(const Pt& p) { return xyzzx_to_boundary(p); }
+};
+
+// boundary SRS (packed x||y, R-form) -> internal affine table of EcFx (x||y, 29-bit limbs, R'-form)
+template <class X>
+__global__ __launch_bounds__(MSM_THREADS) void srs_to_internal_kernel(const uint32_t* __restrict__ xy, unsigned long long n, uint32_t* __restrict__ out) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * MSM_THREADS + threadIdx.x;
+    if (i >= n) return;
+    const Fp<X> x = load_fp<X>(xy + i * 2 * X::N), y = load_fp<X>(xy + i * 2 * X::N + X::N);
+    const Fx<X> fx = fx_from_boundary<X>(x), fy = fx_from_boundary<X>(y);
+    uint32_t* dst = out + i * 2 * X::XN;
+#pragma unroll
+    for (int k = 0; k < X::XN; k++) { dst[k] = fx.l[k]; dst[X::XN + k] = fy.l[k]; }
+}
+
+// one thread per (window, bucket): sum of +-P over the bucket's sorted run
+template <class EC>
 __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(const uint32_t* __restrict__ bases, unsigned long long n,
                                                                           const uint32_t* __restrict__ offs, const uint32_t* __restrict__ hist,
                                                                           const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ order,
@@ -219,21 +315,20 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(const u
     const uint32_t start = offs[t];
     const uint32_t cnt = min(hist[t], cap);                    // the rest of an over-long bucket: msm_long_* kernels
     const uint32_t* list = sorted + w * n + start;
-    XYZZ<Fp<FQ>> acc = XYZZ<Fp<FQ>>::inf();
+    typename EC::Pt acc = EC::inf();
     if (cnt) {
         // software pipeline: the gather of point k+1 is in flight while point k is being added
         uint32_t e = list[0];
-        Affine<Fp<FQ>> p = load_affine<FQ>(bases, e & 0x7fffffffu);
+        typename EC::Aff p = EC::load_aff(bases, e & 0x7fffffffu);
         for (uint32_t k = 0; k < cnt; k++) {
             const uint32_t e_next = list[k + 1 < cnt ? k + 1 : k];
-            Affine<Fp<FQ>> p_next = load_affine<FQ>(bases, e_next & 0x7fffffffu);
-            if (e >> 31) p.y = neg(p.y);
-            acc = xyzz_madd(acc, p);
+            typename EC::Aff p_next = EC::load_aff(bases, e_next & 0x7fffffffu);
+            acc = EC::madd(acc, p, (e >> 31) != 0);
             p = p_next;
             e = e_next;
         }
     }
-    store_xyzz<FQ>(buckets, t, acc);
+    EC::store_pt(buckets, t, acc);
 }
 
 // ---- over-long buckets (skewed scalars) ------------------------------------------------------------
@@ -286,7 +381,7 @@ __global__ __launch_bounds__(1024) void msm_long_find_kernel(const uint32_t* __r
 }
 
 // one thread per chunk descriptor
-template <class FQ>
+template <class EC>
 __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_long_chunk_kernel(const uint32_t* __restrict__ bases, unsigned long long n,
                                                                           const uint32_t* __restrict__ sorted, const LongDesc* __restrict__ desc,
                                                                           const uint32_t* __restrict__ desc_count, uint32_t desc_cap,
@@ -296,20 +391,18 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_long_chunk_kernel(const u
     if (i >= desc_count[w]) return;
     const LongDesc d = desc[(size_t)w * desc_cap + i];
     const uint32_t* list = sorted + (size_t)w * n + d.start;
-    XYZZ<Fp<FQ>> acc = XYZZ<Fp<FQ>>::inf();
+    typename EC::Pt acc = EC::inf();
     for (uint32_t k = 0; k < d.len; k++) {
         const uint32_t e = list[k];
-        Affine<Fp<FQ>> p = load_affine<FQ>(bases, e & 0x7fffffffu);
-        if (e >> 31) p.y = neg(p.y);
-        acc = xyzz_madd(acc, p);
+        acc = EC::madd(acc, EC::load_aff(bases, e & 0x7fffffffu), (e >> 31) != 0);
     }
-    store_xyzz<FQ>(parts, (size_t)w * desc_cap + i, acc);
+    EC::store_pt(parts, (size_t)w * desc_cap + i, acc);
 }
 
 // one 1024-thread workgroup per window: pairwise tree over each bucket's run of chunk sums, then
 // bucket += run total.  Chunk sums live in global memory; a workgroup barrier plus a workgroup-scope
 // fence orders the passes (all traffic stays on one CU).
-template <class FQ>
+template <class EC>
 __global__ __launch_bounds__(1024) void msm_long_combine_kernel(const LongDesc* __restrict__ desc, const uint32_t* __restrict__ desc_count,
                                                                 uint32_t desc_cap, uint32_t M, uint32_t* __restrict__ parts,
                                                                 uint32_t* __restrict__ buckets) {
@@ -322,8 +415,8 @@ __global__ __launch_bounds__(1024) void msm_long_combine_kernel(const LongDesc* 
         for (uint32_t i = t; i < cnt; i += 1024) {
             const LongDesc d = dw[i];
             if ((d.idx_in_run & (2 * s - 1)) == 0 && d.idx_in_run + s < d.run_len) {
-                XYZZ<Fp<FQ>> a = load_xyzz<FQ>(parts, pbase + i), b = load_xyzz<FQ>(parts, pbase + i + s);
-                store_xyzz<FQ>(parts, pbase + i, xyzz_add(a, b));
+                typename EC::Pt a = EC::load_pt(parts, pbase + i), b = EC::load_pt(parts, pbase + i + s);
+                EC::store_pt(parts, pbase + i, EC::add(a, b));
             }
         }
         __threadfence_block();
@@ -333,15 +426,15 @@ __global__ __launch_bounds__(1024) void msm_long_combine_kernel(const LongDesc* 
         const LongDesc d = dw[i];
         if (d.idx_in_run == 0) {
             const size_t bi = (size_t)w * M + d.bucket;
-            XYZZ<Fp<FQ>> a = load_xyzz<FQ>(buckets, bi), b = load_xyzz<FQ>(parts, pbase + i);
-            store_xyzz<FQ>(buckets, bi, xyzz_add(a, b));
+            typename EC::Pt a = EC::load_pt(buckets, bi), b = EC::load_pt(parts, pbase + i);
+            EC::store_pt(buckets, bi, EC::add(a, b));
         }
     }
 }
 
 // level with half-size h: segment 0 is the main array (base 0), segment j >= 1 is T_j (base M>>j);
 // X[base+i] += X[base+h+i].  grid covers n_win * nseg * h threads.
-template <class FQ>
+template <class EC>
 __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_fold_kernel(uint32_t* __restrict__ buckets, uint32_t M, uint32_t h, int nseg, int n_win) {
     const unsigned long long t = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
     const unsigned long long per_win = (unsigned long long)nseg * h;
@@ -349,20 +442,20 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_fold_kernel(uint32_t* __r
     const unsigned long long w = t / per_win, r = t % per_win;
     const uint32_t seg = (uint32_t)(r / h), i = (uint32_t)(r % h);
     const unsigned long long base = w * M + (seg ? (M >> seg) : 0u);
-    XYZZ<Fp<FQ>> a = load_xyzz<FQ>(buckets, base + i);
-    XYZZ<Fp<FQ>> b = load_xyzz<FQ>(buckets, base + h + i);
-    store_xyzz<FQ>(buckets, base + i, xyzz_add(a, b));
+    typename EC::Pt a = EC::load_pt(buckets, base + i);
+    typename EC::Pt b = EC::load_pt(buckets, base + h + i);
+    EC::store_pt(buckets, base + i, EC::add(a, b));
 }
 
-// out[w][0] = X[w*M], out[w][j] = X[w*M + (M>>j)], j = 1..log2 M
-template <class FQ>
+// out[w][0] = X[w*M], out[w][j] = X[w*M + (M>>j)], j = 1..log2 M, converted to the boundary form
+template <class EC>
 __global__ void msm_collect_kernel(const uint32_t* __restrict__ buckets, uint32_t M, int log_m, int n_win, uint32_t* __restrict__ out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int per = log_m + 1;
     if (t >= n_win * per) return;
     const int w = t / per, j = t % per;
-    XYZZ<Fp<FQ>> p = load_xyzz<FQ>(buckets, (unsigned long long)w * M + (j ? (M >> j) : 0u));
-    store_xyzz<FQ>(out, t, p);
+    typename EC::Pt p = EC::load_pt(buckets, (unsigned long long)w * M + (j ? (M >> j) : 0u));
+    store_xyzz<typename EC::Field>(out, t, EC::to_boundary(p));
 }
 
 // ------------------------------------------------------------------------------------------------

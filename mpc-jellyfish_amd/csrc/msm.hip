@@ -56,8 +56,9 @@ void write_infinity(uint32_t* out_xyz) {
 // `count` MSMs that share the window size: sort + accumulate run one after the other (they fill the
 // chip on their own), the latency-bound recursive halving runs ONCE over all count*n_win windows, one
 // copy brings every partial sum to the host, and the host Horner tails run on separate threads.
-template <class FR, class FQ>
+template <class FR, class EC>
 int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, hipStream_t st) {
+    using FQ = typename EC::Field;
     const uint32_t M = 1u << (c - 1);
     const int log_m = c - 1;
     const int n_win = msm_num_windows(is_mont ? FR::BITS : 256, c);
@@ -73,12 +74,12 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, hipSt
     const uint32_t cap_max = (uint32_t)std::max<unsigned long long>(256ull, 8ull * (n_max / M + 1));
     const uint32_t desc_cap_max = (uint32_t)(n_max / 256 + 1);
     MZK_TRY(g_ws.long_desc.reserve((size_t)n_win * desc_cap_max * sizeof(LongDesc) + (size_t)n_win * 4));
-    MZK_TRY(g_ws.long_parts.reserve((size_t)n_win * desc_cap_max * 4 * FQ::N * 4));
+    MZK_TRY(g_ws.long_parts.reserve((size_t)n_win * desc_cap_max * EC::PT_WORDS * 4));
     (void)cap_max;
     const unsigned long long dstride_max = (n_max + 7) & ~7ull;
     MZK_TRY(g_ws.digits.reserve((size_t)n_win * dstride_max * 2));
     MZK_TRY(g_ws.sorted.reserve((size_t)n_win * n_max * 4));
-    MZK_TRY(g_ws.buckets.reserve((size_t)count * wm * 4 * FQ::N * 4));
+    MZK_TRY(g_ws.buckets.reserve((size_t)count * wm * EC::PT_WORDS * 4));
     const int n_out_one = n_win * (log_m + 1);
     const int n_out = n_out_one * count;
     const size_t out_bytes = (size_t)n_out * 4 * FQ::N * 4;
@@ -104,7 +105,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, hipSt
             const uint64_t n = items[p].n;
             const uint32_t* d_scalars = items[p].d_scalars;
             const uint32_t* d_bases = items[p].d_bases;
-            uint32_t* buckets = g_ws.buckets.as<uint32_t>() + (size_t)p * wm * 4 * FQ::N;
+            uint32_t* buckets = g_ws.buckets.as<uint32_t>() + (size_t)p * wm * EC::PT_WORDS;
             const uint32_t cap = (uint32_t)std::max<unsigned long long>(256ull, 8ull * (n / M + 1));
             const uint32_t desc_cap = (uint32_t)(n / cap + 1);
             uint32_t* desc_count = reinterpret_cast<uint32_t*>(desc + (size_t)n_win * desc_cap);
@@ -120,16 +121,16 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, hipSt
             }
             {
                 ProfScope ps("msm_accumulate", st);
-                hipLaunchKernelGGL((msm_accumulate_kernel<FQ>), dim3((unsigned)((wm + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
+                hipLaunchKernelGGL((msm_accumulate_kernel<EC>), dim3((unsigned)((wm + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
                                    d_bases, n, offs, hist, sorted, order, M, n_win, cap, buckets);
             }
             {
                 // over-long buckets (skewed scalars); no-ops for uniformly random scalars
                 ProfScope ps("msm_long", st);
                 hipLaunchKernelGGL(msm_long_find_kernel, dim3(n_win), dim3(1024), 0, st, hist, offs, M, cap, desc_cap, desc, desc_count);
-                hipLaunchKernelGGL((msm_long_chunk_kernel<FQ>), dim3((desc_cap + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, n_win), dim3(MSM_ACC_THREADS), 0, st,
+                hipLaunchKernelGGL((msm_long_chunk_kernel<EC>), dim3((desc_cap + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, n_win), dim3(MSM_ACC_THREADS), 0, st,
                                    d_bases, n, sorted, desc, desc_count, desc_cap, parts);
-                hipLaunchKernelGGL((msm_long_combine_kernel<FQ>), dim3(n_win), dim3(1024), 0, st, desc, desc_count, desc_cap, M, parts, buckets);
+                hipLaunchKernelGGL((msm_long_combine_kernel<EC>), dim3(n_win), dim3(1024), 0, st, desc, desc_count, desc_cap, M, parts, buckets);
             }
         }
         {
@@ -139,10 +140,10 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, hipSt
             for (int lvl = 1; lvl <= log_m; lvl++) {
                 const uint32_t h = M >> lvl;
                 const size_t threads = (size_t)nw_all * lvl * h;
-                hipLaunchKernelGGL((msm_fold_kernel<FQ>), dim3((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
+                hipLaunchKernelGGL((msm_fold_kernel<EC>), dim3((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
                                    buckets, M, h, lvl, nw_all);
             }
-            hipLaunchKernelGGL((msm_collect_kernel<FQ>), dim3((n_out + 63) / 64), dim3(64), 0, st, buckets, M, log_m, nw_all, collect);
+            hipLaunchKernelGGL((msm_collect_kernel<EC>), dim3((n_out + 63) / 64), dim3(64), 0, st, buckets, M, log_m, nw_all, collect);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(g_ws.h_collect, collect, out_bytes, hipMemcpyDeviceToHost, st));
@@ -161,8 +162,9 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, hipSt
     return MZK_OK;
 }
 
-template <class FR, class FQ>
+template <class FR, class EC>
 int32_t msm_batch_dev(const MsmItem* items, int count, int is_mont, hipStream_t st) {
+    using FQ = typename EC::Field;
     // runs of consecutive non-empty MSMs with one window size share a fused reduction
     int i = 0;
     while (i < count) {
@@ -171,7 +173,7 @@ int32_t msm_batch_dev(const MsmItem* items, int count, int is_mont, hipStream_t 
         const int c = msm_choose_window(items[i].n);
         int j = i + 1;
         while (j < count && j - i < 16 && items[j].n != 0 && items[j].n < (1ull << 31) && msm_choose_window(items[j].n) == c) j++;
-        MZK_TRY((msm_group_dev<FR, FQ>(items + i, j - i, c, is_mont, st)));
+        MZK_TRY((msm_group_dev<FR, EC>(items + i, j - i, c, is_mont, st)));
         i = j;
     }
     return MZK_OK;
@@ -187,6 +189,10 @@ int32_t msm_dispatch(const Srs& s, uint64_t base_offset, const uint32_t* d_scala
 int32_t msm_batch_dispatch(const Srs& s, uint32_t n_polys, const uint32_t* const* d_scalars, const uint64_t* lens, const uint64_t* base_offsets,
                            int is_mont, uint32_t* out_xyz, hipStream_t st) {
     const int fw = fq_words(s.curve);
+    // BLS12-381 runs on the reduced-radix internal table (EcFx), BN254 on the boundary form (EcFp)
+    const bool internal = s.d_int != nullptr;
+    const size_t aff_words = internal ? (size_t)EcFx<BlsFqX>::AFF_WORDS : (size_t)2 * fw;
+    const uint32_t* table = internal ? s.d_int : s.d_xy;
     std::vector<MsmItem> items(n_polys);
     for (uint32_t i = 0; i < n_polys; i++) {
         const uint64_t off = base_offsets ? base_offsets[i] : 0;
@@ -194,10 +200,25 @@ int32_t msm_batch_dispatch(const Srs& s, uint32_t n_polys, const uint32_t* const
             set_error("MSM longer than the registered SRS (poly degree larger than allowed)");
             return MZK_ERR_INVALID_ARG;
         }
-        items[i] = MsmItem{s.d_xy + off * 2 * fw, d_scalars[i], lens[i], out_xyz + (size_t)i * 3 * fw};
+        items[i] = MsmItem{table + off * aff_words, d_scalars[i], lens[i], out_xyz + (size_t)i * 3 * fw};
     }
-    if (s.curve == MZK_CURVE_BLS12_381) return msm_batch_dev<BlsFr, BlsFq>(items.data(), (int)n_polys, is_mont, st);
-    return msm_batch_dev<BnFr, BnFq>(items.data(), (int)n_polys, is_mont, st);
+    if (s.curve == MZK_CURVE_BLS12_381) return msm_batch_dev<BlsFr, EcFx<BlsFqX>>(items.data(), (int)n_polys, is_mont, st);
+    return msm_batch_dev<BnFr, EcFp<BnFq>>(items.data(), (int)n_polys, is_mont, st);
+}
+
+// builds the internal (reduced-radix) copy of a freshly registered BLS12-381 SRS; BN254 keeps d_int = nullptr
+int32_t srs_build_internal(Srs& s, hipStream_t st) {
+    s.d_int = nullptr;
+    if (s.curve != MZK_CURVE_BLS12_381) return MZK_OK;
+    using EC = EcFx<BlsFqX>;
+    HIP_TRY(hipMalloc((void**)&s.d_int, (size_t)(s.n ? s.n : 1) * EC::AFF_WORDS * 4));
+    if (s.n) {
+        hipLaunchKernelGGL((srs_to_internal_kernel<BlsFqX>), dim3((unsigned)((s.n + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0, st,
+                           s.d_xy, s.n, s.d_int);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));
+    }
+    return MZK_OK;
 }
 
 namespace {

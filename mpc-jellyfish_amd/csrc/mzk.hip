@@ -130,7 +130,7 @@ int32_t mzk_shutdown(void) {
     if (!g_init) return MZK_OK;
     (void)hipSetDevice(g_device);
     (void)hipDeviceSynchronize();
-    for (auto& kv : g_srs) (void)hipFree(kv.second.d_xy);
+    for (auto& kv : g_srs) { (void)hipFree(kv.second.d_xy); if (kv.second.d_int) (void)hipFree(kv.second.d_int); }
     g_srs.clear();
     ntt_release_plans();
     plonk_release_all();
@@ -162,10 +162,11 @@ int32_t mzk_srs_register(int32_t curve_id, const uint64_t* xy_mont, uint64_t n_p
     std::lock_guard<std::mutex> lk(g_lock);
     MZK_TRY(require_init());
     if ((curve_id != 0 && curve_id != 1) || !out_handle || (!xy_mont && n_points)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
-    Srs s{curve_id, n_points, nullptr};
+    Srs s{curve_id, n_points, nullptr, nullptr};
     const size_t bytes = (size_t)n_points * 2 * fq_words(curve_id) * 4;
     HIP_TRY(hipMalloc((void**)&s.d_xy, bytes ? bytes : 4));
     if (bytes) HIP_TRY(hipMemcpy(s.d_xy, xy_mont, bytes, hipMemcpyHostToDevice));
+    MZK_TRY(srs_build_internal(s, nullptr));
     *out_handle = g_next_handle++;
     g_srs[*out_handle] = s;
     return MZK_OK;
@@ -174,13 +175,14 @@ int32_t mzk_srs_register_dev(int32_t curve_id, const void* d_xy_mont, uint64_t n
     std::lock_guard<std::mutex> lk(g_lock);
     MZK_TRY(require_init());
     if ((curve_id != 0 && curve_id != 1) || !out_handle || (!d_xy_mont && n_points)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
-    Srs s{curve_id, n_points, nullptr};
+    Srs s{curve_id, n_points, nullptr, nullptr};
     const size_t bytes = (size_t)n_points * 2 * fq_words(curve_id) * 4;
     HIP_TRY(hipMalloc((void**)&s.d_xy, bytes ? bytes : 4));
     if (bytes) {
         HIP_TRY(hipMemcpyAsync(s.d_xy, d_xy_mont, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
         HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     }
+    MZK_TRY(srs_build_internal(s, (hipStream_t)stream));
     *out_handle = g_next_handle++;
     g_srs[*out_handle] = s;
     return MZK_OK;
@@ -192,6 +194,7 @@ int32_t mzk_srs_release(uint64_t handle) {
     if (it == g_srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipFree(it->second.d_xy));
+    if (it->second.d_int) HIP_TRY(hipFree(it->second.d_int));
     g_srs.erase(it);
     return MZK_OK;
 }
@@ -199,7 +202,7 @@ int32_t mzk_srs_generate_for_testing(int32_t curve_id, const uint64_t* beta_cano
     std::lock_guard<std::mutex> lk(g_lock);
     MZK_TRY(require_init());
     if ((curve_id != 0 && curve_id != 1) || !out_handle || !beta_canonical) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
-    Srs s{curve_id, n_points, nullptr};
+    Srs s{curve_id, n_points, nullptr, nullptr};
     const size_t bytes = (size_t)n_points * 2 * fq_words(curve_id) * 4;
     HIP_TRY(hipMalloc((void**)&s.d_xy, bytes ? bytes : 4));
     int32_t rc = MZK_OK;
@@ -207,6 +210,7 @@ int32_t mzk_srs_generate_for_testing(int32_t curve_id, const uint64_t* beta_cano
         const uint32_t* beta = reinterpret_cast<const uint32_t*>(beta_canonical);
         rc = srs_generate_dispatch(curve_id, beta, n_points, s.d_xy);
     }
+    if (rc == MZK_OK) rc = srs_build_internal(s, nullptr);
     if (rc != MZK_OK) { (void)hipFree(s.d_xy); return rc; }
     *out_handle = g_next_handle++;
     g_srs[*out_handle] = s;
