@@ -316,17 +316,9 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(const u
     const uint32_t cnt = min(hist[t], cap);                    // the rest of an over-long bucket: msm_long_* kernels
     const uint32_t* list = sorted + w * n + start;
     typename EC::Pt acc = EC::inf();
-    if (cnt) {
-        // software pipeline: the gather of point k+1 is in flight while point k is being added
-        uint32_t e = list[0];
-        typename EC::Aff p = EC::load_aff(bases, e & 0x7fffffffu);
-        for (uint32_t k = 0; k < cnt; k++) {
-            const uint32_t e_next = list[k + 1 < cnt ? k + 1 : k];
-            typename EC::Aff p_next = EC::load_aff(bases, e_next & 0x7fffffffu);
-            acc = EC::madd(acc, p, (e >> 31) != 0);
-            p = p_next;
-            e = e_next;
-        }
+    for (uint32_t k = 0; k < cnt; k++) {
+        const uint32_t e = list[k];
+        acc = EC::madd(acc, EC::load_aff(bases, e & 0x7fffffffu), (e >> 31) != 0);
     }
     EC::store_pt(buckets, t, acc);
 }
