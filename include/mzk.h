@@ -157,6 +157,9 @@ MZK_API int32_t mzk_profile_enable(int32_t on);
  * milliseconds and launch count since the last reset (synchronises the recorded events). */
 MZK_API int32_t mzk_profile_get(const char* name, double* out_ms, uint64_t* out_count);
 MZK_API int32_t mzk_profile_reset(void);
+/* MSMs of >= 2^17 pairs over a BLS12-381 SRS use a table of precomputed multiples 2^(c*w) * P_i built in HBM on
+ * the first such call (13 x the SRS size for 2^20 points); on != 0 (default) enables it.  Results are identical. */
+MZK_API int32_t mzk_msm_set_precompute(int32_t on);
 /* Last MSM's shape: window bits, windows, buckets per window (for DESIGN.md's op counts). */
 MZK_API int32_t mzk_msm_last_shape(uint32_t* out_window_bits, uint32_t* out_windows, uint32_t* out_buckets);
 

@@ -38,7 +38,7 @@ struct DevBuf {
 };
 
 struct Workspace {
-    DevBuf ntt_scratch, scalars, hist, offs, cursor, sorted, buckets, collect, io, misc, digits, long_desc, long_parts, plonk_polys, plonk_out;
+    DevBuf ntt_scratch, scalars, hist, offs, cursor, sorted, buckets, collect, io, misc, digits, long_desc, long_parts, plonk_polys, plonk_out, pre_cnt, pre_off, pre_ce, pre_cb;
     void* h_collect = nullptr;
     size_t h_collect_cap = 0;
     hipEvent_t last_use = nullptr;
@@ -62,12 +62,15 @@ struct ProfScope {
     ~ProfScope();
 };
 extern uint32_t g_last_c, g_last_w, g_last_m;
+extern bool g_msm_precompute;
 
 struct Srs {
     int curve;
     uint64_t n;
     uint32_t* d_xy;   // n * 2 * fq words, boundary form (what mzk_srs_download returns)
     uint32_t* d_int;  // internal reduced-radix table used by the MSM (BLS12-381), else nullptr
+    uint32_t* d_pre = nullptr;  // [W][n] precomputed multiples 2^(c*w) P_i (msm_pre.cuh), built on first large MSM
+    int pre_c = 0;              // window bits of d_pre; -1 = do not build
 };
 inline int fq_words(int curve) { return curve == MZK_CURVE_BLS12_381 ? 12 : 8; }
 

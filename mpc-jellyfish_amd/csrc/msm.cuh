@@ -153,29 +153,54 @@ __global__ __launch_bounds__(1024) void msm_scan_kernel(const uint32_t* __restri
     }
 }
 
-// order[w*M + rank] = bucket, buckets of a window listed by descending point count (counting sort on
-// the count, clamped to 1023), so the 64 lanes of an accumulation wave run loops of equal length.
-__global__ __launch_bounds__(1024) void msm_order_kernel(const uint32_t* __restrict__ hist, uint32_t* __restrict__ order, uint32_t M) {
+// order[w*M + rank] = bucket, buckets of a window listed by descending point count (counting sort on the
+// count, clamped to 1023), so the 64 lanes of an accumulation wave run loops of equal length.
+// Three small kernels; a workgroup owns MSM_ORDER_SLICE consecutive buckets of one window.
+constexpr uint32_t MSM_ORDER_SLICE = 8192;
+__device__ __forceinline__ uint32_t order_key(uint32_t count) { return 1023u - min(count, 1023u); }
+
+// keycnt[w][key] += number of buckets of this slice with that key   (keycnt zeroed first)
+__global__ __launch_bounds__(1024) void msm_order_hist_kernel(const uint32_t* __restrict__ hist, uint32_t M, uint32_t* __restrict__ keycnt) {
     __shared__ uint32_t cnt[1024];
-    __shared__ uint32_t part[1024];
-    const int w = blockIdx.x, t = threadIdx.x;
+    const uint32_t w = blockIdx.y, t = threadIdx.x;
+    const uint32_t lo = blockIdx.x * MSM_ORDER_SLICE, hi = min(M, lo + MSM_ORDER_SLICE);
     cnt[t] = 0;
     __syncthreads();
-    for (uint32_t b = t; b < M; b += 1024) atomicAdd(&cnt[1023 - min(hist[(size_t)w * M + b], 1023u)], 1u);
+    for (uint32_t b = lo + t; b < hi; b += 1024) atomicAdd(&cnt[order_key(hist[(size_t)w * M + b])], 1u);
     __syncthreads();
-    const uint32_t mine = cnt[t];
+    if (cnt[t]) atomicAdd(&keycnt[(size_t)w * 1024 + t], cnt[t]);
+}
+// keycnt[w][key] -> exclusive start of that key in the window's order array (in place)
+__global__ __launch_bounds__(1024) void msm_order_scan_kernel(uint32_t* __restrict__ keycnt) {
+    __shared__ uint32_t part[1024];
+    const uint32_t w = blockIdx.x, t = threadIdx.x;
+    const uint32_t mine = keycnt[(size_t)w * 1024 + t];
     part[t] = mine;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
-        uint32_t v = t >= d ? part[t - d] : 0;
+        uint32_t v = t >= (uint32_t)d ? part[t - d] : 0;
         __syncthreads();
         part[t] += v;
         __syncthreads();
     }
-    cnt[t] = part[t] - mine;                         // exclusive start of key t (key = 1023 - count)
+    keycnt[(size_t)w * 1024 + t] = part[t] - mine;
+}
+// each slice reserves, per key, a range of the window's order array and fills it
+__global__ __launch_bounds__(1024) void msm_order_scatter_kernel(const uint32_t* __restrict__ hist, uint32_t M, uint32_t* __restrict__ keycur,
+                                                                 uint32_t* __restrict__ order) {
+    __shared__ uint32_t cnt[1024];
+    const uint32_t w = blockIdx.y, t = threadIdx.x;
+    const uint32_t lo = blockIdx.x * MSM_ORDER_SLICE, hi = min(M, lo + MSM_ORDER_SLICE);
+    cnt[t] = 0;
     __syncthreads();
-    for (uint32_t b = t; b < M; b += 1024) {
-        const uint32_t pos = atomicAdd(&cnt[1023 - min(hist[(size_t)w * M + b], 1023u)], 1u);
+    for (uint32_t b = lo + t; b < hi; b += 1024) atomicAdd(&cnt[order_key(hist[(size_t)w * M + b])], 1u);
+    __syncthreads();
+    const uint32_t mine = cnt[t];
+    __syncthreads();
+    cnt[t] = mine ? atomicAdd(&keycur[(size_t)w * 1024 + t], mine) : 0u;      // start of this slice's range for key t
+    __syncthreads();
+    for (uint32_t b = lo + t; b < hi; b += 1024) {
+        const uint32_t pos = atomicAdd(&cnt[order_key(hist[(size_t)w * M + b])], 1u);
         order[(size_t)w * M + pos] = b;
     }
 }
@@ -331,44 +356,27 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(const u
 // three kernels below exit at once.
 struct LongDesc { uint32_t bucket, start, len, idx_in_run, run_len; };
 
-// one 1024-thread workgroup per window: descriptors in bucket order, at most n/cap per window
-__global__ __launch_bounds__(1024) void msm_long_find_kernel(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs, uint32_t M,
-                                                             uint32_t cap, uint32_t desc_cap, LongDesc* __restrict__ desc,
-                                                             uint32_t* __restrict__ desc_count) {
-    __shared__ uint32_t part[1024];
-    const int w = blockIdx.x, t = threadIdx.x;
-    const uint32_t per = (M + 1023) / 1024;
-    const uint32_t lo = t * per, hi = min(M, lo + per);
-    uint32_t sum = 0;
-    for (uint32_t b = lo; b < hi; b++) {
-        const uint32_t c = hist[(size_t)w * M + b];
-        if (c > cap) sum += (c - cap + cap - 1) / cap;
-    }
-    part[t] = sum;
-    __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
-        uint32_t v = t >= d ? part[t - d] : 0;
-        __syncthreads();
-        part[t] += v;
-        __syncthreads();
-    }
-    uint32_t pos = part[t] - sum;
-    if (t == 1023) desc_count[w] = min(part[1023], desc_cap);
-    for (uint32_t b = lo; b < hi; b++) {
-        const uint32_t c = hist[(size_t)w * M + b];
-        if (c <= cap) continue;
-        const uint32_t nch = (c - cap + cap - 1) / cap;
-        for (uint32_t j = 0; j < nch; j++) {
-            if (pos + j >= desc_cap) break;                  // cannot happen: sum of (c-cap)/cap <= n/cap
-            LongDesc d;
-            d.bucket = b;
-            d.start = offs[(size_t)w * M + b] + cap * (j + 1);
-            d.len = min(cap, c - cap * (j + 1));
-            d.idx_in_run = j;
-            d.run_len = nch;
-            desc[(size_t)w * desc_cap + pos + j] = d;
-        }
-        pos += nch;
+// one thread per (window, bucket): a long bucket reserves its run of descriptors with one atomic
+// (desc_count must be zeroed first); runs of different buckets land in arrival order, each contiguous
+__global__ __launch_bounds__(256) void msm_long_find_kernel(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs, uint32_t M, int n_win,
+                                                            uint32_t cap, uint32_t desc_cap, LongDesc* __restrict__ desc,
+                                                            uint32_t* __restrict__ desc_count) {
+    const unsigned long long t = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (unsigned long long)n_win * M) return;
+    const uint32_t c = hist[t];
+    if (c <= cap) return;
+    const uint32_t w = (uint32_t)(t / M), b = (uint32_t)(t % M);
+    const uint32_t nch = (c - cap + cap - 1) / cap;
+    const uint32_t pos = atomicAdd(&desc_count[w], nch);
+    for (uint32_t j = 0; j < nch; j++) {
+        if (pos + j >= desc_cap) break;                      // cannot happen: sum of (c-cap)/cap <= n/cap
+        LongDesc d;
+        d.bucket = b;
+        d.start = offs[t] + cap * (j + 1);
+        d.len = min(cap, c - cap * (j + 1));
+        d.idx_in_run = j;
+        d.run_len = nch;
+        desc[(size_t)w * desc_cap + pos + j] = d;
     }
 }
 
@@ -380,7 +388,7 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_long_chunk_kernel(const u
                                                                           uint32_t* __restrict__ parts) {
     const uint32_t w = blockIdx.y;
     const uint32_t i = blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
-    if (i >= desc_count[w]) return;
+    if (i >= min(desc_count[w], desc_cap)) return;
     const LongDesc d = desc[(size_t)w * desc_cap + i];
     const uint32_t* list = sorted + (size_t)w * n + d.start;
     typename EC::Pt acc = EC::inf();
@@ -399,7 +407,7 @@ __global__ __launch_bounds__(1024) void msm_long_combine_kernel(const LongDesc* 
                                                                 uint32_t desc_cap, uint32_t M, uint32_t* __restrict__ parts,
                                                                 uint32_t* __restrict__ buckets) {
     const uint32_t w = blockIdx.x, t = threadIdx.x;
-    const uint32_t cnt = desc_count[w];
+    const uint32_t cnt = min(desc_count[w], desc_cap);
     if (cnt == 0) return;
     const LongDesc* dw = desc + (size_t)w * desc_cap;
     const size_t pbase = (size_t)w * desc_cap;

@@ -6,8 +6,10 @@
 #include "internal.hpp"
 #include "hostfp.hpp"
 #include "msm.cuh"
+#include "msm_pre.cuh"
 
 namespace mzk {
+bool g_msm_precompute = true;
 namespace {
 
 // ---- MSM ------------------------------------------------------------------------------------------
@@ -40,11 +42,13 @@ void host_horner(const uint32_t* pts, int n_win, int c, uint32_t* out_xyz) {
 }
 
 struct MsmItem {
-    const uint32_t* d_bases;     // first base of this MSM
+    const uint32_t* d_bases;     // plain path: first base of this MSM; pre path: the precomputed table
     const uint32_t* d_scalars;
     uint64_t n;
     uint32_t* out_xyz;           // host, Jacobian
+    uint64_t base_off;           // pre path: index of this MSM's first SRS point
 };
+struct PreInfo { int c = 0; uint64_t tab_stride = 0; };      // c == 0: plain path
 
 template <class FQ>
 void write_infinity(uint32_t* out_xyz) {
@@ -54,31 +58,39 @@ void write_infinity(uint32_t* out_xyz) {
 }
 
 // `count` MSMs that share the window size: sort + accumulate run one after the other (they fill the
-// chip on their own), the latency-bound recursive halving runs ONCE over all count*n_win windows, one
-// copy brings every partial sum to the host, and the host Horner tails run on separate threads.
+// chip on their own), the latency-bound recursive halving runs ONCE over all bucket sets, one copy
+// brings every partial sum to the host, and the host Horner tails run on separate threads.
+// Plain path: n_dig windows, each with its own 2^(c-1) buckets.  Pre path (msm_pre.cuh): the digits of
+// all windows index rows of the precomputed table and share one bucket set.
 template <class FR, class EC>
-int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, hipStream_t st) {
+int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const PreInfo& pre, hipStream_t st) {
     using FQ = typename EC::Field;
     const uint32_t M = 1u << (c - 1);
     const int log_m = c - 1;
-    const int n_win = msm_num_windows(is_mont ? FR::BITS : 256, c);
-    g_last_c = c; g_last_w = n_win; g_last_m = M;
+    const int n_dig = msm_num_windows(is_mont ? FR::BITS : 256, c);      // digits per scalar
+    const int n_win = pre.c ? 1 : n_dig;                                 // bucket sets per MSM
+    g_last_c = c; g_last_w = n_dig; g_last_m = M;
     const size_t wm = (size_t)n_win * M;
     uint64_t n_max = 0;
     for (int p = 0; p < count; p++) n_max = std::max<uint64_t>(n_max, items[p].n);
+    const uint64_t sorted_max = pre.c ? n_max * n_dig : n_max;           // entries per bucket set
     MZK_TRY(ws_acquire(st));
     MZK_TRY(g_ws.hist.reserve(wm * 4));
     MZK_TRY(g_ws.offs.reserve(wm * 4));
-    MZK_TRY(g_ws.cursor.reserve(wm * 4));                       // bucket order by load
-    // per-thread cap on a bucket's run: 8x the mean load, at least 256
-    const uint32_t cap_max = (uint32_t)std::max<unsigned long long>(256ull, 8ull * (n_max / M + 1));
-    const uint32_t desc_cap_max = (uint32_t)(n_max / 256 + 1);
+    MZK_TRY(g_ws.cursor.reserve(wm * 4));                                // bucket order by load
+    const uint32_t desc_cap_max = (uint32_t)(sorted_max / 256 + 1);
     MZK_TRY(g_ws.long_desc.reserve((size_t)n_win * desc_cap_max * sizeof(LongDesc) + (size_t)n_win * 4));
     MZK_TRY(g_ws.long_parts.reserve((size_t)n_win * desc_cap_max * EC::PT_WORDS * 4));
-    (void)cap_max;
     const unsigned long long dstride_max = (n_max + 7) & ~7ull;
-    MZK_TRY(g_ws.digits.reserve((size_t)n_win * dstride_max * 2));
-    MZK_TRY(g_ws.sorted.reserve((size_t)n_win * n_max * 4));
+    MZK_TRY(g_ws.digits.reserve((size_t)n_dig * dstride_max * (pre.c ? 4 : 2)));
+    MZK_TRY(g_ws.sorted.reserve((size_t)n_dig * n_max * 4));
+    const uint32_t n_bins = pre.c ? std::max<uint32_t>(1u, M >> PRE_FINE_LOG) : 0u;
+    MZK_TRY(g_ws.pre_cnt.reserve((2048 + (size_t)n_win * 1024) * 4));     // bin totals, bin cursors, order keys
+    if (pre.c) {
+        MZK_TRY(g_ws.pre_off.reserve(2048 * 4));
+        MZK_TRY(g_ws.pre_ce.reserve((size_t)n_dig * n_max * 4));
+        MZK_TRY(g_ws.pre_cb.reserve((size_t)n_dig * n_max * 2));
+    }
     MZK_TRY(g_ws.buckets.reserve((size_t)count * wm * EC::PT_WORDS * 4));
     const int n_out_one = n_win * (log_m + 1);
     const int n_out = n_out_one * count;
@@ -93,7 +105,6 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, hipSt
     uint32_t* hist = g_ws.hist.as<uint32_t>();
     uint32_t* offs = g_ws.offs.as<uint32_t>();
     uint32_t* order = g_ws.cursor.as<uint32_t>();
-    uint16_t* digits = g_ws.digits.as<uint16_t>();
     uint32_t* sorted = g_ws.sorted.as<uint32_t>();
     uint32_t* collect = g_ws.collect.as<uint32_t>();
     LongDesc* desc = g_ws.long_desc.as<LongDesc>();
@@ -106,37 +117,68 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, hipSt
             const uint32_t* d_scalars = items[p].d_scalars;
             const uint32_t* d_bases = items[p].d_bases;
             uint32_t* buckets = g_ws.buckets.as<uint32_t>() + (size_t)p * wm * EC::PT_WORDS;
-            const uint32_t cap = (uint32_t)std::max<unsigned long long>(256ull, 8ull * (n / M + 1));
-            const uint32_t desc_cap = (uint32_t)(n / cap + 1);
+            const uint64_t n_sorted = pre.c ? n * (uint64_t)n_dig : n;
+            // per-thread cap on a bucket's run: 8x the mean load, at least 256
+            const uint32_t cap = (uint32_t)std::max<unsigned long long>(256ull, 8ull * (n_sorted / M + 1));
+            const uint32_t desc_cap = (uint32_t)(n_sorted / cap + 1);
             uint32_t* desc_count = reinterpret_cast<uint32_t*>(desc + (size_t)n_win * desc_cap);
             const unsigned long long dstride = (n + 7) & ~7ull;
             const unsigned gs = (unsigned)((n + MSM_THREADS - 1) / MSM_THREADS);
-            {
+            if (!pre.c) {
                 ProfScope ps("msm_sort", st);
+                uint16_t* digits = g_ws.digits.as<uint16_t>();
                 hipLaunchKernelGGL((msm_digits_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, st, d_scalars, n, is_mont, c, n_win, digits, dstride);
                 hipLaunchKernelGGL((msm_sort_kernel<false>), dim3(n_ranges, n_win), dim3(MSM_SORT_THREADS), 0, st, digits, n, dstride, M, hist, offs, sorted);
                 hipLaunchKernelGGL(msm_scan_kernel, dim3(n_win), dim3(1024), 0, st, hist, offs, M);
                 hipLaunchKernelGGL((msm_sort_kernel<true>), dim3(n_ranges, n_win), dim3(MSM_SORT_THREADS), 0, st, digits, n, dstride, M, hist, offs, sorted);
-                hipLaunchKernelGGL(msm_order_kernel, dim3(n_win), dim3(1024), 0, st, hist, order, M);
+            } else {
+                ProfScope ps("msm_sort", st);
+                uint32_t* dig32 = g_ws.digits.as<uint32_t>();
+                uint32_t* cnt = g_ws.pre_cnt.as<uint32_t>();
+                uint32_t* coff = g_ws.pre_off.as<uint32_t>();
+                uint32_t* ce = g_ws.pre_ce.as<uint32_t>();
+                uint16_t* cb = g_ws.pre_cb.as<uint16_t>();
+                const uint32_t n_chunks = (uint32_t)((n + PRE_CHUNK - 1) / PRE_CHUNK);
+                uint32_t* bin_total = cnt;                       // [n_bins]
+                uint32_t* bin_cursor = cnt + 1024;               // [n_bins]
+                uint32_t* bin_start = coff;                      // [n_bins + 1]
+                hipLaunchKernelGGL((pre_digits_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, st, d_scalars, n, is_mont, c, n_dig, dig32, dstride);
+                HIP_TRY(hipMemsetAsync(bin_total, 0, n_bins * 4, st));
+                hipLaunchKernelGGL(pre_coarse_count_kernel, dim3(n_chunks), dim3(256), 0, st, dig32, n, dstride, n_dig, (int)n_bins, bin_total);
+                hipLaunchKernelGGL(pre_bin_scan_kernel, dim3(1), dim3(1024), 0, st, bin_total, (int)n_bins, bin_start, bin_cursor);
+                hipLaunchKernelGGL(pre_coarse_scatter_kernel, dim3(n_chunks), dim3(256), 0, st, dig32, n, dstride, n_dig, (int)n_bins, pre.tab_stride,
+                                   items[p].base_off, bin_cursor, ce, cb);
+                hipLaunchKernelGGL(pre_fine_kernel, dim3(n_bins), dim3(1024), 0, st, bin_start, ce, cb, M, hist, offs, sorted);
+            }
+            {
+                // buckets ranked by load within each bucket set
+                ProfScope ps("msm_sort", st);
+                uint32_t* keycnt = g_ws.pre_cnt.as<uint32_t>() + 2048;       // [n_win][1024]
+                const unsigned slices = (M + MSM_ORDER_SLICE - 1) / MSM_ORDER_SLICE;
+                HIP_TRY(hipMemsetAsync(keycnt, 0, (size_t)n_win * 1024 * 4, st));
+                hipLaunchKernelGGL(msm_order_hist_kernel, dim3(slices, n_win), dim3(1024), 0, st, hist, M, keycnt);
+                hipLaunchKernelGGL(msm_order_scan_kernel, dim3(n_win), dim3(1024), 0, st, keycnt);
+                hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(slices, n_win), dim3(1024), 0, st, hist, M, keycnt, order);
             }
             {
                 ProfScope ps("msm_accumulate", st);
                 hipLaunchKernelGGL((msm_accumulate_kernel<EC>), dim3((unsigned)((wm + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
-                                   d_bases, n, offs, hist, sorted, order, M, n_win, cap, buckets);
+                                   d_bases, n_sorted, offs, hist, sorted, order, M, n_win, cap, buckets);
             }
             {
                 // over-long buckets (skewed scalars); no-ops for uniformly random scalars
                 ProfScope ps("msm_long", st);
-                hipLaunchKernelGGL(msm_long_find_kernel, dim3(n_win), dim3(1024), 0, st, hist, offs, M, cap, desc_cap, desc, desc_count);
+                HIP_TRY(hipMemsetAsync(desc_count, 0, (size_t)n_win * 4, st));
+                hipLaunchKernelGGL(msm_long_find_kernel, dim3((unsigned)((wm + 255) / 256)), dim3(256), 0, st, hist, offs, M, n_win, cap, desc_cap, desc, desc_count);
                 hipLaunchKernelGGL((msm_long_chunk_kernel<EC>), dim3((desc_cap + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, n_win), dim3(MSM_ACC_THREADS), 0, st,
-                                   d_bases, n, sorted, desc, desc_count, desc_cap, parts);
+                                   d_bases, n_sorted, sorted, desc, desc_count, desc_cap, parts);
                 hipLaunchKernelGGL((msm_long_combine_kernel<EC>), dim3(n_win), dim3(1024), 0, st, desc, desc_count, desc_cap, M, parts, buckets);
             }
         }
         {
             ProfScope ps("msm_reduce", st);
             uint32_t* buckets = g_ws.buckets.as<uint32_t>();
-            const int nw_all = n_win * count;                   // every (MSM, window) pair folds independently
+            const int nw_all = n_win * count;                   // every bucket set folds independently
             for (int lvl = 1; lvl <= log_m; lvl++) {
                 const uint32_t h = M >> lvl;
                 const size_t threads = (size_t)nw_all * lvl * h;
@@ -162,20 +204,54 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, hipSt
     return MZK_OK;
 }
 
+constexpr uint64_t PRE_MIN_N = 1ull << 17;       // smaller MSMs stay on the plain path
+
 template <class FR, class EC>
-int32_t msm_batch_dev(const MsmItem* items, int count, int is_mont, hipStream_t st) {
+int32_t msm_batch_dev(const MsmItem* items, int count, int is_mont, const PreInfo& pre, const uint32_t* plain_table, size_t aff_words,
+                      hipStream_t st) {
     using FQ = typename EC::Field;
     // runs of consecutive non-empty MSMs with one window size share a fused reduction
+    std::vector<MsmItem> run;
     int i = 0;
     while (i < count) {
         if (items[i].n == 0) { write_infinity<FQ>(items[i].out_xyz); i++; continue; }
-        if (items[i].n >= (1ull << 31)) { set_error("MSM size must be < 2^31"); return MZK_ERR_INVALID_ARG; }
-        const int c = msm_choose_window(items[i].n);
+        if (items[i].n >= (1ull << 27)) { set_error("MSM size must be < 2^27"); return MZK_ERR_INVALID_ARG; }
+        auto use_pre = [&](const MsmItem& it) { return pre.c != 0 && it.n >= PRE_MIN_N; };
+        auto win_of = [&](const MsmItem& it) { return use_pre(it) ? pre.c : msm_choose_window(it.n); };
+        const bool p0 = use_pre(items[i]);
+        const int c = win_of(items[i]);
         int j = i + 1;
-        while (j < count && j - i < 16 && items[j].n != 0 && items[j].n < (1ull << 31) && msm_choose_window(items[j].n) == c) j++;
-        MZK_TRY((msm_group_dev<FR, EC>(items + i, j - i, c, is_mont, st)));
+        while (j < count && j - i < 16 && items[j].n != 0 && items[j].n < (1ull << 27) && use_pre(items[j]) == p0 && win_of(items[j]) == c) j++;
+        run.assign(items + i, items + j);
+        if (!p0)
+            for (auto& it : run) it.d_bases = plain_table + it.base_off * aff_words;   // plain path: pointer to the first base
+        MZK_TRY((msm_group_dev<FR, EC>(run.data(), j - i, c, is_mont, p0 ? pre : PreInfo{}, st)));
         i = j;
     }
+    return MZK_OK;
+}
+
+// table[w][i] = 2^(c*w) * P_i for every SRS point (msm_pre.cuh); BLS12-381 only for now
+int32_t srs_build_pre(Srs& s, hipStream_t st) {
+    if (s.d_pre || s.pre_c < 0 || s.curve != MZK_CURVE_BLS12_381 || !s.d_int) return MZK_OK;
+    using EC = EcFx<BlsFqX>;
+    int lg = 0;
+    while ((2ull << lg) <= s.n) lg++;
+    const int c = lg < 18 ? 18 : (lg > 22 ? 22 : lg);
+    const int W = msm_num_windows(256, c);
+    const size_t level = (size_t)s.n * EC::AFF_WORDS;
+    size_t free_b = 0, total_b = 0;
+    HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+    if ((size_t)W * level * 4 > free_b / 2) { s.pre_c = -1; return MZK_OK; }      // not worth half the free HBM
+    HIP_TRY(hipMalloc((void**)&s.d_pre, (size_t)W * level * 4));
+    HIP_TRY(hipMemcpyAsync(s.d_pre, s.d_int, level * 4, hipMemcpyDeviceToDevice, st));
+    const unsigned long long threads = (s.n + 3) / 4;
+    for (int w = 1; w < W; w++)
+        hipLaunchKernelGGL((pre_next_level_kernel<BlsFqX>), dim3((unsigned)((threads + 127) / 128)), dim3(128), 0, st,
+                           s.d_pre + (size_t)(w - 1) * level, s.d_pre + (size_t)w * level, (unsigned long long)s.n, c);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipStreamSynchronize(st));
+    s.pre_c = c;
     return MZK_OK;
 }
 
@@ -194,21 +270,33 @@ int32_t msm_batch_dispatch(const Srs& s, uint32_t n_polys, const uint32_t* const
     const size_t aff_words = internal ? (size_t)EcFx<BlsFqX>::AFF_WORDS : (size_t)2 * fw;
     const uint32_t* table = internal ? s.d_int : s.d_xy;
     std::vector<MsmItem> items(n_polys);
+    bool want_pre = false;
     for (uint32_t i = 0; i < n_polys; i++) {
         const uint64_t off = base_offsets ? base_offsets[i] : 0;
         if (off > s.n || lens[i] > s.n - off) {
             set_error("MSM longer than the registered SRS (poly degree larger than allowed)");
             return MZK_ERR_INVALID_ARG;
         }
-        items[i] = MsmItem{table + off * aff_words, d_scalars[i], lens[i], out_xyz + (size_t)i * 3 * fw};
+        want_pre |= lens[i] >= PRE_MIN_N;
+        items[i] = MsmItem{nullptr, d_scalars[i], lens[i], out_xyz + (size_t)i * 3 * fw, off};
     }
-    if (s.curve == MZK_CURVE_BLS12_381) return msm_batch_dev<BlsFr, EcFx<BlsFqX>>(items.data(), (int)n_polys, is_mont, st);
-    return msm_batch_dev<BnFr, EcFp<BnFq>>(items.data(), (int)n_polys, is_mont, st);
+    PreInfo pre;
+    if (want_pre && g_msm_precompute) {
+        Srs& ms = const_cast<Srs&>(s);
+        MZK_TRY(srs_build_pre(ms, st));               // first large MSM on this SRS pays for the table
+        if (ms.d_pre && ms.pre_c > 0) { pre.c = ms.pre_c; pre.tab_stride = ms.n; }
+    }
+    if (pre.c)
+        for (auto& it : items) it.d_bases = s.d_pre;
+    if (s.curve == MZK_CURVE_BLS12_381) return msm_batch_dev<BlsFr, EcFx<BlsFqX>>(items.data(), (int)n_polys, is_mont, pre, table, aff_words, st);
+    return msm_batch_dev<BnFr, EcFp<BnFq>>(items.data(), (int)n_polys, is_mont, pre, table, aff_words, st);
 }
 
 // builds the internal (reduced-radix) copy of a freshly registered BLS12-381 SRS; BN254 keeps d_int = nullptr
 int32_t srs_build_internal(Srs& s, hipStream_t st) {
     s.d_int = nullptr;
+    s.d_pre = nullptr;
+    s.pre_c = 0;
     if (s.curve != MZK_CURVE_BLS12_381) return MZK_OK;
     using EC = EcFx<BlsFqX>;
     HIP_TRY(hipMalloc((void**)&s.d_int, (size_t)(s.n ? s.n : 1) * EC::AFF_WORDS * 4));

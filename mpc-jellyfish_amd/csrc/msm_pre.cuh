@@ -1,0 +1,209 @@
+// msm_pre.cuh -- MSM over a precomputed SRS: table[w][i] = 2^(c*w) * P_i kept in HBM per SRS
+// (KZG commits always use the same bases: primitives/src/pcs/univariate_kzg/mod.rs:109-111).
+// With the window shifts folded into the bases, all windows share ONE set of 2^(c-1) buckets:
+//   * the bucket reduction runs over one window instead of W (so c can grow to ~log2 n: fewer adds),
+//   * no cross-window doublings remain, so the host tail shrinks to c doublings.
+// 13 x 2^20 x 112 B = 1.5 GB for the 2^20-point BLS12-381 SRS -- the kind of trade 288 GB of HBM allows.
+// Sorting 13.6 M (entry, bucket) pairs into 2^19 buckets takes two LDS levels: a coarse partition on
+// the top bits (one workgroup per chunk of scalars), then one workgroup per coarse bin.
+#pragma once
+#include "msm.cuh"
+
+namespace mzk {
+
+constexpr int PRE_CHUNK = 2048;              // scalars per coarse-partition workgroup (multiple of 1024)
+constexpr int PRE_FINE_LOG = 10;             // buckets per fine workgroup (2^19 buckets -> 512 workgroups)
+constexpr uint32_t PRE_EMPTY = 0xFFFFFFFFu;
+
+// digits[w*stride + i] = sign<<31 | (magnitude-1), PRE_EMPTY for a zero digit
+template <class FR>
+__global__ __launch_bounds__(MSM_THREADS) void pre_digits_kernel(const uint32_t* __restrict__ scalars, unsigned long long n, int is_mont,
+                                                                  int c, int n_win, uint32_t* __restrict__ digits, unsigned long long stride) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * MSM_THREADS + threadIdx.x;
+    if (i >= n) return;
+    DigitIter it;
+    load_scalar<FR>(it, scalars, i, is_mont);
+    for (int w = 0; w < n_win; w++) {
+        uint32_t mag, ng;
+        it.next(w, c, mag, ng);
+        digits[(size_t)w * stride + i] = mag ? ((ng << 31) | (mag - 1)) : PRE_EMPTY;
+    }
+}
+
+// Coarse partition on the top bucket bits.  A workgroup owns PRE_CHUNK scalars (all their windows).
+//   pre_coarse_count:   bin_total[bin] += entries of this chunk in that bin          (bin_total zeroed first)
+//   pre_bin_scan:       bin_start = exclusive scan of bin_total (n_bins + 1 entries), bin_cursor = copy
+//   pre_coarse_scatter: counts its chunk again in LDS, reserves a range per bin with ONE global atomic
+//                       per bin, then writes (entry, low bucket bits) into it.
+// entry = w*tab_stride + base_off + i (row of the precomputed table), sign in bit 31.
+__global__ __launch_bounds__(256) void pre_coarse_count_kernel(const uint32_t* __restrict__ digits, unsigned long long n, unsigned long long stride,
+                                                                int n_win, int n_bins, uint32_t* __restrict__ bin_total) {
+    __shared__ uint32_t bins[1024];
+    const uint32_t tid = threadIdx.x;
+    for (int j = tid; j < n_bins; j += 256) bins[j] = 0u;
+    __syncthreads();
+    const unsigned long long lo = (unsigned long long)blockIdx.x * PRE_CHUNK, hi = min(n, lo + PRE_CHUNK);
+    for (int w = 0; w < n_win; w++) {
+        const uint32_t* dw = digits + (size_t)w * stride;
+        for (unsigned long long i = lo + 4ull * tid; i < hi; i += 1024) {           // stride rows are 16-B aligned, lo is too
+            const uint4 v = *reinterpret_cast<const uint4*>(dw + i);
+            const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (i + k < hi && d4[k] != PRE_EMPTY) atomicAdd(&bins[(d4[k] & 0x7FFFFFFFu) >> PRE_FINE_LOG], 1u);
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < n_bins; j += 256)
+        if (bins[j]) atomicAdd(&bin_total[j], bins[j]);
+}
+
+__global__ __launch_bounds__(1024) void pre_bin_scan_kernel(const uint32_t* __restrict__ bin_total, int n_bins, uint32_t* __restrict__ bin_start,
+                                                            uint32_t* __restrict__ bin_cursor) {
+    __shared__ uint32_t part[1024];
+    const int t = threadIdx.x;
+    const uint32_t mine = t < n_bins ? bin_total[t] : 0u;
+    part[t] = mine;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        uint32_t v = t >= d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    if (t < n_bins) { bin_start[t] = part[t] - mine; bin_cursor[t] = part[t] - mine; }
+    if (t == n_bins - 1) bin_start[n_bins] = part[t];                 // total
+}
+
+__global__ __launch_bounds__(256) void pre_coarse_scatter_kernel(const uint32_t* __restrict__ digits, unsigned long long n, unsigned long long stride,
+                                                                  int n_win, int n_bins, unsigned long long tab_stride, unsigned long long base_off,
+                                                                  uint32_t* __restrict__ bin_cursor, uint32_t* __restrict__ coarse_e,
+                                                                  uint16_t* __restrict__ coarse_b) {
+    __shared__ uint32_t bins[1024];
+    const uint32_t tid = threadIdx.x;
+    for (int j = tid; j < n_bins; j += 256) bins[j] = 0u;
+    __syncthreads();
+    const unsigned long long lo = (unsigned long long)blockIdx.x * PRE_CHUNK, hi = min(n, lo + PRE_CHUNK);
+    for (int w = 0; w < n_win; w++) {
+        const uint32_t* dw = digits + (size_t)w * stride;
+        for (unsigned long long i = lo + 4ull * tid; i < hi; i += 1024) {
+            const uint4 v = *reinterpret_cast<const uint4*>(dw + i);
+            const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (i + k < hi && d4[k] != PRE_EMPTY) atomicAdd(&bins[(d4[k] & 0x7FFFFFFFu) >> PRE_FINE_LOG], 1u);
+        }
+    }
+    __syncthreads();
+    for (int j = tid; j < n_bins; j += 256) {
+        const uint32_t c = bins[j];
+        bins[j] = c ? atomicAdd(&bin_cursor[j], c) : 0u;              // this chunk's range in bin j starts here
+    }
+    __syncthreads();
+    for (int w = 0; w < n_win; w++) {
+        const uint32_t* dw = digits + (size_t)w * stride;
+        for (unsigned long long i = lo + 4ull * tid; i < hi; i += 1024) {
+            const uint4 v = *reinterpret_cast<const uint4*>(dw + i);
+            const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const uint32_t d = d4[k];
+                if (i + k >= hi || d == PRE_EMPTY) continue;
+                const uint32_t b = d & 0x7FFFFFFFu;
+                const uint32_t pos = atomicAdd(&bins[b >> PRE_FINE_LOG], 1u);
+                coarse_e[pos] = (uint32_t)((unsigned long long)w * tab_stride + base_off + i + k) | (d & 0x80000000u);
+                coarse_b[pos] = (uint16_t)(b & ((1u << PRE_FINE_LOG) - 1));
+            }
+        }
+    }
+}
+
+// one workgroup per coarse bin: counts its buckets, scans them, and writes the bucket-sorted
+// entries plus the per-bucket hist / offs that the accumulation kernels read.
+__global__ __launch_bounds__(1024) void pre_fine_kernel(const uint32_t* __restrict__ bin_start, const uint32_t* __restrict__ coarse_e,
+                                                        const uint16_t* __restrict__ coarse_b, uint32_t M, uint32_t* __restrict__ hist,
+                                                        uint32_t* __restrict__ offs, uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t bins[1 << PRE_FINE_LOG];
+    __shared__ uint32_t part[1024];
+    const uint32_t bin = blockIdx.x, tid = threadIdx.x;
+    const uint32_t rsize = M < (1u << PRE_FINE_LOG) ? M : (1u << PRE_FINE_LOG);
+    const uint32_t start = bin_start[bin], end = bin_start[bin + 1];
+    for (uint32_t j = tid; j < rsize; j += 1024) bins[j] = 0;
+    __syncthreads();
+    for (uint32_t k = start + tid; k < end; k += 1024) atomicAdd(&bins[coarse_b[k]], 1u);
+    __syncthreads();
+    const uint32_t per = (rsize + 1023) / 1024;
+    uint32_t sum = 0;
+    for (uint32_t j = tid * per; j < min(rsize, (tid + 1) * per); j++) sum += bins[j];
+    part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        uint32_t v = tid >= (uint32_t)d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = start + part[tid] - sum;
+    for (uint32_t j = tid * per; j < min(rsize, (tid + 1) * per); j++) {
+        const uint32_t c = bins[j];
+        hist[(size_t)bin * rsize + j] = c;
+        offs[(size_t)bin * rsize + j] = run;
+        bins[j] = run;                               // becomes the scatter cursor
+        run += c;
+    }
+    __syncthreads();
+    for (uint32_t k = start + tid; k < end; k += 1024) sorted[atomicAdd(&bins[coarse_b[k]], 1u)] = coarse_e[k];
+}
+
+// ---- table construction: next[i] = 2^c * cur[i], affine, 8 points per thread share one inversion ----
+template <class X>
+__device__ __forceinline__ Fx<X> fx_inv(const Fx<X>& a) {          // a^(p-2), a weakly normalised, result class M
+    Fx<X> acc = Fx<X>::one(), base = a;
+    for (int i = 0; i < X::N; i++) {
+        uint32_t e = X::MOD[i] - (i == 0 ? 2u : 0u);                // p - 2: every modulus here ends in ...1 or ...b, no borrow
+        for (int b = 0; b < 32; b++) {
+            if ((e >> b) & 1) acc = fx_mul(acc, base);
+            base = fx_sqr(base);
+        }
+    }
+    return acc;
+}
+
+template <class X>
+__global__ __launch_bounds__(128) void pre_next_level_kernel(const uint32_t* __restrict__ cur, uint32_t* __restrict__ next, unsigned long long n, int c) {
+    constexpr int B = 4;
+    using EC = EcFx<X>;
+    const unsigned long long t = (unsigned long long)blockIdx.x * 128 + threadIdx.x;
+    const unsigned long long start = t * B;
+    if (start >= n) return;
+    XYZZX<X> pt[B];
+    Fx<X> pref[B];
+    Fx<X> run = Fx<X>::one();
+#pragma unroll
+    for (int j = 0; j < B; j++) {
+        const unsigned long long i = start + j < n ? start + j : n - 1;
+        XYZZX<X> p = XYZZX<X>::from_affine(EC::load_aff(cur, i));
+        for (int k = 0; k < c; k++) p = xyzzx_dbl(p);
+        pt[j] = p;
+        pref[j] = run;
+        if (!p.is_inf()) run = fx_mul(run, p.zzz);                   // zzz is class M
+    }
+    Fx<X> inv_run = fx_inv(run);
+#pragma unroll
+    for (int j = B - 1; j >= 0; j--) {
+        if (start + j >= n) continue;
+        uint32_t* dst = next + (start + j) * EC::AFF_WORDS;
+        if (pt[j].is_inf()) {
+            for (int k = 0; k < EC::AFF_WORDS; k++) dst[k] = 0;
+            continue;
+        }
+        const Fx<X> zi = fx_mul(inv_run, pref[j]);                   // 1 / ZZZ_j
+        inv_run = fx_mul(inv_run, pt[j].zzz);
+        const Fx<X> zzi = fx_sqr(fx_mul(zi, pt[j].zz));              // (ZZ/ZZZ)^2 = 1/ZZ
+        const Fx<X> x = fx_canonical(fx_mul(pt[j].x, zzi)), y = fx_canonical(fx_mul(pt[j].y, zi));
+#pragma unroll
+        for (int k = 0; k < X::XN; k++) { dst[k] = x.l[k]; dst[X::XN + k] = y.l[k]; }
+    }
+}
+
+}  // namespace mzk

@@ -30,7 +30,7 @@ void DevBuf::release() {
     cap = 0;
 }
 void Workspace::release() {
-    for (DevBuf* b : {&ntt_scratch, &scalars, &hist, &offs, &cursor, &sorted, &buckets, &collect, &io, &misc, &digits, &long_desc, &long_parts, &plonk_polys, &plonk_out}) b->release();
+    for (DevBuf* b : {&ntt_scratch, &scalars, &hist, &offs, &cursor, &sorted, &buckets, &collect, &io, &misc, &digits, &long_desc, &long_parts, &plonk_polys, &plonk_out, &pre_cnt, &pre_off, &pre_ce, &pre_cb}) b->release();
     if (h_collect) (void)hipHostFree(h_collect);
     h_collect = nullptr;
     h_collect_cap = 0;
@@ -130,7 +130,7 @@ int32_t mzk_shutdown(void) {
     if (!g_init) return MZK_OK;
     (void)hipSetDevice(g_device);
     (void)hipDeviceSynchronize();
-    for (auto& kv : g_srs) { (void)hipFree(kv.second.d_xy); if (kv.second.d_int) (void)hipFree(kv.second.d_int); }
+    for (auto& kv : g_srs) { (void)hipFree(kv.second.d_xy); if (kv.second.d_int) (void)hipFree(kv.second.d_int); if (kv.second.d_pre) (void)hipFree(kv.second.d_pre); }
     g_srs.clear();
     ntt_release_plans();
     plonk_release_all();
@@ -162,7 +162,7 @@ int32_t mzk_srs_register(int32_t curve_id, const uint64_t* xy_mont, uint64_t n_p
     std::lock_guard<std::mutex> lk(g_lock);
     MZK_TRY(require_init());
     if ((curve_id != 0 && curve_id != 1) || !out_handle || (!xy_mont && n_points)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
-    Srs s{curve_id, n_points, nullptr, nullptr};
+    Srs s{curve_id, n_points, nullptr, nullptr, nullptr, 0};
     const size_t bytes = (size_t)n_points * 2 * fq_words(curve_id) * 4;
     HIP_TRY(hipMalloc((void**)&s.d_xy, bytes ? bytes : 4));
     if (bytes) HIP_TRY(hipMemcpy(s.d_xy, xy_mont, bytes, hipMemcpyHostToDevice));
@@ -175,7 +175,7 @@ int32_t mzk_srs_register_dev(int32_t curve_id, const void* d_xy_mont, uint64_t n
     std::lock_guard<std::mutex> lk(g_lock);
     MZK_TRY(require_init());
     if ((curve_id != 0 && curve_id != 1) || !out_handle || (!d_xy_mont && n_points)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
-    Srs s{curve_id, n_points, nullptr, nullptr};
+    Srs s{curve_id, n_points, nullptr, nullptr, nullptr, 0};
     const size_t bytes = (size_t)n_points * 2 * fq_words(curve_id) * 4;
     HIP_TRY(hipMalloc((void**)&s.d_xy, bytes ? bytes : 4));
     if (bytes) {
@@ -195,6 +195,7 @@ int32_t mzk_srs_release(uint64_t handle) {
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipFree(it->second.d_xy));
     if (it->second.d_int) HIP_TRY(hipFree(it->second.d_int));
+    if (it->second.d_pre) HIP_TRY(hipFree(it->second.d_pre));
     g_srs.erase(it);
     return MZK_OK;
 }
@@ -202,7 +203,7 @@ int32_t mzk_srs_generate_for_testing(int32_t curve_id, const uint64_t* beta_cano
     std::lock_guard<std::mutex> lk(g_lock);
     MZK_TRY(require_init());
     if ((curve_id != 0 && curve_id != 1) || !out_handle || !beta_canonical) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
-    Srs s{curve_id, n_points, nullptr, nullptr};
+    Srs s{curve_id, n_points, nullptr, nullptr, nullptr, 0};
     const size_t bytes = (size_t)n_points * 2 * fq_words(curve_id) * 4;
     HIP_TRY(hipMalloc((void**)&s.d_xy, bytes ? bytes : 4));
     int32_t rc = MZK_OK;
@@ -464,6 +465,11 @@ int32_t mzk_profile_reset(void) {
     std::lock_guard<std::mutex> lk(g_lock);
     for (auto& r : g_prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof_recs.clear();
+    return MZK_OK;
+}
+int32_t mzk_msm_set_precompute(int32_t on) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    g_msm_precompute = on != 0;
     return MZK_OK;
 }
 int32_t mzk_msm_last_shape(uint32_t* out_window_bits, uint32_t* out_windows, uint32_t* out_buckets) {

@@ -50,6 +50,7 @@ _SIGS = {
     "mzk_profile_enable": [C.c_int32],
     "mzk_profile_get": [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
     "mzk_profile_reset": [],
+    "mzk_msm_set_precompute": [C.c_int32],
     "mzk_msm_last_shape": [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
 }
 _STR_FUNCS = ("mzk_strerror", "mzk_last_error", "mzk_version")
