@@ -447,6 +447,27 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_fold_kernel(uint32_t* __r
     EC::store_pt(buckets, base + i, EC::add(a, b));
 }
 
+// the last levels of the recursive halving in ONE launch: a 256-thread workgroup per
+// bucket set walks the levels with a workgroup barrier between them (each level is one EC add deep,
+// so separate launches would pay a launch gap per level for a few hundred threads of work)
+template <class EC>
+__global__ __launch_bounds__(256) void msm_fold_tail_kernel(uint32_t* __restrict__ buckets, uint32_t M, int log_m, int first_lvl) {
+    const unsigned long long w = blockIdx.x;
+    for (int lvl = first_lvl; lvl <= log_m; lvl++) {
+        const uint32_t h = M >> lvl;
+        const uint32_t items = (uint32_t)lvl * h;
+        for (uint32_t r = threadIdx.x; r < items; r += 256) {
+            const uint32_t seg = r / h, i = r % h;
+            const unsigned long long base = w * M + (seg ? (M >> seg) : 0u);
+            typename EC::Pt a = EC::load_pt(buckets, base + i);
+            typename EC::Pt b = EC::load_pt(buckets, base + h + i);
+            EC::store_pt(buckets, base + i, EC::add(a, b));
+        }
+        __threadfence_block();
+        __syncthreads();
+    }
+}
+
 // out[w][0] = X[w*M], out[w][j] = X[w*M + (M>>j)], j = 1..log2 M, converted to the boundary form
 template <class EC>
 __global__ void msm_collect_kernel(const uint32_t* __restrict__ buckets, uint32_t M, int log_m, int n_win, uint32_t* __restrict__ out) {

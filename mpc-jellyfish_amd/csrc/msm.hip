@@ -88,8 +88,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     MZK_TRY(g_ws.pre_cnt.reserve((2048 + (size_t)n_win * 1024) * 4));     // bin totals, bin cursors, order keys
     if (pre.c) {
         MZK_TRY(g_ws.pre_off.reserve(2048 * 4));
-        MZK_TRY(g_ws.pre_ce.reserve((size_t)n_dig * n_max * 4));
-        MZK_TRY(g_ws.pre_cb.reserve((size_t)n_dig * n_max * 2));
+        MZK_TRY(g_ws.pre_ce.reserve((size_t)n_dig * n_max * 8));
     }
     MZK_TRY(g_ws.buckets.reserve((size_t)count * wm * EC::PT_WORDS * 4));
     const int n_out_one = n_win * (log_m + 1);
@@ -136,19 +135,18 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 uint32_t* dig32 = g_ws.digits.as<uint32_t>();
                 uint32_t* cnt = g_ws.pre_cnt.as<uint32_t>();
                 uint32_t* coff = g_ws.pre_off.as<uint32_t>();
-                uint32_t* ce = g_ws.pre_ce.as<uint32_t>();
-                uint16_t* cb = g_ws.pre_cb.as<uint16_t>();
+                unsigned long long* coarse = g_ws.pre_ce.as<unsigned long long>();
                 const uint32_t n_chunks = (uint32_t)((n + PRE_CHUNK - 1) / PRE_CHUNK);
                 uint32_t* bin_total = cnt;                       // [n_bins]
                 uint32_t* bin_cursor = cnt + 1024;               // [n_bins]
                 uint32_t* bin_start = coff;                      // [n_bins + 1]
                 hipLaunchKernelGGL((pre_digits_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, st, d_scalars, n, is_mont, c, n_dig, dig32, dstride);
                 HIP_TRY(hipMemsetAsync(bin_total, 0, n_bins * 4, st));
-                hipLaunchKernelGGL(pre_coarse_count_kernel, dim3(n_chunks), dim3(256), 0, st, dig32, n, dstride, n_dig, (int)n_bins, bin_total);
+                hipLaunchKernelGGL(pre_coarse_count_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, st, dig32, n, dstride, n_dig, (int)n_bins, bin_total);
                 hipLaunchKernelGGL(pre_bin_scan_kernel, dim3(1), dim3(1024), 0, st, bin_total, (int)n_bins, bin_start, bin_cursor);
-                hipLaunchKernelGGL(pre_coarse_scatter_kernel, dim3(n_chunks), dim3(256), 0, st, dig32, n, dstride, n_dig, (int)n_bins, pre.tab_stride,
-                                   items[p].base_off, bin_cursor, ce, cb);
-                hipLaunchKernelGGL(pre_fine_kernel, dim3(n_bins), dim3(1024), 0, st, bin_start, ce, cb, M, hist, offs, sorted);
+                hipLaunchKernelGGL(pre_coarse_scatter_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, st, dig32, n, dstride, n_dig, (int)n_bins,
+                                   pre.tab_stride, items[p].base_off, bin_cursor, coarse);
+                hipLaunchKernelGGL(pre_fine_kernel, dim3(n_bins), dim3(1024), 0, st, bin_start, coarse, M, hist, offs, sorted);
             }
             {
                 // buckets ranked by load within each bucket set
@@ -179,12 +177,17 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
             ProfScope ps("msm_reduce", st);
             uint32_t* buckets = g_ws.buckets.as<uint32_t>();
             const int nw_all = n_win * count;                   // every bucket set folds independently
-            for (int lvl = 1; lvl <= log_m; lvl++) {
+            // wide levels: one launch each over all bucket sets; narrow levels (<= 256 adds per set): one launch in all
+            int first_tail = 1;
+            while (first_tail <= log_m && (size_t)first_tail * (M >> first_tail) > 256) first_tail++;
+            for (int lvl = 1; lvl < first_tail; lvl++) {
                 const uint32_t h = M >> lvl;
                 const size_t threads = (size_t)nw_all * lvl * h;
                 hipLaunchKernelGGL((msm_fold_kernel<EC>), dim3((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
                                    buckets, M, h, lvl, nw_all);
             }
+            if (first_tail <= log_m)
+                hipLaunchKernelGGL((msm_fold_tail_kernel<EC>), dim3(nw_all), dim3(256), 0, st, buckets, M, log_m, first_tail);
             hipLaunchKernelGGL((msm_collect_kernel<EC>), dim3((n_out + 63) / 64), dim3(64), 0, st, buckets, M, log_m, nw_all, collect);
         }
         HIP_TRY(hipGetLastError());

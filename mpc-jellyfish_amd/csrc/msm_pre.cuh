@@ -11,8 +11,9 @@
 
 namespace mzk {
 
-constexpr int PRE_CHUNK = 2048;              // scalars per coarse-partition workgroup (multiple of 1024)
-constexpr int PRE_FINE_LOG = 10;             // buckets per fine workgroup (2^19 buckets -> 512 workgroups)
+constexpr int PRE_CHUNK = 4096;              // scalars per coarse-partition workgroup (multiple of 4 * PRE_CTHREADS)
+constexpr int PRE_CTHREADS = 1024;
+constexpr int PRE_FINE_LOG = 11;             // buckets per fine workgroup (2^19 buckets -> 256 workgroups)
 constexpr uint32_t PRE_EMPTY = 0xFFFFFFFFu;
 
 // digits[w*stride + i] = sign<<31 | (magnitude-1), PRE_EMPTY for a zero digit
@@ -36,16 +37,16 @@ __global__ __launch_bounds__(MSM_THREADS) void pre_digits_kernel(const uint32_t*
 //   pre_coarse_scatter: counts its chunk again in LDS, reserves a range per bin with ONE global atomic
 //                       per bin, then writes (entry, low bucket bits) into it.
 // entry = w*tab_stride + base_off + i (row of the precomputed table), sign in bit 31.
-__global__ __launch_bounds__(256) void pre_coarse_count_kernel(const uint32_t* __restrict__ digits, unsigned long long n, unsigned long long stride,
+__global__ __launch_bounds__(PRE_CTHREADS) void pre_coarse_count_kernel(const uint32_t* __restrict__ digits, unsigned long long n, unsigned long long stride,
                                                                 int n_win, int n_bins, uint32_t* __restrict__ bin_total) {
     __shared__ uint32_t bins[1024];
     const uint32_t tid = threadIdx.x;
-    for (int j = tid; j < n_bins; j += 256) bins[j] = 0u;
+    for (int j = tid; j < n_bins; j += PRE_CTHREADS) bins[j] = 0u;
     __syncthreads();
     const unsigned long long lo = (unsigned long long)blockIdx.x * PRE_CHUNK, hi = min(n, lo + PRE_CHUNK);
     for (int w = 0; w < n_win; w++) {
         const uint32_t* dw = digits + (size_t)w * stride;
-        for (unsigned long long i = lo + 4ull * tid; i < hi; i += 1024) {           // stride rows are 16-B aligned, lo is too
+        for (unsigned long long i = lo + 4ull * tid; i < hi; i += 4 * PRE_CTHREADS) {           // stride rows are 16-B aligned, lo is too
             const uint4 v = *reinterpret_cast<const uint4*>(dw + i);
             const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -54,7 +55,7 @@ __global__ __launch_bounds__(256) void pre_coarse_count_kernel(const uint32_t* _
         }
     }
     __syncthreads();
-    for (int j = tid; j < n_bins; j += 256)
+    for (int j = tid; j < n_bins; j += PRE_CTHREADS)
         if (bins[j]) atomicAdd(&bin_total[j], bins[j]);
 }
 
@@ -75,18 +76,17 @@ __global__ __launch_bounds__(1024) void pre_bin_scan_kernel(const uint32_t* __re
     if (t == n_bins - 1) bin_start[n_bins] = part[t];                 // total
 }
 
-__global__ __launch_bounds__(256) void pre_coarse_scatter_kernel(const uint32_t* __restrict__ digits, unsigned long long n, unsigned long long stride,
+__global__ __launch_bounds__(PRE_CTHREADS) void pre_coarse_scatter_kernel(const uint32_t* __restrict__ digits, unsigned long long n, unsigned long long stride,
                                                                   int n_win, int n_bins, unsigned long long tab_stride, unsigned long long base_off,
-                                                                  uint32_t* __restrict__ bin_cursor, uint32_t* __restrict__ coarse_e,
-                                                                  uint16_t* __restrict__ coarse_b) {
+                                                                  uint32_t* __restrict__ bin_cursor, unsigned long long* __restrict__ coarse) {
     __shared__ uint32_t bins[1024];
     const uint32_t tid = threadIdx.x;
-    for (int j = tid; j < n_bins; j += 256) bins[j] = 0u;
+    for (int j = tid; j < n_bins; j += PRE_CTHREADS) bins[j] = 0u;
     __syncthreads();
     const unsigned long long lo = (unsigned long long)blockIdx.x * PRE_CHUNK, hi = min(n, lo + PRE_CHUNK);
     for (int w = 0; w < n_win; w++) {
         const uint32_t* dw = digits + (size_t)w * stride;
-        for (unsigned long long i = lo + 4ull * tid; i < hi; i += 1024) {
+        for (unsigned long long i = lo + 4ull * tid; i < hi; i += 4 * PRE_CTHREADS) {
             const uint4 v = *reinterpret_cast<const uint4*>(dw + i);
             const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -95,14 +95,14 @@ __global__ __launch_bounds__(256) void pre_coarse_scatter_kernel(const uint32_t*
         }
     }
     __syncthreads();
-    for (int j = tid; j < n_bins; j += 256) {
+    for (int j = tid; j < n_bins; j += PRE_CTHREADS) {
         const uint32_t c = bins[j];
         bins[j] = c ? atomicAdd(&bin_cursor[j], c) : 0u;              // this chunk's range in bin j starts here
     }
     __syncthreads();
     for (int w = 0; w < n_win; w++) {
         const uint32_t* dw = digits + (size_t)w * stride;
-        for (unsigned long long i = lo + 4ull * tid; i < hi; i += 1024) {
+        for (unsigned long long i = lo + 4ull * tid; i < hi; i += 4 * PRE_CTHREADS) {
             const uint4 v = *reinterpret_cast<const uint4*>(dw + i);
             const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -111,18 +111,19 @@ __global__ __launch_bounds__(256) void pre_coarse_scatter_kernel(const uint32_t*
                 if (i + k >= hi || d == PRE_EMPTY) continue;
                 const uint32_t b = d & 0x7FFFFFFFu;
                 const uint32_t pos = atomicAdd(&bins[b >> PRE_FINE_LOG], 1u);
-                coarse_e[pos] = (uint32_t)((unsigned long long)w * tab_stride + base_off + i + k) | (d & 0x80000000u);
-                coarse_b[pos] = (uint16_t)(b & ((1u << PRE_FINE_LOG) - 1));
+                const uint32_t e = (uint32_t)((unsigned long long)w * tab_stride + base_off + i + k) | (d & 0x80000000u);
+                coarse[pos] = ((unsigned long long)(b & ((1u << PRE_FINE_LOG) - 1)) << 32) | e;          // one 8-byte record
             }
         }
     }
 }
 
 // one workgroup per coarse bin: counts its buckets, scans them, and writes the bucket-sorted
-// entries plus the per-bucket hist / offs that the accumulation kernels read.
-__global__ __launch_bounds__(1024) void pre_fine_kernel(const uint32_t* __restrict__ bin_start, const uint32_t* __restrict__ coarse_e,
-                                                        const uint16_t* __restrict__ coarse_b, uint32_t M, uint32_t* __restrict__ hist,
-                                                        uint32_t* __restrict__ offs, uint32_t* __restrict__ sorted) {
+// entries plus the per-bucket hist / offs that the accumulation kernels read.  Four independent
+// record loads are in flight per thread (the loops are latency-, not bandwidth-bound).
+__global__ __launch_bounds__(1024) void pre_fine_kernel(const uint32_t* __restrict__ bin_start, const unsigned long long* __restrict__ coarse,
+                                                        uint32_t M, uint32_t* __restrict__ hist, uint32_t* __restrict__ offs,
+                                                        uint32_t* __restrict__ sorted) {
     __shared__ uint32_t bins[1 << PRE_FINE_LOG];
     __shared__ uint32_t part[1024];
     const uint32_t bin = blockIdx.x, tid = threadIdx.x;
@@ -130,7 +131,14 @@ __global__ __launch_bounds__(1024) void pre_fine_kernel(const uint32_t* __restri
     const uint32_t start = bin_start[bin], end = bin_start[bin + 1];
     for (uint32_t j = tid; j < rsize; j += 1024) bins[j] = 0;
     __syncthreads();
-    for (uint32_t k = start + tid; k < end; k += 1024) atomicAdd(&bins[coarse_b[k]], 1u);
+    for (uint32_t k = start + tid; k < end; k += 4096) {
+        unsigned long long r[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) r[q] = k + q * 1024 < end ? coarse[k + q * 1024] : ~0ull;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (k + q * 1024 < end) atomicAdd(&bins[(uint32_t)(r[q] >> 32)], 1u);
+    }
     __syncthreads();
     const uint32_t per = (rsize + 1023) / 1024;
     uint32_t sum = 0;
@@ -152,7 +160,14 @@ __global__ __launch_bounds__(1024) void pre_fine_kernel(const uint32_t* __restri
         run += c;
     }
     __syncthreads();
-    for (uint32_t k = start + tid; k < end; k += 1024) sorted[atomicAdd(&bins[coarse_b[k]], 1u)] = coarse_e[k];
+    for (uint32_t k = start + tid; k < end; k += 4096) {
+        unsigned long long r[4];
+#pragma unroll
+        for (int q = 0; q < 4; q++) r[q] = k + q * 1024 < end ? coarse[k + q * 1024] : ~0ull;
+#pragma unroll
+        for (int q = 0; q < 4; q++)
+            if (k + q * 1024 < end) sorted[atomicAdd(&bins[(uint32_t)(r[q] >> 32)], 1u)] = (uint32_t)r[q];
+    }
 }
 
 // ---- table construction: next[i] = 2^c * cur[i], affine, 8 points per thread share one inversion ----
