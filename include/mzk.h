@@ -143,6 +143,15 @@ MZK_API int32_t mzk_plonk_quotient_dev(uint64_t pk_handle, void* d_polys, uint64
 MZK_API int32_t mzk_plonk_quotient(uint64_t pk_handle, const uint64_t* polys, uint64_t in_len, const uint64_t* alpha_mont,
                                    const uint64_t* beta_mont, const uint64_t* gamma_mont, uint64_t* out);
 
+/* Round 2: replaces Arithmetization::compute_prod_permutation_polynomial
+ * (relation/src/constraint_system.rs:1197-1223), whose loop performs one field division per gate.
+ * wire_values: 5 x n wire evaluations witness[wire_variable(i, j)]; the sigma evaluations come from the
+ * registered proving key.  out: the n coefficients of the permutation product polynomial (unmasked). */
+MZK_API int32_t mzk_plonk_perm_product_dev(uint64_t pk_handle, const void* d_wire_values, const uint64_t* beta_mont,
+                                           const uint64_t* gamma_mont, void* d_out, void* stream);
+MZK_API int32_t mzk_plonk_perm_product(uint64_t pk_handle, const uint64_t* wire_values, const uint64_t* beta_mont,
+                                       const uint64_t* gamma_mont, uint64_t* out);
+
 /* ---- device memory helpers for bindings without HIP of their own ---- */
 MZK_API int32_t mzk_dev_alloc(uint64_t bytes, void** out_dptr);
 MZK_API int32_t mzk_dev_free(void* dptr);

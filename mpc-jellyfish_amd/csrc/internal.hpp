@@ -94,6 +94,7 @@ int32_t plonk_pk_release(uint64_t handle);
 void plonk_release_all();
 int32_t plonk_quotient_dev(uint64_t handle, uint32_t* d_polys, uint64_t in_len, const uint32_t* alpha, const uint32_t* beta, const uint32_t* gamma,
                            uint32_t* d_out, hipStream_t st);
+int32_t plonk_perm_product_dev(uint64_t handle, const uint32_t* d_wires, const uint32_t* beta, const uint32_t* gamma, uint32_t* d_out, hipStream_t st);
 int plonk_pk_log_n(uint64_t handle);
 int plonk_pk_wires(uint64_t handle);
 

@@ -404,6 +404,31 @@ int32_t mzk_plonk_quotient(uint64_t pk_handle, const uint64_t* polys, uint64_t i
     return MZK_OK;
 }
 
+int32_t mzk_plonk_perm_product_dev(uint64_t pk_handle, const void* d_wire_values, const uint64_t* beta_mont, const uint64_t* gamma_mont, void* d_out,
+                                   void* stream) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    return plonk_perm_product_dev(pk_handle, reinterpret_cast<const uint32_t*>(d_wire_values), reinterpret_cast<const uint32_t*>(beta_mont),
+                                  reinterpret_cast<const uint32_t*>(gamma_mont), reinterpret_cast<uint32_t*>(d_out), (hipStream_t)stream);
+}
+int32_t mzk_plonk_perm_product(uint64_t pk_handle, const uint64_t* wire_values, const uint64_t* beta_mont, const uint64_t* gamma_mont, uint64_t* out) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    const int log_n = plonk_pk_log_n(pk_handle), W = plonk_pk_wires(pk_handle);
+    if (log_n < 0) { set_error("unknown proving-key handle"); return MZK_ERR_BAD_HANDLE; }
+    if (!wire_values || !out) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    const uint64_t n = 1ull << log_n;
+    hipStream_t st = nullptr;
+    MZK_TRY(g_ws.plonk_polys.reserve((size_t)W * n * 32));
+    MZK_TRY(g_ws.plonk_out.reserve(n * 32));
+    HIP_TRY(hipMemcpyAsync(g_ws.plonk_polys.p, wire_values, (size_t)W * n * 32, hipMemcpyHostToDevice, st));
+    MZK_TRY(plonk_perm_product_dev(pk_handle, g_ws.plonk_polys.as<uint32_t>(), reinterpret_cast<const uint32_t*>(beta_mont),
+                                   reinterpret_cast<const uint32_t*>(gamma_mont), g_ws.plonk_out.as<uint32_t>(), st));
+    HIP_TRY(hipMemcpyAsync(out, g_ws.plonk_out.p, n * 32, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return MZK_OK;
+}
+
 // ---- device memory helpers --------------------------------------------------------------------------
 int32_t mzk_dev_alloc(uint64_t bytes, void** out_dptr) {
     std::lock_guard<std::mutex> lk(g_lock);

@@ -114,4 +114,152 @@ __global__ __launch_bounds__(PLK_THREADS) void plonk_domain_tables_kernel(const 
     }
 }
 
+// ---- round 2: the permutation grand product ---------------------------------------
+// Replaces the serial loop of Arithmetization::compute_prod_permutation_polynomial
+// (relation/src/constraint_system.rs:1197-1223), which performs one field division per gate:
+//   z[0] = 1,  z[j+1] = z[j] * prod_i (w_ij + gamma + beta k_i w^j) / prod_i (w_ij + gamma + beta sigma_ij),  j < n-1.
+// Here: ratios with one shared inversion per 8 gates, then a three-phase parallel prefix product.
+constexpr int PERM_B = 8;             // gates per thread in the ratio kernel
+constexpr int SCAN_T = 256;           // threads per scan workgroup
+constexpr int SCAN_E = 8;             // elements per thread
+constexpr int SCAN_BLOCK = SCAN_T * SCAN_E;
+
+struct PermArgs {
+    const uint32_t* wire;      // [W][n] wire values (evaluations on H)
+    const uint32_t* sigma;     // [W][n] extended permutation values sigma_i(w^j)
+    const uint32_t* omega;     // [n] w^j
+    uint32_t* ratio;           // [n] out: ratio[j] for j < n-1, ratio[n-1] = 1
+    unsigned long long n;
+    uint32_t k[PLK_WIRES][8];
+    uint32_t beta[8], gamma[8];
+};
+
+template <class P>
+__global__ __launch_bounds__(PLK_THREADS) void plonk_perm_ratio_kernel(PermArgs a) {
+    using F = Fp<P>;
+    const unsigned long long t = (unsigned long long)blockIdx.x * PLK_THREADS + threadIdx.x;
+    const unsigned long long start = t * PERM_B;
+    if (start >= a.n) return;
+    const F beta = arg_fp<P>(a.beta), gamma = arg_fp<P>(a.gamma);
+    F num[PERM_B], pref[PERM_B];
+    F run = F::one();
+#pragma unroll
+    for (int q = 0; q < PERM_B; q++) {
+        const unsigned long long j = start + q;
+        F nu = F::one(), de = F::one();
+        if (j + 1 < a.n) {
+            const F bw = beta * load_fp<P>(a.omega + j * 8);
+#pragma unroll
+            for (int i = 0; i < PLK_WIRES; i++) {
+                const F wg = load_fp<P>(a.wire + ((size_t)i * a.n + j) * 8) + gamma;
+                nu = nu * (wg + bw * arg_fp<P>(a.k[i]));
+                de = de * (wg + beta * load_fp<P>(a.sigma + ((size_t)i * a.n + j) * 8));
+            }
+        }
+        num[q] = nu;
+        pref[q] = run;
+        run = run * de;
+        store_fp<P>(a.ratio + j * 8, de);                   // parked
+    }
+    F inv_run = inv(run);            // a zero denominator (probability ~ n/r) yields 0, as 1/0 would panic in the reference
+#pragma unroll
+    for (int q = PERM_B - 1; q >= 0; q--) {
+        const unsigned long long j = start + q;
+        const F de = load_fp<P>(a.ratio + j * 8);
+        store_fp<P>(a.ratio + j * 8, num[q] * (inv_run * pref[q]));
+        inv_run = inv_run * de;
+    }
+}
+
+// phase 1: inclusive products inside each 2048-element block (in place), block total to totals[block]
+template <class P>
+__global__ __launch_bounds__(SCAN_T) void fr_scan_mul_block_kernel(uint32_t* __restrict__ data, unsigned long long n, uint32_t* __restrict__ totals) {
+    using F = Fp<P>;
+    __shared__ uint4 sh[2 * SCAN_T];
+    const unsigned long long base = (unsigned long long)blockIdx.x * SCAN_BLOCK + (unsigned long long)threadIdx.x * SCAN_E;
+    F v[SCAN_E];
+    F run = F::one();
+#pragma unroll
+    for (int q = 0; q < SCAN_E; q++) {
+        v[q] = base + q < n ? load_fp<P>(data + (base + q) * 8) : F::one();
+        run = run * v[q];
+        v[q] = run;
+    }
+    // Hillis-Steele over the SCAN_T thread totals
+    auto put = [&](int i, const F& x) { sh[2 * i] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]); sh[2 * i + 1] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]); };
+    auto get = [&](int i) { F x; uint4 p = sh[2 * i], q = sh[2 * i + 1]; x.l[0] = p.x; x.l[1] = p.y; x.l[2] = p.z; x.l[3] = p.w; x.l[4] = q.x; x.l[5] = q.y; x.l[6] = q.z; x.l[7] = q.w; return x; };
+    F incl = run;
+    put(threadIdx.x, incl);
+    __syncthreads();
+    for (int d = 1; d < SCAN_T; d <<= 1) {
+        F other = F::one();
+        const bool has = (int)threadIdx.x >= d;
+        if (has) other = get(threadIdx.x - d);
+        __syncthreads();
+        if (has) incl = incl * other;
+        put(threadIdx.x, incl);
+        __syncthreads();
+    }
+    const F excl = threadIdx.x ? get(threadIdx.x - 1) : F::one();
+#pragma unroll
+    for (int q = 0; q < SCAN_E; q++)
+        if (base + q < n) store_fp<P>(data + (base + q) * 8, excl * v[q]);
+    if (threadIdx.x == SCAN_T - 1) store_fp<P>(totals + (size_t)blockIdx.x * 8, incl);
+}
+
+// phase 2: exclusive scan of the block totals by one workgroup (n_blocks <= 64 K: loops in chunks of 1024)
+template <class P>
+__global__ __launch_bounds__(1024) void fr_scan_mul_totals_kernel(uint32_t* __restrict__ totals, unsigned int n_blocks) {
+    using F = Fp<P>;
+    __shared__ uint4 sh[2 * 1024];
+    auto put = [&](int i, const F& x) { sh[2 * i] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]); sh[2 * i + 1] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]); };
+    auto get = [&](int i) { F x; uint4 p = sh[2 * i], q = sh[2 * i + 1]; x.l[0] = p.x; x.l[1] = p.y; x.l[2] = p.z; x.l[3] = p.w; x.l[4] = q.x; x.l[5] = q.y; x.l[6] = q.z; x.l[7] = q.w; return x; };
+    F carry = F::one();
+    for (unsigned int c0 = 0; c0 < n_blocks; c0 += 1024) {
+        const unsigned int i = c0 + threadIdx.x;
+        const F mine = i < n_blocks ? load_fp<P>(totals + (size_t)i * 8) : F::one();
+        F incl = mine;
+        put(threadIdx.x, incl);
+        __syncthreads();
+        for (int d = 1; d < 1024; d <<= 1) {
+            F other = F::one();
+            const bool has = (int)threadIdx.x >= d;
+            if (has) other = get(threadIdx.x - d);
+            __syncthreads();
+            if (has) incl = incl * other;
+            put(threadIdx.x, incl);
+            __syncthreads();
+        }
+        const F excl = carry * (threadIdx.x ? get(threadIdx.x - 1) : F::one());
+        if (i < n_blocks) store_fp<P>(totals + (size_t)i * 8, excl);
+        carry = carry * get(1023);
+        __syncthreads();
+    }
+}
+
+// phase 3: out[0] = 1, out[j+1] = prefix[block(j)] * incl[j]  (the exclusive product, shifted by one)
+template <class P>
+__global__ __launch_bounds__(PLK_THREADS) void fr_scan_mul_apply_kernel(const uint32_t* __restrict__ incl, const uint32_t* __restrict__ totals,
+                                                                         unsigned long long n, uint32_t* __restrict__ out) {
+    using F = Fp<P>;
+    const unsigned long long j = (unsigned long long)blockIdx.x * PLK_THREADS + threadIdx.x;
+    if (j >= n) return;
+    if (j == 0) store_fp<P>(out, F::one());
+    if (j + 1 < n) store_fp<P>(out + (j + 1) * 8, load_fp<P>(totals + (j / SCAN_BLOCK) * 8) * load_fp<P>(incl + j * 8));
+}
+
+// omega[j] = w^j, 16 per thread
+template <class P>
+__global__ __launch_bounds__(PLK_THREADS) void fr_powers_mont_kernel(const uint32_t* __restrict__ w_mont, unsigned long long n, uint32_t* __restrict__ out) {
+    using F = Fp<P>;
+    const unsigned long long start = ((unsigned long long)blockIdx.x * PLK_THREADS + threadIdx.x) * 16;
+    if (start >= n) return;
+    const F w = load_fp<P>(w_mont);
+    F x = pow_u64(w, start);
+    for (int q = 0; q < 16 && start + q < n; q++) {
+        store_fp<P>(out + (start + q) * 8, x);
+        x = x * w;
+    }
+}
+
 }  // namespace mzk

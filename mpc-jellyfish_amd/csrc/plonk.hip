@@ -13,6 +13,8 @@ struct PlonkPk {
     uint32_t* d_fixed = nullptr;        // [13 + W][m] coset evaluations of selectors then sigmas
     uint32_t* d_xs = nullptr;           // [m]
     uint32_t* d_inv_den = nullptr;      // [m]
+    uint32_t* d_sigma_n = nullptr;      // [W][n] sigma_i on the gate domain H (extended permutation values)
+    uint32_t* d_omega_n = nullptr;      // [n] w_n^j
     uint32_t k[PLK_WIRES][8];
     uint32_t zh_inv[PLK_RATIO][8];
     uint32_t gen[8];
@@ -54,9 +56,47 @@ int32_t pk_build(PlonkPk& pk, const uint32_t* sel_coeffs, const uint32_t* sig_co
     hipLaunchKernelGGL((plonk_domain_tables_kernel<P>), dim3((unsigned)((threads + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st,
                        d_c, d_c + 8, m, pk.d_xs, pk.d_inv_den);
     HIP_TRY(hipGetLastError());
+    // gate-domain tables for the permutation product (round 2): sigma_i(w^j) and w^j
+    HIP_TRY(hipMalloc((void**)&pk.d_sigma_n, (size_t)pk.W * n * 32));
+    HIP_TRY(hipMalloc((void**)&pk.d_omega_n, n * 32));
+    HIP_TRY(hipMemsetAsync(pk.d_sigma_n, 0, (size_t)pk.W * n * 32, st));
+    const uint64_t sl = poly_len < n ? poly_len : n;
+    HIP_TRY(hipMemcpy2DAsync(pk.d_sigma_n, n * 32, sig_coeffs, poly_len * 32, sl * 32, pk.W, hipMemcpyHostToDevice, st));
+    F wn = F::from_const(P::ROOT);
+    for (int i = pk.log_n; i < P::TWO_ADICITY; i++) wn = sqr(wn);
+    HIP_TRY(hipMemcpyAsync(d_c + 8, wn.l, 32, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL((fr_powers_mont_kernel<P>), dim3((unsigned)(((n + 15) / 16 + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st,
+                       d_c + 8, n, pk.d_omega_n);
+    HIP_TRY(hipGetLastError());
     MZK_TRY(ws_release(st));
+    MZK_TRY(ntt_dispatch(pk.curve, pk.d_sigma_n, sl, pk.log_n, false, nullptr, pk.W, n, st));
     HIP_TRY(hipStreamSynchronize(st));
     return MZK_OK;
+}
+
+// z = ifft(running product), constraint_system.rs:1197-1223; d_out receives the n coefficients
+template <class P>
+int32_t perm_product_run(const PlonkPk& pk, const uint32_t* d_wires, const uint32_t* beta, const uint32_t* gamma, uint32_t* d_out, hipStream_t st) {
+    const uint64_t n = 1ull << pk.log_n;
+    ProfScope total("plonk_perm_product", st);
+    MZK_TRY(ws_acquire(st));
+    const unsigned n_blocks = (unsigned)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    MZK_TRY(g_ws.io.reserve(n * 32 + (size_t)n_blocks * 32));
+    uint32_t* ratio = g_ws.io.as<uint32_t>();
+    uint32_t* totals = ratio + n * 8;
+    PermArgs a;
+    a.wire = d_wires; a.sigma = pk.d_sigma_n; a.omega = pk.d_omega_n; a.ratio = ratio; a.n = n;
+    std::memcpy(a.k, pk.k, sizeof a.k);
+    std::memcpy(a.beta, beta, 32);
+    std::memcpy(a.gamma, gamma, 32);
+    const uint64_t rthreads = (n + PERM_B - 1) / PERM_B;
+    hipLaunchKernelGGL((plonk_perm_ratio_kernel<P>), dim3((unsigned)((rthreads + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st, a);
+    hipLaunchKernelGGL((fr_scan_mul_block_kernel<P>), dim3(n_blocks), dim3(SCAN_T), 0, st, ratio, n, totals);
+    hipLaunchKernelGGL((fr_scan_mul_totals_kernel<P>), dim3(1), dim3(1024), 0, st, totals, n_blocks);
+    hipLaunchKernelGGL((fr_scan_mul_apply_kernel<P>), dim3((unsigned)((n + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st, ratio, totals, n, d_out);
+    HIP_TRY(hipGetLastError());
+    MZK_TRY(ws_release(st));
+    return ntt_dispatch(pk.curve, d_out, n, pk.log_n, true, nullptr, 1, n, st);
 }
 
 template <class P>
@@ -111,7 +151,7 @@ int32_t plonk_pk_register(int curve, int log_n, int W, const uint32_t* sel, cons
     std::memcpy(pk->k, k_mont, sizeof pk->k);
     int32_t rc = curve == 0 ? pk_build<BlsFr>(*pk, sel, sig, poly_len) : pk_build<BnFr>(*pk, sel, sig, poly_len);
     if (rc != MZK_OK) {
-        for (auto* d : {pk->d_fixed, pk->d_xs, pk->d_inv_den}) if (d) (void)hipFree(d);
+        for (auto* d : {pk->d_fixed, pk->d_xs, pk->d_inv_den, pk->d_sigma_n, pk->d_omega_n}) if (d) (void)hipFree(d);
         return rc;
     }
     *out_handle = g_next_pk++;
@@ -123,13 +163,13 @@ int32_t plonk_pk_release(uint64_t handle) {
     auto it = g_pks.find(handle);
     if (it == g_pks.end()) { set_error("unknown proving-key handle"); return MZK_ERR_BAD_HANDLE; }
     HIP_TRY(hipDeviceSynchronize());
-    for (auto* d : {it->second->d_fixed, it->second->d_xs, it->second->d_inv_den}) if (d) (void)hipFree(d);
+    for (auto* d : {it->second->d_fixed, it->second->d_xs, it->second->d_inv_den, it->second->d_sigma_n, it->second->d_omega_n}) if (d) (void)hipFree(d);
     g_pks.erase(it);
     return MZK_OK;
 }
 void plonk_release_all() {
     for (auto& kv : g_pks)
-        for (auto* d : {kv.second->d_fixed, kv.second->d_xs, kv.second->d_inv_den}) if (d) (void)hipFree(d);
+        for (auto* d : {kv.second->d_fixed, kv.second->d_xs, kv.second->d_inv_den, kv.second->d_sigma_n, kv.second->d_omega_n}) if (d) (void)hipFree(d);
     g_pks.clear();
 }
 
@@ -141,6 +181,13 @@ int32_t plonk_quotient_dev(uint64_t handle, uint32_t* d_polys, uint64_t in_len, 
     if (!d_polys || !d_out || !alpha || !beta || !gamma || in_len > (8ull << pk.log_n)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
     return pk.curve == 0 ? quotient_run<BlsFr>(pk, d_polys, in_len, alpha, beta, gamma, d_out, st)
                          : quotient_run<BnFr>(pk, d_polys, in_len, alpha, beta, gamma, d_out, st);
+}
+int32_t plonk_perm_product_dev(uint64_t handle, const uint32_t* d_wires, const uint32_t* beta, const uint32_t* gamma, uint32_t* d_out, hipStream_t st) {
+    auto it = g_pks.find(handle);
+    if (it == g_pks.end()) { set_error("unknown proving-key handle"); return MZK_ERR_BAD_HANDLE; }
+    if (!d_wires || !d_out || !beta || !gamma) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    const PlonkPk& pk = *it->second;
+    return pk.curve == 0 ? perm_product_run<BlsFr>(pk, d_wires, beta, gamma, d_out, st) : perm_product_run<BnFr>(pk, d_wires, beta, gamma, d_out, st);
 }
 int plonk_pk_log_n(uint64_t handle) {
     auto it = g_pks.find(handle);

@@ -42,6 +42,8 @@ _SIGS = {
     "mzk_plonk_pk_release": [C.c_uint64],
     "mzk_plonk_quotient_dev": [C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "mzk_plonk_quotient": [C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "mzk_plonk_perm_product_dev": [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "mzk_plonk_perm_product": [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "mzk_dev_alloc": [C.c_uint64, C.POINTER(C.c_void_p)],
     "mzk_dev_free": [C.c_void_p],
     "mzk_dev_upload": [C.c_void_p, C.c_void_p, C.c_uint64],

@@ -105,3 +105,16 @@ def compute_quotient_polynomial_dev(pk: ProvingKeyDevice, challenges: Challenges
                                                          ch[1].ctypes.data_as(C.c_void_p), ch[2].ctypes.data_as(C.c_void_p),
                                                          out_dev.data_ptr(), st), "mzk_plonk_quotient_dev")
     return out_dev
+
+
+def compute_prod_permutation_polynomial(pk: ProvingKeyDevice, beta: int, gamma: int, wire_values) -> np.ndarray:
+    """relation/src/constraint_system.rs:1197-1223: the permutation grand product z, as n coefficients.
+    wire_values: (5, n, 4) Montgomery wire evaluations (witness[wire_variable(i, j)])."""
+    w = np.ascontiguousarray(wire_values, dtype=np.uint64)
+    if w.shape != (NUM_WIRE_TYPES, pk.domain_size, 4):
+        raise PlonkError("expected (5, n, 4) wire values")
+    ch = fr_to_mont(pk.curve, [beta, gamma])
+    out = np.empty((pk.domain_size, 4), dtype=np.uint64)
+    _lib.check(_lib.ensure_init().mzk_plonk_perm_product(pk.handle, w.ctypes.data_as(C.c_void_p), ch[0].ctypes.data_as(C.c_void_p),
+                                                         ch[1].ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)), "mzk_plonk_perm_product")
+    return out

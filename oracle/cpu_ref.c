@@ -221,6 +221,15 @@ EXPORT int orc_plonk_quotient(int curve, int log_n, int num_wire_types, const u6
     return -2;
 }
 
+/* permutation grand-product polynomial (constraint_system.rs:1197-1223) */
+EXPORT int orc_plonk_perm_product(int curve, int log_n, int num_wire_types, const u64 *wires, const u64 *sigma_vals, const u64 *k_mont,
+                                  const u64 *beta, const u64 *gamma, u64 *out, int threads) {
+    if (threads < 1) threads = 1;
+    if (curve == 0) return blsplk_perm_product(log_n, num_wire_types, wires, sigma_vals, k_mont, beta, gamma, out, threads);
+    if (curve == 1) return bnplk_perm_product(log_n, num_wire_types, wires, sigma_vals, k_mont, beta, gamma, out, threads);
+    return -2;
+}
+
 /* MSM: bases packed x||y Montgomery ((0,0) = infinity), scalars 4 limbs each (canonical, or
  * Montgomery when scalars_are_mont), out = Jacobian X,Y,Z Montgomery (Z = 0 => infinity).
  * window_bits 0 => arkworks rule. */

@@ -40,6 +40,7 @@ def lib():
         L.orc_g1_count_off_curve.argtypes = [C.c_int, u64p, C.c_size_t]
         L.orc_g1_count_off_curve.restype = C.c_long
         L.orc_plonk_quotient.argtypes = [C.c_int, C.c_int, C.c_int, u64p, C.c_size_t, u64p, u64p, u64p, u64p, u64p, C.c_int]
+        L.orc_plonk_perm_product.argtypes = [C.c_int, C.c_int, C.c_int, u64p, u64p, u64p, u64p, u64p, u64p, C.c_int]
         _LIB = L
     return _LIB
 
@@ -174,4 +175,15 @@ def plonk_quotient(curve: int, log_n: int, polys: np.ndarray, k_mont: np.ndarray
     out = np.empty((8 << log_n, 4), dtype=np.uint64)
     args = [np.ascontiguousarray(a, dtype=np.uint64) for a in (k_mont, alpha, beta, gamma)]
     _chk(lib().orc_plonk_quotient(curve, log_n, 5, _p(p), p.shape[1], _p(args[0]), _p(args[1]), _p(args[2]), _p(args[3]), _p(out), threads))
+    return out
+
+
+def plonk_perm_product(curve: int, log_n: int, wires: np.ndarray, sigma_vals: np.ndarray, k_mont: np.ndarray, beta, gamma, threads: int = 1) -> np.ndarray:
+    """wires, sigma_vals: (5, n, 4) Montgomery values; returns the n coefficients of the permutation
+    product polynomial (constraint_system.rs:1197-1223)."""
+    w = np.ascontiguousarray(wires, dtype=np.uint64)
+    sg = np.ascontiguousarray(sigma_vals, dtype=np.uint64)
+    out = np.empty((1 << log_n, 4), dtype=np.uint64)
+    args = [np.ascontiguousarray(a, dtype=np.uint64) for a in (k_mont, beta, gamma)]
+    _chk(lib().orc_plonk_perm_product(curve, log_n, 5, _p(w), _p(sg), _p(args[0]), _p(args[1]), _p(args[2]), _p(out), threads))
     return out

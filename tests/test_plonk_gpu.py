@@ -121,3 +121,77 @@ def test_quotient_device_resident_and_errors(gpu, mj, cref):
     pk.release()
     with pytest.raises(mj.MzkError):
         mj.plonk.compute_quotient_polynomial(pk.__class__(c, 424242, n), ch, list(polys[18:23]), polys[23], polys[24])
+
+
+@pytest.mark.parametrize("curve_id", [0, 1])
+@pytest.mark.parametrize("log_n", [1, 4, 11, 14])
+def test_perm_product_matches_c_oracle(gpu, mj, cref, curve_id, log_n):
+    """Round 2 (N2): z = ifft(running product) against the restatement of constraint_system.rs:1197-1223
+    (one field division per gate there; shared inversions + a parallel prefix product here)."""
+    c = mj.params.CURVES[curve_id]
+    n = 1 << log_n
+    rng = random.Random(log_n + 100 * curve_id)
+    fixed = mj.params.random_fr_mont(c, 18 * n, seed=log_n + 5).reshape(18, n, 4)
+    k = [rng.randrange(1, c.r) for _ in range(5)]
+    pk = mj.plonk.ProvingKeyDevice.register(c, n, list(fixed[:13]), list(fixed[13:]), k)
+    wires = mj.params.random_fr_mont(c, 5 * n, seed=log_n + 6).reshape(5, n, 4)
+    beta, gamma = rng.randrange(c.r), rng.randrange(c.r)
+    got = mj.plonk.compute_prod_permutation_polynomial(pk, beta, gamma, wires)
+    sigma_vals = np.stack([cref.ntt(curve_id, fixed[13 + i], log_n, False, None, threads=4) for i in range(5)])
+    want = cref.plonk_perm_product(curve_id, log_n, wires, sigma_vals, mj.params.fr_to_mont(c, k), *mj.params.fr_to_mont(c, [beta, gamma]), threads=4)
+    assert np.array_equal(got, want)
+    pk.release()
+
+
+def test_perm_product_of_a_valid_permutation(gpu, mj, pyref):
+    """With sigma a true permutation of the extended identity and a witness that respects it, the grand
+    product telescopes: z(w^j) as computed, times the last row's ratio, returns to 1; the identity
+    permutation gives z = 1 exactly."""
+    c = mj.params.BLS12_381
+    pc = pyref.BLS12_381
+    log_n, n = 5, 32
+    r = c.r
+    rng = random.Random(3)
+    k = [1, 7, 13, 17, 23]
+    w_n = pc.root_of_unity(log_n)
+    ident = [[k[i] * pow(w_n, j, r) % r for j in range(n)] for i in range(5)]
+    # a permutation made of 3-cycles over random cells; cells of one cycle carry one witness value
+    cells = [(i, j) for i in range(5) for j in range(n)]
+    rng.shuffle(cells)
+    perm = {cell: cell for cell in cells}
+    wires = [[rng.randrange(r) for _ in range(n)] for _ in range(5)]
+    for q in range(0, 60, 3):
+        a, b, d = cells[q], cells[q + 1], cells[q + 2]
+        perm[a], perm[b], perm[d] = b, d, a
+        v = rng.randrange(r)
+        for (i, j) in (a, b, d):
+            wires[i][j] = v
+    sigma_vals = [[ident[perm[(i, j)][0]][perm[(i, j)][1]] for j in range(n)] for i in range(5)]
+    dom = mj.Radix2EvaluationDomain(c, log_n)
+    sigma_polys = [dom.ifft(fr_mont_limbs(c, sv)) for sv in sigma_vals]
+    zero_sel = [np.zeros((1, 4), dtype=np.uint64)] * 13
+    pk = mj.plonk.ProvingKeyDevice.register(c, n, zero_sel, sigma_polys, k)
+    beta, gamma = rng.randrange(r), rng.randrange(r)
+    z_poly = mj.plonk.compute_prod_permutation_polynomial(pk, beta, gamma, np.stack([fr_mont_limbs(c, col) for col in wires]))
+    z_vals = fr_from_mont_limbs(c, dom.fft(z_poly))
+    assert z_vals[0] == 1
+    num = den = 1
+    for i in range(5):
+        num = num * (wires[i][n - 1] + gamma + beta * ident[i][n - 1]) % r
+        den = den * (wires[i][n - 1] + gamma + beta * sigma_vals[i][n - 1]) % r
+    assert z_vals[n - 1] * num % r == den % r * 1, "grand product of a satisfied permutation must close to 1"
+    # a broken copy constraint does not close
+    wires[cells[0][0]][cells[0][1]] = (wires[cells[0][0]][cells[0][1]] + 1) % r
+    z_bad = fr_from_mont_limbs(c, dom.fft(mj.plonk.compute_prod_permutation_polynomial(pk, beta, gamma, np.stack([fr_mont_limbs(c, col) for col in wires]))))
+    num = den = 1
+    for i in range(5):
+        num = num * (wires[i][n - 1] + gamma + beta * ident[i][n - 1]) % r
+        den = den * (wires[i][n - 1] + gamma + beta * sigma_vals[i][n - 1]) % r
+    assert z_bad[n - 1] * num % r != den % r
+    pk.release()
+    # identity permutation: z == 1
+    id_polys = [fr_mont_limbs(c, [0, kj] + [0] * (n - 2)) for kj in k]
+    pk = mj.plonk.ProvingKeyDevice.register(c, n, zero_sel, id_polys, k)
+    z1 = mj.plonk.compute_prod_permutation_polynomial(pk, beta, gamma, mj.params.random_fr_mont(c, 5 * n, seed=1).reshape(5, n, 4))
+    assert fr_from_mont_limbs(c, z1) == [1] + [0] * (n - 1)
+    pk.release()
