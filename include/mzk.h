@@ -152,6 +152,21 @@ MZK_API int32_t mzk_plonk_perm_product_dev(uint64_t pk_handle, const void* d_wir
 MZK_API int32_t mzk_plonk_perm_product(uint64_t pk_handle, const uint64_t* wire_values, const uint64_t* beta_mont,
                                        const uint64_t* gamma_mont, uint64_t* out);
 
+/* ---- dense-polynomial primitives of prover rounds 4 and 5 on device-resident coefficient vectors ----
+ * evaluate: `DensePolynomial::evaluate` (plonk/src/proof_system/prover.rs:216-235): `batch` polynomials of
+ * `len` coefficients, `batch_stride` elements apart, all at the point x; out_mont: batch x 4 limbs on the
+ * HOST (the call synchronises). */
+MZK_API int32_t mzk_poly_eval_dev(int32_t curve_id, const void* d_coeffs, uint64_t len, uint32_t batch, uint64_t batch_stride,
+                                  const uint64_t* x_mont, uint64_t* out_mont, void* stream);
+/* out[j] = sum_k scalars[k] * polys[k][j], j < out_len (a polynomial shorter than out_len counts as zero beyond its
+ * length): `mul_poly` and the polynomial additions of prover.rs:302-358, 497-501, 1115-1122.  At most 32 terms;
+ * d_out may be one of the inputs.  scalars_mont: n_terms x 4 limbs, host.  Asynchronous. */
+MZK_API int32_t mzk_poly_lincomb_dev(int32_t curve_id, uint32_t n_terms, const void* const* d_polys, const uint64_t* lens,
+                                     const uint64_t* scalars_mont, void* d_out, uint64_t out_len, void* stream);
+/* quotient of p(X) / (X - z), len - 1 coefficients into d_out (remainder dropped, as ark-poly's `/` does at
+ * prover.rs:504-506).  d_out must not alias d_poly.  Asynchronous. */
+MZK_API int32_t mzk_poly_div_linear_dev(int32_t curve_id, const void* d_poly, uint64_t len, const uint64_t* z_mont, void* d_out, void* stream);
+
 /* ---- device memory helpers for bindings without HIP of their own ---- */
 MZK_API int32_t mzk_dev_alloc(uint64_t bytes, void** out_dptr);
 MZK_API int32_t mzk_dev_free(void* dptr);

@@ -38,7 +38,7 @@ struct DevBuf {
 };
 
 struct Workspace {
-    DevBuf ntt_scratch, scalars, hist, offs, cursor, sorted, buckets, collect, io, misc, digits, long_desc, long_parts, plonk_polys, plonk_out, pre_cnt, pre_off, pre_ce, pre_cb;
+    DevBuf ntt_scratch, scalars, hist, offs, cursor, sorted, buckets, collect, io, misc, digits, long_desc, long_parts, plonk_polys, plonk_out, pre_cnt, pre_off, pre_ce, pre_cb, poly_tmp;
     void* h_collect = nullptr;
     size_t h_collect_cap = 0;
     hipEvent_t last_use = nullptr;
@@ -87,6 +87,12 @@ int32_t srs_generate_dispatch(int curve, const uint32_t* beta_canon, uint64_t n,
 void jac_to_affine_host_dispatch(int curve, const uint64_t* xyz, uint64_t* xy);
 void jac_sum_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uint64_t* out);
 
+// poly.hip
+int32_t poly_eval_dispatch(int curve, const uint32_t* d_coeffs, uint64_t stride, uint64_t len, uint32_t batch, const uint32_t* x_mont, uint32_t* out_host,
+                           hipStream_t st);
+int32_t poly_div_dispatch(int curve, const uint32_t* d_poly, uint64_t len, const uint32_t* z_mont, uint32_t* d_out, hipStream_t st);
+int32_t poly_lincomb_dispatch(int curve, uint32_t n_terms, const uint32_t* const* d_polys, const uint64_t* lens, const uint32_t* scalars, uint32_t* d_out,
+                              uint64_t out_len, hipStream_t st);
 // plonk.hip
 int32_t plonk_pk_register(int curve, int log_n, int W, const uint32_t* sel, const uint32_t* sig, uint64_t poly_len, const uint32_t* k_mont,
                           uint64_t* out_handle);

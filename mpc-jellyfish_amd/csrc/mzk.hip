@@ -30,7 +30,7 @@ void DevBuf::release() {
     cap = 0;
 }
 void Workspace::release() {
-    for (DevBuf* b : {&ntt_scratch, &scalars, &hist, &offs, &cursor, &sorted, &buckets, &collect, &io, &misc, &digits, &long_desc, &long_parts, &plonk_polys, &plonk_out, &pre_cnt, &pre_off, &pre_ce, &pre_cb}) b->release();
+    for (DevBuf* b : {&ntt_scratch, &scalars, &hist, &offs, &cursor, &sorted, &buckets, &collect, &io, &misc, &digits, &long_desc, &long_parts, &plonk_polys, &plonk_out, &pre_cnt, &pre_off, &pre_ce, &pre_cb, &poly_tmp}) b->release();
     if (h_collect) (void)hipHostFree(h_collect);
     h_collect = nullptr;
     h_collect_cap = 0;
@@ -427,6 +427,34 @@ int32_t mzk_plonk_perm_product(uint64_t pk_handle, const uint64_t* wire_values, 
     HIP_TRY(hipMemcpyAsync(out, g_ws.plonk_out.p, n * 32, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return MZK_OK;
+}
+
+// ---- dense-polynomial primitives (prover rounds 4 and 5) ---------------------------------------------
+int32_t mzk_poly_eval_dev(int32_t curve_id, const void* d_coeffs, uint64_t len, uint32_t batch, uint64_t batch_stride, const uint64_t* x_mont,
+                          uint64_t* out_mont, void* stream) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    if ((!d_coeffs && len) || !x_mont || !out_mont || (batch > 1 && batch_stride < len) || batch > 65535) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
+    if (batch == 0) return MZK_OK;
+    return poly_eval_dispatch(curve_id, reinterpret_cast<const uint32_t*>(d_coeffs), batch_stride, len, batch, reinterpret_cast<const uint32_t*>(x_mont),
+                              reinterpret_cast<uint32_t*>(out_mont), (hipStream_t)stream);
+}
+int32_t mzk_poly_lincomb_dev(int32_t curve_id, uint32_t n_terms, const void* const* d_polys, const uint64_t* lens, const uint64_t* scalars_mont,
+                             void* d_out, uint64_t out_len, void* stream) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    if (n_terms && (!d_polys || !lens || !scalars_mont)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    if (!d_out && out_len) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    return poly_lincomb_dispatch(curve_id, n_terms, reinterpret_cast<const uint32_t* const*>(d_polys), lens, reinterpret_cast<const uint32_t*>(scalars_mont),
+                                 reinterpret_cast<uint32_t*>(d_out), out_len, (hipStream_t)stream);
+}
+int32_t mzk_poly_div_linear_dev(int32_t curve_id, const void* d_poly, uint64_t len, const uint64_t* z_mont, void* d_out, void* stream) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    if ((!d_poly || !d_out) && len > 1) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    if (!z_mont) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    return poly_div_dispatch(curve_id, reinterpret_cast<const uint32_t*>(d_poly), len, reinterpret_cast<const uint32_t*>(z_mont),
+                             reinterpret_cast<uint32_t*>(d_out), (hipStream_t)stream);
 }
 
 // ---- device memory helpers --------------------------------------------------------------------------

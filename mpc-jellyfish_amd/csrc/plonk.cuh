@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include "fp.cuh"
+#include "poly.cuh"
 
 namespace mzk {
 
@@ -246,20 +247,6 @@ __global__ __launch_bounds__(PLK_THREADS) void fr_scan_mul_apply_kernel(const ui
     if (j >= n) return;
     if (j == 0) store_fp<P>(out, F::one());
     if (j + 1 < n) store_fp<P>(out + (j + 1) * 8, load_fp<P>(totals + (j / SCAN_BLOCK) * 8) * load_fp<P>(incl + j * 8));
-}
-
-// omega[j] = w^j, 16 per thread
-template <class P>
-__global__ __launch_bounds__(PLK_THREADS) void fr_powers_mont_kernel(const uint32_t* __restrict__ w_mont, unsigned long long n, uint32_t* __restrict__ out) {
-    using F = Fp<P>;
-    const unsigned long long start = ((unsigned long long)blockIdx.x * PLK_THREADS + threadIdx.x) * 16;
-    if (start >= n) return;
-    const F w = load_fp<P>(w_mont);
-    F x = pow_u64(w, start);
-    for (int q = 0; q < 16 && start + q < n; q++) {
-        store_fp<P>(out + (start + q) * 8, x);
-        x = x * w;
-    }
 }
 
 }  // namespace mzk

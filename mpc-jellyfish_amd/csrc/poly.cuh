@@ -1,0 +1,194 @@
+// poly.cuh -- dense-polynomial primitives of prover rounds 4 and 5, on device-resident coefficient
+// vectors ("mul_poly/axpy chains, Horner evals, division by (X - z)"):
+//   evaluate        DensePolynomial::evaluate            plonk/src/proof_system/prover.rs:216-235 (a14)
+//   lincomb         mul_poly + poly additions            prover.rs:302-358, 1115-1122, 497-501   (a15, a16)
+//   div_linear      &batch_poly / &(X - z)               prover.rs:504-506                        (a16)
+// The reference evaluates with a serial Horner per polynomial and divides with a serial synthetic
+// division; here both are a strided Horner / a prefix sum so that every access is coalesced.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "fp.cuh"
+
+namespace mzk {
+
+constexpr int POLY_THREADS = 256;
+constexpr int POLY_EVAL_T = 16384;           // threads (= stride) per polynomial in the strided Horner
+constexpr int POLY_MAX_TERMS = 32;
+
+template <class P>
+__device__ __forceinline__ Fp<P> block_sum(Fp<P> v, uint4* sh) {
+    // tree sum over the 256 threads of a workgroup; result valid in thread 0
+    auto put = [&](int i, const Fp<P>& x) { sh[2 * i] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]); sh[2 * i + 1] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]); };
+    auto get = [&](int i) { Fp<P> x; uint4 p = sh[2 * i], q = sh[2 * i + 1]; x.l[0] = p.x; x.l[1] = p.y; x.l[2] = p.z; x.l[3] = p.w; x.l[4] = q.x; x.l[5] = q.y; x.l[6] = q.z; x.l[7] = q.w; return x; };
+    put(threadIdx.x, v);
+    __syncthreads();
+    for (int d = POLY_THREADS / 2; d > 0; d >>= 1) {
+        if ((int)threadIdx.x < d) { v = v + get(threadIdx.x + d); put(threadIdx.x, v); }
+        __syncthreads();
+    }
+    return v;
+}
+
+// partial[poly][block] = sum over the block's threads t of x^t * ( sum_k c[t + k T] y^k ),  y = x^T.
+// grid = (T / 256, batch)
+template <class P>
+__global__ __launch_bounds__(POLY_THREADS) void poly_eval_partial_kernel(const uint32_t* __restrict__ coeffs, unsigned long long stride, unsigned long long len,
+                                                                          const uint32_t* __restrict__ xpow /* [T] */, const uint32_t* __restrict__ y_mont,
+                                                                          uint32_t* __restrict__ partial) {
+    using F = Fp<P>;
+    __shared__ uint4 sh[2 * POLY_THREADS];
+    const unsigned long long t = (unsigned long long)blockIdx.x * POLY_THREADS + threadIdx.x;
+    const uint32_t* c = coeffs + (unsigned long long)blockIdx.y * stride * 8;
+    const F y = load_fp<P>(y_mont);
+    F acc = F::zero();
+    if (t < len) {
+        const unsigned long long kmax = (len - 1 - t) / POLY_EVAL_T;             // highest k with t + k T < len
+        acc = load_fp<P>(c + (t + kmax * POLY_EVAL_T) * 8);
+        for (unsigned long long k = kmax; k-- > 0;) acc = acc * y + load_fp<P>(c + (t + k * POLY_EVAL_T) * 8);
+        acc = acc * load_fp<P>(xpow + t * 8);
+    }
+    const F s = block_sum<P>(acc, sh);
+    if (threadIdx.x == 0) store_fp<P>(partial + ((size_t)blockIdx.y * gridDim.x + blockIdx.x) * 8, s);
+}
+// out[poly] = sum of that polynomial's partials; grid = batch, 256 threads
+template <class P>
+__global__ __launch_bounds__(POLY_THREADS) void poly_eval_final_kernel(const uint32_t* __restrict__ partial, int per_poly, uint32_t* __restrict__ out) {
+    using F = Fp<P>;
+    __shared__ uint4 sh[2 * POLY_THREADS];
+    F acc = F::zero();
+    for (int i = threadIdx.x; i < per_poly; i += POLY_THREADS) acc = acc + load_fp<P>(partial + ((size_t)blockIdx.x * per_poly + i) * 8);
+    const F s = block_sum<P>(acc, sh);
+    if (threadIdx.x == 0) store_fp<P>(out + (size_t)blockIdx.x * 8, s);
+}
+
+// out[j] = w^j (Montgomery), 16 per thread
+template <class P>
+__global__ __launch_bounds__(POLY_THREADS) void fr_powers_mont_kernel(const uint32_t* __restrict__ w_mont, unsigned long long n, uint32_t* __restrict__ out) {
+    using F = Fp<P>;
+    const unsigned long long start = ((unsigned long long)blockIdx.x * POLY_THREADS + threadIdx.x) * 16;
+    if (start >= n) return;
+    const F w = load_fp<P>(w_mont);
+    F x = pow_u64(w, start);
+    for (int q = 0; q < 16 && start + q < n; q++) {
+        store_fp<P>(out + (start + q) * 8, x);
+        x = x * w;
+    }
+}
+
+struct LincombArgs {
+    const uint32_t* poly[POLY_MAX_TERMS];
+    unsigned long long len[POLY_MAX_TERMS];
+    uint32_t scalar[POLY_MAX_TERMS][8];
+    int n_terms;
+    unsigned long long out_len;
+    uint32_t* out;
+};
+// out[j] = sum_k scalar_k * poly_k[j]   (poly_k[j] = 0 for j >= len_k); out may alias one of the inputs
+template <class P>
+__global__ __launch_bounds__(POLY_THREADS) void poly_lincomb_kernel(LincombArgs a) {
+    using F = Fp<P>;
+    const unsigned long long j = (unsigned long long)blockIdx.x * POLY_THREADS + threadIdx.x;
+    if (j >= a.out_len) return;
+    F acc = F::zero();
+    for (int k = 0; k < a.n_terms; k++) {
+        if (j < a.len[k]) {
+            F s;
+#pragma unroll
+            for (int q = 0; q < 8; q++) s.l[q] = a.scalar[k][q];
+            acc = acc + s * load_fp<P>(a.poly[k] + j * 8);
+        }
+    }
+    store_fp<P>(a.out + j * 8, acc);
+}
+
+// ---- division by (X - z): q_k = sum_{i>k} c_i z^(i-k-1) = z^-(k+1) * S_k,  S_k = sum_{i>k} c_i z^i ----
+// step 1: t[i] = c_i * z^i  (zpow table);  step 2: inclusive suffix sums inside 2048-blocks + block totals;
+// step 3: scan of totals;  step 4: q_k = (suffix_excl_k) * zinv^(k+1).
+constexpr int DIV_E = 8;
+constexpr int DIV_BLOCK = POLY_THREADS * DIV_E;
+
+template <class P>
+__global__ __launch_bounds__(POLY_THREADS) void poly_div_scale_kernel(const uint32_t* __restrict__ c, const uint32_t* __restrict__ zpow, unsigned long long len,
+                                                                       uint32_t* __restrict__ t) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * POLY_THREADS + threadIdx.x;
+    if (i < len) store_fp<P>(t + i * 8, load_fp<P>(c + i * 8) * load_fp<P>(zpow + i * 8));
+}
+// in-place inclusive suffix sum inside each block (indices descending), block total to totals[block]
+template <class P>
+__global__ __launch_bounds__(POLY_THREADS) void fr_suffix_add_block_kernel(uint32_t* __restrict__ data, unsigned long long n, uint32_t* __restrict__ totals) {
+    using F = Fp<P>;
+    __shared__ uint4 sh[2 * POLY_THREADS];
+    auto put = [&](int i, const F& x) { sh[2 * i] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]); sh[2 * i + 1] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]); };
+    auto get = [&](int i) { F x; uint4 p = sh[2 * i], q = sh[2 * i + 1]; x.l[0] = p.x; x.l[1] = p.y; x.l[2] = p.z; x.l[3] = p.w; x.l[4] = q.x; x.l[5] = q.y; x.l[6] = q.z; x.l[7] = q.w; return x; };
+    // thread r (reversed order) owns elements base .. base + E - 1, processed from the top
+    const int r = POLY_THREADS - 1 - threadIdx.x;           // r = 0 owns the highest indices
+    const unsigned long long base = (unsigned long long)blockIdx.x * DIV_BLOCK + (unsigned long long)threadIdx.x * DIV_E;
+    F v[DIV_E];
+    F run = F::zero();
+#pragma unroll
+    for (int q = DIV_E - 1; q >= 0; q--) {
+        const F x = base + q < n ? load_fp<P>(data + (base + q) * 8) : F::zero();
+        run = run + x;
+        v[q] = run;
+    }
+    F incl = run;
+    put(r, incl);
+    __syncthreads();
+    for (int d = 1; d < POLY_THREADS; d <<= 1) {
+        F other = F::zero();
+        const bool has = r >= d;
+        if (has) other = get(r - d);
+        __syncthreads();
+        if (has) incl = incl + other;
+        put(r, incl);
+        __syncthreads();
+    }
+    const F excl = r ? get(r - 1) : F::zero();
+#pragma unroll
+    for (int q = 0; q < DIV_E; q++)
+        if (base + q < n) store_fp<P>(data + (base + q) * 8, excl + v[q]);
+    if (r == POLY_THREADS - 1) store_fp<P>(totals + (size_t)blockIdx.x * 8, incl);
+}
+// totals[b] <- sum of totals of blocks above b (exclusive suffix), one 1024-thread workgroup
+template <class P>
+__global__ __launch_bounds__(1024) void fr_suffix_add_totals_kernel(uint32_t* __restrict__ totals, unsigned int n_blocks) {
+    using F = Fp<P>;
+    __shared__ uint4 sh[2 * 1024];
+    auto put = [&](int i, const F& x) { sh[2 * i] = make_uint4(x.l[0], x.l[1], x.l[2], x.l[3]); sh[2 * i + 1] = make_uint4(x.l[4], x.l[5], x.l[6], x.l[7]); };
+    auto get = [&](int i) { F x; uint4 p = sh[2 * i], q = sh[2 * i + 1]; x.l[0] = p.x; x.l[1] = p.y; x.l[2] = p.z; x.l[3] = p.w; x.l[4] = q.x; x.l[5] = q.y; x.l[6] = q.z; x.l[7] = q.w; return x; };
+    const unsigned int per = (n_blocks + 1023) / 1024;
+    const int r = 1023 - (int)threadIdx.x;                       // r = 0 owns the highest blocks
+    const unsigned int lo = threadIdx.x * per, hi = min(n_blocks, lo + per);
+    F mine = F::zero();
+    for (unsigned int b = lo; b < hi; b++) mine = mine + load_fp<P>(totals + (size_t)b * 8);
+    F incl = mine;
+    put(r, incl);
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        F other = F::zero();
+        const bool has = r >= d;
+        if (has) other = get(r - d);
+        __syncthreads();
+        if (has) incl = incl + other;
+        put(r, incl);
+        __syncthreads();
+    }
+    F run = r ? get(r - 1) : F::zero();                          // everything above this thread's blocks
+    for (unsigned int b = hi; b-- > lo;) {
+        const F t = load_fp<P>(totals + (size_t)b * 8);
+        store_fp<P>(totals + (size_t)b * 8, run);
+        run = run + t;
+    }
+}
+// q[k] = (S_incl[k+1] + above(block(k+1))) * zinv^(k+1), k < len - 1
+template <class P>
+__global__ __launch_bounds__(POLY_THREADS) void poly_div_finish_kernel(const uint32_t* __restrict__ sfx, const uint32_t* __restrict__ totals,
+                                                                        const uint32_t* __restrict__ zinvpow, unsigned long long len, uint32_t* __restrict__ q) {
+    const unsigned long long k = (unsigned long long)blockIdx.x * POLY_THREADS + threadIdx.x;
+    if (k + 1 >= len) return;
+    const Fp<P> s = load_fp<P>(sfx + (k + 1) * 8) + load_fp<P>(totals + ((k + 1) / DIV_BLOCK) * 8);
+    store_fp<P>(q + k * 8, s * load_fp<P>(zinvpow + (k + 1) * 8));
+}
+
+}  // namespace mzk

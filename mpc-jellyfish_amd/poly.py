@@ -1,0 +1,70 @@
+"""Dense-polynomial primitives of prover rounds 4 and 5 on device-resident coefficient vectors --
+mirror of the ark-poly `DensePolynomial` operations the jf-plonk prover uses there:
+
+    poly.evaluate(&zeta)                          plonk/src/proof_system/prover.rs:216-235
+    mul_poly(&p, &c), p + q                       prover.rs:302-358, 1115-1122, 497-501
+    &batch_poly / &(X - z)                        prover.rs:504-506
+
+Coefficient vectors are (len, 4) int64 CUDA tensors (Montgomery limbs); scalars are Python ints.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import lib as _lib
+from .params import curve as _curve, fr_from_mont, fr_to_mont
+
+
+def _stream(t, stream):
+    import torch
+    return torch.cuda.current_stream(t.device).cuda_stream if stream is None else stream
+
+
+def evaluate(curve, polys_dev, x: int, length: int | None = None) -> list[int]:
+    """polys_dev: (len, 4) or (batch, stride, 4) CUDA tensor; every polynomial is evaluated at x over its
+    first `length` coefficients.  Returns canonical Python ints (the call synchronises)."""
+    c = _curve(curve)
+    t = polys_dev
+    if t.dim() == 2:
+        batch, stride = 1, t.shape[0]
+    else:
+        batch, stride = t.shape[0], t.shape[1]
+    n = stride if length is None else length
+    assert t.is_cuda and t.is_contiguous() and t.shape[-1] == 4 and n <= stride
+    xm = fr_to_mont(c, [x])[0]
+    out = np.empty((batch, 4), dtype=np.uint64)
+    _lib.check(_lib.ensure_init().mzk_poly_eval_dev(c.curve_id, t.data_ptr(), n, batch, stride, xm.ctypes.data_as(C.c_void_p),
+                                                    out.ctypes.data_as(C.c_void_p), _stream(t, None)), "mzk_poly_eval_dev")
+    return fr_from_mont(c, out)
+
+
+def lincomb(curve, terms, out_len: int | None = None, out=None, stream=None):
+    """terms: list of (scalar:int, poly:(len,4) CUDA tensor).  Returns sum_k scalar_k * poly_k as a
+    (out_len, 4) CUDA tensor (default: the longest input)."""
+    import torch
+    c = _curve(curve)
+    k = len(terms)
+    polys = [p for _, p in terms]
+    n_out = max(p.shape[0] for p in polys) if out_len is None else out_len
+    if out is None:
+        out = torch.empty((n_out, 4), dtype=torch.int64, device=polys[0].device)
+    ptrs = (C.c_void_p * k)(*[p.data_ptr() for p in polys])
+    lens = (C.c_uint64 * k)(*[p.shape[0] for p in polys])
+    sc = fr_to_mont(c, [s for s, _ in terms])
+    _lib.check(_lib.ensure_init().mzk_poly_lincomb_dev(c.curve_id, k, ptrs, lens, sc.ctypes.data_as(C.c_void_p), out.data_ptr(), n_out,
+                                                       _stream(out, stream)), "mzk_poly_lincomb_dev")
+    return out
+
+
+def div_by_linear(curve, poly_dev, z: int, stream=None):
+    """Quotient of p(X) / (X - z) as a (len-1, 4) CUDA tensor (remainder dropped, as ark-poly does)."""
+    import torch
+    c = _curve(curve)
+    n = poly_dev.shape[0]
+    out = torch.zeros((max(n - 1, 0), 4), dtype=torch.int64, device=poly_dev.device)
+    zm = fr_to_mont(c, [z])[0]
+    _lib.check(_lib.ensure_init().mzk_poly_div_linear_dev(c.curve_id, poly_dev.data_ptr(), n, zm.ctypes.data_as(C.c_void_p), out.data_ptr(),
+                                                          _stream(poly_dev, stream)), "mzk_poly_div_linear_dev")
+    return out

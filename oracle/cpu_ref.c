@@ -197,6 +197,35 @@ EXPORT int orc_poly_eval(int curve, const u64 *coeffs, size_t n, const u64 *x_mo
     return 0;
 }
 
+/* quotient of p(X) / (X - z) by synthetic division, len-1 coefficients (ark-poly's `/`, used at prover.rs:504-506) */
+EXPORT int orc_poly_div_linear(int curve, const u64 *coeffs, size_t len, const u64 *z_mont, u64 *out) {
+    if (len < 2) return 0;
+    if (curve == 0) {
+        blsfr_t z, q; memcpy(&z, z_mont, 32); memcpy(&q, coeffs + 4 * (len - 1), 32);
+        for (size_t k = len - 1; k-- > 0;) { memcpy(out + 4 * k, &q, 32); blsfr_mul(&q, &q, &z); blsfr_add(&q, &q, (const blsfr_t *)(coeffs + 4 * k)); }
+    } else if (curve == 1) {
+        bnfr_t z, q; memcpy(&z, z_mont, 32); memcpy(&q, coeffs + 4 * (len - 1), 32);
+        for (size_t k = len - 1; k-- > 0;) { memcpy(out + 4 * k, &q, 32); bnfr_mul(&q, &q, &z); bnfr_add(&q, &q, (const bnfr_t *)(coeffs + 4 * k)); }
+    } else return -2;
+    return 0;
+}
+
+/* out[j] = sum_k scalars[k] * polys[k][j]; polys are n_terms rows of `stride` elements, row k valid for lens[k] */
+EXPORT int orc_poly_lincomb(int curve, int n_terms, const u64 *polys, size_t stride, const size_t *lens, const u64 *scalars, u64 *out, size_t out_len) {
+    for (size_t j = 0; j < out_len; j++) {
+        if (curve == 0) {
+            blsfr_t acc, t; memset(&acc, 0, sizeof acc);
+            for (int k = 0; k < n_terms; k++) if (j < lens[k]) { blsfr_mul(&t, (const blsfr_t *)(scalars + 4 * k), (const blsfr_t *)(polys + ((size_t)k * stride + j) * 4)); blsfr_add(&acc, &acc, &t); }
+            memcpy(out + 4 * j, &acc, 32);
+        } else if (curve == 1) {
+            bnfr_t acc, t; memset(&acc, 0, sizeof acc);
+            for (int k = 0; k < n_terms; k++) if (j < lens[k]) { bnfr_mul(&t, (const bnfr_t *)(scalars + 4 * k), (const bnfr_t *)(polys + ((size_t)k * stride + j) * 4)); bnfr_add(&acc, &acc, &t); }
+            memcpy(out + 4 * j, &acc, 32);
+        } else return -2;
+    }
+    return 0;
+}
+
 /* omega_N^k * offset as a Montgomery element (domain.element(k)) */
 EXPORT int orc_domain_element(int curve, int log_n, u64 k, const u64 *coset_mont, u64 *out_mont) {
     u64 e[1] = {k};

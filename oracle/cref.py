@@ -41,6 +41,8 @@ def lib():
         L.orc_g1_count_off_curve.restype = C.c_long
         L.orc_plonk_quotient.argtypes = [C.c_int, C.c_int, C.c_int, u64p, C.c_size_t, u64p, u64p, u64p, u64p, u64p, C.c_int]
         L.orc_plonk_perm_product.argtypes = [C.c_int, C.c_int, C.c_int, u64p, u64p, u64p, u64p, u64p, u64p, C.c_int]
+        L.orc_poly_div_linear.argtypes = [C.c_int, u64p, C.c_size_t, u64p, u64p]
+        L.orc_poly_lincomb.argtypes = [C.c_int, C.c_int, u64p, C.c_size_t, C.POINTER(C.c_size_t), u64p, u64p, C.c_size_t]
         _LIB = L
     return _LIB
 
@@ -186,4 +188,26 @@ def plonk_perm_product(curve: int, log_n: int, wires: np.ndarray, sigma_vals: np
     out = np.empty((1 << log_n, 4), dtype=np.uint64)
     args = [np.ascontiguousarray(a, dtype=np.uint64) for a in (k_mont, beta, gamma)]
     _chk(lib().orc_plonk_perm_product(curve, log_n, 5, _p(w), _p(sg), _p(args[0]), _p(args[1]), _p(args[2]), _p(out), threads))
+    return out
+
+
+def poly_div_linear(curve: int, coeffs: np.ndarray, z_mont: np.ndarray) -> np.ndarray:
+    """Quotient of p(X) / (X - z): (len-1, 4)."""
+    c = np.ascontiguousarray(coeffs, dtype=np.uint64).reshape(-1, 4)
+    out = np.zeros((max(c.shape[0] - 1, 0), 4), dtype=np.uint64)
+    if c.shape[0] >= 2:
+        _chk(lib().orc_poly_div_linear(curve, _p(c), c.shape[0], _p(np.ascontiguousarray(z_mont, dtype=np.uint64)), _p(out)))
+    return out
+
+
+def poly_lincomb(curve: int, polys, scalars_mont: np.ndarray, out_len: int) -> np.ndarray:
+    """sum_k scalars[k] * polys[k], polys a list of (len_k, 4) arrays."""
+    stride = max([p.shape[0] for p in polys] + [1])
+    slab = np.zeros((len(polys), stride, 4), dtype=np.uint64)
+    lens = (C.c_size_t * len(polys))()
+    for k, p in enumerate(polys):
+        slab[k, :p.shape[0]] = p
+        lens[k] = p.shape[0]
+    out = np.empty((out_len, 4), dtype=np.uint64)
+    _chk(lib().orc_poly_lincomb(curve, len(polys), _p(slab), stride, lens, _p(np.ascontiguousarray(scalars_mont, dtype=np.uint64)), _p(out), out_len))
     return out
