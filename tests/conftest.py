@@ -111,3 +111,46 @@ def jacobian_to_affine_ints(c, xyz):
 
 def golden_pt(p):
     return None if p is None else (int(p[0], 16), int(p[1], 16))
+
+
+def build_circuit(c, log_n, rng):
+    """selectors (13 x n), sigma values (5 x n), k, wires (5 x n), public input (n): gates on every 4th
+    row family as in test_plonk_gpu, copy constraints as 3-cycles between free cells."""
+    n, r = 1 << log_n, c.r
+    k = [1, 7, 13, 17, 23]
+    w_n = c.root_of_unity(log_n)
+    w = [[rng.randrange(r) for _ in range(n)] for _ in range(5)]
+    sel = [[0] * n for _ in range(13)]
+    free = []
+    for i in range(n):
+        kind = i % 4
+        if kind == 0:
+            sel[0][i] = sel[1][i] = 1; sel[10][i] = 1
+            w[4][i] = (w[0][i] + w[1][i]) % r
+            free += [(2, i), (3, i)]
+        elif kind == 1:
+            sel[4][i] = 3; sel[5][i] = 1; sel[10][i] = 1
+            w[4][i] = (3 * w[0][i] * w[1][i] + w[2][i] * w[3][i]) % r
+        elif kind == 2:
+            sel[6][i] = 1; sel[9][i] = 2; sel[10][i] = 1
+            w[4][i] = (pow(w[0][i], 5, r) + 2 * pow(w[3][i], 5, r)) % r
+            free += [(1, i), (2, i)]
+        else:
+            free += [(j, i) for j in range(5)]          # no gate on this row: every cell is free
+    pi = [0] * n
+    # public input on row 3: q_c + pi + ... = 0 with all selectors 0 except q_lc0 = ... keep it simple: pi = -q_c
+    sel[11][3] = 5
+    pi[3] = r - 5
+    ident = [[k[i] * pow(w_n, j, r) % r for j in range(n)] for i in range(5)]
+    perm = {(i, j): (i, j) for i in range(5) for j in range(n)}
+    rng.shuffle(free)
+    for q in range(0, len(free) - 2, 3):
+        a, b, d = free[q], free[q + 1], free[q + 2]
+        perm[a], perm[b], perm[d] = b, d, a
+        v = rng.randrange(r)
+        for (i, j) in (a, b, d):
+            w[i][j] = v
+    sigma_vals = [[ident[perm[(i, j)][0]][perm[(i, j)][1]] for j in range(n)] for i in range(5)]
+    return sel, sigma_vals, k, w, pi
+
+

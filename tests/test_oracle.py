@@ -4,7 +4,7 @@ import random
 
 import numpy as np
 
-from conftest import (affine_from_limbs, affine_limbs, fr_from_mont_limbs, fr_mont_limbs, golden_pt,
+from conftest import (affine_from_limbs, affine_limbs, build_circuit, fr_from_mont_limbs, fr_mont_limbs, golden_pt,
                       jacobian_to_affine_ints, limbs_ints, load_golden)
 
 
@@ -91,3 +91,36 @@ def test_c_oracle_field_and_group_helpers(pyref, cref):
         assert cref.count_off_curve(c.curve_id, bases) == 0
         assert affine_from_limbs(c, bases[8]) == pyref.g1_mul(c, 11 + 5 * 8, pyref.g1_gen(c))
         assert affine_from_limbs(c, cref.g1_mul(c.curve_id, bases[2], c.r - 1)) == pyref.g1_neg(c, pyref.g1_mul(c, 21, pyref.g1_gen(c)))
+
+
+def test_plonk_restatements_agree(pyref, cref):
+    """The two prover oracles pin each other on a satisfied circuit: pyref_plonk (schoolbook polynomial
+    arithmetic, exact division by X^n - 1) against cpu_ref.c's restatement of the reference's own method
+    (coset FFTs + pointwise closure, prover.rs:512-759) and of the grand product (constraint_system.rs:1197-1223)."""
+    import pyref_plonk as PP
+    for curve_id, log_n in ((0, 3), (1, 4)):
+        c = pyref.CURVES[curve_id]
+        n, r = 1 << log_n, c.r
+        rng = random.Random(77 + curve_id)
+        sel, sigma_vals, k, w, pi = build_circuit(c, log_n, rng)
+        blind = {"wires": [[rng.randrange(r), rng.randrange(r)] for _ in range(5)], "z": [rng.randrange(r) for _ in range(3)],
+                 "quot": [rng.randrange(r) for _ in range(4)]}
+        ch = {x: rng.randrange(r) for x in ("beta", "gamma", "alpha", "zeta", "v")}
+        want = PP.prove_core(c, log_n, sel, sigma_vals, k, w, pi, blind, ch, srs_beta=rng.randrange(r))
+        assert want["divisible"] and want["quot_degree_ok"]
+        # grand product: C restatement (unmasked) + mask == pyref_plonk's z
+        kz = fr_mont_limbs(c, k)
+        z_c = cref.plonk_perm_product(curve_id, log_n, np.stack([fr_mont_limbs(c, col) for col in w]),
+                                      np.stack([fr_mont_limbs(c, col) for col in sigma_vals]), kz, *fr_mont_limbs(c, [ch["beta"], ch["gamma"]]))
+        assert PP.pstrip(PP.mask(c, fr_from_mont_limbs(c, z_c), blind["z"], n)) == PP.pstrip(want["z_poly"])
+        # quotient: C restatement on the masked polynomials == schoolbook quotient
+        plen = n + 3
+        polys = np.zeros((25, plen, 4), dtype=np.uint64)
+        rows = want["selectors"] + want["sigmas"] + want["wire_polys"] + [want["z_poly"], want["pi_poly"]]
+        for i, p in enumerate(rows):
+            polys[i, :len(p)] = fr_mont_limbs(c, p)
+        q_c = cref.plonk_quotient(curve_id, log_n, polys, kz, *fr_mont_limbs(c, [ch["alpha"], ch["beta"], ch["gamma"]]), threads=2)
+        assert PP.pstrip(fr_from_mont_limbs(c, q_c)) == PP.pstrip(want["quot"])
+        # an unsatisfied witness is not divisible
+        w[4][0] = (w[4][0] + 1) % r
+        assert not PP.prove_core(c, log_n, sel, sigma_vals, k, w, pi, blind, ch)["divisible"]
