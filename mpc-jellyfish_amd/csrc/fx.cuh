@@ -75,9 +75,40 @@ MZK_HD Fx<X> fx_mul(const Fx<X>& x, const Fx<X>& y) {
     t.l[N - 1] = (uint32_t)acc;
     return t;
 }
+// x^2/R': the off-diagonal products x_i*x_j (i < j) are taken once against the doubled operand 2*x_j
+// (limbs < 2^30: no overflow, and a column still sums to < 2^64), so the x*x half needs N(N+1)/2
+// multiply-adds instead of N^2 -- 23 % fewer v_mad_u64_u32 per squaring at 14 limbs.  Same contract as fx_mul.
 template <class X>
 MZK_HD Fx<X> fx_sqr(const Fx<X>& x) {
-    return fx_mul(x, x);
+    constexpr int N = X::XN;
+    uint32_t m[N], x2[N];
+    Fx<X> t;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) x2[i] = x.l[i] << 1;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+#pragma unroll
+        for (int i = 0; 2 * i < k; i++) acc += (uint64_t)x.l[i] * x2[k - i];
+        if (k % 2 == 0) acc += (uint64_t)x.l[k / 2] * x.l[k / 2];
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * X::XP[k - i];
+        m[k] = ((uint32_t)acc * X::XINV) & XMASK;
+        acc += (uint64_t)m[k] * X::XP[0];
+        acc >>= XL;
+    }
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; k++) {
+#pragma unroll
+        for (int i = k - N + 1; 2 * i < k; i++) acc += (uint64_t)x.l[i] * x2[k - i];
+        if (k % 2 == 0) acc += (uint64_t)x.l[k / 2] * x.l[k / 2];
+#pragma unroll
+        for (int i = k - N + 1; i < N; i++) acc += (uint64_t)m[i] * X::XP[k - i];
+        t.l[k - N] = (uint32_t)acc & XMASK;
+        acc >>= XL;
+    }
+    t.l[N - 1] = (uint32_t)acc;
+    return t;
 }
 
 template <class X>

@@ -25,8 +25,10 @@ __global__ void kcheck(const uint32_t* in, uint32_t* bad) {
     cmp(fx_mul(Bi, Fx<X>::from_const(X::XFROM)), b, 8);
     cmp(fx_mul(fx_norm(fx_sub8(fx_add(A, B), fx_add(B, C))), Fx<X>::one()), a - c, 16);      // (a+b)-(b+c)
     Fx<X> s = fx_add(fx_add(A, B), fx_add(C, A));                                              // lazy sum < 4p
-    cmp(fx_mul(fx_norm(fx_sub32(fx_add(s, s), s)), Fx<X>::one()), a + a + b + c, 32);
+    cmp(fx_mul(fx_norm(fx_sub32(fx_norm(fx_add(s, s)), s)), Fx<X>::one()), a + a + b + c, 32);
     cmp(fx_mul(fx_norm(fx_mul(A, Bi)), Ci), (a * b) * c, 64);
+    cmp(fx_mul(fx_sqr(fx_norm(fx_add(A, B))), Fx<X>::from_const(X::XTO)), (a + b) * (a + b), 128);          // (a+b)^2 R: sqr gives (a+b)^2 R^2/R'
+    cmp(fx_mul(fx_sqr(Bi), Fx<X>::from_const(X::XFROM)), b * b, 256);
     bad[t] = err;
 }
 
