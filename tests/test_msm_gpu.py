@@ -192,3 +192,41 @@ def test_msm_batch_fused(gpu, mj, cref):
     jac2 = mj.msm_bigint_batch(pp, dev_sets, offs, scalars_are_mont=True)
     assert np.array_equal(mj.jacobian_to_affine(c, jac2), aff)
     pp.release()
+
+
+def test_msm_precomputed_table_path(gpu, mj, cref):
+    """n >= 2^17 over a BLS12-381 SRS runs on the precomputed-multiples table (one bucket set, c >= 18):
+    sub-ranges of the SRS (base_offset), a batch mixing table and plain paths, and the switch that turns
+    the table off must all give the oracle's point."""
+    curve_id = 0
+    c = mj.params.CURVES[curve_id]
+    n_srs = (1 << 17) + 64
+    bases = cref.g1_arith_bases(curve_id, 0xfeed, 0x1d, n_srs)
+    pp = mj.UnivariateProverParam.from_affine(curve_id, bases)
+    scalars = mj.params.random_fr_mont(c, n_srs, seed=171)
+    scalars[5] = 0
+    scalars[6] = _bigints([c.r - 1])[0]
+    cases = [(0, n_srs), (7, 1 << 17), (64, 1 << 17), (3, (1 << 17) + 11)]
+    for off, n in cases:
+        want = cref.jac_to_affine(curve_id, cref.msm(curve_id, bases[off:off + n], scalars[:n], threads=8))[0]
+        got = cref.jac_to_affine(curve_id, mj.msm_bigint(pp, scalars[:n], base_offset=off))[0]
+        assert np.array_equal(got, want), (off, n)
+    assert mj.lib.msm_last_shape()[0] >= 18, "large MSMs must have taken the precomputed-table path"
+    # batch: large (table) and small (plain) members interleaved
+    sets = [scalars[:1 << 17], scalars[:1000], scalars[:(1 << 17) + 3], scalars[:0]]
+    offs = [1, 2, 0, 0]
+    jac = mj.msm_bigint_batch(pp, sets, offs)
+    for i, (s, o) in enumerate(zip(sets, offs)):
+        want = cref.jac_to_affine(curve_id, cref.msm(curve_id, bases[o:o + len(s)], s, threads=8))[0]
+        assert np.array_equal(cref.jac_to_affine(curve_id, jac[i])[0], want), i
+    # same result with the table disabled
+    L = mj.load()
+    L.mzk_msm_set_precompute(0)
+    try:
+        got = cref.jac_to_affine(curve_id, mj.msm_bigint(pp, scalars[:1 << 17], base_offset=7))[0]
+        assert mj.lib.msm_last_shape()[0] <= 16
+    finally:
+        L.mzk_msm_set_precompute(1)
+    want = cref.jac_to_affine(curve_id, cref.msm(curve_id, bases[7:7 + (1 << 17)], scalars[:1 << 17], threads=8))[0]
+    assert np.array_equal(got, want)
+    pp.release()
