@@ -9,9 +9,10 @@ polynomials kept in HBM between rounds (SURVEY.md 8(f) N1 + N2).
     round 4  compute_evaluations                 prover.rs:216-235
     round 5  linearisation + opening proofs      prover.rs:302-358, 362-419, 490-509, 963-1035
 
-What is NOT here: the Fiat-Shamir transcript and the blinding RNG.  Challenges and
-blinding scalars are inputs, exactly as the reference's own per-round tests fix them
-(multiprover/proof_system/prover.rs:1316-1556); a Rust caller supplies them from its transcript.
+Challenges come either from the caller (`ProverChallenges`: the way the reference's own per-round tests
+fix them, multiprover/proof_system/prover.rs:1316-1556) or from the Merlin transcript mirror
+(`transcript.StandardTranscript`, message order of snark.rs:263-431).  The blinding RNG (`test_rng`, ChaCha)
+is not restated: blinding scalars are inputs.
 """
 from __future__ import annotations
 
@@ -20,6 +21,7 @@ from dataclasses import dataclass, field
 import numpy as np
 
 from . import kzg, plonk, poly
+from . import transcript as _transcript
 from .domain import Radix2EvaluationDomain
 from .params import CurveParams, curve as _curve, fr_to_mont
 
@@ -40,6 +42,72 @@ class ProverChallenges:
     alpha: int
     zeta: int
     v: int
+
+
+class FixedChallenges:
+    """Challenge source with externally fixed values."""
+
+    def __init__(self, ch: ProverChallenges):
+        self.ch = ch
+
+    def after_round1(self, wires_comms):
+        return self.ch.beta, self.ch.gamma
+
+    def after_round2(self, z_comm):
+        return self.ch.alpha
+
+    def after_round3(self, split_comms):
+        return self.ch.zeta
+
+    def after_round4(self, wires_evals, wire_sigma_evals, perm_next_eval):
+        return self.ch.v
+
+
+class TranscriptChallenges:
+    """Challenge source following batch_prove_internal (snark.rs:263-431) on a StandardTranscript."""
+
+    def __init__(self, prover: "TurboPlonkProver", pub_input, extra_msg: bytes | None = None):
+        c = prover.curve
+        self.c = c
+        self.t = _transcript.StandardTranscript(c, b"PlonkProof")
+        if extra_msg is not None:
+            self.t.append_message(b"extra info", extra_msg)
+        sel, sig = prover.vk_commitments()
+        self.t.append_vk_and_pub_input(prover.n, len(pub_input), prover.k, [self._pt(x) for x in sel], [self._pt(x) for x in sig], pub_input)
+        self.challenges = {}
+
+    def _pt(self, comm: kzg.Commitment):
+        if comm.is_infinity():
+            return None
+        from .params import fq_from_mont
+        x, y = fq_from_mont(self.c, comm.xy)
+        return (x, y)
+
+    def _squeeze(self, name: str) -> int:
+        v = self.t.get_and_append_challenge(name.encode())
+        self.challenges[name] = v
+        return v
+
+    def after_round1(self, wires_comms):
+        self.t.append_commitments(b"witness_poly_comms", [self._pt(cm) for cm in wires_comms])
+        self._squeeze("tau")                                   # squeezed even without Plookup (snark.rs:293)
+        return self._squeeze("beta"), self._squeeze("gamma")
+
+    def after_round2(self, z_comm):
+        self.t.append_commitment(b"perm_poly_comms", self._pt(z_comm))
+        return self._squeeze("alpha")
+
+    def after_round3(self, split_comms):
+        self.t.append_commitments(b"quot_poly_comms", [self._pt(cm) for cm in split_comms])
+        return self._squeeze("zeta")
+
+    def after_round4(self, wires_evals, wire_sigma_evals, perm_next_eval):
+        for e in wires_evals:
+            self.t.append_field_elem(b"wire_evals", e)
+        for e in wire_sigma_evals:
+            self.t.append_field_elem(b"wire_sigma_evals", e)
+        self.t.append_field_elem(b"perm_next_eval", perm_next_eval)
+        return self._squeeze("v")
 
 
 @dataclass
@@ -74,6 +142,14 @@ class TurboPlonkProver:
         self.domain = Radix2EvaluationDomain(self.curve, self.log_n)
         self.w_n = pow(self.curve.fr_generator, (self.curve.r - 1) >> self.log_n, self.curve.r)
 
+    def vk_commitments(self):
+        """selector_comms, sigma_comms of the verifying key (preprocess, snark.rs:562-594): 18 commits, cached."""
+        if getattr(self, "_vk", None) is None:
+            jac = kzg.msm_bigint_batch(self.ck, [self.fixed[i] for i in range(18)], scalars_are_mont=True)
+            xy = kzg.jacobian_to_affine(self.curve, jac)
+            self._vk = ([kzg.Commitment(self.curve, xy[i]) for i in range(13)], [kzg.Commitment(self.curve, xy[13 + i]) for i in range(5)])
+        return self._vk
+
     def release(self):
         self.pk.release()
 
@@ -89,7 +165,9 @@ class TurboPlonkProver:
         poly.lincomb(self.curve, [(one, head), (one, nb)], out=t[row, :h])
         t[row, self.n:self.n + h] = b
 
-    def prove(self, wire_values, pub_input_values, ch: ProverChallenges, blind: Blinders, profile: bool = False) -> ProofCore:
+    def prove(self, wire_values, pub_input_values, ch, blind: Blinders, profile: bool = False) -> ProofCore:
+        """ch: ProverChallenges (fixed) or a challenge source (FixedChallenges / TranscriptChallenges)."""
+        src = FixedChallenges(ch) if isinstance(ch, ProverChallenges) else ch
         import time
         import torch
         c, n, r = self.curve, self.n, self.curve.r
@@ -124,7 +202,8 @@ class TurboPlonkProver:
         tick("r1_commit", t0)
         # ---- round 2 (prover.rs:125-141; constraint_system.rs:1197-1223)
         t0 = time.perf_counter()
-        bg = fr_to_mont(c, [ch.beta, ch.gamma])
+        beta, gamma = src.after_round1(wires_comms)
+        bg = fr_to_mont(c, [beta, gamma])
         from . import lib as _lib
         import ctypes as C
         _lib.check(_lib.ensure_init().mzk_plonk_perm_product_dev(self.pk.handle, wv.data_ptr(), bg[0].ctypes.data_as(C.c_void_p),
@@ -141,7 +220,8 @@ class TurboPlonkProver:
         t0 = time.perf_counter()
         keep = slab[:6, :n + 3].clone()                                  # coefficient forms survive the in-place coset NTT
         quot = torch.empty((m, 4), dtype=torch.int64, device=dev)
-        plonk.compute_quotient_polynomial_dev(self.pk, plonk.Challenges(ch.alpha, ch.beta, ch.gamma), slab, n + 3, quot)
+        alpha = src.after_round2(z_comm)
+        plonk.compute_quotient_polynomial_dev(self.pk, plonk.Challenges(alpha, beta, gamma), slab, n + 3, quot)
         tick("r3_quotient", t0)
         t0 = time.perf_counter()
         expected = 5 * (n + 1) + 2
@@ -168,13 +248,15 @@ class TurboPlonkProver:
         t0 = time.perf_counter()
         wire_polys = [keep[i, :n + 2] for i in range(5)]
         z_poly = keep[5]
-        wires_evals = poly.evaluate(c, keep[:5], ch.zeta, length=n + 2)
-        wire_sigma_evals = poly.evaluate(c, self.fixed[13:17], ch.zeta)
-        perm_next_eval = poly.evaluate(c, z_poly, ch.zeta * self.w_n % r)[0]
+        zeta = src.after_round3(split_comms)
+        wires_evals = poly.evaluate(c, keep[:5], zeta, length=n + 2)
+        wire_sigma_evals = poly.evaluate(c, self.fixed[13:17], zeta)
+        perm_next_eval = poly.evaluate(c, z_poly, zeta * self.w_n % r)[0]
         tick("r4_evals", t0)
         # ---- round 5: linearisation polynomial (prover.rs:963-1035, 343-358) and openings (362-419, 490-509)
         t0 = time.perf_counter()
-        we, beta, gamma, alpha, zeta = wires_evals, ch.beta, ch.gamma, ch.alpha, ch.zeta
+        v_ch = src.after_round4(wires_evals, wire_sigma_evals, perm_next_eval)
+        we = wires_evals
         sel = self.fixed
         terms = [(we[j], sel[j]) for j in range(4)]
         terms += [(we[0] * we[1] % r, sel[4]), (we[2] * we[3] % r, sel[5])]
@@ -197,10 +279,10 @@ class TurboPlonkProver:
             cf = cf * zeta_n2 % r
         lin = poly.lincomb(c, terms, out_len=n + 3)
         bterms = [(1, lin)]
-        cf = ch.v
+        cf = v_ch
         for p in wire_polys + [self.fixed[13 + j] for j in range(4)]:
             bterms.append((cf, p))
-            cf = cf * ch.v % r
+            cf = cf * v_ch % r
         batch = poly.lincomb(c, bterms, out_len=n + 3)
         opening = poly.div_by_linear(c, batch, zeta)
         shifted = poly.div_by_linear(c, z_poly.contiguous(), zeta * self.w_n % r)

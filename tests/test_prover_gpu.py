@@ -62,3 +62,49 @@ def test_prover_core_matches_bigint_restatement(gpu, mj, pyref, curve_id, log_n)
     assert (b_at(srs_beta) - b_at(ch["zeta"])) % r == (srs_beta - ch["zeta"]) * dl["opening"] % r
     prover.release()
     ck.release()
+
+
+def test_prover_with_merlin_transcript(gpu, mj, pyref):
+    """Challenges derived by the Merlin transcript mirror between the rounds (snark.rs:263-431): the restated
+    prover, fed the challenges the device run derived, must reproduce the same proof -- and a transcript
+    replayed over the RESTATED commitments must derive the same challenges."""
+    import pyref_plonk as PP
+    curve_id, log_n = 0, 4
+    c = mj.params.CURVES[curve_id]
+    pc = pyref.CURVES[curve_id]
+    n, r = 1 << log_n, c.r
+    rng = random.Random(99)
+    sel, sigma_vals, k, w, pi = build_circuit(pc, log_n, rng)
+    blind = {"wires": [[rng.randrange(r), rng.randrange(r)] for _ in range(5)], "z": [rng.randrange(r) for _ in range(3)],
+             "quot": [rng.randrange(r) for _ in range(4)]}
+    srs_beta = rng.randrange(r)
+    dom = mj.Radix2EvaluationDomain(c, log_n)
+    ck = mj.UnivariateProverParam.gen_srs_for_testing(c, srs_beta, n + 2)
+    prover = mj.prover.TurboPlonkProver(c, n, [dom.ifft(fr_mont_limbs(c, s)) for s in sel], [dom.ifft(fr_mont_limbs(c, s)) for s in sigma_vals], k, ck)
+    pub = [pi[3]]                                              # one public input (row 3)
+    src = mj.prover.TranscriptChallenges(prover, pub)
+    proof = prover.prove(np.stack([fr_mont_limbs(c, col) for col in w]), fr_mont_limbs(c, pi), src,
+                         mj.prover.Blinders(blind["wires"], blind["z"], blind["quot"]))
+    ch = {x: src.challenges[x] for x in ("beta", "gamma", "alpha", "zeta", "v")}
+    assert len(set(ch.values())) == 5
+    want = PP.prove_core(pc, log_n, sel, sigma_vals, k, w, pi, blind, ch, srs_beta)
+    assert want["divisible"]
+    G = pyref.g1_gen(pc)
+    dl = want["commit_dlogs"]
+    assert affine_from_limbs(pc, proof.opening_proof.xy) == pyref.g1_mul(pc, dl["opening"], G)
+    assert affine_from_limbs(pc, proof.shifted_opening_proof.xy) == pyref.g1_mul(pc, dl["shifted_opening"], G)
+    assert proof.wires_evals == want["wires_evals"] and proof.perm_next_eval == want["perm_next_eval"]
+    # replay the transcript over the restated commitments (points from big-int scalar multiplications)
+    t = mj.transcript.StandardTranscript(c)
+    sel_pts = [pyref.g1_mul(pc, pyref.poly_eval(pc, p, srs_beta), G) for p in want["selectors"]]
+    sig_pts = [pyref.g1_mul(pc, pyref.poly_eval(pc, p, srs_beta), G) for p in want["sigmas"]]
+    t.append_vk_and_pub_input(n, 1, k, sel_pts, sig_pts, pub)
+    t.append_commitments(b"witness_poly_comms", [pyref.g1_mul(pc, d, G) for d in dl["wires"]])
+    t.get_and_append_challenge(b"tau")
+    assert t.get_and_append_challenge(b"beta") == ch["beta"] and t.get_and_append_challenge(b"gamma") == ch["gamma"]
+    t.append_commitment(b"perm_poly_comms", pyref.g1_mul(pc, dl["z"], G))
+    assert t.get_and_append_challenge(b"alpha") == ch["alpha"]
+    t.append_commitments(b"quot_poly_comms", [pyref.g1_mul(pc, d, G) for d in dl["split"]])
+    assert t.get_and_append_challenge(b"zeta") == ch["zeta"]
+    prover.release()
+    ck.release()
