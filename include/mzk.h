@@ -44,6 +44,7 @@ extern "C" {
 #define MZK_ERR_UNSUPPORTED (-5)
 #define MZK_ERR_OOM (-6)
 #define MZK_ERR_NOT_INIT (-7)
+#define MZK_ERR_LOOKUP (-8)       /* Plookup: a lookup value is not in the table (constraint_system.rs:1410-1412) */
 
 #define MZK_CURVE_BLS12_381 0
 #define MZK_CURVE_BN254 1
@@ -143,10 +144,33 @@ MZK_API int32_t mzk_plonk_quotient_dev(uint64_t pk_handle, void* d_polys, uint64
 MZK_API int32_t mzk_plonk_quotient(uint64_t pk_handle, const uint64_t* polys, uint64_t in_len, const uint64_t* alpha_mont,
                                    const uint64_t* beta_mont, const uint64_t* gamma_mont, uint64_t* out);
 
+/* ---- UltraPlonk (Plookup).  The proving key additionally holds q_lookup as the 14th
+ * selector, a 6th wire type (sigma, k) and the four table polynomials `PlookupProvingKey{range_table_poly,
+ * key_table_poly, table_dom_sep_poly, q_dom_sep_poly}` (plonk/src/proof_system/structs.rs:592-640).
+ * selector_coeffs: 14 x poly_len, sigma_coeffs: 6 x poly_len, table_coeffs: 4 x poly_len in the order range, key,
+ * table_dom_sep, q_dom_sep; k_mont: 6 coset representatives. */
+MZK_API int32_t mzk_plonk_pk_register_ultra(int32_t curve_id, uint32_t log_n, const uint64_t* selector_coeffs, const uint64_t* sigma_coeffs,
+                                            const uint64_t* table_coeffs, uint64_t poly_len, const uint64_t* k_mont, uint64_t* out_handle);
+/* Quotient with the Plookup terms (prover.rs:512-673 with compute_quotient_plookup_contribution, :773-888).
+ * d_polys: (6 + 2 + 3) x 8n elements: wires, z, public input, h_1, h_2, Plookup product polynomial. */
+MZK_API int32_t mzk_plonk_quotient_ultra_dev(uint64_t pk_handle, void* d_polys, uint64_t in_len, const uint64_t* tau_mont,
+                                             const uint64_t* alpha_mont, const uint64_t* beta_mont, const uint64_t* gamma_mont, void* d_out,
+                                             void* stream);
+/* Round 1.5: replaces compute_merged_lookup_table (relation/src/constraint_system.rs:1290-1309) and the merge of
+ * compute_lookup_sorted_vec_polynomials (:1370-1417, before its two iFFTs).  d_wire_values: 6 x n wire evaluations.
+ * Outputs (device): merged table (n), merged lookup witness (n), sorted vector (2n - 1): h_1 = ifft(sorted[..n]),
+ * h_2 = ifft(sorted[n-1..]).  Returns MZK_ERR_LOOKUP when a looked-up value is not in the table.  Synchronises. */
+MZK_API int32_t mzk_plookup_sorted_vec_dev(uint64_t pk_handle, const void* d_wire_values, const uint64_t* tau_mont, void* d_merged_table,
+                                           void* d_merged_lookup, void* d_sorted, void* stream);
+/* Round 2.5: replaces compute_lookup_prod_polynomial (constraint_system.rs:1311-1368; one division per row there).
+ * d_out: the n coefficients of the (unmasked) Plookup product polynomial.  Asynchronous. */
+MZK_API int32_t mzk_plookup_product_dev(uint64_t pk_handle, const void* d_merged_table, const void* d_merged_lookup, const void* d_sorted,
+                                        const uint64_t* beta_mont, const uint64_t* gamma_mont, void* d_out, void* stream);
+
 /* Round 2: replaces Arithmetization::compute_prod_permutation_polynomial
  * (relation/src/constraint_system.rs:1197-1223), whose loop performs one field division per gate.
- * wire_values: 5 x n wire evaluations witness[wire_variable(i, j)]; the sigma evaluations come from the
- * registered proving key.  out: the n coefficients of the permutation product polynomial (unmasked). */
+ * wire_values: 5 x n (UltraPlonk key: 6 x n) wire evaluations witness[wire_variable(i, j)]; the sigma evaluations
+ * come from the registered proving key.  out: the n coefficients of the permutation product polynomial (unmasked). */
 MZK_API int32_t mzk_plonk_perm_product_dev(uint64_t pk_handle, const void* d_wire_values, const uint64_t* beta_mont,
                                            const uint64_t* gamma_mont, void* d_out, void* stream);
 MZK_API int32_t mzk_plonk_perm_product(uint64_t pk_handle, const uint64_t* wire_values, const uint64_t* beta_mont,

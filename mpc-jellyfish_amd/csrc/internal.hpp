@@ -94,12 +94,17 @@ int32_t poly_div_dispatch(int curve, const uint32_t* d_poly, uint64_t len, const
 int32_t poly_lincomb_dispatch(int curve, uint32_t n_terms, const uint32_t* const* d_polys, const uint64_t* lens, const uint32_t* scalars, uint32_t* d_out,
                               uint64_t out_len, hipStream_t st);
 // plonk.hip
-int32_t plonk_pk_register(int curve, int log_n, int W, const uint32_t* sel, const uint32_t* sig, uint64_t poly_len, const uint32_t* k_mont,
-                          uint64_t* out_handle);
+int32_t plonk_pk_register(int curve, int log_n, int W, const uint32_t* sel, const uint32_t* sig, const uint32_t* tab /* NULL: TurboPlonk */,
+                          uint64_t poly_len, const uint32_t* k_mont, uint64_t* out_handle);
 int32_t plonk_pk_release(uint64_t handle);
 void plonk_release_all();
-int32_t plonk_quotient_dev(uint64_t handle, uint32_t* d_polys, uint64_t in_len, const uint32_t* alpha, const uint32_t* beta, const uint32_t* gamma,
-                           uint32_t* d_out, hipStream_t st);
+int32_t plonk_quotient_dev(uint64_t handle, uint32_t* d_polys, uint64_t in_len, const uint32_t* tau /* NULL: TurboPlonk */, const uint32_t* alpha,
+                           const uint32_t* beta, const uint32_t* gamma, uint32_t* d_out, hipStream_t st);
+int32_t plookup_sorted_vec_dev(uint64_t handle, const uint32_t* d_wires, const uint32_t* tau, uint32_t* d_table, uint32_t* d_lookup, uint32_t* d_sorted,
+                               hipStream_t st);
+int32_t plookup_product_dev(uint64_t handle, const uint32_t* d_table, const uint32_t* d_lookup, const uint32_t* d_sorted, const uint32_t* beta,
+                            const uint32_t* gamma, uint32_t* d_out, hipStream_t st);
+int plonk_pk_is_ultra(uint64_t handle);
 int32_t plonk_perm_product_dev(uint64_t handle, const uint32_t* d_wires, const uint32_t* beta, const uint32_t* gamma, uint32_t* d_out, hipStream_t st);
 int plonk_pk_log_n(uint64_t handle);
 int plonk_pk_wires(uint64_t handle);

@@ -151,6 +151,7 @@ const char* mzk_strerror(int32_t code) {
         case MZK_ERR_UNSUPPORTED: return "unsupported";
         case MZK_ERR_OOM: return "out of device memory";
         case MZK_ERR_NOT_INIT: return "mzk_init not called";
+        case MZK_ERR_LOOKUP: return "Plookup: lookup value outside the table";
         default: return "unknown error";
     }
 }
@@ -368,8 +369,17 @@ int32_t mzk_plonk_pk_register(int32_t curve_id, uint32_t log_n, uint32_t num_wir
                               const uint64_t* sigma_coeffs, uint64_t poly_len, const uint64_t* k_mont, uint64_t* out_handle) {
     std::lock_guard<std::mutex> lk(g_lock);
     MZK_TRY(require_init());
+    if (num_wire_types != 5) { set_error("TurboPlonk proving key: 5 wire types (UltraPlonk: mzk_plonk_pk_register_ultra)"); return MZK_ERR_INVALID_ARG; }
     return plonk_pk_register(curve_id, (int)log_n, (int)num_wire_types, reinterpret_cast<const uint32_t*>(selector_coeffs),
-                             reinterpret_cast<const uint32_t*>(sigma_coeffs), poly_len, reinterpret_cast<const uint32_t*>(k_mont), out_handle);
+                             reinterpret_cast<const uint32_t*>(sigma_coeffs), nullptr, poly_len, reinterpret_cast<const uint32_t*>(k_mont), out_handle);
+}
+int32_t mzk_plonk_pk_register_ultra(int32_t curve_id, uint32_t log_n, const uint64_t* selector_coeffs, const uint64_t* sigma_coeffs,
+                                    const uint64_t* table_coeffs, uint64_t poly_len, const uint64_t* k_mont, uint64_t* out_handle) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    if (!table_coeffs) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    return plonk_pk_register(curve_id, (int)log_n, 6, reinterpret_cast<const uint32_t*>(selector_coeffs), reinterpret_cast<const uint32_t*>(sigma_coeffs),
+                             reinterpret_cast<const uint32_t*>(table_coeffs), poly_len, reinterpret_cast<const uint32_t*>(k_mont), out_handle);
 }
 int32_t mzk_plonk_pk_release(uint64_t pk_handle) {
     std::lock_guard<std::mutex> lk(g_lock);
@@ -380,9 +390,35 @@ int32_t mzk_plonk_quotient_dev(uint64_t pk_handle, void* d_polys, uint64_t in_le
                                const uint64_t* gamma_mont, void* d_out, void* stream) {
     std::lock_guard<std::mutex> lk(g_lock);
     MZK_TRY(require_init());
-    return plonk_quotient_dev(pk_handle, reinterpret_cast<uint32_t*>(d_polys), in_len, reinterpret_cast<const uint32_t*>(alpha_mont),
+    if (plonk_pk_is_ultra(pk_handle) == 1) { set_error("UltraPlonk proving key: use mzk_plonk_quotient_ultra_dev"); return MZK_ERR_INVALID_ARG; }
+    return plonk_quotient_dev(pk_handle, reinterpret_cast<uint32_t*>(d_polys), in_len, nullptr, reinterpret_cast<const uint32_t*>(alpha_mont),
                               reinterpret_cast<const uint32_t*>(beta_mont), reinterpret_cast<const uint32_t*>(gamma_mont),
                               reinterpret_cast<uint32_t*>(d_out), (hipStream_t)stream);
+}
+int32_t mzk_plonk_quotient_ultra_dev(uint64_t pk_handle, void* d_polys, uint64_t in_len, const uint64_t* tau_mont, const uint64_t* alpha_mont,
+                                     const uint64_t* beta_mont, const uint64_t* gamma_mont, void* d_out, void* stream) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    if (plonk_pk_is_ultra(pk_handle) == 0) { set_error("TurboPlonk proving key: use mzk_plonk_quotient_dev"); return MZK_ERR_INVALID_ARG; }
+    return plonk_quotient_dev(pk_handle, reinterpret_cast<uint32_t*>(d_polys), in_len, reinterpret_cast<const uint32_t*>(tau_mont),
+                              reinterpret_cast<const uint32_t*>(alpha_mont), reinterpret_cast<const uint32_t*>(beta_mont),
+                              reinterpret_cast<const uint32_t*>(gamma_mont), reinterpret_cast<uint32_t*>(d_out), (hipStream_t)stream);
+}
+int32_t mzk_plookup_sorted_vec_dev(uint64_t pk_handle, const void* d_wire_values, const uint64_t* tau_mont, void* d_merged_table, void* d_merged_lookup,
+                                   void* d_sorted, void* stream) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    return plookup_sorted_vec_dev(pk_handle, reinterpret_cast<const uint32_t*>(d_wire_values), reinterpret_cast<const uint32_t*>(tau_mont),
+                                  reinterpret_cast<uint32_t*>(d_merged_table), reinterpret_cast<uint32_t*>(d_merged_lookup),
+                                  reinterpret_cast<uint32_t*>(d_sorted), (hipStream_t)stream);
+}
+int32_t mzk_plookup_product_dev(uint64_t pk_handle, const void* d_merged_table, const void* d_merged_lookup, const void* d_sorted, const uint64_t* beta_mont,
+                                const uint64_t* gamma_mont, void* d_out, void* stream) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    return plookup_product_dev(pk_handle, reinterpret_cast<const uint32_t*>(d_merged_table), reinterpret_cast<const uint32_t*>(d_merged_lookup),
+                               reinterpret_cast<const uint32_t*>(d_sorted), reinterpret_cast<const uint32_t*>(beta_mont),
+                               reinterpret_cast<const uint32_t*>(gamma_mont), reinterpret_cast<uint32_t*>(d_out), (hipStream_t)stream);
 }
 int32_t mzk_plonk_quotient(uint64_t pk_handle, const uint64_t* polys, uint64_t in_len, const uint64_t* alpha_mont, const uint64_t* beta_mont,
                            const uint64_t* gamma_mont, uint64_t* out) {
@@ -390,13 +426,14 @@ int32_t mzk_plonk_quotient(uint64_t pk_handle, const uint64_t* polys, uint64_t i
     MZK_TRY(require_init());
     const int log_n = plonk_pk_log_n(pk_handle), W = plonk_pk_wires(pk_handle);
     if (log_n < 0) { set_error("unknown proving-key handle"); return MZK_ERR_BAD_HANDLE; }
+    if (plonk_pk_is_ultra(pk_handle) == 1) { set_error("UltraPlonk proving key: use mzk_plonk_quotient_ultra_dev"); return MZK_ERR_INVALID_ARG; }
     if (!polys || !out || in_len == 0 || in_len > (8ull << log_n)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
     const uint64_t m = 8ull << log_n;
     hipStream_t st = nullptr;
     MZK_TRY(g_ws.plonk_polys.reserve((size_t)(W + 2) * m * 32));
     MZK_TRY(g_ws.plonk_out.reserve(m * 32));
     HIP_TRY(hipMemcpy2DAsync(g_ws.plonk_polys.p, m * 32, polys, in_len * 32, in_len * 32, W + 2, hipMemcpyHostToDevice, st));
-    MZK_TRY(plonk_quotient_dev(pk_handle, g_ws.plonk_polys.as<uint32_t>(), in_len, reinterpret_cast<const uint32_t*>(alpha_mont),
+    MZK_TRY(plonk_quotient_dev(pk_handle, g_ws.plonk_polys.as<uint32_t>(), in_len, nullptr, reinterpret_cast<const uint32_t*>(alpha_mont),
                                reinterpret_cast<const uint32_t*>(beta_mont), reinterpret_cast<const uint32_t*>(gamma_mont),
                                g_ws.plonk_out.as<uint32_t>(), st));
     HIP_TRY(hipMemcpyAsync(out, g_ws.plonk_out.p, m * 32, hipMemcpyDeviceToHost, st));

@@ -20,10 +20,11 @@ namespace mzk {
 constexpr int PLK_THREADS = 256;
 constexpr int PLK_SELECTORS = 13;
 constexpr int PLK_WIRES = 5;
+constexpr int PLK_MAX_WIRES = 6;              // UltraPlonk adds the range/lookup wire (relation/src/constants.rs)
 constexpr int PLK_RATIO = 8;                 // m / n for TurboPlonk and UltraPlonk
 
 struct QuotientArgs {
-    const uint32_t* sel;      // [13][m] coset evaluations
+    const uint32_t* sel;      // [13 (14)][m] coset evaluations; UltraPlonk: q_lookup last
     const uint32_t* sig;      // [W][m]
     const uint32_t* wire;     // [W][m]
     const uint32_t* z;        // [m]
@@ -32,9 +33,15 @@ struct QuotientArgs {
     const uint32_t* inv_den;  // [m]  1 / (n * (x_i - 1))
     uint32_t* out;            // [m]
     unsigned long long m;
-    uint32_t k[PLK_WIRES][8];         // coset representatives k_j (Montgomery)
+    uint32_t k[PLK_MAX_WIRES][8];     // coset representatives k_j (Montgomery)
     uint32_t alpha[8], alpha2[8], beta[8], gamma[8];
     uint32_t zh_inv[PLK_RATIO][8];    // 1 / Z_H(x_i), period 8 in i
+    // ---- UltraPlonk only (prover.rs:773-888)
+    const uint32_t* tab;      // [4][m] range, key, table_dom_sep, q_dom_sep
+    const uint32_t* h;        // [2][m] sorted-vector polynomials h_1, h_2
+    const uint32_t* pl;       // [m] Plookup product polynomial
+    const uint32_t* inv_den_n;// [m]  w^(n-1) / (n * (x_i - w^(n-1)))
+    uint32_t tau[8], alpha3[8], w_inv[8];
 };
 
 template <class P>
@@ -45,15 +52,17 @@ __device__ __forceinline__ Fp<P> arg_fp(const uint32_t (&a)[8]) {
     return r;
 }
 
-template <class P>
+template <class P, bool ULTRA>
 __global__ __launch_bounds__(PLK_THREADS) void plonk_quotient_kernel(QuotientArgs a) {
     using F = Fp<P>;
+    constexpr int W = ULTRA ? 6 : 5;
     const unsigned long long i = (unsigned long long)blockIdx.x * PLK_THREADS + threadIdx.x;
     if (i >= a.m) return;
     const unsigned long long m = a.m;
-    F w[PLK_WIRES];
+    const unsigned long long inext = (i + PLK_RATIO) % m;             // the point w_n * x_i (prover.rs:611, 627, 804)
+    F w[W];
 #pragma unroll
-    for (int j = 0; j < PLK_WIRES; j++) w[j] = load_fp<P>(a.wire + ((size_t)j * m + i) * 8);
+    for (int j = 0; j < W; j++) w[j] = load_fp<P>(a.wire + ((size_t)j * m + i) * 8);
     auto sel = [&](int j) { return load_fp<P>(a.sel + ((size_t)j * m + i) * 8); };
     // ---- gate identity (prover.rs:696-708)
     F t = sel(11) + load_fp<P>(a.pi + i * 8);                       // q_c + pi
@@ -71,17 +80,41 @@ __global__ __launch_bounds__(PLK_THREADS) void plonk_quotient_kernel(QuotientArg
     // ---- copy constraints (prover.rs:741-758)
     const F alpha = arg_fp<P>(a.alpha), beta = arg_fp<P>(a.beta), gamma = arg_fp<P>(a.gamma);
     const F z_x = load_fp<P>(a.z + i * 8);
-    const F z_xw = load_fp<P>(a.z + ((i + PLK_RATIO) % m) * 8);
-    const F xb = load_fp<P>(a.xs + i * 8) * beta;
+    const F z_xw = load_fp<P>(a.z + inext * 8);
+    const F x = load_fp<P>(a.xs + i * 8);
+    const F xb = x * beta;
     F acc1 = z_x, acc2 = z_xw;
 #pragma unroll
-    for (int j = 0; j < PLK_WIRES; j++) {
+    for (int j = 0; j < W; j++) {
         const F wg = w[j] + gamma;
         acc1 = acc1 * (wg + arg_fp<P>(a.k[j]) * xb);
         acc2 = acc2 * (wg + load_fp<P>(a.sig + ((size_t)j * m + i) * 8) * beta);
     }
-    const F t1 = t + alpha * (acc1 - acc2);
-    const F t2 = arg_fp<P>(a.alpha2) * ((z_x - F::one()) * load_fp<P>(a.inv_den + i * 8));
+    F t1 = t + alpha * (acc1 - acc2);
+    F t2 = arg_fp<P>(a.alpha2) * ((z_x - F::one()) * load_fp<P>(a.inv_den + i * 8));
+    if constexpr (ULTRA) {
+        // ---- Plookup (prover.rs:773-888): alpha^3 L_n (h1 - h2(wX)) + alpha^4 L_1 (p - 1) + alpha^5 L_n (p - 1) + alpha^6 (X - w^-1) [...]
+        auto tab = [&](int j, unsigned long long at) { return load_fp<P>(a.tab + ((size_t)j * m + at) * 8); };
+        const F tau = arg_fp<P>(a.tau), alpha3 = arg_fp<P>(a.alpha3);
+        const F ql = sel(13), ql_next = load_fp<P>(a.sel + ((size_t)13 * m + inext) * 8);
+        const F h1 = load_fp<P>(a.h + i * 8), h1n = load_fp<P>(a.h + inext * 8);
+        const F h2 = load_fp<P>(a.h + (m + i) * 8), h2n = load_fp<P>(a.h + (m + inext) * 8);
+        const F p = load_fp<P>(a.pl + i * 8), pn = load_fp<P>(a.pl + inext * 8);
+        auto merged = [&](const F& first, const F& q, const F& ds, const F& a0, const F& a1, const F& a2) {
+            return first + q * tau * (ds + tau * (a0 + tau * (a1 + tau * a2)));
+        };
+        const F mt = merged(tab(0, i), ql, tab(2, i), tab(1, i), w[3], w[4]);
+        const F mt_next = merged(tab(0, inext), ql_next, tab(2, inext), tab(1, inext), load_fp<P>(a.wire + ((size_t)3 * m + inext) * 8),
+                                 load_fp<P>(a.wire + ((size_t)4 * m + inext) * 8));
+        const F ml = merged(w[5], ql, tab(3, i), w[0], w[1], w[2]);
+        const F lag_n = load_fp<P>(a.inv_den_n + i * 8), lag_1 = load_fp<P>(a.inv_den + i * 8);
+        const F pm1 = p - F::one();
+        // result_2 = alpha^3 term_h + alpha^4 term_p1 + alpha^5 term_p2 = alpha^3 (term_h + alpha (term_p1 + alpha term_p2))
+        t2 = t2 + alpha3 * ((h1 - h2n) * lag_n + alpha * (pm1 * lag_1 + alpha * (pm1 * lag_n)));
+        const F b1 = beta + F::one(), g1 = gamma * b1;
+        const F term3 = (x - arg_fp<P>(a.w_inv)) * (p * b1 * (gamma + ml) * (g1 + mt + beta * mt_next) - pn * (g1 + h1 + beta * h1n) * (g1 + h2 + beta * h2n));
+        t1 = t1 + sqr(alpha3) * term3;
+    }
     store_fp<P>(a.out + i * 8, t1 * arg_fp<P>(a.zh_inv[i % PLK_RATIO]) + t2);          // prover.rs:657
 }
 
@@ -131,7 +164,8 @@ struct PermArgs {
     const uint32_t* omega;     // [n] w^j
     uint32_t* ratio;           // [n] out: ratio[j] for j < n-1, ratio[n-1] = 1
     unsigned long long n;
-    uint32_t k[PLK_WIRES][8];
+    int W;                     // 5 (TurboPlonk) or 6 (UltraPlonk)
+    uint32_t k[PLK_MAX_WIRES][8];
     uint32_t beta[8], gamma[8];
 };
 
@@ -151,7 +185,8 @@ __global__ __launch_bounds__(PLK_THREADS) void plonk_perm_ratio_kernel(PermArgs 
         if (j + 1 < a.n) {
             const F bw = beta * load_fp<P>(a.omega + j * 8);
 #pragma unroll
-            for (int i = 0; i < PLK_WIRES; i++) {
+            for (int i = 0; i < PLK_MAX_WIRES; i++) {
+                if (i >= a.W) break;
                 const F wg = load_fp<P>(a.wire + ((size_t)i * a.n + j) * 8) + gamma;
                 nu = nu * (wg + bw * arg_fp<P>(a.k[i]));
                 de = de * (wg + beta * load_fp<P>(a.sigma + ((size_t)i * a.n + j) * 8));
@@ -160,12 +195,13 @@ __global__ __launch_bounds__(PLK_THREADS) void plonk_perm_ratio_kernel(PermArgs 
         num[q] = nu;
         pref[q] = run;
         run = run * de;
-        store_fp<P>(a.ratio + j * 8, de);                   // parked
+        if (j < a.n) store_fp<P>(a.ratio + j * 8, de);      // parked
     }
     F inv_run = inv(run);            // a zero denominator (probability ~ n/r) yields 0, as 1/0 would panic in the reference
 #pragma unroll
     for (int q = PERM_B - 1; q >= 0; q--) {
         const unsigned long long j = start + q;
+        if (j >= a.n) continue;
         const F de = load_fp<P>(a.ratio + j * 8);
         store_fp<P>(a.ratio + j * 8, num[q] * (inv_run * pref[q]));
         inv_run = inv_run * de;

@@ -1,42 +1,78 @@
 // plonk.hip -- host side of the device-resident TurboPlonk quotient round (plonk.cuh).
+#include <array>
 #include <map>
 #include <memory>
 
 #include "internal.hpp"
 #include "plonk.cuh"
+#include "plookup.cuh"
 
 namespace mzk {
 namespace {
 
 struct PlonkPk {
     int curve = 0, log_n = 0, W = 0;
-    uint32_t* d_fixed = nullptr;        // [13 + W][m] coset evaluations of selectors then sigmas
+    bool ultra = false;                 // UltraPlonk: 14 selectors (q_lookup last), 6 wire types, 4 table polynomials
+    int nsel = PLK_SELECTORS;
+    uint32_t* d_fixed = nullptr;        // [nsel + W (+ 4)][m] coset evaluations of selectors, sigmas (, range, key, table_dom_sep, q_dom_sep)
     uint32_t* d_xs = nullptr;           // [m]
-    uint32_t* d_inv_den = nullptr;      // [m]
+    uint32_t* d_inv_den = nullptr;      // [m]  1 / (n (x - 1))
+    uint32_t* d_inv_den_n = nullptr;    // [m]  w^-1 / (n (x - w^-1))   (UltraPlonk)
     uint32_t* d_sigma_n = nullptr;      // [W][n] sigma_i on the gate domain H (extended permutation values)
     uint32_t* d_omega_n = nullptr;      // [n] w_n^j
-    uint32_t k[PLK_WIRES][8];
+    uint32_t* d_tab_n = nullptr;        // [5][n] range, key, table_dom_sep, q_dom_sep, q_lookup on H (UltraPlonk)
+    uint32_t k[PLK_MAX_WIRES][8];
     uint32_t zh_inv[PLK_RATIO][8];
     uint32_t gen[8];
+    uint32_t w_inv[8];                  // w_n^-1
+    std::array<uint32_t*, 7> bufs() const { return {d_fixed, d_xs, d_inv_den, d_inv_den_n, d_sigma_n, d_omega_n, d_tab_n}; }
 };
 std::map<uint64_t, std::unique_ptr<PlonkPk>> g_pks;
 uint64_t g_next_pk = 1;
 
+// out[i] = 1 / (scale * (xs[i] - c)), 16 points per thread with one shared inversion
 template <class P>
-int32_t pk_build(PlonkPk& pk, const uint32_t* sel_coeffs, const uint32_t* sig_coeffs, uint64_t poly_len) {
+__global__ __launch_bounds__(PLK_THREADS) void plonk_shifted_inverse_kernel(const uint32_t* __restrict__ xs, unsigned long long m, const uint32_t* __restrict__ c_mont,
+                                                                            const uint32_t* __restrict__ scale_mont, uint32_t* __restrict__ out) {
+    using F = Fp<P>;
+    constexpr int B = 16;
+    const unsigned long long start = ((unsigned long long)blockIdx.x * PLK_THREADS + threadIdx.x) * B;
+    if (start >= m) return;
+    const F c = load_fp<P>(c_mont), sc = load_fp<P>(scale_mont);
+    const int cnt = (int)(start + B <= m ? B : m - start);
+    F pref[B];
+    F run = F::one();
+    for (int j = 0; j < cnt; j++) {
+        const F d = sc * (load_fp<P>(xs + (start + j) * 8) - c);
+        pref[j] = run;
+        run = run * d;
+        store_fp<P>(out + (start + j) * 8, d);
+    }
+    F inv_run = inv(run);
+    for (int j = cnt - 1; j >= 0; j--) {
+        const F d = load_fp<P>(out + (start + j) * 8);
+        store_fp<P>(out + (start + j) * 8, inv_run * pref[j]);
+        inv_run = inv_run * d;
+    }
+}
+
+template <class P>
+int32_t pk_build(PlonkPk& pk, const uint32_t* sel_coeffs, const uint32_t* sig_coeffs, const uint32_t* tab_coeffs, uint64_t poly_len) {
     using F = Fp<P>;
     const int log_m = pk.log_n + 3;
     const uint64_t n = 1ull << pk.log_n, m = 1ull << log_m;
-    const int nfix = PLK_SELECTORS + pk.W;
+    const int nfix = pk.nsel + pk.W + (pk.ultra ? 4 : 0);
     hipStream_t st = nullptr;
     HIP_TRY(hipMalloc((void**)&pk.d_fixed, (size_t)nfix * m * 32));
     HIP_TRY(hipMalloc((void**)&pk.d_xs, m * 32));
     HIP_TRY(hipMalloc((void**)&pk.d_inv_den, m * 32));
     HIP_TRY(hipMemsetAsync(pk.d_fixed, 0, (size_t)nfix * m * 32, st));
-    HIP_TRY(hipMemcpy2DAsync(pk.d_fixed, m * 32, sel_coeffs, poly_len * 32, poly_len * 32, PLK_SELECTORS, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpy2DAsync(pk.d_fixed + (size_t)PLK_SELECTORS * m * 8, m * 32, sig_coeffs, poly_len * 32, poly_len * 32, pk.W, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpy2DAsync(pk.d_fixed, m * 32, sel_coeffs, poly_len * 32, poly_len * 32, pk.nsel, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpy2DAsync(pk.d_fixed + (size_t)pk.nsel * m * 8, m * 32, sig_coeffs, poly_len * 32, poly_len * 32, pk.W, hipMemcpyHostToDevice, st));
+    if (pk.ultra)
+        HIP_TRY(hipMemcpy2DAsync(pk.d_fixed + (size_t)(pk.nsel + pk.W) * m * 8, m * 32, tab_coeffs, poly_len * 32, poly_len * 32, 4, hipMemcpyHostToDevice, st));
     for (int i = 0; i < 8; i++) pk.gen[i] = P::GENERATOR[i];
-    // coset evaluations of the fixed polynomials, once per proving key (prover.rs:552-558 does it per proof)
+    // coset evaluations of the fixed polynomials, once per proving key (prover.rs:552-558, 577-584 do it per proof)
     MZK_TRY(ntt_dispatch(pk.curve, pk.d_fixed, poly_len, log_m, false, pk.gen, nfix, m, st));
     // host constants: w_m, n, 1/Z_H on the 8 coset classes
     F w = F::from_const(P::ROOT);
@@ -47,8 +83,12 @@ int32_t pk_build(PlonkPk& pk, const uint32_t* sel_coeffs, const uint32_t* sig_co
         F xi = inv(x);
         for (int q = 0; q < 8; q++) pk.zh_inv[i][q] = xi.l[q];
     }
+    F wn = F::from_const(P::ROOT);
+    for (int i = pk.log_n; i < P::TWO_ADICITY; i++) wn = sqr(wn);
+    const F wn_inv = inv(wn);
+    for (int q = 0; q < 8; q++) pk.w_inv[q] = wn_inv.l[q];
     MZK_TRY(ws_acquire(st));
-    MZK_TRY(g_ws.misc.reserve(64));
+    MZK_TRY(g_ws.misc.reserve(128));
     uint32_t* d_c = g_ws.misc.as<uint32_t>();
     HIP_TRY(hipMemcpyAsync(d_c, w.l, 32, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_c + 8, nf.l, 32, hipMemcpyHostToDevice, st));
@@ -56,21 +96,48 @@ int32_t pk_build(PlonkPk& pk, const uint32_t* sel_coeffs, const uint32_t* sig_co
     hipLaunchKernelGGL((plonk_domain_tables_kernel<P>), dim3((unsigned)((threads + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st,
                        d_c, d_c + 8, m, pk.d_xs, pk.d_inv_den);
     HIP_TRY(hipGetLastError());
-    // gate-domain tables for the permutation product (round 2): sigma_i(w^j) and w^j
+    if (pk.ultra) {
+        // L_n(x) / Z_H(x) = w^-1 / (n (x - w^-1)) = 1 / (n w (x - w^-1))   (prover.rs:794-795)
+        HIP_TRY(hipMalloc((void**)&pk.d_inv_den_n, m * 32));
+        const F scale = nf * wn;
+        HIP_TRY(hipMemcpyAsync(d_c + 16, wn_inv.l, 32, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_c + 24, scale.l, 32, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL((plonk_shifted_inverse_kernel<P>), dim3((unsigned)((threads + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st,
+                           pk.d_xs, m, d_c + 16, d_c + 24, pk.d_inv_den_n);
+        HIP_TRY(hipGetLastError());
+    }
+    // gate-domain tables for the grand products (rounds 2, 2.5): sigma_i(w^j), w^j and the table polynomials' values
     HIP_TRY(hipMalloc((void**)&pk.d_sigma_n, (size_t)pk.W * n * 32));
     HIP_TRY(hipMalloc((void**)&pk.d_omega_n, n * 32));
     HIP_TRY(hipMemsetAsync(pk.d_sigma_n, 0, (size_t)pk.W * n * 32, st));
     const uint64_t sl = poly_len < n ? poly_len : n;
     HIP_TRY(hipMemcpy2DAsync(pk.d_sigma_n, n * 32, sig_coeffs, poly_len * 32, sl * 32, pk.W, hipMemcpyHostToDevice, st));
-    F wn = F::from_const(P::ROOT);
-    for (int i = pk.log_n; i < P::TWO_ADICITY; i++) wn = sqr(wn);
     HIP_TRY(hipMemcpyAsync(d_c + 8, wn.l, 32, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL((fr_powers_mont_kernel<P>), dim3((unsigned)(((n + 15) / 16 + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st,
                        d_c + 8, n, pk.d_omega_n);
     HIP_TRY(hipGetLastError());
     MZK_TRY(ws_release(st));
     MZK_TRY(ntt_dispatch(pk.curve, pk.d_sigma_n, sl, pk.log_n, false, nullptr, pk.W, n, st));
+    if (pk.ultra) {
+        HIP_TRY(hipMalloc((void**)&pk.d_tab_n, (size_t)5 * n * 32));
+        HIP_TRY(hipMemsetAsync(pk.d_tab_n, 0, (size_t)5 * n * 32, st));
+        HIP_TRY(hipMemcpy2DAsync(pk.d_tab_n, n * 32, tab_coeffs, poly_len * 32, sl * 32, 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(pk.d_tab_n + (size_t)4 * n * 8, sel_coeffs + (size_t)13 * poly_len * 8, sl * 32, hipMemcpyHostToDevice, st));
+        MZK_TRY(ntt_dispatch(pk.curve, pk.d_tab_n, sl, pk.log_n, false, nullptr, 5, n, st));
+    }
     HIP_TRY(hipStreamSynchronize(st));
+    return MZK_OK;
+}
+
+// prefix product of ratio[0..n) into d_out: out[0] = 1, out[j+1] = prod_{i<=j} ratio[i]; then iFFT
+template <class P>
+int32_t scan_and_interpolate(const PlonkPk& pk, uint32_t* ratio, uint32_t* totals, unsigned n_blocks, bool last_one, uint32_t* d_out, hipStream_t st) {
+    const uint64_t n = 1ull << pk.log_n;
+    hipLaunchKernelGGL((fr_scan_mul_block_kernel<P>), dim3(n_blocks), dim3(SCAN_T), 0, st, ratio, n, totals);
+    hipLaunchKernelGGL((fr_scan_mul_totals_kernel<P>), dim3(1), dim3(1024), 0, st, totals, n_blocks);
+    hipLaunchKernelGGL((fr_scan_mul_apply_kernel<P>), dim3((unsigned)((n + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st, ratio, totals, n, d_out);
+    if (last_one) hipLaunchKernelGGL((plookup_set_last_one_kernel<P>), dim3(1), dim3(64), 0, st, d_out, n);
+    HIP_TRY(hipGetLastError());
     return MZK_OK;
 }
 
@@ -85,32 +152,102 @@ int32_t perm_product_run(const PlonkPk& pk, const uint32_t* d_wires, const uint3
     uint32_t* ratio = g_ws.io.as<uint32_t>();
     uint32_t* totals = ratio + n * 8;
     PermArgs a;
-    a.wire = d_wires; a.sigma = pk.d_sigma_n; a.omega = pk.d_omega_n; a.ratio = ratio; a.n = n;
+    a.wire = d_wires; a.sigma = pk.d_sigma_n; a.omega = pk.d_omega_n; a.ratio = ratio; a.n = n; a.W = pk.W;
     std::memcpy(a.k, pk.k, sizeof a.k);
     std::memcpy(a.beta, beta, 32);
     std::memcpy(a.gamma, gamma, 32);
     const uint64_t rthreads = (n + PERM_B - 1) / PERM_B;
     hipLaunchKernelGGL((plonk_perm_ratio_kernel<P>), dim3((unsigned)((rthreads + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st, a);
-    hipLaunchKernelGGL((fr_scan_mul_block_kernel<P>), dim3(n_blocks), dim3(SCAN_T), 0, st, ratio, n, totals);
-    hipLaunchKernelGGL((fr_scan_mul_totals_kernel<P>), dim3(1), dim3(1024), 0, st, totals, n_blocks);
-    hipLaunchKernelGGL((fr_scan_mul_apply_kernel<P>), dim3((unsigned)((n + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st, ratio, totals, n, d_out);
-    HIP_TRY(hipGetLastError());
+    MZK_TRY(scan_and_interpolate<P>(pk, ratio, totals, n_blocks, false, d_out, st));
     MZK_TRY(ws_release(st));
     return ntt_dispatch(pk.curve, d_out, n, pk.log_n, true, nullptr, 1, n, st);
 }
 
+// merged table, merged lookup witness and their sorted concatenation (constraint_system.rs:1290-1309, 1370-1417).
+// Synchronises: the "lookup value outside the table" condition is read back.
 template <class P>
-int32_t quotient_run(const PlonkPk& pk, uint32_t* d_polys, uint64_t in_len, const uint32_t* alpha, const uint32_t* beta,
+int32_t sorted_vec_run(const PlonkPk& pk, const uint32_t* d_wires, const uint32_t* tau, uint32_t* d_table, uint32_t* d_lookup, uint32_t* d_sorted, hipStream_t st) {
+    const uint64_t n = 1ull << pk.log_n;
+    ProfScope total("plookup_sorted_vec", st);
+    MergeArgs ma;
+    ma.wire = d_wires;
+    ma.range = pk.d_tab_n; ma.key = pk.d_tab_n + n * 8; ma.table_dom_sep = pk.d_tab_n + 2 * n * 8; ma.q_dom_sep = pk.d_tab_n + 3 * n * 8;
+    ma.q_lookup = pk.d_tab_n + 4 * n * 8;
+    ma.table = d_table; ma.lookup = d_lookup; ma.n = n;
+    std::memcpy(ma.tau, tau, 32);
+    const unsigned gn = (unsigned)((n + PLK_THREADS - 1) / PLK_THREADS);
+    hipLaunchKernelGGL((plookup_merge_kernel<P>), dim3(gn), dim3(PLK_THREADS), 0, st, ma);
+    uint64_t slots = 4;
+    while (slots < 4 * n) slots <<= 1;
+    const unsigned n_blocks = (unsigned)((n + PLK_SCAN_BLOCK - 1) / PLK_SCAN_BLOCK);
+    MZK_TRY(ws_acquire(st));
+    MZK_TRY(g_ws.io.reserve(slots * 4 + n * 4 + n * 4 + (size_t)n_blocks * 4 + 64));
+    uint32_t* d_slots = g_ws.io.as<uint32_t>();
+    uint32_t* d_count = d_slots + slots;
+    uint32_t* d_pos = d_count + n;
+    uint32_t* d_totals = d_pos + n;
+    uint32_t* d_missing = d_totals + n_blocks;
+    HIP_TRY(hipMemsetAsync(d_slots, 0xFF, slots * 4, st));
+    HIP_TRY(hipMemsetAsync(d_count, 0, n * 4, st));
+    HIP_TRY(hipMemsetAsync(d_missing, 0, 4, st));
+    const uint4* t4 = reinterpret_cast<const uint4*>(d_table);
+    hipLaunchKernelGGL(plookup_hash_insert_kernel, dim3(gn), dim3(PLK_THREADS), 0, st, t4, n, d_slots, (uint32_t)(slots - 1));
+    // only the first n-1 rows are looked up (constraint_system.rs:1383, 1388)
+    hipLaunchKernelGGL(plookup_hash_count_kernel, dim3(gn), dim3(PLK_THREADS), 0, st, t4, reinterpret_cast<const uint4*>(d_lookup), n - 1, d_slots,
+                       (uint32_t)(slots - 1), d_count, d_missing);
+    hipLaunchKernelGGL(plookup_scan_block_kernel, dim3(n_blocks), dim3(PLK_SCAN_T), 0, st, d_count, n, d_pos, d_totals);
+    hipLaunchKernelGGL(plookup_scan_totals_kernel, dim3(1), dim3(1024), 0, st, d_totals, n_blocks);
+    hipLaunchKernelGGL(plookup_scan_apply_kernel, dim3(gn), dim3(PLK_THREADS), 0, st, d_pos, d_totals, n);
+    const uint64_t out_len = 2 * n - 1;
+    hipLaunchKernelGGL(plookup_gather_kernel, dim3((unsigned)((out_len + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st, t4, d_pos, n, out_len,
+                       reinterpret_cast<uint4*>(d_sorted));
+    HIP_TRY(hipGetLastError());
+    uint32_t missing = 0;
+    HIP_TRY(hipMemcpyAsync(&missing, d_missing, 4, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    MZK_TRY(ws_release(st));
+    if (missing) {
+        set_error("The sorted vector has wrong length, some lookup variables might be outside the table");      // constraint_system.rs:1410-1412
+        return MZK_ERR_LOOKUP;
+    }
+    return MZK_OK;
+}
+
+// Plookup product polynomial (constraint_system.rs:1311-1368): n coefficients into d_out
+template <class P>
+int32_t lookup_product_run(const PlonkPk& pk, const uint32_t* d_table, const uint32_t* d_lookup, const uint32_t* d_sorted, const uint32_t* beta,
+                           const uint32_t* gamma, uint32_t* d_out, hipStream_t st) {
+    const uint64_t n = 1ull << pk.log_n;
+    ProfScope total("plookup_product", st);
+    MZK_TRY(ws_acquire(st));
+    const unsigned n_blocks = (unsigned)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
+    MZK_TRY(g_ws.io.reserve(n * 32 + (size_t)n_blocks * 32));
+    uint32_t* ratio = g_ws.io.as<uint32_t>();
+    uint32_t* totals = ratio + n * 8;
+    LookupProdArgs a;
+    a.table = d_table; a.lookup = d_lookup; a.sorted = d_sorted; a.ratio = ratio; a.n = n;
+    std::memcpy(a.beta, beta, 32);
+    std::memcpy(a.gamma, gamma, 32);
+    const uint64_t rthreads = (n + PERM_B - 1) / PERM_B;
+    hipLaunchKernelGGL((plookup_ratio_kernel<P>), dim3((unsigned)((rthreads + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st, a);
+    MZK_TRY(scan_and_interpolate<P>(pk, ratio, totals, n_blocks, true, d_out, st));
+    MZK_TRY(ws_release(st));
+    return ntt_dispatch(pk.curve, d_out, n, pk.log_n, true, nullptr, 1, n, st);
+}
+
+// d_polys rows: W wires, z, public input (, h_1, h_2, Plookup product)
+template <class P>
+int32_t quotient_run(const PlonkPk& pk, uint32_t* d_polys, uint64_t in_len, const uint32_t* tau, const uint32_t* alpha, const uint32_t* beta,
                      const uint32_t* gamma, uint32_t* d_out, hipStream_t st) {
     using F = Fp<P>;
     const int log_m = pk.log_n + 3;
     const uint64_t m = 1ull << log_m;
     ProfScope total("plonk_quotient_total", st);
-    // coset FFT of the W wires, z and the public-input polynomial (prover.rs:559-567), in place
-    MZK_TRY(ntt_dispatch(pk.curve, d_polys, in_len, log_m, false, pk.gen, pk.W + 2, m, st));
+    // coset FFT of the W wires, z and the public-input polynomial (prover.rs:559-567; Plookup oracles :585-590), in place
+    MZK_TRY(ntt_dispatch(pk.curve, d_polys, in_len, log_m, false, pk.gen, pk.W + 2 + (pk.ultra ? 3 : 0), m, st));
     QuotientArgs a;
     a.sel = pk.d_fixed;
-    a.sig = pk.d_fixed + (size_t)PLK_SELECTORS * m * 8;
+    a.sig = pk.d_fixed + (size_t)pk.nsel * m * 8;
     a.wire = d_polys;
     a.z = d_polys + (size_t)pk.W * m * 8;
     a.pi = d_polys + (size_t)(pk.W + 1) * m * 8;
@@ -127,9 +264,22 @@ int32_t quotient_run(const PlonkPk& pk, uint32_t* d_polys, uint64_t in_len, cons
     std::memcpy(a.alpha2, a2.l, 32);
     std::memcpy(a.beta, beta, 32);
     std::memcpy(a.gamma, gamma, 32);
+    a.tab = a.h = a.pl = a.inv_den_n = nullptr;
+    if (pk.ultra) {
+        a.tab = pk.d_fixed + (size_t)(pk.nsel + pk.W) * m * 8;
+        a.h = d_polys + (size_t)(pk.W + 2) * m * 8;
+        a.pl = d_polys + (size_t)(pk.W + 4) * m * 8;
+        a.inv_den_n = pk.d_inv_den_n;
+        const F a3 = a2 * al;
+        std::memcpy(a.tau, tau, 32);
+        std::memcpy(a.alpha3, a3.l, 32);
+        std::memcpy(a.w_inv, pk.w_inv, 32);
+    }
     {
         ProfScope ps("plonk_quotient_kernel", st);
-        hipLaunchKernelGGL((plonk_quotient_kernel<P>), dim3((unsigned)((m + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st, a);
+        const dim3 grid((unsigned)((m + PLK_THREADS - 1) / PLK_THREADS));
+        if (pk.ultra) hipLaunchKernelGGL((plonk_quotient_kernel<P, true>), grid, dim3(PLK_THREADS), 0, st, a);
+        else hipLaunchKernelGGL((plonk_quotient_kernel<P, false>), grid, dim3(PLK_THREADS), 0, st, a);
         HIP_TRY(hipGetLastError());
     }
     // coefficient form: coset.ifft (prover.rs:672)
@@ -137,21 +287,29 @@ int32_t quotient_run(const PlonkPk& pk, uint32_t* d_polys, uint64_t in_len, cons
     return MZK_OK;
 }
 
+const PlonkPk* find_pk(uint64_t handle) {
+    auto it = g_pks.find(handle);
+    if (it == g_pks.end()) { set_error("unknown proving-key handle"); return nullptr; }
+    return it->second.get();
+}
+
 }  // namespace
 
-int32_t plonk_pk_register(int curve, int log_n, int W, const uint32_t* sel, const uint32_t* sig, uint64_t poly_len, const uint32_t* k_mont,
-                          uint64_t* out_handle) {
-    if ((curve != 0 && curve != 1) || W != PLK_WIRES || log_n < 1 || log_n + 3 > (curve == 0 ? 32 : 28) || log_n + 3 > 30 ||
+int32_t plonk_pk_register(int curve, int log_n, int W, const uint32_t* sel, const uint32_t* sig, const uint32_t* tab, uint64_t poly_len,
+                          const uint32_t* k_mont, uint64_t* out_handle) {
+    const bool ultra = tab != nullptr;
+    if ((curve != 0 && curve != 1) || W != (ultra ? PLK_MAX_WIRES : PLK_WIRES) || log_n < 1 || log_n + 3 > (curve == 0 ? 32 : 28) || log_n + 3 > 30 ||
         poly_len == 0 || poly_len > (8ull << log_n) || !sel || !sig || !k_mont || !out_handle) {
-        set_error("bad argument (TurboPlonk: 5 wire types, 13 selectors)");
+        set_error("bad argument (TurboPlonk: 5 wire types, 13 selectors; UltraPlonk: 6 wire types, 14 selectors, 4 table polynomials)");
         return MZK_ERR_INVALID_ARG;
     }
     auto pk = std::make_unique<PlonkPk>();
-    pk->curve = curve; pk->log_n = log_n; pk->W = W;
-    std::memcpy(pk->k, k_mont, sizeof pk->k);
-    int32_t rc = curve == 0 ? pk_build<BlsFr>(*pk, sel, sig, poly_len) : pk_build<BnFr>(*pk, sel, sig, poly_len);
+    pk->curve = curve; pk->log_n = log_n; pk->W = W; pk->ultra = ultra; pk->nsel = PLK_SELECTORS + (ultra ? 1 : 0);
+    std::memset(pk->k, 0, sizeof pk->k);
+    std::memcpy(pk->k, k_mont, (size_t)W * 32);
+    int32_t rc = curve == 0 ? pk_build<BlsFr>(*pk, sel, sig, tab, poly_len) : pk_build<BnFr>(*pk, sel, sig, tab, poly_len);
     if (rc != MZK_OK) {
-        for (auto* d : {pk->d_fixed, pk->d_xs, pk->d_inv_den, pk->d_sigma_n, pk->d_omega_n}) if (d) (void)hipFree(d);
+        for (auto* d : pk->bufs()) if (d) (void)hipFree(d);
         return rc;
     }
     *out_handle = g_next_pk++;
@@ -163,31 +321,51 @@ int32_t plonk_pk_release(uint64_t handle) {
     auto it = g_pks.find(handle);
     if (it == g_pks.end()) { set_error("unknown proving-key handle"); return MZK_ERR_BAD_HANDLE; }
     HIP_TRY(hipDeviceSynchronize());
-    for (auto* d : {it->second->d_fixed, it->second->d_xs, it->second->d_inv_den, it->second->d_sigma_n, it->second->d_omega_n}) if (d) (void)hipFree(d);
+    for (auto* d : it->second->bufs()) if (d) (void)hipFree(d);
     g_pks.erase(it);
     return MZK_OK;
 }
 void plonk_release_all() {
     for (auto& kv : g_pks)
-        for (auto* d : {kv.second->d_fixed, kv.second->d_xs, kv.second->d_inv_den, kv.second->d_sigma_n, kv.second->d_omega_n}) if (d) (void)hipFree(d);
+        for (auto* d : kv.second->bufs()) if (d) (void)hipFree(d);
     g_pks.clear();
 }
 
-int32_t plonk_quotient_dev(uint64_t handle, uint32_t* d_polys, uint64_t in_len, const uint32_t* alpha, const uint32_t* beta, const uint32_t* gamma,
-                           uint32_t* d_out, hipStream_t st) {
-    auto it = g_pks.find(handle);
-    if (it == g_pks.end()) { set_error("unknown proving-key handle"); return MZK_ERR_BAD_HANDLE; }
-    const PlonkPk& pk = *it->second;
-    if (!d_polys || !d_out || !alpha || !beta || !gamma || in_len > (8ull << pk.log_n)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
-    return pk.curve == 0 ? quotient_run<BlsFr>(pk, d_polys, in_len, alpha, beta, gamma, d_out, st)
-                         : quotient_run<BnFr>(pk, d_polys, in_len, alpha, beta, gamma, d_out, st);
+int32_t plonk_quotient_dev(uint64_t handle, uint32_t* d_polys, uint64_t in_len, const uint32_t* tau, const uint32_t* alpha, const uint32_t* beta,
+                           const uint32_t* gamma, uint32_t* d_out, hipStream_t st) {
+    const PlonkPk* pk = find_pk(handle);
+    if (!pk) return MZK_ERR_BAD_HANDLE;
+    if (!d_polys || !d_out || !alpha || !beta || !gamma || (pk->ultra && !tau) || in_len > (8ull << pk->log_n)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
+    return pk->curve == 0 ? quotient_run<BlsFr>(*pk, d_polys, in_len, tau, alpha, beta, gamma, d_out, st)
+                          : quotient_run<BnFr>(*pk, d_polys, in_len, tau, alpha, beta, gamma, d_out, st);
 }
 int32_t plonk_perm_product_dev(uint64_t handle, const uint32_t* d_wires, const uint32_t* beta, const uint32_t* gamma, uint32_t* d_out, hipStream_t st) {
-    auto it = g_pks.find(handle);
-    if (it == g_pks.end()) { set_error("unknown proving-key handle"); return MZK_ERR_BAD_HANDLE; }
+    const PlonkPk* pk = find_pk(handle);
+    if (!pk) return MZK_ERR_BAD_HANDLE;
     if (!d_wires || !d_out || !beta || !gamma) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
-    const PlonkPk& pk = *it->second;
-    return pk.curve == 0 ? perm_product_run<BlsFr>(pk, d_wires, beta, gamma, d_out, st) : perm_product_run<BnFr>(pk, d_wires, beta, gamma, d_out, st);
+    return pk->curve == 0 ? perm_product_run<BlsFr>(*pk, d_wires, beta, gamma, d_out, st) : perm_product_run<BnFr>(*pk, d_wires, beta, gamma, d_out, st);
+}
+int32_t plookup_sorted_vec_dev(uint64_t handle, const uint32_t* d_wires, const uint32_t* tau, uint32_t* d_table, uint32_t* d_lookup, uint32_t* d_sorted,
+                               hipStream_t st) {
+    const PlonkPk* pk = find_pk(handle);
+    if (!pk) return MZK_ERR_BAD_HANDLE;
+    if (!pk->ultra || !d_wires || !tau || !d_table || !d_lookup || !d_sorted || pk->log_n < 2) {
+        set_error("bad argument (needs an UltraPlonk proving key)");
+        return MZK_ERR_INVALID_ARG;
+    }
+    return pk->curve == 0 ? sorted_vec_run<BlsFr>(*pk, d_wires, tau, d_table, d_lookup, d_sorted, st)
+                          : sorted_vec_run<BnFr>(*pk, d_wires, tau, d_table, d_lookup, d_sorted, st);
+}
+int32_t plookup_product_dev(uint64_t handle, const uint32_t* d_table, const uint32_t* d_lookup, const uint32_t* d_sorted, const uint32_t* beta,
+                            const uint32_t* gamma, uint32_t* d_out, hipStream_t st) {
+    const PlonkPk* pk = find_pk(handle);
+    if (!pk) return MZK_ERR_BAD_HANDLE;
+    if (!pk->ultra || !d_table || !d_lookup || !d_sorted || !beta || !gamma || !d_out || pk->log_n < 2) {
+        set_error("bad argument (needs an UltraPlonk proving key)");
+        return MZK_ERR_INVALID_ARG;
+    }
+    return pk->curve == 0 ? lookup_product_run<BlsFr>(*pk, d_table, d_lookup, d_sorted, beta, gamma, d_out, st)
+                          : lookup_product_run<BnFr>(*pk, d_table, d_lookup, d_sorted, beta, gamma, d_out, st);
 }
 int plonk_pk_log_n(uint64_t handle) {
     auto it = g_pks.find(handle);
@@ -196,6 +374,10 @@ int plonk_pk_log_n(uint64_t handle) {
 int plonk_pk_wires(uint64_t handle) {
     auto it = g_pks.find(handle);
     return it == g_pks.end() ? -1 : it->second->W;
+}
+int plonk_pk_is_ultra(uint64_t handle) {
+    auto it = g_pks.find(handle);
+    return it == g_pks.end() ? -1 : (it->second->ultra ? 1 : 0);
 }
 
 }  // namespace mzk

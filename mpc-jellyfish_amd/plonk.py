@@ -1,4 +1,4 @@
-"""TurboPlonk quotient round on the GPU -- mirror of the prover-side surface it replaces:
+"""TurboPlonk / UltraPlonk quotient round and grand products on the GPU -- mirror of the prover-side surface they replace:
 
     ProvingKey{selectors, sigmas, vk.k}                plonk/src/proof_system/structs.rs:575-590
     Prover::compute_quotient_polynomial(challenges, pks, online_oracles, num_wire_types)
@@ -6,8 +6,11 @@
     Oracles{wire_polys, pub_inp_poly, prod_perm_poly}   structs.rs:875-887
     Challenges{alpha, beta, gamma, ...}                 structs.rs:863-872
 
-One instance, no Plookup.  Polynomials are (len,4) uint64 Montgomery coefficient arrays.  The proving
-key's 18 fixed polynomials are transformed to the quotient coset once and stay in HBM.
+    PlookupProvingKey{range_table_poly, key_table_poly, table_dom_sep_poly, q_dom_sep_poly}   structs.rs:592-640
+    Arithmetization::compute_lookup_sorted_vec_polynomials / compute_lookup_prod_polynomial    relation/src/constraint_system.rs:1311-1417
+
+One instance.  Polynomials are (len,4) uint64 Montgomery coefficient arrays.  The proving key's 18 (UltraPlonk: 24)
+fixed polynomials are transformed to the quotient coset once and stay in HBM.
 """
 from __future__ import annotations
 
@@ -22,6 +25,9 @@ from .params import CurveParams, curve as _curve, fr_to_mont
 GATE_WIDTH = 4                 # relation/src/constants.rs:18
 N_TURBO_PLONK_SELECTORS = 13   # relation/src/constants.rs:22
 NUM_WIRE_TYPES = GATE_WIDTH + 1
+N_ULTRA_PLONK_SELECTORS = 14   # + q_lookup
+NUM_WIRE_TYPES_ULTRA = GATE_WIDTH + 2
+PLOOKUP_TABLE_POLYS = ("range_table_poly", "key_table_poly", "table_dom_sep_poly", "q_dom_sep_poly")
 
 
 @dataclass
@@ -30,6 +36,7 @@ class Challenges:
     alpha: int
     beta: int
     gamma: int
+    tau: int = 0
 
 
 class PlonkError(Exception):
@@ -37,20 +44,26 @@ class PlonkError(Exception):
 
 
 class ProvingKeyDevice:
-    """selectors/sigmas of a ProvingKey, resident on the GPU as coset evaluations."""
+    """selectors/sigmas (and Plookup table polynomials) of a ProvingKey, resident on the GPU as coset evaluations."""
 
-    def __init__(self, curve: CurveParams, handle: int, domain_size: int):
-        self.curve, self.handle, self.domain_size = curve, handle, domain_size
+    def __init__(self, curve: CurveParams, handle: int, domain_size: int, ultra: bool = False):
+        self.curve, self.handle, self.domain_size, self.ultra = curve, handle, domain_size, ultra
+        self.num_wire_types = NUM_WIRE_TYPES_ULTRA if ultra else NUM_WIRE_TYPES
 
     @classmethod
-    def register(cls, curve, domain_size: int, selectors, sigmas, k) -> "ProvingKeyDevice":
-        """selectors: 13 coefficient arrays, sigmas: 5, k: 5 Python ints (coset representatives)."""
+    def register(cls, curve, domain_size: int, selectors, sigmas, k, plookup=None) -> "ProvingKeyDevice":
+        """selectors: 13 coefficient arrays, sigmas: 5, k: 5 Python ints (coset representatives).
+        UltraPlonk: 14 selectors (q_lookup last), 6 sigmas, 6 k and plookup = {range_table_poly, key_table_poly,
+        table_dom_sep_poly, q_dom_sep_poly} coefficient arrays."""
         c = _curve(curve)
+        ultra = plookup is not None
+        nsel, W = (N_ULTRA_PLONK_SELECTORS, NUM_WIRE_TYPES_ULTRA) if ultra else (N_TURBO_PLONK_SELECTORS, NUM_WIRE_TYPES)
         if domain_size & (domain_size - 1) or domain_size < 2:
             raise PlonkError("domain size must be a power of two")
-        if len(selectors) != N_TURBO_PLONK_SELECTORS or len(sigmas) != NUM_WIRE_TYPES or len(k) != NUM_WIRE_TYPES:
-            raise PlonkError("TurboPlonk proving key: 13 selectors, 5 sigmas, 5 coset representatives")
-        polys = [np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 4) for p in list(selectors) + list(sigmas)]
+        if len(selectors) != nsel or len(sigmas) != W or len(k) != W:
+            raise PlonkError("proving key: %d selectors, %d sigmas, %d coset representatives" % (nsel, W, W))
+        tabs = [plookup[x] for x in PLOOKUP_TABLE_POLYS] if ultra else []
+        polys = [np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 4) for p in list(selectors) + list(sigmas) + tabs]
         plen = max(p.shape[0] for p in polys)
         slab = np.zeros((len(polys), plen, 4), dtype=np.uint64)
         for i, p in enumerate(polys):
@@ -58,11 +71,16 @@ class ProvingKeyDevice:
         kk = fr_to_mont(c, list(k))
         L = _lib.ensure_init()
         h = C.c_uint64()
-        _lib.check(L.mzk_plonk_pk_register(c.curve_id, domain_size.bit_length() - 1, NUM_WIRE_TYPES,
-                                           slab[:N_TURBO_PLONK_SELECTORS].ctypes.data_as(C.c_void_p),
-                                           np.ascontiguousarray(slab[N_TURBO_PLONK_SELECTORS:]).ctypes.data_as(C.c_void_p),
-                                           plen, kk.ctypes.data_as(C.c_void_p), C.byref(h)), "mzk_plonk_pk_register")
-        return cls(c, h.value, domain_size)
+        ptr = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
+        sel_a, sig_a = np.ascontiguousarray(slab[:nsel]), np.ascontiguousarray(slab[nsel:nsel + W])
+        if ultra:
+            tab_a = np.ascontiguousarray(slab[nsel + W:])
+            _lib.check(L.mzk_plonk_pk_register_ultra(c.curve_id, domain_size.bit_length() - 1, ptr(sel_a), ptr(sig_a), ptr(tab_a), plen, ptr(kk), C.byref(h)),
+                       "mzk_plonk_pk_register_ultra")
+        else:
+            _lib.check(L.mzk_plonk_pk_register(c.curve_id, domain_size.bit_length() - 1, W, ptr(sel_a), ptr(sig_a), plen, ptr(kk), C.byref(h)),
+                       "mzk_plonk_pk_register")
+        return cls(c, h.value, domain_size, ultra)
 
     def release(self):
         if self.handle:
@@ -73,7 +91,7 @@ class ProvingKeyDevice:
 def compute_quotient_polynomial(pk: ProvingKeyDevice, challenges: Challenges, wire_polys, prod_perm_poly, pub_inp_poly) -> np.ndarray:
     """prover.rs:512-673 for one instance: returns the 8n coefficients of the quotient polynomial
     (callers strip trailing zeros as DensePolynomial::from_coefficients_vec does)."""
-    if len(wire_polys) != NUM_WIRE_TYPES:
+    if len(wire_polys) != NUM_WIRE_TYPES or pk.ultra:
         raise PlonkError("inconsistent pks/online oracles when computing quotient polys")      # prover.rs:519-524
     polys = [np.ascontiguousarray(p, dtype=np.uint64).reshape(-1, 4) for p in list(wire_polys) + [prod_perm_poly, pub_inp_poly]]
     plen = max(1, max(p.shape[0] for p in polys))
@@ -92,27 +110,94 @@ def compute_quotient_polynomial(pk: ProvingKeyDevice, challenges: Challenges, wi
 
 
 def compute_quotient_polynomial_dev(pk: ProvingKeyDevice, challenges: Challenges, polys_dev, in_len: int, out_dev, stream=None):
-    """Device-resident form: polys_dev is a (7, 8n, 4) int64 CUDA tensor holding the coefficients of the
-    5 wire polynomials, z and the public-input polynomial in its first in_len rows (overwritten with the
-    coset evaluations); out_dev (8n, 4) receives the quotient coefficients.  Asynchronous."""
+    """Device-resident form: polys_dev is a (W + 2, 8n, 4) int64 CUDA tensor holding the coefficients of the
+    wire polynomials, z and the public-input polynomial in its first in_len rows (overwritten with the
+    coset evaluations) -- UltraPlonk: (6 + 2 + 3, 8n, 4) with h_1, h_2 and the Plookup product polynomial appended;
+    out_dev (8n, 4) receives the quotient coefficients.  Asynchronous."""
     import torch
     m = 8 * pk.domain_size
-    assert polys_dev.shape == (NUM_WIRE_TYPES + 2, m, 4) and out_dev.shape == (m, 4)
+    rows = pk.num_wire_types + 2 + (3 if pk.ultra else 0)
+    assert polys_dev.shape == (rows, m, 4) and out_dev.shape == (m, 4)
     assert polys_dev.is_cuda and polys_dev.is_contiguous() and out_dev.is_contiguous() and polys_dev.dtype == torch.int64
     st = torch.cuda.current_stream(polys_dev.device).cuda_stream if stream is None else stream
-    ch = fr_to_mont(pk.curve, [challenges.alpha, challenges.beta, challenges.gamma])
-    _lib.check(_lib.ensure_init().mzk_plonk_quotient_dev(pk.handle, polys_dev.data_ptr(), in_len, ch[0].ctypes.data_as(C.c_void_p),
-                                                         ch[1].ctypes.data_as(C.c_void_p), ch[2].ctypes.data_as(C.c_void_p),
-                                                         out_dev.data_ptr(), st), "mzk_plonk_quotient_dev")
+    ch = fr_to_mont(pk.curve, [challenges.alpha, challenges.beta, challenges.gamma, challenges.tau])
+    p = lambda i: ch[i].ctypes.data_as(C.c_void_p)
+    if pk.ultra:
+        _lib.check(_lib.ensure_init().mzk_plonk_quotient_ultra_dev(pk.handle, polys_dev.data_ptr(), in_len, p(3), p(0), p(1), p(2), out_dev.data_ptr(), st),
+                   "mzk_plonk_quotient_ultra_dev")
+    else:
+        _lib.check(_lib.ensure_init().mzk_plonk_quotient_dev(pk.handle, polys_dev.data_ptr(), in_len, p(0), p(1), p(2), out_dev.data_ptr(), st),
+                   "mzk_plonk_quotient_dev")
     return out_dev
+
+
+def _to_dev(x):
+    import torch
+    if hasattr(x, "is_cuda"):
+        return x.contiguous()
+    return torch.from_numpy(np.ascontiguousarray(x, dtype=np.uint64).view(np.int64)).cuda()
+
+
+def compute_prod_permutation_polynomial_dev(pk: ProvingKeyDevice, beta: int, gamma: int, wire_values_dev, out_dev=None):
+    """constraint_system.rs:1197-1223 on device tensors: (W, n, 4) wire values -> (n, 4) coefficients.  Asynchronous."""
+    import torch
+    n = pk.domain_size
+    assert wire_values_dev.shape == (pk.num_wire_types, n, 4) and wire_values_dev.is_contiguous()
+    out = torch.empty((n, 4), dtype=torch.int64, device=wire_values_dev.device) if out_dev is None else out_dev
+    ch = fr_to_mont(pk.curve, [beta, gamma])
+    _lib.check(_lib.ensure_init().mzk_plonk_perm_product_dev(pk.handle, wire_values_dev.data_ptr(), ch[0].ctypes.data_as(C.c_void_p),
+                                                             ch[1].ctypes.data_as(C.c_void_p), out.data_ptr(),
+                                                             torch.cuda.current_stream(wire_values_dev.device).cuda_stream), "mzk_plonk_perm_product_dev")
+    return out
+
+
+def compute_lookup_sorted_vec(pk: ProvingKeyDevice, tau: int, wire_values):
+    """compute_merged_lookup_table + the merge of compute_lookup_sorted_vec_polynomials
+    (constraint_system.rs:1290-1309, 1370-1408).  wire_values: (6, n, 4) numpy or CUDA tensor.
+    Returns CUDA tensors (merged_table (n,4), merged_lookup_witness (n,4), sorted_vec (2n-1,4)); raises PlonkError
+    like the reference when a lookup value is not in the table."""
+    import torch
+    if not pk.ultra:
+        raise PlonkError("Mismatched Plonk types between the proving key and the circuit")       # snark.rs:249-254
+    n = pk.domain_size
+    w = _to_dev(wire_values)
+    if tuple(w.shape) != (NUM_WIRE_TYPES_ULTRA, n, 4):
+        raise PlonkError("expected (6, n, 4) wire values")
+    table = torch.empty((n, 4), dtype=torch.int64, device=w.device)
+    lookup = torch.empty((n, 4), dtype=torch.int64, device=w.device)
+    sorted_vec = torch.empty((2 * n - 1, 4), dtype=torch.int64, device=w.device)
+    t = fr_to_mont(pk.curve, [tau])
+    rc = _lib.ensure_init().mzk_plookup_sorted_vec_dev(pk.handle, w.data_ptr(), t[0].ctypes.data_as(C.c_void_p), table.data_ptr(), lookup.data_ptr(),
+                                                       sorted_vec.data_ptr(), torch.cuda.current_stream(w.device).cuda_stream)
+    if rc == -8:
+        raise PlonkError("The sorted vector has wrong length, some lookup variables might be outside the table")
+    _lib.check(rc, "mzk_plookup_sorted_vec_dev")
+    return table, lookup, sorted_vec
+
+
+def compute_lookup_prod_polynomial(pk: ProvingKeyDevice, beta: int, gamma: int, merged_table, merged_lookup, sorted_vec, out_dev=None):
+    """constraint_system.rs:1311-1368: coefficients (n, 4) of the Plookup product polynomial, CUDA tensor.  Asynchronous."""
+    import torch
+    n = pk.domain_size
+    t, l, s = _to_dev(merged_table), _to_dev(merged_lookup), _to_dev(sorted_vec)
+    if tuple(t.shape) != (n, 4) or tuple(l.shape) != (n, 4):
+        raise PlonkError("Domain size should match the size of the padded lookup table")           # constraint_system.rs:1329-1332
+    if tuple(s.shape) != (2 * n - 1, 4):
+        raise PlonkError("The sorted vector has wrong length")                                      # constraint_system.rs:1334-1336
+    out = torch.empty((n, 4), dtype=torch.int64, device=t.device) if out_dev is None else out_dev
+    ch = fr_to_mont(pk.curve, [beta, gamma])
+    _lib.check(_lib.ensure_init().mzk_plookup_product_dev(pk.handle, t.data_ptr(), l.data_ptr(), s.data_ptr(), ch[0].ctypes.data_as(C.c_void_p),
+                                                          ch[1].ctypes.data_as(C.c_void_p), out.data_ptr(), torch.cuda.current_stream(t.device).cuda_stream),
+               "mzk_plookup_product_dev")
+    return out
 
 
 def compute_prod_permutation_polynomial(pk: ProvingKeyDevice, beta: int, gamma: int, wire_values) -> np.ndarray:
     """relation/src/constraint_system.rs:1197-1223: the permutation grand product z, as n coefficients.
-    wire_values: (5, n, 4) Montgomery wire evaluations (witness[wire_variable(i, j)])."""
+    wire_values: (W, n, 4) Montgomery wire evaluations (witness[wire_variable(i, j)])."""
     w = np.ascontiguousarray(wire_values, dtype=np.uint64)
-    if w.shape != (NUM_WIRE_TYPES, pk.domain_size, 4):
-        raise PlonkError("expected (5, n, 4) wire values")
+    if w.shape != (pk.num_wire_types, pk.domain_size, 4):
+        raise PlonkError("expected (%d, n, 4) wire values" % pk.num_wire_types)
     ch = fr_to_mont(pk.curve, [beta, gamma])
     out = np.empty((pk.domain_size, 4), dtype=np.uint64)
     _lib.check(_lib.ensure_init().mzk_plonk_perm_product(pk.handle, w.ctypes.data_as(C.c_void_p), ch[0].ctypes.data_as(C.c_void_p),

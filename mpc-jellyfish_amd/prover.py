@@ -1,13 +1,15 @@
-"""Device-resident arithmetic of one TurboPlonk proof -- the five rounds of
-`PlonkKzgSnark::batch_prove_internal` (plonk/src/proof_system/snark.rs:201-469) for a single instance
-without Plookup, with every NTT, MSM, pointwise pass, scan and polynomial operation on the GPU and all
+"""Device-resident arithmetic of one TurboPlonk or UltraPlonk proof -- the rounds of
+`PlonkKzgSnark::batch_prove_internal` (plonk/src/proof_system/snark.rs:201-469) for a single instance,
+with every NTT, MSM, pointwise pass, scan, hash-join and polynomial operation on the GPU and all
 polynomials kept in HBM between rounds (SURVEY.md 8(f) N1 + N2).
 
     round 1  run_1st_round   prover.rs:72-87     wire iNTTs, masking, batch_commit, public-input iNTT
+    round 1.5 run_plookup_1st_round prover.rs:89-118   merged table, sorted vector, h_1 / h_2, batch_commit      (UltraPlonk)
     round 2  run_2nd_round   prover.rs:125-141   permutation grand product, masking, commit
+    round 2.5 run_plookup_2nd_round prover.rs:143-183  Plookup grand product, masking, commit                       (UltraPlonk)
     round 3  run_3rd_round   prover.rs:192-209   quotient (coset NTTs + fused kernel + coset iNTT), split, batch_commit
-    round 4  compute_evaluations                 prover.rs:216-235
-    round 5  linearisation + opening proofs      prover.rs:302-358, 362-419, 490-509, 963-1035
+    round 4  compute_evaluations (+ compute_plookup_evaluations)   prover.rs:216-299
+    round 5  linearisation + opening proofs      prover.rs:302-358, 362-460, 490-509, 963-1112
 
 Challenges come either from the caller (`ProverChallenges`: the way the reference's own per-round tests
 fix them, multiprover/proof_system/prover.rs:1316-1556) or from the Merlin transcript mirror
@@ -28,11 +30,13 @@ from .params import CurveParams, curve as _curve, fr_to_mont
 
 @dataclass
 class Blinders:
-    """DensePolynomial::rand draws, in the reference's order (SURVEY.md Appendix C): 5 x 2 for the wires,
-    3 for z, 4 for the split quotient."""
+    """DensePolynomial::rand draws, in the reference's order (SURVEY.md Appendix C): W x 2 for the wires,
+    (2 x 3 for h_1, h_2,) 3 for z, (3 for the Plookup product,) W - 1 for the split quotient."""
     wires: list
     z: list
     quot: list
+    h: list | None = None
+    prod_lookup: list | None = None
 
 
 @dataclass
@@ -42,6 +46,12 @@ class ProverChallenges:
     alpha: int
     zeta: int
     v: int
+    tau: int = 0
+
+
+PLOOKUP_EVALS = ("range_table_eval", "key_table_eval", "h_1_eval", "q_lookup_eval", "prod_next_eval", "table_dom_sep_eval", "q_dom_sep_eval",
+                 "range_table_next_eval", "key_table_next_eval", "h_1_next_eval", "h_2_next_eval", "q_lookup_next_eval", "w_3_next_eval",
+                 "w_4_next_eval", "table_dom_sep_next_eval")                  # PlookupEvaluations, structs.rs:225-266
 
 
 class FixedChallenges:
@@ -51,15 +61,18 @@ class FixedChallenges:
         self.ch = ch
 
     def after_round1(self, wires_comms):
+        return self.ch.tau
+
+    def after_round1_5(self, h_comms):
         return self.ch.beta, self.ch.gamma
 
-    def after_round2(self, z_comm):
+    def after_round2(self, z_comm, prod_lookup_comm):
         return self.ch.alpha
 
     def after_round3(self, split_comms):
         return self.ch.zeta
 
-    def after_round4(self, wires_evals, wire_sigma_evals, perm_next_eval):
+    def after_round4(self, wires_evals, wire_sigma_evals, perm_next_eval, plookup_evals):
         return self.ch.v
 
 
@@ -90,23 +103,31 @@ class TranscriptChallenges:
 
     def after_round1(self, wires_comms):
         self.t.append_commitments(b"witness_poly_comms", [self._pt(cm) for cm in wires_comms])
-        self._squeeze("tau")                                   # squeezed even without Plookup (snark.rs:293)
+        return self._squeeze("tau")                            # squeezed even without Plookup (snark.rs:293)
+
+    def after_round1_5(self, h_comms):
+        if h_comms is not None:
+            self.t.append_commitments(b"h_poly_comms", [self._pt(cm) for cm in h_comms])
         return self._squeeze("beta"), self._squeeze("gamma")
 
-    def after_round2(self, z_comm):
+    def after_round2(self, z_comm, prod_lookup_comm):
         self.t.append_commitment(b"perm_poly_comms", self._pt(z_comm))
+        if prod_lookup_comm is not None:
+            self.t.append_commitment(b"plookup_poly_comms", self._pt(prod_lookup_comm))
         return self._squeeze("alpha")
 
     def after_round3(self, split_comms):
         self.t.append_commitments(b"quot_poly_comms", [self._pt(cm) for cm in split_comms])
         return self._squeeze("zeta")
 
-    def after_round4(self, wires_evals, wire_sigma_evals, perm_next_eval):
+    def after_round4(self, wires_evals, wire_sigma_evals, perm_next_eval, plookup_evals):
         for e in wires_evals:
             self.t.append_field_elem(b"wire_evals", e)
         for e in wire_sigma_evals:
             self.t.append_field_elem(b"wire_sigma_evals", e)
         self.t.append_field_elem(b"perm_next_eval", perm_next_eval)
+        if plookup_evals is not None:
+            self.t.append_plookup_evaluations(plookup_evals)
         return self._squeeze("v")
 
 
@@ -122,33 +143,53 @@ class ProofCore:
     wire_sigma_evals: list
     perm_next_eval: int
     timings_ms: dict = field(default_factory=dict)
+    h_poly_comms: list | None = None                 # PlookupProof (structs.rs:208-222)
+    prod_lookup_poly_comm: kzg.Commitment | None = None
+    plookup_evals: dict | None = None
 
 
 class TurboPlonkProver:
     """Holds a proving key on the device: coefficient forms (for rounds 4-5), the resident coset
-    evaluations (round 3) and the commit key."""
+    evaluations (round 3) and the commit key.  With `plookup` (the four table polynomials of
+    PlookupProvingKey) it is the UltraPlonk prover: 14 selectors, 6 wire types."""
 
-    def __init__(self, curve, domain_size: int, selector_polys, sigma_polys, k, commit_key: kzg.UnivariateProverParam):
+    def __init__(self, curve, domain_size: int, selector_polys, sigma_polys, k, commit_key: kzg.UnivariateProverParam, plookup=None):
         import torch
         self.curve: CurveParams = _curve(curve)
         self.n = domain_size
         self.log_n = domain_size.bit_length() - 1
         self.k = list(k)
         self.ck = commit_key
-        self.pk = plonk.ProvingKeyDevice.register(self.curve, domain_size, selector_polys, sigma_polys, k)
+        self.ultra = plookup is not None
+        self.W = len(sigma_polys)
+        self.nsel = len(selector_polys)
+        self.pk = plonk.ProvingKeyDevice.register(self.curve, domain_size, selector_polys, sigma_polys, k, plookup)
         pad = lambda p: np.concatenate([np.asarray(p, dtype=np.uint64).reshape(-1, 4),
                                         np.zeros((domain_size - np.asarray(p).reshape(-1, 4).shape[0], 4), dtype=np.uint64)])
-        self.fixed = torch.from_numpy(np.stack([pad(p) for p in list(selector_polys) + list(sigma_polys)]).view(np.int64)).cuda()
+        tabs = [plookup[x] for x in plonk.PLOOKUP_TABLE_POLYS] if self.ultra else []
+        self.fixed = torch.from_numpy(np.stack([pad(p) for p in list(selector_polys) + list(sigma_polys) + tabs]).view(np.int64)).cuda()
+        self.sigma0 = self.nsel                      # row of sigma_0 in self.fixed
+        self.tab0 = self.nsel + self.W               # rows of range, key, table_dom_sep, q_dom_sep
         self.domain = Radix2EvaluationDomain(self.curve, self.log_n)
         self.w_n = pow(self.curve.fr_generator, (self.curve.r - 1) >> self.log_n, self.curve.r)
 
     def vk_commitments(self):
-        """selector_comms, sigma_comms of the verifying key (preprocess, snark.rs:562-594): 18 commits, cached."""
+        """selector_comms, sigma_comms of the verifying key (preprocess, snark.rs:562-594), cached."""
         if getattr(self, "_vk", None) is None:
-            jac = kzg.msm_bigint_batch(self.ck, [self.fixed[i] for i in range(18)], scalars_are_mont=True)
+            nf = self.nsel + self.W
+            jac = kzg.msm_bigint_batch(self.ck, [self.fixed[i] for i in range(nf)], scalars_are_mont=True)
             xy = kzg.jacobian_to_affine(self.curve, jac)
-            self._vk = ([kzg.Commitment(self.curve, xy[i]) for i in range(13)], [kzg.Commitment(self.curve, xy[13 + i]) for i in range(5)])
+            self._vk = ([kzg.Commitment(self.curve, xy[i]) for i in range(self.nsel)],
+                        [kzg.Commitment(self.curve, xy[self.nsel + i]) for i in range(self.W)])
         return self._vk
+
+    def plookup_vk_commitments(self):
+        """PlookupVerifyingKey{range_table_comm, key_table_comm, table_dom_sep_comm, q_dom_sep_comm} (snark.rs:575-590)."""
+        assert self.ultra
+        if getattr(self, "_pvk", None) is None:
+            jac = kzg.msm_bigint_batch(self.ck, [self.fixed[self.tab0 + i] for i in range(4)], scalars_are_mont=True)
+            self._pvk = [kzg.Commitment(self.curve, xy) for xy in kzg.jacobian_to_affine(self.curve, jac)]
+        return self._pvk
 
     def release(self):
         self.pk.release()
@@ -165,12 +206,16 @@ class TurboPlonkProver:
         poly.lincomb(self.curve, [(one, head), (one, nb)], out=t[row, :h])
         t[row, self.n:self.n + h] = b
 
+    def _commit(self, polys):
+        jac = kzg.msm_bigint_batch(self.ck, [p.contiguous() for p in polys], scalars_are_mont=True)
+        return [kzg.Commitment(self.curve, xy) for xy in kzg.jacobian_to_affine(self.curve, jac)]
+
     def prove(self, wire_values, pub_input_values, ch, blind: Blinders, profile: bool = False) -> ProofCore:
         """ch: ProverChallenges (fixed) or a challenge source (FixedChallenges / TranscriptChallenges)."""
         src = FixedChallenges(ch) if isinstance(ch, ProverChallenges) else ch
         import time
         import torch
-        c, n, r = self.curve, self.n, self.curve.r
+        c, n, r, W, ultra = self.curve, self.n, self.curve.r, self.W, self.ultra
         m = 8 * n
         tm = {}
 
@@ -182,80 +227,118 @@ class TurboPlonkProver:
         dev = self.fixed.device
         wv = wire_values if hasattr(wire_values, "is_cuda") else torch.from_numpy(np.ascontiguousarray(wire_values).view(np.int64)).to(dev)
         pv = pub_input_values if hasattr(pub_input_values, "is_cuda") else torch.from_numpy(np.ascontiguousarray(pub_input_values).view(np.int64)).to(dev)
-        # one slab for round 3: rows 0-4 wires, 5 z, 6 public input; coefficients in the first n+3 columns
+        # one slab for round 3: rows 0..W-1 wires, W z, W+1 public input (, h_1, h_2, Plookup product); coefficients in the first n+3 columns
+        Z, PI, H1, PL = W, W + 1, W + 2, W + 4
+        rows = W + 2 + (3 if ultra else 0)
         t0 = time.perf_counter()
-        slab = torch.zeros((7, m, 4), dtype=torch.int64, device=dev)
+        slab = torch.zeros((rows, m, 4), dtype=torch.int64, device=dev)
         # ---- round 1 (prover.rs:72-87)
-        coeff = torch.empty((6, n, 4), dtype=torch.int64, device=dev)
-        coeff[:5] = wv
-        coeff[5] = pv
+        coeff = torch.empty((W + 1, n, 4), dtype=torch.int64, device=dev)
+        coeff[:W] = wv
+        coeff[W] = pv
         self.domain.ifft_in_place(coeff)
-        slab[:5, :n] = coeff[:5]
-        slab[6, :n] = coeff[5]
-        for i in range(5):
+        slab[:W, :n] = coeff[:W]
+        slab[PI, :n] = coeff[W]
+        for i in range(W):
             self._mask(slab, i, blind.wires[i])
-        wire_polys = [slab[i, :n + 2] for i in range(5)]
+        wire_polys = [slab[i, :n + 2] for i in range(W)]
         tick("r1_ntt_mask", t0)
         t0 = time.perf_counter()
-        jac = kzg.msm_bigint_batch(self.ck, [p.contiguous() for p in wire_polys], scalars_are_mont=True)
-        wires_comms = [kzg.Commitment(c, xy) for xy in kzg.jacobian_to_affine(c, jac)]
+        wires_comms = self._commit(wire_polys)
         tick("r1_commit", t0)
+        tau = src.after_round1(wires_comms)
+        # ---- round 1.5 (prover.rs:89-118; constraint_system.rs:1290-1309, 1370-1417)
+        h_comms = None
+        if ultra:
+            t0 = time.perf_counter()
+            table, lookup, sorted_vec = plonk.compute_lookup_sorted_vec(self.pk, tau, wv)
+            hh = torch.empty((2, n, 4), dtype=torch.int64, device=dev)
+            hh[0] = sorted_vec[:n]
+            hh[1] = sorted_vec[n - 1:]
+            self.domain.ifft_in_place(hh)
+            slab[H1:H1 + 2, :n] = hh
+            self._mask(slab, H1, blind.h[0])
+            self._mask(slab, H1 + 1, blind.h[1])
+            tick("r1_5_sorted_vec", t0)
+            t0 = time.perf_counter()
+            h_comms = self._commit([slab[H1, :n + 3], slab[H1 + 1, :n + 3]])
+            tick("r1_5_commit", t0)
         # ---- round 2 (prover.rs:125-141; constraint_system.rs:1197-1223)
         t0 = time.perf_counter()
-        beta, gamma = src.after_round1(wires_comms)
-        bg = fr_to_mont(c, [beta, gamma])
-        from . import lib as _lib
-        import ctypes as C
-        _lib.check(_lib.ensure_init().mzk_plonk_perm_product_dev(self.pk.handle, wv.data_ptr(), bg[0].ctypes.data_as(C.c_void_p),
-                                                                 bg[1].ctypes.data_as(C.c_void_p), coeff[0].data_ptr(),
-                                                                 torch.cuda.current_stream(dev).cuda_stream), "mzk_plonk_perm_product_dev")
-        slab[5, :n] = coeff[0]
-        self._mask(slab, 5, blind.z)
-        z_poly = slab[5, :n + 3]
+        beta, gamma = src.after_round1_5(h_comms)
+        plonk.compute_prod_permutation_polynomial_dev(self.pk, beta, gamma, wv.contiguous(), out_dev=coeff[0])
+        slab[Z, :n] = coeff[0]
+        self._mask(slab, Z, blind.z)
+        z_poly = slab[Z, :n + 3]
         tick("r2_product", t0)
         t0 = time.perf_counter()
-        z_comm = kzg.Commitment(c, kzg.jacobian_to_affine(c, kzg.msm_bigint(self.ck, z_poly.contiguous(), scalars_are_mont=True))[0])
+        z_comm = self._commit([z_poly])[0]
         tick("r2_commit", t0)
+        # ---- round 2.5 (prover.rs:143-183; constraint_system.rs:1311-1368)
+        pl_comm = None
+        if ultra:
+            t0 = time.perf_counter()
+            plonk.compute_lookup_prod_polynomial(self.pk, beta, gamma, table, lookup, sorted_vec, out_dev=coeff[0])
+            slab[PL, :n] = coeff[0]
+            self._mask(slab, PL, blind.prod_lookup)
+            tick("r2_5_product", t0)
+            t0 = time.perf_counter()
+            pl_comm = self._commit([slab[PL, :n + 3]])[0]
+            tick("r2_5_commit", t0)
         # ---- round 3 (prover.rs:192-209, 512-673, 902-960)
         t0 = time.perf_counter()
-        keep = slab[:6, :n + 3].clone()                                  # coefficient forms survive the in-place coset NTT
+        keep = slab[:, :n + 3].clone()                                   # coefficient forms survive the in-place coset NTT
         quot = torch.empty((m, 4), dtype=torch.int64, device=dev)
-        alpha = src.after_round2(z_comm)
-        plonk.compute_quotient_polynomial_dev(self.pk, plonk.Challenges(alpha, beta, gamma), slab, n + 3, quot)
+        alpha = src.after_round2(z_comm, pl_comm)
+        plonk.compute_quotient_polynomial_dev(self.pk, plonk.Challenges(alpha, beta, gamma, tau), slab, n + 3, quot)
         tick("r3_quotient", t0)
         t0 = time.perf_counter()
-        expected = 5 * (n + 1) + 2
+        expected = W * (n + 1) + 2                                       # quotient_polynomial_degree, prover.rs:1125-1128
         split = []
         last = 0
-        for i in range(5):
+        for i in range(W):
             lo = i * (n + 2)
-            hi = (i + 1) * (n + 2) if i < 4 else expected + 1
+            hi = (i + 1) * (n + 2) if i < W - 1 else expected + 1
             p = torch.zeros((n + 3, 4), dtype=torch.int64, device=dev)
             p[:hi - lo] = quot[lo:hi]
-            if i < 4:
+            if i < W - 1:
                 p[n + 2] = torch.from_numpy(fr_to_mont(c, [blind.quot[i]]).view(np.int64)).to(dev)[0]
             if last:
                 negl = torch.from_numpy(fr_to_mont(c, [(-last) % r]).view(np.int64)).to(dev)
                 poly.lincomb(c, [(1, p[:1].clone()), (1, negl)], out=p[:1])
-            last = blind.quot[i] if i < 4 else 0
-            split.append(p if i < 4 else p[:n])
+            last = blind.quot[i] if i < W - 1 else 0
+            split.append(p if i < W - 1 else p[:hi - lo])
         tick("r3_split", t0)
         t0 = time.perf_counter()
-        jac = kzg.msm_bigint_batch(self.ck, [p.contiguous() for p in split], scalars_are_mont=True)
-        split_comms = [kzg.Commitment(c, xy) for xy in kzg.jacobian_to_affine(c, jac)]
+        split_comms = self._commit(split)
         tick("r3_commit", t0)
-        # ---- round 4 (prover.rs:216-235)
+        # ---- round 4 (prover.rs:216-299)
         t0 = time.perf_counter()
-        wire_polys = [keep[i, :n + 2] for i in range(5)]
-        z_poly = keep[5]
+        wire_polys = [keep[i, :n + 2] for i in range(W)]
+        z_poly = keep[Z]
         zeta = src.after_round3(split_comms)
-        wires_evals = poly.evaluate(c, keep[:5], zeta, length=n + 2)
-        wire_sigma_evals = poly.evaluate(c, self.fixed[13:17], zeta)
-        perm_next_eval = poly.evaluate(c, z_poly, zeta * self.w_n % r)[0]
+        zeta_w = zeta * self.w_n % r
+        sig = [self.fixed[self.sigma0 + j] for j in range(W)]
+        wires_evals = poly.evaluate(c, keep[:W], zeta, length=n + 2)
+        wire_sigma_evals = poly.evaluate(c, self.fixed[self.sigma0:self.sigma0 + W - 1], zeta)
+        perm_next_eval = poly.evaluate(c, z_poly, zeta_w)[0]
+        pe = None
+        if ultra:
+            tabs = self.fixed[self.tab0:self.tab0 + 4]                    # range, key, table_dom_sep, q_dom_sep
+            q_lookup = self.fixed[13]
+            h1, h2, pl_poly = keep[H1], keep[H1 + 1], keep[PL]
+            at_zeta = poly.evaluate(c, tabs, zeta)
+            at_next = poly.evaluate(c, tabs[:3], zeta_w)
+            pe = {"range_table_eval": at_zeta[0], "key_table_eval": at_zeta[1], "table_dom_sep_eval": at_zeta[2], "q_dom_sep_eval": at_zeta[3],
+                  "range_table_next_eval": at_next[0], "key_table_next_eval": at_next[1], "table_dom_sep_next_eval": at_next[2],
+                  "h_1_eval": poly.evaluate(c, h1, zeta)[0], "q_lookup_eval": poly.evaluate(c, q_lookup, zeta)[0],
+                  "q_lookup_next_eval": poly.evaluate(c, q_lookup, zeta_w)[0]}
+            nx = poly.evaluate(c, keep[[PL, H1, H1 + 1, 3, 4]], zeta_w)
+            pe.update({"prod_next_eval": nx[0], "h_1_next_eval": nx[1], "h_2_next_eval": nx[2], "w_3_next_eval": nx[3], "w_4_next_eval": nx[4]})
         tick("r4_evals", t0)
-        # ---- round 5: linearisation polynomial (prover.rs:963-1035, 343-358) and openings (362-419, 490-509)
+        # ---- round 5: linearisation polynomial (prover.rs:963-1112, 343-358) and openings (362-460, 490-509)
         t0 = time.perf_counter()
-        v_ch = src.after_round4(wires_evals, wire_sigma_evals, perm_next_eval)
+        v_ch = src.after_round4(wires_evals, wire_sigma_evals, perm_next_eval, pe)
         we = wires_evals
         sel = self.fixed
         terms = [(we[j], sel[j]) for j in range(4)]
@@ -265,32 +348,56 @@ class TurboPlonkProver:
         vanish = (pow(zeta, n, r) - 1) % r
         lagrange_1 = vanish * pow(n * (zeta - 1) % r, -1, r) % r
         cf = alpha
-        for j in range(5):
+        for j in range(W):
             cf = cf * (we[j] + beta * self.k[j] % r * zeta + gamma) % r
         terms.append(((cf + alpha * alpha % r * lagrange_1) % r, z_poly))
         cf = alpha * beta % r * perm_next_eval % r
-        for j in range(4):
+        for j in range(W - 1):
             cf = cf * (we[j] + beta * wire_sigma_evals[j] + gamma) % r
-        terms.append(((-cf) % r, self.fixed[17]))
+        terms.append(((-cf) % r, sig[W - 1]))
+        if ultra:                                                        # compute_lin_poly_plookup_contribution, prover.rs:1037-1112
+            em = lambda first, ql, ds, a0, a1, a2: (first + ql * tau % r * (ds + tau * (a0 + tau * (a1 + tau * a2))) % r) % r
+            mt = em(pe["range_table_eval"], pe["q_lookup_eval"], pe["table_dom_sep_eval"], pe["key_table_eval"], we[3], we[4])
+            mt_next = em(pe["range_table_next_eval"], pe["q_lookup_next_eval"], pe["table_dom_sep_next_eval"], pe["key_table_next_eval"],
+                         pe["w_3_next_eval"], pe["w_4_next_eval"])
+            ml = em(we[5], pe["q_lookup_eval"], pe["q_dom_sep_eval"], we[0], we[1], we[2])
+            w_inv = pow(self.w_n, -1, r)
+            lagrange_n = vanish * w_inv % r * pow(n * (zeta - w_inv) % r, -1, r) % r
+            a4, a5, a6 = (pow(alpha, e, r) for e in (4, 5, 6))
+            b1 = (1 + beta) % r
+            g1 = gamma * b1 % r
+            zmg = (zeta - w_inv) % r
+            cf = (a4 * lagrange_1 + a5 * lagrange_n + a6 * zmg % r * b1 % r * ((gamma + ml) % r) % r * ((g1 + mt + beta * mt_next) % r)) % r
+            terms.append((cf, pl_poly))
+            cf = a6 * zmg % r * pe["prod_next_eval"] % r * ((g1 + pe["h_1_eval"] + beta * pe["h_1_next_eval"]) % r) % r
+            terms.append(((-cf) % r, h2))
         zeta_n2 = (vanish + 1) * zeta % r * zeta % r
         cf = 1
-        for i in range(5):
+        for i in range(W):
             terms.append(((-vanish) * cf % r, split[i]))
             cf = cf * zeta_n2 % r
         lin = poly.lincomb(c, terms, out_len=n + 3)
-        bterms = [(1, lin)]
-        cf = v_ch
-        for p in wire_polys + [self.fixed[13 + j] for j in range(4)]:
-            bterms.append((cf, p))
-            cf = cf * v_ch % r
-        batch = poly.lincomb(c, bterms, out_len=n + 3)
-        opening = poly.div_by_linear(c, batch, zeta)
-        shifted = poly.div_by_linear(c, z_poly.contiguous(), zeta * self.w_n % r)
+        open_polys = [lin] + wire_polys + sig[:W - 1]
+        shifted_polys = [z_poly]
+        if ultra:                                                        # plookup_open_polys_ref / plookup_shifted_open_polys_ref, prover.rs:421-460
+            open_polys += [tabs[0], tabs[1], h1, q_lookup, tabs[2], tabs[3]]
+            shifted_polys += [pl_poly, tabs[0], tabs[1], h1, h2, q_lookup, wire_polys[3], wire_polys[4], tabs[2]]
+
+        def batched(polys, point):                                       # compute_batched_witness_polynomial_commitment, prover.rs:490-509
+            bterms, cf = [], 1
+            for p in polys:
+                bterms.append((cf, p))
+                cf = cf * v_ch % r
+            return poly.div_by_linear(c, poly.lincomb(c, bterms, out_len=n + 3), point)
+
+        opening = batched(open_polys, zeta)
+        shifted = batched(shifted_polys, zeta_w) if len(shifted_polys) > 1 else poly.div_by_linear(c, z_poly.contiguous(), zeta_w)
         tick("r5_polys", t0)
         t0 = time.perf_counter()
-        jac = kzg.msm_bigint_batch(self.ck, [opening, shifted], scalars_are_mont=True)
-        xy = kzg.jacobian_to_affine(c, jac)
+        open_comms = self._commit([opening, shifted])
         tick("r5_commit", t0)
         self.last = {"wire_polys": wire_polys, "z_poly": z_poly, "quot": quot, "split": split, "lin": lin, "opening": opening, "shifted": shifted}
-        return ProofCore(wires_comms, z_comm, split_comms, kzg.Commitment(c, xy[0]), kzg.Commitment(c, xy[1]),
-                         wires_evals, wire_sigma_evals, perm_next_eval, tm)
+        if ultra:
+            self.last.update({"h_polys": [h1, h2], "prod_lookup_poly": pl_poly, "sorted_vec": sorted_vec, "merged_table": table, "merged_lookup": lookup})
+        return ProofCore(wires_comms, z_comm, split_comms, open_comms[0], open_comms[1], wires_evals, wire_sigma_evals, perm_next_eval, tm,
+                         h_comms, pl_comm, pe)

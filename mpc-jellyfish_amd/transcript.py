@@ -184,6 +184,12 @@ class StandardTranscript:
         for x in pub_input:
             self.append_field_elem(b"public input", x)
 
+    def append_plookup_evaluations(self, evals: dict) -> None:
+        """transcript/mod.rs:165-202: six of the fifteen Plookup evaluations are absorbed."""
+        for label, key in ((b"lookup_table_eval", "range_table_eval"), (b"h_1_eval", "h_1_eval"), (b"prod_next_eval", "prod_next_eval"),
+                           (b"lookup_table_next_eval", "range_table_next_eval"), (b"h_1_next_eval", "h_1_next_eval"), (b"h_2_next_eval", "h_2_next_eval")):
+            self.append_field_elem(label, evals[key])
+
     def get_and_append_challenge(self, label: bytes) -> int:
         buf = self.t.challenge_bytes(label, 64)
         ch = int.from_bytes(buf, "little") % self.curve.r
