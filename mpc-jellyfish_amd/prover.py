@@ -49,9 +49,9 @@ class ProverChallenges:
     tau: int = 0
 
 
-PLOOKUP_EVALS = ("range_table_eval", "key_table_eval", "h_1_eval", "q_lookup_eval", "prod_next_eval", "table_dom_sep_eval", "q_dom_sep_eval",
-                 "range_table_next_eval", "key_table_next_eval", "h_1_next_eval", "h_2_next_eval", "q_lookup_next_eval", "w_3_next_eval",
-                 "w_4_next_eval", "table_dom_sep_next_eval")                  # PlookupEvaluations, structs.rs:225-266
+PLOOKUP_EVALS = ("range_table_eval", "key_table_eval", "table_dom_sep_eval", "q_dom_sep_eval", "h_1_eval", "q_lookup_eval", "prod_next_eval",
+                 "range_table_next_eval", "key_table_next_eval", "table_dom_sep_next_eval", "h_1_next_eval", "h_2_next_eval",
+                 "q_lookup_next_eval", "w_3_next_eval", "w_4_next_eval")      # field order of PlookupEvaluations, structs.rs:496-541
 
 
 class FixedChallenges:

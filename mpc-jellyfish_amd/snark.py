@@ -1,0 +1,180 @@
+"""`PlonkKzgSnark::{preprocess, prove}` around the device prover core, with the reference's own deterministic inputs
+(SURVEY.md 8(d), 8(f) N3/N4):
+
+    gen_circuit_for_bench            plonk/benches/bench.rs:29-46        a = 0; repeat (gates - 10) times a = a + 1
+    PlonkCircuit::new / finalize     relation/src/constraint_system.rs:195-225, 966-999 (padding gates, wire permutation)
+    PlonkKzgSnark::preprocess        plonk/src/proof_system/snark.rs:529-617 (selector / sigma polynomials and commitments)
+    PlonkKzgSnark::prove             snark.rs:624-651 -> batch_prove_internal :201-469 (one instance)
+    Proof / PlookupProof layout      plonk/src/proof_system/structs.rs:59-84, 208-222, 440-450, 496-541 (ark-serialize, compressed)
+
+The circuit builder here is not the reference's constraint-system DSL (out of scope): it produces, vectorised, exactly
+the finalised arithmetisation that DSL yields for the bench circuit -- gate order, padding rows, the variable -> wire
+cycles of compute_wire_permutation (:743-778) and the ChaCha-derived coset representatives.
+"""
+from __future__ import annotations
+
+import struct
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import kzg, poly, prover as _prover, rng as _rng, transcript as _transcript
+from .domain import Radix2EvaluationDomain
+from .params import CurveParams, curve as _curve, fr_to_mont, fq_from_mont
+
+TURBO, ULTRA = "TurboPlonk", "UltraPlonk"
+
+
+@dataclass
+class BenchCircuit:
+    """What `Arithmetization` exposes of a finalised PlonkCircuit (relation/src/traits.rs), as device tensors."""
+    curve: CurveParams
+    plonk_type: str
+    n: int
+    k: list
+    wire_values: object          # (W, n, 4) int64 CUDA, Montgomery: witness[wire_variable(i, j)]
+    selector_values: object      # (13 | 14, n, 4)
+    sigma_values: object         # (W, n, 4): extended permutation k[pi] * w^pj
+    pub_input_values: object     # (n, 4) -- the bench circuit has no public input
+    public_input: list
+    table_values: object | None  # (4, n, 4): range, key, table_dom_sep, q_dom_sep (UltraPlonk)
+
+    @property
+    def num_wire_types(self):
+        return 6 if self.plonk_type == ULTRA else 5
+
+
+def _to_mont_dev(c: CurveParams, canon):
+    """(len, 4) int64 CUDA tensor of canonical limbs -> Montgomery form: x * (R mod r) with the Montgomery product."""
+    return poly.lincomb(c, [((1 << 256) % c.r, canon)])
+
+
+def gen_circuit_for_bench(curve, num_gates: int, plonk_type: str = TURBO, range_bit_len: int = 8) -> BenchCircuit:
+    import torch
+    c = _curve(curve)
+    assert num_gates >= 16 and plonk_type in (TURBO, ULTRA)
+    ultra = plonk_type == ULTRA
+    W = 6 if ultra else 5
+    n_add = num_gates - 10                                   # bench.rs:38-41
+    used = 2 + n_add                                         # two constant gates for the variables 0 and 1 (:221-223)
+    need = max(used, (1 << range_bit_len) + 1) if ultra else used          # constraint_system.rs:982-987 / proof_linking/mod.rs:78-88
+    n = 1 << (need - 1).bit_length()
+    log_n = n.bit_length() - 1
+    dev = torch.device("cuda")
+    # variable index on every (wire, row): 0 = zero, 1 = one, 2 + t = output of the t-th addition
+    var = torch.zeros((W, n), dtype=torch.int64, device=dev)
+    rows = torch.arange(2, 2 + n_add, device=dev)
+    var[0, 2:2 + n_add] = torch.where(rows == 2, torch.zeros_like(rows), rows - 1)          # a: previous sum (the first is `zero`)
+    var[1, 2:2 + n_add] = 1                                                                # b = one
+    var[4, 1] = 1                                                                          # constant gate of `one`
+    var[4, 2:2 + n_add] = rows                                                             # c = 2 + t  (row 2 + t)
+    # witness: zero, one, then 1, 2, 3, ...
+    wit = torch.zeros((2 + n_add, 4), dtype=torch.int64, device=dev)
+    wit[1, 0] = 1
+    wit[2:, 0] = torch.arange(1, n_add + 1, device=dev)
+    wit = _to_mont_dev(c, wit)
+    wire_values = wit[var.reshape(-1)].reshape(W, n, 4).contiguous()
+    one = torch.from_numpy(fr_to_mont(c, [1]).view(np.int64)).to(dev)[0]
+    nsel = 14 if ultra else 13
+    sel = torch.zeros((nsel, n, 4), dtype=torch.int64, device=dev)
+    sel[0, 2:2 + n_add] = one                                # AdditionGate: q_lc = [1, 1, 0, 0], q_o = 1 (gates/arithmetic.rs:38-51)
+    sel[1, 2:2 + n_add] = one
+    sel[10, 0:2 + n_add] = one                               # q_o of the constant and addition gates
+    sel[11, 1] = one                                         # ConstantGate(1): q_c = 1
+    # wire permutation (constraint_system.rs:743-778): occurrences of a variable in (wire, row) order form a cycle
+    flat = var.reshape(-1)
+    order = torch.argsort(flat, stable=True)
+    sv = flat[order]
+    first = torch.ones_like(sv, dtype=torch.bool)
+    first[1:] = sv[1:] != sv[:-1]
+    last = torch.ones_like(first)
+    last[:-1] = first[1:]
+    idx = torch.arange(flat.numel(), device=dev)
+    group_start = torch.cummax(torch.where(first, idx, torch.zeros_like(idx)), 0).values
+    nxt = torch.where(last, order[group_start], torch.roll(order, -1))
+    perm = torch.empty_like(order)
+    perm[order] = nxt
+    k = _rng.compute_coset_representatives(c, W, n)
+    dom = Radix2EvaluationDomain(c, log_n)
+    ext = torch.zeros((W, n, 4), dtype=torch.int64, device=dev)                            # id[i*n + j] = k_i * w^j  (:913-931)
+    ext[:, 1] = torch.from_numpy(fr_to_mont(c, k).view(np.int64)).to(dev)                  # the polynomial k_i * X ...
+    dom.fft_in_place(ext)                                                                  # ... evaluated on H
+    sigma = ext.reshape(-1, 4)[perm].reshape(W, n, 4).contiguous()
+    tables = None
+    if ultra:
+        tables = torch.zeros((4, n, 4), dtype=torch.int64, device=dev)
+        rt = torch.zeros((1 << range_bit_len, 4), dtype=torch.int64, device=dev)
+        rt[:, 0] = torch.arange(1 << range_bit_len, device=dev)
+        tables[0, :1 << range_bit_len] = _to_mont_dev(c, rt)                               # compute_range_table (:1423-1438)
+    return BenchCircuit(c, plonk_type, n, k, wire_values, sel, sigma, torch.zeros((n, 4), dtype=torch.int64, device=dev), [], tables)
+
+
+def preprocess(commit_key: kzg.UnivariateProverParam, circuit: BenchCircuit) -> _prover.TurboPlonkProver:
+    """snark.rs:529-617: interpolate selectors, sigmas (and Plookup tables), keep them with the commit key.  The
+    verifying-key commitments are produced on demand by `TurboPlonkProver.vk_commitments()`."""
+    c, n = circuit.curve, circuit.n
+    if commit_key.length < n + 3:
+        raise ValueError("SRS too small: need domain size + 3 powers (srs.rs:88)")          # snark.rs:535-541
+    dom = Radix2EvaluationDomain(c, n.bit_length() - 1)
+    sel = circuit.selector_values.clone()
+    sig = circuit.sigma_values.clone()
+    dom.ifft_in_place(sel)
+    dom.ifft_in_place(sig)
+    host = lambda t: t.cpu().numpy().view(np.uint64)
+    plookup = None
+    if circuit.table_values is not None:
+        tab = circuit.table_values.clone()
+        dom.ifft_in_place(tab)
+        tab_h = host(tab)
+        plookup = {name: tab_h[i] for i, name in enumerate(("range_table_poly", "key_table_poly", "table_dom_sep_poly", "q_dom_sep_poly"))}
+    return _prover.TurboPlonkProver(c, n, list(host(sel)), list(host(sig)), circuit.k, commit_key, plookup=plookup)
+
+
+def draw_blinders(curve, rng: _rng.ChaChaRng, num_wire_types: int, ultra: bool) -> _prover.Blinders:
+    """Every `DensePolynomial::rand` / `F::rand` of one proof, in the order the rounds draw them (prover.rs:79-83, 113-114,
+    133-138, 169-180, 947-955): the draws depend on nothing the rounds compute, so they can be taken up front."""
+    c = _curve(curve)
+    wires = [_rng.dense_poly_rand(c, 1, rng) for _ in range(num_wire_types)]
+    h = [_rng.dense_poly_rand(c, 2, rng) for _ in range(2)] if ultra else None
+    z = _rng.dense_poly_rand(c, 2, rng)
+    pl = _rng.dense_poly_rand(c, 2, rng) if ultra else None
+    quot = [_rng.fr_rand(c, rng) for _ in range(num_wire_types - 1)]
+    return _prover.Blinders(wires, z, quot, h, pl)
+
+
+def _g1(c: CurveParams, comm: kzg.Commitment) -> bytes:
+    if comm.is_infinity():
+        return _transcript.g1_bytes(c, None)
+    x, y = fq_from_mont(c, comm.xy)
+    return _transcript.g1_bytes(c, (x, y))
+
+
+def serialize_proof(curve, proof: _prover.ProofCore) -> bytes:
+    """`Proof::serialize_compressed` (derive(CanonicalSerialize), structs.rs:59-84): fields in declaration order,
+    Vec = u64 LE length + items, Option = one byte + payload, G1 compressed, Fr 32 bytes LE."""
+    c = _curve(curve)
+    fr = lambda v: _transcript.fr_bytes(c, v)
+    vec = lambda items, enc: struct.pack("<Q", len(items)) + b"".join(enc(x) for x in items)
+    g1 = lambda cm: _g1(c, cm)
+    out = vec(proof.wires_poly_comms, g1) + g1(proof.prod_perm_poly_comm) + vec(proof.split_quot_poly_comms, g1)
+    out += g1(proof.opening_proof) + g1(proof.shifted_opening_proof)
+    out += vec(proof.wires_evals, fr) + vec(proof.wire_sigma_evals, fr) + fr(proof.perm_next_eval)              # ProofEvaluations :440-450
+    if proof.plookup_evals is None:
+        out += b"\x00"
+    else:                                                                                                        # PlookupProof :208-222
+        out += b"\x01" + vec(proof.h_poly_comms, g1) + g1(proof.prod_lookup_poly_comm)
+        out += b"".join(fr(proof.plookup_evals[name]) for name in _prover.PLOOKUP_EVALS)                          # PlookupEvaluations :496-541
+    return out
+
+
+def prove(rng: _rng.ChaChaRng, circuit: BenchCircuit, pk: _prover.TurboPlonkProver, extra_transcript_init_msg: bytes | None = None,
+          profile: bool = False):
+    """PlonkKzgSnark::prove (snark.rs:624-651): returns (ProofCore, compressed proof bytes)."""
+    if (circuit.plonk_type == ULTRA) != pk.ultra:
+        raise ValueError("Mismatched Plonk types between the proving key and the circuit")                       # snark.rs:249-254
+    if circuit.n != pk.n:
+        raise ValueError("proving key domain size %d != expected domain size %d" % (pk.n, circuit.n))           # snark.rs:233-240
+    blind = draw_blinders(circuit.curve, rng, circuit.num_wire_types, pk.ultra)
+    src = _prover.TranscriptChallenges(pk, circuit.public_input, extra_transcript_init_msg)
+    core = pk.prove(circuit.wire_values, circuit.pub_input_values, src, blind, profile=profile)
+    return core, serialize_proof(circuit.curve, core)

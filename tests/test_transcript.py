@@ -70,3 +70,32 @@ def test_standard_transcript_challenges(mj):
     u2.append_vk_and_pub_input(1 << 10, 1, [1, 2, 3, 4, 5], [(c.gx, c.gy)] * 13, [None] * 5, [43])   # different public input
     u2.append_commitments(b"witness_poly_comms", [(c.gx, c.gy)] * 5)
     assert u2.get_and_append_challenge(b"tau") != tau
+
+
+def test_chacha_and_field_sampling(mj):
+    """rand_chacha: ChaCha20 / ChaCha12 / ChaCha8 keystream blocks for the all-zero key (RFC 7539 2.3.2-style vector and the
+    ChaCha test-vector draft TC1); BlockRng's u64 = two consecutive words; ark-ff's rejection sampling stays below r."""
+    import struct
+    R = mj.rng
+    blk = lambda rounds: struct.pack("<16I", *R.chacha_block((0,) * 8, 0, rounds)).hex()
+    assert blk(20) == ("76b8e0ada0f13d90405d6ae55386bd28bdd219b8a08ded1aa836efcc8b770dc7"
+                       "da41597c5157488d7724e03fb8d84a376a43b8f41518a11cc387b669b2ee6586")
+    assert blk(12) == ("9bf49a6a0755f953811fce125f2683d50429c3bb49e074147e0089a52eae155f"
+                       "0564f879d27ae3c02ce82834acfa8c793a629f2ca0de6919610be82f411326be")
+    assert blk(8) == ("3e00ef2f895f40d67f5bb8e81f09a5a12c840ec3ce9a7f3b181be188ef711a1e"
+                      "984ce172b9216f419f445367456d5619314a42a3da86b001387bfdb80e0cfe42")
+    g = R.ChaChaRng(bytes(32), 20)
+    words = R.chacha_block((0,) * 8, 0, 20)
+    assert g.next_u64() == words[0] | (words[1] << 32) and g.next_u32() == words[2]
+    g2 = R.ChaChaRng(bytes(32), 20)
+    for _ in range(32):
+        g2.next_u64()                                         # drains the four-block buffer exactly
+    assert g2.next_u64() == (lambda w: w[0] | (w[1] << 32))(R.chacha_block((0,) * 8, 4, 20))
+    for cid in (0, 1):
+        c = mj.params.CURVES[cid]
+        rng = R.test_rng()
+        vals = [R.fr_rand(c, rng) for _ in range(50)]
+        assert all(0 <= v < c.r for v in vals) and len(set(vals)) == 50
+        ks = R.compute_coset_representatives(c, 6, 1 << 10)
+        assert ks[0] == 1 and len({pow(k, 1 << 10, c.r) for k in ks}) == 6           # six distinct cosets of H
+        assert R.compute_coset_representatives(c, 5, 1 << 10) == ks[:5]
