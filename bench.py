@@ -49,6 +49,7 @@ def main():
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-plonk", action="store_true", help="skip the TurboPlonk round-3 (quotient) measurement")
     ap.add_argument("--plonk-log-n", type=int, default=20)
+    ap.add_argument("--ultra-log-n", type=int, default=20, help="UltraPlonk/BN254 prove leg (0 disables; config C5 is 22)")
     args = ap.parse_args()
 
     import torch
@@ -206,35 +207,74 @@ def main():
         pk.release()
         del d_polys, d_out, d_coeffs
 
-    # ---- secondary: the whole five-round prover core at 2^20 gates (config C4 minus transcript) -----
+    # ---- secondary: PlonkKzgSnark::prove on the reference's bench circuit at 2^20 gates (config C4, bench.rs:29-74) -----
     prove = None
     if not args.no_plonk and rank == 0 and world == 1:
         pl, pn = args.plonk_log_n, 1 << args.plonk_log_n
         ck = pp if pp.length >= pn + 3 else mj.UnivariateProverParam.gen_srs_for_testing(curve, beta, pn + 2)
-        fixed = mj.params.random_fr_mont(curve, 18 * pn, seed=41).reshape(18, pn, 4)
-        prover = mj.prover.TurboPlonkProver(curve, pn, list(fixed[:13]), list(fixed[13:]), [1, 2, 3, 4, 5], ck)
-        del fixed
-        wv = torch.from_numpy(mj.params.random_fr_mont(curve, 5 * pn, seed=42).reshape(5, pn, 4).view(np.int64)).to(dev)
-        pv = torch.zeros((pn, 4), dtype=torch.int64, device=dev)
-        chs = mj.prover.ProverChallenges(0x1111111, 0x2222222, 0x3333333, 0x4444444, 0x5555555)
-        bl = mj.prover.Blinders([[3, 5]] * 5, [7, 11, 13], [17, 19, 23, 29])
-        prover.prove(wv, pv, chs, bl)                       # warm-up (builds plans, precomputed SRS table)
+        t1 = time.perf_counter()
+        cs = mj.snark.gen_circuit_for_bench(curve, pn, "TurboPlonk")
+        torch.cuda.synchronize()
+        t_circ = time.perf_counter() - t1
+        t1 = time.perf_counter()
+        prover = mj.snark.preprocess(ck, cs)
+        prover.vk_commitments()
+        t_pre = time.perf_counter() - t1
+        rng = mj.rng.test_rng()
+        mj.snark.prove(rng, cs, prover)                     # warm-up (builds plans, precomputed SRS table)
         torch.cuda.synchronize()
         reps = 3
         t1 = time.perf_counter()
         for _ in range(reps):
-            proof = prover.prove(wv, pv, chs, bl)
+            core, proof_bytes = mj.snark.prove(rng, cs, prover)
         torch.cuda.synchronize()
         prove_ms = (time.perf_counter() - t1) / reps * 1e3
-        proof = prover.prove(wv, pv, chs, bl, profile=True)
-        prove = {"what": "all five rounds of one TurboPlonk proof on the device (7 iNTT(n), grand product, 7+1 NTT(8n), quotient, "
-                         "13 MSM, evaluations, linearisation, openings); challenges and blinders supplied, no transcript; random witness",
-                 "log_n": pl, "prove_core_ms": round(prove_ms, 2), "ns_per_gate": round(prove_ms * 1e6 / pn, 1),
-                 "rounds_ms": proof.timings_ms,
+        core, proof_bytes = mj.snark.prove(rng, cs, prover, profile=True)
+        quot = prover.last["quot"]
+        deg = 5 * (pn + 1) + 2
+        satisfied = bool(quot[deg].any().item()) and not bool(quot[deg + 1:].any().item())       # prover.rs:916-919
+        prove = {"what": "PlonkKzgSnark::prove of one TurboPlonk proof on the reference's bench circuit (bench.rs:29-46: a = a + 1, "
+                         "gates - 10 times): 7 iNTT(n), grand product, 7+1 NTT(8n), quotient, 13 MSM, evaluations, linearisation, "
+                         "openings, ChaCha test_rng blinders, Merlin transcript, compressed proof bytes; proving key resident",
+                 "log_n": pl, "prove_ms": round(prove_ms, 2), "ns_per_gate": round(prove_ms * 1e6 / pn, 1),
+                 "rounds_ms": core.timings_ms, "proof_bytes": len(proof_bytes), "quotient_degree_ok": satisfied,
+                 "circuit_build_s": round(t_circ, 3), "preprocess_s": round(t_pre, 3),
                  "reference_published": "29591 ns/gate at 2^15 gates, 24 threads of a 5900X (bench.md:16); not comparable hardware"}
         prover.release()
+        del cs, quot
         if ck is not pp:
             ck.release()
+
+    # ---- secondary: UltraPlonk (Plookup) on BN254, the shape of config C5 at --ultra-log-n gates, one GPU ---------------
+    ultra = None
+    if not args.no_plonk and rank == 0 and world == 1 and args.ultra_log_n:
+        ul, un = args.ultra_log_n, 1 << args.ultra_log_n
+        bn = mj.params.BN254
+        ck2 = mj.UnivariateProverParam.gen_srs_for_testing(bn, beta, un + 2)
+        cs = mj.snark.gen_circuit_for_bench(bn, un, "UltraPlonk")
+        t1 = time.perf_counter()
+        prover = mj.snark.preprocess(ck2, cs)
+        prover.vk_commitments()
+        t_pre = time.perf_counter() - t1
+        rng = mj.rng.test_rng()
+        mj.snark.prove(rng, cs, prover)
+        torch.cuda.synchronize()
+        reps = 2
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            core, proof_bytes = mj.snark.prove(rng, cs, prover)
+        torch.cuda.synchronize()
+        prove_ms = (time.perf_counter() - t1) / reps * 1e3
+        core, proof_bytes = mj.snark.prove(rng, cs, prover, profile=True)
+        quot = prover.last["quot"]
+        deg = 6 * (un + 1) + 2
+        satisfied = bool(quot[deg].any().item()) and not bool(quot[deg + 1:].any().item())
+        ultra = {"what": "PlonkKzgSnark::prove, UltraPlonk (Plookup, range_bit_len 8) bench circuit over BN254 on ONE GPU",
+                 "log_n": ul, "prove_ms": round(prove_ms, 2), "ns_per_gate": round(prove_ms * 1e6 / un, 1), "rounds_ms": core.timings_ms,
+                 "proof_bytes": len(proof_bytes), "quotient_degree_ok": satisfied, "preprocess_s": round(t_pre, 3)}
+        prover.release()
+        ck2.release()
+        del cs, quot
 
     # ---- CPU baseline: the C oracle ("port" of the ark-ec algorithm) on this host, rank 0 only -------
     cpu = None
@@ -273,7 +313,7 @@ def main():
                          "note": "integer-ALU bound (384-bit Montgomery mixed adds), not HBM bound: see DESIGN.md"},
             "phases_ms": {"sort": round(sort_ms / max(tot_cnt, 1), 4), "accumulate": round(acc_avg_ms, 4),
                           "reduce": round(red_ms / max(tot_cnt, 1), 4), "device_total": round(tot_ms / max(tot_cnt, 1), 4)},
-            "cpu_baseline": cpu, "ntt": ntt, "plonk_round3": plonk, "batch_commit5": batch, "prove_core": prove,
+            "cpu_baseline": cpu, "ntt": ntt, "plonk_round3": plonk, "batch_commit5": batch, "prove": prove, "prove_ultra_bn254": ultra,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

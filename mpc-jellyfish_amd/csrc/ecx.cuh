@@ -4,6 +4,10 @@
 // limb capacity has to be tracked).  Same formulas as ec.cuh (EFD madd-2008-s / add-2008-s /
 // dbl-2008-s-1 / mdbl-2008-s-1), same exceptional cases.
 //
+// BN254 Fq runs on 10 limbs (290 bits for a 254-bit p): the subtraction pads are then XPAD_MULT = 128 times larger
+// (constants.cuh), every "< Kp" below reads "< 128 Kp" (< 2^13 p at most, products still come out below 1.01 p), and
+// a pad exceeds the value it is subtracted from by more than 3 * 2^261 ~ 507 p, which the top-limb borrow needs.
+//
 // Limb classes:  M = every limb < 2^29 (an fx_mul result, or a canonical value)
 //                N = every limb < 2^29 + 8 (after fx_norm)
 // Invariant of an accumulator: X, Y in N with value < 64p; ZZ, ZZZ in M; infinity <=> ZZ == 0 (all limbs).

@@ -26,11 +26,12 @@ namespace mzk {
 constexpr int MSM_THREADS = 256;
 constexpr int MSM_ACC_THREADS = 128;
 
-// window size: ~log2(n) - 4, clamped; 16 divides 256 so the top signed digit always fits
+// window size of the plain path: ~log2(n) - 2 (mean bucket load ~8: short dependent chains, enough buckets to
+// fill the chip even for small n), clamped to [4, 16]
 inline int msm_choose_window(unsigned long long n) {
     int lg = 0;
     while ((1ull << (lg + 1)) <= n) lg++;
-    int c = lg - 4;
+    int c = lg - 2;
     if (c < 4) c = 4;
     if (c > 16) c = 16;
     return c;

@@ -3,6 +3,8 @@
 #include <thread>
 #include <vector>
 
+#include <cmath>
+
 #include "internal.hpp"
 #include "hostfp.hpp"
 #include "msm.cuh"
@@ -48,6 +50,7 @@ struct MsmItem {
     uint32_t* out_xyz;           // host, Jacobian
     uint64_t base_off;           // pre path: index of this MSM's first SRS point
 };
+constexpr unsigned long long MSM_MIN_CAP = 48;
 struct PreInfo { int c = 0; uint64_t tab_stride = 0; };      // c == 0: plain path
 
 template <class FQ>
@@ -78,7 +81,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     MZK_TRY(g_ws.hist.reserve(wm * 4));
     MZK_TRY(g_ws.offs.reserve(wm * 4));
     MZK_TRY(g_ws.cursor.reserve(wm * 4));                                // bucket order by load
-    const uint32_t desc_cap_max = (uint32_t)(sorted_max / 256 + 1);
+    const uint32_t desc_cap_max = (uint32_t)(sorted_max / MSM_MIN_CAP + 1);          // cap >= MSM_MIN_CAP below
     MZK_TRY(g_ws.long_desc.reserve((size_t)n_win * desc_cap_max * sizeof(LongDesc) + (size_t)n_win * 4));
     MZK_TRY(g_ws.long_parts.reserve((size_t)n_win * desc_cap_max * EC::PT_WORDS * 4));
     const unsigned long long dstride_max = (n_max + 7) & ~7ull;
@@ -117,8 +120,17 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
             const uint32_t* d_bases = items[p].d_bases;
             uint32_t* buckets = g_ws.buckets.as<uint32_t>() + (size_t)p * wm * EC::PT_WORDS;
             const uint64_t n_sorted = pre.c ? n * (uint64_t)n_dig : n;
-            // per-thread cap on a bucket's run: 8x the mean load, at least 256
-            const uint32_t cap = (uint32_t)std::max<unsigned long long>(256ull, 8ull * (n_sorted / M + 1));
+            // per-thread cap on a bucket's run (a chain of dependent mixed adds, ~5 us each when a wave runs alone): the
+            // expected peak load plus six standard deviations.  On the table path the short top digit (scalar bits above
+            // c * (n_dig - 1)) lands in the low 2^top_bits buckets only, which therefore carry n / 2^top_bits more points
+            // than the mean.  What exceeds the cap (skewed scalars; the plain path's short top window) goes to the
+            // chunked path below.
+            unsigned long long peak = n_sorted / M + 1;
+            if (pre.c) {
+                const int top_bits = (is_mont ? FR::BITS : 256) - c * (n_dig - 1);
+                if (top_bits < c - 1) peak += n >> (top_bits > 0 ? top_bits : 0);
+            }
+            const uint32_t cap = (uint32_t)std::max<unsigned long long>(MSM_MIN_CAP, peak + 6 * (unsigned long long)std::sqrt((double)peak) + 8);
             const uint32_t desc_cap = (uint32_t)(n_sorted / cap + 1);
             uint32_t* desc_count = reinterpret_cast<uint32_t*>(desc + (size_t)n_win * desc_cap);
             const unsigned long long dstride = (n + 7) & ~7ull;
@@ -207,7 +219,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     return MZK_OK;
 }
 
-constexpr uint64_t PRE_MIN_N = 1ull << 17;       // smaller MSMs stay on the plain path
+constexpr uint64_t PRE_MIN_N = 1ull << 10;       // smaller MSMs stay on the plain path
 
 template <class FR, class EC>
 int32_t msm_batch_dev(const MsmItem* items, int count, int is_mont, const PreInfo& pre, const uint32_t* plain_table, size_t aff_words,
@@ -234,13 +246,13 @@ int32_t msm_batch_dev(const MsmItem* items, int count, int is_mont, const PreInf
     return MZK_OK;
 }
 
-// table[w][i] = 2^(c*w) * P_i for every SRS point (msm_pre.cuh); BLS12-381 only for now
-int32_t srs_build_pre(Srs& s, hipStream_t st) {
-    if (s.d_pre || s.pre_c < 0 || s.curve != MZK_CURVE_BLS12_381 || !s.d_int) return MZK_OK;
-    using EC = EcFx<BlsFqX>;
+// table[w][i] = 2^(c*w) * P_i for every SRS point (msm_pre.cuh)
+template <class X>
+int32_t srs_build_pre_t(Srs& s, hipStream_t st) {
+    using EC = EcFx<X>;
     int lg = 0;
     while ((2ull << lg) <= s.n) lg++;
-    const int c = lg < 18 ? 18 : (lg > 22 ? 22 : lg);
+    const int c = lg < 12 ? 12 : (lg > 22 ? 22 : lg);
     const int W = msm_num_windows(256, c);
     const size_t level = (size_t)s.n * EC::AFF_WORDS;
     size_t free_b = 0, total_b = 0;
@@ -250,12 +262,16 @@ int32_t srs_build_pre(Srs& s, hipStream_t st) {
     HIP_TRY(hipMemcpyAsync(s.d_pre, s.d_int, level * 4, hipMemcpyDeviceToDevice, st));
     const unsigned long long threads = (s.n + 3) / 4;
     for (int w = 1; w < W; w++)
-        hipLaunchKernelGGL((pre_next_level_kernel<BlsFqX>), dim3((unsigned)((threads + 127) / 128)), dim3(128), 0, st,
+        hipLaunchKernelGGL((pre_next_level_kernel<X>), dim3((unsigned)((threads + 127) / 128)), dim3(128), 0, st,
                            s.d_pre + (size_t)(w - 1) * level, s.d_pre + (size_t)w * level, (unsigned long long)s.n, c);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
     s.pre_c = c;
     return MZK_OK;
+}
+int32_t srs_build_pre(Srs& s, hipStream_t st) {
+    if (s.d_pre || s.pre_c < 0 || !s.d_int) return MZK_OK;
+    return s.curve == MZK_CURVE_BLS12_381 ? srs_build_pre_t<BlsFqX>(s, st) : srs_build_pre_t<BnFqX>(s, st);
 }
 
 }  // namespace
@@ -268,10 +284,11 @@ int32_t msm_dispatch(const Srs& s, uint64_t base_offset, const uint32_t* d_scala
 int32_t msm_batch_dispatch(const Srs& s, uint32_t n_polys, const uint32_t* const* d_scalars, const uint64_t* lens, const uint64_t* base_offsets,
                            int is_mont, uint32_t* out_xyz, hipStream_t st) {
     const int fw = fq_words(s.curve);
-    // BLS12-381 runs on the reduced-radix internal table (EcFx), BN254 on the boundary form (EcFp)
-    const bool internal = s.d_int != nullptr;
-    const size_t aff_words = internal ? (size_t)EcFx<BlsFqX>::AFF_WORDS : (size_t)2 * fw;
-    const uint32_t* table = internal ? s.d_int : s.d_xy;
+    // both curves run on the reduced-radix internal table (EcFx: 14 x 29-bit limbs for BLS12-381 Fq, 10 x 29 for BN254 Fq)
+    const bool bls = s.curve == MZK_CURVE_BLS12_381;
+    const size_t aff_words = bls ? (size_t)EcFx<BlsFqX>::AFF_WORDS : (size_t)EcFx<BnFqX>::AFF_WORDS;
+    const uint32_t* table = s.d_int;
+    if (!table) { set_error("SRS has no internal table"); return MZK_ERR_BAD_HANDLE; }
     std::vector<MsmItem> items(n_polys);
     bool want_pre = false;
     for (uint32_t i = 0; i < n_polys; i++) {
@@ -291,25 +308,28 @@ int32_t msm_batch_dispatch(const Srs& s, uint32_t n_polys, const uint32_t* const
     }
     if (pre.c)
         for (auto& it : items) it.d_bases = s.d_pre;
-    if (s.curve == MZK_CURVE_BLS12_381) return msm_batch_dev<BlsFr, EcFx<BlsFqX>>(items.data(), (int)n_polys, is_mont, pre, table, aff_words, st);
-    return msm_batch_dev<BnFr, EcFp<BnFq>>(items.data(), (int)n_polys, is_mont, pre, table, aff_words, st);
+    if (bls) return msm_batch_dev<BlsFr, EcFx<BlsFqX>>(items.data(), (int)n_polys, is_mont, pre, table, aff_words, st);
+    return msm_batch_dev<BnFr, EcFx<BnFqX>>(items.data(), (int)n_polys, is_mont, pre, table, aff_words, st);
 }
 
-// builds the internal (reduced-radix) copy of a freshly registered BLS12-381 SRS; BN254 keeps d_int = nullptr
-int32_t srs_build_internal(Srs& s, hipStream_t st) {
-    s.d_int = nullptr;
-    s.d_pre = nullptr;
-    s.pre_c = 0;
-    if (s.curve != MZK_CURVE_BLS12_381) return MZK_OK;
-    using EC = EcFx<BlsFqX>;
+// builds the internal (reduced-radix) copy of a freshly registered SRS
+template <class X>
+static int32_t srs_build_internal_t(Srs& s, hipStream_t st) {
+    using EC = EcFx<X>;
     HIP_TRY(hipMalloc((void**)&s.d_int, (size_t)(s.n ? s.n : 1) * EC::AFF_WORDS * 4));
     if (s.n) {
-        hipLaunchKernelGGL((srs_to_internal_kernel<BlsFqX>), dim3((unsigned)((s.n + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0, st,
+        hipLaunchKernelGGL((srs_to_internal_kernel<X>), dim3((unsigned)((s.n + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0, st,
                            s.d_xy, s.n, s.d_int);
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(st));
     }
     return MZK_OK;
+}
+int32_t srs_build_internal(Srs& s, hipStream_t st) {
+    s.d_int = nullptr;
+    s.d_pre = nullptr;
+    s.pre_c = 0;
+    return s.curve == MZK_CURVE_BLS12_381 ? srs_build_internal_t<BlsFqX>(s, st) : srs_build_internal_t<BnFqX>(s, st);
 }
 
 namespace {

@@ -196,9 +196,11 @@ __global__ __launch_bounds__(128) void pre_next_level_kernel(const uint32_t* __r
     Fx<X> run = Fx<X>::one();
 #pragma unroll
     for (int j = 0; j < B; j++) {
-        const unsigned long long i = start + j < n ? start + j : n - 1;
-        XYZZX<X> p = XYZZX<X>::from_affine(EC::load_aff(cur, i));
-        for (int k = 0; k < c; k++) p = xyzzx_dbl(p);
+        XYZZX<X> p = XYZZX<X>::inf();                                // slots past the end stay out of the shared inversion
+        if (start + j < n) {
+            p = XYZZX<X>::from_affine(EC::load_aff(cur, start + j));
+            for (int k = 0; k < c; k++) p = xyzzx_dbl(p);
+        }
         pt[j] = p;
         pref[j] = run;
         if (!p.is_inf()) run = fx_mul(run, p.zzz);                   // zzz is class M
