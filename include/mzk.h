@@ -102,6 +102,11 @@ MZK_API int32_t mzk_g1_sum_jacobian(int32_t curve_id, const uint64_t* xyz_mont, 
 /* Host-only: n Jacobian points -> affine x||y ((0,0) for infinity): `.into_affine()` (mod.rs:111) / normalize_batch. */
 MZK_API int32_t mzk_g1_jacobian_to_affine(int32_t curve_id, const uint64_t* xyz_mont, uint64_t n, uint64_t* out_xy_mont);
 
+/* Host-only: the Keccak-f[1600] permutation on 200 bytes (lane (x, y) at byte offset 8 (x + 5 y), little-endian): the
+ * primitive under merlin's STROBE-128, for hosts that mirror the transcript of plonk/src/transcript/standard.rs:16-46
+ * outside Rust (the Python prover mirror; a Rust caller keeps using merlin). */
+MZK_API int32_t mzk_keccak_f1600(uint8_t* state200);
+
 /* ---- NTT: replaces EvaluationDomain::{fft,ifft}_in_place on Radix2EvaluationDomain
  *      forward coset: plonk/src/proof_system/prover.rs:554,557,561,566,567,579-591
  *      inverse coset: plonk/src/proof_system/prover.rs:672

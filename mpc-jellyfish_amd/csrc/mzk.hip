@@ -364,6 +364,34 @@ int32_t mzk_ntt(int32_t curve_id, uint64_t* data_mont, uint64_t in_len, uint32_t
     return mzk_ntt_batch(curve_id, 1, ptrs, lens, log_n, inverse, coset_offset_mont);
 }
 
+// ---- host-only: Keccak-f[1600] for the Merlin/STROBE transcript mirror (plonk/src/transcript/standard.rs) ----------------
+int32_t mzk_keccak_f1600(uint8_t* state200) {
+    if (!state200) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    static const uint64_t RC[24] = {0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull, 0x000000000000808Bull,
+                                    0x0000000080000001ull, 0x8000000080008081ull, 0x8000000000008009ull, 0x000000000000008Aull, 0x0000000000000088ull,
+                                    0x0000000080008009ull, 0x000000008000000Aull, 0x000000008000808Bull, 0x800000000000008Bull, 0x8000000000008089ull,
+                                    0x8000000000008003ull, 0x8000000000008002ull, 0x8000000000000080ull, 0x000000000000800Aull, 0x800000008000000Aull,
+                                    0x8000000080008081ull, 0x8000000000008080ull, 0x0000000080000001ull, 0x8000000080008008ull};
+    static const int ROT[25] = {0, 1, 62, 28, 27, 36, 44, 6, 55, 20, 3, 10, 43, 25, 39, 41, 45, 15, 21, 8, 18, 2, 61, 56, 14};     // lane x + 5y
+    uint64_t a[25], b[25], c[5];
+    std::memcpy(a, state200, 200);                                   // little-endian host
+    auto rol = [](uint64_t v, int n) { return n ? (v << n) | (v >> (64 - n)) : v; };
+    for (int r = 0; r < 24; r++) {
+        for (int x = 0; x < 5; x++) c[x] = a[x] ^ a[x + 5] ^ a[x + 10] ^ a[x + 15] ^ a[x + 20];
+        for (int x = 0; x < 5; x++) {
+            const uint64_t d = c[(x + 4) % 5] ^ rol(c[(x + 1) % 5], 1);
+            for (int y = 0; y < 5; y++) a[x + 5 * y] ^= d;
+        }
+        for (int x = 0; x < 5; x++)
+            for (int y = 0; y < 5; y++) b[y + 5 * ((2 * x + 3 * y) % 5)] = rol(a[x + 5 * y], ROT[x + 5 * y]);
+        for (int x = 0; x < 5; x++)
+            for (int y = 0; y < 5; y++) a[x + 5 * y] = b[x + 5 * y] ^ (~b[(x + 1) % 5 + 5 * y] & b[(x + 2) % 5 + 5 * y]);
+        a[0] ^= RC[r];
+    }
+    std::memcpy(state200, a, 200);
+    return MZK_OK;
+}
+
 // ---- TurboPlonk quotient round ------------------------------------------------------------------------
 int32_t mzk_plonk_pk_register(int32_t curve_id, uint32_t log_n, uint32_t num_wire_types, const uint64_t* selector_coeffs,
                               const uint64_t* sigma_coeffs, uint64_t poly_len, const uint64_t* k_mont, uint64_t* out_handle) {

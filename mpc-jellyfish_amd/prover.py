@@ -161,6 +161,7 @@ class TurboPlonkProver:
         self.k = list(k)
         self.ck = commit_key
         self.ultra = plookup is not None
+        self.committer = None                        # set to a sharding.ShardedCommitter for multi-GPU commits
         self.W = len(sigma_polys)
         self.nsel = len(selector_polys)
         self.pk = plonk.ProvingKeyDevice.register(self.curve, domain_size, selector_polys, sigma_polys, k, plookup)
@@ -172,6 +173,14 @@ class TurboPlonkProver:
         self.tab0 = self.nsel + self.W               # rows of range, key, table_dom_sep, q_dom_sep
         self.domain = Radix2EvaluationDomain(self.curve, self.log_n)
         self.w_n = pow(self.curve.fr_generator, (self.curve.r - 1) >> self.log_n, self.curve.r)
+        # per-proof workspace, allocated once (the round-3 slab alone is (W + 2 [+ 3]) x 8n x 32 B: 1.9 GB at n = 2^20):
+        # the caching allocator would otherwise re-acquire gigabytes per proof
+        rows = self.W + 2 + (3 if self.ultra else 0)
+        dev = self.fixed.device
+        self._slab = torch.empty((rows, 8 * domain_size, 4), dtype=torch.int64, device=dev)
+        self._quot = torch.empty((8 * domain_size, 4), dtype=torch.int64, device=dev)
+        self._keep = torch.empty((rows, domain_size + 3, 4), dtype=torch.int64, device=dev)
+        self._coeff = torch.empty((self.W + 1, domain_size, 4), dtype=torch.int64, device=dev)
 
     def vk_commitments(self):
         """selector_comms, sigma_comms of the verifying key (preprocess, snark.rs:562-594), cached."""
@@ -207,7 +216,12 @@ class TurboPlonkProver:
         t[row, self.n:self.n + h] = b
 
     def _commit(self, polys):
-        jac = kzg.msm_bigint_batch(self.ck, [p.contiguous() for p in polys], scalars_are_mont=True)
+        """batch_commit (mod.rs:119-131); with `self.committer` (sharding.ShardedCommitter) the MSMs are split by point
+        range over the ranks of a process group and every rank obtains the same commitments."""
+        if self.committer is not None:
+            jac = self.committer.commit_jacobian([p.contiguous() for p in polys])
+        else:
+            jac = kzg.msm_bigint_batch(self.ck, [p.contiguous() for p in polys], scalars_are_mont=True)
         return [kzg.Commitment(self.curve, xy) for xy in kzg.jacobian_to_affine(self.curve, jac)]
 
     def prove(self, wire_values, pub_input_values, ch, blind: Blinders, profile: bool = False) -> ProofCore:
@@ -231,9 +245,10 @@ class TurboPlonkProver:
         Z, PI, H1, PL = W, W + 1, W + 2, W + 4
         rows = W + 2 + (3 if ultra else 0)
         t0 = time.perf_counter()
-        slab = torch.zeros((rows, m, 4), dtype=torch.int64, device=dev)
+        slab = self._slab                                               # only the first n + 3 columns are read (in_len of the coset NTT)
+        slab[:, n:n + 3] = 0
         # ---- round 1 (prover.rs:72-87)
-        coeff = torch.empty((W + 1, n, 4), dtype=torch.int64, device=dev)
+        coeff = self._coeff
         coeff[:W] = wv
         coeff[W] = pv
         self.domain.ifft_in_place(coeff)
@@ -287,8 +302,9 @@ class TurboPlonkProver:
             tick("r2_5_commit", t0)
         # ---- round 3 (prover.rs:192-209, 512-673, 902-960)
         t0 = time.perf_counter()
-        keep = slab[:, :n + 3].clone()                                   # coefficient forms survive the in-place coset NTT
-        quot = torch.empty((m, 4), dtype=torch.int64, device=dev)
+        keep = self._keep
+        keep.copy_(slab[:, :n + 3])                                      # coefficient forms survive the in-place coset NTT
+        quot = self._quot
         alpha = src.after_round2(z_comm, pl_comm)
         plonk.compute_quotient_polynomial_dev(self.pk, plonk.Challenges(alpha, beta, gamma, tau), slab, n + 3, quot)
         tick("r3_quotient", t0)
@@ -317,6 +333,8 @@ class TurboPlonkProver:
         wire_polys = [keep[i, :n + 2] for i in range(W)]
         z_poly = keep[Z]
         zeta = src.after_round3(split_comms)
+        tick("r4_transcript", t0)
+        t0 = time.perf_counter()
         zeta_w = zeta * self.w_n % r
         sig = [self.fixed[self.sigma0 + j] for j in range(W)]
         wires_evals = poly.evaluate(c, keep[:W], zeta, length=n + 2)
@@ -324,6 +342,8 @@ class TurboPlonkProver:
         perm_next_eval = poly.evaluate(c, z_poly, zeta_w)[0]
         pe = None
         if ultra:
+            tick("r4_evals", t0)
+            t0 = time.perf_counter()
             tabs = self.fixed[self.tab0:self.tab0 + 4]                    # range, key, table_dom_sep, q_dom_sep
             q_lookup = self.fixed[13]
             h1, h2, pl_poly = keep[H1], keep[H1 + 1], keep[PL]
@@ -335,7 +355,9 @@ class TurboPlonkProver:
                   "q_lookup_next_eval": poly.evaluate(c, q_lookup, zeta_w)[0]}
             nx = poly.evaluate(c, keep[[PL, H1, H1 + 1, 3, 4]], zeta_w)
             pe.update({"prod_next_eval": nx[0], "h_1_next_eval": nx[1], "h_2_next_eval": nx[2], "w_3_next_eval": nx[3], "w_4_next_eval": nx[4]})
-        tick("r4_evals", t0)
+            tick("r4_5_plookup_evals", t0)
+        else:
+            tick("r4_evals", t0)
         # ---- round 5: linearisation polynomial (prover.rs:963-1112, 343-358) and openings (362-460, 490-509)
         t0 = time.perf_counter()
         v_ch = src.after_round4(wires_evals, wire_sigma_evals, perm_next_eval, pe)

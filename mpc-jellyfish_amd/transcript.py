@@ -29,8 +29,9 @@ def _rol(x, n):
     return ((x << n) | (x >> (64 - n))) & _M64 if n else x
 
 
-def keccak_f1600(state: bytearray) -> None:
-    """In-place Keccak-f[1600] on 200 bytes (lane (x, y) at byte offset 8 (x + 5 y), little-endian)."""
+def keccak_f1600_py(state: bytearray) -> None:
+    """In-place Keccak-f[1600] on 200 bytes (lane (x, y) at byte offset 8 (x + 5 y), little-endian); pure Python,
+    kept as the cross-check of the library's host function."""
     a = [[int.from_bytes(state[8 * (x + 5 * y):8 * (x + 5 * y) + 8], "little") for y in range(5)] for x in range(5)]
     for rc in _RC:
         c = [a[x][0] ^ a[x][1] ^ a[x][2] ^ a[x][3] ^ a[x][4] for x in range(5)]
@@ -45,6 +46,14 @@ def keccak_f1600(state: bytearray) -> None:
     for x in range(5):
         for y in range(5):
             state[8 * (x + 5 * y):8 * (x + 5 * y) + 8] = a[x][y].to_bytes(8, "little")
+
+
+def keccak_f1600(state: bytearray) -> None:
+    """In-place Keccak-f[1600] through the library's host-only entry point (no GPU involved)."""
+    import ctypes as C
+    from . import lib as _lib
+    buf = (C.c_uint8 * 200).from_buffer(state)
+    _lib.check(_lib.load().mzk_keccak_f1600(C.addressof(buf)), "mzk_keccak_f1600")
 
 
 class Strobe128:

@@ -75,3 +75,39 @@ def test_host_ec_sum_edge_cases(mj, cref):
         assert not s[2].any()
         s = mj.sharding.sum_jacobian(c, np.zeros((0, 3, L), dtype=np.uint64))
         assert not s[2].any()
+
+
+def _committer_worker(rank, world, port, curve_id, lens, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import cref
+    import mpc_jellyfish_amd as mj
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c = mj.params.CURVES[curve_id]
+        bases = cref.g1_arith_bases(curve_id, 99, 5, max(lens))
+        polys = [mj.params.random_fr_mont(c, n, seed=300 + i) for i, n in enumerate(lens)]
+        oracle_batch = lambda ck, slices, offs: np.stack([cref.msm(curve_id, bases[o:o + len(s)], s, scalars_are_mont=True) for s, o in zip(slices, offs)])
+        com = mj.sharding.ShardedCommitter(c, None, msm_batch=oracle_batch)
+        np.save(os.path.join(out_dir, f"commits_{rank}.npy"), com.commit_jacobian(polys))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_batch_commit(tmp_path, cref, mj, world):
+    """ShardedCommitter: k polynomials of different lengths (one empty, one shorter than the world size), every rank ends
+    with the same k commitments = the unsharded MSMs."""
+    import torch.multiprocessing as mp
+    curve_id, lens = 0, [130, 131, 0, 1, 64]
+    port = 29500 + (os.getpid() + 7 * world) % 2000
+    mp.spawn(_committer_worker, args=(world, port, curve_id, lens, str(tmp_path)), nprocs=world, join=True)
+    c = mj.params.CURVES[curve_id]
+    bases = cref.g1_arith_bases(curve_id, 99, 5, max(lens))
+    for i, n in enumerate(lens):
+        want = cref.jac_to_affine(curve_id, cref.msm(curve_id, bases[:n], mj.params.random_fr_mont(c, n, seed=300 + i), scalars_are_mont=True))[0]
+        for rank in range(world):
+            got = np.load(tmp_path / f"commits_{rank}.npy")[i]
+            assert np.array_equal(cref.jac_to_affine(curve_id, got)[0], want), (i, rank)

@@ -20,6 +20,10 @@ def _sha3_256(T, msg: bytes) -> bytes:
 
 def test_keccak_f1600_against_hashlib(mj):
     T = mj.transcript
+    st1, st2 = bytearray(range(200)), bytearray(range(200))
+    T.keccak_f1600(st1)                                   # library host function
+    T.keccak_f1600_py(st2)                                # pure-Python cross-check
+    assert st1 == st2
     for msg in (b"", b"abc", b"\x00" * 135, b"\xff" * 136, b"jellyfish" * 50):
         assert _sha3_256(T, msg) == hashlib.sha3_256(msg).digest()
 
