@@ -62,16 +62,25 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libmi355zk has no CPU fallback)")
+    # rehearsal switches (not used by the driver): all ranks on GPU 0 with gloo collectives, to exercise the N > 1 code on a 1-GPU box
+    backend = os.environ.get("MZK_BENCH_BACKEND", "nccl")
+    if os.environ.get("MZK_BENCH_SINGLE_DEVICE"):
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    cdev = dev if backend == "nccl" else torch.device("cpu")          # where collective payloads live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=dev)
+        else:
+            dist.init_process_group(backend)
 
     import mpc_jellyfish_amd as mj
     from importlib import import_module
     mlib = import_module("mpc-jellyfish_amd.lib")
     L = mlib.init(local_rank)
+    coll_dev = dev if backend == "nccl" else None
 
     curve = mj.params.BLS12_381
     n = 1 << args.log_n
@@ -90,7 +99,7 @@ def main():
     def step():
         jac = mj.msm_bigint(pp, d_scalars, scalars_are_mont=True)            # one Pippenger MSM, result on host
         if world > 1:
-            jac = mj.sharding.all_gather_sum(curve, jac, device=dev)
+            jac = mj.sharding.all_gather_sum(curve, jac, device=coll_dev)
         return jac
 
     for _ in range(args.warmup):
@@ -109,7 +118,7 @@ def main():
     elapsed = time.perf_counter() - t0
     L.mzk_profile_enable(0)
     if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
     acc_ms, acc_cnt = mlib.profile_get("msm_accumulate")
@@ -246,6 +255,41 @@ def main():
         if ck is not pp:
             ck.release()
 
+    # ---- secondary, N > 1: the same proof with every commitment's MSM split by point range over the ranks;
+    #      NTTs, quotient and polynomial work are replicated, so this is the strong-scaling figure of the commit half only
+    prove_sharded = None
+    if not args.no_plonk and world > 1:
+        pl, pn = args.plonk_log_n, 1 << args.plonk_log_n
+        ck = mj.UnivariateProverParam.gen_srs_for_testing(curve, beta, pn + 2)          # the same SRS on every rank
+        cs = mj.snark.gen_circuit_for_bench(curve, pn, "TurboPlonk")
+        prover = mj.snark.preprocess(ck, cs)
+        prover.vk_commitments()
+        prover.committer = mj.sharding.ShardedCommitter(curve, ck, device=coll_dev)
+        rng = mj.rng.test_rng()
+        for _ in range(3):
+            mj.snark.prove(rng, cs, prover)
+        torch.cuda.synchronize()
+        dist.barrier()
+        reps = 3
+        t1 = time.perf_counter()
+        for _ in range(reps):
+            core, proof_bytes = mj.snark.prove(rng, cs, prover)
+        torch.cuda.synchronize()
+        dist.barrier()
+        tmax = torch.tensor([(time.perf_counter() - t1) / reps * 1e3], dtype=torch.float64, device=cdev)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        digest = torch.tensor([int.from_bytes(proof_bytes[8:15], "little")], dtype=torch.int64, device=cdev)
+        lo, hi = digest.clone(), digest.clone()
+        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+        prove_sharded = {"what": "PlonkKzgSnark::prove, TurboPlonk bench circuit, commitments sharded by point range over the ranks "
+                                 "(all-gather of Jacobian partials + local EC sum), everything else replicated",
+                         "log_n": pl, "prove_ms": round(float(tmax.item()), 2), "ranks_agree_on_proof": bool(lo.item() == hi.item()),
+                         "proof_bytes": len(proof_bytes)}
+        prover.release()
+        ck.release()
+        del cs
+
     # ---- secondary: UltraPlonk (Plookup) on BN254, the shape of config C5 at --ultra-log-n gates, one GPU ---------------
     ultra = None
     if not args.no_plonk and rank == 0 and world == 1 and args.ultra_log_n:
@@ -315,7 +359,7 @@ def main():
                          "note": "integer-ALU bound (384-bit Montgomery mixed adds), not HBM bound: see DESIGN.md"},
             "phases_ms": {"sort": round(sort_ms / max(tot_cnt, 1), 4), "accumulate": round(acc_avg_ms, 4),
                           "reduce": round(red_ms / max(tot_cnt, 1), 4), "device_total": round(tot_ms / max(tot_cnt, 1), 4)},
-            "cpu_baseline": cpu, "ntt": ntt, "plonk_round3": plonk, "batch_commit5": batch, "prove": prove, "prove_ultra_bn254": ultra,
+            "cpu_baseline": cpu, "ntt": ntt, "plonk_round3": plonk, "batch_commit5": batch, "prove": prove, "prove_sharded": prove_sharded, "prove_ultra_bn254": ultra,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -412,7 +412,16 @@ __global__ __launch_bounds__(1024) void msm_long_combine_kernel(const LongDesc* 
     if (cnt == 0) return;
     const LongDesc* dw = desc + (size_t)w * desc_cap;
     const size_t pbase = (size_t)w * desc_cap;
-    for (uint32_t s = 1; s < cnt; s <<= 1) {
+    // the tree is as deep as the longest run
+    __shared__ uint32_t max_run;
+    if (t == 0) max_run = 0;
+    __syncthreads();
+    uint32_t mine = 0;
+    for (uint32_t i = t; i < cnt; i += 1024) mine = max(mine, dw[i].run_len);
+    if (mine) atomicMax(&max_run, mine);
+    __syncthreads();
+    const uint32_t longest = max_run;
+    for (uint32_t s = 1; s < longest; s <<= 1) {
         for (uint32_t i = t; i < cnt; i += 1024) {
             const LongDesc d = dw[i];
             if ((d.idx_in_run & (2 * s - 1)) == 0 && d.idx_in_run + s < d.run_len) {

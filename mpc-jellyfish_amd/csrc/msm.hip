@@ -123,12 +123,13 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
             // per-thread cap on a bucket's run (a chain of dependent mixed adds, ~5 us each when a wave runs alone): the
             // expected peak load plus six standard deviations.  On the table path the short top digit (scalar bits above
             // c * (n_dig - 1)) lands in the low 2^top_bits buckets only, which therefore carry n / 2^top_bits more points
-            // than the mean.  What exceeds the cap (skewed scalars; the plain path's short top window) goes to the
-            // chunked path below.
+            // than the mean -- folded into the cap while moderate.  What exceeds the cap (skewed scalars; a short top
+            // window) goes to the chunked path below.
             unsigned long long peak = n_sorted / M + 1;
             if (pre.c) {
                 const int top_bits = (is_mont ? FR::BITS : 256) - c * (n_dig - 1);
-                if (top_bits < c - 1) peak += n >> (top_bits > 0 ? top_bits : 0);
+                const unsigned long long extra = top_bits < c - 1 ? n >> (top_bits > 0 ? top_bits : 0) : 0;
+                if (extra <= 4 * peak) peak += extra;      // a very short top digit (few buckets, huge runs) is left to the chunked path
             }
             const uint32_t cap = (uint32_t)std::max<unsigned long long>(MSM_MIN_CAP, peak + 6 * (unsigned long long)std::sqrt((double)peak) + 8);
             const uint32_t desc_cap = (uint32_t)(n_sorted / cap + 1);
@@ -252,7 +253,14 @@ int32_t srs_build_pre_t(Srs& s, hipStream_t st) {
     using EC = EcFx<X>;
     int lg = 0;
     while ((2ull << lg) <= s.n) lg++;
-    const int c = lg < 12 ? 12 : (lg > 22 ? 22 : lg);
+    // Window size of the table.  Only sizes whose TOP digit still spans many buckets are eligible: with all windows sharing
+    // one bucket set, a top digit of t bits piles n / 2^t extra points onto each of the lowest 2^t buckets (bits(r) = 255
+    // for BLS12-381, 254 for BN254; digits = ceil((bits + 1) / c)):
+    //   BLS12-381: c = 16 -> 16 digits, top 15 bits;  c = 20 -> 13 digits, top 15 bits
+    //   BN254:     c = 15 -> 17 digits, top 14 bits;  c = 17 -> 15 digits, top 16 bits;  c = 20 -> 13 digits, top 14 bits
+    int c;
+    if (s.curve == MZK_CURVE_BLS12_381) c = lg <= 16 ? 16 : 20;
+    else c = lg <= 15 ? 15 : (lg <= 18 ? 17 : 20);
     const int W = msm_num_windows(256, c);
     const size_t level = (size_t)s.n * EC::AFF_WORDS;
     size_t free_b = 0, total_b = 0;
