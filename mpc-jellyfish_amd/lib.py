@@ -75,6 +75,13 @@ def load():
         if not os.path.exists(path):
             raise FileNotFoundError(f"{path} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
                                     "(hipcc, gfx950). There is no CPU fallback.")
+        # One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64 (same SONAME as /opt/rocm's).  If this
+        # library were loaded first it would bind /opt/rocm's copy, torch would then bring up its own, and the first one
+        # would find no device.  Importing torch first makes both share torch's copy.
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
         L = C.CDLL(path)
         for name, args in _SIGS.items():
             f = getattr(L, name)
