@@ -172,6 +172,23 @@ MZK_API int32_t mzk_plookup_sorted_vec_dev(uint64_t pk_handle, const void* d_wir
 MZK_API int32_t mzk_plookup_product_dev(uint64_t pk_handle, const void* d_merged_table, const void* d_merged_lookup, const void* d_sorted,
                                         const uint64_t* beta_mont, const uint64_t* gamma_mont, void* d_out, void* stream);
 
+/* ---- Coset-chunked quotient for multi-GPU proving.  The 8n-point coset g*H_8n is the union of the 8
+ * cosets h_k*H_n, h_k = g*w_8n^k (the residue classes of the point index mod 8); the closure of prover.rs:605-659 reads
+ * index i and (i + 8) mod 8n only, so each class is self-contained.  A chunked key holds the fixed polynomials on the listed
+ * classes only (strictly increasing `classes`, each < 8); num_wire_types 5 (table_coeffs NULL) or 6.
+ * mzk_plonk_quotient_chunked_dev: d_polys = (W + 2 [+ 3]) rows of in_stride elements, coefficients in the first in_len
+ * (<= 2n) slots, NOT overwritten; d_out = n_classes x n elements: for each resident class k the n coefficients of
+ * t mod (X^n - h_k^n) (local inverse coset NTT done).  After the ranks exchange these (one all-gather / all-to-all),
+ * mzk_plonk_quotient_combine_dev turns the 8 class remainders (class-major, 8 x n) into the 8n coefficients that
+ * `coset.ifft` returns at prover.rs:672 (an 8-point inverse DFT per coefficient index). */
+MZK_API int32_t mzk_plonk_pk_register_chunked(int32_t curve_id, uint32_t log_n, uint32_t num_wire_types, const uint64_t* selector_coeffs,
+                                              const uint64_t* sigma_coeffs, const uint64_t* table_coeffs, uint64_t poly_len,
+                                              const uint64_t* k_mont, const uint32_t* classes, uint32_t n_classes, uint64_t* out_handle);
+MZK_API int32_t mzk_plonk_quotient_chunked_dev(uint64_t pk_handle, const void* d_polys, uint64_t in_stride, uint64_t in_len,
+                                               const uint64_t* tau_mont, const uint64_t* alpha_mont, const uint64_t* beta_mont,
+                                               const uint64_t* gamma_mont, void* d_out, void* stream);
+MZK_API int32_t mzk_plonk_quotient_combine_dev(int32_t curve_id, uint32_t log_n, const void* d_class_remainders, void* d_out, void* stream);
+
 /* Round 2: replaces Arithmetization::compute_prod_permutation_polynomial
  * (relation/src/constraint_system.rs:1197-1223), whose loop performs one field division per gate.
  * wire_values: 5 x n (UltraPlonk key: 6 x n) wire evaluations witness[wire_variable(i, j)]; the sigma evaluations

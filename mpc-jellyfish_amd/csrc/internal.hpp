@@ -95,7 +95,11 @@ int32_t poly_lincomb_dispatch(int curve, uint32_t n_terms, const uint32_t* const
                               uint64_t out_len, hipStream_t st);
 // plonk.hip
 int32_t plonk_pk_register(int curve, int log_n, int W, const uint32_t* sel, const uint32_t* sig, const uint32_t* tab /* NULL: TurboPlonk */,
-                          uint64_t poly_len, const uint32_t* k_mont, uint64_t* out_handle);
+                          uint64_t poly_len, const uint32_t* k_mont, const uint32_t* classes /* NULL: whole domain */, uint32_t n_classes,
+                          uint64_t* out_handle);
+int32_t plonk_quotient_chunked_dev(uint64_t handle, const uint32_t* d_polys, uint64_t in_stride, uint64_t in_len, const uint32_t* tau, const uint32_t* alpha,
+                                   const uint32_t* beta, const uint32_t* gamma, uint32_t* d_out, hipStream_t st);
+int32_t plonk_quotient_combine_dev(int curve, int log_n, const uint32_t* d_r, uint32_t* d_out, hipStream_t st);
 int32_t plonk_pk_release(uint64_t handle);
 void plonk_release_all();
 int32_t plonk_quotient_dev(uint64_t handle, uint32_t* d_polys, uint64_t in_len, const uint32_t* tau /* NULL: TurboPlonk */, const uint32_t* alpha,

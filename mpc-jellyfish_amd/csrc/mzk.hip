@@ -399,7 +399,8 @@ int32_t mzk_plonk_pk_register(int32_t curve_id, uint32_t log_n, uint32_t num_wir
     MZK_TRY(require_init());
     if (num_wire_types != 5) { set_error("TurboPlonk proving key: 5 wire types (UltraPlonk: mzk_plonk_pk_register_ultra)"); return MZK_ERR_INVALID_ARG; }
     return plonk_pk_register(curve_id, (int)log_n, (int)num_wire_types, reinterpret_cast<const uint32_t*>(selector_coeffs),
-                             reinterpret_cast<const uint32_t*>(sigma_coeffs), nullptr, poly_len, reinterpret_cast<const uint32_t*>(k_mont), out_handle);
+                             reinterpret_cast<const uint32_t*>(sigma_coeffs), nullptr, poly_len, reinterpret_cast<const uint32_t*>(k_mont), nullptr, 0,
+                             out_handle);
 }
 int32_t mzk_plonk_pk_register_ultra(int32_t curve_id, uint32_t log_n, const uint64_t* selector_coeffs, const uint64_t* sigma_coeffs,
                                     const uint64_t* table_coeffs, uint64_t poly_len, const uint64_t* k_mont, uint64_t* out_handle) {
@@ -407,7 +408,31 @@ int32_t mzk_plonk_pk_register_ultra(int32_t curve_id, uint32_t log_n, const uint
     MZK_TRY(require_init());
     if (!table_coeffs) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     return plonk_pk_register(curve_id, (int)log_n, 6, reinterpret_cast<const uint32_t*>(selector_coeffs), reinterpret_cast<const uint32_t*>(sigma_coeffs),
-                             reinterpret_cast<const uint32_t*>(table_coeffs), poly_len, reinterpret_cast<const uint32_t*>(k_mont), out_handle);
+                             reinterpret_cast<const uint32_t*>(table_coeffs), poly_len, reinterpret_cast<const uint32_t*>(k_mont), nullptr, 0, out_handle);
+}
+int32_t mzk_plonk_pk_register_chunked(int32_t curve_id, uint32_t log_n, uint32_t num_wire_types, const uint64_t* selector_coeffs,
+                                      const uint64_t* sigma_coeffs, const uint64_t* table_coeffs, uint64_t poly_len, const uint64_t* k_mont,
+                                      const uint32_t* classes, uint32_t n_classes, uint64_t* out_handle) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    if (!classes || (num_wire_types == 6) != (table_coeffs != nullptr)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
+    return plonk_pk_register(curve_id, (int)log_n, (int)num_wire_types, reinterpret_cast<const uint32_t*>(selector_coeffs),
+                             reinterpret_cast<const uint32_t*>(sigma_coeffs), reinterpret_cast<const uint32_t*>(table_coeffs), poly_len,
+                             reinterpret_cast<const uint32_t*>(k_mont), classes, n_classes, out_handle);
+}
+int32_t mzk_plonk_quotient_chunked_dev(uint64_t pk_handle, const void* d_polys, uint64_t in_stride, uint64_t in_len, const uint64_t* tau_mont,
+                                       const uint64_t* alpha_mont, const uint64_t* beta_mont, const uint64_t* gamma_mont, void* d_out, void* stream) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    return plonk_quotient_chunked_dev(pk_handle, reinterpret_cast<const uint32_t*>(d_polys), in_stride, in_len, reinterpret_cast<const uint32_t*>(tau_mont),
+                                      reinterpret_cast<const uint32_t*>(alpha_mont), reinterpret_cast<const uint32_t*>(beta_mont),
+                                      reinterpret_cast<const uint32_t*>(gamma_mont), reinterpret_cast<uint32_t*>(d_out), (hipStream_t)stream);
+}
+int32_t mzk_plonk_quotient_combine_dev(int32_t curve_id, uint32_t log_n, const void* d_class_remainders, void* d_out, void* stream) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    return plonk_quotient_combine_dev(curve_id, (int)log_n, reinterpret_cast<const uint32_t*>(d_class_remainders), reinterpret_cast<uint32_t*>(d_out),
+                                      (hipStream_t)stream);
 }
 int32_t mzk_plonk_pk_release(uint64_t pk_handle) {
     std::lock_guard<std::mutex> lk(g_lock);

@@ -32,7 +32,10 @@ struct QuotientArgs {
     const uint32_t* xs;       // [m]  x_i = g * w_m^i
     const uint32_t* inv_den;  // [m]  1 / (n * (x_i - 1))
     uint32_t* out;            // [m]
-    unsigned long long m;
+    unsigned long long m;     // points per stream in this launch: 8n (whole quotient domain) or n (one residue class mod 8)
+    unsigned long long fstride, ostride;   // elements between consecutive fixed (sel, sig, tab) / online (wire, h) polynomials
+    unsigned int next_off;    // index distance of the point w_n * x: 8 in natural order, 1 inside a residue class
+    int zh_class;             // >= 0: the residue class of every point of this launch; < 0: i % 8
     uint32_t k[PLK_MAX_WIRES][8];     // coset representatives k_j (Montgomery)
     uint32_t alpha[8], alpha2[8], beta[8], gamma[8];
     uint32_t zh_inv[PLK_RATIO][8];    // 1 / Z_H(x_i), period 8 in i
@@ -59,11 +62,12 @@ __global__ __launch_bounds__(PLK_THREADS) void plonk_quotient_kernel(QuotientArg
     const unsigned long long i = (unsigned long long)blockIdx.x * PLK_THREADS + threadIdx.x;
     if (i >= a.m) return;
     const unsigned long long m = a.m;
-    const unsigned long long inext = (i + PLK_RATIO) % m;             // the point w_n * x_i (prover.rs:611, 627, 804)
+    const unsigned long long inext = (i + a.next_off) % m;            // the point w_n * x_i (prover.rs:611, 627, 804)
+    const unsigned long long fs = a.fstride, os = a.ostride;
     F w[W];
 #pragma unroll
-    for (int j = 0; j < W; j++) w[j] = load_fp<P>(a.wire + ((size_t)j * m + i) * 8);
-    auto sel = [&](int j) { return load_fp<P>(a.sel + ((size_t)j * m + i) * 8); };
+    for (int j = 0; j < W; j++) w[j] = load_fp<P>(a.wire + ((size_t)j * os + i) * 8);
+    auto sel = [&](int j) { return load_fp<P>(a.sel + ((size_t)j * fs + i) * 8); };
     // ---- gate identity (prover.rs:696-708)
     F t = sel(11) + load_fp<P>(a.pi + i * 8);                       // q_c + pi
 #pragma unroll
@@ -88,24 +92,24 @@ __global__ __launch_bounds__(PLK_THREADS) void plonk_quotient_kernel(QuotientArg
     for (int j = 0; j < W; j++) {
         const F wg = w[j] + gamma;
         acc1 = acc1 * (wg + arg_fp<P>(a.k[j]) * xb);
-        acc2 = acc2 * (wg + load_fp<P>(a.sig + ((size_t)j * m + i) * 8) * beta);
+        acc2 = acc2 * (wg + load_fp<P>(a.sig + ((size_t)j * fs + i) * 8) * beta);
     }
     F t1 = t + alpha * (acc1 - acc2);
     F t2 = arg_fp<P>(a.alpha2) * ((z_x - F::one()) * load_fp<P>(a.inv_den + i * 8));
     if constexpr (ULTRA) {
         // ---- Plookup (prover.rs:773-888): alpha^3 L_n (h1 - h2(wX)) + alpha^4 L_1 (p - 1) + alpha^5 L_n (p - 1) + alpha^6 (X - w^-1) [...]
-        auto tab = [&](int j, unsigned long long at) { return load_fp<P>(a.tab + ((size_t)j * m + at) * 8); };
+        auto tab = [&](int j, unsigned long long at) { return load_fp<P>(a.tab + ((size_t)j * fs + at) * 8); };
         const F tau = arg_fp<P>(a.tau), alpha3 = arg_fp<P>(a.alpha3);
-        const F ql = sel(13), ql_next = load_fp<P>(a.sel + ((size_t)13 * m + inext) * 8);
+        const F ql = sel(13), ql_next = load_fp<P>(a.sel + ((size_t)13 * fs + inext) * 8);
         const F h1 = load_fp<P>(a.h + i * 8), h1n = load_fp<P>(a.h + inext * 8);
-        const F h2 = load_fp<P>(a.h + (m + i) * 8), h2n = load_fp<P>(a.h + (m + inext) * 8);
+        const F h2 = load_fp<P>(a.h + (os + i) * 8), h2n = load_fp<P>(a.h + (os + inext) * 8);
         const F p = load_fp<P>(a.pl + i * 8), pn = load_fp<P>(a.pl + inext * 8);
         auto merged = [&](const F& first, const F& q, const F& ds, const F& a0, const F& a1, const F& a2) {
             return first + q * tau * (ds + tau * (a0 + tau * (a1 + tau * a2)));
         };
         const F mt = merged(tab(0, i), ql, tab(2, i), tab(1, i), w[3], w[4]);
-        const F mt_next = merged(tab(0, inext), ql_next, tab(2, inext), tab(1, inext), load_fp<P>(a.wire + ((size_t)3 * m + inext) * 8),
-                                 load_fp<P>(a.wire + ((size_t)4 * m + inext) * 8));
+        const F mt_next = merged(tab(0, inext), ql_next, tab(2, inext), tab(1, inext), load_fp<P>(a.wire + ((size_t)3 * os + inext) * 8),
+                                 load_fp<P>(a.wire + ((size_t)4 * os + inext) * 8));
         const F ml = merged(w[5], ql, tab(3, i), w[0], w[1], w[2]);
         const F lag_n = load_fp<P>(a.inv_den_n + i * 8), lag_1 = load_fp<P>(a.inv_den + i * 8);
         const F pm1 = p - F::one();
@@ -115,7 +119,7 @@ __global__ __launch_bounds__(PLK_THREADS) void plonk_quotient_kernel(QuotientArg
         const F term3 = (x - arg_fp<P>(a.w_inv)) * (p * b1 * (gamma + ml) * (g1 + mt + beta * mt_next) - pn * (g1 + h1 + beta * h1n) * (g1 + h2 + beta * h2n));
         t1 = t1 + sqr(alpha3) * term3;
     }
-    store_fp<P>(a.out + i * 8, t1 * arg_fp<P>(a.zh_inv[i % PLK_RATIO]) + t2);          // prover.rs:657
+    store_fp<P>(a.out + i * 8, t1 * arg_fp<P>(a.zh_inv[a.zh_class >= 0 ? a.zh_class : (int)(i % PLK_RATIO)]) + t2);          // prover.rs:657
 }
 
 // xs[i] = g * w^i and inv_den[i] = 1/(n (xs[i] - 1)), 16 points per thread with one shared inversion
@@ -145,6 +149,49 @@ __global__ __launch_bounds__(PLK_THREADS) void plonk_domain_tables_kernel(const 
         const F d = load_fp<P>(inv_den + (start + j) * 8);
         store_fp<P>(inv_den + (start + j) * 8, inv_run * pref[j]);
         inv_run = inv_run * d;
+    }
+}
+
+// ---- coset-chunked quotient -----------------------------------------------------------------------
+// The 8n-point coset g*H_8n splits into 8 residue classes mod 8: class k is the coset h_k * H_n with h_k = g * w_8n^k.
+// A polynomial p of degree < 2n evaluates on class k as the size-n coset NTT (offset h_k) of p mod (X^n - h_k^n):
+//   folded[j] = p[j] + h_k^n * p[n + j].
+template <class P>
+__global__ __launch_bounds__(PLK_THREADS) void plonk_fold_kernel(const uint32_t* __restrict__ src, unsigned long long src_stride, unsigned long long in_len,
+                                                                  unsigned long long n, int rows, const uint32_t* __restrict__ c_mont,
+                                                                  uint32_t* __restrict__ dst) {
+    using F = Fp<P>;
+    const unsigned long long t = (unsigned long long)blockIdx.x * PLK_THREADS + threadIdx.x;
+    if (t >= n * (unsigned long long)rows) return;
+    const unsigned long long row = t / n, j = t % n;
+    const uint32_t* p = src + row * src_stride * 8;
+    F v = j < in_len ? load_fp<P>(p + j * 8) : F::zero();
+    if (n + j < in_len) v = v + load_fp<P>(c_mont) * load_fp<P>(p + (n + j) * 8);
+    store_fp<P>(dst + t * 8, v);
+}
+
+// r_k = t mod (X^n - c_k), c_k = g^n w_8^k, for the 8 classes k  ->  the 8 coefficient slabs T_q of t = sum_q X^(qn) T_q:
+//   r_k[j] = sum_q c_k^q T_q[j]   =>   T_q[j] = g^(-nq) / 8 * sum_k w_8^(-kq) r_k[j]      (an 8-point inverse DFT per j)
+struct CombineArgs {
+    const uint32_t* r;         // [8][n] class-major
+    uint32_t* out;             // [8n]
+    unsigned long long n;
+    uint32_t mat[8][8][8];     // mat[q][k] = g^(-nq) / 8 * w_8^(-kq), Montgomery
+};
+template <class P>
+__global__ __launch_bounds__(PLK_THREADS) void plonk_combine_kernel(CombineArgs a) {
+    using F = Fp<P>;
+    const unsigned long long j = (unsigned long long)blockIdx.x * PLK_THREADS + threadIdx.x;
+    if (j >= a.n) return;
+    F r[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) r[k] = load_fp<P>(a.r + ((size_t)k * a.n + j) * 8);
+#pragma unroll 1
+    for (int q = 0; q < 8; q++) {
+        F acc = arg_fp<P>(a.mat[q][0]) * r[0];
+#pragma unroll
+        for (int k = 1; k < 8; k++) acc = acc + arg_fp<P>(a.mat[q][k]) * r[k];
+        store_fp<P>(a.out + ((size_t)q * a.n + j) * 8, acc);
     }
 }
 

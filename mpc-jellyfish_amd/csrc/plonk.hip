@@ -1,6 +1,7 @@
 // plonk.hip -- host side of the device-resident TurboPlonk quotient round (plonk.cuh).
 #include <array>
 #include <map>
+#include <vector>
 #include <memory>
 
 #include "internal.hpp"
@@ -25,6 +26,11 @@ struct PlonkPk {
     uint32_t zh_inv[PLK_RATIO][8];
     uint32_t gen[8];
     uint32_t w_inv[8];                  // w_n^-1
+    // coset-chunked key: only the residue classes mod 8 listed in cls are resident, class-major
+    // ([poly][local class][n]); empty = the whole 8n-point domain in natural order
+    std::vector<int> cls;
+    uint32_t h_cls[PLK_RATIO][8];       // h_k = g * w_8n^k
+    uint32_t c_cls[PLK_RATIO][8];       // h_k^n
     std::array<uint32_t*, 7> bufs() const { return {d_fixed, d_xs, d_inv_den, d_inv_den_n, d_sigma_n, d_omega_n, d_tab_n}; }
 };
 std::map<uint64_t, std::unique_ptr<PlonkPk>> g_pks;
@@ -254,7 +260,7 @@ int32_t quotient_run(const PlonkPk& pk, uint32_t* d_polys, uint64_t in_len, cons
     a.xs = pk.d_xs;
     a.inv_den = pk.d_inv_den;
     a.out = d_out;
-    a.m = m;
+    a.m = m; a.fstride = m; a.ostride = m; a.next_off = PLK_RATIO; a.zh_class = -1;
     std::memcpy(a.k, pk.k, sizeof a.k);
     std::memcpy(a.zh_inv, pk.zh_inv, sizeof a.zh_inv);
     F al, a2;
@@ -287,6 +293,187 @@ int32_t quotient_run(const PlonkPk& pk, uint32_t* d_polys, uint64_t in_len, cons
     return MZK_OK;
 }
 
+// xs[j] = h * w^j, 16 points per thread
+template <class P>
+__global__ __launch_bounds__(PLK_THREADS) void plonk_class_points_kernel(const uint32_t* __restrict__ w_mont, const uint32_t* __restrict__ h_mont,
+                                                                         unsigned long long n, uint32_t* __restrict__ xs) {
+    using F = Fp<P>;
+    const unsigned long long start = ((unsigned long long)blockIdx.x * PLK_THREADS + threadIdx.x) * 16;
+    if (start >= n) return;
+    const F w = load_fp<P>(w_mont);
+    F x = pow_u64(w, start) * load_fp<P>(h_mont);
+    for (int j = 0; j < 16 && start + j < n; j++) {
+        store_fp<P>(xs + (start + j) * 8, x);
+        x = x * w;
+    }
+}
+
+// proving key holding only the residue classes `pk.cls` of the quotient domain (each class = the coset h_k * H_n)
+template <class P>
+int32_t pk_build_chunked(PlonkPk& pk, const uint32_t* sel_coeffs, const uint32_t* sig_coeffs, const uint32_t* tab_coeffs, uint64_t poly_len) {
+    using F = Fp<P>;
+    const int log_m = pk.log_n + 3;
+    const uint64_t n = 1ull << pk.log_n;
+    const int nfix = pk.nsel + pk.W + (pk.ultra ? 4 : 0);
+    const size_t ncl = pk.cls.size();
+    hipStream_t st = nullptr;
+    for (int i = 0; i < 8; i++) pk.gen[i] = P::GENERATOR[i];
+    F w = F::from_const(P::ROOT);
+    for (int i = log_m; i < P::TWO_ADICITY; i++) w = sqr(w);
+    F wn = F::from_const(P::ROOT);
+    for (int i = pk.log_n; i < P::TWO_ADICITY; i++) wn = sqr(wn);
+    const F g = F::from_const(P::GENERATOR), nf = from_u64<P>(n), wn_inv = inv(wn);
+    for (int q = 0; q < 8; q++) pk.w_inv[q] = wn_inv.l[q];
+    for (int i = 0; i < PLK_RATIO; i++) {
+        const F h = pow_u64(w, (uint64_t)i) * g, c = pow_u64(h, n);
+        const F zi = inv(c - F::one());
+        for (int q = 0; q < 8; q++) { pk.h_cls[i][q] = h.l[q]; pk.c_cls[i][q] = c.l[q]; pk.zh_inv[i][q] = zi.l[q]; }
+    }
+    HIP_TRY(hipMalloc((void**)&pk.d_fixed, (size_t)nfix * ncl * n * 32));
+    HIP_TRY(hipMalloc((void**)&pk.d_xs, ncl * n * 32));
+    HIP_TRY(hipMalloc((void**)&pk.d_inv_den, ncl * n * 32));
+    if (pk.ultra) HIP_TRY(hipMalloc((void**)&pk.d_inv_den_n, ncl * n * 32));
+    HIP_TRY(hipMemsetAsync(pk.d_fixed, 0, (size_t)nfix * ncl * n * 32, st));
+    const uint64_t sl = poly_len < n ? poly_len : n;               // fixed polynomials have degree < n
+    MZK_TRY(ws_acquire(st));
+    MZK_TRY(g_ws.misc.reserve(256));
+    uint32_t* d_c = g_ws.misc.as<uint32_t>();
+    const F one = F::one(), scale_n = nf * wn;
+    HIP_TRY(hipMemcpyAsync(d_c, wn.l, 32, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_c + 8, nf.l, 32, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_c + 16, one.l, 32, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_c + 24, wn_inv.l, 32, hipMemcpyHostToDevice, st));
+    HIP_TRY(hipMemcpyAsync(d_c + 32, scale_n.l, 32, hipMemcpyHostToDevice, st));
+    const unsigned tg = (unsigned)(((n + 15) / 16 + PLK_THREADS - 1) / PLK_THREADS);
+    for (size_t lc = 0; lc < ncl; lc++) {
+        const int k = pk.cls[lc];
+        uint32_t* base = pk.d_fixed + lc * n * 8;
+        const size_t row = ncl * n * 32;                              // bytes between consecutive polynomials
+        HIP_TRY(hipMemcpy2DAsync(base, row, sel_coeffs, poly_len * 32, sl * 32, pk.nsel, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpy2DAsync(base + (size_t)pk.nsel * ncl * n * 8, row, sig_coeffs, poly_len * 32, sl * 32, pk.W, hipMemcpyHostToDevice, st));
+        if (pk.ultra)
+            HIP_TRY(hipMemcpy2DAsync(base + (size_t)(pk.nsel + pk.W) * ncl * n * 8, row, tab_coeffs, poly_len * 32, sl * 32, 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(d_c + 40, pk.h_cls[k], 32, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL((plonk_class_points_kernel<P>), dim3(tg), dim3(PLK_THREADS), 0, st, d_c, d_c + 40, n, pk.d_xs + lc * n * 8);
+        hipLaunchKernelGGL((plonk_shifted_inverse_kernel<P>), dim3(tg), dim3(PLK_THREADS), 0, st, pk.d_xs + lc * n * 8, n, d_c + 16, d_c + 8,
+                           pk.d_inv_den + lc * n * 8);
+        if (pk.ultra)
+            hipLaunchKernelGGL((plonk_shifted_inverse_kernel<P>), dim3(tg), dim3(PLK_THREADS), 0, st, pk.d_xs + lc * n * 8, n, d_c + 24, d_c + 32,
+                               pk.d_inv_den_n + lc * n * 8);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipStreamSynchronize(st));                            // d_c + 40 is rewritten for the next class
+    }
+    // gate-domain tables for the grand products (replicated on every rank)
+    HIP_TRY(hipMalloc((void**)&pk.d_sigma_n, (size_t)pk.W * n * 32));
+    HIP_TRY(hipMalloc((void**)&pk.d_omega_n, n * 32));
+    HIP_TRY(hipMemsetAsync(pk.d_sigma_n, 0, (size_t)pk.W * n * 32, st));
+    HIP_TRY(hipMemcpy2DAsync(pk.d_sigma_n, n * 32, sig_coeffs, poly_len * 32, sl * 32, pk.W, hipMemcpyHostToDevice, st));
+    hipLaunchKernelGGL((fr_powers_mont_kernel<P>), dim3(tg), dim3(PLK_THREADS), 0, st, d_c, n, pk.d_omega_n);
+    HIP_TRY(hipGetLastError());
+    MZK_TRY(ws_release(st));
+    // class evaluations of the fixed polynomials: size-n coset NTTs with offset h_k, all polynomials of a class in one batch
+    for (size_t lc = 0; lc < ncl; lc++)
+        MZK_TRY(ntt_dispatch(pk.curve, pk.d_fixed + lc * n * 8, sl, pk.log_n, false, pk.h_cls[pk.cls[lc]], nfix, ncl * n, st));
+    MZK_TRY(ntt_dispatch(pk.curve, pk.d_sigma_n, sl, pk.log_n, false, nullptr, pk.W, n, st));
+    if (pk.ultra) {
+        HIP_TRY(hipMalloc((void**)&pk.d_tab_n, (size_t)5 * n * 32));
+        HIP_TRY(hipMemsetAsync(pk.d_tab_n, 0, (size_t)5 * n * 32, st));
+        HIP_TRY(hipMemcpy2DAsync(pk.d_tab_n, n * 32, tab_coeffs, poly_len * 32, sl * 32, 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipMemcpyAsync(pk.d_tab_n + (size_t)4 * n * 8, sel_coeffs + (size_t)13 * poly_len * 8, sl * 32, hipMemcpyHostToDevice, st));
+        MZK_TRY(ntt_dispatch(pk.curve, pk.d_tab_n, sl, pk.log_n, false, nullptr, 5, n, st));
+    }
+    HIP_TRY(hipStreamSynchronize(st));
+    return MZK_OK;
+}
+
+// per resident class: fold the online polynomials mod (X^n - h_k^n), size-n coset NTTs, the fused kernel on n points,
+// size-n inverse coset NTT.  d_out[lc] = t mod (X^n - h_k^n), n coefficients per class.
+template <class P>
+int32_t quotient_chunked_run(const PlonkPk& pk, const uint32_t* d_polys, uint64_t in_stride, uint64_t in_len, const uint32_t* tau, const uint32_t* alpha,
+                             const uint32_t* beta, const uint32_t* gamma, uint32_t* d_out, hipStream_t st) {
+    using F = Fp<P>;
+    const uint64_t n = 1ull << pk.log_n;
+    const int rows = pk.W + 2 + (pk.ultra ? 3 : 0);
+    const size_t ncl = pk.cls.size();
+    ProfScope total("plonk_quotient_chunked_total", st);
+    MZK_TRY(ws_acquire(st));
+    MZK_TRY(g_ws.plonk_polys.reserve((size_t)rows * n * 32 + 64));
+    uint32_t* work = g_ws.plonk_polys.as<uint32_t>();
+    uint32_t* d_c = work + (size_t)rows * n * 8;
+    QuotientArgs a;
+    a.m = n; a.fstride = ncl * n; a.ostride = n; a.next_off = 1;
+    std::memcpy(a.k, pk.k, sizeof a.k);
+    std::memcpy(a.zh_inv, pk.zh_inv, sizeof a.zh_inv);
+    F al, a2;
+    std::memcpy(al.l, alpha, 32);
+    a2 = sqr(al);
+    std::memcpy(a.alpha, alpha, 32);
+    std::memcpy(a.alpha2, a2.l, 32);
+    std::memcpy(a.beta, beta, 32);
+    std::memcpy(a.gamma, gamma, 32);
+    if (pk.ultra) {
+        const F a3 = a2 * al;
+        std::memcpy(a.tau, tau, 32);
+        std::memcpy(a.alpha3, a3.l, 32);
+        std::memcpy(a.w_inv, pk.w_inv, 32);
+    }
+    const unsigned long long fold_threads = n * (unsigned long long)rows;
+    for (size_t lc = 0; lc < ncl; lc++) {
+        const int k = pk.cls[lc];
+        HIP_TRY(hipMemcpyAsync(d_c, pk.c_cls[k], 32, hipMemcpyHostToDevice, st));
+        hipLaunchKernelGGL((plonk_fold_kernel<P>), dim3((unsigned)((fold_threads + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st,
+                           d_polys, in_stride, in_len, n, rows, d_c, work);
+        HIP_TRY(hipGetLastError());
+        MZK_TRY(ntt_dispatch(pk.curve, work, n, pk.log_n, false, pk.h_cls[k], rows, n, st));
+        a.sel = pk.d_fixed + lc * n * 8;
+        a.sig = pk.d_fixed + ((size_t)pk.nsel * ncl + lc) * n * 8;
+        a.tab = pk.ultra ? pk.d_fixed + ((size_t)(pk.nsel + pk.W) * ncl + lc) * n * 8 : nullptr;
+        a.wire = work;
+        a.z = work + (size_t)pk.W * n * 8;
+        a.pi = work + (size_t)(pk.W + 1) * n * 8;
+        a.h = pk.ultra ? work + (size_t)(pk.W + 2) * n * 8 : nullptr;
+        a.pl = pk.ultra ? work + (size_t)(pk.W + 4) * n * 8 : nullptr;
+        a.xs = pk.d_xs + lc * n * 8;
+        a.inv_den = pk.d_inv_den + lc * n * 8;
+        a.inv_den_n = pk.ultra ? pk.d_inv_den_n + lc * n * 8 : nullptr;
+        a.out = d_out + lc * n * 8;
+        a.zh_class = k;
+        const dim3 grid((unsigned)((n + PLK_THREADS - 1) / PLK_THREADS));
+        if (pk.ultra) hipLaunchKernelGGL((plonk_quotient_kernel<P, true>), grid, dim3(PLK_THREADS), 0, st, a);
+        else hipLaunchKernelGGL((plonk_quotient_kernel<P, false>), grid, dim3(PLK_THREADS), 0, st, a);
+        HIP_TRY(hipGetLastError());
+        MZK_TRY(ntt_dispatch(pk.curve, d_out + lc * n * 8, n, pk.log_n, true, pk.h_cls[k], 1, n, st));
+    }
+    MZK_TRY(ws_release(st));
+    return MZK_OK;
+}
+
+// the 8 class remainders (class-major, all resident here after the exchange) -> the 8n quotient coefficients
+template <class P>
+int32_t quotient_combine_run(int log_n, const uint32_t* d_r, uint32_t* d_out, hipStream_t st) {
+    using F = Fp<P>;
+    const uint64_t n = 1ull << log_n;
+    F w8 = F::from_const(P::ROOT);
+    for (int i = 3; i < P::TWO_ADICITY; i++) w8 = sqr(w8);                   // primitive 8th root of unity = w_8n^n
+    const F g = F::from_const(P::GENERATOR);
+    const F gn_inv = inv(pow_u64(g, n)), w8_inv = inv(w8), eighth = inv(from_u64<P>(8));
+    CombineArgs a;
+    a.r = d_r; a.out = d_out; a.n = n;
+    F sq = eighth;                                                            // g^(-nq) / 8
+    for (int q = 0; q < 8; q++) {
+        const F step = pow_u64(w8_inv, (uint64_t)q);                          // w_8^(-q)
+        F e = sq;
+        for (int k = 0; k < 8; k++) {
+            std::memcpy(a.mat[q][k], e.l, 32);
+            e = e * step;
+        }
+        sq = sq * gn_inv;
+    }
+    hipLaunchKernelGGL((plonk_combine_kernel<P>), dim3((unsigned)((n + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st, a);
+    HIP_TRY(hipGetLastError());
+    return MZK_OK;
+}
+
 const PlonkPk* find_pk(uint64_t handle) {
     auto it = g_pks.find(handle);
     if (it == g_pks.end()) { set_error("unknown proving-key handle"); return nullptr; }
@@ -296,8 +483,13 @@ const PlonkPk* find_pk(uint64_t handle) {
 }  // namespace
 
 int32_t plonk_pk_register(int curve, int log_n, int W, const uint32_t* sel, const uint32_t* sig, const uint32_t* tab, uint64_t poly_len,
-                          const uint32_t* k_mont, uint64_t* out_handle) {
+                          const uint32_t* k_mont, const uint32_t* classes, uint32_t n_classes, uint64_t* out_handle) {
     const bool ultra = tab != nullptr;
+    if (classes) {
+        bool ok = n_classes >= 1 && n_classes <= PLK_RATIO && poly_len <= (1ull << log_n);
+        for (uint32_t i = 0; ok && i < n_classes; i++) ok = classes[i] < PLK_RATIO && (i == 0 || classes[i] > classes[i - 1]);
+        if (!ok) { set_error("chunked proving key: 1..8 strictly increasing residue classes < 8, fixed polynomials of degree < n"); return MZK_ERR_INVALID_ARG; }
+    }
     if ((curve != 0 && curve != 1) || W != (ultra ? PLK_MAX_WIRES : PLK_WIRES) || log_n < 1 || log_n + 3 > (curve == 0 ? 32 : 28) || log_n + 3 > 30 ||
         poly_len == 0 || poly_len > (8ull << log_n) || !sel || !sig || !k_mont || !out_handle) {
         set_error("bad argument (TurboPlonk: 5 wire types, 13 selectors; UltraPlonk: 6 wire types, 14 selectors, 4 table polynomials)");
@@ -307,7 +499,13 @@ int32_t plonk_pk_register(int curve, int log_n, int W, const uint32_t* sel, cons
     pk->curve = curve; pk->log_n = log_n; pk->W = W; pk->ultra = ultra; pk->nsel = PLK_SELECTORS + (ultra ? 1 : 0);
     std::memset(pk->k, 0, sizeof pk->k);
     std::memcpy(pk->k, k_mont, (size_t)W * 32);
-    int32_t rc = curve == 0 ? pk_build<BlsFr>(*pk, sel, sig, tab, poly_len) : pk_build<BnFr>(*pk, sel, sig, tab, poly_len);
+    int32_t rc;
+    if (classes) {
+        pk->cls.assign(classes, classes + n_classes);
+        rc = curve == 0 ? pk_build_chunked<BlsFr>(*pk, sel, sig, tab, poly_len) : pk_build_chunked<BnFr>(*pk, sel, sig, tab, poly_len);
+    } else {
+        rc = curve == 0 ? pk_build<BlsFr>(*pk, sel, sig, tab, poly_len) : pk_build<BnFr>(*pk, sel, sig, tab, poly_len);
+    }
     if (rc != MZK_OK) {
         for (auto* d : pk->bufs()) if (d) (void)hipFree(d);
         return rc;
@@ -336,6 +534,7 @@ int32_t plonk_quotient_dev(uint64_t handle, uint32_t* d_polys, uint64_t in_len, 
     const PlonkPk* pk = find_pk(handle);
     if (!pk) return MZK_ERR_BAD_HANDLE;
     if (!d_polys || !d_out || !alpha || !beta || !gamma || (pk->ultra && !tau) || in_len > (8ull << pk->log_n)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
+    if (!pk->cls.empty()) { set_error("chunked proving key: use mzk_plonk_quotient_chunked_dev"); return MZK_ERR_INVALID_ARG; }
     return pk->curve == 0 ? quotient_run<BlsFr>(*pk, d_polys, in_len, tau, alpha, beta, gamma, d_out, st)
                           : quotient_run<BnFr>(*pk, d_polys, in_len, tau, alpha, beta, gamma, d_out, st);
 }
@@ -366,6 +565,22 @@ int32_t plookup_product_dev(uint64_t handle, const uint32_t* d_table, const uint
     }
     return pk->curve == 0 ? lookup_product_run<BlsFr>(*pk, d_table, d_lookup, d_sorted, beta, gamma, d_out, st)
                           : lookup_product_run<BnFr>(*pk, d_table, d_lookup, d_sorted, beta, gamma, d_out, st);
+}
+int32_t plonk_quotient_chunked_dev(uint64_t handle, const uint32_t* d_polys, uint64_t in_stride, uint64_t in_len, const uint32_t* tau, const uint32_t* alpha,
+                                   const uint32_t* beta, const uint32_t* gamma, uint32_t* d_out, hipStream_t st) {
+    const PlonkPk* pk = find_pk(handle);
+    if (!pk) return MZK_ERR_BAD_HANDLE;
+    if (pk->cls.empty()) { set_error("not a chunked proving key"); return MZK_ERR_INVALID_ARG; }
+    if (!d_polys || !d_out || !alpha || !beta || !gamma || (pk->ultra && !tau) || in_len > (2ull << pk->log_n) || in_len > in_stride) {
+        set_error("bad argument (online polynomials have degree < 2n)");
+        return MZK_ERR_INVALID_ARG;
+    }
+    return pk->curve == 0 ? quotient_chunked_run<BlsFr>(*pk, d_polys, in_stride, in_len, tau, alpha, beta, gamma, d_out, st)
+                          : quotient_chunked_run<BnFr>(*pk, d_polys, in_stride, in_len, tau, alpha, beta, gamma, d_out, st);
+}
+int32_t plonk_quotient_combine_dev(int curve, int log_n, const uint32_t* d_r, uint32_t* d_out, hipStream_t st) {
+    if ((curve != 0 && curve != 1) || log_n < 1 || log_n + 3 > (curve == 0 ? 32 : 28) || !d_r || !d_out) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
+    return curve == 0 ? quotient_combine_run<BlsFr>(log_n, d_r, d_out, st) : quotient_combine_run<BnFr>(log_n, d_r, d_out, st);
 }
 int plonk_pk_log_n(uint64_t handle) {
     auto it = g_pks.find(handle);

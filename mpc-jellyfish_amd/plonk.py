@@ -46,15 +46,18 @@ class PlonkError(Exception):
 class ProvingKeyDevice:
     """selectors/sigmas (and Plookup table polynomials) of a ProvingKey, resident on the GPU as coset evaluations."""
 
-    def __init__(self, curve: CurveParams, handle: int, domain_size: int, ultra: bool = False):
+    def __init__(self, curve: CurveParams, handle: int, domain_size: int, ultra: bool = False, classes=None):
         self.curve, self.handle, self.domain_size, self.ultra = curve, handle, domain_size, ultra
         self.num_wire_types = NUM_WIRE_TYPES_ULTRA if ultra else NUM_WIRE_TYPES
+        self.classes = None if classes is None else list(classes)      # residue classes mod 8 resident here (coset-chunked key)
 
     @classmethod
-    def register(cls, curve, domain_size: int, selectors, sigmas, k, plookup=None) -> "ProvingKeyDevice":
+    def register(cls, curve, domain_size: int, selectors, sigmas, k, plookup=None, classes=None) -> "ProvingKeyDevice":
         """selectors: 13 coefficient arrays, sigmas: 5, k: 5 Python ints (coset representatives).
         UltraPlonk: 14 selectors (q_lookup last), 6 sigmas, 6 k and plookup = {range_table_poly, key_table_poly,
-        table_dom_sep_poly, q_dom_sep_poly} coefficient arrays."""
+        table_dom_sep_poly, q_dom_sep_poly} coefficient arrays.
+        classes: None for the whole quotient domain, or the residue classes mod 8 (strictly increasing) this GPU keeps
+        -- the coset-chunked key of SURVEY.md 8(e).3, used with compute_quotient_chunked_dev."""
         c = _curve(curve)
         ultra = plookup is not None
         nsel, W = (N_ULTRA_PLONK_SELECTORS, NUM_WIRE_TYPES_ULTRA) if ultra else (N_TURBO_PLONK_SELECTORS, NUM_WIRE_TYPES)
@@ -73,14 +76,19 @@ class ProvingKeyDevice:
         h = C.c_uint64()
         ptr = lambda a: np.ascontiguousarray(a).ctypes.data_as(C.c_void_p)
         sel_a, sig_a = np.ascontiguousarray(slab[:nsel]), np.ascontiguousarray(slab[nsel:nsel + W])
-        if ultra:
+        if classes is not None:
+            tab_a = np.ascontiguousarray(slab[nsel + W:]) if ultra else None
+            ca = np.ascontiguousarray(list(classes), dtype=np.uint32)
+            _lib.check(L.mzk_plonk_pk_register_chunked(c.curve_id, domain_size.bit_length() - 1, W, ptr(sel_a), ptr(sig_a), ptr(tab_a) if ultra else None, plen,
+                                                       ptr(kk), ca.ctypes.data_as(C.c_void_p), len(ca), C.byref(h)), "mzk_plonk_pk_register_chunked")
+        elif ultra:
             tab_a = np.ascontiguousarray(slab[nsel + W:])
             _lib.check(L.mzk_plonk_pk_register_ultra(c.curve_id, domain_size.bit_length() - 1, ptr(sel_a), ptr(sig_a), ptr(tab_a), plen, ptr(kk), C.byref(h)),
                        "mzk_plonk_pk_register_ultra")
         else:
             _lib.check(L.mzk_plonk_pk_register(c.curve_id, domain_size.bit_length() - 1, W, ptr(sel_a), ptr(sig_a), plen, ptr(kk), C.byref(h)),
                        "mzk_plonk_pk_register")
-        return cls(c, h.value, domain_size, ultra)
+        return cls(c, h.value, domain_size, ultra, classes)
 
     def release(self):
         if self.handle:
@@ -129,6 +137,39 @@ def compute_quotient_polynomial_dev(pk: ProvingKeyDevice, challenges: Challenges
         _lib.check(_lib.ensure_init().mzk_plonk_quotient_dev(pk.handle, polys_dev.data_ptr(), in_len, p(0), p(1), p(2), out_dev.data_ptr(), st),
                    "mzk_plonk_quotient_dev")
     return out_dev
+
+
+def compute_quotient_chunked_dev(pk: ProvingKeyDevice, challenges: Challenges, polys_dev, in_len: int, out_dev=None, stream=None):
+    """SURVEY.md 8(e).3, local part: polys_dev is a (W + 2 [+ 3], stride, 4) CUDA tensor of coefficient rows (first in_len
+    <= 2n slots used, not overwritten); returns (len(pk.classes), n, 4): per resident class k the coefficients of
+    t mod (X^n - h_k^n).  Asynchronous."""
+    import torch
+    n = pk.domain_size
+    rows = pk.num_wire_types + 2 + (3 if pk.ultra else 0)
+    assert pk.classes is not None and polys_dev.dim() == 3 and polys_dev.shape[0] == rows and polys_dev.shape[2] == 4
+    assert polys_dev.is_cuda and polys_dev.is_contiguous() and polys_dev.dtype == torch.int64
+    out = torch.empty((len(pk.classes), n, 4), dtype=torch.int64, device=polys_dev.device) if out_dev is None else out_dev
+    st = torch.cuda.current_stream(polys_dev.device).cuda_stream if stream is None else stream
+    ch = fr_to_mont(pk.curve, [challenges.alpha, challenges.beta, challenges.gamma, challenges.tau])
+    p = lambda i: ch[i].ctypes.data_as(C.c_void_p)
+    _lib.check(_lib.ensure_init().mzk_plonk_quotient_chunked_dev(pk.handle, polys_dev.data_ptr(), polys_dev.shape[1], in_len, p(3) if pk.ultra else None,
+                                                                 p(0), p(1), p(2), out.data_ptr(), st), "mzk_plonk_quotient_chunked_dev")
+    return out
+
+
+def combine_quotient_classes(curve, domain_size: int, class_remainders, out_dev=None, stream=None):
+    """SURVEY.md 8(e).3, after the exchange: (8, n, 4) class remainders (class-major) -> (8n, 4) quotient coefficients,
+    what `coset.ifft` returns at prover.rs:672.  Asynchronous."""
+    import torch
+    c = _curve(curve)
+    n = domain_size
+    r = class_remainders
+    assert tuple(r.shape) == (8, n, 4) and r.is_cuda and r.is_contiguous()
+    out = torch.empty((8 * n, 4), dtype=torch.int64, device=r.device) if out_dev is None else out_dev
+    st = torch.cuda.current_stream(r.device).cuda_stream if stream is None else stream
+    _lib.check(_lib.ensure_init().mzk_plonk_quotient_combine_dev(c.curve_id, n.bit_length() - 1, r.data_ptr(), out.data_ptr(), st),
+               "mzk_plonk_quotient_combine_dev")
+    return out
 
 
 def _to_dev(x):

@@ -153,7 +153,11 @@ class TurboPlonkProver:
     evaluations (round 3) and the commit key.  With `plookup` (the four table polynomials of
     PlookupProvingKey) it is the UltraPlonk prover: 14 selectors, 6 wire types."""
 
-    def __init__(self, curve, domain_size: int, selector_polys, sigma_polys, k, commit_key: kzg.UnivariateProverParam, plookup=None):
+    def __init__(self, curve, domain_size: int, selector_polys, sigma_polys, k, commit_key: kzg.UnivariateProverParam, plookup=None,
+                 quotient_classes=None, quotient_gather=None):
+        """quotient_classes / quotient_gather: the coset-chunked quotient of SURVEY.md 8(e).3 -- this rank keeps the listed residue
+        classes of the quotient domain (sharding.class_range) and `quotient_gather(local) -> (8, n, 4)` performs the one exchange
+        (sharding.gather_quotient_classes); with all 8 classes and no gather it is the single-GPU rehearsal of that path."""
         import torch
         self.curve: CurveParams = _curve(curve)
         self.n = domain_size
@@ -164,7 +168,8 @@ class TurboPlonkProver:
         self.committer = None                        # set to a sharding.ShardedCommitter for multi-GPU commits
         self.W = len(sigma_polys)
         self.nsel = len(selector_polys)
-        self.pk = plonk.ProvingKeyDevice.register(self.curve, domain_size, selector_polys, sigma_polys, k, plookup)
+        self.quotient_gather = quotient_gather
+        self.pk = plonk.ProvingKeyDevice.register(self.curve, domain_size, selector_polys, sigma_polys, k, plookup, classes=quotient_classes)
         pad = lambda p: np.concatenate([np.asarray(p, dtype=np.uint64).reshape(-1, 4),
                                         np.zeros((domain_size - np.asarray(p).reshape(-1, 4).shape[0], 4), dtype=np.uint64)])
         tabs = [plookup[x] for x in plonk.PLOOKUP_TABLE_POLYS] if self.ultra else []
@@ -306,7 +311,12 @@ class TurboPlonkProver:
         keep.copy_(slab[:, :n + 3])                                      # coefficient forms survive the in-place coset NTT
         quot = self._quot
         alpha = src.after_round2(z_comm, pl_comm)
-        plonk.compute_quotient_polynomial_dev(self.pk, plonk.Challenges(alpha, beta, gamma, tau), slab, n + 3, quot)
+        if self.pk.classes is None:
+            plonk.compute_quotient_polynomial_dev(self.pk, plonk.Challenges(alpha, beta, gamma, tau), slab, n + 3, quot)
+        else:                                                            # local classes, one exchange, 8-point iDFT per coefficient
+            local = plonk.compute_quotient_chunked_dev(self.pk, plonk.Challenges(alpha, beta, gamma, tau), slab, n + 3)
+            every = self.quotient_gather(local) if self.quotient_gather is not None else local
+            plonk.combine_quotient_classes(c, n, every.contiguous(), out_dev=quot)
         tick("r3_quotient", t0)
         t0 = time.perf_counter()
         expected = W * (n + 1) + 2                                       # quotient_polynomial_degree, prover.rs:1125-1128
@@ -418,6 +428,7 @@ class TurboPlonkProver:
         t0 = time.perf_counter()
         open_comms = self._commit([opening, shifted])
         tick("r5_commit", t0)
+        self.last_challenges = {"tau": tau, "beta": beta, "gamma": gamma, "alpha": alpha, "zeta": zeta, "v": v_ch}
         self.last = {"wire_polys": wire_polys, "z_poly": z_poly, "quot": quot, "split": split, "lin": lin, "opening": opening, "shifted": shifted}
         if ultra:
             self.last.update({"h_polys": [h1, h2], "prod_lookup_poly": pl_poly, "sorted_vec": sorted_vec, "merged_table": table, "merged_lookup": lookup})

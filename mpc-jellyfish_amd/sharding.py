@@ -99,3 +99,32 @@ class ShardedCommitter:
         dist.all_gather(parts, t, group=self.group)
         stacked = torch.stack(parts).cpu().numpy().view(np.uint64).reshape(world, k, 3, L)
         return np.stack([sum_jacobian(self.c, stacked[:, i]) for i in range(k)])
+
+
+def class_range(rank: int, world: int) -> list[int]:
+    """Residue classes mod 8 of the quotient domain owned by `rank`: contiguous blocks of 8 / world, so
+    that an all-gather in rank order is already class-major.  world must divide 8."""
+    if 8 % world:
+        raise ValueError("the coset-chunked quotient needs a world size dividing 8")
+    per = 8 // world
+    return list(range(rank * per, (rank + 1) * per))
+
+
+def gather_quotient_classes(local, group=None, via_host: bool = False):
+    """The one exchange step of the chunked quotient: every rank contributes its (8 / G, n, 4) class remainders and
+    receives all (8, n, 4).  RCCL: all_gather_into_tensor on device tensors (n * 32 * 8 / G bytes per rank over xGMI);
+    gloo (CPU rehearsal): staged through host memory."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    if world == 1:
+        return local
+    out_shape = (local.shape[0] * world,) + tuple(local.shape[1:])
+    if via_host:
+        h = local.cpu()
+        parts = [torch.empty_like(h) for _ in range(world)]
+        dist.all_gather(parts, h, group=group)
+        return torch.cat(parts).to(local.device)
+    out = torch.empty(out_shape, dtype=local.dtype, device=local.device)
+    dist.all_gather_into_tensor(out, local.contiguous(), group=group)
+    return out
