@@ -258,11 +258,14 @@ def main():
     # ---- secondary, N > 1: the same proof with every commitment's MSM split by point range over the ranks;
     #      NTTs, quotient and polynomial work are replicated, so this is the strong-scaling figure of the commit half only
     prove_sharded = None
-    if not args.no_plonk and world > 1:
+    if not args.no_plonk and world > 1 and not os.environ.get("MZK_BENCH_NO_SHARDED_PROVE"):
         pl, pn = args.plonk_log_n, 1 << args.plonk_log_n
         ck = mj.UnivariateProverParam.gen_srs_for_testing(curve, beta, pn + 2)          # the same SRS on every rank
         cs = mj.snark.gen_circuit_for_bench(curve, pn, "TurboPlonk")
-        prover = mj.snark.preprocess(ck, cs)
+        chunked = 8 % world == 0                                                         # 8(e).3 needs a world size dividing 8
+        gather = lambda local: mj.sharding.gather_quotient_classes(local, via_host=(backend != "nccl"))
+        prover = (mj.snark.preprocess(ck, cs, quotient_classes=mj.sharding.class_range(rank, world), quotient_gather=gather) if chunked
+                  else mj.snark.preprocess(ck, cs))
         prover.vk_commitments()
         prover.committer = mj.sharding.ShardedCommitter(curve, ck, device=coll_dev)
         rng = mj.rng.test_rng()
@@ -282,8 +285,11 @@ def main():
         lo, hi = digest.clone(), digest.clone()
         dist.all_reduce(lo, op=dist.ReduceOp.MIN)
         dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        prove_sharded = {"what": "PlonkKzgSnark::prove, TurboPlonk bench circuit, commitments sharded by point range over the ranks "
-                                 "(all-gather of Jacobian partials + local EC sum), everything else replicated",
+        core, _ = mj.snark.prove(rng, cs, prover, profile=True)
+        prove_sharded = {"what": "PlonkKzgSnark::prove, TurboPlonk bench circuit: commitments sharded by point range over the ranks (all-gather of "
+                                 "Jacobian partials + local EC sum, 8(e).1), quotient domain split into residue classes with one all-gather "
+                                 "(8(e).3) when the world size divides 8; iNTTs, grand product, evaluations, openings' polynomials replicated",
+                         "chunked_quotient": chunked, "rounds_ms_rank0": core.timings_ms,
                          "log_n": pl, "prove_ms": round(float(tmax.item()), 2), "ranks_agree_on_proof": bool(lo.item() == hi.item()),
                          "proof_bytes": len(proof_bytes)}
         prover.release()
