@@ -87,7 +87,19 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     const unsigned long long dstride_max = (n_max + 7) & ~7ull;
     MZK_TRY(g_ws.digits.reserve((size_t)n_dig * dstride_max * (pre.c ? 4 : 2)));
     MZK_TRY(g_ws.sorted.reserve((size_t)n_dig * n_max * 4));
-    const uint32_t n_bins = pre.c ? std::max<uint32_t>(1u, M >> PRE_FINE_LOG) : 0u;
+    // coarse bins of the table path: the low 2^top_bits buckets also receive the short top digit of every scalar, so they
+    // are binned finer by the density ratio 1 + M / (2^top_bits (n_dig - 1)) (msm_pre.cuh PreBins)
+    PreBins pb{0, PRE_FINE_LOG, 0};
+    if (pre.c && n_dig > 1) {
+        const int top_bits = (is_mont ? FR::BITS : 256) - c * (n_dig - 1);
+        if (top_bits >= PRE_FINE_LOG && top_bits < c - 1) {
+            const double rho = 1.0 + (double)M / ((double)(1ull << top_bits) * (n_dig - 1));
+            int shrink = (int)std::lround(std::log2(rho));
+            if (shrink > 3) shrink = 3;
+            if (shrink > 0) { pb.low = 1u << top_bits; pb.low_log = PRE_FINE_LOG - shrink; pb.low_bins = pb.low >> pb.low_log; }
+        }
+    }
+    const uint32_t n_bins = pre.c ? std::max<uint32_t>(1u, pb.count(M)) : 0u;
     MZK_TRY(g_ws.pre_cnt.reserve((2048 + (size_t)n_win * 1024) * 4));     // bin totals, bin cursors, order keys
     if (pre.c) {
         MZK_TRY(g_ws.pre_off.reserve(2048 * 4));
@@ -155,11 +167,11 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 uint32_t* bin_start = coff;                      // [n_bins + 1]
                 hipLaunchKernelGGL((pre_digits_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, st, d_scalars, n, is_mont, c, n_dig, dig32, dstride);
                 HIP_TRY(hipMemsetAsync(bin_total, 0, n_bins * 4, st));
-                hipLaunchKernelGGL(pre_coarse_count_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, st, dig32, n, dstride, n_dig, (int)n_bins, bin_total);
+                hipLaunchKernelGGL(pre_coarse_count_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, st, dig32, n, dstride, n_dig, (int)n_bins, pb, bin_total);
                 hipLaunchKernelGGL(pre_bin_scan_kernel, dim3(1), dim3(1024), 0, st, bin_total, (int)n_bins, bin_start, bin_cursor);
-                hipLaunchKernelGGL(pre_coarse_scatter_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, st, dig32, n, dstride, n_dig, (int)n_bins,
+                hipLaunchKernelGGL(pre_coarse_scatter_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, st, dig32, n, dstride, n_dig, (int)n_bins, pb,
                                    pre.tab_stride, items[p].base_off, bin_cursor, coarse);
-                hipLaunchKernelGGL(pre_fine_kernel, dim3(n_bins), dim3(1024), 0, st, bin_start, coarse, M, hist, offs, sorted);
+                hipLaunchKernelGGL(pre_fine_kernel, dim3(n_bins), dim3(1024), 0, st, bin_start, coarse, M, pb, hist, offs, sorted);
             }
             {
                 // buckets ranked by load within each bucket set

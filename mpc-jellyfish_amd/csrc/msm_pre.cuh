@@ -16,6 +16,21 @@ constexpr int PRE_CTHREADS = 1024;
 constexpr int PRE_FINE_LOG = 11;             // buckets per fine workgroup (2^19 buckets -> 256 workgroups)
 constexpr uint32_t PRE_EMPTY = 0xFFFFFFFFu;
 
+// Coarse bins.  Buckets below `low` (the range of the short top digit, which doubles or triples their load) are
+// binned 2^low_log at a time, the rest 2^PRE_FINE_LOG at a time, so that every fine workgroup gets about the same
+// number of entries.  low == 0: uniform bins.
+struct PreBins {
+    uint32_t low, low_log, low_bins;
+    __host__ __device__ uint32_t bin_of(uint32_t b) const { return b < low ? b >> low_log : low_bins + ((b - low) >> PRE_FINE_LOG); }
+    __host__ __device__ uint32_t first_bucket(uint32_t bin) const { return bin < low_bins ? bin << low_log : low + ((bin - low_bins) << PRE_FINE_LOG); }
+    __host__ __device__ uint32_t size_of(uint32_t bin, uint32_t M) const {
+        const uint32_t full = bin < low_bins ? 1u << low_log : 1u << PRE_FINE_LOG;
+        const uint32_t left = M - first_bucket(bin);
+        return full < left ? full : left;
+    }
+    __host__ __device__ uint32_t count(uint32_t M) const { return low_bins + ((M - low + (1u << PRE_FINE_LOG) - 1) >> PRE_FINE_LOG); }
+};
+
 // digits[w*stride + i] = sign<<31 | (magnitude-1), PRE_EMPTY for a zero digit
 template <class FR>
 __global__ __launch_bounds__(MSM_THREADS) void pre_digits_kernel(const uint32_t* __restrict__ scalars, unsigned long long n, int is_mont,
@@ -38,7 +53,7 @@ __global__ __launch_bounds__(MSM_THREADS) void pre_digits_kernel(const uint32_t*
 //                       per bin, then writes (entry, low bucket bits) into it.
 // entry = w*tab_stride + base_off + i (row of the precomputed table), sign in bit 31.
 __global__ __launch_bounds__(PRE_CTHREADS) void pre_coarse_count_kernel(const uint32_t* __restrict__ digits, unsigned long long n, unsigned long long stride,
-                                                                int n_win, int n_bins, uint32_t* __restrict__ bin_total) {
+                                                                int n_win, int n_bins, PreBins pb, uint32_t* __restrict__ bin_total) {
     __shared__ uint32_t bins[1024];
     const uint32_t tid = threadIdx.x;
     for (int j = tid; j < n_bins; j += PRE_CTHREADS) bins[j] = 0u;
@@ -51,7 +66,7 @@ __global__ __launch_bounds__(PRE_CTHREADS) void pre_coarse_count_kernel(const ui
             const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                if (i + k < hi && d4[k] != PRE_EMPTY) atomicAdd(&bins[(d4[k] & 0x7FFFFFFFu) >> PRE_FINE_LOG], 1u);
+                if (i + k < hi && d4[k] != PRE_EMPTY) atomicAdd(&bins[pb.bin_of(d4[k] & 0x7FFFFFFFu)], 1u);
         }
     }
     __syncthreads();
@@ -77,7 +92,7 @@ __global__ __launch_bounds__(1024) void pre_bin_scan_kernel(const uint32_t* __re
 }
 
 __global__ __launch_bounds__(PRE_CTHREADS) void pre_coarse_scatter_kernel(const uint32_t* __restrict__ digits, unsigned long long n, unsigned long long stride,
-                                                                  int n_win, int n_bins, unsigned long long tab_stride, unsigned long long base_off,
+                                                                  int n_win, int n_bins, PreBins pb, unsigned long long tab_stride, unsigned long long base_off,
                                                                   uint32_t* __restrict__ bin_cursor, unsigned long long* __restrict__ coarse) {
     __shared__ uint32_t bins[1024];
     const uint32_t tid = threadIdx.x;
@@ -91,7 +106,7 @@ __global__ __launch_bounds__(PRE_CTHREADS) void pre_coarse_scatter_kernel(const 
             const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                if (i + k < hi && d4[k] != PRE_EMPTY) atomicAdd(&bins[(d4[k] & 0x7FFFFFFFu) >> PRE_FINE_LOG], 1u);
+                if (i + k < hi && d4[k] != PRE_EMPTY) atomicAdd(&bins[pb.bin_of(d4[k] & 0x7FFFFFFFu)], 1u);
         }
     }
     __syncthreads();
@@ -110,24 +125,32 @@ __global__ __launch_bounds__(PRE_CTHREADS) void pre_coarse_scatter_kernel(const 
                 const uint32_t d = d4[k];
                 if (i + k >= hi || d == PRE_EMPTY) continue;
                 const uint32_t b = d & 0x7FFFFFFFu;
-                const uint32_t pos = atomicAdd(&bins[b >> PRE_FINE_LOG], 1u);
+                const uint32_t bin = pb.bin_of(b);
+                const uint32_t pos = atomicAdd(&bins[bin], 1u);
                 const uint32_t e = (uint32_t)((unsigned long long)w * tab_stride + base_off + i + k) | (d & 0x80000000u);
-                coarse[pos] = ((unsigned long long)(b & ((1u << PRE_FINE_LOG) - 1)) << 32) | e;          // one 8-byte record
+                coarse[pos] = ((unsigned long long)(b - pb.first_bucket(bin)) << 32) | e;               // one 8-byte record: bucket inside the bin, entry
             }
         }
     }
 }
 
-// one workgroup per coarse bin: counts its buckets, scans them, and writes the bucket-sorted
-// entries plus the per-bucket hist / offs that the accumulation kernels read.  Four independent
-// record loads are in flight per thread (the loops are latency-, not bandwidth-bound).
+// one workgroup per coarse bin: counts its buckets, scans them, and writes the bucket-sorted entries plus the
+// per-bucket hist / offs that the accumulation kernels read.  The scatter goes through LDS: a 4-byte write per
+// entry at a random place of the bin's 200 KB output range costs a whole HBM sector each (13.6 M of them at 2^20
+// pairs); instead the bin is emitted in runs of consecutive buckets that fit PRE_STAGE entries of LDS -- the
+// records are re-read once per run (sequential, L2-resident) and every run leaves as one coalesced stream.
+constexpr uint32_t PRE_STAGE = 24576;        // entries staged per run (96 KiB)
+
 __global__ __launch_bounds__(1024) void pre_fine_kernel(const uint32_t* __restrict__ bin_start, const unsigned long long* __restrict__ coarse,
-                                                        uint32_t M, uint32_t* __restrict__ hist, uint32_t* __restrict__ offs,
+                                                        uint32_t M, PreBins pb, uint32_t* __restrict__ hist, uint32_t* __restrict__ offs,
                                                         uint32_t* __restrict__ sorted) {
-    __shared__ uint32_t bins[1 << PRE_FINE_LOG];
+    __shared__ uint32_t bins[1 << PRE_FINE_LOG];          // counts, then scatter cursors (relative to the bin)
+    __shared__ uint32_t loc[(1 << PRE_FINE_LOG) + 1];     // exclusive offsets of the buckets inside the bin
     __shared__ uint32_t part[1024];
+    __shared__ uint32_t stage[PRE_STAGE];
+    __shared__ uint32_t run_hi;
     const uint32_t bin = blockIdx.x, tid = threadIdx.x;
-    const uint32_t rsize = M < (1u << PRE_FINE_LOG) ? M : (1u << PRE_FINE_LOG);
+    const uint32_t rsize = pb.size_of(bin, M), bucket0 = pb.first_bucket(bin);
     const uint32_t start = bin_start[bin], end = bin_start[bin + 1];
     for (uint32_t j = tid; j < rsize; j += 1024) bins[j] = 0;
     __syncthreads();
@@ -151,22 +174,53 @@ __global__ __launch_bounds__(1024) void pre_fine_kernel(const uint32_t* __restri
         part[tid] += v;
         __syncthreads();
     }
-    uint32_t run = start + part[tid] - sum;
+    uint32_t run = part[tid] - sum;                     // offset inside the bin
     for (uint32_t j = tid * per; j < min(rsize, (tid + 1) * per); j++) {
         const uint32_t c = bins[j];
-        hist[(size_t)bin * rsize + j] = c;
-        offs[(size_t)bin * rsize + j] = run;
-        bins[j] = run;                               // becomes the scatter cursor
+        hist[bucket0 + j] = c;
+        offs[bucket0 + j] = start + run;
+        loc[j] = run;
+        bins[j] = run;                                  // becomes the scatter cursor
         run += c;
     }
+    if (tid == 1023) loc[rsize] = end - start;
     __syncthreads();
-    for (uint32_t k = start + tid; k < end; k += 4096) {
-        unsigned long long r[4];
+    uint32_t lo = 0;                                    // uniform across the workgroup
+    while (lo < rsize) {
+        // the longest run of buckets [lo, hi) with at most PRE_STAGE entries; one over-long bucket forms a run of its own
+        if (tid == 0) {
+            uint32_t a = lo + 1, b = rsize;             // hi in [lo + 1, rsize]
+            const uint32_t base = loc[lo];
+            while (a < b) {
+                const uint32_t mid = (a + b + 1) >> 1;
+                if (loc[mid] - base <= PRE_STAGE) a = mid; else b = mid - 1;
+            }
+            run_hi = a;
+        }
+        __syncthreads();
+        const uint32_t hi = run_hi, base = loc[lo], cnt = loc[hi] - base;
+        const bool staged = cnt <= PRE_STAGE;
+        if (cnt) {
+            for (uint32_t k = start + tid; k < end; k += 4096) {
+                unsigned long long r[4];
 #pragma unroll
-        for (int q = 0; q < 4; q++) r[q] = k + q * 1024 < end ? coarse[k + q * 1024] : ~0ull;
+                for (int q = 0; q < 4; q++) r[q] = k + q * 1024 < end ? coarse[k + q * 1024] : ~0ull;
 #pragma unroll
-        for (int q = 0; q < 4; q++)
-            if (k + q * 1024 < end) sorted[atomicAdd(&bins[(uint32_t)(r[q] >> 32)], 1u)] = (uint32_t)r[q];
+                for (int q = 0; q < 4; q++) {
+                    const uint32_t bk = (uint32_t)(r[q] >> 32);
+                    if (k + q * 1024 < end && bk >= lo && bk < hi) {
+                        const uint32_t pos = atomicAdd(&bins[bk], 1u);
+                        if (staged) stage[pos - base] = (uint32_t)r[q];
+                        else sorted[start + pos] = (uint32_t)r[q];      // a single bucket longer than the stage: its range is contiguous anyway
+                    }
+                }
+            }
+            __syncthreads();
+            if (staged)
+                for (uint32_t k = tid; k < cnt; k += 1024) sorted[start + base + k] = stage[k];
+        }
+        __syncthreads();
+        lo = hi;
     }
 }
 
