@@ -96,30 +96,48 @@ __global__ __launch_bounds__(PLK_THREADS) void plonk_quotient_kernel(QuotientArg
     }
     F t1 = t + alpha * (acc1 - acc2);
     F t2 = arg_fp<P>(a.alpha2) * ((z_x - F::one()) * load_fp<P>(a.inv_den + i * 8));
-    if constexpr (ULTRA) {
-        // ---- Plookup (prover.rs:773-888): alpha^3 L_n (h1 - h2(wX)) + alpha^4 L_1 (p - 1) + alpha^5 L_n (p - 1) + alpha^6 (X - w^-1) [...]
+    store_fp<P>(a.out + i * 8, t1 * arg_fp<P>(a.zh_inv[a.zh_class >= 0 ? a.zh_class : (int)(i % PLK_RATIO)]) + t2);          // prover.rs:657
+}
+
+// UltraPlonk, second launch: out[i] += t_lookup_1 * zh_inv + t_lookup_2 (compute_quotient_plookup_contribution,
+// prover.rs:773-888).  Kept apart from the gate / copy-constraint kernel: together the 45 operand streams need > 320
+// VGPRs (one wave per SIMD); field addition is exact, so the split changes nothing in the result.
+template <class P>
+__global__ __launch_bounds__(PLK_THREADS) void plonk_quotient_lookup_kernel(QuotientArgs a) {
+    using F = Fp<P>;
+    const unsigned long long i = (unsigned long long)blockIdx.x * PLK_THREADS + threadIdx.x;
+    if (i >= a.m) return;
+    const unsigned long long m = a.m;
+    const unsigned long long inext = (i + a.next_off) % m;
+    const unsigned long long fs = a.fstride, os = a.ostride;
+    auto wire = [&](int j, unsigned long long at) { return load_fp<P>(a.wire + ((size_t)j * os + at) * 8); };
+    const F alpha = arg_fp<P>(a.alpha), beta = arg_fp<P>(a.beta), gamma = arg_fp<P>(a.gamma);
+    const F x = load_fp<P>(a.xs + i * 8);
+    F t1, t2;
+    {
+        // alpha^3 L_n (h1 - h2(wX)) + alpha^4 L_1 (p - 1) + alpha^5 L_n (p - 1) + alpha^6 (X - w^-1) [...]
         auto tab = [&](int j, unsigned long long at) { return load_fp<P>(a.tab + ((size_t)j * fs + at) * 8); };
         const F tau = arg_fp<P>(a.tau), alpha3 = arg_fp<P>(a.alpha3);
-        const F ql = sel(13), ql_next = load_fp<P>(a.sel + ((size_t)13 * fs + inext) * 8);
+        const F ql = load_fp<P>(a.sel + ((size_t)13 * fs + i) * 8), ql_next = load_fp<P>(a.sel + ((size_t)13 * fs + inext) * 8);
         const F h1 = load_fp<P>(a.h + i * 8), h1n = load_fp<P>(a.h + inext * 8);
         const F h2 = load_fp<P>(a.h + (os + i) * 8), h2n = load_fp<P>(a.h + (os + inext) * 8);
         const F p = load_fp<P>(a.pl + i * 8), pn = load_fp<P>(a.pl + inext * 8);
         auto merged = [&](const F& first, const F& q, const F& ds, const F& a0, const F& a1, const F& a2) {
             return first + q * tau * (ds + tau * (a0 + tau * (a1 + tau * a2)));
         };
-        const F mt = merged(tab(0, i), ql, tab(2, i), tab(1, i), w[3], w[4]);
-        const F mt_next = merged(tab(0, inext), ql_next, tab(2, inext), tab(1, inext), load_fp<P>(a.wire + ((size_t)3 * os + inext) * 8),
-                                 load_fp<P>(a.wire + ((size_t)4 * os + inext) * 8));
-        const F ml = merged(w[5], ql, tab(3, i), w[0], w[1], w[2]);
+        const F mt = merged(tab(0, i), ql, tab(2, i), tab(1, i), wire(3, i), wire(4, i));
+        const F mt_next = merged(tab(0, inext), ql_next, tab(2, inext), tab(1, inext), wire(3, inext), wire(4, inext));
+        const F ml = merged(wire(5, i), ql, tab(3, i), wire(0, i), wire(1, i), wire(2, i));
         const F lag_n = load_fp<P>(a.inv_den_n + i * 8), lag_1 = load_fp<P>(a.inv_den + i * 8);
         const F pm1 = p - F::one();
         // result_2 = alpha^3 term_h + alpha^4 term_p1 + alpha^5 term_p2 = alpha^3 (term_h + alpha (term_p1 + alpha term_p2))
-        t2 = t2 + alpha3 * ((h1 - h2n) * lag_n + alpha * (pm1 * lag_1 + alpha * (pm1 * lag_n)));
+        t2 = alpha3 * ((h1 - h2n) * lag_n + alpha * (pm1 * lag_1 + alpha * (pm1 * lag_n)));
         const F b1 = beta + F::one(), g1 = gamma * b1;
         const F term3 = (x - arg_fp<P>(a.w_inv)) * (p * b1 * (gamma + ml) * (g1 + mt + beta * mt_next) - pn * (g1 + h1 + beta * h1n) * (g1 + h2 + beta * h2n));
-        t1 = t1 + sqr(alpha3) * term3;
+        t1 = sqr(alpha3) * term3;
     }
-    store_fp<P>(a.out + i * 8, t1 * arg_fp<P>(a.zh_inv[a.zh_class >= 0 ? a.zh_class : (int)(i % PLK_RATIO)]) + t2);          // prover.rs:657
+    const F prev = load_fp<P>(a.out + i * 8);
+    store_fp<P>(a.out + i * 8, prev + (t1 * arg_fp<P>(a.zh_inv[a.zh_class >= 0 ? a.zh_class : (int)(i % PLK_RATIO)]) + t2));
 }
 
 // xs[i] = g * w^i and inv_den[i] = 1/(n (xs[i] - 1)), 16 points per thread with one shared inversion
