@@ -350,19 +350,28 @@ def main():
         alg_bytes = 128.0 * n                      # N * (2*|Fq| + 32) bytes per BLS12-381 MSM
         achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9
         traffic = _profile_value("msm_accumulate_hbm_bytes_per_launch")
+        # the kernel's real ceiling: VALU issue.  Wave-instructions per launch from the committed SQ counters, priced at the
+        # measured 1.9 ns per VOP3 wave-instruction per SIMD (profiles/r01_valu_ubench2.txt), 1024 SIMDs
+        valu = None
+        kern = (_profile_value("kernels") or {}).get(_profile_value("msm_accumulate_kernel") or "")
+        if kern and kern.get("SQ_INSTS_VALU") and args.log_n == 20:
+            bound_ms = kern["SQ_INSTS_VALU"] / 1024 * 1.9e-6
+            valu = {"wave_insts_per_launch": kern["SQ_INSTS_VALU"], "issue_bound_ms": round(bound_ms, 3), "util": round(bound_ms / acc_avg_ms, 3),
+                    "note": "SQ_INSTS_VALU of the committed PMC pass (2^20 pairs) x 1.9 ns / 1024 SIMDs vs the live launch time"}
         out = {
             "metric": "msm_g1_scalar_pairs_per_s", "value": world * n * args.steps / elapsed, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32x12 (384-bit Fq Montgomery)",
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (381-bit Fq as 14 x 29-bit limbs, Montgomery)",
             "data": "synthetic",
             "config": {"workload": f"standalone MSM, 2^{args.log_n} G1 x Fr pairs per GPU, BLS12-381 (BASELINE configs[1])",
                        "curve": "bls12-381", "pairs_per_gpu": n, "window_bits": c_bits, "windows": n_win,
                        "buckets_per_window": n_buckets, "sharding": "point-range" if world > 1 else "none",
                        "srs_gen_s": round(t_srs, 3)},
-            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel<BlsFq>", "achieved": round(achieved, 3),
+            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel<EcFx<BlsFqX>>", "achieved": round(achieved, 3),
                          "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
                          "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(acc_avg_ms, 4),
-                         "note": "integer-ALU bound (384-bit Montgomery mixed adds), not HBM bound: see DESIGN.md"},
+                         "valu_issue": valu,
+                         "note": "integer-ALU bound (381-bit Montgomery mixed adds), not HBM bound: see DESIGN.md"},
             "phases_ms": {"sort": round(sort_ms / max(tot_cnt, 1), 4), "accumulate": round(acc_avg_ms, 4),
                           "reduce": round(red_ms / max(tot_cnt, 1), 4), "device_total": round(tot_ms / max(tot_cnt, 1), 4)},
             "cpu_baseline": cpu, "ntt": ntt, "plonk_round3": plonk, "batch_commit5": batch, "prove": prove, "prove_sharded": prove_sharded, "prove_ultra_bn254": ultra,

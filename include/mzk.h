@@ -211,6 +211,11 @@ MZK_API int32_t mzk_poly_lincomb_dev(int32_t curve_id, uint32_t n_terms, const v
                                      const uint64_t* scalars_mont, void* d_out, uint64_t out_len, void* stream);
 /* quotient of p(X) / (X - z), len - 1 coefficients into d_out (remainder dropped, as ark-poly's `/` does at
  * prover.rs:504-506).  d_out must not alias d_poly.  Asynchronous. */
+/* `Prover::mask_polynomial` (prover.rs:463-486) for up to 8 polynomials in one launch: d_polys[i] holds n coefficients in a row
+ * of at least n + n_blinders slots; p += (b_0 + b_1 X + ..)(X^n - 1), i.e. p[j] -= b_j and p[n + j] = b_j.  blinders_mont:
+ * n_polys x n_blinders x 4 limbs, host (the `DensePolynomial::rand` draws, 1 <= n_blinders <= 4).  Asynchronous. */
+MZK_API int32_t mzk_poly_mask_dev(int32_t curve_id, uint32_t n_polys, void* const* d_polys, uint64_t n, uint32_t n_blinders,
+                                  const uint64_t* blinders_mont, void* stream);
 MZK_API int32_t mzk_poly_div_linear_dev(int32_t curve_id, const void* d_poly, uint64_t len, const uint64_t* z_mont, void* d_out, void* stream);
 
 /* ---- device memory helpers for bindings without HIP of their own ---- */

@@ -538,6 +538,13 @@ int32_t mzk_poly_lincomb_dev(int32_t curve_id, uint32_t n_terms, const void* con
     return poly_lincomb_dispatch(curve_id, n_terms, reinterpret_cast<const uint32_t* const*>(d_polys), lens, reinterpret_cast<const uint32_t*>(scalars_mont),
                                  reinterpret_cast<uint32_t*>(d_out), out_len, (hipStream_t)stream);
 }
+int32_t mzk_poly_mask_dev(int32_t curve_id, uint32_t n_polys, void* const* d_polys, uint64_t n, uint32_t n_blinders, const uint64_t* blinders_mont, void* stream) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    if (n_polys && (!d_polys || !blinders_mont)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    return poly_mask_dispatch(curve_id, n_polys, reinterpret_cast<uint32_t* const*>(d_polys), n, n_blinders, reinterpret_cast<const uint32_t*>(blinders_mont),
+                              (hipStream_t)stream);
+}
 int32_t mzk_poly_div_linear_dev(int32_t curve_id, const void* d_poly, uint64_t len, const uint64_t* z_mont, void* d_out, void* stream) {
     std::lock_guard<std::mutex> lk(g_lock);
     MZK_TRY(require_init());

@@ -191,4 +191,28 @@ __global__ __launch_bounds__(POLY_THREADS) void poly_div_finish_kernel(const uin
     store_fp<P>(q + k * 8, s * load_fp<P>(zinvpow + (k + 1) * 8));
 }
 
+// ---- mask_polynomial (prover.rs:463-486): p += (b_0 + b_1 X + .. + b_{h}) (X^n - 1), for up to 8 polynomials at once.
+// p has n coefficients (an iNTT output) in a row of at least n + h + 1 slots: p[j] -= b_j, p[n + j] = b_j.
+constexpr int MASK_MAX_ROWS = 8;
+constexpr int MASK_MAX_BLIND = 4;
+struct MaskArgs {
+    uint32_t* rows[MASK_MAX_ROWS];
+    unsigned long long n;
+    int n_rows, n_blind;
+    uint32_t blind[MASK_MAX_ROWS][MASK_MAX_BLIND][8];       // Montgomery
+};
+template <class P>
+__global__ void poly_mask_kernel(MaskArgs a) {
+    using F = Fp<P>;
+    const int t = threadIdx.x;
+    if (t >= a.n_rows * a.n_blind) return;
+    const int r = t / a.n_blind, j = t % a.n_blind;
+    F b;
+#pragma unroll
+    for (int q = 0; q < 8; q++) b.l[q] = a.blind[r][j][q];
+    uint32_t* p = a.rows[r];
+    store_fp<P>(p + (size_t)j * 8, load_fp<P>(p + (size_t)j * 8) - b);
+    store_fp<P>(p + (a.n + j) * 8, b);
+}
+
 }  // namespace mzk

@@ -110,4 +110,20 @@ int32_t poly_lincomb_dispatch(int curve, uint32_t n_terms, const uint32_t* const
     return MZK_ERR_INVALID_ARG;
 }
 
+int32_t poly_mask_dispatch(int curve, uint32_t n_rows, uint32_t* const* d_rows, uint64_t n, uint32_t n_blind, const uint32_t* blind_mont, hipStream_t st) {
+    if (n_rows == 0) return MZK_OK;
+    if (n_rows > MASK_MAX_ROWS || n_blind == 0 || n_blind > MASK_MAX_BLIND || n_blind > n) { set_error("mask: at most 8 polynomials, 1..4 blinders each"); return MZK_ERR_INVALID_ARG; }
+    MaskArgs a;
+    a.n = n; a.n_rows = (int)n_rows; a.n_blind = (int)n_blind;
+    for (uint32_t r = 0; r < n_rows; r++) {
+        a.rows[r] = d_rows[r];
+        for (uint32_t j = 0; j < n_blind; j++) std::memcpy(a.blind[r][j], blind_mont + ((size_t)r * n_blind + j) * 8, 32);
+    }
+    if (curve == 0) hipLaunchKernelGGL((poly_mask_kernel<BlsFr>), dim3(1), dim3(64), 0, st, a);
+    else if (curve == 1) hipLaunchKernelGGL((poly_mask_kernel<BnFr>), dim3(1), dim3(64), 0, st, a);
+    else { set_error("unknown curve_id"); return MZK_ERR_INVALID_ARG; }
+    HIP_TRY(hipGetLastError());
+    return MZK_OK;
+}
+
 }  // namespace mzk

@@ -68,3 +68,14 @@ def div_by_linear(curve, poly_dev, z: int, stream=None):
     _lib.check(_lib.ensure_init().mzk_poly_div_linear_dev(c.curve_id, poly_dev.data_ptr(), n, zm.ctypes.data_as(C.c_void_p), out.data_ptr(),
                                                           _stream(poly_dev, stream)), "mzk_poly_div_linear_dev")
     return out
+
+
+def mask(curve, rows, n: int, blinders, stream=None):
+    """`Prover::mask_polynomial` (prover.rs:463-486) on device rows, in place: rows[i] (a CUDA tensor view of at least
+    n + h slots holding n coefficients) += (b_0 + b_1 X + .. )(X^n - 1) with blinders[i] = [b_0, .., b_{h-1}] (Python ints)."""
+    c = _curve(curve)
+    k, h = len(rows), len(blinders[0])
+    assert k == len(blinders) and all(len(b) == h for b in blinders) and all(r.is_cuda and r.shape[0] >= n + h for r in rows)
+    bm = fr_to_mont(c, [x for b in blinders for x in b])
+    ptrs = (C.c_void_p * k)(*[r.data_ptr() for r in rows])
+    _lib.check(_lib.ensure_init().mzk_poly_mask_dev(c.curve_id, k, ptrs, n, h, bm.ctypes.data_as(C.c_void_p), _stream(rows[0], stream)), "mzk_poly_mask_dev")

@@ -208,17 +208,9 @@ class TurboPlonkProver:
     def release(self):
         self.pk.release()
 
-    def _mask(self, t, row, blinders):
-        """poly + (b_0 + b_1 X + ..)(X^n - 1) on the device row (prover.rs:463-486)."""
-        import torch
-        b = torch.from_numpy(fr_to_mont(self.curve, blinders).view(np.int64)).to(t.device)
-        nb = torch.from_numpy(fr_to_mont(self.curve, [(-x) % self.curve.r for x in blinders]).view(np.int64)).to(t.device)
-        # coefficients 0..h of an iNTT output are arbitrary: add -b there needs a field addition -> lincomb on a slice
-        h = len(blinders)
-        head = t[row, :h].clone()
-        one = 1
-        poly.lincomb(self.curve, [(one, head), (one, nb)], out=t[row, :h])
-        t[row, self.n:self.n + h] = b
+    def _mask(self, t, rows, blinders):
+        """poly + (b_0 + b_1 X + ..)(X^n - 1) on the device rows (prover.rs:463-486), one launch for all of them."""
+        poly.mask(self.curve, [t[r] for r in rows], self.n, [list(b) for b in blinders])
 
     def _commit(self, polys):
         """batch_commit (mod.rs:119-131); with `self.committer` (sharding.ShardedCommitter) the MSMs are split by point
@@ -259,8 +251,7 @@ class TurboPlonkProver:
         self.domain.ifft_in_place(coeff)
         slab[:W, :n] = coeff[:W]
         slab[PI, :n] = coeff[W]
-        for i in range(W):
-            self._mask(slab, i, blind.wires[i])
+        self._mask(slab, list(range(W)), blind.wires)
         wire_polys = [slab[i, :n + 2] for i in range(W)]
         tick("r1_ntt_mask", t0)
         t0 = time.perf_counter()
@@ -277,8 +268,7 @@ class TurboPlonkProver:
             hh[1] = sorted_vec[n - 1:]
             self.domain.ifft_in_place(hh)
             slab[H1:H1 + 2, :n] = hh
-            self._mask(slab, H1, blind.h[0])
-            self._mask(slab, H1 + 1, blind.h[1])
+            self._mask(slab, [H1, H1 + 1], blind.h)
             tick("r1_5_sorted_vec", t0)
             t0 = time.perf_counter()
             h_comms = self._commit([slab[H1, :n + 3], slab[H1 + 1, :n + 3]])
@@ -288,7 +278,7 @@ class TurboPlonkProver:
         beta, gamma = src.after_round1_5(h_comms)
         plonk.compute_prod_permutation_polynomial_dev(self.pk, beta, gamma, wv.contiguous(), out_dev=coeff[0])
         slab[Z, :n] = coeff[0]
-        self._mask(slab, Z, blind.z)
+        self._mask(slab, [Z], [blind.z])
         z_poly = slab[Z, :n + 3]
         tick("r2_product", t0)
         t0 = time.perf_counter()
@@ -300,7 +290,7 @@ class TurboPlonkProver:
             t0 = time.perf_counter()
             plonk.compute_lookup_prod_polynomial(self.pk, beta, gamma, table, lookup, sorted_vec, out_dev=coeff[0])
             slab[PL, :n] = coeff[0]
-            self._mask(slab, PL, blind.prod_lookup)
+            self._mask(slab, [PL], [blind.prod_lookup])
             tick("r2_5_product", t0)
             t0 = time.perf_counter()
             pl_comm = self._commit([slab[PL, :n + 3]])[0]
