@@ -160,6 +160,33 @@ class UnivariateKzgPCS:
         return [Commitment(pp.curve, xy[i]) for i in range(len(bodies))]
 
 
+    @staticmethod
+    def open(prover_param: UnivariateProverParam, polynomial, point: int):
+        """mod.rs:135-161: witness polynomial p(X) / (X - point) (remainder dropped), its commitment, and p(point).
+        polynomial: (len, 4) Montgomery coefficients, numpy or CUDA tensor.  Returns (Commitment proof, evaluation int)."""
+        import torch
+        from . import poly as _poly
+        pp = prover_param
+        t = polynomial if _is_torch(polynomial) else torch.from_numpy(np.ascontiguousarray(polynomial, dtype=np.uint64).reshape(-1, 4).view(np.int64)).cuda()
+        t = t.contiguous()
+        if t.shape[0] == 0:
+            return Commitment(pp.curve, np.zeros((2, pp.curve.fq_limbs), dtype=np.uint64)), 0
+        ev = _poly.evaluate(pp.curve, t, point)[0]
+        if t.shape[0] == 1:                                                # constant polynomial: zero witness
+            return Commitment(pp.curve, np.zeros((2, pp.curve.fq_limbs), dtype=np.uint64)), ev
+        witness = _poly.div_by_linear(pp.curve, t, point)
+        proof = UnivariateKzgPCS.commit(pp, witness.cpu().numpy().view(np.uint64))
+        return proof, ev
+
+    @staticmethod
+    def batch_open(prover_param: UnivariateProverParam, polynomials, points):
+        """mod.rs:163-190 ("a naive approach"): open every polynomial at its own point."""
+        if len(polynomials) != len(points):
+            raise PCSError("InvalidParameters: poly length %d is different from points length %d" % (len(polynomials), len(points)))
+        out = [UnivariateKzgPCS.open(prover_param, p, z) for p, z in zip(polynomials, points)]
+        return [o[0] for o in out], [o[1] for o in out]
+
+
 def jacobian_to_affine(curve, xyz: np.ndarray) -> np.ndarray:
     """(n,3,fq_limbs) Jacobian -> (n,2,fq_limbs) affine on the host (`into_affine`, mod.rs:111)."""
     c = _curve(curve)

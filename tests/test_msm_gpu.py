@@ -1,5 +1,7 @@
 """GPU parity: the HIP Pippenger MSM / KZG commit (through the C ABI) against the committed
 vectors, the C oracle on seeded inputs, and the trapdoor identity at the benchmark size."""
+import random
+
 import numpy as np
 import pytest
 
@@ -229,4 +231,30 @@ def test_msm_precomputed_table_path(gpu, mj, cref, curve_id):
         L.mzk_msm_set_precompute(1)
     want = cref.jac_to_affine(curve_id, cref.msm(curve_id, bases[7:7 + (1 << 17)], scalars[:1 << 17], threads=8))[0]
     assert np.array_equal(got, want)
+    pp.release()
+
+
+@pytest.mark.parametrize("curve_id", [0, 1])
+def test_kzg_open_matches_definition(gpu, mj, pyref, curve_id):
+    """UnivariateKzgPCS::open / batch_open (mod.rs:135-190): proof = [q(beta)]G for q = (p - p(z)) / (X - z), evaluation = p(z);
+    through the trapdoor the verifier's pairing check reads p(beta) - p(z) == (beta - z) q(beta)."""
+    c = pyref.CURVES[curve_id]
+    r = c.r
+    rng = random.Random(77 + curve_id)
+    beta = rng.randrange(r)
+    pp = mj.UnivariateProverParam.gen_srs_for_testing(c.curve_id, beta, 40)
+    G = pyref.g1_gen(c)
+    polys = [[rng.randrange(r) for _ in range(n)] for n in (41, 17, 2, 1)]
+    polys[1][0] = polys[1][1] = 0                                        # low-order zero coefficients
+    points = [rng.randrange(r) for _ in polys]
+    points[2] = 0                                                        # division by X
+    proofs, evals = mj.UnivariateKzgPCS.batch_open(pp, [fr_mont_limbs(c, p) for p in polys], points)
+    for p, z, proof, ev in zip(polys, points, proofs, evals):
+        assert ev == pyref.poly_eval(c, p, z)
+        q_at_beta = (pyref.poly_eval(c, p, beta) - ev) * pow(beta - z, -1, r) % r
+        want = pyref.g1_mul(c, q_at_beta, G) if q_at_beta else None
+        got = None if proof.is_infinity() else affine_from_limbs(c, proof.xy)
+        assert got == want
+    with pytest.raises(mj.PCSError):
+        mj.UnivariateKzgPCS.batch_open(pp, [fr_mont_limbs(c, polys[0])], points[:2])
     pp.release()
