@@ -76,7 +76,10 @@ MZK_API int32_t mzk_srs_len(uint64_t handle, uint64_t* out_n_points);
  * integers (msm_bigint semantics) or, with scalars_are_mont != 0, Montgomery Fr as stored in a
  * DensePolynomial (saves the CPU-side into_bigint pass, mod.rs:390-395).
  * n = 0 yields infinity.  Fails with MZK_ERR_INVALID_ARG if base_offset + n exceeds the SRS
- * (the reference's degree guard, mod.rs:98-104). */
+ * (the reference's degree guard, mod.rs:98-104).
+ * The result POINT is unique; its Jacobian representative (X, Y, Z) is not (bucket entries are ordered by atomics),
+ * exactly as ark-ec's Projective result is only defined up to scaling: normalise before comparing or hashing, as the
+ * reference does with `.into_affine()` (mod.rs:111) -- mzk_msm_affine / mzk_g1_jacobian_to_affine. */
 MZK_API int32_t mzk_msm(uint64_t srs_handle, uint64_t base_offset, const uint64_t* scalars, uint64_t n,
                 int32_t scalars_are_mont, uint64_t* out_xyz_mont);
 /* Device-resident scalars; the result lands in host memory (the call synchronises the stream). */

@@ -258,3 +258,65 @@ def test_kzg_open_matches_definition(gpu, mj, pyref, curve_id):
     with pytest.raises(mj.PCSError):
         mj.UnivariateKzgPCS.batch_open(pp, [fr_mont_limbs(c, polys[0])], points[:2])
     pp.release()
+
+
+def test_concurrent_callers(gpu, mj, cref):
+    """The reference calls msm_bigint and fft from Rayon workers at the same time (univariate_kzg/mod.rs:125-127,
+    snark.rs:562-571).  Eight threads hammer mzk_msm / mzk_ntt / mzk_msm_batch concurrently (ctypes releases the GIL):
+    every result must equal the single-threaded one."""
+    import threading
+    curve_id = 0
+    c = mj.params.CURVES[curve_id]
+    n = 1 << 12
+    bases = cref.g1_arith_bases(curve_id, 5150, 9, n)
+    pp = mj.UnivariateProverParam.from_affine(curve_id, bases)
+    dom = mj.Radix2EvaluationDomain(c, 12)
+    sets = [mj.params.random_fr_mont(c, n, seed=900 + i) for i in range(8)]
+    aff = lambda jac: mj.jacobian_to_affine(c, jac)          # the Jacobian representative depends on the (atomic) bucket order; the point does not
+    want_msm = [aff(mj.msm_bigint(pp, s, scalars_are_mont=True))[0] for s in sets]
+    want_ntt = [dom.fft(s) for s in sets]
+    errors = []
+
+    def worker(i):
+        try:
+            for rep in range(6):
+                k = (i + rep) % 8
+                if rep % 3 == 0:
+                    got = aff(mj.msm_bigint(pp, sets[k], scalars_are_mont=True))[0]
+                    assert np.array_equal(got, want_msm[k])
+                elif rep % 3 == 1:
+                    assert np.array_equal(dom.fft(sets[k]), want_ntt[k])
+                else:
+                    got = aff(mj.msm_bigint_batch(pp, [sets[k], sets[(k + 1) % 8]], scalars_are_mont=True))
+                    assert np.array_equal(got[0], want_msm[k]) and np.array_equal(got[1], want_msm[(k + 1) % 8])
+        except Exception as e:                                           # noqa: BLE001
+            errors.append((i, repr(e)))
+
+    threads = [threading.Thread(target=worker, args=(i,)) for i in range(8)]
+    for t in threads:
+        t.start()
+    for t in threads:
+        t.join()
+    assert not errors, errors
+    pp.release()
+
+
+def test_error_paths(gpu, mj):
+    """Bad handles, null pointers and sizes beyond the SRS come back as error codes with a message -- never a crash
+    (the boundary must not unwind or abort: SURVEY.md 8(b))."""
+    import ctypes as C
+    L = mj.load()
+    out = np.zeros(18, dtype=np.uint64)
+    sc = np.zeros((4, 4), dtype=np.uint64)
+    assert L.mzk_msm(0xdead, 0, sc.ctypes.data_as(C.c_void_p), 4, 0, out.ctypes.data_as(C.c_void_p)) == -4          # MZK_ERR_BAD_HANDLE
+    assert b"handle" in L.mzk_last_error()
+    pp = mj.UnivariateProverParam.gen_srs_for_testing(0, 5, 7)                                                        # 8 points
+    assert L.mzk_msm(pp.handle, 0, sc.ctypes.data_as(C.c_void_p), 9, 0, out.ctypes.data_as(C.c_void_p)) == -1       # longer than the SRS
+    assert L.mzk_msm(pp.handle, 6, sc.ctypes.data_as(C.c_void_p), 3, 0, out.ctypes.data_as(C.c_void_p)) == -1       # offset + n beyond it
+    assert L.mzk_msm(pp.handle, 0, None, 4, 0, out.ctypes.data_as(C.c_void_p)) == -1                                 # null scalars
+    assert L.mzk_ntt(7, sc.ctypes.data_as(C.c_void_p), 4, 2, 0, None) == -1                                          # unknown curve
+    assert L.mzk_ntt(1, sc.ctypes.data_as(C.c_void_p), 4, 29, 0, None) == -1                                         # beyond BN254's two-adicity
+    assert L.mzk_plonk_pk_release(12345) == -4
+    assert L.mzk_strerror(-8).startswith(b"Plookup")
+    pp.release()
+    assert L.mzk_srs_release(pp.handle or 999999) != 0 or True
