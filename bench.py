@@ -340,10 +340,19 @@ def main():
         want = cref.msm(0, bases, canon, threads=threads)
         cpu_s = time.perf_counter() - t1
         same = np.array_equal(cref.jac_to_affine(0, want)[0], cref.jac_to_affine(0, result)[0])
+        # the same host's figure for config C3 (NTT 2^22), beside the MSM one
+        xs = mj.params.random_fr_mont(curve, 1 << 22, seed=11)
+        t1 = time.perf_counter()
+        ev_cpu = cref.ntt(0, xs, 22, False, None, threads=threads)
+        ntt_cpu_s = time.perf_counter() - t1
+        ntt_same = bool(np.array_equal(ev_cpu[:4096], mj.Radix2EvaluationDomain(curve, 22).fft(xs)[:4096]))
+        del xs, ev_cpu
         cpu = {"value": n / cpu_s, "unit": "pairs/s", "cores": threads, "kind": "port",
                "sample": f"one full 2^{args.log_n}-pair MSM (same bases and scalars as the GPU step), oracle/cpu_ref.c "
                          f"Pippenger with the ark-ec window rule, {threads} threads; restatement of ark-ec, not the Rust binary",
-               "seconds": round(cpu_s, 3), "matches_gpu": bool(same)}
+               "seconds": round(cpu_s, 3), "matches_gpu": bool(same),
+               "ntt_2^22": {"ms": round(ntt_cpu_s * 1e3, 1), "cores": threads, "matches_gpu": ntt_same,
+                            "sample": "one forward 2^22-point NTT, oracle/cpu_ref.c in-order radix-2 (ark-poly's algorithm restated)"}}
 
     if rank == 0:
         acc_avg_ms = acc_ms / max(acc_cnt, 1)

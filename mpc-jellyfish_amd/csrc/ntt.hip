@@ -101,6 +101,8 @@ int32_t ntt_dev(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool in
         a.f_hi = pl->d_fhi;
         a.f_one = pl->d_fone;
         a.in_len = in_len;
+        if (a.is_first && !a.is_final)                                  // zero-padded input: leading stages of pass 1 are copies
+            while (a.skip < lr && in_len <= (N >> (a.skip + 1))) a.skip++;
         int lc = NTT_TILE_LOG - lr;
         if (lc < 0) lc = 0;
         if (a.is_final) lc = K == 1 ? 0 : (lc < pl->h.log_radix[0] ? lc : pl->h.log_radix[0]);

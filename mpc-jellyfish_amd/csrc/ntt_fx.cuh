@@ -45,6 +45,7 @@ struct NttxPassArgs {
     int log_n, log_r, log_c, log_s, log_p;
     int log_lb;
     int is_first, is_final, n_pass;
+    int skip;                  // first pass of a zero-padded input (in_len <= N >> skip): the first `skip` stages are copies
     int log_radix[NTT_MAX_PASSES];
 };
 
@@ -110,6 +111,20 @@ __global__ __launch_bounds__(NTTX_THREADS) void nttx_pass_kernel(NttxPassArgs a)
     }
 
     // ---- load: boundary words -> 29-bit limbs, bit-reversed rows (decimation in time) --------------------
+    // Zero-padded input (the quotient round transforms polynomials of degree n + 2 on 8n points): rows r >= R >> skip are
+    // zero for every tile, so in bit-reversed order each run of 2^skip positions holds one non-zero value first, and the
+    // first `skip` stages -- butterflies whose multiplied operand is zero -- merely copy it across the run.
+    if (a.skip > 0) {
+        const int rows = R >> a.skip, reps = 1 << a.skip;
+        for (int e = tid; e < rows * C; e += NTTX_THREADS) {
+            const int c = e & (C - 1), r = e >> a.log_c;
+            const unsigned long long g = base + ((unsigned long long)r << a.log_s) + c;
+            Fx<X> v = Fx<X>::zero();
+            if (g < a.in_len) v = fx_load_packed<X>(in + g * 8);
+            const int pos = (int)bitrev((unsigned)r, a.log_r) * C + c;
+            for (int t = 0; t < reps; t++) ldsx_store<X>(da, db, dc, pos + t * C, v);
+        }
+    } else
     for (int e = tid; e < TILE; e += NTTX_THREADS) {
         int r, c;
         unsigned long long g;
@@ -130,7 +145,7 @@ __global__ __launch_bounds__(NTTX_THREADS) void nttx_pass_kernel(NttxPassArgs a)
 
     // ---- R-point transforms: one butterfly per thread per stage -------------------------------------------
     const int nbf = TILE >> 1;
-    for (int s = 0; s < a.log_r; s++) {
+    for (int s = a.skip; s < a.log_r; s++) {
         const int half = 1 << s;
         for (int bt = tid; bt < nbf; bt += NTTX_THREADS) {
             const int c = bt & (C - 1);
