@@ -202,7 +202,10 @@ inline void ntt_choose_radices(int log_n, int* log_radix, int* n_pass) {
         log_radix[0] = log_n;
         return;
     }
+    // passes of about 8 bits; beyond 2^24 a fourth pass would cost more (its inter-pass twiddles and 64 B/element of
+    // traffic) than 9-bit radices do (512-row tiles of 4 columns: 128-byte segments), so 2^25..2^27 stay at three passes
     int k = (log_n + 7) / 8;
+    if (k == 4 && log_n <= 3 * NTT_MAX_LOG_R) k = 3;
     *n_pass = k;
     int basebits = log_n / k, extra = log_n % k;
     for (int i = 0; i < k; i++) log_radix[i] = basebits + (i < extra ? 1 : 0);
