@@ -75,8 +75,10 @@ struct Srs {
 inline int fq_words(int curve) { return curve == MZK_CURVE_BLS12_381 ? 12 : 8; }
 
 // ntt.hip
+// scale: 0 = boundary form in and out; 1 = output left in the internal form x * R' (R' = 2^261 = 32 R) of the quotient kernels;
+// 2 = input in that form, output back in the boundary form (the factor rides in the final pass's multiplication)
 int32_t ntt_dispatch(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool inverse, const uint32_t* coset,
-                     uint32_t batch, uint64_t stride, hipStream_t st);
+                     uint32_t batch, uint64_t stride, hipStream_t st, int scale = 0);
 void ntt_release_plans();
 // msm.hip
 int32_t msm_dispatch(const Srs& s, uint64_t base_offset, const uint32_t* d_scalars, uint64_t n, int is_mont, uint32_t* out, hipStream_t st);

@@ -16,7 +16,7 @@ struct NttPlanDev {
     uint32_t *d_tlo = nullptr, *d_thi = nullptr, *d_flo = nullptr, *d_fhi = nullptr, *d_fone = nullptr;
 };
 struct PlanKey {
-    int curve, log_n, inverse;
+    int curve, log_n, inverse, scale;
     uint32_t coset[8];
     bool has_coset;
     bool operator<(const PlanKey& o) const { return std::memcmp(this, &o, sizeof(PlanKey)) < 0; }
@@ -31,16 +31,16 @@ int32_t upload_words(uint32_t** d, const std::vector<uint32_t>& v) {
 }
 
 template <class X>
-int32_t get_plan(int curve, int log_n, bool inverse, const uint32_t* coset, NttPlanDev** out) {
+int32_t get_plan(int curve, int log_n, bool inverse, const uint32_t* coset, int scale, NttPlanDev** out) {
     PlanKey key;
     std::memset(&key, 0, sizeof key);
-    key.curve = curve; key.log_n = log_n; key.inverse = inverse ? 1 : 0;
+    key.curve = curve; key.log_n = log_n; key.inverse = inverse ? 1 : 0; key.scale = scale;
     key.has_coset = coset != nullptr;
     if (coset) std::memcpy(key.coset, coset, 32);
     auto it = g_plans.find(key);
     if (it != g_plans.end()) { *out = it->second.get(); return MZK_OK; }
     auto pl = std::make_unique<NttPlanDev>();
-    nttx_build_plan<X>(pl->h, log_n, inverse, coset);
+    nttx_build_plan<X>(pl->h, log_n, inverse, coset, scale);
     for (int k = 0; k < pl->h.n_pass; k++) MZK_TRY(upload_words(&pl->d_stage[k], pl->h.stage_tw[k]));
     MZK_TRY(upload_words(&pl->d_tlo, pl->h.t_lo));
     MZK_TRY(upload_words(&pl->d_thi, pl->h.t_hi));
@@ -71,15 +71,16 @@ int32_t launch_pass(const NttxPassArgs& a, unsigned long long n_tiles, uint32_t 
 // d_data: batch polynomials, `stride` elements apart, transformed in place (async on st)
 template <class X>
 int32_t ntt_dev(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool inverse, const uint32_t* coset,
-                uint32_t batch, uint64_t stride, hipStream_t st) {
+                uint32_t batch, uint64_t stride, hipStream_t st, int scale) {
     if (log_n < 0 || log_n > X::TWO_ADICITY || log_n > 30) { set_error("log_n out of range"); return MZK_ERR_INVALID_ARG; }
     const uint64_t N = 1ull << log_n;
     if (batch == 0) return MZK_OK;
     if (stride < N || batch > 65535) { set_error("bad batch/stride"); return MZK_ERR_INVALID_ARG; }
     if (in_len > N) in_len = N;
-    if (log_n == 0) return MZK_OK;   // size-1 transform is the identity (offset^0 = 1, N^-1 = 1)
+    if (log_n == 0 && scale == 0) return MZK_OK;   // size-1 transform is the identity (offset^0 = 1, N^-1 = 1)
+    if (log_n == 0) { set_error("scaled size-1 transform"); return MZK_ERR_UNSUPPORTED; }
     NttPlanDev* pl;
-    MZK_TRY(get_plan<X>(curve, log_n, inverse, coset, &pl));
+    MZK_TRY(get_plan<X>(curve, log_n, inverse, coset, scale, &pl));
     MZK_TRY(ws_acquire(st));
     MZK_TRY(g_ws.ntt_scratch.reserve((size_t)batch * N * 32));
     uint32_t* scratch = g_ws.ntt_scratch.as<uint32_t>();
@@ -128,9 +129,9 @@ int32_t ntt_dev(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool in
 }  // namespace
 
 int32_t ntt_dispatch(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool inverse, const uint32_t* coset,
-                     uint32_t batch, uint64_t stride, hipStream_t st) {
-    if (curve == MZK_CURVE_BLS12_381) return ntt_dev<BlsFrX>(curve, d_data, in_len, log_n, inverse, coset, batch, stride, st);
-    if (curve == MZK_CURVE_BN254) return ntt_dev<BnFrX>(curve, d_data, in_len, log_n, inverse, coset, batch, stride, st);
+                     uint32_t batch, uint64_t stride, hipStream_t st, int scale) {
+    if (curve == MZK_CURVE_BLS12_381) return ntt_dev<BlsFrX>(curve, d_data, in_len, log_n, inverse, coset, batch, stride, st, scale);
+    if (curve == MZK_CURVE_BN254) return ntt_dev<BnFrX>(curve, d_data, in_len, log_n, inverse, coset, batch, stride, st, scale);
     set_error("unknown curve_id");
     return MZK_ERR_INVALID_ARG;
 }

@@ -206,7 +206,7 @@ inline void nttx_put(std::vector<uint32_t>& dst, size_t idx, const Fp<X>& a) {
 }
 
 template <class X>
-void nttx_build_plan(NttxPlanHost& pl, int log_n, bool inverse, const uint32_t* coset_mont /* nullable */) {
+void nttx_build_plan(NttxPlanHost& pl, int log_n, bool inverse, const uint32_t* coset_mont /* nullable */, int scale = 0) {
     using F = Fp<X>;
     pl.log_n = log_n;
     pl.inverse = inverse;
@@ -247,7 +247,11 @@ void nttx_build_plan(NttxPlanHost& pl, int log_n, bool inverse, const uint32_t* 
     cur = F::one();
     for (size_t i = 0; i < nhi; i++) { nttx_put<X>(pl.t_hi, i, cur); cur = cur * step; }
     // final-pass multiplier(s)
-    const F ninv = inverse ? inv(from_u64<X>(1ull << log_n)) : F::one();
+    // scale: 1 = leave the output in the internal form x * R' (R' = 32 R), 2 = take an internal-form input back to x * R;
+    // folded into the multiplication the final pass performs anyway (plonk.cuh)
+    F ninv = inverse ? inv(from_u64<X>(1ull << log_n)) : F::one();
+    if (scale == 1) ninv = ninv * from_u64<X>(32);
+    if (scale == 2) ninv = ninv * inv(from_u64<X>(32));
     pl.f_one.assign(NTTX_TW_WORDS, 0);
     nttx_put<X>(pl.f_one, 0, ninv);
     if (inverse && pl.coset) {

@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include "fp.cuh"
+#include "fx.cuh"
 #include "poly.cuh"
 
 namespace mzk {
@@ -55,9 +56,27 @@ __device__ __forceinline__ Fp<P> arg_fp(const uint32_t (&a)[8]) {
     return r;
 }
 
-template <class P, bool ULTRA>
-__global__ __launch_bounds__(PLK_THREADS) void plonk_quotient_kernel(QuotientArgs a) {
-    using F = Fp<P>;
+// ---- the quotient kernels run on the reduced-radix field (fx.cuh: 9 limbs of 29 bits, lazy reduction) ------------------
+// Every operand is held in the INTERNAL Montgomery form x * R', R' = 2^261 = 32 R, packed canonically in 8 words: the
+// proving key's tables are stored that way, the challenges arrive that way (plonk.hip multiplies them by 32), and the coset
+// NTT that produces the online evaluations folds the factor 32 into the multiplication its final pass does anyway -- as the
+// inverse NTT of the result folds 1/32 (ntt.hip `scale`).  So fx_mul(a, b) = a b / R' stays in the form, at no cost.
+// Bounds (H = X::HEADROOM_BITS, 6 for BLS12-381 Fr, 7 for BN254 Fr): fx_mul wants A * B <= 2^H for operands below A p, B p
+// and limbs below 2^29 + 2^27; its result is class M: limbs < 2^29, value < 2 p (here < 1.35 p).  Sums are re-normalised
+// (fx_norm: limbs < 2^29 + 8, value unchanged) before a limb can reach 2^32, i.e. after at most six class-M terms.
+template <class X>
+__device__ __forceinline__ Fx<X> arg_fx(const uint32_t (&a)[8]) { return fx_unpack<X>(a); }
+template <class X>
+__device__ __forceinline__ Fx<X> ldx(const uint32_t* __restrict__ p) { return fx_load_packed<X>(p); }       // canonical: A = 1, limbs < 2^29
+// lazy value below 2^H p / any limb state fx_mul accepts  ->  canonical, packed
+template <class X>
+__device__ __forceinline__ void stx(uint32_t* __restrict__ p, const Fx<X>& v) {
+    fx_store_packed<X>(p, fx_canonical(fx_mul(fx_norm(v), Fx<X>::one())));             // v * R' / R' = v, value < 1.1 p before the last subtraction
+}
+
+template <class X, bool ULTRA>
+__global__ __launch_bounds__(PLK_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void plonk_quotient_kernel(QuotientArgs a) {
+    using F = Fx<X>;
     constexpr int W = ULTRA ? 6 : 5;
     const unsigned long long i = (unsigned long long)blockIdx.x * PLK_THREADS + threadIdx.x;
     if (i >= a.m) return;
@@ -66,78 +85,92 @@ __global__ __launch_bounds__(PLK_THREADS) void plonk_quotient_kernel(QuotientArg
     const unsigned long long fs = a.fstride, os = a.ostride;
     F w[W];
 #pragma unroll
-    for (int j = 0; j < W; j++) w[j] = load_fp<P>(a.wire + ((size_t)j * os + i) * 8);
-    auto sel = [&](int j) { return load_fp<P>(a.sel + ((size_t)j * fs + i) * 8); };
-    // ---- gate identity (prover.rs:696-708)
-    F t = sel(11) + load_fp<P>(a.pi + i * 8);                       // q_c + pi
+    for (int j = 0; j < W; j++) w[j] = ldx<X>(a.wire + ((size_t)j * os + i) * 8);
+    auto sel = [&](int j) { return ldx<X>(a.sel + ((size_t)j * fs + i) * 8); };
+    // ---- gate identity (prover.rs:696-708); value bounds in units of p on the right
+    F t = fx_add(sel(11), ldx<X>(a.pi + i * 8));                                       // q_c + pi                     2
 #pragma unroll
-    for (int j = 0; j < 4; j++) t = t + sel(j) * w[j];              // q_lc
-    const F w01 = w[0] * w[1], w23 = w[2] * w[3];
-    t = t + sel(4) * w01 + sel(5) * w23;                            // q_mul
-    t = t + sel(12) * (w01 * w23 * w[4]);                           // q_ecc
+    for (int j = 0; j < 4; j++) t = fx_add(t, fx_mul(sel(j), w[j]));                  // q_lc                         6.1, limbs < 6 * 2^29
+    t = fx_norm(t);
+    const F w01 = fx_mul(w[0], w[1]), w23 = fx_mul(w[2], w[3]);                       // class M
+    t = fx_add(t, fx_add(fx_mul(sel(4), w01), fx_mul(sel(5), w23)));                  // q_mul                        8.2
+    t = fx_add(t, fx_mul(sel(12), fx_mul(fx_mul(w01, w23), w[4])));                   // q_ecc                        9.3, limbs < 4 * 2^29 + 8
+    t = fx_norm(t);
 #pragma unroll
-    for (int j = 0; j < 4; j++) {                                   // q_hash * w^5
-        const F w2 = sqr(w[j]);
-        t = t + sel(6 + j) * (sqr(w2) * w[j]);
+    for (int j = 0; j < 4; j++) {                                                     // q_hash * w^5                 13.5, limbs < 5 * 2^29 + 8
+        const F w2 = fx_sqr(w[j]);
+        t = fx_add(t, fx_mul(sel(6 + j), fx_mul(fx_sqr(w2), w[j])));
     }
-    t = t - sel(10) * w[4];                                         // q_o
+    t = fx_norm(fx_sub2(t, fx_mul(sel(10), w[4])));                                   // - q_o w4 (+ 2p)               15.5
     // ---- copy constraints (prover.rs:741-758)
-    const F alpha = arg_fp<P>(a.alpha), beta = arg_fp<P>(a.beta), gamma = arg_fp<P>(a.gamma);
-    const F z_x = load_fp<P>(a.z + i * 8);
-    const F z_xw = load_fp<P>(a.z + inext * 8);
-    const F x = load_fp<P>(a.xs + i * 8);
-    const F xb = x * beta;
+    const F alpha = arg_fx<X>(a.alpha), beta = arg_fx<X>(a.beta), gamma = arg_fx<X>(a.gamma);
+    const F z_x = ldx<X>(a.z + i * 8);
+    const F z_xw = ldx<X>(a.z + inext * 8);
+    const F xb = fx_mul(ldx<X>(a.xs + i * 8), beta);                                  // class M
     F acc1 = z_x, acc2 = z_xw;
 #pragma unroll
     for (int j = 0; j < W; j++) {
-        const F wg = w[j] + gamma;
-        acc1 = acc1 * (wg + arg_fp<P>(a.k[j]) * xb);
-        acc2 = acc2 * (wg + load_fp<P>(a.sig + ((size_t)j * fs + i) * 8) * beta);
+        const F wg = fx_add(w[j], gamma);                                             // 2, limbs < 2^30
+        acc1 = fx_mul(acc1, fx_norm(fx_add(wg, fx_mul(arg_fx<X>(a.k[j]), xb))));      // factor 3.1 -> product < 1.06
+        acc2 = fx_mul(acc2, fx_norm(fx_add(wg, fx_mul(ldx<X>(a.sig + ((size_t)j * fs + i) * 8), beta))));
     }
-    F t1 = t + alpha * (acc1 - acc2);
-    F t2 = arg_fp<P>(a.alpha2) * ((z_x - F::one()) * load_fp<P>(a.inv_den + i * 8));
-    store_fp<P>(a.out + i * 8, t1 * arg_fp<P>(a.zh_inv[a.zh_class >= 0 ? a.zh_class : (int)(i % PLK_RATIO)]) + t2);          // prover.rs:657
+    const F t1 = fx_norm(fx_add(t, fx_mul(alpha, fx_norm(fx_sub2(acc1, acc2)))));     // acc1 - acc2 + 2p: 3.2;  t1: 16.6
+    const F t2 = fx_mul(arg_fx<X>(a.alpha2), fx_mul(fx_norm(fx_sub2(z_x, F::one())), ldx<X>(a.inv_den + i * 8)));   // z - 1 (+ 2p): 3
+    const F zh = arg_fx<X>(a.zh_inv[a.zh_class >= 0 ? a.zh_class : (int)(i % PLK_RATIO)]);
+    stx<X>(a.out + i * 8, fx_add(fx_mul(t1, zh), t2));                                // 16.6 / 2^H + 1 + 1.05 < 2.4         prover.rs:657
 }
 
 // UltraPlonk, second launch: out[i] += t_lookup_1 * zh_inv + t_lookup_2 (compute_quotient_plookup_contribution,
 // prover.rs:773-888).  Kept apart from the gate / copy-constraint kernel: together the 45 operand streams need > 320
 // VGPRs (one wave per SIMD); field addition is exact, so the split changes nothing in the result.
-template <class P>
-__global__ __launch_bounds__(PLK_THREADS) void plonk_quotient_lookup_kernel(QuotientArgs a) {
-    using F = Fp<P>;
+template <class X>
+__global__ __launch_bounds__(PLK_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void plonk_quotient_lookup_kernel(QuotientArgs a) {
+    using F = Fx<X>;
     const unsigned long long i = (unsigned long long)blockIdx.x * PLK_THREADS + threadIdx.x;
     if (i >= a.m) return;
     const unsigned long long m = a.m;
     const unsigned long long inext = (i + a.next_off) % m;
     const unsigned long long fs = a.fstride, os = a.ostride;
-    auto wire = [&](int j, unsigned long long at) { return load_fp<P>(a.wire + ((size_t)j * os + at) * 8); };
-    const F alpha = arg_fp<P>(a.alpha), beta = arg_fp<P>(a.beta), gamma = arg_fp<P>(a.gamma);
-    const F x = load_fp<P>(a.xs + i * 8);
-    F t1, t2;
-    {
-        // alpha^3 L_n (h1 - h2(wX)) + alpha^4 L_1 (p - 1) + alpha^5 L_n (p - 1) + alpha^6 (X - w^-1) [...]
-        auto tab = [&](int j, unsigned long long at) { return load_fp<P>(a.tab + ((size_t)j * fs + at) * 8); };
-        const F tau = arg_fp<P>(a.tau), alpha3 = arg_fp<P>(a.alpha3);
-        const F ql = load_fp<P>(a.sel + ((size_t)13 * fs + i) * 8), ql_next = load_fp<P>(a.sel + ((size_t)13 * fs + inext) * 8);
-        const F h1 = load_fp<P>(a.h + i * 8), h1n = load_fp<P>(a.h + inext * 8);
-        const F h2 = load_fp<P>(a.h + (os + i) * 8), h2n = load_fp<P>(a.h + (os + inext) * 8);
-        const F p = load_fp<P>(a.pl + i * 8), pn = load_fp<P>(a.pl + inext * 8);
-        auto merged = [&](const F& first, const F& q, const F& ds, const F& a0, const F& a1, const F& a2) {
-            return first + q * tau * (ds + tau * (a0 + tau * (a1 + tau * a2)));
-        };
-        const F mt = merged(tab(0, i), ql, tab(2, i), tab(1, i), wire(3, i), wire(4, i));
-        const F mt_next = merged(tab(0, inext), ql_next, tab(2, inext), tab(1, inext), wire(3, inext), wire(4, inext));
-        const F ml = merged(wire(5, i), ql, tab(3, i), wire(0, i), wire(1, i), wire(2, i));
-        const F lag_n = load_fp<P>(a.inv_den_n + i * 8), lag_1 = load_fp<P>(a.inv_den + i * 8);
-        const F pm1 = p - F::one();
-        // result_2 = alpha^3 term_h + alpha^4 term_p1 + alpha^5 term_p2 = alpha^3 (term_h + alpha (term_p1 + alpha term_p2))
-        t2 = alpha3 * ((h1 - h2n) * lag_n + alpha * (pm1 * lag_1 + alpha * (pm1 * lag_n)));
-        const F b1 = beta + F::one(), g1 = gamma * b1;
-        const F term3 = (x - arg_fp<P>(a.w_inv)) * (p * b1 * (gamma + ml) * (g1 + mt + beta * mt_next) - pn * (g1 + h1 + beta * h1n) * (g1 + h2 + beta * h2n));
-        t1 = sqr(alpha3) * term3;
-    }
-    const F prev = load_fp<P>(a.out + i * 8);
-    store_fp<P>(a.out + i * 8, prev + (t1 * arg_fp<P>(a.zh_inv[a.zh_class >= 0 ? a.zh_class : (int)(i % PLK_RATIO)]) + t2));
+    auto wire = [&](int j, unsigned long long at) { return ldx<X>(a.wire + ((size_t)j * os + at) * 8); };
+    auto tab = [&](int j, unsigned long long at) { return ldx<X>(a.tab + ((size_t)j * fs + at) * 8); };
+    const F alpha = arg_fx<X>(a.alpha), beta = arg_fx<X>(a.beta), gamma = arg_fx<X>(a.gamma);
+    const F tau = arg_fx<X>(a.tau), alpha3 = arg_fx<X>(a.alpha3);
+    // first + q tau (ds + tau (a0 + tau (a1 + tau a2))): every sum has two terms (value <= 2.1, limbs < 2^30): no norm needed
+    // except for the multiplicand rule (limbs < 2^29 + 2^27): normalise the sums that are multiplied
+    auto merged = [&](const F& first, const F& qtau, const F& ds, const F& a0, const F& a1, const F& a2) {
+        const F in3 = fx_norm(fx_add(a1, fx_mul(tau, a2)));
+        const F in2 = fx_norm(fx_add(a0, fx_mul(tau, in3)));
+        const F in1 = fx_norm(fx_add(ds, fx_mul(tau, in2)));
+        return fx_add(first, fx_mul(qtau, in1));                                      // 2.1, limbs < 2^30
+    };
+    const F qtau = fx_mul(ldx<X>(a.sel + ((size_t)13 * fs + i) * 8), tau);
+    const F qtau_next = fx_mul(ldx<X>(a.sel + ((size_t)13 * fs + inext) * 8), tau);
+    const F mt = merged(tab(0, i), qtau, tab(2, i), tab(1, i), wire(3, i), wire(4, i));
+    const F mt_next = merged(tab(0, inext), qtau_next, tab(2, inext), tab(1, inext), wire(3, inext), wire(4, inext));
+    const F ml = merged(wire(5, i), qtau, tab(3, i), wire(0, i), wire(1, i), wire(2, i));
+    const F h1 = ldx<X>(a.h + i * 8), h1n = ldx<X>(a.h + inext * 8);
+    const F h2 = ldx<X>(a.h + (os + i) * 8), h2n = ldx<X>(a.h + (os + inext) * 8);
+    const F p = ldx<X>(a.pl + i * 8), pn = ldx<X>(a.pl + inext * 8);
+    const F lag_n = ldx<X>(a.inv_den_n + i * 8), lag_1 = ldx<X>(a.inv_den + i * 8);
+    const F pm1 = fx_norm(fx_sub2(p, F::one()));                                      // p - 1 (+ 2p): 3
+    // result_2 = alpha^3 (term_h + alpha (term_p1 + alpha term_p2))
+    const F inner = fx_norm(fx_add(fx_mul(pm1, lag_1), fx_mul(alpha, fx_mul(pm1, lag_n))));            // 2.2
+    const F t2 = fx_mul(alpha3, fx_norm(fx_add(fx_mul(fx_norm(fx_sub2(h1, h2n)), lag_n), fx_mul(alpha, inner))));   // (h1 - h2n + 2p) <= 3
+    const F b1 = fx_add(beta, F::one());                                              // 2, limbs < 2^30
+    const F g1 = fx_mul(gamma, fx_norm(b1));                                          // class M
+    // left = p (1 + beta) (gamma + ml) (g1 + mt + beta mt_next)
+    F left = fx_mul(p, fx_norm(b1));
+    left = fx_mul(left, fx_norm(fx_add(gamma, ml)));                                  // factor 3.1
+    left = fx_mul(left, fx_norm(fx_add(fx_add(g1, mt), fx_mul(beta, fx_norm(mt_next)))));              // factor 1.1 + 2.1 + 1.1 = 4.3
+    // right = p(wX) (g1 + h1 + beta h1(wX)) (g1 + h2 + beta h2(wX))
+    F right = fx_mul(pn, fx_norm(fx_add(fx_add(g1, h1), fx_mul(beta, h1n))));         // factor 3.2
+    right = fx_mul(right, fx_norm(fx_add(fx_add(g1, h2), fx_mul(beta, h2n))));
+    const F xm = fx_norm(fx_sub2(ldx<X>(a.xs + i * 8), arg_fx<X>(a.w_inv)));          // x - w^-1 (+ 2p): 3
+    const F term3 = fx_mul(xm, fx_norm(fx_sub2(left, right)));                        // (3.2) * 3 / 2^H + 1
+    const F t1 = fx_mul(fx_sqr(alpha3), term3);
+    const F zh = arg_fx<X>(a.zh_inv[a.zh_class >= 0 ? a.zh_class : (int)(i % PLK_RATIO)]);
+    const F prev = ldx<X>(a.out + i * 8);
+    stx<X>(a.out + i * 8, fx_add(fx_add(prev, t2), fx_mul(t1, zh)));                  // 1 + 1.1 + 1.1
 }
 
 // xs[i] = g * w^i and inv_den[i] = 1/(n (xs[i] - 1)), 16 points per thread with one shared inversion

@@ -36,6 +36,21 @@ struct PlonkPk {
 std::map<uint64_t, std::unique_ptr<PlonkPk>> g_pks;
 uint64_t g_next_pk = 1;
 
+// data[i] *= c (boundary form -> internal form x * R' with c = 32: plonk.cuh)
+template <class P>
+__global__ __launch_bounds__(PLK_THREADS) void fr_scale_kernel(uint32_t* __restrict__ data, unsigned long long n, const uint32_t* __restrict__ c_mont) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * PLK_THREADS + threadIdx.x;
+    if (i >= n) return;
+    store_fp<P>(data + i * 8, load_fp<P>(data + i * 8) * load_fp<P>(c_mont));
+}
+template <class P>
+void to_internal(uint32_t (&dst)[8], const uint32_t* src_mont) {
+    Fp<P> v;
+    std::memcpy(v.l, src_mont, 32);
+    v = v * from_u64<P>(32);
+    std::memcpy(dst, v.l, 32);
+}
+
 // out[i] = 1 / (scale * (xs[i] - c)), 16 points per thread with one shared inversion
 template <class P>
 __global__ __launch_bounds__(PLK_THREADS) void plonk_shifted_inverse_kernel(const uint32_t* __restrict__ xs, unsigned long long m, const uint32_t* __restrict__ c_mont,
@@ -79,7 +94,8 @@ int32_t pk_build(PlonkPk& pk, const uint32_t* sel_coeffs, const uint32_t* sig_co
         HIP_TRY(hipMemcpy2DAsync(pk.d_fixed + (size_t)(pk.nsel + pk.W) * m * 8, m * 32, tab_coeffs, poly_len * 32, poly_len * 32, 4, hipMemcpyHostToDevice, st));
     for (int i = 0; i < 8; i++) pk.gen[i] = P::GENERATOR[i];
     // coset evaluations of the fixed polynomials, once per proving key (prover.rs:552-558, 577-584 do it per proof)
-    MZK_TRY(ntt_dispatch(pk.curve, pk.d_fixed, poly_len, log_m, false, pk.gen, nfix, m, st));
+    // ... and left in the internal form x * R' the quotient kernels compute in (plonk.cuh)
+    MZK_TRY(ntt_dispatch(pk.curve, pk.d_fixed, poly_len, log_m, false, pk.gen, nfix, m, st, 1));
     // host constants: w_m, n, 1/Z_H on the 8 coset classes
     F w = F::from_const(P::ROOT);
     for (int i = log_m; i < P::TWO_ADICITY; i++) w = sqr(w);
@@ -110,6 +126,15 @@ int32_t pk_build(PlonkPk& pk, const uint32_t* sel_coeffs, const uint32_t* sig_co
         HIP_TRY(hipMemcpyAsync(d_c + 24, scale.l, 32, hipMemcpyHostToDevice, st));
         hipLaunchKernelGGL((plonk_shifted_inverse_kernel<P>), dim3((unsigned)((threads + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st,
                            pk.d_xs, m, d_c + 16, d_c + 24, pk.d_inv_den_n);
+        HIP_TRY(hipGetLastError());
+    }
+    {   // the per-point tables go to the internal form too
+        const F c32 = from_u64<P>(32);
+        HIP_TRY(hipMemcpyAsync(d_c + 8, c32.l, 32, hipMemcpyHostToDevice, st));
+        const unsigned sg = (unsigned)((m + PLK_THREADS - 1) / PLK_THREADS);
+        hipLaunchKernelGGL((fr_scale_kernel<P>), dim3(sg), dim3(PLK_THREADS), 0, st, pk.d_xs, m, d_c + 8);
+        hipLaunchKernelGGL((fr_scale_kernel<P>), dim3(sg), dim3(PLK_THREADS), 0, st, pk.d_inv_den, m, d_c + 8);
+        if (pk.ultra) hipLaunchKernelGGL((fr_scale_kernel<P>), dim3(sg), dim3(PLK_THREADS), 0, st, pk.d_inv_den_n, m, d_c + 8);
         HIP_TRY(hipGetLastError());
     }
     // gate-domain tables for the grand products (rounds 2, 2.5): sigma_i(w^j), w^j and the table polynomials' values
@@ -241,6 +266,31 @@ int32_t lookup_product_run(const PlonkPk& pk, const uint32_t* d_table, const uin
     return ntt_dispatch(pk.curve, d_out, n, pk.log_n, true, nullptr, 1, n, st);
 }
 
+template <class P> struct FxOf;
+template <> struct FxOf<BlsFr> { using type = BlsFrX; };
+template <> struct FxOf<BnFr> { using type = BnFrX; };
+
+// challenges and per-key constants of QuotientArgs, converted to the internal form x * R' (x32)
+template <class P>
+void fill_quotient_constants(QuotientArgs& a, const PlonkPk& pk, const uint32_t* tau, const uint32_t* alpha, const uint32_t* beta, const uint32_t* gamma) {
+    using F = Fp<P>;
+    for (int j = 0; j < PLK_MAX_WIRES; j++) to_internal<P>(a.k[j], pk.k[j]);
+    for (int j = 0; j < PLK_RATIO; j++) to_internal<P>(a.zh_inv[j], pk.zh_inv[j]);
+    F al, a2;
+    std::memcpy(al.l, alpha, 32);
+    a2 = sqr(al);
+    to_internal<P>(a.alpha, alpha);
+    to_internal<P>(a.alpha2, a2.l);
+    to_internal<P>(a.beta, beta);
+    to_internal<P>(a.gamma, gamma);
+    if (pk.ultra) {
+        const F a3 = a2 * al;
+        to_internal<P>(a.tau, tau);
+        to_internal<P>(a.alpha3, a3.l);
+        to_internal<P>(a.w_inv, pk.w_inv);
+    }
+}
+
 // d_polys rows: W wires, z, public input (, h_1, h_2, Plookup product)
 template <class P>
 int32_t quotient_run(const PlonkPk& pk, uint32_t* d_polys, uint64_t in_len, const uint32_t* tau, const uint32_t* alpha, const uint32_t* beta,
@@ -250,7 +300,8 @@ int32_t quotient_run(const PlonkPk& pk, uint32_t* d_polys, uint64_t in_len, cons
     const uint64_t m = 1ull << log_m;
     ProfScope total("plonk_quotient_total", st);
     // coset FFT of the W wires, z and the public-input polynomial (prover.rs:559-567; Plookup oracles :585-590), in place
-    MZK_TRY(ntt_dispatch(pk.curve, d_polys, in_len, log_m, false, pk.gen, pk.W + 2 + (pk.ultra ? 3 : 0), m, st));
+    // -- evaluations left in the internal form x * R' of the kernels (plonk.cuh)
+    MZK_TRY(ntt_dispatch(pk.curve, d_polys, in_len, log_m, false, pk.gen, pk.W + 2 + (pk.ultra ? 3 : 0), m, st, 1));
     QuotientArgs a;
     a.sel = pk.d_fixed;
     a.sig = pk.d_fixed + (size_t)pk.nsel * m * 8;
@@ -261,39 +312,27 @@ int32_t quotient_run(const PlonkPk& pk, uint32_t* d_polys, uint64_t in_len, cons
     a.inv_den = pk.d_inv_den;
     a.out = d_out;
     a.m = m; a.fstride = m; a.ostride = m; a.next_off = PLK_RATIO; a.zh_class = -1;
-    std::memcpy(a.k, pk.k, sizeof a.k);
-    std::memcpy(a.zh_inv, pk.zh_inv, sizeof a.zh_inv);
-    F al, a2;
-    std::memcpy(al.l, alpha, 32);
-    a2 = sqr(al);
-    std::memcpy(a.alpha, alpha, 32);
-    std::memcpy(a.alpha2, a2.l, 32);
-    std::memcpy(a.beta, beta, 32);
-    std::memcpy(a.gamma, gamma, 32);
+    fill_quotient_constants<P>(a, pk, tau, alpha, beta, gamma);
     a.tab = a.h = a.pl = a.inv_den_n = nullptr;
     if (pk.ultra) {
         a.tab = pk.d_fixed + (size_t)(pk.nsel + pk.W) * m * 8;
         a.h = d_polys + (size_t)(pk.W + 2) * m * 8;
         a.pl = d_polys + (size_t)(pk.W + 4) * m * 8;
         a.inv_den_n = pk.d_inv_den_n;
-        const F a3 = a2 * al;
-        std::memcpy(a.tau, tau, 32);
-        std::memcpy(a.alpha3, a3.l, 32);
-        std::memcpy(a.w_inv, pk.w_inv, 32);
     }
     {
         ProfScope ps("plonk_quotient_kernel", st);
         const dim3 grid((unsigned)((m + PLK_THREADS - 1) / PLK_THREADS));
         if (pk.ultra) {
-            hipLaunchKernelGGL((plonk_quotient_kernel<P, true>), grid, dim3(PLK_THREADS), 0, st, a);
-            hipLaunchKernelGGL((plonk_quotient_lookup_kernel<P>), grid, dim3(PLK_THREADS), 0, st, a);
+            hipLaunchKernelGGL((plonk_quotient_kernel<typename FxOf<P>::type, true>), grid, dim3(PLK_THREADS), 0, st, a);
+            hipLaunchKernelGGL((plonk_quotient_lookup_kernel<typename FxOf<P>::type>), grid, dim3(PLK_THREADS), 0, st, a);
         } else {
-            hipLaunchKernelGGL((plonk_quotient_kernel<P, false>), grid, dim3(PLK_THREADS), 0, st, a);
+            hipLaunchKernelGGL((plonk_quotient_kernel<typename FxOf<P>::type, false>), grid, dim3(PLK_THREADS), 0, st, a);
         }
         HIP_TRY(hipGetLastError());
     }
     // coefficient form: coset.ifft (prover.rs:672)
-    MZK_TRY(ntt_dispatch(pk.curve, d_out, m, log_m, true, pk.gen, 1, m, st));
+    MZK_TRY(ntt_dispatch(pk.curve, d_out, m, log_m, true, pk.gen, 1, m, st, 2));          // internal form in, boundary form out
     return MZK_OK;
 }
 
@@ -340,7 +379,7 @@ int32_t pk_build_chunked(PlonkPk& pk, const uint32_t* sel_coeffs, const uint32_t
     HIP_TRY(hipMemsetAsync(pk.d_fixed, 0, (size_t)nfix * ncl * n * 32, st));
     const uint64_t sl = poly_len < n ? poly_len : n;               // fixed polynomials have degree < n
     MZK_TRY(ws_acquire(st));
-    MZK_TRY(g_ws.misc.reserve(256));
+    MZK_TRY(g_ws.misc.reserve(512));
     uint32_t* d_c = g_ws.misc.as<uint32_t>();
     const F one = F::one(), scale_n = nf * wn;
     HIP_TRY(hipMemcpyAsync(d_c, wn.l, 32, hipMemcpyHostToDevice, st));
@@ -367,6 +406,15 @@ int32_t pk_build_chunked(PlonkPk& pk, const uint32_t* sel_coeffs, const uint32_t
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipStreamSynchronize(st));                            // d_c + 40 is rewritten for the next class
     }
+    {   // per-point tables in the internal form x * R' (plonk.cuh)
+        const F c32 = from_u64<P>(32);
+        HIP_TRY(hipMemcpyAsync(d_c + 48, c32.l, 32, hipMemcpyHostToDevice, st));
+        const unsigned sg = (unsigned)((ncl * n + PLK_THREADS - 1) / PLK_THREADS);
+        hipLaunchKernelGGL((fr_scale_kernel<P>), dim3(sg), dim3(PLK_THREADS), 0, st, pk.d_xs, ncl * n, d_c + 48);
+        hipLaunchKernelGGL((fr_scale_kernel<P>), dim3(sg), dim3(PLK_THREADS), 0, st, pk.d_inv_den, ncl * n, d_c + 48);
+        if (pk.ultra) hipLaunchKernelGGL((fr_scale_kernel<P>), dim3(sg), dim3(PLK_THREADS), 0, st, pk.d_inv_den_n, ncl * n, d_c + 48);
+        HIP_TRY(hipGetLastError());
+    }
     // gate-domain tables for the grand products (replicated on every rank)
     HIP_TRY(hipMalloc((void**)&pk.d_sigma_n, (size_t)pk.W * n * 32));
     HIP_TRY(hipMalloc((void**)&pk.d_omega_n, n * 32));
@@ -377,7 +425,7 @@ int32_t pk_build_chunked(PlonkPk& pk, const uint32_t* sel_coeffs, const uint32_t
     MZK_TRY(ws_release(st));
     // class evaluations of the fixed polynomials: size-n coset NTTs with offset h_k, all polynomials of a class in one batch
     for (size_t lc = 0; lc < ncl; lc++)
-        MZK_TRY(ntt_dispatch(pk.curve, pk.d_fixed + lc * n * 8, sl, pk.log_n, false, pk.h_cls[pk.cls[lc]], nfix, ncl * n, st));
+        MZK_TRY(ntt_dispatch(pk.curve, pk.d_fixed + lc * n * 8, sl, pk.log_n, false, pk.h_cls[pk.cls[lc]], nfix, ncl * n, st, 1));     // internal form
     MZK_TRY(ntt_dispatch(pk.curve, pk.d_sigma_n, sl, pk.log_n, false, nullptr, pk.W, n, st));
     if (pk.ultra) {
         HIP_TRY(hipMalloc((void**)&pk.d_tab_n, (size_t)5 * n * 32));
@@ -406,21 +454,7 @@ int32_t quotient_chunked_run(const PlonkPk& pk, const uint32_t* d_polys, uint64_
     uint32_t* d_c = work + (size_t)rows * n * 8;
     QuotientArgs a;
     a.m = n; a.fstride = ncl * n; a.ostride = n; a.next_off = 1;
-    std::memcpy(a.k, pk.k, sizeof a.k);
-    std::memcpy(a.zh_inv, pk.zh_inv, sizeof a.zh_inv);
-    F al, a2;
-    std::memcpy(al.l, alpha, 32);
-    a2 = sqr(al);
-    std::memcpy(a.alpha, alpha, 32);
-    std::memcpy(a.alpha2, a2.l, 32);
-    std::memcpy(a.beta, beta, 32);
-    std::memcpy(a.gamma, gamma, 32);
-    if (pk.ultra) {
-        const F a3 = a2 * al;
-        std::memcpy(a.tau, tau, 32);
-        std::memcpy(a.alpha3, a3.l, 32);
-        std::memcpy(a.w_inv, pk.w_inv, 32);
-    }
+    fill_quotient_constants<P>(a, pk, tau, alpha, beta, gamma);
     const unsigned long long fold_threads = n * (unsigned long long)rows;
     for (size_t lc = 0; lc < ncl; lc++) {
         const int k = pk.cls[lc];
@@ -428,7 +462,7 @@ int32_t quotient_chunked_run(const PlonkPk& pk, const uint32_t* d_polys, uint64_
         hipLaunchKernelGGL((plonk_fold_kernel<P>), dim3((unsigned)((fold_threads + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st,
                            d_polys, in_stride, in_len, n, rows, d_c, work);
         HIP_TRY(hipGetLastError());
-        MZK_TRY(ntt_dispatch(pk.curve, work, n, pk.log_n, false, pk.h_cls[k], rows, n, st));
+        MZK_TRY(ntt_dispatch(pk.curve, work, n, pk.log_n, false, pk.h_cls[k], rows, n, st, 1));          // evaluations in the internal form
         a.sel = pk.d_fixed + lc * n * 8;
         a.sig = pk.d_fixed + ((size_t)pk.nsel * ncl + lc) * n * 8;
         a.tab = pk.ultra ? pk.d_fixed + ((size_t)(pk.nsel + pk.W) * ncl + lc) * n * 8 : nullptr;
@@ -444,13 +478,13 @@ int32_t quotient_chunked_run(const PlonkPk& pk, const uint32_t* d_polys, uint64_
         a.zh_class = k;
         const dim3 grid((unsigned)((n + PLK_THREADS - 1) / PLK_THREADS));
         if (pk.ultra) {
-            hipLaunchKernelGGL((plonk_quotient_kernel<P, true>), grid, dim3(PLK_THREADS), 0, st, a);
-            hipLaunchKernelGGL((plonk_quotient_lookup_kernel<P>), grid, dim3(PLK_THREADS), 0, st, a);
+            hipLaunchKernelGGL((plonk_quotient_kernel<typename FxOf<P>::type, true>), grid, dim3(PLK_THREADS), 0, st, a);
+            hipLaunchKernelGGL((plonk_quotient_lookup_kernel<typename FxOf<P>::type>), grid, dim3(PLK_THREADS), 0, st, a);
         } else {
-            hipLaunchKernelGGL((plonk_quotient_kernel<P, false>), grid, dim3(PLK_THREADS), 0, st, a);
+            hipLaunchKernelGGL((plonk_quotient_kernel<typename FxOf<P>::type, false>), grid, dim3(PLK_THREADS), 0, st, a);
         }
         HIP_TRY(hipGetLastError());
-        MZK_TRY(ntt_dispatch(pk.curve, d_out + lc * n * 8, n, pk.log_n, true, pk.h_cls[k], 1, n, st));
+        MZK_TRY(ntt_dispatch(pk.curve, d_out + lc * n * 8, n, pk.log_n, true, pk.h_cls[k], 1, n, st, 2));  // back to the boundary form
     }
     MZK_TRY(ws_release(st));
     return MZK_OK;
