@@ -195,3 +195,34 @@ def test_perm_product_of_a_valid_permutation(gpu, mj, pyref):
     z1 = mj.plonk.compute_prod_permutation_polynomial(pk, beta, gamma, mj.params.random_fr_mont(c, 5 * n, seed=1).reshape(5, n, 4))
     assert fr_from_mont_limbs(c, z1) == [1] + [0] * (n - 1)
     pk.release()
+
+
+def _adversarial_field_values(c, rng, count):
+    """Field elements x whose INTERNAL image x * 2^261 mod r (what the reduced-radix quotient kernels hold, plonk.cuh) has extreme
+    29-bit limbs: r - 1, all eight low limbs at 2^29 - 1 under the largest admissible top limb, 0, 1, and a few random ones."""
+    r = c.r
+    rp_inv = pow(1 << 261, -1, r)
+    low = (1 << 232) - 1
+    extremes = [r - 1, low + (((r >> 232) - 1) << 232), low, 0, 1, (1 << 232), r - 2]
+    return [(extremes[rng.randrange(len(extremes))] if rng.random() < 0.8 else rng.randrange(r)) * rp_inv % r for _ in range(count)]
+
+
+@pytest.mark.parametrize("curve_id", [0, 1])
+def test_quotient_kernel_limb_extremes(gpu, mj, cref, curve_id):
+    """The lazy-reduction bounds of the quotient kernel (plonk.cuh) at their worst case: every operand stream -- selector, sigma,
+    wire, z and public-input EVALUATIONS on the quotient coset, and the challenges -- is drawn from values whose internal limbs
+    are all-ones / modulus-minus-one patterns.  Polynomials of full length 8n interpolate those evaluations."""
+    c = mj.params.CURVES[curve_id]
+    log_n, n = 3, 8
+    m = 8 * n
+    rng = random.Random(4096 + curve_id)
+    g = mj.params.fr_to_mont(c, [c.fr_generator])[0]
+    evals = fr_mont_limbs(c, _adversarial_field_values(c, rng, 25 * m)).reshape(25, m, 4)
+    polys = np.stack([cref.ntt(curve_id, evals[i], log_n + 3, True, g, threads=1) for i in range(25)])       # coset iFFT: coefficients
+    k = _adversarial_field_values(c, rng, 5)
+    a, b, gm = _adversarial_field_values(c, rng, 3)
+    pk = mj.plonk.ProvingKeyDevice.register(c, n, list(polys[:13]), list(polys[13:18]), k)
+    got = mj.plonk.compute_quotient_polynomial(pk, mj.plonk.Challenges(a, b, gm), list(polys[18:23]), polys[23], polys[24])
+    want = cref.plonk_quotient(curve_id, log_n, polys, mj.params.fr_to_mont(c, k), *mj.params.fr_to_mont(c, [a, b, gm]), threads=2)
+    assert np.array_equal(got, want)
+    pk.release()

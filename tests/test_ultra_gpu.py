@@ -162,3 +162,64 @@ def test_ultra_prover_large_domain_identities(gpu, mj, pyref):
     assert (lin_at_zeta + const) % r == 0
     prover.release()
     ck.release()
+
+
+def test_ultra_quotient_kernels_limb_extremes(gpu, mj, cref):
+    """Both UltraPlonk quotient kernels (plonk.cuh, reduced-radix lazy arithmetic) at their worst-case limb patterns, against a
+    big-int evaluation of the closure of prover.rs:605-659 with compute_quotient_plookup_contribution (:773-888) at every point
+    of the quotient coset.  All 35 operand streams are chosen as EVALUATIONS (full-length polynomials interpolate them)."""
+    import torch
+    from test_plonk_gpu import _adversarial_field_values
+    for curve_id in (0, 1):
+        c = mj.params.CURVES[curve_id]
+        r = c.r
+        log_n, n = 2, 4
+        m = 8 * n
+        rng = random.Random(8192 + curve_id)
+        gmont = mj.params.fr_to_mont(c, [c.fr_generator])[0]
+        E = [_adversarial_field_values(c, rng, m) for _ in range(35)]       # 14 sel, 6 sig, 4 tab, 6 wires, z, pi, h1, h2, pl
+        to_poly = lambda vals: cref.ntt(curve_id, fr_mont_limbs(c, vals), log_n + 3, True, gmont, threads=1)
+        polys = [to_poly(v) for v in E]
+        k = _adversarial_field_values(c, rng, 6)
+        tau, alpha, beta, gamma = _adversarial_field_values(c, rng, 4)
+        tabs = {name: polys[20 + i] for i, name in enumerate(mj.plonk.PLOOKUP_TABLE_POLYS)}
+        pk = mj.plonk.ProvingKeyDevice.register(c, n, polys[:14], polys[14:20], k, plookup=tabs)
+        slab = torch.from_numpy(np.stack(polys[24:35]).view(np.int64)).cuda().contiguous()
+        out = torch.empty((m, 4), dtype=torch.int64, device="cuda")
+        mj.plonk.compute_quotient_polynomial_dev(pk, mj.plonk.Challenges(alpha, beta, gamma, tau), slab, m, out)
+        got = out.cpu().numpy().view(np.uint64)
+        # ---- the closure, point by point
+        sel, sig, tab, w = E[:14], E[14:20], E[20:24], E[24:30]
+        z, pi, h1, h2, pl = E[30], E[31], E[32], E[33], E[34]
+        w_m = pow(c.fr_generator, (r - 1) // m, r)
+        w_n_inv = pow(pow(w_m, 8, r), -1, r)
+        zh_inv = [pow((pow(c.fr_generator * pow(w_m, i, r) % r, n, r) - 1) % r, -1, r) for i in range(8)]
+        b1, g1 = (1 + beta) % r, gamma * (1 + beta) % r
+        merged = lambda first, q, ds, a0, a1, a2: (first + q * tau % r * (ds + tau * (a0 + tau * (a1 + tau * a2))) % r) % r
+        t_evals = []
+        for i in range(m):
+            nx = (i + 8) % m
+            x = c.fr_generator * pow(w_m, i, r) % r
+            wi = [w[j][i] for j in range(6)]
+            t = (sel[11][i] + pi[i] + sum(sel[j][i] * wi[j] for j in range(4)) + sel[4][i] * wi[0] * wi[1] + sel[5][i] * wi[2] * wi[3]
+                 + sel[12][i] * wi[0] * wi[1] * wi[2] * wi[3] * wi[4] + sum(sel[6 + j][i] * pow(wi[j], 5, r) for j in range(4)) - sel[10][i] * wi[4]) % r
+            acc1, acc2 = z[i], z[nx]
+            for j in range(6):
+                acc1 = acc1 * (wi[j] + gamma + k[j] * x % r * beta) % r
+                acc2 = acc2 * (wi[j] + gamma + sig[j][i] * beta) % r
+            lag_1 = pow(n * (x - 1) % r, -1, r)
+            lag_n = w_n_inv * pow(n * (x - w_n_inv) % r, -1, r) % r
+            t1 = (t + alpha * (acc1 - acc2)) % r
+            t2 = alpha * alpha % r * (z[i] - 1) % r * lag_1 % r
+            mt = merged(tab[0][i], sel[13][i], tab[2][i], tab[1][i], wi[3], wi[4])
+            mt_next = merged(tab[0][nx], sel[13][nx], tab[2][nx], tab[1][nx], w[3][nx], w[4][nx])
+            ml = merged(wi[5], sel[13][i], tab[3][i], wi[0], wi[1], wi[2])
+            a3 = pow(alpha, 3, r)
+            t2 = (t2 + a3 * (h1[i] - h2[nx]) % r * lag_n + a3 * alpha % r * (pl[i] - 1) % r * lag_1 + a3 * alpha * alpha % r * (pl[i] - 1) % r * lag_n) % r
+            term3 = (x - w_n_inv) * (pl[i] * b1 % r * (gamma + ml) % r * (g1 + mt + beta * mt_next) % r
+                                     - pl[nx] * (g1 + h1[i] + beta * h1[nx]) % r * (g1 + h2[i] + beta * h2[nx]) % r) % r
+            t1 = (t1 + pow(alpha, 6, r) * term3) % r
+            t_evals.append((t1 * zh_inv[i % 8] + t2) % r)
+        want = cref.ntt(curve_id, fr_mont_limbs(c, t_evals), log_n + 3, True, gmont, threads=1)
+        assert np.array_equal(got, want), curve_id
+        pk.release()
