@@ -14,6 +14,7 @@ struct NttPlanDev {
     NttxPlanHost h;
     uint32_t* d_stage[NTT_MAX_PASSES] = {nullptr, nullptr, nullptr, nullptr};
     uint32_t *d_tlo = nullptr, *d_thi = nullptr, *d_flo = nullptr, *d_fhi = nullptr, *d_fone = nullptr;
+    uint32_t* d_tfull[NTT_MAX_PASSES] = {nullptr, nullptr, nullptr, nullptr};
 };
 struct PlanKey {
     int curve, log_n, inverse, scale;
@@ -42,6 +43,7 @@ int32_t get_plan(int curve, int log_n, bool inverse, const uint32_t* coset, int 
     auto pl = std::make_unique<NttPlanDev>();
     nttx_build_plan<X>(pl->h, log_n, inverse, coset, scale);
     for (int k = 0; k < pl->h.n_pass; k++) MZK_TRY(upload_words(&pl->d_stage[k], pl->h.stage_tw[k]));
+    for (int k = 0; k < pl->h.n_pass; k++) MZK_TRY(upload_words(&pl->d_tfull[k], pl->h.t_full[k]));
     MZK_TRY(upload_words(&pl->d_tlo, pl->h.t_lo));
     MZK_TRY(upload_words(&pl->d_thi, pl->h.t_hi));
     MZK_TRY(upload_words(&pl->d_flo, pl->h.f_lo));
@@ -98,6 +100,7 @@ int32_t ntt_dev(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool in
         a.stage_tw = pl->d_stage[k];
         a.t_lo = pl->d_tlo;
         a.t_hi = pl->d_thi;
+        a.t_full = pl->d_tfull[k];
         a.f_lo = pl->d_flo;             // non-null only for an inverse coset transform
         a.f_hi = pl->d_fhi;
         a.f_one = pl->d_fone;
@@ -141,6 +144,7 @@ void ntt_release_plans() {
         NttPlanDev* p = kv.second.get();
         for (auto* d : p->d_stage) if (d) (void)hipFree(d);
         for (auto* d : {p->d_tlo, p->d_thi, p->d_flo, p->d_fhi, p->d_fone}) if (d) (void)hipFree(d);
+        for (auto* d : p->d_tfull) if (d) (void)hipFree(d);
     }
     g_plans.clear();
 }

@@ -37,6 +37,7 @@ struct NttxPassArgs {
     const uint32_t* stage_tw;  // (R-1) entries of NTTX_TW_WORDS words, entry (half-1+j)
     const uint32_t* t_lo;      // inter-pass twiddles, low LB bits of the exponent (R'-form)
     const uint32_t* t_hi;      // high bits
+    const uint32_t* t_full;    // middle passes: the whole table w_N^(P r s), entry (r << log_s) + s  (N / P entries: small); else null
     const uint32_t* f_lo;      // final pass: N^-1 h^-j = f_lo[j & mask] * f_hi[j >> LB]   (inverse coset), else null
     const uint32_t* f_hi;
     const uint32_t* f_one;     // final pass without coset: the single multiplier (R' mod p, or N^-1 R')
@@ -167,8 +168,13 @@ __global__ __launch_bounds__(NTTX_THREADS) void nttx_pass_kernel(NttxPassArgs a)
         const int r = e >> a.log_c;
         const Fx<X> v = fx_norm(ldsx_load<X>(da, db, dc, r * C + c));
         if (!a.is_final) {
-            const unsigned long long ex = ((unsigned long long)r * (c0 + c)) << a.log_p;
-            const Fx<X> tw = fx_mul(twx_load<X>(a.t_lo, ex & ((1ull << a.log_lb) - 1)), twx_load<X>(a.t_hi, ex >> a.log_lb));
+            Fx<X> tw;
+            if (a.t_full) {                                                          // one product instead of two
+                tw = twx_load<X>(a.t_full, ((unsigned long long)r << a.log_s) + c0 + c);
+            } else {
+                const unsigned long long ex = ((unsigned long long)r * (c0 + c)) << a.log_p;
+                tw = fx_mul(twx_load<X>(a.t_lo, ex & ((1ull << a.log_lb) - 1)), twx_load<X>(a.t_hi, ex >> a.log_lb));
+            }
             const unsigned long long g = base + ((unsigned long long)r << a.log_s) + c;
             fx_store_packed<X>(out + g * 8, fx_mul(v, tw));                          // < 1.3p < 2^256: fully carried limbs
         } else {
@@ -191,6 +197,7 @@ struct NttxPlanHost {
     int log_radix[NTT_MAX_PASSES] = {0, 0, 0, 0};
     std::vector<uint32_t> stage_tw[NTT_MAX_PASSES];
     std::vector<uint32_t> t_lo, t_hi, f_lo, f_hi, f_one;
+    std::vector<uint32_t> t_full[NTT_MAX_PASSES];       // middle passes only
 };
 
 // boundary-form field element (x*R) -> twiddle record (x*R' as 9 limbs, padded)
@@ -234,6 +241,24 @@ void nttx_build_plan(NttxPlanHost& pl, int log_n, bool inverse, const uint32_t* 
                 nttx_put<X>(pl.stage_tw[k], (size_t)(half - 1 + j), cur);
                 cur = cur * wm;
             }
+        }
+        log_p += lr;
+    }
+    // Inter-pass twiddles of pass k: w_N^(P_k r s), r < R_k, s < S_k -- the same for every block, so the table has N / P_k
+    // entries.  For the first pass that is N entries (kept two-level: t_lo, t_hi, one extra product per element); for the
+    // middle passes it is N / R_1 or less (<= 3 MB), read through L2: one product per element.
+    log_p = pl.log_radix[0];
+    for (int k = 1; k + 1 < pl.n_pass; k++) {
+        const int lr = pl.log_radix[k];
+        const int log_s = log_n - log_p - lr;
+        const size_t R = (size_t)1 << lr, S = (size_t)1 << log_s;
+        pl.t_full[k].assign(R * S * NTTX_TW_WORDS, 0);
+        const F wp = pow_u64(w_dir, 1ull << log_p);                 // w_N^P
+        F row = F::one();                                           // (w_N^P)^r
+        for (size_t r = 0; r < R; r++) {
+            F cur = F::one();
+            for (size_t sidx = 0; sidx < S; sidx++) { nttx_put<X>(pl.t_full[k], (r << log_s) + sidx, cur); cur = cur * row; }
+            row = row * wp;
         }
         log_p += lr;
     }
