@@ -328,6 +328,22 @@ def main():
         ck2.release()
         del cs, quot
 
+    # ---- secondary: the same proofs driven by the C++ host layer (mpc-jellyfish_amd/host/, g++, C ABI only; no Python in the loop) ----
+    prove_cpp = None
+    if not args.no_plonk and rank == 0 and world == 1:
+        import subprocess
+        binp = os.path.join(ROOT, "mpc-jellyfish_amd", "mzk_prove")
+        prove_cpp = {}
+        for name, argv in (("turbo_bls12_381", ["0", "turbo", str(1 << args.plonk_log_n), "5"]),
+                           ("ultra_bn254", ["1", "ultra", str(1 << (args.ultra_log_n or args.plonk_log_n)), "5"])):
+            try:
+                r = subprocess.run([binp] + argv, capture_output=True, text=True, timeout=600)
+                d = json.loads(r.stdout.strip().splitlines()[-1])
+                d.pop("proof_hex", None)
+                prove_cpp[name] = d
+            except Exception as e:                      # noqa: BLE001  (the binary is optional for the headline)
+                prove_cpp[name] = {"error": repr(e)[:200]}
+
     # ---- CPU baseline: the C oracle ("port" of the ark-ec algorithm) on this host, rank 0 only -------
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
@@ -383,7 +399,7 @@ def main():
                          "note": "integer-ALU bound (381-bit Montgomery mixed adds), not HBM bound: see DESIGN.md"},
             "phases_ms": {"sort": round(sort_ms / max(tot_cnt, 1), 4), "accumulate": round(acc_avg_ms, 4),
                           "reduce": round(red_ms / max(tot_cnt, 1), 4), "device_total": round(tot_ms / max(tot_cnt, 1), 4)},
-            "cpu_baseline": cpu, "ntt": ntt, "plonk_round3": plonk, "batch_commit5": batch, "prove": prove, "prove_sharded": prove_sharded, "prove_ultra_bn254": ultra,
+            "cpu_baseline": cpu, "ntt": ntt, "plonk_round3": plonk, "batch_commit5": batch, "prove": prove, "prove_cpp_host": prove_cpp, "prove_sharded": prove_sharded, "prove_ultra_bn254": ultra,
         }
         print(json.dumps(out), flush=True)
     if world > 1:

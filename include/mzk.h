@@ -212,13 +212,13 @@ MZK_API int32_t mzk_poly_eval_dev(int32_t curve_id, const void* d_coeffs, uint64
  * d_out may be one of the inputs.  scalars_mont: n_terms x 4 limbs, host.  Asynchronous. */
 MZK_API int32_t mzk_poly_lincomb_dev(int32_t curve_id, uint32_t n_terms, const void* const* d_polys, const uint64_t* lens,
                                      const uint64_t* scalars_mont, void* d_out, uint64_t out_len, void* stream);
-/* quotient of p(X) / (X - z), len - 1 coefficients into d_out (remainder dropped, as ark-poly's `/` does at
- * prover.rs:504-506).  d_out must not alias d_poly.  Asynchronous. */
 /* `Prover::mask_polynomial` (prover.rs:463-486) for up to 8 polynomials in one launch: d_polys[i] holds n coefficients in a row
  * of at least n + n_blinders slots; p += (b_0 + b_1 X + ..)(X^n - 1), i.e. p[j] -= b_j and p[n + j] = b_j.  blinders_mont:
  * n_polys x n_blinders x 4 limbs, host (the `DensePolynomial::rand` draws, 1 <= n_blinders <= 4).  Asynchronous. */
 MZK_API int32_t mzk_poly_mask_dev(int32_t curve_id, uint32_t n_polys, void* const* d_polys, uint64_t n, uint32_t n_blinders,
                                   const uint64_t* blinders_mont, void* stream);
+/* quotient of p(X) / (X - z), len - 1 coefficients into d_out (remainder dropped, as ark-poly's `/` does at
+ * prover.rs:504-506).  d_out must not alias d_poly.  Asynchronous. */
 MZK_API int32_t mzk_poly_div_linear_dev(int32_t curve_id, const void* d_poly, uint64_t len, const uint64_t* z_mont, void* d_out, void* stream);
 
 /* ---- device memory helpers for bindings without HIP of their own ---- */
@@ -227,6 +227,11 @@ MZK_API int32_t mzk_dev_free(void* dptr);
 MZK_API int32_t mzk_dev_upload(void* dptr, const void* host, uint64_t bytes);
 MZK_API int32_t mzk_dev_download(void* host, const void* dptr, uint64_t bytes);
 MZK_API int32_t mzk_dev_sync(void);
+/* device-to-device copy, 2-D copy (pitches and width in bytes) and byte fill, asynchronous on `stream`: what a host
+ * orchestrating device-resident rounds needs between kernels (mpc-jellyfish_amd/host/mzk_host.hpp). */
+MZK_API int32_t mzk_dev_copy(void* dst, const void* src, uint64_t bytes, void* stream);
+MZK_API int32_t mzk_dev_copy2d(void* dst, uint64_t dst_pitch, const void* src, uint64_t src_pitch, uint64_t width, uint64_t height, void* stream);
+MZK_API int32_t mzk_dev_memset(void* dptr, int32_t value, uint64_t bytes, void* stream);
 
 /* ---- measurement hooks (bench.py): HIP-event timing of the library's own kernels ---- */
 /* on != 0: every subsequent call brackets its dominant kernels with hipEvents on the launch stream. */

@@ -586,6 +586,27 @@ int32_t mzk_dev_sync(void) {
     HIP_TRY(hipDeviceSynchronize());
     return MZK_OK;
 }
+int32_t mzk_dev_copy(void* dst, const void* src, uint64_t bytes, void* stream) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    if (bytes && (!dst || !src)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    if (bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MZK_OK;
+}
+int32_t mzk_dev_copy2d(void* dst, uint64_t dst_pitch, const void* src, uint64_t src_pitch, uint64_t width, uint64_t height, void* stream) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    if (width && height && (!dst || !src || width > dst_pitch || width > src_pitch)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
+    if (width && height) HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width, height, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MZK_OK;
+}
+int32_t mzk_dev_memset(void* dptr, int32_t value, uint64_t bytes, void* stream) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    if (bytes && !dptr) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    if (bytes) HIP_TRY(hipMemsetAsync(dptr, value, bytes, (hipStream_t)stream));
+    return MZK_OK;
+}
 
 // ---- profiling ---------------------------------------------------------------------------------------
 int32_t mzk_profile_enable(int32_t on) {

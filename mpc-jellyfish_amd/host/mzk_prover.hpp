@@ -1,0 +1,454 @@
+// mzk_prover.hpp -- the reference's bench circuit, PlonkKzgSnark::preprocess and ::prove in C++ above the C ABI
+// (see mzk_host.hpp for the map to the reference).  One instance, TurboPlonk or UltraPlonk.
+#pragma once
+#include <chrono>
+#include <map>
+
+#include "mzk_host.hpp"
+
+namespace mzk_host {
+
+constexpr size_t EL = 32;                                              // bytes per scalar-field element
+
+struct DevBuf {
+    void* p = nullptr;
+    size_t elems = 0;
+    DevBuf() = default;
+    explicit DevBuf(size_t n_elems) { alloc(n_elems); }
+    DevBuf(const DevBuf&) = delete;
+    DevBuf& operator=(const DevBuf&) = delete;
+    DevBuf(DevBuf&& o) noexcept : p(o.p), elems(o.elems) { o.p = nullptr; o.elems = 0; }
+    DevBuf& operator=(DevBuf&& o) noexcept {
+        if (this != &o) { if (p) (void)mzk_dev_free(p); p = o.p; elems = o.elems; o.p = nullptr; o.elems = 0; }
+        return *this;
+    }
+    ~DevBuf() { if (p) (void)mzk_dev_free(p); }
+    void alloc(size_t n_elems) {
+        if (p) (void)mzk_dev_free(p);
+        p = nullptr;
+        elems = n_elems;
+        check(mzk_dev_alloc((n_elems ? n_elems : 1) * EL, &p), "mzk_dev_alloc");
+    }
+    void* at(size_t idx) const { return static_cast<uint8_t*>(p) + idx * EL; }
+};
+
+template <class C>
+struct BenchCircuit {                                                  // what Arithmetization exposes of the finalised circuit
+    using Fr = Fp64<typename C::Fr>;
+    bool ultra = false;
+    int log_n = 0, W = 5, nsel = 13;
+    uint64_t n = 0;
+    std::vector<Fr> k;
+    DevBuf wire_values, selector_values, sigma_values, table_values;   // W x n, nsel x n, W x n, 4 x n (UltraPlonk)
+
+    // plonk/benches/bench.rs:29-46 through PlonkCircuit::new, Circuit::add and finalize_for_arithmetization
+    static BenchCircuit generate(uint64_t num_gates, bool ultra, int range_bit_len = 8) {
+        BenchCircuit cs;
+        cs.ultra = ultra;
+        cs.W = ultra ? 6 : 5;
+        cs.nsel = ultra ? 14 : 13;
+        const uint64_t n_add = num_gates - 10, used = 2 + n_add;
+        const uint64_t need = ultra ? std::max<uint64_t>(used, (1ull << range_bit_len) + 1) : used;
+        cs.log_n = 0;
+        while ((1ull << cs.log_n) < need) cs.log_n++;
+        const uint64_t n = cs.n = 1ull << cs.log_n;
+        const int W = cs.W;
+        // variable on every (wire, row): 0 = zero, 1 = one, 2 + t = output of the t-th addition
+        std::vector<uint32_t> var((size_t)W * n, 0);
+        for (uint64_t t = 0; t < n_add; t++) {
+            const uint64_t row = 2 + t;
+            var[0 * n + row] = t == 0 ? 0 : (uint32_t)(1 + t);            // a: the previous sum (the first one is `zero`)
+            var[1 * n + row] = 1;                                         // b = one
+            var[4 * n + row] = (uint32_t)(2 + t);                         // c
+        }
+        var[4 * n + 1] = 1;                                               // constant gate of `one`
+        const size_t n_vars = 2 + n_add;
+        std::vector<Fr> witness(n_vars);
+        const Fr one = Fr::one();
+        witness[0] = Fr::zero();                                          // 0, 1, then the running sums 1, 2, 3, ...: witness[2 + t] = t + 1
+        witness[1] = one;
+        if (n_vars > 2) witness[2] = one;
+        for (size_t v = 3; v < n_vars; v++) witness[v] = witness[v - 1] + one;
+        std::vector<Fr> buf((size_t)W * n);
+        for (size_t i = 0; i < buf.size(); i++) buf[i] = witness[var[i]];
+        cs.wire_values.alloc(buf.size());
+        check(mzk_dev_upload(cs.wire_values.p, buf.data(), buf.size() * EL), "upload wires");
+        // selectors: AdditionGate q_lc = [1,1,0,0], q_o = 1; ConstantGate q_c = value, q_o = 1; PaddingGate all zero
+        std::vector<Fr> sel((size_t)cs.nsel * n, Fr::zero());
+        for (uint64_t row = 2; row < 2 + n_add; row++) sel[0 * n + row] = sel[1 * n + row] = one;
+        for (uint64_t row = 0; row < 2 + n_add; row++) sel[10 * n + row] = one;
+        sel[11 * n + 1] = one;
+        cs.selector_values.alloc(sel.size());
+        check(mzk_dev_upload(cs.selector_values.p, sel.data(), sel.size() * EL), "upload selectors");
+        // wire permutation (constraint_system.rs:743-778): the occurrences of a variable, in (wire, row) order, form a cycle
+        std::vector<uint32_t> cnt(n_vars + 1, 0);
+        for (uint32_t v : var) cnt[v + 1]++;
+        for (size_t v = 0; v < n_vars; v++) cnt[v + 1] += cnt[v];
+        std::vector<uint32_t> cells(var.size()), fill(cnt.begin(), cnt.end() - 1);
+        for (uint32_t cell = 0; cell < var.size(); cell++) cells[fill[var[cell]]++] = cell;
+        std::vector<uint32_t> perm(var.size());
+        for (size_t v = 0; v < n_vars; v++)
+            for (uint32_t i = cnt[v]; i < cnt[v + 1]; i++) perm[cells[i]] = cells[i + 1 < cnt[v + 1] ? i + 1 : cnt[v]];
+        // extended identity k_i * w^j (:913-931) and sigma = id o perm
+        cs.k = compute_coset_representatives<typename C::Fr>(W, n);
+        const Fr w = root_of_unity<typename C::Fr>(cs.log_n);
+        std::vector<Fr> ext((size_t)W * n);
+        Fr cur = Fr::one();
+        for (uint64_t j = 0; j < n; j++) { ext[j] = cur; cur = cur * w; }
+        for (int i = 1; i < W; i++)
+            for (uint64_t j = 0; j < n; j++) ext[(size_t)i * n + j] = cs.k[i] * ext[j];
+        for (size_t i = 0; i < buf.size(); i++) buf[i] = ext[perm[i]];
+        cs.sigma_values.alloc(buf.size());
+        check(mzk_dev_upload(cs.sigma_values.p, buf.data(), buf.size() * EL), "upload sigma");
+        if (ultra) {
+            std::vector<Fr> tab((size_t)4 * n, Fr::zero());
+            Fr v = Fr::zero();
+            for (uint64_t i = 0; i < (1ull << range_bit_len); i++) { tab[i] = v; v = v + one; }       // compute_range_table (:1423-1438)
+            cs.table_values.alloc(tab.size());
+            check(mzk_dev_upload(cs.table_values.p, tab.data(), tab.size() * EL), "upload tables");
+        }
+        return cs;
+    }
+};
+
+template <class C>
+struct Proof {                                                         // structs.rs:59-84 (+ PlookupProof :208-222)
+    using E = Encoding<C>;
+    using Fr = typename E::Fr;
+    using Affine = typename E::Affine;
+    std::vector<Affine> wires_poly_comms, split_quot_poly_comms, h_poly_comms;
+    Affine prod_perm_poly_comm, opening_proof, shifted_opening_proof, prod_lookup_poly_comm;
+    std::vector<Fr> wires_evals, wire_sigma_evals, plookup_evals;      // plookup_evals in the field order of PlookupEvaluations (:496-541)
+    Fr perm_next_eval;
+    bool has_plookup = false;
+
+    std::vector<uint8_t> serialize_compressed() const {
+        std::vector<uint8_t> out;
+        auto u64le = [&](uint64_t v) { for (int i = 0; i < 8; i++) out.push_back((uint8_t)(v >> (8 * i))); };
+        auto g1 = [&](const Affine& p) { uint8_t b[48]; E::g1_bytes(p, b); out.insert(out.end(), b, b + C::G1_BYTES); };
+        auto fr = [&](const Fr& v) { uint8_t b[32]; E::fr_bytes(v, b); out.insert(out.end(), b, b + 32); };
+        u64le(wires_poly_comms.size()); for (auto& p : wires_poly_comms) g1(p);
+        g1(prod_perm_poly_comm);
+        u64le(split_quot_poly_comms.size()); for (auto& p : split_quot_poly_comms) g1(p);
+        g1(opening_proof); g1(shifted_opening_proof);
+        u64le(wires_evals.size()); for (auto& v : wires_evals) fr(v);
+        u64le(wire_sigma_evals.size()); for (auto& v : wire_sigma_evals) fr(v);
+        fr(perm_next_eval);
+        out.push_back(has_plookup ? 1 : 0);
+        if (has_plookup) {
+            u64le(h_poly_comms.size()); for (auto& p : h_poly_comms) g1(p);
+            g1(prod_lookup_poly_comm);
+            for (auto& v : plookup_evals) fr(v);
+        }
+        return out;
+    }
+};
+
+// indices into Proof::plookup_evals (declaration order of PlookupEvaluations)
+enum PlookupEval { RANGE_TABLE, KEY_TABLE, TABLE_DOM_SEP, Q_DOM_SEP, H_1, Q_LOOKUP, PROD_NEXT, RANGE_TABLE_NEXT, KEY_TABLE_NEXT, TABLE_DOM_SEP_NEXT,
+                   H_1_NEXT, H_2_NEXT, Q_LOOKUP_NEXT, W_3_NEXT, W_4_NEXT, N_PLOOKUP_EVALS };
+
+template <class C>
+struct Prover {                                                        // ProvingKey on the device + Prover of prover.rs
+    using E = Encoding<C>;
+    using Fr = typename E::Fr;
+    using Affine = typename E::Affine;
+    using FrP = typename C::Fr;
+    static constexpr int QL = E::QL;
+
+    bool ultra;
+    int log_n, W, nsel, rows;
+    uint64_t n, m;
+    std::vector<Fr> k;
+    uint64_t srs = 0, pk = 0;
+    DevBuf fixed;                                                      // (nsel + W [+ 4]) x n coefficient forms
+    DevBuf slab, quot, keep, coeff, split, lin, batch, opening, shifted, hh, table, lookup, sorted, tmp;
+    std::vector<Affine> selector_comms, sigma_comms;
+    std::map<std::string, double> timings_ms;
+    Fr w_n, gen;
+
+    // PlonkKzgSnark::preprocess (snark.rs:529-617)
+    Prover(uint64_t srs_handle, const BenchCircuit<C>& cs)
+        : ultra(cs.ultra), log_n(cs.log_n), W(cs.W), nsel(cs.nsel), rows(cs.W + 2 + (cs.ultra ? 3 : 0)), n(cs.n), m(8 * cs.n), k(cs.k), srs(srs_handle) {
+        uint64_t srs_len = 0;
+        check(mzk_srs_len(srs, &srs_len), "mzk_srs_len");
+        if (srs_len < n + 3) throw std::runtime_error("SRS too small: need domain size + 3 powers (srs.rs:88)");
+        const int nfix = nsel + W + (ultra ? 4 : 0);
+        fixed.alloc((size_t)nfix * n);
+        check(mzk_dev_copy(fixed.p, cs.selector_values.p, (size_t)nsel * n * EL, nullptr), "copy");
+        check(mzk_dev_copy(fixed.at((size_t)nsel * n), cs.sigma_values.p, (size_t)W * n * EL, nullptr), "copy");
+        if (ultra) check(mzk_dev_copy(fixed.at((size_t)(nsel + W) * n), cs.table_values.p, (size_t)4 * n * EL, nullptr), "copy");
+        check(mzk_ntt_dev(C::ID, fixed.p, n, log_n, 1, nullptr, nfix, n, nullptr), "mzk_ntt_dev");        // selector / sigma / table polynomials
+        std::vector<uint64_t> host((size_t)nfix * n * 4);
+        check(mzk_dev_download(host.data(), fixed.p, host.size() * 8), "download");
+        std::vector<uint64_t> kk((size_t)W * 4);
+        for (int i = 0; i < W; i++) std::memcpy(&kk[4 * i], k[i].l, 32);
+        const uint64_t* sel = host.data();
+        const uint64_t* sig = sel + (size_t)nsel * n * 4;
+        if (ultra) check(mzk_plonk_pk_register_ultra(C::ID, log_n, sel, sig, sig + (size_t)W * n * 4, n, kk.data(), &pk), "mzk_plonk_pk_register_ultra");
+        else check(mzk_plonk_pk_register(C::ID, log_n, W, sel, sig, n, kk.data(), &pk), "mzk_plonk_pk_register");
+        slab.alloc((size_t)rows * m); quot.alloc(m); keep.alloc((size_t)rows * (n + 3)); coeff.alloc((size_t)(W + 1) * n);
+        split.alloc((size_t)W * (n + 3)); lin.alloc(n + 3); batch.alloc(n + 3); opening.alloc(n + 3); shifted.alloc(n + 3); tmp.alloc(64);
+        if (ultra) { hh.alloc(2 * n); table.alloc(n); lookup.alloc(n); sorted.alloc(2 * n); }
+        w_n = root_of_unity<FrP>(log_n);
+        gen = Fr::from_words(FrP::GENERATOR);
+        // verifying-key commitments (snark.rs:562-594)
+        std::vector<const void*> ptrs;
+        std::vector<uint64_t> lens;
+        for (int i = 0; i < nsel + W; i++) { ptrs.push_back(fixed.at((size_t)i * n)); lens.push_back(n); }
+        auto comms = commit(ptrs, lens);
+        selector_comms.assign(comms.begin(), comms.begin() + nsel);
+        sigma_comms.assign(comms.begin() + nsel, comms.end());
+    }
+    ~Prover() { if (pk) (void)mzk_plonk_pk_release(pk); }
+
+    // UnivariateKzgPCS::batch_commit (mod.rs:119-131) on device-resident coefficient vectors
+    std::vector<Affine> commit(const std::vector<const void*>& polys, const std::vector<uint64_t>& lens) {
+        const uint32_t kpolys = (uint32_t)polys.size();
+        std::vector<uint64_t> xyz((size_t)kpolys * 3 * QL), xy((size_t)kpolys * 2 * QL);
+        check(mzk_msm_batch_dev(srs, kpolys, polys.data(), lens.data(), nullptr, 1, xyz.data(), nullptr), "mzk_msm_batch_dev");
+        check(mzk_g1_jacobian_to_affine(C::ID, xyz.data(), kpolys, xy.data()), "mzk_g1_jacobian_to_affine");
+        std::vector<Affine> out(kpolys);
+        for (uint32_t i = 0; i < kpolys; i++) std::memcpy(out[i].data(), &xy[(size_t)i * 2 * QL], sizeof(Affine));
+        return out;
+    }
+    std::vector<Fr> evaluate(const void* d, uint64_t len, uint32_t batch_n, uint64_t stride, const Fr& x) {
+        std::vector<Fr> out(batch_n);
+        check(mzk_poly_eval_dev(C::ID, d, len, batch_n, stride, x.l, reinterpret_cast<uint64_t*>(out.data()), nullptr), "mzk_poly_eval_dev");
+        return out;
+    }
+    struct Term { Fr s; const void* p; uint64_t len; };
+    void lincomb(const std::vector<Term>& terms, void* out, uint64_t out_len) {
+        std::vector<const void*> ptrs;
+        std::vector<uint64_t> lens, sc;
+        for (auto& t : terms) { ptrs.push_back(t.p); lens.push_back(t.len); for (int i = 0; i < 4; i++) sc.push_back(t.s.l[i]); }
+        check(mzk_poly_lincomb_dev(C::ID, (uint32_t)terms.size(), ptrs.data(), lens.data(), sc.data(), out, out_len, nullptr), "mzk_poly_lincomb_dev");
+    }
+    void mask(const std::vector<int>& slab_rows, const std::vector<std::vector<Fr>>& blinders) {     // prover.rs:463-486
+        std::vector<void*> ptrs;
+        std::vector<uint64_t> b;
+        for (size_t i = 0; i < slab_rows.size(); i++) {
+            ptrs.push_back(slab.at((size_t)slab_rows[i] * m));
+            for (auto& v : blinders[i]) for (int q = 0; q < 4; q++) b.push_back(v.l[q]);
+        }
+        check(mzk_poly_mask_dev(C::ID, (uint32_t)ptrs.size(), ptrs.data(), n, (uint32_t)blinders[0].size(), b.data(), nullptr), "mzk_poly_mask_dev");
+    }
+    struct Tick {
+        std::map<std::string, double>& t; bool on; std::chrono::steady_clock::time_point t0;
+        Tick(std::map<std::string, double>& tt, bool o) : t(tt), on(o) { reset(); }
+        void reset() { if (on) { (void)mzk_dev_sync(); t0 = std::chrono::steady_clock::now(); } }
+        void mark(const char* name) { if (on) { (void)mzk_dev_sync(); t[name] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); reset(); } }
+    };
+
+    // PlonkKzgSnark::prove (snark.rs:624-651) -> batch_prove_internal (:201-469), one instance
+    Proof<C> prove(ChaChaRng& rng, const BenchCircuit<C>& cs, bool profile = false) {
+        Tick tick(timings_ms, profile);
+        // blinders: every DensePolynomial::rand / F::rand of the proof in draw order (prover.rs:79-83, 113-114, 133-138, 169-180, 947-955)
+        auto draw = [&](int cnt) { std::vector<Fr> v; for (int i = 0; i < cnt; i++) v.push_back(fr_rand<FrP>(rng)); return v; };
+        std::vector<std::vector<Fr>> b_wires, b_h;
+        for (int i = 0; i < W; i++) b_wires.push_back(draw(2));
+        if (ultra) { b_h.push_back(draw(3)); b_h.push_back(draw(3)); }
+        const std::vector<Fr> b_z = draw(3), b_pl = ultra ? draw(3) : std::vector<Fr>{}, b_quot = draw(W - 1);
+        // transcript (snark.rs:263-270)
+        StandardTranscript<C> tr;
+        tr.append_u32("field size in bits", (uint32_t)FrP::BITS);
+        tr.append_u64("domain size", n);
+        tr.append_u64("input size", 0);
+        for (auto& ki : k) tr.append_fr("wire subsets separators", ki);
+        for (auto& cm : selector_comms) tr.append_commitment("selector commitments", cm);
+        for (auto& cm : sigma_comms) tr.append_commitment("sigma commitments", cm);
+        Proof<C> proof;
+        proof.has_plookup = ultra;
+        const int Z = W, PI = W + 1, H1 = W + 2, PL = W + 4;
+        auto row = [&](int r) { return slab.at((size_t)r * m); };
+        auto krow = [&](int r) { return keep.at((size_t)r * (n + 3)); };
+        auto fix = [&](int r) { return fixed.at((size_t)r * n); };
+        const int sigma0 = nsel, tab0 = nsel + W;
+        // ---- round 1 (prover.rs:72-87)
+        check(mzk_dev_copy(coeff.p, cs.wire_values.p, (size_t)W * n * EL, nullptr), "copy");
+        check(mzk_dev_memset(coeff.at((size_t)W * n), 0, n * EL, nullptr), "memset");                        // the bench circuit has no public input
+        check(mzk_ntt_dev(C::ID, coeff.p, n, log_n, 1, nullptr, W + 1, n, nullptr), "mzk_ntt_dev");
+        for (int r = 0; r < rows; r++) check(mzk_dev_memset(static_cast<uint8_t*>(row(r)) + n * EL, 0, 3 * EL, nullptr), "memset");
+        check(mzk_dev_copy2d(slab.p, m * EL, coeff.p, n * EL, n * EL, W, nullptr), "copy2d");
+        check(mzk_dev_copy(row(PI), coeff.at((size_t)W * n), n * EL, nullptr), "copy");
+        { std::vector<int> rs; for (int i = 0; i < W; i++) rs.push_back(i); mask(rs, b_wires); }
+        tick.mark("r1_ntt_mask");
+        {
+            std::vector<const void*> p; std::vector<uint64_t> l;
+            for (int i = 0; i < W; i++) { p.push_back(row(i)); l.push_back(n + 2); }
+            proof.wires_poly_comms = commit(p, l);
+        }
+        tick.mark("r1_commit");
+        for (auto& cm : proof.wires_poly_comms) tr.append_commitment("witness_poly_comms", cm);
+        const Fr tau = tr.get_and_append_challenge("tau");
+        // ---- round 1.5 (prover.rs:89-118)
+        if (ultra) {
+            check(mzk_plookup_sorted_vec_dev(pk, cs.wire_values.p, tau.l, table.p, lookup.p, sorted.p, nullptr), "mzk_plookup_sorted_vec_dev");
+            check(mzk_dev_copy(hh.p, sorted.p, n * EL, nullptr), "copy");
+            check(mzk_dev_copy(hh.at(n), sorted.at(n - 1), n * EL, nullptr), "copy");
+            check(mzk_ntt_dev(C::ID, hh.p, n, log_n, 1, nullptr, 2, n, nullptr), "mzk_ntt_dev");
+            check(mzk_dev_copy2d(row(H1), m * EL, hh.p, n * EL, n * EL, 2, nullptr), "copy2d");
+            mask({H1, H1 + 1}, b_h);
+            tick.mark("r1_5_sorted_vec");
+            proof.h_poly_comms = commit({row(H1), row(H1 + 1)}, {n + 3, n + 3});
+            tick.mark("r1_5_commit");
+            for (auto& cm : proof.h_poly_comms) tr.append_commitment("h_poly_comms", cm);
+        }
+        // ---- round 2 (prover.rs:125-141)
+        const Fr beta = tr.get_and_append_challenge("beta"), gamma = tr.get_and_append_challenge("gamma");
+        check(mzk_plonk_perm_product_dev(pk, cs.wire_values.p, beta.l, gamma.l, coeff.p, nullptr), "mzk_plonk_perm_product_dev");
+        check(mzk_dev_copy(row(Z), coeff.p, n * EL, nullptr), "copy");
+        mask({Z}, {b_z});
+        tick.mark("r2_product");
+        proof.prod_perm_poly_comm = commit({row(Z)}, {n + 3})[0];
+        tick.mark("r2_commit");
+        tr.append_commitment("perm_poly_comms", proof.prod_perm_poly_comm);
+        // ---- round 2.5 (prover.rs:143-183)
+        if (ultra) {
+            check(mzk_plookup_product_dev(pk, table.p, lookup.p, sorted.p, beta.l, gamma.l, coeff.p, nullptr), "mzk_plookup_product_dev");
+            check(mzk_dev_copy(row(PL), coeff.p, n * EL, nullptr), "copy");
+            mask({PL}, {b_pl});
+            tick.mark("r2_5_product");
+            proof.prod_lookup_poly_comm = commit({row(PL)}, {n + 3})[0];
+            tick.mark("r2_5_commit");
+            tr.append_commitment("plookup_poly_comms", proof.prod_lookup_poly_comm);
+        }
+        // ---- round 3 (prover.rs:192-209, 512-673, 902-960)
+        const Fr alpha = tr.get_and_append_challenge("alpha");
+        check(mzk_dev_copy2d(keep.p, (n + 3) * EL, slab.p, m * EL, (n + 3) * EL, rows, nullptr), "copy2d");   // coefficient forms survive the in-place coset NTT
+        if (ultra) check(mzk_plonk_quotient_ultra_dev(pk, slab.p, n + 3, tau.l, alpha.l, beta.l, gamma.l, quot.p, nullptr), "mzk_plonk_quotient_ultra_dev");
+        else check(mzk_plonk_quotient_dev(pk, slab.p, n + 3, alpha.l, beta.l, gamma.l, quot.p, nullptr), "mzk_plonk_quotient_dev");
+        tick.mark("r3_quotient");
+        const uint64_t expected = (uint64_t)W * (n + 1) + 2;                                                  // quotient_polynomial_degree
+        check(mzk_dev_memset(split.p, 0, (size_t)W * (n + 3) * EL, nullptr), "memset");
+        std::vector<uint64_t> split_len(W);
+        Fr last = Fr::zero();
+        for (int i = 0; i < W; i++) {
+            const uint64_t lo = (uint64_t)i * (n + 2), hi = i < W - 1 ? lo + n + 2 : expected + 1;
+            void* p = split.at((size_t)i * (n + 3));
+            check(mzk_dev_copy(p, quot.at(lo), (hi - lo) * EL, nullptr), "copy");
+            if (i < W - 1) check(mzk_dev_upload(static_cast<uint8_t*>(p) + (n + 2) * EL, b_quot[i].l, EL), "upload");
+            if (i > 0) {                                                                                      // t_i[0] -= b_{i-1}
+                const Fr negl = mzk::neg(last);
+                check(mzk_dev_upload(tmp.p, negl.l, EL), "upload");
+                lincomb({{Fr::one(), p, 1}, {Fr::one(), tmp.p, 1}}, p, 1);
+            }
+            if (i < W - 1) last = b_quot[i];
+            split_len[i] = i < W - 1 ? n + 3 : hi - lo;
+        }
+        tick.mark("r3_split");
+        {
+            std::vector<const void*> p;
+            for (int i = 0; i < W; i++) p.push_back(split.at((size_t)i * (n + 3)));
+            proof.split_quot_poly_comms = commit(p, split_len);
+        }
+        tick.mark("r3_commit");
+        for (auto& cm : proof.split_quot_poly_comms) tr.append_commitment("quot_poly_comms", cm);
+        // ---- round 4 (prover.rs:216-299)
+        const Fr zeta = tr.get_and_append_challenge("zeta"), zeta_w = zeta * w_n;
+        proof.wires_evals = evaluate(keep.p, n + 2, W, n + 3, zeta);
+        proof.wire_sigma_evals = evaluate(fix(sigma0), n, W - 1, n, zeta);
+        proof.perm_next_eval = evaluate(krow(Z), n + 3, 1, n + 3, zeta_w)[0];
+        for (auto& v : proof.wires_evals) tr.append_fr("wire_evals", v);
+        for (auto& v : proof.wire_sigma_evals) tr.append_fr("wire_sigma_evals", v);
+        tr.append_fr("perm_next_eval", proof.perm_next_eval);
+        std::vector<Fr>& pe = proof.plookup_evals;
+        if (ultra) {
+            pe.assign(N_PLOOKUP_EVALS, Fr::zero());
+            const auto at_zeta = evaluate(fix(tab0), n, 4, n, zeta);                                           // range, key, table_dom_sep, q_dom_sep
+            const auto at_next = evaluate(fix(tab0), n, 3, n, zeta_w);
+            pe[RANGE_TABLE] = at_zeta[0]; pe[KEY_TABLE] = at_zeta[1]; pe[TABLE_DOM_SEP] = at_zeta[2]; pe[Q_DOM_SEP] = at_zeta[3];
+            pe[RANGE_TABLE_NEXT] = at_next[0]; pe[KEY_TABLE_NEXT] = at_next[1]; pe[TABLE_DOM_SEP_NEXT] = at_next[2];
+            pe[H_1] = evaluate(krow(H1), n + 3, 1, n + 3, zeta)[0];
+            pe[Q_LOOKUP] = evaluate(fix(13), n, 1, n, zeta)[0];
+            pe[Q_LOOKUP_NEXT] = evaluate(fix(13), n, 1, n, zeta_w)[0];
+            pe[PROD_NEXT] = evaluate(krow(PL), n + 3, 1, n + 3, zeta_w)[0];
+            const auto hn = evaluate(krow(H1), n + 3, 2, n + 3, zeta_w);
+            pe[H_1_NEXT] = hn[0]; pe[H_2_NEXT] = hn[1];
+            const auto wn = evaluate(krow(3), n + 2, 2, n + 3, zeta_w);
+            pe[W_3_NEXT] = wn[0]; pe[W_4_NEXT] = wn[1];
+            tr.append_fr("lookup_table_eval", pe[RANGE_TABLE]); tr.append_fr("h_1_eval", pe[H_1]); tr.append_fr("prod_next_eval", pe[PROD_NEXT]);
+            tr.append_fr("lookup_table_next_eval", pe[RANGE_TABLE_NEXT]); tr.append_fr("h_1_next_eval", pe[H_1_NEXT]);
+            tr.append_fr("h_2_next_eval", pe[H_2_NEXT]);                                                      // transcript/mod.rs:165-202
+        }
+        tick.mark("r4_evals");
+        // ---- round 5: linearisation polynomial (prover.rs:302-358, 963-1112) and opening proofs (:362-460, 490-509)
+        const Fr v = tr.get_and_append_challenge("v");
+        const std::vector<Fr>& we = proof.wires_evals;
+        auto pow5 = [](const Fr& x) { const Fr x2 = x * x; return x2 * x2 * x; };
+        std::vector<Term> terms;
+        for (int j = 0; j < 4; j++) terms.push_back({we[j], fix(j), n});
+        terms.push_back({we[0] * we[1], fix(4), n});
+        terms.push_back({we[2] * we[3], fix(5), n});
+        for (int j = 0; j < 4; j++) terms.push_back({pow5(we[j]), fix(6 + j), n});
+        terms.push_back({we[0] * we[1] * we[2] * we[3] * we[4], fix(12), n});
+        terms.push_back({mzk::neg(we[4]), fix(10), n});
+        terms.push_back({Fr::one(), fix(11), n});
+        const Fr one = Fr::one(), nf = from_u64<FrP>(n);
+        const Fr vanish = pow_u64(zeta, n) - one;
+        const Fr lagrange_1 = vanish * inv(nf * (zeta - one));
+        Fr cf = alpha;
+        for (int j = 0; j < W; j++) cf = cf * (we[j] + beta * k[j] * zeta + gamma);
+        terms.push_back({cf + alpha * alpha * lagrange_1, krow(Z), n + 3});
+        cf = alpha * beta * proof.perm_next_eval;
+        for (int j = 0; j < W - 1; j++) cf = cf * (we[j] + beta * proof.wire_sigma_evals[j] + gamma);
+        terms.push_back({mzk::neg(cf), fix(sigma0 + W - 1), n});
+        if (ultra) {                                                                                          // compute_lin_poly_plookup_contribution
+            auto em = [&](const Fr& first, const Fr& ql, const Fr& ds, const Fr& a0, const Fr& a1, const Fr& a2) {
+                return first + ql * tau * (ds + tau * (a0 + tau * (a1 + tau * a2)));
+            };
+            const Fr mt = em(pe[RANGE_TABLE], pe[Q_LOOKUP], pe[TABLE_DOM_SEP], pe[KEY_TABLE], we[3], we[4]);
+            const Fr mt_next = em(pe[RANGE_TABLE_NEXT], pe[Q_LOOKUP_NEXT], pe[TABLE_DOM_SEP_NEXT], pe[KEY_TABLE_NEXT], pe[W_3_NEXT], pe[W_4_NEXT]);
+            const Fr ml = em(we[5], pe[Q_LOOKUP], pe[Q_DOM_SEP], we[0], we[1], we[2]);
+            const Fr w_inv = inv(w_n);
+            const Fr lagrange_n = vanish * w_inv * inv(nf * (zeta - w_inv));
+            const Fr a2 = alpha * alpha, a4 = a2 * a2, a5 = a4 * alpha, a6 = a4 * a2;
+            const Fr b1 = one + beta, g1 = gamma * b1, zmg = zeta - w_inv;
+            terms.push_back({a4 * lagrange_1 + a5 * lagrange_n + a6 * zmg * b1 * (gamma + ml) * (g1 + mt + beta * mt_next), krow(PL), n + 3});
+            terms.push_back({mzk::neg(a6 * zmg * pe[PROD_NEXT] * (g1 + pe[H_1] + beta * pe[H_1_NEXT])), krow(H1 + 1), n + 3});
+        }
+        const Fr zeta_n2 = (vanish + one) * zeta * zeta;
+        cf = one;
+        for (int i = 0; i < W; i++) {
+            terms.push_back({mzk::neg(vanish) * cf, split.at((size_t)i * (n + 3)), split_len[i]});
+            cf = cf * zeta_n2;
+        }
+        lincomb(terms, lin.p, n + 3);
+        auto batched = [&](const std::vector<Term>& polys, const Fr& point, DevBuf& out) {                     // prover.rs:490-509
+            std::vector<Term> t;
+            Fr c = one;
+            for (auto& p : polys) { t.push_back({c, p.p, p.len}); c = c * v; }
+            lincomb(t, batch.p, n + 3);
+            check(mzk_poly_div_linear_dev(C::ID, batch.p, n + 3, point.l, out.p, nullptr), "mzk_poly_div_linear_dev");
+        };
+        std::vector<Term> open_polys{{one, lin.p, n + 3}}, shifted_polys{{one, krow(Z), n + 3}};
+        for (int i = 0; i < W; i++) open_polys.push_back({one, krow(i), n + 2});
+        for (int i = 0; i < W - 1; i++) open_polys.push_back({one, fix(sigma0 + i), n});
+        if (ultra) {                                                                                          // prover.rs:421-460
+            for (const void* p : {(const void*)fix(tab0), (const void*)fix(tab0 + 1)}) open_polys.push_back({one, p, n});
+            open_polys.push_back({one, krow(H1), n + 3});
+            open_polys.push_back({one, fix(13), n});
+            open_polys.push_back({one, fix(tab0 + 2), n});
+            open_polys.push_back({one, fix(tab0 + 3), n});
+            shifted_polys.push_back({one, krow(PL), n + 3});
+            shifted_polys.push_back({one, fix(tab0), n});
+            shifted_polys.push_back({one, fix(tab0 + 1), n});
+            shifted_polys.push_back({one, krow(H1), n + 3});
+            shifted_polys.push_back({one, krow(H1 + 1), n + 3});
+            shifted_polys.push_back({one, fix(13), n});
+            shifted_polys.push_back({one, krow(3), n + 2});
+            shifted_polys.push_back({one, krow(4), n + 2});
+            shifted_polys.push_back({one, fix(tab0 + 2), n});
+        }
+        batched(open_polys, zeta, opening);
+        batched(shifted_polys, zeta_w, shifted);
+        tick.mark("r5_polys");
+        const auto oc = commit({opening.p, shifted.p}, {n + 2, n + 2});
+        proof.opening_proof = oc[0];
+        proof.shifted_opening_proof = oc[1];
+        tick.mark("r5_commit");
+        return proof;
+    }
+};
+
+}  // namespace mzk_host

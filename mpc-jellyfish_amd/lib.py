@@ -62,6 +62,9 @@ _SIGS = {
     "mzk_dev_upload": [C.c_void_p, C.c_void_p, C.c_uint64],
     "mzk_dev_download": [C.c_void_p, C.c_void_p, C.c_uint64],
     "mzk_dev_sync": [],
+    "mzk_dev_copy": [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p],
+    "mzk_dev_copy2d": [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p],
+    "mzk_dev_memset": [C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p],
     "mzk_profile_enable": [C.c_int32],
     "mzk_profile_get": [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
     "mzk_profile_reset": [],

@@ -26,3 +26,5 @@ def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
     cb = d["cpu_baseline"]
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(cb) and cb["kind"] in ("port", "reference") and cb["matches_gpu"] is True
     assert d["prove"]["quotient_degree_ok"] is True and d["prove_ultra_bn254"]["quotient_degree_ok"] is True
+    assert d["prove_cpp_host"]["turbo_bls12_381"]["proof_bytes"] == d["prove"]["proof_bytes"]
+    assert d["prove_cpp_host"]["ultra_bn254"]["proof_bytes"] == d["prove_ultra_bn254"]["proof_bytes"]
