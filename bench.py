@@ -334,12 +334,17 @@ def main():
         import subprocess
         binp = os.path.join(ROOT, "mpc-jellyfish_amd", "mzk_prove")
         prove_cpp = {}
+        # ... and at the reference's own bench size (NUM_GATES_LARGE = 32768, plonk/benches/bench.rs:26), whose published CPU figures
+        # are 29 591 (TurboPlonk, BLS12-381) and 33 701 (UltraPlonk, BN254) ns per constraint on 24 threads of a 5900X (bench.md)
         for name, argv in (("turbo_bls12_381", ["0", "turbo", str(1 << args.plonk_log_n), "5"]),
-                           ("ultra_bn254", ["1", "ultra", str(1 << (args.ultra_log_n or args.plonk_log_n)), "5"])):
+                           ("ultra_bn254", ["1", "ultra", str(1 << (args.ultra_log_n or args.plonk_log_n)), "5"]),
+                           ("turbo_bls12_381_32768_gates", ["0", "turbo", "32768", "20"]),
+                           ("ultra_bn254_32768_gates", ["1", "ultra", "32768", "20"])):
             try:
                 r = subprocess.run([binp] + argv, capture_output=True, text=True, timeout=600)
                 d = json.loads(r.stdout.strip().splitlines()[-1])
                 d.pop("proof_hex", None)
+                d["ns_per_gate"] = round(d["prove_ms"] * 1e6 / d["num_gates"], 1)
                 prove_cpp[name] = d
             except Exception as e:                      # noqa: BLE001  (the binary is optional for the headline)
                 prove_cpp[name] = {"error": repr(e)[:200]}
