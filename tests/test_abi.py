@@ -69,3 +69,18 @@ def test_host_encodings(mj, pyref):
         assert rnd.shape == (5000, 4) and all(P.limbs_to_int(row) < c.r for row in rnd[:200])
         assert np.array_equal(rnd, P.random_fr_mont(c, 5000, seed=3))
         assert len({bytes(r) for r in rnd}) == 5000
+
+
+def test_cpp_host_layer_builds_and_refuses_to_run_without_a_gpu(mj):
+    """mpc-jellyfish_amd/host/ (C++ above the C ABI) compiles with g++ against include/mzk.h, and -- like everything else in
+    the product -- has no CPU path: without a device it exits with the library's error."""
+    import subprocess
+    import torch
+    host = os.path.join(ROOT, "mpc-jellyfish_amd", "host")
+    subprocess.check_call(["make", "-C", host, "-s"])
+    binp = os.path.join(ROOT, "mpc-jellyfish_amd", "mzk_prove")
+    assert os.path.exists(binp)
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    r = subprocess.run([binp, "0", "turbo", "32"], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 1 and "no HIP device" in r.stderr
