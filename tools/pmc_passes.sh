@@ -9,4 +9,6 @@ rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYC
 rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -d $R/gpurun_out/$TAG/p2 -- python3 bench.py $ARGS > gpurun_out/$TAG/p2.log 2>&1
 rocprofv3 --kernel-trace --pmc WRITE_SIZE --output-format csv -d $R/gpurun_out/$TAG/p3 -- python3 bench.py $ARGS > gpurun_out/$TAG/p3.log 2>&1
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/$TAG/stats -- python3 bench.py --steps 5 --warmup 1 --no-cpu-baseline > gpurun_out/$TAG/stats.json 2> gpurun_out/$TAG/stats.log
+# bench.py spawns mzk_prove (the C++ host) for its prove legs: the stats directory holds one *_kernel_stats.csv per process, the
+# first (lowest pid) is bench.py itself
 find gpurun_out/$TAG -name "*.csv" | wc -l
