@@ -376,14 +376,18 @@ int32_t srs_generate(const uint32_t* beta_canon, uint64_t n, uint32_t* d_out) {
     return MZK_OK;
 }
 
+// n Jacobian points -> affine on the host (`normalize_batch`): ONE Fermat inversion for all of them (Montgomery's trick)
 template <class FQ>
-void jac_to_affine_host(const uint64_t* xyz, uint64_t* xy) {
+void jac_to_affine_host(const uint64_t* xyz, uint64_t n, uint64_t* xy) {
     using F = Fp64<FQ>;
     constexpr int L = FQ::N / 2;
-    F X = F::from_words((const uint32_t*)xyz), Y = F::from_words((const uint32_t*)(xyz + L)), Z = F::from_words((const uint32_t*)(xyz + 2 * L));
-    if (Z.is_zero()) { std::memset(xy, 0, 2 * L * 8); return; }
-    // Z^-1 by Fermat on the host
-    F e = Z, acc = F::one();
+    std::vector<F> pref(n + 1);
+    pref[0] = F::one();
+    for (uint64_t i = 0; i < n; i++) {
+        const F Z = F::from_words((const uint32_t*)(xyz + i * 3 * L + 2 * L));
+        pref[i + 1] = Z.is_zero() ? pref[i] : pref[i] * Z;
+    }
+    F e = pref[n], acc = F::one();                 // (prod Z)^-1 by Fermat
     uint64_t ex[L];
     for (int i = 0; i < L; i++) ex[i] = F::mod(i);
     ex[0] -= 2;                                   // p - 2 (p odd and > 2: no borrow)
@@ -392,10 +396,18 @@ void jac_to_affine_host(const uint64_t* xyz, uint64_t* xy) {
             if ((ex[i] >> b) & 1) acc = acc * e;
             e = e * e;
         }
-    F zi2 = acc * acc;
-    F x = X * zi2, y = Y * zi2 * acc;
-    x.to_words((uint32_t*)xy);
-    y.to_words((uint32_t*)(xy + L));
+    for (uint64_t i = n; i-- > 0;) {
+        const uint64_t* p = xyz + i * 3 * L;
+        uint64_t* o = xy + i * 2 * L;
+        const F Z = F::from_words((const uint32_t*)(p + 2 * L));
+        if (Z.is_zero()) { std::memset(o, 0, 2 * L * 8); continue; }
+        const F zi = acc * pref[i];               // 1 / Z_i
+        acc = acc * Z;
+        const F X = F::from_words((const uint32_t*)p), Y = F::from_words((const uint32_t*)(p + L)), zi2 = zi * zi;
+        const F x = X * zi2, y = Y * zi2 * zi;
+        x.to_words((uint32_t*)o);
+        y.to_words((uint32_t*)(o + L));
+    }
 }
 
 }  // namespace
@@ -428,9 +440,9 @@ void jac_sum_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uint64_t*
 int32_t srs_generate_dispatch(int curve, const uint32_t* beta_canon, uint64_t n, uint32_t* d_out) {
     return curve == 0 ? srs_generate<BlsFr, BlsFq>(beta_canon, n, d_out) : srs_generate<BnFr, BnFq>(beta_canon, n, d_out);
 }
-void jac_to_affine_host_dispatch(int curve, const uint64_t* xyz, uint64_t* xy) {
-    if (curve == 0) jac_to_affine_host<BlsFq>(xyz, xy);
-    else jac_to_affine_host<BnFq>(xyz, xy);
+void jac_to_affine_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uint64_t* xy) {
+    if (curve == 0) jac_to_affine_host<BlsFq>(xyz, n, xy);
+    else jac_to_affine_host<BnFq>(xyz, n, xy);
 }
 
 }  // namespace mzk

@@ -308,7 +308,7 @@ int32_t mzk_msm_affine(uint64_t srs_handle, uint64_t base_offset, const uint64_t
         curve = it->second.curve;
         MZK_TRY(msm_host_locked(it->second, base_offset, scalars, n, scalars_are_mont, xyz));
     }
-    jac_to_affine_host_dispatch(curve, xyz, out_xy_mont);
+    jac_to_affine_host_dispatch(curve, xyz, 1, out_xy_mont);
     return MZK_OK;
 }
 
@@ -321,7 +321,8 @@ int32_t mzk_g1_sum_jacobian(int32_t curve_id, const uint64_t* xyz_mont, uint64_t
 int32_t mzk_g1_jacobian_to_affine(int32_t curve_id, const uint64_t* xyz_mont, uint64_t n, uint64_t* out_xy_mont) {
     if ((curve_id != 0 && curve_id != 1) || ((!xyz_mont || !out_xy_mont) && n)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
     const int L = fq_words(curve_id) / 2;
-    for (uint64_t i = 0; i < n; i++) jac_to_affine_host_dispatch(curve_id, xyz_mont + i * 3 * L, out_xy_mont + i * 2 * L);
+    (void)L;
+    jac_to_affine_host_dispatch(curve_id, xyz_mont, n, out_xy_mont);
     return MZK_OK;
 }
 

@@ -111,3 +111,17 @@ def test_sharded_batch_commit(tmp_path, cref, mj, world):
         for rank in range(world):
             got = np.load(tmp_path / f"commits_{rank}.npy")[i]
             assert np.array_equal(cref.jac_to_affine(curve_id, got)[0], want), (i, rank)
+
+
+@pytest.mark.parametrize("curve_id", [0, 1])
+def test_host_batch_normalisation(mj, cref, curve_id):
+    """mzk_g1_jacobian_to_affine (host only; `normalize_batch` / `.into_affine()`): one shared inversion over a batch that
+    contains points at infinity at the ends and in the middle."""
+    c = mj.params.CURVES[curve_id]
+    pts = [cref.msm(curve_id, cref.g1_arith_bases(curve_id, 10 + i, 3, 4), mj.params.random_fr_mont(c, 4, seed=i)) for i in range(5)]
+    inf = np.zeros_like(pts[0])
+    batch = np.stack([inf, pts[0], pts[1], inf, inf, pts[2], pts[3], pts[4], inf])
+    got = mj.jacobian_to_affine(c, batch)
+    for i in range(batch.shape[0]):
+        assert np.array_equal(got[i], cref.jac_to_affine(curve_id, batch[i])[0]), i
+    assert mj.jacobian_to_affine(c, batch[:1]).any() == False and mj.jacobian_to_affine(c, batch[:0]).shape[0] == 0
