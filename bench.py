@@ -50,6 +50,7 @@ def main():
     ap.add_argument("--no-plonk", action="store_true", help="skip the TurboPlonk round-3 (quotient) measurement")
     ap.add_argument("--plonk-log-n", type=int, default=20)
     ap.add_argument("--ultra-log-n", type=int, default=20, help="UltraPlonk/BN254 prove leg (0 disables; config C5 is 22)")
+    ap.add_argument("--ultra-sharded-log-n", type=int, default=22, help="N > 1: UltraPlonk/BN254 sharded prove leg (config C5: 22; 0 disables)")
     args = ap.parse_args()
 
     import torch
@@ -259,42 +260,48 @@ def main():
     #      NTTs, quotient and polynomial work are replicated, so this is the strong-scaling figure of the commit half only
     prove_sharded = None
     if not args.no_plonk and world > 1 and not os.environ.get("MZK_BENCH_NO_SHARDED_PROVE"):
-        pl, pn = args.plonk_log_n, 1 << args.plonk_log_n
-        ck = mj.UnivariateProverParam.gen_srs_for_testing(curve, beta, pn + 2)          # the same SRS on every rank
-        cs = mj.snark.gen_circuit_for_bench(curve, pn, "TurboPlonk")
-        chunked = 8 % world == 0                                                         # 8(e).3 needs a world size dividing 8
-        gather = lambda local: mj.sharding.gather_quotient_classes(local, via_host=(backend != "nccl"))
-        prover = (mj.snark.preprocess(ck, cs, quotient_classes=mj.sharding.class_range(rank, world), quotient_gather=gather) if chunked
-                  else mj.snark.preprocess(ck, cs))
-        prover.vk_commitments()
-        prover.committer = mj.sharding.ShardedCommitter(curve, ck, device=coll_dev)
-        rng = mj.rng.test_rng()
-        for _ in range(3):
-            mj.snark.prove(rng, cs, prover)
-        torch.cuda.synchronize()
-        dist.barrier()
-        reps = 3
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            core, proof_bytes = mj.snark.prove(rng, cs, prover)
-        torch.cuda.synchronize()
-        dist.barrier()
-        tmax = torch.tensor([(time.perf_counter() - t1) / reps * 1e3], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        digest = torch.tensor([int.from_bytes(proof_bytes[8:15], "little")], dtype=torch.int64, device=cdev)
-        lo, hi = digest.clone(), digest.clone()
-        dist.all_reduce(lo, op=dist.ReduceOp.MIN)
-        dist.all_reduce(hi, op=dist.ReduceOp.MAX)
-        core, _ = mj.snark.prove(rng, cs, prover, profile=True)
-        prove_sharded = {"what": "PlonkKzgSnark::prove, TurboPlonk bench circuit: commitments sharded by point range over the ranks (all-gather of "
-                                 "Jacobian partials + local EC sum, 8(e).1), quotient domain split into residue classes with one all-gather "
-                                 "(8(e).3) when the world size divides 8; iNTTs, grand product, evaluations, openings' polynomials replicated",
-                         "chunked_quotient": chunked, "rounds_ms_rank0": core.timings_ms,
-                         "log_n": pl, "prove_ms": round(float(tmax.item()), 2), "ranks_agree_on_proof": bool(lo.item() == hi.item()),
-                         "proof_bytes": len(proof_bytes)}
-        prover.release()
-        ck.release()
-        del cs
+        def sharded_prove(crv, log_gates, plonk_type):
+            pn = 1 << log_gates
+            ck = mj.UnivariateProverParam.gen_srs_for_testing(crv, beta, pn + 2)          # the same SRS on every rank
+            cs = mj.snark.gen_circuit_for_bench(crv, pn, plonk_type)
+            chunked = 8 % world == 0                                                     # 8(e).3 needs a world size dividing 8
+            gather = lambda local: mj.sharding.gather_quotient_classes(local, via_host=(backend != "nccl"))
+            prover = (mj.snark.preprocess(ck, cs, quotient_classes=mj.sharding.class_range(rank, world), quotient_gather=gather) if chunked
+                      else mj.snark.preprocess(ck, cs))
+            prover.vk_commitments()
+            prover.committer = mj.sharding.ShardedCommitter(crv, ck, device=coll_dev)
+            rng = mj.rng.test_rng()
+            for _ in range(3):
+                mj.snark.prove(rng, cs, prover)
+            torch.cuda.synchronize()
+            dist.barrier()
+            reps = 3
+            t1 = time.perf_counter()
+            for _ in range(reps):
+                core, proof_bytes = mj.snark.prove(rng, cs, prover)
+            torch.cuda.synchronize()
+            dist.barrier()
+            tmax = torch.tensor([(time.perf_counter() - t1) / reps * 1e3], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            digest = torch.tensor([int.from_bytes(proof_bytes[8:15], "little")], dtype=torch.int64, device=cdev)
+            lo, hi = digest.clone(), digest.clone()
+            dist.all_reduce(lo, op=dist.ReduceOp.MIN)
+            dist.all_reduce(hi, op=dist.ReduceOp.MAX)
+            core, _ = mj.snark.prove(rng, cs, prover, profile=True)
+            out = {"plonk_type": plonk_type, "curve": crv.name, "log_n": cs.n.bit_length() - 1, "chunked_quotient": chunked,
+                   "prove_ms": round(float(tmax.item()), 2), "ranks_agree_on_proof": bool(lo.item() == hi.item()),
+                   "proof_bytes": len(proof_bytes), "rounds_ms_rank0": core.timings_ms}
+            prover.release()
+            ck.release()
+            return out
+
+        prove_sharded = {"what": "PlonkKzgSnark::prove on the bench circuit, strong scaling: commitments sharded by point range over the ranks "
+                                 "(all-gather of Jacobian partials + local EC sum, 8(e).1), quotient domain split into residue classes with one "
+                                 "all-gather (8(e).3) when the world size divides 8; iNTTs, grand products, evaluations, openings' polynomials "
+                                 "replicated.  Python-orchestrated (compare with `prove` of the 1-GPU line, not with `prove_cpp_host`)",
+                         "turbo_bls12_381": sharded_prove(curve, args.plonk_log_n, "TurboPlonk")}
+        if args.ultra_sharded_log_n:                                   # config C5: UltraPlonk over BN254, 2^22 constraints
+            prove_sharded["ultra_bn254"] = sharded_prove(mj.params.BN254, args.ultra_sharded_log_n, "UltraPlonk")
 
     # ---- secondary: UltraPlonk (Plookup) on BN254, the shape of config C5 at --ultra-log-n gates, one GPU ---------------
     ultra = None
