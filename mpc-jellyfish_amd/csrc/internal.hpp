@@ -68,7 +68,7 @@ struct Srs {
     int curve;
     uint64_t n;
     uint32_t* d_xy;   // n * 2 * fq words, boundary form (what mzk_srs_download returns)
-    uint32_t* d_int;  // internal reduced-radix table used by the MSM (BLS12-381), else nullptr
+    uint32_t* d_int;  // internal reduced-radix table used by the MSM (29-bit limbs, R'-Montgomery form: ecx.cuh)
     uint32_t* d_pre = nullptr;  // [W][n] precomputed multiples 2^(c*w) P_i (msm_pre.cuh), built on first large MSM
     int pre_c = 0;              // window bits of d_pre; -1 = do not build
 };

@@ -234,10 +234,11 @@ __device__ __forceinline__ void store_xyzz(uint32_t* __restrict__ buf, unsigned 
 }
 
 // ---- EC back ends -----------------------------------------------------------------------------------
-// The bucket kernels are written once against a small policy: EcFp keeps points in the boundary's
-// 32-bit-limb Montgomery form (BN254); EcFx keeps them in the reduced-radix form of fx.cuh / ecx.cuh
-// (BLS12-381: one v_mad_u64_u32 per partial product and carry-free additions), with the SRS
-// converted once at registration and results converted back when they are collected.
+// The bucket kernels are written once against a small policy.  EcFx keeps points in the reduced-radix form of
+// fx.cuh / ecx.cuh (one v_mad_u64_u32 per partial product and carry-free additions; 14 limbs for BLS12-381 Fq, 10 for
+// BN254 Fq), with the SRS converted once at registration and results converted back when they are collected: it is
+// what the library runs.  EcFp keeps points in the boundary's 32-bit-limb Montgomery form; it stays as the baseline
+// that tools/madd_bench.hip compares against.
 template <class FQ>
 struct EcFp {
     using Field = FQ;

@@ -35,7 +35,7 @@
 namespace mzk {
 
 constexpr int NTT_MAX_PASSES = 4;
-constexpr int NTT_TILE_LOG = 11;        // R*C <= 2048 elements = 64 KiB of LDS
+constexpr int NTT_TILE_LOG = 11;        // R*C <= 2048 elements = 72 KiB of LDS at 9 limbs (ntt_fx.cuh)
 constexpr int NTT_MAX_LOG_R = 9;
 
 __device__ __forceinline__ unsigned bitrev(unsigned x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
