@@ -345,6 +345,7 @@ def main():
         # are 29 591 (TurboPlonk, BLS12-381) and 33 701 (UltraPlonk, BN254) ns per constraint on 24 threads of a 5900X (bench.md)
         for name, argv in (("turbo_bls12_381", ["0", "turbo", str(1 << args.plonk_log_n), "5"]),
                            ("ultra_bn254", ["1", "ultra", str(1 << (args.ultra_log_n or args.plonk_log_n)), "5"]),
+                           ("turbo_bls12_381_1024_gates", ["0", "turbo", "1024", "20"]),
                            ("turbo_bls12_381_32768_gates", ["0", "turbo", "32768", "20"]),
                            ("ultra_bn254_32768_gates", ["1", "ultra", "32768", "20"])):
             try:
@@ -375,10 +376,31 @@ def main():
         ntt_cpu_s = time.perf_counter() - t1
         ntt_same = bool(np.array_equal(ev_cpu[:4096], mj.Radix2EvaluationDomain(curve, 22).fft(xs)[:4096]))
         del xs, ev_cpu
+        # config C1 (BASELINE.json configs[0]): TurboPlonk over BLS12-381 at 2^10 constraints on ONE CPU thread -- the C restatement
+        # assembled into a prover (oracle/cref_prover.py), with the challenges and blinders of a device proof, compared piece by piece
+        import cref_prover
+        cs1 = mj.snark.gen_circuit_for_bench(curve, 1 << 10, "TurboPlonk")
+        rng1 = mj.rng.test_rng()
+        ck1 = mj.UnivariateProverParam.gen_srs_for_testing(curve, mj.rng.fr_rand(curve, rng1), cs1.n + 2)
+        pk1 = mj.snark.preprocess(ck1, cs1)
+        bl1 = mj.snark.draw_blinders(curve, rng1, 5, False)
+        src1 = mj.prover.TranscriptChallenges(pk1, [])
+        core1 = pk1.prove(cs1.wire_values, cs1.pub_input_values, src1, bl1)
+        hostv = lambda t: t.cpu().numpy().view(np.uint64)
+        c1 = cref_prover.prove_turbo(0, curve.r, curve.fr_generator, 10, hostv(cs1.selector_values), hostv(cs1.sigma_values), cs1.k, hostv(cs1.wire_values),
+                                     hostv(cs1.pub_input_values), {"wires": bl1.wires, "z": bl1.z, "quot": bl1.quot}, dict(src1.challenges),
+                                     ck1.powers_of_g(), threads=1)
+        c1_same = bool(np.array_equal(core1.opening_proof.xy, c1["opening"]) and np.array_equal(core1.shifted_opening_proof.xy, c1["shifted"])
+                       and core1.wires_evals == c1["wires_evals"])
+        pk1.release()
+        ck1.release()
         cpu = {"value": n / cpu_s, "unit": "pairs/s", "cores": threads, "kind": "port",
                "sample": f"one full 2^{args.log_n}-pair MSM (same bases and scalars as the GPU step), oracle/cpu_ref.c "
                          f"Pippenger with the ark-ec window rule, {threads} threads; restatement of ark-ec, not the Rust binary",
                "seconds": round(cpu_s, 3), "matches_gpu": bool(same),
+               "prove_c1": {"ms": round(c1["seconds"] * 1e3, 1), "cores": 1, "matches_gpu": c1_same,
+                            "sample": "one TurboPlonk proof of the 2^10-gate bench circuit over BLS12-381 (BASELINE configs[0]) by the C "
+                                      "restatement on one thread (oracle/cref_prover.py); GPU figure: prove_cpp_host.turbo_bls12_381_1024_gates"},
                "ntt_2^22": {"ms": round(ntt_cpu_s * 1e3, 1), "cores": threads, "matches_gpu": ntt_same,
                             "sample": "one forward 2^22-point NTT, oracle/cpu_ref.c in-order radix-2 (ark-poly's algorithm restated)"}}
 

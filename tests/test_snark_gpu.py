@@ -71,3 +71,31 @@ def test_bench_circuit_and_proof(gpu, mj, pyref, curve_id, plonk_type, num_gates
     assert proof_bytes[off + W * 32 + 8 + (W - 1) * 32 + 32] == (1 if ultra else 0)
     pk.release()
     ck.release()
+
+
+@pytest.mark.parametrize("curve_id,num_gates", [(0, 1 << 10), (1, 1 << 12)])
+def test_prove_at_config_c1_size_against_the_cpu_restatement(gpu, mj, cref, curve_id, num_gates):
+    """BASELINE.json configs[0]: TurboPlonk over BLS12-381 at 2^10 constraints -- the CPU path there is the C restatement of the
+    ark-poly / ark-ec algorithms (oracle/cref_prover.py: FFT-based quotient, serial grand product, ark-style Pippenger), fed the
+    challenges the device run squeezed from its transcript.  Every commitment and evaluation of the proof must agree."""
+    import cref_prover
+    c = mj.params.CURVES[curve_id]
+    cs = mj.snark.gen_circuit_for_bench(c, num_gates, "TurboPlonk")
+    n, log_n = cs.n, cs.n.bit_length() - 1
+    rng = mj.rng.test_rng()
+    srs_beta = mj.rng.fr_rand(c, rng)
+    ck = mj.UnivariateProverParam.gen_srs_for_testing(c, srs_beta, n + 2)
+    pk = mj.snark.preprocess(ck, cs)
+    bl = mj.snark.draw_blinders(c, rng, 5, False)
+    src = mj.prover.TranscriptChallenges(pk, [])
+    core = pk.prove(cs.wire_values, cs.pub_input_values, src, bl)
+    host = lambda t: t.cpu().numpy().view(np.uint64)
+    want = cref_prover.prove_turbo(curve_id, c.r, c.fr_generator, log_n, host(cs.selector_values), host(cs.sigma_values), cs.k, host(cs.wire_values),
+                                   host(cs.pub_input_values), {"wires": bl.wires, "z": bl.z, "quot": bl.quot}, dict(src.challenges),
+                                   ck.powers_of_g(), threads=8)
+    for got, exp in zip(core.wires_poly_comms + [core.prod_perm_poly_comm] + core.split_quot_poly_comms + [core.opening_proof, core.shifted_opening_proof],
+                        want["wires_comms"] + [want["z_comm"]] + want["split_comms"] + [want["opening"], want["shifted"]]):
+        assert np.array_equal(got.xy, exp)
+    assert core.wires_evals == want["wires_evals"] and core.wire_sigma_evals == want["wire_sigma_evals"] and core.perm_next_eval == want["perm_next_eval"]
+    pk.release()
+    ck.release()
