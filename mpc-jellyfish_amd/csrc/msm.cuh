@@ -350,6 +350,40 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(const u
     EC::store_pt(buckets, t, acc);
 }
 
+// Small and medium MSMs are latency bound: few buckets, each a chain of dependent mixed adds (~5 us apiece when a wave runs
+// alone).  There every bucket is split over S = 2^log_split threads -- thread s takes entries s, s + S, ... of the run -- and
+// msm_split_combine_kernel adds the S partial sums: chains S times shorter for (S - 1) M extra additions.
+template <class EC>
+__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_split_kernel(const uint32_t* __restrict__ bases, unsigned long long n,
+                                                                                const uint32_t* __restrict__ offs, const uint32_t* __restrict__ hist,
+                                                                                const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ order,
+                                                                                uint32_t M, int n_win, uint32_t cap, int log_split, uint32_t* __restrict__ sub) {
+    const unsigned long long t1 = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
+    const unsigned long long t0 = t1 >> log_split;
+    if (t0 >= (unsigned long long)n_win * M) return;
+    const uint32_t S = 1u << log_split, part = (uint32_t)(t1 & (S - 1));
+    const unsigned long long w = t0 / M;
+    const unsigned long long t = w * M + order[t0];
+    const uint32_t start = offs[t];
+    const uint32_t cnt = min(hist[t], cap);
+    const uint32_t* list = sorted + w * n + start;
+    typename EC::Pt acc = EC::inf();
+    for (uint32_t k = part; k < cnt; k += S) {
+        const uint32_t e = list[k];
+        acc = EC::madd(acc, EC::load_aff(bases, e & 0x7fffffffu), (e >> 31) != 0);
+    }
+    EC::store_pt(sub, (t << log_split) + part, acc);
+}
+template <class EC>
+__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_split_combine_kernel(const uint32_t* __restrict__ sub, unsigned long long n_buckets, int log_split,
+                                                                             uint32_t* __restrict__ buckets) {
+    const unsigned long long t = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
+    if (t >= n_buckets) return;
+    typename EC::Pt acc = EC::load_pt(sub, t << log_split);
+    for (uint32_t s = 1; s < (1u << log_split); s++) acc = EC::add(acc, EC::load_pt(sub, (t << log_split) + s));
+    EC::store_pt(buckets, t, acc);
+}
+
 // ---- over-long buckets (skewed scalars) ------------------------------------------------------------
 // A bucket with more than `cap` points would serialise one thread for its whole run (all-equal
 // scalars put n points into one bucket per window).  Its first `cap` points stay with the regular

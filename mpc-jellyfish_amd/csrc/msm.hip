@@ -185,8 +185,29 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
             }
             {
                 ProfScope ps("msm_accumulate", st);
-                hipLaunchKernelGGL((msm_accumulate_kernel<EC>), dim3((unsigned)((wm + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
-                                   d_bases, n_sorted, offs, hist, sorted, order, M, n_win, cap, buckets);
+                // latency-bound sizes: split every bucket over 2^log_split threads (msm.cuh), aiming at chains of ~4 adds
+                // -- as long as the grid stays below what fills the chip (2^18 threads); beyond that only while the (S - 1) M extra
+                // additions stay under ~5 % of the work (S - 1 <= mean / 32)
+                int log_split = 0;
+                const unsigned long long mean = n_sorted / M;
+                while (log_split < 3) {
+                    const int nx = log_split + 1;
+                    const bool small_grid = (wm << nx) <= (1ull << 18);
+                    if (small_grid ? (mean >> (nx + 1)) == 0 : ((1ull << nx) - 1) * 32 > mean) break;
+                    log_split = nx;
+                }
+                if (log_split == 0) {
+                    hipLaunchKernelGGL((msm_accumulate_kernel<EC>), dim3((unsigned)((wm + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
+                                       d_bases, n_sorted, offs, hist, sorted, order, M, n_win, cap, buckets);
+                } else {
+                    const size_t threads = wm << log_split;
+                    MZK_TRY(g_ws.split.reserve(threads * EC::PT_WORDS * 4));
+                    uint32_t* sub = g_ws.split.as<uint32_t>();
+                    hipLaunchKernelGGL((msm_accumulate_split_kernel<EC>), dim3((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS),
+                                       0, st, d_bases, n_sorted, offs, hist, sorted, order, M, n_win, cap, log_split, sub);
+                    hipLaunchKernelGGL((msm_split_combine_kernel<EC>), dim3((unsigned)((wm + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
+                                       sub, (unsigned long long)wm, log_split, buckets);
+                }
             }
             {
                 // over-long buckets (skewed scalars); no-ops for uniformly random scalars

@@ -30,7 +30,7 @@ void DevBuf::release() {
     cap = 0;
 }
 void Workspace::release() {
-    for (DevBuf* b : {&ntt_scratch, &scalars, &hist, &offs, &cursor, &sorted, &buckets, &collect, &io, &misc, &digits, &long_desc, &long_parts, &plonk_polys, &plonk_out, &pre_cnt, &pre_off, &pre_ce, &pre_cb, &poly_tmp}) b->release();
+    for (DevBuf* b : {&ntt_scratch, &scalars, &hist, &offs, &cursor, &sorted, &buckets, &collect, &io, &misc, &digits, &long_desc, &long_parts, &plonk_polys, &plonk_out, &pre_cnt, &pre_off, &pre_ce, &pre_cb, &poly_tmp, &split}) b->release();
     if (h_collect) (void)hipHostFree(h_collect);
     h_collect = nullptr;
     h_collect_cap = 0;
