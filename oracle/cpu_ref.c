@@ -386,6 +386,30 @@ EXPORT int orc_srs_powers(int curve, const u64 beta[4], size_t n, u64 *out_xy, i
     return 0;
 }
 
+/* UltraPlonk (Plookup) restatements; see plonk_impl.inc */
+EXPORT int orc_plookup_merge(int curve, size_t n, const u64 *wires, const u64 *tabs, const u64 *q_lookup, const u64 *tau_m, u64 *out_table, u64 *out_lookup) {
+    if (curve == 0) blsplk_lookup_merge(n, wires, tabs, q_lookup, tau_m, out_table, out_lookup);
+    else if (curve == 1) bnplk_lookup_merge(n, wires, tabs, q_lookup, tau_m, out_table, out_lookup);
+    else return -2;
+    return 0;
+}
+EXPORT long orc_plookup_sorted(int curve, size_t n, const u64 *table, const u64 *lookup, u64 *out) {
+    if (curve == 0) return blsplk_lookup_sorted(n, table, lookup, out);
+    if (curve == 1) return bnplk_lookup_sorted(n, table, lookup, out);
+    return -2;
+}
+EXPORT int orc_plookup_product(int curve, int log_n, const u64 *table, const u64 *lookup, const u64 *sorted, const u64 *beta_m, const u64 *gamma_m, u64 *out, int threads) {
+    if (curve == 0) return blsplk_lookup_product(log_n, table, lookup, sorted, beta_m, gamma_m, out, threads);
+    if (curve == 1) return bnplk_lookup_product(log_n, table, lookup, sorted, beta_m, gamma_m, out, threads);
+    return -2;
+}
+EXPORT int orc_plonk_quotient_ultra(int curve, int log_n, const u64 *polys, size_t poly_len, const u64 *k_mont, const u64 *tau_m, const u64 *alpha_m,
+                                    const u64 *beta_m, const u64 *gamma_m, u64 *out, int threads) {
+    if (curve == 0) return blsplk_quotient_ultra(log_n, polys, poly_len, k_mont, tau_m, alpha_m, beta_m, gamma_m, out, threads);
+    if (curve == 1) return bnplk_quotient_ultra(log_n, polys, poly_len, k_mont, tau_m, alpha_m, beta_m, gamma_m, out, threads);
+    return -2;
+}
+
 /* on-curve check of packed affine points; returns number of points NOT on the curve */
 EXPORT long orc_g1_count_off_curve(int curve, const u64 *xy, size_t n) {
     long bad = 0;

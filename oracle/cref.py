@@ -39,6 +39,11 @@ def lib():
         L.orc_srs_powers.argtypes = [C.c_int, u64p, C.c_size_t, u64p, C.c_int]
         L.orc_g1_count_off_curve.argtypes = [C.c_int, u64p, C.c_size_t]
         L.orc_g1_count_off_curve.restype = C.c_long
+        L.orc_plookup_sorted.restype = C.c_long
+        L.orc_plookup_merge.argtypes = [C.c_int, C.c_size_t, u64p, u64p, u64p, u64p, u64p, u64p]
+        L.orc_plookup_sorted.argtypes = [C.c_int, C.c_size_t, u64p, u64p, u64p]
+        L.orc_plookup_product.argtypes = [C.c_int, C.c_int, u64p, u64p, u64p, u64p, u64p, u64p, C.c_int]
+        L.orc_plonk_quotient_ultra.argtypes = [C.c_int, C.c_int, u64p, C.c_size_t, u64p, u64p, u64p, u64p, u64p, u64p, C.c_int]
         L.orc_plonk_quotient.argtypes = [C.c_int, C.c_int, C.c_int, u64p, C.c_size_t, u64p, u64p, u64p, u64p, u64p, C.c_int]
         L.orc_plonk_perm_product.argtypes = [C.c_int, C.c_int, C.c_int, u64p, u64p, u64p, u64p, u64p, u64p, C.c_int]
         L.orc_poly_div_linear.argtypes = [C.c_int, u64p, C.c_size_t, u64p, u64p]
@@ -187,7 +192,44 @@ def plonk_perm_product(curve: int, log_n: int, wires: np.ndarray, sigma_vals: np
     sg = np.ascontiguousarray(sigma_vals, dtype=np.uint64)
     out = np.empty((1 << log_n, 4), dtype=np.uint64)
     args = [np.ascontiguousarray(a, dtype=np.uint64) for a in (k_mont, beta, gamma)]
-    _chk(lib().orc_plonk_perm_product(curve, log_n, 5, _p(w), _p(sg), _p(args[0]), _p(args[1]), _p(args[2]), _p(out), threads))
+    _chk(lib().orc_plonk_perm_product(curve, log_n, w.shape[0], _p(w), _p(sg), _p(args[0]), _p(args[1]), _p(args[2]), _p(out), threads))
+    return out
+
+
+def plookup_merge(curve: int, wires: np.ndarray, tabs: np.ndarray, q_lookup: np.ndarray, tau) -> tuple[np.ndarray, np.ndarray]:
+    """constraint_system.rs:1290-1309, 1441-1480: wires (6, n, 4), tabs (4, n, 4) = range, key, table_dom_sep, q_dom_sep,
+    q_lookup (n, 4) values -> (merged table, merged lookup witness), each (n, 4)."""
+    w, t, q = (np.ascontiguousarray(a, dtype=np.uint64) for a in (wires, tabs, q_lookup))
+    n = q.shape[0]
+    table, lookup = np.empty((n, 4), dtype=np.uint64), np.empty((n, 4), dtype=np.uint64)
+    _chk(lib().orc_plookup_merge(curve, n, _p(w), _p(t), _p(q), _p(np.ascontiguousarray(tau, dtype=np.uint64)), _p(table), _p(lookup)))
+    return table, lookup
+
+
+def plookup_sorted(curve: int, table: np.ndarray, lookup: np.ndarray):
+    """constraint_system.rs:1370-1408: the merged sorted vector, or None when a lookup value is not in the table."""
+    t, l = np.ascontiguousarray(table, dtype=np.uint64), np.ascontiguousarray(lookup, dtype=np.uint64)
+    n = t.shape[0]
+    out = np.empty((2 * n, 4), dtype=np.uint64)
+    ln = lib().orc_plookup_sorted(curve, n, _p(t), _p(l), _p(out))
+    return None if ln < 0 else out[:ln]
+
+
+def plookup_product(curve: int, log_n: int, table, lookup, sorted_vec, beta, gamma, threads: int = 1) -> np.ndarray:
+    """constraint_system.rs:1311-1368: the n coefficients of the Plookup product polynomial."""
+    args = [np.ascontiguousarray(a, dtype=np.uint64) for a in (table, lookup, sorted_vec, beta, gamma)]
+    out = np.empty((1 << log_n, 4), dtype=np.uint64)
+    _chk(lib().orc_plookup_product(curve, log_n, _p(args[0]), _p(args[1]), _p(args[2]), _p(args[3]), _p(args[4]), _p(out), threads))
+    return out
+
+
+def plonk_quotient_ultra(curve: int, log_n: int, polys: np.ndarray, k_mont, tau, alpha, beta, gamma, threads: int = 1) -> np.ndarray:
+    """polys: (35, poly_len, 4): selectors[14], sigmas[6], tables[4], wires[6], z, pi, h_1, h_2, prod_lookup (prover.rs:512-888)."""
+    p = np.ascontiguousarray(polys, dtype=np.uint64)
+    assert p.ndim == 3 and p.shape[0] == 35 and p.shape[2] == 4
+    out = np.empty((8 << log_n, 4), dtype=np.uint64)
+    args = [np.ascontiguousarray(a, dtype=np.uint64) for a in (k_mont, tau, alpha, beta, gamma)]
+    _chk(lib().orc_plonk_quotient_ultra(curve, log_n, _p(p), p.shape[1], *[_p(a) for a in args], _p(out), threads))
     return out
 
 

@@ -182,3 +182,31 @@ def test_restated_prover_satisfies_the_reference_identities(pyref, curve_id, ult
         w[5][2] = (1 << 3) + 1                                             # a range-wire value outside the 3-bit range table
         with pytest.raises(AssertionError):
             PP.prove_core(c, log_n, sel, sig, k, w, pi, blind, ch, plookup=plookup)
+
+
+def test_c_restatement_of_the_plookup_builders_matches_the_definitions(pyref, cref):
+    """oracle/plonk_impl.inc (merge, sorted vector, Plookup product) against the big-int restatement on a satisfied UltraPlonk
+    instance; a lookup value outside the table is reported, not merged."""
+    import pyref_plonk as PP
+    from conftest import build_ultra_circuit
+    for curve_id in (0, 1):
+        c = pyref.CURVES[curve_id]
+        r, log_n = c.r, 5
+        n = 1 << log_n
+        rng = random.Random(900 + curve_id)
+        sel, sig, k, w, pi, plookup = build_ultra_circuit(c, log_n, rng)
+        tau, beta, gamma = (rng.randrange(r) for _ in range(3))
+        m = lambda vals: fr_mont_limbs(c, vals)
+        tabs = np.stack([m(plookup[x]) for x in ("range", "key", "table_dom_sep", "q_dom_sep")])
+        table, lookup = cref.plookup_merge(curve_id, np.stack([m(col) for col in w]), tabs, m(sel[13]), m([tau])[0])
+        want_table = PP.merged_table_values(c, tau, plookup, sel[13], w)
+        want_lookup = PP.merged_lookup_values(c, tau, plookup, sel[13], w)
+        assert fr_from_mont_limbs(c, table) == want_table and fr_from_mont_limbs(c, lookup) == want_lookup
+        sorted_vec = cref.plookup_sorted(curve_id, table, lookup)
+        want_sorted = PP.sorted_lookup_vec(want_table, want_lookup[:n - 1])
+        assert fr_from_mont_limbs(c, sorted_vec) == want_sorted
+        prod = cref.plookup_product(curve_id, log_n, table, lookup, sorted_vec, m([beta])[0], m([gamma])[0])
+        want = pyref.ntt_fast(c, PP.lookup_product_values(c, n, tau, beta, gamma, want_table, want_lookup, want_sorted), log_n, 1, inverse=True)
+        assert fr_from_mont_limbs(c, prod) == want
+        lookup[3] = m([r - 5])[0]
+        assert cref.plookup_sorted(curve_id, table, lookup) is None

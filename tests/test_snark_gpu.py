@@ -99,3 +99,33 @@ def test_prove_at_config_c1_size_against_the_cpu_restatement(gpu, mj, cref, curv
     assert core.wires_evals == want["wires_evals"] and core.wire_sigma_evals == want["wire_sigma_evals"] and core.perm_next_eval == want["perm_next_eval"]
     pk.release()
     ck.release()
+
+
+@pytest.mark.parametrize("curve_id,num_gates", [(1, 1 << 10), (0, 1 << 11)])
+def test_ultra_prove_against_the_cpu_restatement(gpu, mj, cref, curve_id, num_gates):
+    """UltraPlonk at 2^10 / 2^11 gates (every NTT multi-pass, every MSM on the table path): the device proof against the C
+    restatement of the Plookup builders, the Ultra quotient closure and the rest (oracle/cref_prover.py::prove_ultra)."""
+    import cref_prover
+    c = mj.params.CURVES[curve_id]
+    cs = mj.snark.gen_circuit_for_bench(c, num_gates, "UltraPlonk")
+    n, log_n = cs.n, cs.n.bit_length() - 1
+    rng = mj.rng.test_rng()
+    ck = mj.UnivariateProverParam.gen_srs_for_testing(c, mj.rng.fr_rand(c, rng), n + 2)
+    pk = mj.snark.preprocess(ck, cs)
+    bl = mj.snark.draw_blinders(c, rng, 6, True)
+    src = mj.prover.TranscriptChallenges(pk, [])
+    core = pk.prove(cs.wire_values, cs.pub_input_values, src, bl)
+    host = lambda t: t.cpu().numpy().view(np.uint64)
+    want = cref_prover.prove_ultra(curve_id, c.r, c.fr_generator, log_n, host(cs.selector_values), host(cs.sigma_values), host(cs.table_values), cs.k,
+                                   host(cs.wire_values), host(cs.pub_input_values),
+                                   {"wires": bl.wires, "z": bl.z, "quot": bl.quot, "h": bl.h, "prod_lookup": bl.prod_lookup}, dict(src.challenges),
+                                   ck.powers_of_g(), threads=8)
+    got = core.wires_poly_comms + core.h_poly_comms + [core.prod_perm_poly_comm, core.prod_lookup_poly_comm] + core.split_quot_poly_comms + \
+        [core.opening_proof, core.shifted_opening_proof]
+    exp = want["wires_comms"] + want["h_comms"] + [want["z_comm"], want["prod_lookup_comm"]] + want["split_comms"] + [want["opening"], want["shifted"]]
+    for i, (g, e) in enumerate(zip(got, exp)):
+        assert np.array_equal(g.xy, e), i
+    assert core.wires_evals == want["wires_evals"] and core.wire_sigma_evals == want["wire_sigma_evals"] and core.perm_next_eval == want["perm_next_eval"]
+    assert core.plookup_evals == want["plookup_evals"]
+    pk.release()
+    ck.release()
