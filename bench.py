@@ -415,7 +415,11 @@ def main():
         kern = (_profile_value("kernels") or {}).get(_profile_value("msm_accumulate_kernel") or "")
         if kern and kern.get("SQ_INSTS_VALU") and args.log_n == 20:
             bound_ms = kern["SQ_INSTS_VALU"] / 1024 * 1.9e-6
+            # 32-bit integer multiply-adds (v_mad_u64_u32) the launch retires: 13 windows x n mixed adds x (8 products of 2 * 14^2
+            # MADs + 2 squarings of 14 * 15 / 2 + 14^2), SURVEY.md 8(d)'s second figure; peak = 64 lanes / 1.9 ns on 1024 SIMDs
+            mads = n_win * n * (8 * 2 * 196 + 2 * (105 + 196))
             valu = {"wave_insts_per_launch": kern["SQ_INSTS_VALU"], "issue_bound_ms": round(bound_ms, 3), "util": round(bound_ms / acc_avg_ms, 3),
+                    "int_mad_per_s": round(mads / (acc_avg_ms * 1e-3), -9), "int_mad_peak_per_s": round(1024 * 64 / 1.9e-9, -9),
                     "note": "SQ_INSTS_VALU of the committed PMC pass (2^20 pairs) x 1.9 ns / 1024 SIMDs vs the live launch time"}
         out = {
             "metric": "msm_g1_scalar_pairs_per_s", "value": world * n * args.steps / elapsed, "unit": "pairs/s",
