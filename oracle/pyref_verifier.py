@@ -1,0 +1,322 @@
+"""oracle/pyref_verifier.py -- TEST INFRASTRUCTURE ONLY.
+
+Restatement of the reference VERIFIER for one TurboPlonk / UltraPlonk instance, from the compressed proof bytes:
+    Proof::deserialize_compressed          plonk/src/proof_system/structs.rs:59-84, 208-222, 440-450, 496-541
+    Verifier::compute_challenges           plonk/src/proof_system/verifier.rs:256-321
+    Verifier::compute_lin_poly_constant_term                                :340-414
+    Verifier::linearization_scalars_and_bases / aggregate_poly_commitments  :421-668
+    Verifier::aggregate_evaluations                                         :673-733
+    Verifier::batch_verify_opening_proofs                                   :195-251
+It shares no code with the restated provers (pyref_plonk / cref_prover) nor with the device path, so a proof it accepts is a
+proof the reference's verification equation accepts.
+
+The last step is a pairing check  e(A, [beta]_2) == e(B, [1]_2).  The test SRS is generated from a known beta (as the
+reference's own `gen_srs_for_testing` does), and for such an SRS that check is equivalent to  beta * A == B  in G1, which is
+what `verify` evaluates -- G1 arithmetic only (pyref.g1_*), no G2 / Fq12 tower needed.
+
+The Fiat-Shamir transcript is passed in by the caller (an object with append_message / append_vk_and_pub_input /
+append_commitment(s) / append_field_elem / append_plookup_evaluations / get_and_append_challenge -- the product's
+StandardTranscript, pinned by the Merlin KAT in tests/test_transcript.py).
+PARITY UNPINNED by reference vectors (none exist for this path).
+"""
+from __future__ import annotations
+
+import struct
+
+import pyref as P
+
+GATE_WIDTH = 4
+PLOOKUP_EVAL_FIELDS = ("range_table_eval", "key_table_eval", "table_dom_sep_eval", "q_dom_sep_eval", "h_1_eval", "q_lookup_eval",
+                       "prod_next_eval", "range_table_next_eval", "key_table_next_eval", "table_dom_sep_next_eval",
+                       "h_1_next_eval", "h_2_next_eval", "q_lookup_next_eval", "w_3_next_eval", "w_4_next_eval")   # structs.rs:496-541
+
+
+class VerifyError(Exception):
+    pass
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# ark-serialize, compressed
+# ---------------------------------------------------------------------------------------------------------------------
+def _sqrt_fq(c, a):
+    """both base fields have q = 3 (mod 4)"""
+    assert c.q % 4 == 3
+    y = pow(a, (c.q + 1) // 4, c.q)
+    if y * y % c.q != a % c.q:
+        raise VerifyError("x is not on the curve")
+    return y
+
+
+def g1_decompress(c, b: bytes):
+    """inverse of the G1 encodings (BLS12-381: zcash flags, big-endian; BN254: arkworks SW flags, little-endian)."""
+    if c.curve_id == 0:
+        if len(b) != 48 or not b[0] & 0x80:
+            raise VerifyError("bad BLS12-381 G1 encoding")
+        if b[0] & 0x40:
+            if b[0] != 0xC0 or any(b[1:]):
+                raise VerifyError("bad infinity encoding")
+            return None
+        greatest = bool(b[0] & 0x20)
+        x = int.from_bytes(bytes([b[0] & 0x1F]) + b[1:], "big")
+    else:
+        if len(b) != 32:
+            raise VerifyError("bad BN254 G1 encoding")
+        if b[31] & 0x40:
+            if b[31] != 0x40 or any(b[:31]):
+                raise VerifyError("bad infinity encoding")
+            return None
+        greatest = bool(b[31] & 0x80)
+        x = int.from_bytes(b[:31] + bytes([b[31] & 0x3F]), "little")
+    if x >= c.q:
+        raise VerifyError("x not reduced")
+    y = _sqrt_fq(c, (x * x % c.q * x + c.b) % c.q)
+    if (y > c.q - y) != greatest:
+        y = c.q - y
+    pt = (x, y)
+    assert P.g1_on_curve(c, pt)
+    return pt
+
+
+class _Reader:
+    def __init__(self, c, data: bytes):
+        self.c, self.d, self.o = c, data, 0
+        self.g1_len = 48 if c.curve_id == 0 else 32
+
+    def take(self, n):
+        if self.o + n > len(self.d):
+            raise VerifyError("proof truncated")
+        out = self.d[self.o:self.o + n]
+        self.o += n
+        return out
+
+    def g1(self):
+        return g1_decompress(self.c, self.take(self.g1_len))
+
+    def fr(self):
+        x = int.from_bytes(self.take(32), "little")
+        if x >= self.c.r:
+            raise VerifyError("scalar not reduced")
+        return x
+
+    def vec(self, item):
+        (n,) = struct.unpack("<Q", self.take(8))
+        if n > 64:
+            raise VerifyError("implausible vector length")
+        return [item() for _ in range(n)]
+
+
+def deserialize_proof(c, data: bytes) -> dict:
+    """field order of `Proof` (structs.rs:59-84)."""
+    rd = _Reader(c, data)
+    pr = {"wires_poly_comms": rd.vec(rd.g1), "prod_perm_poly_comm": rd.g1(), "split_quot_poly_comms": rd.vec(rd.g1),
+          "opening_proof": rd.g1(), "shifted_opening_proof": rd.g1(),
+          "wires_evals": rd.vec(rd.fr), "wire_sigma_evals": rd.vec(rd.fr), "perm_next_eval": rd.fr(), "plookup": None}
+    tag = rd.take(1)[0]
+    if tag == 1:
+        pl = {"h_poly_comms": rd.vec(rd.g1), "prod_lookup_poly_comm": rd.g1()}
+        pl["evals"] = {name: rd.fr() for name in PLOOKUP_EVAL_FIELDS}
+        pr["plookup"] = pl
+    elif tag != 0:
+        raise VerifyError("bad Option tag")
+    if rd.o != len(data):
+        raise VerifyError("trailing bytes")
+    return pr
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the verifier
+# ---------------------------------------------------------------------------------------------------------------------
+def compute_challenges(transcript, vk: dict, pub_input, pr: dict, extra_msg=None) -> dict:
+    """verifier.rs:256-321, one instance.  `transcript` is a fresh b"PlonkProof" transcript."""
+    t = transcript
+    if extra_msg is not None:
+        t.append_message(b"extra info", extra_msg)
+    t.append_vk_and_pub_input(vk["domain_size"], vk["num_inputs"], vk["k"], vk["selector_comms"], vk["sigma_comms"], pub_input)
+    t.append_commitments(b"witness_poly_comms", pr["wires_poly_comms"])
+    ch = {"tau": t.get_and_append_challenge(b"tau")}
+    pl = pr["plookup"]
+    if pl is not None:
+        t.append_commitments(b"h_poly_comms", pl["h_poly_comms"])
+    ch["beta"] = t.get_and_append_challenge(b"beta")
+    ch["gamma"] = t.get_and_append_challenge(b"gamma")
+    t.append_commitment(b"perm_poly_comms", pr["prod_perm_poly_comm"])
+    if pl is not None:
+        t.append_commitment(b"plookup_poly_comms", pl["prod_lookup_poly_comm"])
+    ch["alpha"] = t.get_and_append_challenge(b"alpha")
+    t.append_commitments(b"quot_poly_comms", pr["split_quot_poly_comms"])
+    ch["zeta"] = t.get_and_append_challenge(b"zeta")
+    for e in pr["wires_evals"]:                                            # transcript/mod.rs:140-163
+        t.append_field_elem(b"wire_evals", e)
+    for e in pr["wire_sigma_evals"]:
+        t.append_field_elem(b"wire_sigma_evals", e)
+    t.append_field_elem(b"perm_next_eval", pr["perm_next_eval"])
+    if pl is not None:
+        t.append_plookup_evaluations(pl["evals"])
+    ch["v"] = t.get_and_append_challenge(b"v")
+    t.append_commitment(b"open_proof", pr["opening_proof"])
+    t.append_commitment(b"shifted_open_proof", pr["shifted_opening_proof"])
+    ch["u"] = t.get_and_append_challenge(b"u")
+    return ch
+
+
+def _evaluate_pi_poly(c, n, w, pub_input, z, vanish_eval):
+    """verifier.rs:845-880, unmerged circuit."""
+    r = c.r
+    if vanish_eval == 0:
+        return 0
+    vn = vanish_eval * pow(n, -1, r) % r
+    out, g = 0, 1
+    for val in pub_input:
+        out = (out + vn * g % r * pow((z - g) % r, -1, r) % r * val) % r
+        g = g * w % r
+    return out
+
+
+def prepare_pcs_info(c, vk: dict, pub_input, pr: dict, ch: dict) -> dict:
+    """verifier.rs:68-184 for one instance (alpha_bases = [1]).  Returns u, eval points, the aggregated evaluation and the
+    (scalar, base) list of the aggregated commitment."""
+    r = c.r
+    n = vk["domain_size"]
+    log_n = n.bit_length() - 1
+    if len(pub_input) != vk["num_inputs"]:
+        raise VerifyError("the circuit public input length != the verification key public input length")
+    ultra = vk.get("plookup") is not None
+    if ultra != (pr["plookup"] is not None):
+        raise VerifyError("Mismatched proof type and verification key type")
+    W = GATE_WIDTH + 1 + (1 if ultra else 0)
+    if len(pr["wires_poly_comms"]) != W or len(pr["wires_evals"]) != W or len(pr["wire_sigma_evals"]) != W - 1 \
+            or len(pr["split_quot_poly_comms"]) != W or len(vk["sigma_comms"]) != W or len(vk["k"]) != W \
+            or len(vk["selector_comms"]) != 2 * GATE_WIDTH + 5 + (1 if ultra else 0):
+        raise VerifyError("wrong number of commitments / evaluations")
+    w = c.root_of_unity(log_n)
+    w_inv = pow(w, -1, r)
+    tau, beta, gamma, alpha, zeta, v, u = (ch[x] for x in ("tau", "beta", "gamma", "alpha", "zeta", "v", "u"))
+    a2 = alpha * alpha % r
+    a3, a4 = a2 * alpha % r, a2 * a2 % r
+    a5, a6 = a4 * alpha % r, a4 * a2 % r
+    alpha_powers = [a2, a3, a4, a5, a6]
+    vanish = (pow(zeta, n, r) - 1) % r
+    l1 = vanish * pow(n * (zeta - 1) % r, -1, r) % r                       # :776-788
+    ln = vanish * w_inv % r * pow(n * (zeta - w_inv) % r, -1, r) % r
+    we, se, zn = pr["wires_evals"], pr["wire_sigma_evals"], pr["perm_next_eval"]
+    pl = pr["plookup"]
+    ev = pl["evals"] if ultra else None
+    b1 = (1 + beta) % r
+    g_b1 = gamma * b1 % r
+
+    # --- constant term of the linearisation polynomial (:340-414)
+    tmp = (_evaluate_pi_poly(c, n, w, pub_input, zeta, vanish) - alpha_powers[0] * l1) % r
+    acc = alpha * zn % r * ((gamma + we[W - 1]) % r) % r
+    for we_i, se_i in zip(we[:W - 1], se):
+        acc = acc * ((gamma + we_i + beta * se_i) % r) % r
+    tmp = (tmp - acc) % r
+    if ultra:
+        pc = (ln * ((ev["h_1_eval"] - ev["h_2_next_eval"] - alpha_powers[0]) % r) - alpha * l1
+              - alpha_powers[1] * ((zeta - w_inv) % r) % r * ev["prod_next_eval"] % r
+              * ((g_b1 + ev["h_1_eval"] + beta * ev["h_1_next_eval"]) % r) % r * ((g_b1 + beta * ev["h_2_next_eval"]) % r)) % r
+        tmp = (tmp + alpha_powers[1] * pc) % r
+    lin_const = tmp
+
+    # --- [D]_1 (:513-668)
+    sb = []                                                                 # (scalar, base)
+    coeff = alpha
+    for we_i, k_i in zip(we, vk["k"]):
+        coeff = coeff * ((beta * k_i % r * zeta + gamma + we_i) % r) % r
+    coeff = (coeff + alpha_powers[0] * l1) % r
+    sb.append((coeff, pr["prod_perm_poly_comm"]))
+    coeff = alpha * beta % r * zn % r
+    for we_i, se_i in zip(we[:W - 1], se):
+        coeff = coeff * ((beta * se_i + gamma + we_i) % r) % r
+    sb.append((-coeff % r, vk["sigma_comms"][-1]))
+    q = [we[0], we[1], we[2], we[3], we[0] * we[1] % r, we[2] * we[3] % r, pow(we[0], 5, r), pow(we[1], 5, r), pow(we[2], 5, r),
+         pow(we[3], 5, r), -we[4] % r, 1, we[0] * we[1] % r * we[2] % r * we[3] % r * we[4] % r]
+    for s, base in zip(q, vk["selector_comms"]):                            # q_lookup (14th) gets no scalar: zip stops at 13
+        sb.append((s, base))
+    if ultra:
+        merged_lookup_x = (we[5] + ev["q_lookup_eval"] * tau % r * (ev["q_dom_sep_eval"] + tau * (we[0] + tau * (we[1] + tau * we[2]))) % r) % r
+        def merged_table(rng_e, key_e, ql_e, w3_e, w4_e, dom_e):             # structs.rs:925-940
+            return (rng_e + ql_e * tau % r * (dom_e + tau * (key_e + tau * (w3_e + tau * w4_e))) % r) % r
+        table_x = merged_table(ev["range_table_eval"], ev["key_table_eval"], ev["q_lookup_eval"], we[3], we[4], ev["table_dom_sep_eval"])
+        table_xw = merged_table(ev["range_table_next_eval"], ev["key_table_next_eval"], ev["q_lookup_next_eval"], ev["w_3_next_eval"],
+                                ev["w_4_next_eval"], ev["table_dom_sep_next_eval"])
+        coeff = (alpha_powers[2] * l1 + alpha_powers[3] * ln
+                 + alpha_powers[4] * ((zeta - w_inv) % r) % r * b1 % r * ((gamma + merged_lookup_x) % r) % r
+                 * ((g_b1 + table_x + beta * table_xw) % r)) % r
+        sb.append((coeff, pl["prod_lookup_poly_comm"]))
+        coeff = alpha_powers[4] * ((w_inv - zeta) % r) % r * ev["prod_next_eval"] % r * ((g_b1 + ev["h_1_eval"] + beta * ev["h_1_next_eval"]) % r) % r
+        sb.append((coeff, pl["h_poly_comms"][1]))
+    zeta_n2 = (1 + vanish) * zeta % r * zeta % r
+    coeff = -vanish % r
+    for i, cm in enumerate(pr["split_quot_poly_comms"]):
+        if i:
+            coeff = coeff * zeta_n2 % r
+        sb.append((coeff, cm))
+
+    # --- the remaining commitments with powers of v / u v (:453-506) and the matching evaluations (:673-733)
+    eval_ = -lin_const % r
+    v_base, uv_base = v, u
+
+    def at_zeta(comm, e):
+        nonlocal v_base, eval_
+        sb.append((v_base, comm))
+        eval_ = (eval_ + e * v_base) % r
+        v_base = v_base * v % r
+
+    def at_zeta_omega(comm, e):
+        nonlocal uv_base, eval_
+        sb.append((uv_base, comm))
+        eval_ = (eval_ + e * uv_base) % r
+        uv_base = uv_base * v % r
+
+    # aggregate_evaluations walks the buffer in commitment order, so the two lists are zipped here
+    for cm, e in zip(pr["wires_poly_comms"], we):
+        at_zeta(cm, e)
+    for cm, e in zip(vk["sigma_comms"][:W - 1], se):
+        at_zeta(cm, e)
+    at_zeta_omega(pr["prod_perm_poly_comm"], zn)
+    if ultra:
+        pvk = vk["plookup"]
+        q_lookup_comm = vk["selector_comms"][-1]
+        for cm, name in ((pvk["range_table_comm"], "range_table_eval"), (pvk["key_table_comm"], "key_table_eval"),
+                         (pl["h_poly_comms"][0], "h_1_eval"), (q_lookup_comm, "q_lookup_eval"),
+                         (pvk["table_dom_sep_comm"], "table_dom_sep_eval"), (pvk["q_dom_sep_comm"], "q_dom_sep_eval")):    # :793-805, structs.rs:545-554
+            at_zeta(cm, ev[name])
+        for cm, name in ((pl["prod_lookup_poly_comm"], "prod_next_eval"), (pvk["range_table_comm"], "range_table_next_eval"),
+                         (pvk["key_table_comm"], "key_table_next_eval"), (pl["h_poly_comms"][0], "h_1_next_eval"),
+                         (pl["h_poly_comms"][1], "h_2_next_eval"), (q_lookup_comm, "q_lookup_next_eval"),
+                         (pr["wires_poly_comms"][3], "w_3_next_eval"), (pr["wires_poly_comms"][4], "w_4_next_eval"),
+                         (pvk["table_dom_sep_comm"], "table_dom_sep_next_eval")):                                            # :810-826, structs.rs:557-569
+            at_zeta_omega(cm, ev[name])
+    return {"u": u, "eval_point": zeta, "next_eval_point": zeta * w % r, "eval": eval_, "comm_scalars_and_bases": sb,
+            "opening_proof": pr["opening_proof"], "shifted_opening_proof": pr["shifted_opening_proof"]}
+
+
+def _msm(c, pairs):
+    acc = None
+    for s, base in pairs:
+        if base is None or s % c.r == 0:
+            continue
+        acc = P.g1_add(c, acc, P.g1_mul(c, s % c.r, base))
+    return acc
+
+
+def batch_verify_opening_proof(c, g, srs_beta: int, info: dict) -> bool:
+    """verifier.rs:195-251 with one PcsInfo (r = 1).  e(A, [beta]_2) == e(B, [1]_2)  <=>  beta A == B."""
+    r = c.r
+    A = _msm(c, [(1, info["opening_proof"]), (info["u"], info["shifted_opening_proof"])])
+    B = _msm(c, info["comm_scalars_and_bases"] + [(info["eval_point"], info["opening_proof"]),
+                                                  (info["u"] * info["next_eval_point"] % r, info["shifted_opening_proof"]),
+                                                  (-info["eval"] % r, g)])
+    lhs = P.g1_mul(c, srs_beta % r, A) if A is not None else None
+    return lhs == B
+
+
+def verify(c, transcript, vk: dict, pub_input, proof_bytes: bytes, g, srs_beta: int, extra_msg=None) -> bool:
+    """PlonkKzgSnark::verify (snark.rs:653-671 -> batch_verify :118-146) for one proof.
+    vk: {"domain_size", "num_inputs", "k", "selector_comms", "sigma_comms", "plookup": None | {"range_table_comm",
+    "key_table_comm", "table_dom_sep_comm", "q_dom_sep_comm"}} with commitments as canonical affine (x, y) or None.
+    g = powers_of_g[0]; srs_beta = the trapdoor of the test SRS."""
+    pr = deserialize_proof(c, proof_bytes)
+    ch = compute_challenges(transcript, vk, pub_input, pr, extra_msg)
+    info = prepare_pcs_info(c, vk, pub_input, pr, ch)
+    return batch_verify_opening_proof(c, g, srs_beta, info)

@@ -1,0 +1,122 @@
+"""CPU: the restated reference verifier (oracle/pyref_verifier.py: verifier.rs:68-251, 340-733) must accept the proofs of the
+schoolbook prover restatement (oracle/pyref_plonk.py), which shares no code with it, and reject them once anything is altered.
+The GPU-side use (device proofs, from their serialized bytes, challenges recomputed from the transcript) is
+tests/test_verifier_gpu.py."""
+import random
+
+import pytest
+
+from conftest import build_circuit, build_ultra_circuit
+
+
+def restated_instance(pyref, curve_id, ultra, seed):
+    """A satisfied circuit, its proof by pyref_plonk, and the verifying key -- commitments through the trapdoor."""
+    import pyref_plonk as PP
+    c = pyref.CURVES[curve_id]
+    r = c.r
+    rng = random.Random(seed)
+    log_n = 5 if ultra else 4
+    W = 6 if ultra else 5
+    plookup = None
+    if ultra:
+        sel, sig, k, w, pi, plookup = build_ultra_circuit(c, log_n, rng)
+    else:
+        sel, sig, k, w, pi = build_circuit(c, log_n, rng)
+    blind = {"wires": [[rng.randrange(r) for _ in range(2)] for _ in range(W)], "z": [rng.randrange(r) for _ in range(3)],
+             "quot": [rng.randrange(r) for _ in range(W - 1)], "h": [[rng.randrange(r) for _ in range(3)] for _ in range(2)],
+             "prod_lookup": [rng.randrange(r) for _ in range(3)]}
+    ch = {x: rng.randrange(r) for x in ("tau", "beta", "gamma", "alpha", "zeta", "v")}
+    srs_beta = rng.randrange(1, r)
+    out = PP.prove_core(c, log_n, sel, sig, k, w, pi, blind, ch, srs_beta, plookup=plookup)
+    assert out["divisible"] and out["quot_degree_ok"]
+    G = pyref.g1_gen(c)
+    pt = lambda dlog: pyref.g1_mul(c, dlog % r, G) if dlog % r else None
+    commit = lambda poly: pt(pyref.poly_eval(c, poly, srs_beta))
+    dl = out["commit_dlogs"]
+    proof = {"wires_poly_comms": [pt(d) for d in dl["wires"]], "prod_perm_poly_comm": pt(dl["z"]),
+             "split_quot_poly_comms": [pt(d) for d in dl["split"]], "opening_proof": pt(dl["opening"]),
+             "shifted_opening_proof": pt(dl["shifted_opening"]), "wires_evals": out["wires_evals"],
+             "wire_sigma_evals": out["wire_sigma_evals"], "perm_next_eval": out["perm_next_eval"], "plookup": None}
+    vk = {"domain_size": 1 << log_n, "num_inputs": 4, "k": k, "selector_comms": [commit(p) for p in out["selectors"]],
+          "sigma_comms": [commit(p) for p in out["sigmas"]], "plookup": None}
+    if ultra:
+        proof["plookup"] = {"h_poly_comms": [pt(d) for d in dl["h"]], "prod_lookup_poly_comm": pt(dl["prod_lookup"]),
+                            "evals": dict(out["plookup_evals"])}
+        tab = out["table_polys"]
+        vk["plookup"] = {"range_table_comm": commit(tab["range"]), "key_table_comm": commit(tab["key"]),
+                         "table_dom_sep_comm": commit(tab["table_dom_sep"]), "q_dom_sep_comm": commit(tab["q_dom_sep"])}
+    ch["u"] = rng.randrange(r)
+    return c, vk, pi[:4], proof, ch, srs_beta
+
+
+@pytest.mark.parametrize("curve_id", [0, 1])
+@pytest.mark.parametrize("ultra", [False, True])
+def test_restated_verifier_accepts_the_restated_prover(pyref, curve_id, ultra):
+    import pyref_verifier as V
+    c, vk, pub, proof, ch, srs_beta = restated_instance(pyref, curve_id, ultra, 7000 + curve_id + 2 * ultra)
+    G = pyref.g1_gen(c)
+    accept = lambda pr, pub_=pub, ch_=ch: V.batch_verify_opening_proof(c, G, srs_beta, V.prepare_pcs_info(c, vk, pub_, pr, ch_))
+    assert pub[3] != 0, "the instance has a non-trivial public input"
+    assert accept(proof)
+    # soundness of the check itself: every altered part is rejected
+    r = c.r
+    bad = dict(proof, wires_evals=[(proof["wires_evals"][0] + 1) % r] + proof["wires_evals"][1:])
+    assert not accept(bad)
+    bad = dict(proof, perm_next_eval=(proof["perm_next_eval"] + 1) % r)
+    assert not accept(bad)
+    bad = dict(proof, split_quot_poly_comms=proof["split_quot_poly_comms"][::-1])
+    assert not accept(bad)
+    bad = dict(proof, opening_proof=proof["shifted_opening_proof"], shifted_opening_proof=proof["opening_proof"])
+    assert not accept(bad)
+    assert not accept(proof, pub_=[pub[0], pub[1], pub[2], (pub[3] + 1) % r])
+    assert not accept(proof, ch_=dict(ch, alpha=(ch["alpha"] + 1) % r))
+    if ultra:
+        pl = proof["plookup"]
+        bad = dict(proof, plookup=dict(pl, evals=dict(pl["evals"], h_2_next_eval=(pl["evals"]["h_2_next_eval"] + 1) % r)))
+        assert not accept(bad)
+        bad = dict(proof, plookup=dict(pl, h_poly_comms=pl["h_poly_comms"][::-1]))
+        assert not accept(bad)
+        with pytest.raises(V.VerifyError):
+            accept(dict(proof, plookup=None))
+    with pytest.raises(V.VerifyError):
+        accept(proof, pub_=pub[:3])
+
+
+@pytest.mark.parametrize("curve_id", [0, 1])
+def test_compressed_g1_round_trip_and_malformed_encodings(pyref, mj, curve_id):
+    """g1_decompress inverts the boundary's G1 encoding (ark-serialize compressed: zcash flags for BLS12-381, arkworks
+    short-Weierstrass flags for BN254), both y signs and infinity; malformed encodings raise."""
+    import pyref_verifier as V
+    c = pyref.CURVES[curve_id]
+    pc = mj.params.CURVES[curve_id]
+    G = pyref.g1_gen(c)
+    rng = random.Random(31 + curve_id)
+    signs = set()
+    for _ in range(12):
+        p = pyref.g1_mul(c, rng.randrange(1, c.r), G)
+        b = mj.transcript.g1_bytes(pc, p)
+        assert V.g1_decompress(c, b) == p
+        signs.add(p[1] > c.q - p[1])
+    assert signs == {True, False}
+    inf = mj.transcript.g1_bytes(pc, None)
+    assert V.g1_decompress(c, inf) is None
+    x = 0
+    while pow((x ** 3 + c.b) % c.q, (c.q - 1) // 2, c.q) == 1 or (x ** 3 + c.b) % c.q == 0:
+        x += 1                                                            # an x with no point above it
+    enc = bytearray(x.to_bytes(48, "big")) if curve_id == 0 else bytearray(x.to_bytes(32, "little"))
+    if curve_id == 0:
+        enc[0] |= 0x80
+    with pytest.raises(V.VerifyError):
+        V.g1_decompress(c, bytes(enc))
+    with pytest.raises(V.VerifyError):
+        V.g1_decompress(c, inf[:-1])
+    # a proof cut short, or with bytes appended, does not deserialize
+    vec = lambda items: len(items).to_bytes(8, "little") + b"".join(items)
+    g = mj.transcript.g1_bytes(pc, G)
+    fr = (5).to_bytes(32, "little")
+    blob = vec([g] * 5) + g + vec([g] * 5) + g + g + vec([fr] * 5) + vec([fr] * 4) + fr + b"\x00"
+    pr = V.deserialize_proof(c, blob)
+    assert pr["wires_poly_comms"] == [G] * 5 and pr["wire_sigma_evals"] == [5] * 4 and pr["plookup"] is None
+    for bad in (blob[:-1], blob + b"\x00", blob[:-1] + b"\x02"):
+        with pytest.raises(V.VerifyError):
+            V.deserialize_proof(c, bad)
