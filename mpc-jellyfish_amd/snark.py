@@ -179,3 +179,12 @@ def prove(rng: _rng.ChaChaRng, circuit: BenchCircuit, pk: _prover.TurboPlonkProv
     src = _prover.TranscriptChallenges(pk, circuit.public_input, extra_transcript_init_msg)
     core = pk.prove(circuit.wire_values, circuit.pub_input_values, src, blind, profile=profile)
     return core, serialize_proof(circuit.curve, core)
+
+
+def prove_with_link_hint(rng: _rng.ChaChaRng, circuit: BenchCircuit, pk: _prover.TurboPlonkProver, extra_transcript_init_msg: bytes | None = None):
+    """PlonkKzgSnark::prove_with_link_hint (snark.rs:81-119): the proof plus the LinkingHint -- the masked wire polynomial that
+    carries the proof-linking gates (wire PROOF_LINK_WIRE_IDX, device resident) and its commitment from round 1."""
+    from . import linking
+    core, proof_bytes = prove(rng, circuit, pk, extra_transcript_init_msg)
+    hint = linking.LinkingHint(pk.last["wire_polys"][linking.PROOF_LINK_WIRE_IDX].clone(), core.wires_poly_comms[linking.PROOF_LINK_WIRE_IDX])
+    return core, proof_bytes, hint

@@ -113,17 +113,20 @@ def golden_pt(p):
     return None if p is None else (int(p[0], 16), int(p[1], 16))
 
 
-def build_circuit(c, log_n, rng):
+def build_circuit(c, log_n, rng, reserved=None):
     """selectors (13 x n), sigma values (5 x n), k, wires (5 x n), public input (n): gates on every 4th
-    row family as in test_plonk_gpu, copy constraints as 3-cycles between free cells."""
+    row family as in test_plonk_gpu, copy constraints as 3-cycles between free cells.
+    reserved: {row: value} -- proof-linking gates (relation/src/gates: a(x) * 0 = 0, every selector zero) holding `value`
+    on wire 0 of that row."""
     n, r = 1 << log_n, c.r
+    reserved = reserved or {}
     k = [1, 7, 13, 17, 23]
     w_n = c.root_of_unity(log_n)
     w = [[rng.randrange(r) for _ in range(n)] for _ in range(5)]
     sel = [[0] * n for _ in range(13)]
     free = []
     for i in range(n):
-        kind = i % 4
+        kind = 3 if i in reserved else i % 4
         if kind == 0:
             sel[0][i] = sel[1][i] = 1; sel[10][i] = 1
             w[4][i] = (w[0][i] + w[1][i]) % r
@@ -135,6 +138,9 @@ def build_circuit(c, log_n, rng):
             sel[6][i] = 1; sel[9][i] = 2; sel[10][i] = 1
             w[4][i] = (pow(w[0][i], 5, r) + 2 * pow(w[3][i], 5, r)) % r
             free += [(1, i), (2, i)]
+        elif i in reserved:
+            w[0][i] = reserved[i] % r
+            free += [(j, i) for j in range(1, 5)]
         else:
             free += [(j, i) for j in range(5)]          # no gate on this row: every cell is free
     pi = [0] * n
