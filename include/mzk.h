@@ -220,6 +220,15 @@ MZK_API int32_t mzk_poly_mask_dev(int32_t curve_id, uint32_t n_polys, void* cons
 /* quotient of p(X) / (X - z), len - 1 coefficients into d_out (remainder dropped, as ark-poly's `/` does at
  * prover.rs:504-506).  d_out must not alias d_poly.  Asynchronous. */
 MZK_API int32_t mzk_poly_div_linear_dev(int32_t curve_id, const void* d_poly, uint64_t len, const uint64_t* z_mont, void* d_out, void* stream);
+/* floor quotient of p(X) by the vanishing polynomial of a proof-linking domain, Z_D(X) = prod_{i < count} (X - w^(first + i))
+ * with w the primitive 2^log_order-th root of unity (GroupLayout{alignment = log_order, offset = first, size = count},
+ * relation/src/proof_linking/mod.rs:16-54): len - count coefficients into d_out, remainder dropped.  Replaces
+ * compute_vanishing_polynomial + `&diff / &vanishing_poly` of compute_linking_quotient
+ * (plonk/src/proof_system/proof_linking.rs:119-158).  When p vanishes on the whole domain (a valid link) the quotient comes
+ * from two coset NTTs and a pointwise 1 / Z_D(x); otherwise the linear factors are divided out one by one -- same
+ * coefficients either way.  d_out must not alias d_poly.  The call synchronises the stream (it reads p at the roots). */
+MZK_API int32_t mzk_poly_div_roots_dev(int32_t curve_id, const void* d_poly, uint64_t len, uint32_t log_order, uint64_t first, uint64_t count,
+                                       void* d_out, void* stream);
 
 /* ---- device memory helpers for bindings without HIP of their own ---- */
 MZK_API int32_t mzk_dev_alloc(uint64_t bytes, void** out_dptr);

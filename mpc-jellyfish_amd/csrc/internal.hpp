@@ -38,7 +38,7 @@ struct DevBuf {
 };
 
 struct Workspace {
-    DevBuf ntt_scratch, scalars, hist, offs, cursor, sorted, buckets, collect, io, misc, digits, long_desc, long_parts, plonk_polys, plonk_out, pre_cnt, pre_off, pre_ce, pre_cb, poly_tmp, split;
+    DevBuf ntt_scratch, scalars, hist, offs, cursor, sorted, buckets, collect, io, misc, digits, long_desc, long_parts, plonk_polys, plonk_out, pre_cnt, pre_off, pre_ce, pre_cb, poly_tmp, split, link_tmp;
     void* h_collect = nullptr;
     size_t h_collect_cap = 0;
     hipEvent_t last_use = nullptr;
@@ -93,6 +93,8 @@ void jac_sum_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uint64_t*
 int32_t poly_eval_dispatch(int curve, const uint32_t* d_coeffs, uint64_t stride, uint64_t len, uint32_t batch, const uint32_t* x_mont, uint32_t* out_host,
                            hipStream_t st);
 int32_t poly_div_dispatch(int curve, const uint32_t* d_poly, uint64_t len, const uint32_t* z_mont, uint32_t* d_out, hipStream_t st);
+int32_t poly_div_roots_dispatch(int curve, const uint32_t* d_poly, uint64_t len, uint32_t log_order, uint64_t first, uint64_t count, uint32_t* d_out,
+                                hipStream_t st);
 int32_t poly_lincomb_dispatch(int curve, uint32_t n_terms, const uint32_t* const* d_polys, const uint64_t* lens, const uint32_t* scalars, uint32_t* d_out,
                               uint64_t out_len, hipStream_t st);
 int32_t poly_mask_dispatch(int curve, uint32_t n_rows, uint32_t* const* d_rows, uint64_t n, uint32_t n_blind, const uint32_t* blind_mont, hipStream_t st);

@@ -30,7 +30,7 @@ void DevBuf::release() {
     cap = 0;
 }
 void Workspace::release() {
-    for (DevBuf* b : {&ntt_scratch, &scalars, &hist, &offs, &cursor, &sorted, &buckets, &collect, &io, &misc, &digits, &long_desc, &long_parts, &plonk_polys, &plonk_out, &pre_cnt, &pre_off, &pre_ce, &pre_cb, &poly_tmp, &split}) b->release();
+    for (DevBuf* b : {&ntt_scratch, &scalars, &hist, &offs, &cursor, &sorted, &buckets, &collect, &io, &misc, &digits, &long_desc, &long_parts, &plonk_polys, &plonk_out, &pre_cnt, &pre_off, &pre_ce, &pre_cb, &poly_tmp, &split, &link_tmp}) b->release();
     if (h_collect) (void)hipHostFree(h_collect);
     h_collect = nullptr;
     h_collect_cap = 0;
@@ -553,6 +553,14 @@ int32_t mzk_poly_div_linear_dev(int32_t curve_id, const void* d_poly, uint64_t l
     if (!z_mont) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     return poly_div_dispatch(curve_id, reinterpret_cast<const uint32_t*>(d_poly), len, reinterpret_cast<const uint32_t*>(z_mont),
                              reinterpret_cast<uint32_t*>(d_out), (hipStream_t)stream);
+}
+int32_t mzk_poly_div_roots_dev(int32_t curve_id, const void* d_poly, uint64_t len, uint32_t log_order, uint64_t first, uint64_t count, void* d_out,
+                               void* stream) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    if ((!d_poly || !d_out) && len > count) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    return poly_div_roots_dispatch(curve_id, reinterpret_cast<const uint32_t*>(d_poly), len, log_order, first, count, reinterpret_cast<uint32_t*>(d_out),
+                                   (hipStream_t)stream);
 }
 
 // ---- device memory helpers --------------------------------------------------------------------------

@@ -215,4 +215,77 @@ __global__ void poly_mask_kernel(MaskArgs a) {
     store_fp<P>(p + (a.n + j) * 8, b);
 }
 
+// ---- division by the vanishing polynomial of a proof-linking domain (proof_linking.rs:119-158) -------------------------
+// Z_D(X) = prod_{i < count} (X - rho g^i).  When Z_D divides p, the quotient is p(x) / Z_D(x) pointwise on a coset that
+// avoids the roots; this kernel multiplies the coset evaluations by 1 / Z_D(x): thread t owns the K points
+// t, t + T, .., reads the roots from a table and inverts its K products with one field inversion (K = 8 on large domains,
+// fewer points per thread when the domain alone would not fill the chip).
+struct DivRootsArgs {
+    uint32_t* evals;
+    const uint32_t* roots;                                   // [count] rho g^i, Montgomery
+    unsigned long long threads;                              // T: n_points = K * T
+    unsigned int count;
+    uint32_t h[8], w[8], w_step[8];                          // coset offset, domain generator, w^T (Montgomery)
+};
+template <class P, int K>
+__global__ __launch_bounds__(POLY_THREADS) void poly_div_roots_pointwise_kernel(DivRootsArgs a) {
+    using F = Fp<P>;
+    const unsigned long long t = (unsigned long long)blockIdx.x * POLY_THREADS + threadIdx.x;
+    if (t >= a.threads) return;
+    auto cst = [](const uint32_t* c) { F r; for (int q = 0; q < 8; q++) r.l[q] = c[q]; return r; };
+    F x[K], z[K];
+    const F step = cst(a.w_step);
+    x[0] = cst(a.h) * pow_u64(cst(a.w), t);
+    z[0] = F::one();
+#pragma unroll
+    for (int k = 1; k < K; k++) { x[k] = x[k - 1] * step; z[k] = F::one(); }
+    for (unsigned int i = 0; i < a.count; i++) {
+        const F r = load_fp<P>(a.roots + (size_t)i * 8);                 // same address in every lane
+#pragma unroll
+        for (int k = 0; k < K; k++) z[k] = z[k] * (x[k] - r);
+    }
+    // x[k] := z[0] .. z[k]; one inversion; unwind
+    x[0] = z[0];
+#pragma unroll
+    for (int k = 1; k < K; k++) x[k] = x[k - 1] * z[k];
+    F iv = inv(x[K - 1]);
+#pragma unroll
+    for (int k = K - 1; k > 0; k--) {
+        const F zi = iv * x[k - 1];
+        iv = iv * z[k];
+        z[k] = zi;
+    }
+    z[0] = iv;
+#pragma unroll
+    for (int k = 0; k < K; k++) {
+        uint32_t* e = a.evals + (t + (unsigned long long)k * a.threads) * 8;
+        store_fp<P>(e, load_fp<P>(e) * z[k]);
+    }
+}
+// out[j] = sum_k c^k p[j + k N], j < N:  p mod (X^N - c) -- p on the N points x with x^N = c is this polynomial on them
+template <class P>
+__global__ __launch_bounds__(POLY_THREADS) void poly_fold_kernel(const uint32_t* __restrict__ p, unsigned long long len, unsigned long long N, DivRootsArgs a,
+                                                                  uint32_t* __restrict__ out) {
+    using F = Fp<P>;
+    const unsigned long long j = (unsigned long long)blockIdx.x * POLY_THREADS + threadIdx.x;
+    if (j >= N) return;
+    F acc = F::zero();
+    if (j < len) {
+        F c;
+#pragma unroll
+        for (int q = 0; q < 8; q++) c.l[q] = a.h[q];                     // the fold multiplier travels in a.h
+        const unsigned long long kmax = (len - 1 - j) / N;
+        acc = load_fp<P>(p + (j + kmax * N) * 8);
+        for (unsigned long long k = kmax; k-- > 0;) acc = acc * c + load_fp<P>(p + (j + k * N) * 8);
+    }
+    store_fp<P>(out + j * 8, acc);
+}
+// out[i] = src[((first + i) mod order) * step]: the evaluations of p at the roots, out of an NTT over a domain that contains them
+template <class P>
+__global__ void poly_gather_roots_kernel(const uint32_t* __restrict__ src, unsigned long long first, unsigned long long order_mask, unsigned long long step,
+                                         unsigned long long count, uint32_t* __restrict__ out) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < count) store_fp<P>(out + i * 8, load_fp<P>(src + ((first + i) & order_mask) * step * 8));
+}
+
 }  // namespace mzk

@@ -67,6 +67,94 @@ int32_t div_run(const uint32_t* d_poly, uint64_t len, const uint32_t* z_mont, ui
     return MZK_OK;
 }
 
+// floor(p / prod_{i<count} (X - w^(first+i))), w the primitive 2^log_order-th root of unity.  Fast path (the roots are distinct
+// and p vanishes on all of them, i.e. the remainder is zero): coset NTT, pointwise 1/Z_D, inverse coset NTT.  Otherwise the
+// linear factors are divided out one at a time -- floor division by a product is the composition of the floor divisions.
+template <class P>
+int32_t div_roots_run(int curve, const uint32_t* d_poly, uint64_t len, uint32_t log_order, uint64_t first, uint64_t count, uint32_t* d_out, hipStream_t st) {
+    using F = Fp<P>;
+    if (log_order > (uint32_t)P::TWO_ADICITY) { set_error("log_order exceeds the two-adicity of the scalar field"); return MZK_ERR_INVALID_ARG; }
+    if (len <= count) return MZK_OK;                               // quotient is the zero polynomial: nothing to write
+    const uint64_t out_len = len - count;
+    if (count == 0) {
+        HIP_TRY(hipMemcpyAsync(d_out, d_poly, len * 32, hipMemcpyDeviceToDevice, st));
+        return MZK_OK;
+    }
+    F g = F::from_const(P::ROOT);
+    for (int i = (int)log_order; i < P::TWO_ADICITY; i++) g = sqr(g);
+    const F root0 = pow_u64(g, first);
+    // the quotient has out_len coefficients: a coset of 2^log_q >= out_len points determines it, and p on that coset is
+    // (p mod X^N - h^N) on it; the roots of Z_D are 2^log_order-th roots of unity, where p is (p mod X^Ne - 1)
+    int log_q = 6;
+    while ((1ull << log_q) < out_len) log_q++;
+    const int log_e = log_q > (int)log_order ? log_q : (int)log_order;
+    bool fast = len >= 64 && count <= (1ull << log_order) && log_e <= P::TWO_ADICITY && log_e <= 27;
+    const uint64_t Ne = 1ull << log_e, Nq = 1ull << log_q;
+    MZK_TRY(ws_acquire(st));
+    MZK_TRY(g_ws.link_tmp.reserve(((fast && Ne > 2 * len) ? Ne : 2 * len) * 32 + 2 * count * 32));     // either path may follow the root check
+    uint32_t* T = g_ws.link_tmp.as<uint32_t>();
+    uint32_t* d_at_roots = T + (((fast && Ne > 2 * len) ? Ne : 2 * len)) * 8;
+    uint32_t* d_roots = d_at_roots + count * 8;
+    DivRootsArgs a;
+    std::memset(&a, 0, sizeof a);
+    std::vector<uint32_t> roots;
+    if (fast) {
+        roots.resize(count * 8);
+        F cur = root0;
+        for (uint64_t i = 0; i < count; i++) { std::memcpy(&roots[i * 8], cur.l, 32); cur = cur * g; }
+        HIP_TRY(hipMemcpyAsync(d_roots, roots.data(), count * 32, hipMemcpyHostToDevice, st));
+        std::memcpy(a.h, P::R1, 32);
+        hipLaunchKernelGGL((poly_fold_kernel<P>), dim3((unsigned)((Ne + POLY_THREADS - 1) / POLY_THREADS)), dim3(POLY_THREADS), 0, st, d_poly, len, Ne, a, T);
+        MZK_TRY(ntt_dispatch(curve, T, Ne, log_e, false, nullptr, 1, Ne, st));
+        hipLaunchKernelGGL((poly_gather_roots_kernel<P>), dim3((unsigned)((count + 255) / 256)), dim3(256), 0, st, T, first, (1ull << log_order) - 1,
+                           1ull << (log_e - (int)log_order), count, d_at_roots);
+        HIP_TRY(hipGetLastError());
+        std::vector<uint32_t> at_roots(count * 8);
+        HIP_TRY(hipMemcpyAsync(at_roots.data(), d_at_roots, count * 32, hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));                             // (also: the roots table has left the host vector)
+        for (uint32_t v : at_roots) if (v) { fast = false; break; }
+    }
+    if (fast) {
+        const F h = F::from_const(P::GENERATOR);
+        const F h_n = pow_u64(h, Nq);
+        std::memcpy(a.h, h_n.l, 32);
+        hipLaunchKernelGGL((poly_fold_kernel<P>), dim3((unsigned)((Nq + POLY_THREADS - 1) / POLY_THREADS)), dim3(POLY_THREADS), 0, st, d_poly, len, Nq, a, T);
+        MZK_TRY(ntt_dispatch(curve, T, Nq, log_q, false, P::GENERATOR, 1, Nq, st));
+        const int K = log_q >= 20 ? 8 : log_q >= 18 ? 2 : 1;            // points per thread: keep >= 2^17 threads where the domain allows
+        a.evals = T;
+        a.roots = d_roots;
+        a.threads = Nq / K;
+        a.count = (unsigned)count;
+        F w = F::from_const(P::ROOT);
+        for (int i = log_q; i < P::TWO_ADICITY; i++) w = sqr(w);
+        const F w_step = pow_u64(w, a.threads);
+        std::memcpy(a.h, h.l, 32);
+        std::memcpy(a.w, w.l, 32);
+        std::memcpy(a.w_step, w_step.l, 32);
+        const dim3 grid((unsigned)((a.threads + POLY_THREADS - 1) / POLY_THREADS));
+        if (K == 8) hipLaunchKernelGGL((poly_div_roots_pointwise_kernel<P, 8>), grid, dim3(POLY_THREADS), 0, st, a);
+        else if (K == 2) hipLaunchKernelGGL((poly_div_roots_pointwise_kernel<P, 2>), grid, dim3(POLY_THREADS), 0, st, a);
+        else hipLaunchKernelGGL((poly_div_roots_pointwise_kernel<P, 1>), grid, dim3(POLY_THREADS), 0, st, a);
+        HIP_TRY(hipGetLastError());
+        MZK_TRY(ntt_dispatch(curve, T, Nq, log_q, true, P::GENERATOR, 1, Nq, st));
+        HIP_TRY(hipMemcpyAsync(d_out, T, out_len * 32, hipMemcpyDeviceToDevice, st));
+    } else {
+        uint32_t* buf[2] = {T, T + len * 8};
+        const uint32_t* cur = d_poly;
+        uint64_t cur_len = len;
+        F root = root0;
+        for (uint64_t i = 0; i < count; i++) {
+            uint32_t* dst = (i + 1 == count) ? d_out : buf[i & 1];
+            MZK_TRY((div_run<P>(cur, cur_len, root.l, dst, st)));
+            cur = dst;
+            cur_len--;
+            root = root * g;
+        }
+    }
+    MZK_TRY(ws_release(st));
+    return MZK_OK;
+}
+
 template <class P>
 int32_t lincomb_run(uint32_t n_terms, const uint32_t* const* d_polys, const uint64_t* lens, const uint32_t* scalars, uint32_t* d_out, uint64_t out_len,
                     hipStream_t st) {
@@ -98,6 +186,12 @@ int32_t poly_eval_dispatch(int curve, const uint32_t* d_coeffs, uint64_t stride,
 int32_t poly_div_dispatch(int curve, const uint32_t* d_poly, uint64_t len, const uint32_t* z_mont, uint32_t* d_out, hipStream_t st) {
     if (curve == 0) return div_run<BlsFr>(d_poly, len, z_mont, d_out, st);
     if (curve == 1) return div_run<BnFr>(d_poly, len, z_mont, d_out, st);
+    set_error("unknown curve_id");
+    return MZK_ERR_INVALID_ARG;
+}
+int32_t poly_div_roots_dispatch(int curve, const uint32_t* d_poly, uint64_t len, uint32_t log_order, uint64_t first, uint64_t count, uint32_t* d_out, hipStream_t st) {
+    if (curve == 0) return div_roots_run<BlsFr>(curve, d_poly, len, log_order, first, count, d_out, st);
+    if (curve == 1) return div_roots_run<BnFr>(curve, d_poly, len, log_order, first, count, d_out, st);
     set_error("unknown curve_id");
     return MZK_ERR_INVALID_ARG;
 }

@@ -122,9 +122,17 @@ def msm_bigint(pp: UnivariateProverParam, bigints, base_offset: int = 0, scalars
 
 class UnivariateKzgPCS:
     @staticmethod
-    def commit(prover_param: UnivariateProverParam, poly: np.ndarray) -> Commitment:
-        """mod.rs:90-116: degree guard, skip low-order zero coefficients, MSM, into_affine."""
+    def commit(prover_param: UnivariateProverParam, poly) -> Commitment:
+        """mod.rs:90-116: degree guard, skip low-order zero coefficients, MSM, into_affine.
+        poly: (len, 4) Montgomery coefficients, host array or CUDA tensor."""
         pp = prover_param
+        if _is_torch(poly) and poly.is_cuda and 0 < poly.shape[0] <= pp.length:
+            # device-resident coefficients that fit the key: zero coefficients contribute nothing to the MSM, so skipping the
+            # leading ones (mod.rs:106) needs no host copy
+            jac = msm_bigint(pp, poly.contiguous(), 0, scalars_are_mont=True)
+            return Commitment(pp.curve, jacobian_to_affine(pp.curve, jac[None])[0])
+        if _is_torch(poly):
+            poly = poly.cpu().numpy().view(np.uint64)
         coeffs = np.ascontiguousarray(poly, dtype=np.uint64).reshape(-1, 4)
         degree, lead = _degree_and_leading_zeros(coeffs)
         if degree > pp.length:                                             # mod.rs:98
@@ -133,6 +141,8 @@ class UnivariateKzgPCS:
         if lead + body.shape[0] > pp.length:
             # degree == powers_of_g.len(): passes the reference's guard, then ark-ec truncates to min(len)
             body = body[:pp.length - lead]
+        if not body.size:
+            lead = 0                                                       # the zero polynomial (ark-poly keeps no coefficients for it)
         L = _lib.ensure_init()
         out = np.empty((2, pp.curve.fq_limbs), dtype=np.uint64)
         _lib.check(L.mzk_msm_affine(pp.handle, pp.offset + lead, body.ctypes.data_as(C.c_void_p) if body.size else None,
@@ -175,7 +185,7 @@ class UnivariateKzgPCS:
         if t.shape[0] == 1:                                                # constant polynomial: zero witness
             return Commitment(pp.curve, np.zeros((2, pp.curve.fq_limbs), dtype=np.uint64)), ev
         witness = _poly.div_by_linear(pp.curve, t, point)
-        proof = UnivariateKzgPCS.commit(pp, witness.cpu().numpy().view(np.uint64))
+        proof = UnivariateKzgPCS.commit(pp, witness)
         return proof, ev
 
     @staticmethod

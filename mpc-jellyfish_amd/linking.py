@@ -7,9 +7,10 @@ proof-linking sub-protocol ("proof-linking commits through th
     LinkingProof::serialize_compressed        proof_linking.rs:33-39
 
 The reference expands Z_D(X) = prod (X - g^(offset+i)) and runs one dense long division (proof_linking.rs:119-158); here the
-difference a_1 - a_2 stays on the device and is divided by the `size` linear factors one after another with the synthetic
-division kernel of round 5 (mzk_poly_div_linear_dev) -- floor division by a product equals the composition of the floor
-divisions by its factors, so the quotient (remainder dropped, as ark-poly drops it) has the same coefficients.  The two
+difference a_1 - a_2 stays on the device and mzk_poly_div_roots_dev divides it: when it vanishes on the link domain (a valid
+link) by two coset NTTs around a pointwise 1 / Z_D(x), otherwise by the `size` linear factors one after another with the
+synthetic division of round 5 -- floor division by a product equals the composition of the floor divisions by its
+factors, so the quotient (remainder dropped, as ark-poly drops it) has the reference's coefficients in both cases.  The two
 commitments are MSMs over the registered SRS (mzk_msm_affine).  There is no CPU path: without the HIP library every call
 raises.
 """
@@ -97,22 +98,15 @@ def compute_quotient_challenge(curve, a1_comm: kzg.Commitment, a2_comm: kzg.Comm
 def compute_linking_quotient(curve, a1, a2, layout: GroupLayout):
     """(a_1 - a_2) / Z_D on the device (proof_linking.rs:119-134).  Returns (difference, quotient) as CUDA tensors."""
     c = _curve(curve)
+    layout.get_domain_generator(c)                          # two-adicity check
     diff = poly.lincomb(c, [(1, a1), (c.r - 1, a2)])
-    g = layout.get_domain_generator(c)
-    root = pow(g, layout.offset, c.r)
-    q = diff
-    for _ in range(layout.size):
-        if q.shape[0] == 0:
-            break
-        q = poly.div_by_linear(c, q, root)
-        root = root * g % c.r
-    return diff, q
+    return diff, poly.div_by_roots_of_unity(c, diff, layout.alignment, layout.offset, layout.size)
 
 
 def _commit_dev(ck, t) -> kzg.Commitment:
     if t.shape[0] == 0:
         return kzg.Commitment(ck.curve, np.zeros((2, ck.curve.fq_limbs), dtype=np.uint64))
-    return kzg.UnivariateKzgPCS.commit(ck, t.cpu().numpy().view(np.uint64))
+    return kzg.UnivariateKzgPCS.commit(ck, t)
 
 
 def link_proofs(lhs_link_hint: LinkingHint, rhs_link_hint: LinkingHint, group_layout: GroupLayout, commit_key: kzg.UnivariateProverParam) -> LinkingProof:

@@ -70,6 +70,19 @@ def div_by_linear(curve, poly_dev, z: int, stream=None):
     return out
 
 
+def div_by_roots_of_unity(curve, poly_dev, log_order: int, first: int, count: int, stream=None):
+    """Quotient of p(X) / prod_{i<count} (X - w^(first+i)), w the primitive 2^log_order-th root of unity, as a
+    (len - count, 4) CUDA tensor (remainder dropped) -- the division of `compute_linking_quotient`
+    (plonk/src/proof_system/proof_linking.rs:119-158).  The call synchronises."""
+    import torch
+    c = _curve(curve)
+    n = poly_dev.shape[0]
+    out = torch.zeros((max(n - count, 0), 4), dtype=torch.int64, device=poly_dev.device)
+    _lib.check(_lib.ensure_init().mzk_poly_div_roots_dev(c.curve_id, poly_dev.data_ptr(), n, log_order, first, count, out.data_ptr(),
+                                                         _stream(poly_dev, stream)), "mzk_poly_div_roots_dev")
+    return out
+
+
 def mask(curve, rows, n: int, blinders, stream=None):
     """`Prover::mask_polynomial` (prover.rs:463-486) on device rows, in place: rows[i] (a CUDA tensor view of at least
     n + h slots holding n coefficients) += (b_0 + b_1 X + .. )(X^n - 1) with blinders[i] = [b_0, .., b_{h-1}] (Python ints)."""

@@ -146,3 +146,41 @@ def test_link_large_polynomials(gpu, mj, pyref):
     assert L.verify_link_proof(pc, fresh(), *args, olayout, srs_beta)
     assert not L.verify_link_proof(pc, fresh(), *args, L.GroupLayout(12, 17, 301), srs_beta)
     ck.release()
+
+
+@pytest.mark.parametrize("curve_id", [0, 1])
+def test_div_by_roots_of_unity_matches_long_division(gpu, mj, pyref, curve_id):
+    """mzk_poly_div_roots_dev against the dense long division by the expanded vanishing polynomial (proof_linking.rs:119-158),
+    on both of its paths: exact (p vanishes on the domain: NTT path) and with a remainder (factor-by-factor path), roots finer
+    or coarser than the polynomial's length, repeated roots, and the degenerate lengths."""
+    import torch
+    import pyref_linking as L
+    c, pc = mj.params.CURVES[curve_id], pyref.CURVES[curve_id]
+    r = c.r
+    rng = random.Random(300 + curve_id)
+    dev = lambda ints: torch.from_numpy(fr_mont_limbs(c, ints).view(np.int64)).cuda()
+    ints = lambda t: fr_from_mont_limbs(c, t.cpu().numpy().view(np.uint64).reshape(-1, 4)) if t.shape[0] else []
+    cases = [(100, 5, 3, 7), (100, 9, 500, 12), (1500, 6, 60, 50), (5000, 13, 100, 64), (64, 6, 0, 64), (777, 10, 1020, 9), (4097, 12, 0, 1)]
+    for length, log_order, first, count in cases:
+        lay = L.GroupLayout(log_order, first, count)
+        z = L.vanishing_polynomial(pc, lay)
+        s = [rng.randrange(r) for _ in range(length - count)]
+        exact = [0] * length                                               # s * Z_D
+        for i, x in enumerate(s):
+            for j, y in enumerate(z):
+                exact[i + j] = (exact[i + j] + x * y) % r
+        got = ints(mj.poly.div_by_roots_of_unity(c, dev(exact), log_order, first, count))
+        assert got == s, ("exact", length, log_order, first, count)
+        rough = [(v + rng.randrange(r)) % r for v in exact]                 # a remainder appears
+        got = ints(mj.poly.div_by_roots_of_unity(c, dev(rough), log_order, first, count))
+        assert L.pstrip(got) == L.pdiv(pc, rough, z), ("with remainder", length, log_order, first, count)
+    # more roots than the order of w: the factors repeat; still the floor division by their product
+    p = [rng.randrange(r) for _ in range(90)]
+    got = ints(mj.poly.div_by_roots_of_unity(c, dev(p), 3, 2, 11))
+    assert L.pstrip(got) == L.pdiv(pc, p, L.vanishing_polynomial(pc, L.GroupLayout(3, 2, 11)))
+    # degenerate lengths
+    assert mj.poly.div_by_roots_of_unity(c, dev(p[:5]), 4, 0, 5).shape[0] == 0
+    assert mj.poly.div_by_roots_of_unity(c, dev(p[:5]), 4, 0, 9).shape[0] == 0
+    assert ints(mj.poly.div_by_roots_of_unity(c, dev(p[:5]), 4, 3, 0)) == p[:5]
+    with pytest.raises(mj.MzkError):
+        mj.poly.div_by_roots_of_unity(c, dev(p), 33, 0, 2)
