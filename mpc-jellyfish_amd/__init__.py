@@ -15,6 +15,6 @@ The directory name carries a hyphen, so import it with
 from . import params  # noqa: F401
 from .lib import MzkError, lib_path, load  # noqa: F401
 from .domain import Radix2EvaluationDomain  # noqa: F401
-from . import linking, plonk, poly, prover, rng, sharding, snark, transcript  # noqa: F401
+from . import batch, linking, plonk, poly, prover, rng, sharding, snark, transcript  # noqa: F401
 from .kzg import (Commitment, PCSError, UnivariateKzgPCS, UnivariateProverParam,  # noqa: F401
                   jacobian_to_affine, msm_bigint, msm_bigint_batch)

@@ -17,6 +17,9 @@ from . import lib as _lib
 from .params import curve as _curve, fr_from_mont, fr_to_mont
 
 
+MAX_TERMS = 32                                              # POLY_MAX_TERMS of csrc/poly.cuh: terms of one lincomb launch
+
+
 def _stream(t, stream):
     import torch
     return torch.cuda.current_stream(t.device).cuda_stream if stream is None else stream

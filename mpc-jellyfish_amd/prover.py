@@ -221,94 +221,117 @@ class TurboPlonkProver:
             jac = kzg.msm_bigint_batch(self.ck, [p.contiguous() for p in polys], scalars_are_mont=True)
         return [kzg.Commitment(self.curve, xy) for xy in kzg.jacobian_to_affine(self.curve, jac)]
 
-    def prove(self, wire_values, pub_input_values, ch, blind: Blinders, profile: bool = False) -> ProofCore:
-        """ch: ProverChallenges (fixed) or a challenge source (FixedChallenges / TranscriptChallenges)."""
-        src = FixedChallenges(ch) if isinstance(ch, ProverChallenges) else ch
+    # ---- the rounds of one instance, as separate stages so that batch_prove (batch.py) can interleave several instances the way
+    # ---- batch_prove_internal does (snark.rs:263-431); `st` carries what Oracles (structs.rs:875-887) carries, on the device
+    def _stage_round1(self, wire_values, pub_input_values, blind: Blinders, tick):
+        """prover.rs:72-87: wire and public-input iNTTs, masking, W commitments."""
         import time
+        import types
         import torch
-        c, n, r, W, ultra = self.curve, self.n, self.curve.r, self.W, self.ultra
-        m = 8 * n
-        tm = {}
-
-        def tick(name, t0):
-            if profile:
-                torch.cuda.synchronize()
-                tm[name] = round((time.perf_counter() - t0) * 1e3, 3)
-
+        n, W, ultra = self.n, self.W, self.ultra
+        st = types.SimpleNamespace(blind=blind)
         dev = self.fixed.device
-        wv = wire_values if hasattr(wire_values, "is_cuda") else torch.from_numpy(np.ascontiguousarray(wire_values).view(np.int64)).to(dev)
+        st.wv = wire_values if hasattr(wire_values, "is_cuda") else torch.from_numpy(np.ascontiguousarray(wire_values).view(np.int64)).to(dev)
         pv = pub_input_values if hasattr(pub_input_values, "is_cuda") else torch.from_numpy(np.ascontiguousarray(pub_input_values).view(np.int64)).to(dev)
         # one slab for round 3: rows 0..W-1 wires, W z, W+1 public input (, h_1, h_2, Plookup product); coefficients in the first n+3 columns
-        Z, PI, H1, PL = W, W + 1, W + 2, W + 4
-        rows = W + 2 + (3 if ultra else 0)
+        st.Z, st.PI, st.H1, st.PL = W, W + 1, W + 2, W + 4
         t0 = time.perf_counter()
         slab = self._slab                                               # only the first n + 3 columns are read (in_len of the coset NTT)
         slab[:, n:n + 3] = 0
-        # ---- round 1 (prover.rs:72-87)
         coeff = self._coeff
-        coeff[:W] = wv
+        coeff[:W] = st.wv
         coeff[W] = pv
         self.domain.ifft_in_place(coeff)
         slab[:W, :n] = coeff[:W]
-        slab[PI, :n] = coeff[W]
+        slab[st.PI, :n] = coeff[W]
         self._mask(slab, list(range(W)), blind.wires)
-        wire_polys = [slab[i, :n + 2] for i in range(W)]
         tick("r1_ntt_mask", t0)
         t0 = time.perf_counter()
-        wires_comms = self._commit(wire_polys)
+        wires_comms = self._commit([slab[i, :n + 2] for i in range(W)])
         tick("r1_commit", t0)
-        tau = src.after_round1(wires_comms)
-        # ---- round 1.5 (prover.rs:89-118; constraint_system.rs:1290-1309, 1370-1417)
-        h_comms = None
-        if ultra:
-            t0 = time.perf_counter()
-            table, lookup, sorted_vec = plonk.compute_lookup_sorted_vec(self.pk, tau, wv)
-            hh = torch.empty((2, n, 4), dtype=torch.int64, device=dev)
-            hh[0] = sorted_vec[:n]
-            hh[1] = sorted_vec[n - 1:]
-            self.domain.ifft_in_place(hh)
-            slab[H1:H1 + 2, :n] = hh
-            self._mask(slab, [H1, H1 + 1], blind.h)
-            tick("r1_5_sorted_vec", t0)
-            t0 = time.perf_counter()
-            h_comms = self._commit([slab[H1, :n + 3], slab[H1 + 1, :n + 3]])
-            tick("r1_5_commit", t0)
-        # ---- round 2 (prover.rs:125-141; constraint_system.rs:1197-1223)
+        return st, wires_comms
+
+    def _stage_round1_5(self, st, tau, tick):
+        """prover.rs:89-118; constraint_system.rs:1290-1309, 1370-1417 (UltraPlonk only; None otherwise)."""
+        import time
+        import torch
+        st.tau = tau
+        if not self.ultra:
+            return None
+        n, slab = self.n, self._slab
         t0 = time.perf_counter()
-        beta, gamma = src.after_round1_5(h_comms)
-        plonk.compute_prod_permutation_polynomial_dev(self.pk, beta, gamma, wv.contiguous(), out_dev=coeff[0])
-        slab[Z, :n] = coeff[0]
-        self._mask(slab, [Z], [blind.z])
-        z_poly = slab[Z, :n + 3]
+        st.table, st.lookup, st.sorted_vec = plonk.compute_lookup_sorted_vec(self.pk, tau, st.wv)
+        hh = torch.empty((2, n, 4), dtype=torch.int64, device=self.fixed.device)
+        hh[0] = st.sorted_vec[:n]
+        hh[1] = st.sorted_vec[n - 1:]
+        self.domain.ifft_in_place(hh)
+        slab[st.H1:st.H1 + 2, :n] = hh
+        self._mask(slab, [st.H1, st.H1 + 1], st.blind.h)
+        tick("r1_5_sorted_vec", t0)
+        t0 = time.perf_counter()
+        h_comms = self._commit([slab[st.H1, :n + 3], slab[st.H1 + 1, :n + 3]])
+        tick("r1_5_commit", t0)
+        return h_comms
+
+    def _stage_round2(self, st, beta, gamma, tick):
+        """prover.rs:125-141; constraint_system.rs:1197-1223"""
+        import time
+        n, slab, coeff = self.n, self._slab, self._coeff
+        st.beta, st.gamma = beta, gamma
+        t0 = time.perf_counter()
+        plonk.compute_prod_permutation_polynomial_dev(self.pk, beta, gamma, st.wv.contiguous(), out_dev=coeff[0])
+        slab[st.Z, :n] = coeff[0]
+        self._mask(slab, [st.Z], [st.blind.z])
         tick("r2_product", t0)
         t0 = time.perf_counter()
-        z_comm = self._commit([z_poly])[0]
+        z_comm = self._commit([slab[st.Z, :n + 3]])[0]
         tick("r2_commit", t0)
-        # ---- round 2.5 (prover.rs:143-183; constraint_system.rs:1311-1368)
-        pl_comm = None
-        if ultra:
-            t0 = time.perf_counter()
-            plonk.compute_lookup_prod_polynomial(self.pk, beta, gamma, table, lookup, sorted_vec, out_dev=coeff[0])
-            slab[PL, :n] = coeff[0]
-            self._mask(slab, [PL], [blind.prod_lookup])
-            tick("r2_5_product", t0)
-            t0 = time.perf_counter()
-            pl_comm = self._commit([slab[PL, :n + 3]])[0]
-            tick("r2_5_commit", t0)
-        # ---- round 3 (prover.rs:192-209, 512-673, 902-960)
+        return z_comm
+
+    def _stage_round2_5(self, st, tick):
+        """prover.rs:143-183; constraint_system.rs:1311-1368 (UltraPlonk only)"""
+        import time
+        if not self.ultra:
+            return None
+        n, slab, coeff = self.n, self._slab, self._coeff
         t0 = time.perf_counter()
-        keep = self._keep
+        plonk.compute_lookup_prod_polynomial(self.pk, st.beta, st.gamma, st.table, st.lookup, st.sorted_vec, out_dev=coeff[0])
+        slab[st.PL, :n] = coeff[0]
+        self._mask(slab, [st.PL], [st.blind.prod_lookup])
+        tick("r2_5_product", t0)
+        t0 = time.perf_counter()
+        pl_comm = self._commit([slab[st.PL, :n + 3]])[0]
+        tick("r2_5_commit", t0)
+        return pl_comm
+
+    def _stage_quotient(self, st, alpha, tick):
+        """prover.rs:512-673 for this instance: the quotient's 8n coefficients into self._quot (the sum over instances and the
+        split are the caller's: prover.rs:661-669, 902-960)."""
+        import time
+        c, n = self.curve, self.n
+        st.alpha = alpha
+        t0 = time.perf_counter()
+        slab, keep, quot = self._slab, self._keep, self._quot
         keep.copy_(slab[:, :n + 3])                                      # coefficient forms survive the in-place coset NTT
-        quot = self._quot
-        alpha = src.after_round2(z_comm, pl_comm)
+        ch = plonk.Challenges(alpha, st.beta, st.gamma, st.tau)
         if self.pk.classes is None:
-            plonk.compute_quotient_polynomial_dev(self.pk, plonk.Challenges(alpha, beta, gamma, tau), slab, n + 3, quot)
+            plonk.compute_quotient_polynomial_dev(self.pk, ch, slab, n + 3, quot)
         else:                                                            # SURVEY.md 8(e).3: local classes, one exchange, 8-point iDFT per coefficient
-            local = plonk.compute_quotient_chunked_dev(self.pk, plonk.Challenges(alpha, beta, gamma, tau), slab, n + 3)
+            local = plonk.compute_quotient_chunked_dev(self.pk, ch, slab, n + 3)
             every = self.quotient_gather(local) if self.quotient_gather is not None else local
             plonk.combine_quotient_classes(c, n, every.contiguous(), out_dev=quot)
         tick("r3_quotient", t0)
-        t0 = time.perf_counter()
+        st.wire_polys = [keep[i, :n + 2] for i in range(self.W)]
+        st.z_poly = keep[st.Z]
+        if self.ultra:
+            st.h1, st.h2, st.pl_poly = keep[st.H1], keep[st.H1 + 1], keep[st.PL]
+        return quot
+
+    def _split_quotient(self, quot, blind_quot):
+        """split_quotient_polynomial (prover.rs:902-960): W slices of n + 2 coefficients, masked by W - 1 scalars."""
+        import torch
+        c, n, r, W = self.curve, self.n, self.curve.r, self.W
+        dev = self.fixed.device
         expected = W * (n + 1) + 2                                       # quotient_polynomial_degree, prover.rs:1125-1128
         split = []
         last = 0
@@ -318,50 +341,51 @@ class TurboPlonkProver:
             p = torch.zeros((n + 3, 4), dtype=torch.int64, device=dev)
             p[:hi - lo] = quot[lo:hi]
             if i < W - 1:
-                p[n + 2] = torch.from_numpy(fr_to_mont(c, [blind.quot[i]]).view(np.int64)).to(dev)[0]
+                p[n + 2] = torch.from_numpy(fr_to_mont(c, [blind_quot[i]]).view(np.int64)).to(dev)[0]
             if last:
                 negl = torch.from_numpy(fr_to_mont(c, [(-last) % r]).view(np.int64)).to(dev)
                 poly.lincomb(c, [(1, p[:1].clone()), (1, negl)], out=p[:1])
-            last = blind.quot[i] if i < W - 1 else 0
+            last = blind_quot[i] if i < W - 1 else 0
             split.append(p if i < W - 1 else p[:hi - lo])
-        tick("r3_split", t0)
-        t0 = time.perf_counter()
-        split_comms = self._commit(split)
-        tick("r3_commit", t0)
-        # ---- round 4 (prover.rs:216-299)
-        t0 = time.perf_counter()
-        wire_polys = [keep[i, :n + 2] for i in range(W)]
-        z_poly = keep[Z]
-        zeta = src.after_round3(split_comms)
-        tick("r4_transcript", t0)
+        return split
+
+    def _stage_round4(self, st, zeta, tick):
+        """compute_evaluations / compute_plookup_evaluations (prover.rs:216-299)"""
+        import time
+        c, n, r, W = self.curve, self.n, self.curve.r, self.W
+        keep = self._keep
+        st.zeta = zeta
         t0 = time.perf_counter()
         zeta_w = zeta * self.w_n % r
-        sig = [self.fixed[self.sigma0 + j] for j in range(W)]
-        wires_evals = poly.evaluate(c, keep[:W], zeta, length=n + 2)
-        wire_sigma_evals = poly.evaluate(c, self.fixed[self.sigma0:self.sigma0 + W - 1], zeta)
-        perm_next_eval = poly.evaluate(c, z_poly, zeta_w)[0]
-        pe = None
-        if ultra:
+        st.wires_evals = poly.evaluate(c, keep[:W], zeta, length=n + 2)
+        st.wire_sigma_evals = poly.evaluate(c, self.fixed[self.sigma0:self.sigma0 + W - 1], zeta)
+        st.perm_next_eval = poly.evaluate(c, st.z_poly, zeta_w)[0]
+        st.pe = None
+        if self.ultra:
             tick("r4_evals", t0)
             t0 = time.perf_counter()
             tabs = self.fixed[self.tab0:self.tab0 + 4]                    # range, key, table_dom_sep, q_dom_sep
             q_lookup = self.fixed[13]
-            h1, h2, pl_poly = keep[H1], keep[H1 + 1], keep[PL]
             at_zeta = poly.evaluate(c, tabs, zeta)
             at_next = poly.evaluate(c, tabs[:3], zeta_w)
             pe = {"range_table_eval": at_zeta[0], "key_table_eval": at_zeta[1], "table_dom_sep_eval": at_zeta[2], "q_dom_sep_eval": at_zeta[3],
                   "range_table_next_eval": at_next[0], "key_table_next_eval": at_next[1], "table_dom_sep_next_eval": at_next[2],
-                  "h_1_eval": poly.evaluate(c, h1, zeta)[0], "q_lookup_eval": poly.evaluate(c, q_lookup, zeta)[0],
+                  "h_1_eval": poly.evaluate(c, st.h1, zeta)[0], "q_lookup_eval": poly.evaluate(c, q_lookup, zeta)[0],
                   "q_lookup_next_eval": poly.evaluate(c, q_lookup, zeta_w)[0]}
-            nx = poly.evaluate(c, keep[[PL, H1, H1 + 1, 3, 4]], zeta_w)
+            nx = poly.evaluate(c, keep[[st.PL, st.H1, st.H1 + 1, 3, 4]], zeta_w)
             pe.update({"prod_next_eval": nx[0], "h_1_next_eval": nx[1], "h_2_next_eval": nx[2], "w_3_next_eval": nx[3], "w_4_next_eval": nx[4]})
+            st.pe = pe
             tick("r4_5_plookup_evals", t0)
         else:
             tick("r4_evals", t0)
-        # ---- round 5: linearisation polynomial (prover.rs:963-1112, 343-358) and openings (362-460, 490-509)
-        t0 = time.perf_counter()
-        v_ch = src.after_round4(wires_evals, wire_sigma_evals, perm_next_eval, pe)
-        we = wires_evals
+        return st.wires_evals, st.wire_sigma_evals, st.perm_next_eval, st.pe
+
+    def _lin_poly_terms(self, st, alpha_base: int = 1):
+        """compute_non_quotient_component_for_lin_poly (prover.rs:302-337, 963-1112) as (scalar, polynomial) terms, every scalar
+        times alpha_base (the combiner over instances, snark.rs:408-428)."""
+        r, n, W = self.curve.r, self.n, self.W
+        alpha, beta, gamma, tau, zeta = st.alpha, st.beta, st.gamma, st.tau, st.zeta
+        we, wire_sigma_evals, perm_next_eval, pe = st.wires_evals, st.wire_sigma_evals, st.perm_next_eval, st.pe
         sel = self.fixed
         terms = [(we[j], sel[j]) for j in range(4)]
         terms += [(we[0] * we[1] % r, sel[4]), (we[2] * we[3] % r, sel[5])]
@@ -372,12 +396,12 @@ class TurboPlonkProver:
         cf = alpha
         for j in range(W):
             cf = cf * (we[j] + beta * self.k[j] % r * zeta + gamma) % r
-        terms.append(((cf + alpha * alpha % r * lagrange_1) % r, z_poly))
+        terms.append(((cf + alpha * alpha % r * lagrange_1) % r, st.z_poly))
         cf = alpha * beta % r * perm_next_eval % r
         for j in range(W - 1):
             cf = cf * (we[j] + beta * wire_sigma_evals[j] + gamma) % r
-        terms.append(((-cf) % r, sig[W - 1]))
-        if ultra:                                                        # compute_lin_poly_plookup_contribution, prover.rs:1037-1112
+        terms.append(((-cf) % r, self.fixed[self.sigma0 + W - 1]))
+        if self.ultra:                                                   # compute_lin_poly_plookup_contribution, prover.rs:1037-1112
             em = lambda first, ql, ds, a0, a1, a2: (first + ql * tau % r * (ds + tau * (a0 + tau * (a1 + tau * a2))) % r) % r
             mt = em(pe["range_table_eval"], pe["q_lookup_eval"], pe["table_dom_sep_eval"], pe["key_table_eval"], we[3], we[4])
             mt_next = em(pe["range_table_next_eval"], pe["q_lookup_next_eval"], pe["table_dom_sep_next_eval"], pe["key_table_next_eval"],
@@ -390,37 +414,102 @@ class TurboPlonkProver:
             g1 = gamma * b1 % r
             zmg = (zeta - w_inv) % r
             cf = (a4 * lagrange_1 + a5 * lagrange_n + a6 * zmg % r * b1 % r * ((gamma + ml) % r) % r * ((g1 + mt + beta * mt_next) % r)) % r
-            terms.append((cf, pl_poly))
+            terms.append((cf, st.pl_poly))
             cf = a6 * zmg % r * pe["prod_next_eval"] % r * ((g1 + pe["h_1_eval"] + beta * pe["h_1_next_eval"]) % r) % r
-            terms.append(((-cf) % r, h2))
+            terms.append(((-cf) % r, st.h2))
+        if alpha_base != 1:
+            terms = [(s * alpha_base % r, p) for s, p in terms]
+        return terms
+
+    def _quotient_lin_terms(self, zeta, split):
+        """compute_quotient_component_for_lin_poly (prover.rs:343-358)"""
+        r, n = self.curve.r, self.n
+        vanish = (pow(zeta, n, r) - 1) % r
         zeta_n2 = (vanish + 1) * zeta % r * zeta % r
-        cf = 1
-        for i in range(W):
-            terms.append(((-vanish) * cf % r, split[i]))
+        terms, cf = [], 1
+        for p in split:
+            terms.append(((-vanish) * cf % r, p))
             cf = cf * zeta_n2 % r
-        lin = poly.lincomb(c, terms, out_len=n + 3)
-        open_polys = [lin] + wire_polys + sig[:W - 1]
-        shifted_polys = [z_poly]
-        if ultra:                                                        # plookup_open_polys_ref / plookup_shifted_open_polys_ref, prover.rs:421-460
-            open_polys += [tabs[0], tabs[1], h1, q_lookup, tabs[2], tabs[3]]
-            shifted_polys += [pl_poly, tabs[0], tabs[1], h1, h2, q_lookup, wire_polys[3], wire_polys[4], tabs[2]]
+        return terms
 
-        def batched(polys, point):                                       # compute_batched_witness_polynomial_commitment, prover.rs:490-509
-            bterms, cf = [], 1
-            for p in polys:
-                bterms.append((cf, p))
-                cf = cf * v_ch % r
+    def _open_lists(self, st):
+        """the polynomials opened at zeta (after the linearisation polynomial) and at zeta * w for this instance
+        (compute_opening_proofs, prover.rs:362-419; plookup lists :421-460)"""
+        W = self.W
+        sig = [self.fixed[self.sigma0 + j] for j in range(W)]
+        open_polys = list(st.wire_polys) + sig[:W - 1]
+        shifted_polys = [st.z_poly]
+        if self.ultra:
+            tabs = self.fixed[self.tab0:self.tab0 + 4]
+            q_lookup = self.fixed[13]
+            open_polys += [tabs[0], tabs[1], st.h1, q_lookup, tabs[2], tabs[3]]
+            shifted_polys += [st.pl_poly, tabs[0], tabs[1], st.h1, st.h2, q_lookup, st.wire_polys[3], st.wire_polys[4], tabs[2]]
+        return open_polys, shifted_polys
+
+    def _batched_witness(self, polys, v_ch, point):
+        """compute_batched_witness_polynomial_commitment (prover.rs:490-509) up to the commitment: sum_i v^i p_i, divided by (X - point)"""
+        c, r, n = self.curve, self.curve.r, self.n
+        if len(polys) == 1:
+            return poly.div_by_linear(c, polys[0].contiguous(), point)
+        bterms, cf = [], 1
+        for p in polys:
+            bterms.append((cf, p))
+            cf = cf * v_ch % r
+        if len(bterms) <= poly.MAX_TERMS:
             return poly.div_by_linear(c, poly.lincomb(c, bterms, out_len=n + 3), point)
+        acc = poly.lincomb(c, bterms[:poly.MAX_TERMS], out_len=n + 3)      # more terms than one launch takes: accumulate
+        for i in range(poly.MAX_TERMS, len(bterms), poly.MAX_TERMS - 1):
+            acc = poly.lincomb(c, [(1, acc)] + bterms[i:i + poly.MAX_TERMS - 1], out_len=n + 3)
+        return poly.div_by_linear(c, acc, point)
 
-        opening = batched(open_polys, zeta)
-        shifted = batched(shifted_polys, zeta_w) if len(shifted_polys) > 1 else poly.div_by_linear(c, z_poly.contiguous(), zeta_w)
+    def prove(self, wire_values, pub_input_values, ch, blind: Blinders, profile: bool = False) -> ProofCore:
+        """ch: ProverChallenges (fixed) or a challenge source (FixedChallenges / TranscriptChallenges)."""
+        src = FixedChallenges(ch) if isinstance(ch, ProverChallenges) else ch
+        import time
+        import torch
+        c, n, r, W, ultra = self.curve, self.n, self.curve.r, self.W, self.ultra
+        tm = {}
+
+        def tick(name, t0):
+            if profile:
+                torch.cuda.synchronize()
+                tm[name] = round((time.perf_counter() - t0) * 1e3, 3)
+
+        st, wires_comms = self._stage_round1(wire_values, pub_input_values, blind, tick)
+        tau = src.after_round1(wires_comms)
+        h_comms = self._stage_round1_5(st, tau, tick)
+        beta, gamma = src.after_round1_5(h_comms)
+        z_comm = self._stage_round2(st, beta, gamma, tick)
+        pl_comm = self._stage_round2_5(st, tick)
+        # ---- round 3 (prover.rs:192-209, 512-673, 902-960)
+        alpha = src.after_round2(z_comm, pl_comm)
+        quot = self._stage_quotient(st, alpha, tick)
+        t0 = time.perf_counter()
+        split = self._split_quotient(quot, blind.quot)
+        tick("r3_split", t0)
+        t0 = time.perf_counter()
+        split_comms = self._commit(split)
+        tick("r3_commit", t0)
+        # ---- round 4 (prover.rs:216-299)
+        t0 = time.perf_counter()
+        zeta = src.after_round3(split_comms)
+        tick("r4_transcript", t0)
+        wires_evals, wire_sigma_evals, perm_next_eval, pe = self._stage_round4(st, zeta, tick)
+        # ---- round 5: linearisation polynomial (prover.rs:963-1112, 343-358) and openings (362-460, 490-509)
+        t0 = time.perf_counter()
+        v_ch = src.after_round4(wires_evals, wire_sigma_evals, perm_next_eval, pe)
+        lin = poly.lincomb(c, self._lin_poly_terms(st) + self._quotient_lin_terms(zeta, split), out_len=n + 3)
+        open_polys, shifted_polys = self._open_lists(st)
+        opening = self._batched_witness([lin] + open_polys, v_ch, zeta)
+        shifted = self._batched_witness(shifted_polys, v_ch, zeta * self.w_n % r)
         tick("r5_polys", t0)
         t0 = time.perf_counter()
         open_comms = self._commit([opening, shifted])
         tick("r5_commit", t0)
         self.last_challenges = {"tau": tau, "beta": beta, "gamma": gamma, "alpha": alpha, "zeta": zeta, "v": v_ch}
-        self.last = {"wire_polys": wire_polys, "z_poly": z_poly, "quot": quot, "split": split, "lin": lin, "opening": opening, "shifted": shifted}
+        self.last = {"wire_polys": st.wire_polys, "z_poly": st.z_poly, "quot": quot, "split": split, "lin": lin, "opening": opening, "shifted": shifted}
         if ultra:
-            self.last.update({"h_polys": [h1, h2], "prod_lookup_poly": pl_poly, "sorted_vec": sorted_vec, "merged_table": table, "merged_lookup": lookup})
+            self.last.update({"h_polys": [st.h1, st.h2], "prod_lookup_poly": st.pl_poly, "sorted_vec": st.sorted_vec, "merged_table": st.table,
+                              "merged_lookup": st.lookup})
         return ProofCore(wires_comms, z_comm, split_comms, open_comms[0], open_comms[1], wires_evals, wire_sigma_evals, perm_next_eval, tm,
                          h_comms, pl_comm, pe)

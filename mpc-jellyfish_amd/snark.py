@@ -188,3 +188,40 @@ def prove_with_link_hint(rng: _rng.ChaChaRng, circuit: BenchCircuit, pk: _prover
     core, proof_bytes = prove(rng, circuit, pk, extra_transcript_init_msg)
     hint = linking.LinkingHint(pk.last["wire_polys"][linking.PROOF_LINK_WIRE_IDX].clone(), core.wires_poly_comms[linking.PROOF_LINK_WIRE_IDX])
     return core, proof_bytes, hint
+
+
+def draw_batch_blinders(curve, rng: _rng.ChaChaRng, num_wire_types: int, ultras: list):
+    """The masking draws of batch_prove_internal in the reference's order (snark.rs:277-360): round 1 of every instance, round
+    1.5 of every (UltraPlonk) instance, round 2, round 2.5, then the W - 1 scalars of the one quotient split.
+    Returns ([Blinders per instance], quot_blinders)."""
+    c = _curve(curve)
+    wires = [[_rng.dense_poly_rand(c, 1, rng) for _ in range(num_wire_types)] for _ in ultras]
+    h = [[_rng.dense_poly_rand(c, 2, rng) for _ in range(2)] if u else None for u in ultras]
+    z = [_rng.dense_poly_rand(c, 2, rng) for _ in ultras]
+    pl = [_rng.dense_poly_rand(c, 2, rng) if u else None for u in ultras]
+    quot = [_rng.fr_rand(c, rng) for _ in range(num_wire_types - 1)]
+    return [_prover.Blinders(wires[i], z[i], quot, h[i], pl[i]) for i in range(len(ultras))], quot
+
+
+def batch_prove(rng: _rng.ChaChaRng, circuits: list, pks: list, extra_transcript_init_msg: bytes | None = None):
+    """PlonkKzgSnark::batch_prove (snark.rs:64-78): one aggregated proof for several instances of one domain size.
+    Returns (BatchProofCore, compressed BatchProof bytes)."""
+    from . import batch as _batch
+    if not circuits:
+        raise ValueError("zero number of circuits/proving keys")
+    if len(circuits) != len(pks):
+        raise ValueError("the number of circuits %d != the number of proving keys %d" % (len(circuits), len(pks)))
+    n, W = circuits[0].n, circuits[0].num_wire_types
+    for cs, pk in zip(circuits, pks):
+        if cs.n != n:
+            raise ValueError("circuit domain size %d != expected domain size %d" % (cs.n, n))
+        if pk.n != n:
+            raise ValueError("proving key domain size %d != expected domain size %d" % (pk.n, n))
+        if (cs.plonk_type == ULTRA) != pk.ultra:
+            raise ValueError("Mismatched Plonk types between the proving key and the circuit")
+        if cs.num_wire_types != W:
+            raise ValueError("inconsistent plonk circuit types")
+    blinds, quot = draw_batch_blinders(circuits[0].curve, rng, W, [pk.ultra for pk in pks])
+    core = _batch.batch_prove(pks, [cs.wire_values for cs in circuits], [cs.pub_input_values for cs in circuits],
+                              [cs.public_input for cs in circuits], blinds, quot, extra_transcript_init_msg)
+    return core, _batch.serialize_batch_proof(circuits[0].curve, core)

@@ -309,3 +309,84 @@ def prove_core(c, log_n, selector_vals, sigma_vals, k, wire_vals, pi_vals, blind
         if ultra:
             out["commit_dlogs"].update({"h": [dl(p) for p in h_polys], "prod_lookup": dl(pl_poly)})
     return out
+
+
+def batch_prove_core(c, log_n, instances, ch, quot_blind, srs_beta=None):
+    """Aggregated proof over several instances of one domain size -- `batch_prove_internal` (snark.rs:201-469) assembled from
+    `prove_core` runs of the single instances, which is legitimate because everything shared is linear in them:
+      quotient      t = sum_k alpha_base_k t_k, alpha_base_{k+1} = alpha_base_k * alpha^3 (alpha^7 with Plookup)  (prover.rs:661-669)
+      lin. poly     the quotient part once (prover.rs:343-358) + alpha_base_k * (non-quotient part of instance k)  (snark.rs:403-428)
+      openings      one batched witness polynomial per point over the concatenated lists                            (prover.rs:362-419)
+    instances: dicts {"selector_vals", "sigma_vals", "k", "wire_vals", "pi_vals", "blind", "plookup"}; the "quot" entry of a blind is
+    ignored -- quot_blind holds the W - 1 scalars of the one split.  ch: tau beta gamma alpha zeta v, shared."""
+    r = c.r
+    n = 1 << log_n
+    w_n = c.root_of_unity(log_n)
+    alpha, zeta, v = ch["alpha"], ch["zeta"], ch["v"]
+    W = len(instances[0]["wire_vals"])
+    outs, bases, base = [], [], 1
+    for inst in instances:
+        assert len(inst["wire_vals"]) == W, "inconsistent plonk circuit types"
+        blind = dict(inst["blind"], quot=[0] * (W - 1))
+        outs.append(prove_core(c, log_n, inst["selector_vals"], inst["sigma_vals"], inst["k"], inst["wire_vals"], inst["pi_vals"], blind, ch,
+                               None, plookup=inst.get("plookup")))
+        bases.append(base)
+        base = base * pow(alpha, 7 if inst.get("plookup") is not None else 3, r) % r
+    vanish = (pow(zeta, n, r) - 1) % r
+    zeta_n2 = (vanish + 1) * zeta % r * zeta % r
+
+    def quotient_lin_part(split):
+        acc, cf = [0], 1
+        for p in split:
+            acc = padd(c, acc, pscale(c, p, (-vanish) * cf % r))
+            cf = cf * zeta_n2 % r
+        return acc
+
+    quot = [0]
+    for o, b in zip(outs, bases):
+        quot = padd(c, quot, pscale(c, o["quot"], b))
+    quot = pstrip(quot)
+    split = [quot[i * (n + 2):(i + 1) * (n + 2)] if i < W - 1 else quot[(W - 1) * (n + 2):] for i in range(W)]
+    last = 0
+    for i in range(W - 1):
+        now = quot_blind[i]
+        split[i] = list(split[i]) + [0] * (n + 2 - len(split[i]))
+        split[i][0] = (split[i][0] - last) % r
+        split[i].append(now)
+        last = now
+    if split[W - 1]:
+        split[W - 1] = list(split[W - 1])
+        split[W - 1][0] = (split[W - 1][0] - last) % r
+    lin = quotient_lin_part(split)
+    for o, b in zip(outs, bases):
+        non_quot = padd(c, o["lin_poly"], pscale(c, quotient_lin_part(o["split"]), r - 1))
+        lin = padd(c, lin, pscale(c, non_quot, b))
+    open_polys, shifted_polys = [lin], []
+    for o in outs:
+        Wk = len(o["wire_polys"])
+        open_polys += o["wire_polys"] + o["sigmas"][:Wk - 1]
+        shifted_polys.append(o["z_poly"])
+        if "h_polys" in o:
+            tab, sel, h, pl = o["table_polys"], o["selectors"], o["h_polys"], o["prod_lookup_poly"]
+            open_polys += [tab["range"], tab["key"], h[0], sel[13], tab["table_dom_sep"], tab["q_dom_sep"]]
+            shifted_polys += [pl, tab["range"], tab["key"], h[0], h[1], sel[13], o["wire_polys"][3], o["wire_polys"][4], tab["table_dom_sep"]]
+
+    def batched(polys, point):
+        batch, cf = [0], 1
+        for poly in polys:
+            batch = padd(c, batch, pscale(c, poly, cf))
+            cf = cf * v % r
+        return div_by_linear(c, batch, point)
+
+    opening = batched(open_polys, zeta)
+    shifted = batched(shifted_polys, zeta * w_n % r)
+    res = {"instances": outs, "alpha_bases": bases, "quot": quot, "split": split, "lin_poly": lin, "opening_poly": opening,
+           "shifted_opening_poly": shifted, "divisible": all(o["divisible"] for o in outs),
+           "quot_degree_ok": len(quot) - 1 == W * (n + 1) + 2}
+    if srs_beta is not None:
+        dl = lambda poly: P.poly_eval(c, poly, srs_beta)
+        res["commit_dlogs"] = {"split": [dl(p) for p in split], "opening": dl(opening), "shifted_opening": dl(shifted),
+                               "wires": [[dl(p) for p in o["wire_polys"]] for o in outs], "z": [dl(o["z_poly"]) for o in outs],
+                               "h": [[dl(p) for p in o["h_polys"]] if "h_polys" in o else None for o in outs],
+                               "prod_lookup": [dl(o["prod_lookup_poly"]) if "h_polys" in o else None for o in outs]}
+    return res

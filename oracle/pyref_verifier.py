@@ -1,6 +1,7 @@
 """oracle/pyref_verifier.py -- TEST INFRASTRUCTURE ONLY.
 
-Restatement of the reference VERIFIER for one TurboPlonk / UltraPlonk instance, from the compressed proof bytes:
+Restatement of the reference VERIFIER for TurboPlonk / UltraPlonk proofs (one instance, or one aggregated BatchProof over
+several), from the compressed proof bytes:
     Proof::deserialize_compressed          plonk/src/proof_system/structs.rs:59-84, 208-222, 440-450, 496-541
     Verifier::compute_challenges           plonk/src/proof_system/verifier.rs:256-321
     Verifier::compute_lin_poly_constant_term                                :340-414
@@ -105,58 +106,100 @@ class _Reader:
         return [item() for _ in range(n)]
 
 
+def _read_plookup(rd):
+    tag = rd.take(1)[0]
+    if tag == 0:
+        return None
+    if tag != 1:
+        raise VerifyError("bad Option tag")
+    pl = {"h_poly_comms": rd.vec(rd.g1), "prod_lookup_poly_comm": rd.g1()}
+    pl["evals"] = {name: rd.fr() for name in PLOOKUP_EVAL_FIELDS}
+    return pl
+
+
 def deserialize_proof(c, data: bytes) -> dict:
     """field order of `Proof` (structs.rs:59-84)."""
     rd = _Reader(c, data)
     pr = {"wires_poly_comms": rd.vec(rd.g1), "prod_perm_poly_comm": rd.g1(), "split_quot_poly_comms": rd.vec(rd.g1),
           "opening_proof": rd.g1(), "shifted_opening_proof": rd.g1(),
-          "wires_evals": rd.vec(rd.fr), "wire_sigma_evals": rd.vec(rd.fr), "perm_next_eval": rd.fr(), "plookup": None}
-    tag = rd.take(1)[0]
-    if tag == 1:
-        pl = {"h_poly_comms": rd.vec(rd.g1), "prod_lookup_poly_comm": rd.g1()}
-        pl["evals"] = {name: rd.fr() for name in PLOOKUP_EVAL_FIELDS}
-        pr["plookup"] = pl
-    elif tag != 0:
-        raise VerifyError("bad Option tag")
+          "wires_evals": rd.vec(rd.fr), "wire_sigma_evals": rd.vec(rd.fr), "perm_next_eval": rd.fr()}
+    pr["plookup"] = _read_plookup(rd)
     if rd.o != len(data):
         raise VerifyError("trailing bytes")
     return pr
 
 
+def deserialize_batch_proof(c, data: bytes) -> dict:
+    """field order of `BatchProof` (structs.rs:266-291)."""
+    rd = _Reader(c, data)
+    evals = lambda: {"wires_evals": rd.vec(rd.fr), "wire_sigma_evals": rd.vec(rd.fr), "perm_next_eval": rd.fr()}
+    bp = {"wires_poly_comms_vec": rd.vec(lambda: rd.vec(rd.g1)), "prod_perm_poly_comms_vec": rd.vec(rd.g1), "poly_evals_vec": rd.vec(evals),
+          "plookup_proofs_vec": rd.vec(lambda: _read_plookup(rd)), "split_quot_poly_comms": rd.vec(rd.g1), "opening_proof": rd.g1(),
+          "shifted_opening_proof": rd.g1()}
+    if rd.o != len(data):
+        raise VerifyError("trailing bytes")
+    return bp
+
+
+def batch_proof_from(pr: dict) -> dict:
+    """impl From<Proof> for BatchProof (structs.rs:316-328)"""
+    return {"wires_poly_comms_vec": [pr["wires_poly_comms"]], "prod_perm_poly_comms_vec": [pr["prod_perm_poly_comm"]],
+            "poly_evals_vec": [{k: pr[k] for k in ("wires_evals", "wire_sigma_evals", "perm_next_eval")}], "plookup_proofs_vec": [pr["plookup"]],
+            "split_quot_poly_comms": pr["split_quot_poly_comms"], "opening_proof": pr["opening_proof"],
+            "shifted_opening_proof": pr["shifted_opening_proof"]}
+
+
 # ---------------------------------------------------------------------------------------------------------------------
 # the verifier
 # ---------------------------------------------------------------------------------------------------------------------
-def compute_challenges(transcript, vk: dict, pub_input, pr: dict, extra_msg=None) -> dict:
-    """verifier.rs:256-321, one instance.  `transcript` is a fresh b"PlonkProof" transcript."""
+def _check_lengths(vks, pubs, bp):
+    k = len(bp["prod_perm_poly_comms_vec"])
+    if not (len(vks) == len(pubs) == k == len(bp["wires_poly_comms_vec"]) == len(bp["poly_evals_vec"]) == len(bp["plookup_proofs_vec"])) or k == 0:
+        raise VerifyError("the number of verification keys / instances / public inputs differ")
+
+
+def compute_challenges_batch(transcript, vks, pubs, bp: dict, extra_msg=None) -> dict:
+    """verifier.rs:256-321.  `transcript` is a fresh b"PlonkProof" transcript."""
+    _check_lengths(vks, pubs, bp)
     t = transcript
     if extra_msg is not None:
         t.append_message(b"extra info", extra_msg)
-    t.append_vk_and_pub_input(vk["domain_size"], vk["num_inputs"], vk["k"], vk["selector_comms"], vk["sigma_comms"], pub_input)
-    t.append_commitments(b"witness_poly_comms", pr["wires_poly_comms"])
+    for vk, pub in zip(vks, pubs):
+        t.append_vk_and_pub_input(vk["domain_size"], vk["num_inputs"], vk["k"], vk["selector_comms"], vk["sigma_comms"], pub)
+    for comms in bp["wires_poly_comms_vec"]:
+        t.append_commitments(b"witness_poly_comms", comms)
     ch = {"tau": t.get_and_append_challenge(b"tau")}
-    pl = pr["plookup"]
-    if pl is not None:
-        t.append_commitments(b"h_poly_comms", pl["h_poly_comms"])
+    for pl in bp["plookup_proofs_vec"]:
+        if pl is not None:
+            t.append_commitments(b"h_poly_comms", pl["h_poly_comms"])
     ch["beta"] = t.get_and_append_challenge(b"beta")
     ch["gamma"] = t.get_and_append_challenge(b"gamma")
-    t.append_commitment(b"perm_poly_comms", pr["prod_perm_poly_comm"])
-    if pl is not None:
-        t.append_commitment(b"plookup_poly_comms", pl["prod_lookup_poly_comm"])
+    for cm in bp["prod_perm_poly_comms_vec"]:
+        t.append_commitment(b"perm_poly_comms", cm)
+    for pl in bp["plookup_proofs_vec"]:
+        if pl is not None:
+            t.append_commitment(b"plookup_poly_comms", pl["prod_lookup_poly_comm"])
     ch["alpha"] = t.get_and_append_challenge(b"alpha")
-    t.append_commitments(b"quot_poly_comms", pr["split_quot_poly_comms"])
+    t.append_commitments(b"quot_poly_comms", bp["split_quot_poly_comms"])
     ch["zeta"] = t.get_and_append_challenge(b"zeta")
-    for e in pr["wires_evals"]:                                            # transcript/mod.rs:140-163
-        t.append_field_elem(b"wire_evals", e)
-    for e in pr["wire_sigma_evals"]:
-        t.append_field_elem(b"wire_sigma_evals", e)
-    t.append_field_elem(b"perm_next_eval", pr["perm_next_eval"])
-    if pl is not None:
-        t.append_plookup_evaluations(pl["evals"])
+    for ev in bp["poly_evals_vec"]:                                        # transcript/mod.rs:140-163
+        for e in ev["wires_evals"]:
+            t.append_field_elem(b"wire_evals", e)
+        for e in ev["wire_sigma_evals"]:
+            t.append_field_elem(b"wire_sigma_evals", e)
+        t.append_field_elem(b"perm_next_eval", ev["perm_next_eval"])
+    for pl in bp["plookup_proofs_vec"]:
+        if pl is not None:
+            t.append_plookup_evaluations(pl["evals"])
     ch["v"] = t.get_and_append_challenge(b"v")
-    t.append_commitment(b"open_proof", pr["opening_proof"])
-    t.append_commitment(b"shifted_open_proof", pr["shifted_opening_proof"])
+    t.append_commitment(b"open_proof", bp["opening_proof"])
+    t.append_commitment(b"shifted_open_proof", bp["shifted_opening_proof"])
     ch["u"] = t.get_and_append_challenge(b"u")
     return ch
+
+
+def compute_challenges(transcript, vk: dict, pub_input, pr: dict, extra_msg=None) -> dict:
+    return compute_challenges_batch(transcript, [vk], [pub_input], batch_proof_from(pr), extra_msg)
 
 
 def _evaluate_pi_poly(c, n, w, pub_input, z, vanish_eval):
@@ -172,82 +215,93 @@ def _evaluate_pi_poly(c, n, w, pub_input, z, vanish_eval):
     return out
 
 
-def prepare_pcs_info(c, vk: dict, pub_input, pr: dict, ch: dict) -> dict:
-    """verifier.rs:68-184 for one instance (alpha_bases = [1]).  Returns u, eval points, the aggregated evaluation and the
-    (scalar, base) list of the aggregated commitment."""
+def prepare_pcs_info_batch(c, vks, pubs, bp: dict, ch: dict) -> dict:
+    """verifier.rs:68-184.  Returns u, the evaluation points, the aggregated evaluation and the (scalar, base) list of the
+    aggregated commitment -- over all the instances of one BatchProof."""
     r = c.r
-    n = vk["domain_size"]
+    _check_lengths(vks, pubs, bp)
+    n = vks[0]["domain_size"]
     log_n = n.bit_length() - 1
-    if len(pub_input) != vk["num_inputs"]:
-        raise VerifyError("the circuit public input length != the verification key public input length")
-    ultra = vk.get("plookup") is not None
-    if ultra != (pr["plookup"] is not None):
-        raise VerifyError("Mismatched proof type and verification key type")
-    W = GATE_WIDTH + 1 + (1 if ultra else 0)
-    if len(pr["wires_poly_comms"]) != W or len(pr["wires_evals"]) != W or len(pr["wire_sigma_evals"]) != W - 1 \
-            or len(pr["split_quot_poly_comms"]) != W or len(vk["sigma_comms"]) != W or len(vk["k"]) != W \
-            or len(vk["selector_comms"]) != 2 * GATE_WIDTH + 5 + (1 if ultra else 0):
-        raise VerifyError("wrong number of commitments / evaluations")
+    for i, (vk, pub) in enumerate(zip(vks, pubs)):
+        if len(pub) != vk["num_inputs"]:
+            raise VerifyError("the circuit public input length != the %d-th verification key public input length" % i)
+        if (vk.get("plookup") is not None) != (bp["plookup_proofs_vec"][i] is not None):
+            raise VerifyError("Mismatched proof type and verification key type for the %d-th instance" % i)
+        if vk["domain_size"] != n:
+            raise VerifyError("the domain size of the %d-th verification key is different" % i)
     w = c.root_of_unity(log_n)
     w_inv = pow(w, -1, r)
     tau, beta, gamma, alpha, zeta, v, u = (ch[x] for x in ("tau", "beta", "gamma", "alpha", "zeta", "v", "u"))
     a2 = alpha * alpha % r
     a3, a4 = a2 * alpha % r, a2 * a2 % r
-    a5, a6 = a4 * alpha % r, a4 * a2 % r
+    a5, a6, a7 = a4 * alpha % r, a4 * a2 % r, a4 * a3 % r
     alpha_powers = [a2, a3, a4, a5, a6]
+    alpha_bases = [1]                                                       # :130-138: the step is chosen by the FIRST key's type
+    tmp = a7 if vks[0].get("plookup") is not None else a3
+    for _ in range(len(vks) - 1):
+        alpha_bases.append(tmp)
+        tmp = tmp * alpha_bases[1] % r
     vanish = (pow(zeta, n, r) - 1) % r
     l1 = vanish * pow(n * (zeta - 1) % r, -1, r) % r                       # :776-788
     ln = vanish * w_inv % r * pow(n * (zeta - w_inv) % r, -1, r) % r
-    we, se, zn = pr["wires_evals"], pr["wire_sigma_evals"], pr["perm_next_eval"]
-    pl = pr["plookup"]
-    ev = pl["evals"] if ultra else None
     b1 = (1 + beta) % r
     g_b1 = gamma * b1 % r
 
-    # --- constant term of the linearisation polynomial (:340-414)
-    tmp = (_evaluate_pi_poly(c, n, w, pub_input, zeta, vanish) - alpha_powers[0] * l1) % r
-    acc = alpha * zn % r * ((gamma + we[W - 1]) % r) % r
-    for we_i, se_i in zip(we[:W - 1], se):
-        acc = acc * ((gamma + we_i + beta * se_i) % r) % r
-    tmp = (tmp - acc) % r
-    if ultra:
-        pc = (ln * ((ev["h_1_eval"] - ev["h_2_next_eval"] - alpha_powers[0]) % r) - alpha * l1
-              - alpha_powers[1] * ((zeta - w_inv) % r) % r * ev["prod_next_eval"] % r
-              * ((g_b1 + ev["h_1_eval"] + beta * ev["h_1_next_eval"]) % r) % r * ((g_b1 + beta * ev["h_2_next_eval"]) % r)) % r
-        tmp = (tmp + alpha_powers[1] * pc) % r
-    lin_const = tmp
-
-    # --- [D]_1 (:513-668)
+    lin_const = 0
     sb = []                                                                 # (scalar, base)
-    coeff = alpha
-    for we_i, k_i in zip(we, vk["k"]):
-        coeff = coeff * ((beta * k_i % r * zeta + gamma + we_i) % r) % r
-    coeff = (coeff + alpha_powers[0] * l1) % r
-    sb.append((coeff, pr["prod_perm_poly_comm"]))
-    coeff = alpha * beta % r * zn % r
-    for we_i, se_i in zip(we[:W - 1], se):
-        coeff = coeff * ((beta * se_i + gamma + we_i) % r) % r
-    sb.append((-coeff % r, vk["sigma_comms"][-1]))
-    q = [we[0], we[1], we[2], we[3], we[0] * we[1] % r, we[2] * we[3] % r, pow(we[0], 5, r), pow(we[1], 5, r), pow(we[2], 5, r),
-         pow(we[3], 5, r), -we[4] % r, 1, we[0] * we[1] % r * we[2] % r * we[3] % r * we[4] % r]
-    for s, base in zip(q, vk["selector_comms"]):                            # q_lookup (14th) gets no scalar: zip stops at 13
-        sb.append((s, base))
-    if ultra:
-        merged_lookup_x = (we[5] + ev["q_lookup_eval"] * tau % r * (ev["q_dom_sep_eval"] + tau * (we[0] + tau * (we[1] + tau * we[2]))) % r) % r
-        def merged_table(rng_e, key_e, ql_e, w3_e, w4_e, dom_e):             # structs.rs:925-940
-            return (rng_e + ql_e * tau % r * (dom_e + tau * (key_e + tau * (w3_e + tau * w4_e))) % r) % r
-        table_x = merged_table(ev["range_table_eval"], ev["key_table_eval"], ev["q_lookup_eval"], we[3], we[4], ev["table_dom_sep_eval"])
-        table_xw = merged_table(ev["range_table_next_eval"], ev["key_table_next_eval"], ev["q_lookup_next_eval"], ev["w_3_next_eval"],
-                                ev["w_4_next_eval"], ev["table_dom_sep_next_eval"])
-        coeff = (alpha_powers[2] * l1 + alpha_powers[3] * ln
-                 + alpha_powers[4] * ((zeta - w_inv) % r) % r * b1 % r * ((gamma + merged_lookup_x) % r) % r
-                 * ((g_b1 + table_x + beta * table_xw) % r)) % r
-        sb.append((coeff, pl["prod_lookup_poly_comm"]))
-        coeff = alpha_powers[4] * ((w_inv - zeta) % r) % r * ev["prod_next_eval"] % r * ((g_b1 + ev["h_1_eval"] + beta * ev["h_1_next_eval"]) % r) % r
-        sb.append((coeff, pl["h_poly_comms"][1]))
+    for i, (vk, pub, base) in enumerate(zip(vks, pubs, alpha_bases)):
+        ev_i = bp["poly_evals_vec"][i]
+        we, se, zn = ev_i["wires_evals"], ev_i["wire_sigma_evals"], ev_i["perm_next_eval"]
+        pl = bp["plookup_proofs_vec"][i]
+        ultra = pl is not None
+        ev = pl["evals"] if ultra else None
+        W = GATE_WIDTH + 1 + (1 if ultra else 0)
+        if len(bp["wires_poly_comms_vec"][i]) != W or len(we) != W or len(se) != W - 1 or len(vk["sigma_comms"]) != W or len(vk["k"]) != W \
+                or len(vk["selector_comms"]) != 2 * GATE_WIDTH + 5 + (1 if ultra else 0):
+            raise VerifyError("wrong number of commitments / evaluations")
+        # --- constant term of the linearisation polynomial (:340-414)
+        tmp = (_evaluate_pi_poly(c, n, w, pub, zeta, vanish) - alpha_powers[0] * l1) % r
+        acc = alpha * zn % r * ((gamma + we[W - 1]) % r) % r
+        for we_i, se_i in zip(we[:W - 1], se):
+            acc = acc * ((gamma + we_i + beta * se_i) % r) % r
+        tmp = (tmp - acc) % r
+        if ultra:
+            pc = (ln * ((ev["h_1_eval"] - ev["h_2_next_eval"] - alpha_powers[0]) % r) - alpha * l1
+                  - alpha_powers[1] * ((zeta - w_inv) % r) % r * ev["prod_next_eval"] % r
+                  * ((g_b1 + ev["h_1_eval"] + beta * ev["h_1_next_eval"]) % r) % r * ((g_b1 + beta * ev["h_2_next_eval"]) % r)) % r
+            tmp = (tmp + alpha_powers[1] * pc) % r
+        lin_const = (lin_const + base * tmp) % r
+        # --- [D]_1 (:513-652)
+        coeff = alpha
+        for we_i, k_i in zip(we, vk["k"]):
+            coeff = coeff * ((beta * k_i % r * zeta + gamma + we_i) % r) % r
+        coeff = (coeff + alpha_powers[0] * l1) % r * base % r
+        sb.append((coeff, bp["prod_perm_poly_comms_vec"][i]))
+        coeff = alpha * beta % r * zn % r
+        for we_i, se_i in zip(we[:W - 1], se):
+            coeff = coeff * ((beta * se_i + gamma + we_i) % r) % r
+        sb.append((-coeff * base % r, vk["sigma_comms"][-1]))
+        q = [we[0], we[1], we[2], we[3], we[0] * we[1] % r, we[2] * we[3] % r, pow(we[0], 5, r), pow(we[1], 5, r), pow(we[2], 5, r),
+             pow(we[3], 5, r), -we[4] % r, 1, we[0] * we[1] % r * we[2] % r * we[3] % r * we[4] % r]
+        for s_, comm in zip(q, vk["selector_comms"]):                       # q_lookup (14th) gets no scalar: zip stops at 13
+            sb.append((s_ * base % r, comm))
+        if ultra:
+            merged_lookup_x = (we[5] + ev["q_lookup_eval"] * tau % r * (ev["q_dom_sep_eval"] + tau * (we[0] + tau * (we[1] + tau * we[2]))) % r) % r
+            def merged_table(rng_e, key_e, ql_e, w3_e, w4_e, dom_e):         # structs.rs:925-940
+                return (rng_e + ql_e * tau % r * (dom_e + tau * (key_e + tau * (w3_e + tau * w4_e))) % r) % r
+            table_x = merged_table(ev["range_table_eval"], ev["key_table_eval"], ev["q_lookup_eval"], we[3], we[4], ev["table_dom_sep_eval"])
+            table_xw = merged_table(ev["range_table_next_eval"], ev["key_table_next_eval"], ev["q_lookup_next_eval"], ev["w_3_next_eval"],
+                                    ev["w_4_next_eval"], ev["table_dom_sep_next_eval"])
+            coeff = (alpha_powers[2] * l1 + alpha_powers[3] * ln
+                     + alpha_powers[4] * ((zeta - w_inv) % r) % r * b1 % r * ((gamma + merged_lookup_x) % r) % r
+                     * ((g_b1 + table_x + beta * table_xw) % r)) % r
+            sb.append((coeff * base % r, pl["prod_lookup_poly_comm"]))
+            coeff = alpha_powers[4] * ((w_inv - zeta) % r) % r * ev["prod_next_eval"] % r * ((g_b1 + ev["h_1_eval"] + beta * ev["h_1_next_eval"]) % r) % r
+            sb.append((coeff * base % r, pl["h_poly_comms"][1]))
+    # split quotient commitments (:654-665)
     zeta_n2 = (1 + vanish) * zeta % r * zeta % r
     coeff = -vanish % r
-    for i, cm in enumerate(pr["split_quot_poly_comms"]):
+    for i, cm in enumerate(bp["split_quot_poly_comms"]):
         if i:
             coeff = coeff * zeta_n2 % r
         sb.append((coeff, cm))
@@ -269,26 +323,38 @@ def prepare_pcs_info(c, vk: dict, pub_input, pr: dict, ch: dict) -> dict:
         uv_base = uv_base * v % r
 
     # aggregate_evaluations walks the buffer in commitment order, so the two lists are zipped here
-    for cm, e in zip(pr["wires_poly_comms"], we):
-        at_zeta(cm, e)
-    for cm, e in zip(vk["sigma_comms"][:W - 1], se):
-        at_zeta(cm, e)
-    at_zeta_omega(pr["prod_perm_poly_comm"], zn)
-    if ultra:
-        pvk = vk["plookup"]
-        q_lookup_comm = vk["selector_comms"][-1]
-        for cm, name in ((pvk["range_table_comm"], "range_table_eval"), (pvk["key_table_comm"], "key_table_eval"),
-                         (pl["h_poly_comms"][0], "h_1_eval"), (q_lookup_comm, "q_lookup_eval"),
-                         (pvk["table_dom_sep_comm"], "table_dom_sep_eval"), (pvk["q_dom_sep_comm"], "q_dom_sep_eval")):    # :793-805, structs.rs:545-554
-            at_zeta(cm, ev[name])
-        for cm, name in ((pl["prod_lookup_poly_comm"], "prod_next_eval"), (pvk["range_table_comm"], "range_table_next_eval"),
-                         (pvk["key_table_comm"], "key_table_next_eval"), (pl["h_poly_comms"][0], "h_1_next_eval"),
-                         (pl["h_poly_comms"][1], "h_2_next_eval"), (q_lookup_comm, "q_lookup_next_eval"),
-                         (pr["wires_poly_comms"][3], "w_3_next_eval"), (pr["wires_poly_comms"][4], "w_4_next_eval"),
-                         (pvk["table_dom_sep_comm"], "table_dom_sep_next_eval")):                                            # :810-826, structs.rs:557-569
-            at_zeta_omega(cm, ev[name])
+    for i, vk in enumerate(vks):
+        ev_i = bp["poly_evals_vec"][i]
+        wires = bp["wires_poly_comms_vec"][i]
+        W = len(wires)
+        pl = bp["plookup_proofs_vec"][i]
+        for cm, e in zip(wires, ev_i["wires_evals"]):
+            at_zeta(cm, e)
+        for cm, e in zip(vk["sigma_comms"][:W - 1], ev_i["wire_sigma_evals"]):
+            at_zeta(cm, e)
+        at_zeta_omega(bp["prod_perm_poly_comms_vec"][i], ev_i["perm_next_eval"])
+        if pl is not None:
+            ev = pl["evals"]
+            pvk = vk["plookup"]
+            q_lookup_comm = vk["selector_comms"][-1]
+            for cm, name in ((pvk["range_table_comm"], "range_table_eval"), (pvk["key_table_comm"], "key_table_eval"),
+                             (pl["h_poly_comms"][0], "h_1_eval"), (q_lookup_comm, "q_lookup_eval"),
+                             (pvk["table_dom_sep_comm"], "table_dom_sep_eval"), (pvk["q_dom_sep_comm"], "q_dom_sep_eval")):    # :793-805, structs.rs:545-554
+                at_zeta(cm, ev[name])
+            for cm, name in ((pl["prod_lookup_poly_comm"], "prod_next_eval"), (pvk["range_table_comm"], "range_table_next_eval"),
+                             (pvk["key_table_comm"], "key_table_next_eval"), (pl["h_poly_comms"][0], "h_1_next_eval"),
+                             (pl["h_poly_comms"][1], "h_2_next_eval"), (q_lookup_comm, "q_lookup_next_eval"),
+                             (wires[3], "w_3_next_eval"), (wires[4], "w_4_next_eval"),
+                             (pvk["table_dom_sep_comm"], "table_dom_sep_next_eval")):                                            # :810-826, structs.rs:557-569
+                at_zeta_omega(cm, ev[name])
     return {"u": u, "eval_point": zeta, "next_eval_point": zeta * w % r, "eval": eval_, "comm_scalars_and_bases": sb,
-            "opening_proof": pr["opening_proof"], "shifted_opening_proof": pr["shifted_opening_proof"]}
+            "opening_proof": bp["opening_proof"], "shifted_opening_proof": bp["shifted_opening_proof"]}
+
+
+def prepare_pcs_info(c, vk: dict, pub_input, pr: dict, ch: dict) -> dict:
+    if len(pr["split_quot_poly_comms"]) != len(pr["wires_poly_comms"]):
+        raise VerifyError("wrong number of commitments / evaluations")
+    return prepare_pcs_info_batch(c, [vk], [pub_input], batch_proof_from(pr), ch)
 
 
 def _msm(c, pairs):
@@ -319,4 +385,12 @@ def verify(c, transcript, vk: dict, pub_input, proof_bytes: bytes, g, srs_beta: 
     pr = deserialize_proof(c, proof_bytes)
     ch = compute_challenges(transcript, vk, pub_input, pr, extra_msg)
     info = prepare_pcs_info(c, vk, pub_input, pr, ch)
+    return batch_verify_opening_proof(c, g, srs_beta, info)
+
+
+def verify_batch_proof(c, transcript, vks, pubs, batch_proof_bytes: bytes, g, srs_beta: int, extra_msg=None) -> bool:
+    """PlonkKzgSnark::verify_batch_proof (snark.rs:148-169): one aggregated BatchProof over several instances."""
+    bp = deserialize_batch_proof(c, batch_proof_bytes)
+    ch = compute_challenges_batch(transcript, vks, pubs, bp, extra_msg)
+    info = prepare_pcs_info_batch(c, vks, pubs, bp, ch)
     return batch_verify_opening_proof(c, g, srs_beta, info)

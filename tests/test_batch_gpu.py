@@ -1,0 +1,136 @@
+"""GPU: aggregated proofs over several instances (mpc-jellyfish_amd/batch.py = PlonkKzgSnark::batch_prove, snark.rs:64-78, 201-469)
+against the restated batch prover (oracle/pyref_plonk.py::batch_prove_core) commitment by commitment, and accepted -- from the
+serialized BatchProof bytes -- by the restated verifier (oracle/pyref_verifier.py::verify_batch_proof, snark.rs:117-138)."""
+import random
+
+import numpy as np
+import pytest
+
+from conftest import affine_from_limbs, build_circuit, build_ultra_circuit, fr_mont_limbs
+from test_verifier_gpu import verifying_key
+
+pytestmark = pytest.mark.gpu
+TABLES = ("range", "key", "table_dom_sep", "q_dom_sep")
+
+
+@pytest.mark.parametrize("curve_id,plonk_type,gates,range_bits", [(0, "TurboPlonk", (25, 28, 31), 8), (1, "UltraPlonk", (100, 110), 4),
+                                                                  (1, "TurboPlonk", (900, 1000, 950, 990), 8)])
+def test_batch_prove_bench_circuits_verifies(gpu, mj, pyref, curve_id, plonk_type, gates, range_bits):
+    """snark.batch_prove with the reference's `test_rng` draws on bench circuits of one domain size; K = 4 exceeds one
+    linear-combination launch (37 polynomials opened at zeta)."""
+    import pyref_verifier as V
+    c, pc = mj.params.CURVES[curve_id], pyref.CURVES[curve_id]
+    circuits = [mj.snark.gen_circuit_for_bench(c, g, plonk_type, range_bit_len=range_bits) for g in gates]
+    n = circuits[0].n
+    assert all(cs.n == n for cs in circuits)
+    rng = mj.rng.test_rng()
+    srs_beta = mj.rng.fr_rand(c, rng)
+    ck = mj.UnivariateProverParam.gen_srs_for_testing(c, srs_beta, n + 2)
+    pks = [mj.snark.preprocess(ck, cs) for cs in circuits]
+    core, blob = mj.snark.batch_prove(rng, circuits, pks)
+    assert len(core) == len(gates)
+    vks = [verifying_key(mj, pc, pk, 0) for pk in pks]
+    pubs = [[] for _ in gates]
+    G = pyref.g1_gen(pc)
+    fresh = lambda: mj.transcript.StandardTranscript(c, b"PlonkProof")
+    assert V.verify_batch_proof(pc, fresh(), vks, pubs, blob, G, srs_beta)
+    # the verifier re-derives the prover's challenges
+    bp = V.deserialize_batch_proof(pc, blob)
+    ch = V.compute_challenges_batch(fresh(), vks, pubs, bp)
+    assert {k: ch[k] for k in core.challenges} == core.challenges
+    # keys in another order, a flipped evaluation byte, a dropped instance
+    assert not V.verify_batch_proof(pc, fresh(), vks[::-1], pubs, blob, G, srs_beta)
+    g1_len, K, W = (48 if curve_id == 0 else 32), len(gates), circuits[0].num_wire_types
+    first_eval = 8 + K * (8 + W * g1_len) + (8 + K * g1_len) + 8 + 8          # wires comms, z comms, len(poly_evals_vec), len(wires_evals)
+    for at in (first_eval, first_eval + 32 * W + 8 + 32):
+        bad = bytearray(blob)
+        bad[at] ^= 1
+        assert not V.verify_batch_proof(pc, fresh(), vks, pubs, bytes(bad), G, srs_beta), at
+    with pytest.raises(V.VerifyError):
+        V.verify_batch_proof(pc, fresh(), vks[:-1], pubs[:-1], blob, G, srs_beta)
+    # deterministic in (rng, circuits, keys); and an aggregate of ONE instance is that instance's plain proof
+    _, blob2 = mj.snark.batch_prove(_rng_after_srs(mj, c), circuits, pks)
+    assert blob2 == blob
+    one_core, one_blob = mj.snark.batch_prove(_rng_after_srs(mj, c), circuits[:1], pks[:1])
+    _, single = mj.snark.prove(_rng_after_srs(mj, c), circuits[0], pks[0])
+    pr = V.deserialize_proof(pc, single)
+    assert V.deserialize_batch_proof(pc, one_blob) == V.batch_proof_from(pr)
+    # parameter errors of batch_prove_internal (snark.rs:213-260)
+    with pytest.raises(ValueError):
+        mj.snark.batch_prove(rng, [], [])
+    with pytest.raises(ValueError):
+        mj.snark.batch_prove(rng, circuits, pks[:-1])
+    small = mj.snark.gen_circuit_for_bench(c, 17, plonk_type, range_bit_len=range_bits)
+    if small.n != n:
+        with pytest.raises(ValueError):
+            mj.snark.batch_prove(rng, [circuits[0], small], [pks[0], pks[0]])
+    for pk in pks:
+        pk.release()
+    ck.release()
+
+
+def _rng_after_srs(mj, c):
+    rng = mj.rng.test_rng()
+    mj.rng.fr_rand(c, rng)
+    return rng
+
+
+@pytest.mark.parametrize("curve_id,ultra,log_n", [(0, False, 5), (1, True, 5)])
+def test_batch_prove_matches_the_restated_batch_prover(gpu, mj, pyref, curve_id, ultra, log_n):
+    """Three circuits with public inputs, copy constraints (and lookups): every commitment and evaluation of the device
+    BatchProof equals the restatement's, fed the challenges the device transcript produced."""
+    import pyref_plonk as PP
+    import pyref_verifier as V
+    c, pc = mj.params.CURVES[curve_id], pyref.CURVES[curve_id]
+    n, r = 1 << log_n, c.r
+    rng = random.Random(600 + curve_id)
+    W = 6 if ultra else 5
+    srs_beta = rng.randrange(1, r)
+    ck = mj.UnivariateProverParam.gen_srs_for_testing(c, srs_beta, n + 2)
+    dom = mj.Radix2EvaluationDomain(c, log_n)
+    instances, provers, blinds = [], [], []
+    for _ in range(3):
+        tabs = None
+        if ultra:
+            sel, sig, k, w, pi, tabs = build_ultra_circuit(pc, log_n, rng)
+        else:
+            sel, sig, k, w, pi = build_circuit(pc, log_n, rng)
+        blind = {"wires": [[rng.randrange(r) for _ in range(2)] for _ in range(W)], "z": [rng.randrange(r) for _ in range(3)],
+                 "h": [[rng.randrange(r) for _ in range(3)] for _ in range(2)], "prod_lookup": [rng.randrange(r) for _ in range(3)]}
+        instances.append({"selector_vals": sel, "sigma_vals": sig, "k": k, "wire_vals": w, "pi_vals": pi, "blind": blind, "plookup": tabs})
+        kw = {"plookup": {name: dom.ifft(fr_mont_limbs(c, tabs[key])) for name, key in zip(mj.plonk.PLOOKUP_TABLE_POLYS, TABLES)}} if ultra else {}
+        provers.append(mj.prover.TurboPlonkProver(c, n, [dom.ifft(fr_mont_limbs(c, s)) for s in sel], [dom.ifft(fr_mont_limbs(c, s)) for s in sig], k, ck, **kw))
+        blinds.append(mj.prover.Blinders(blind["wires"], blind["z"], [], blind["h"] if ultra else None, blind["prod_lookup"] if ultra else None))
+    quot_blind = [rng.randrange(r) for _ in range(W - 1)]
+    pubs = [inst["pi_vals"][:4] for inst in instances]
+    core = mj.batch.batch_prove(provers, [np.stack([fr_mont_limbs(c, col) for col in inst["wire_vals"]]) for inst in instances],
+                                [fr_mont_limbs(c, inst["pi_vals"]) for inst in instances], pubs, blinds, quot_blind, extra_transcript_init_msg=b"batch")
+    want = PP.batch_prove_core(pc, log_n, instances, core.challenges, quot_blind, srs_beta)
+    assert want["divisible"] and want["quot_degree_ok"]
+    G = pyref.g1_gen(pc)
+    pt = lambda cm: None if cm.is_infinity() else affine_from_limbs(pc, cm.xy)
+    at = lambda d: pyref.g1_mul(pc, d % r, G)
+    dl = want["commit_dlogs"]
+    assert [pt(x) for x in core.split_quot_poly_comms] == [at(d) for d in dl["split"]]
+    assert pt(core.opening_proof) == at(dl["opening"]) and pt(core.shifted_opening_proof) == at(dl["shifted_opening"])
+    for i, o in enumerate(want["instances"]):
+        assert [pt(x) for x in core.wires_poly_comms_vec[i]] == [at(d) for d in dl["wires"][i]], i
+        assert pt(core.prod_perm_poly_comms_vec[i]) == at(dl["z"][i])
+        assert core.poly_evals_vec[i] == (o["wires_evals"], o["wire_sigma_evals"], o["perm_next_eval"])
+        if ultra:
+            h, pl, evals = core.plookup_proofs_vec[i]
+            assert [pt(x) for x in h] == [at(d) for d in dl["h"][i]] and pt(pl) == at(dl["prod_lookup"][i]) and evals == o["plookup_evals"]
+        else:
+            assert core.plookup_proofs_vec[i] is None
+    # ... and the serialized aggregate verifies under the three keys and public inputs
+    blob = mj.batch.serialize_batch_proof(c, core)
+    vks = [verifying_key(mj, pc, p, 4) for p in provers]
+    fresh = lambda: mj.transcript.StandardTranscript(c, b"PlonkProof")
+    assert V.verify_batch_proof(pc, fresh(), vks, pubs, blob, G, srs_beta, extra_msg=b"batch")
+    assert not V.verify_batch_proof(pc, fresh(), vks, pubs, blob, G, srs_beta)
+    other = [pubs[0], pubs[1][:3] + [(pubs[1][3] + 1) % r], pubs[2]]
+    assert not V.verify_batch_proof(pc, fresh(), vks, other, blob, G, srs_beta, extra_msg=b"batch")
+    assert not V.verify_batch_proof(pc, fresh(), [vks[2], vks[1], vks[0]], pubs, blob, G, srs_beta, extra_msg=b"batch")
+    for p in provers:
+        p.release()
+    ck.release()

@@ -120,3 +120,66 @@ def test_compressed_g1_round_trip_and_malformed_encodings(pyref, mj, curve_id):
     for bad in (blob[:-1], blob + b"\x00", blob[:-1] + b"\x02"):
         with pytest.raises(V.VerifyError):
             V.deserialize_proof(c, bad)
+
+
+@pytest.mark.parametrize("curve_id,ultra", [(0, False), (1, True)])
+def test_restated_batch_verifier_accepts_the_restated_batch_prover(pyref, curve_id, ultra):
+    """An aggregated proof over three instances (snark.rs:201-469 restated by pyref_plonk.batch_prove_core) against
+    prepare_pcs_info over several verifying keys (verifier.rs:68-184: alpha_bases, running v / uv powers)."""
+    import pyref_plonk as PP
+    import pyref_verifier as V
+    c = pyref.CURVES[curve_id]
+    r = c.r
+    rng = random.Random(8100 + curve_id)
+    log_n = 5 if ultra else 4
+    W = 6 if ultra else 5
+    instances = []
+    for _ in range(3):
+        plookup = None
+        if ultra:
+            sel, sig, k, w, pi, plookup = build_ultra_circuit(c, log_n, rng)
+        else:
+            sel, sig, k, w, pi = build_circuit(c, log_n, rng)
+        blind = {"wires": [[rng.randrange(r) for _ in range(2)] for _ in range(W)], "z": [rng.randrange(r) for _ in range(3)],
+                 "h": [[rng.randrange(r) for _ in range(3)] for _ in range(2)], "prod_lookup": [rng.randrange(r) for _ in range(3)]}
+        instances.append({"selector_vals": sel, "sigma_vals": sig, "k": k, "wire_vals": w, "pi_vals": pi, "blind": blind, "plookup": plookup})
+    ch = {x: rng.randrange(r) for x in ("tau", "beta", "gamma", "alpha", "zeta", "v")}
+    srs_beta = rng.randrange(1, r)
+    out = PP.batch_prove_core(c, log_n, instances, ch, [rng.randrange(r) for _ in range(W - 1)], srs_beta)
+    assert out["divisible"] and out["quot_degree_ok"]
+    G = pyref.g1_gen(c)
+    pt = lambda dlog: pyref.g1_mul(c, dlog % r, G) if dlog % r else None
+    commit = lambda poly: pt(pyref.poly_eval(c, poly, srs_beta))
+    dl = out["commit_dlogs"]
+    bp = {"wires_poly_comms_vec": [[pt(d) for d in ws] for ws in dl["wires"]], "prod_perm_poly_comms_vec": [pt(d) for d in dl["z"]],
+          "poly_evals_vec": [{k_: o[k_] for k_ in ("wires_evals", "wire_sigma_evals", "perm_next_eval")} for o in out["instances"]],
+          "plookup_proofs_vec": [None] * 3, "split_quot_poly_comms": [pt(d) for d in dl["split"]], "opening_proof": pt(dl["opening"]),
+          "shifted_opening_proof": pt(dl["shifted_opening"])}
+    vks, pubs = [], []
+    for i, (inst, o) in enumerate(zip(instances, out["instances"])):
+        vk = {"domain_size": 1 << log_n, "num_inputs": 4, "k": inst["k"], "selector_comms": [commit(p) for p in o["selectors"]],
+              "sigma_comms": [commit(p) for p in o["sigmas"]], "plookup": None}
+        if ultra:
+            bp["plookup_proofs_vec"][i] = {"h_poly_comms": [pt(d) for d in dl["h"][i]], "prod_lookup_poly_comm": pt(dl["prod_lookup"][i]),
+                                           "evals": dict(o["plookup_evals"])}
+            tab = o["table_polys"]
+            vk["plookup"] = {"range_table_comm": commit(tab["range"]), "key_table_comm": commit(tab["key"]),
+                             "table_dom_sep_comm": commit(tab["table_dom_sep"]), "q_dom_sep_comm": commit(tab["q_dom_sep"])}
+        vks.append(vk)
+        pubs.append(inst["pi_vals"][:4])
+    ch["u"] = rng.randrange(r)
+    accept = lambda bp_, vks_=vks, pubs_=pubs: V.batch_verify_opening_proof(c, G, srs_beta, V.prepare_pcs_info_batch(c, vks_, pubs_, bp_, ch))
+    assert accept(bp)
+    # instance order matters everywhere (snark.rs test :1735-1738 swaps public inputs)
+    other_pub = [pubs[0][:3] + [(pubs[0][3] + 1) % r]] + pubs[1:]
+    assert not accept(bp, pubs_=other_pub)
+    assert not accept(bp, vks_=[vks[1], vks[0], vks[2]])
+    assert not accept(dict(bp, prod_perm_poly_comms_vec=bp["prod_perm_poly_comms_vec"][::-1]))
+    ev2 = dict(bp["poly_evals_vec"][2], perm_next_eval=(bp["poly_evals_vec"][2]["perm_next_eval"] + 1) % r)
+    assert not accept(dict(bp, poly_evals_vec=bp["poly_evals_vec"][:2] + [ev2]))
+    with pytest.raises(V.VerifyError):
+        accept(bp, vks_=vks[:2])
+    # one instance of it alone is the plain single-instance case: the aggregate of one equals Proof -> BatchProof
+    assert V.batch_proof_from({"wires_poly_comms": 1, "prod_perm_poly_comm": 2, "wires_evals": 3, "wire_sigma_evals": 4, "perm_next_eval": 5,
+                               "plookup": None, "split_quot_poly_comms": 6, "opening_proof": 7, "shifted_opening_proof": 8})["poly_evals_vec"] == \
+        [{"wires_evals": 3, "wire_sigma_evals": 4, "perm_next_eval": 5}]
