@@ -50,6 +50,8 @@ def main():
     ap.add_argument("--no-plonk", action="store_true", help="skip the TurboPlonk round-3 (quotient) measurement")
     ap.add_argument("--plonk-log-n", type=int, default=20)
     ap.add_argument("--ultra-log-n", type=int, default=20, help="UltraPlonk/BN254 prove leg (0 disables; config C5 is 22)")
+    ap.add_argument("--secondary-timeout", type=int, default=420, help="N > 1: seconds after which a stalled secondary (sharded prove) section "
+                    "is abandoned and the headline line printed as it stands (0 disables)")
     ap.add_argument("--ultra-sharded-log-n", type=int, default=22, help="N > 1: UltraPlonk/BN254 sharded prove leg (config C5: 22; 0 disables)")
     args = ap.parse_args()
 
@@ -127,6 +129,67 @@ def main():
     sort_ms, _ = mlib.profile_get("msm_sort")
     red_ms, _ = mlib.profile_get("msm_reduce")
     c_bits, n_win, n_buckets = mlib.msm_last_shape()
+
+    out = None
+    if rank == 0:
+        acc_avg_ms = acc_ms / max(acc_cnt, 1)
+        alg_bytes = 128.0 * n                      # SURVEY.md 8(d): N * (2*|Fq| + 32) bytes per BLS12-381 MSM
+        achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9
+        traffic = _profile_value("msm_accumulate_hbm_bytes_per_launch")
+        # the kernel's real ceiling: VALU issue.  Wave-instructions per launch from the committed SQ counters, priced at the
+        # measured 1.9 ns per VOP3 wave-instruction per SIMD (profiles/r01_valu_ubench2.txt), 1024 SIMDs
+        valu = None
+        kern = (_profile_value("kernels") or {}).get(_profile_value("msm_accumulate_kernel") or "")
+        if kern and kern.get("SQ_INSTS_VALU") and args.log_n == 20:
+            bound_ms = kern["SQ_INSTS_VALU"] / 1024 * 1.9e-6
+            # 32-bit integer multiply-adds (v_mad_u64_u32) the launch retires: 13 windows x n mixed adds x (8 products of 2 * 14^2
+            # MADs + 2 squarings of 14 * 15 / 2 + 14^2), SURVEY.md 8(d)'s second figure; peak = 64 lanes / 1.9 ns on 1024 SIMDs
+            mads = n_win * n * (8 * 2 * 196 + 2 * (105 + 196))
+            valu = {"wave_insts_per_launch": kern["SQ_INSTS_VALU"], "issue_bound_ms": round(bound_ms, 3), "util": round(bound_ms / acc_avg_ms, 3),
+                    "int_mad_per_s": round(mads / (acc_avg_ms * 1e-3), -9), "int_mad_peak_per_s": round(1024 * 64 / 1.9e-9, -9),
+                    "note": "SQ_INSTS_VALU of the committed PMC pass (2^20 pairs) x 1.9 ns / 1024 SIMDs vs the live launch time"}
+        out = {
+            "metric": "msm_g1_scalar_pairs_per_s", "value": world * n * args.steps / elapsed, "unit": "pairs/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (381-bit Fq as 14 x 29-bit limbs, Montgomery)",
+            "data": "synthetic",
+            "config": {"workload": f"standalone MSM, 2^{args.log_n} G1 x Fr pairs per GPU, BLS12-381 (BASELINE configs[1])",
+                       "curve": "bls12-381", "pairs_per_gpu": n, "window_bits": c_bits, "windows": n_win,
+                       "buckets_per_window": n_buckets, "sharding": "point-range" if world > 1 else "none",
+                       "srs_gen_s": round(t_srs, 3)},
+            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel<EcFx<BlsFqX>>", "achieved": round(achieved, 3),
+                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
+                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(acc_avg_ms, 4),
+                         "valu_issue": valu,
+                         "note": "integer-ALU bound (381-bit Montgomery mixed adds), not HBM bound: see DESIGN.md"},
+            "phases_ms": {"sort": round(sort_ms / max(tot_cnt, 1), 4), "accumulate": round(acc_avg_ms, 4),
+                          "reduce": round(red_ms / max(tot_cnt, 1), 4), "device_total": round(tot_ms / max(tot_cnt, 1), 4)},
+            "cpu_baseline": None, "ntt": None, "plonk_round3": None, "batch_commit5": None, "prove": None, "prove_cpp_host": None,
+            "prove_sharded": None, "prove_ultra_bn254": None,
+        }
+
+    # The headline line is complete here; everything below is secondary.  With several ranks the secondary part holds collectives
+    # (the sharded proofs): if a rank fails or stalls there, the others would wait for ever and the line would never be printed --
+    # a watchdog prints the headline as it stands and ends the process instead.
+    state = {"printed": False}
+
+    def emit():
+        if rank == 0 and not state["printed"]:
+            state["printed"] = True
+            print(json.dumps(out), flush=True)
+
+    def bail():
+        if rank == 0 and not state["printed"]:
+            out["prove_sharded"] = {"error": "watchdog: the secondary multi-rank section did not finish in %d s" % args.secondary_timeout}
+            emit()
+        os._exit(0)
+
+    watchdog = None
+    if world > 1 and args.secondary_timeout > 0:
+        import threading
+        watchdog = threading.Timer(args.secondary_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
 
     # ---- secondary: batch_commit of 5 polynomials (round 1 / round 3 of a proof) in one fused call -----
     batch = None
@@ -299,9 +362,13 @@ def main():
                                  "(all-gather of Jacobian partials + local EC sum, 8(e).1), quotient domain split into residue classes with one "
                                  "all-gather (8(e).3) when the world size divides 8; iNTTs, grand products, evaluations, openings' polynomials "
                                  "replicated.  Python-orchestrated (compare with `prove` of the 1-GPU line, not with `prove_cpp_host`)",
-                         "turbo_bls12_381": sharded_prove(curve, args.plonk_log_n, "TurboPlonk")}
-        if args.ultra_sharded_log_n:                                   # config C5: UltraPlonk over BN254, 2^22 constraints
-            prove_sharded["ultra_bn254"] = sharded_prove(mj.params.BN254, args.ultra_sharded_log_n, "UltraPlonk")
+                         }
+        try:
+            prove_sharded["turbo_bls12_381"] = sharded_prove(curve, args.plonk_log_n, "TurboPlonk")
+            if args.ultra_sharded_log_n:                               # config C5: UltraPlonk over BN254, 2^22 constraints
+                prove_sharded["ultra_bn254"] = sharded_prove(mj.params.BN254, args.ultra_sharded_log_n, "UltraPlonk")
+        except Exception as e:                                         # noqa: BLE001  (secondary: the headline must still be printed)
+            prove_sharded["error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
 
     # ---- secondary: UltraPlonk (Plookup) on BN254, the shape of config C5 at --ultra-log-n gates, one GPU ---------------
     ultra = None
@@ -405,43 +472,13 @@ def main():
                             "sample": "one forward 2^22-point NTT, oracle/cpu_ref.c in-order radix-2 (ark-poly's algorithm restated)"}}
 
     if rank == 0:
-        acc_avg_ms = acc_ms / max(acc_cnt, 1)
-        alg_bytes = 128.0 * n                      # SURVEY.md 8(d): N * (2*|Fq| + 32) bytes per BLS12-381 MSM
-        achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9
-        traffic = _profile_value("msm_accumulate_hbm_bytes_per_launch")
-        # the kernel's real ceiling: VALU issue.  Wave-instructions per launch from the committed SQ counters, priced at the
-        # measured 1.9 ns per VOP3 wave-instruction per SIMD (profiles/r01_valu_ubench2.txt), 1024 SIMDs
-        valu = None
-        kern = (_profile_value("kernels") or {}).get(_profile_value("msm_accumulate_kernel") or "")
-        if kern and kern.get("SQ_INSTS_VALU") and args.log_n == 20:
-            bound_ms = kern["SQ_INSTS_VALU"] / 1024 * 1.9e-6
-            # 32-bit integer multiply-adds (v_mad_u64_u32) the launch retires: 13 windows x n mixed adds x (8 products of 2 * 14^2
-            # MADs + 2 squarings of 14 * 15 / 2 + 14^2), SURVEY.md 8(d)'s second figure; peak = 64 lanes / 1.9 ns on 1024 SIMDs
-            mads = n_win * n * (8 * 2 * 196 + 2 * (105 + 196))
-            valu = {"wave_insts_per_launch": kern["SQ_INSTS_VALU"], "issue_bound_ms": round(bound_ms, 3), "util": round(bound_ms / acc_avg_ms, 3),
-                    "int_mad_per_s": round(mads / (acc_avg_ms * 1e-3), -9), "int_mad_peak_per_s": round(1024 * 64 / 1.9e-9, -9),
-                    "note": "SQ_INSTS_VALU of the committed PMC pass (2^20 pairs) x 1.9 ns / 1024 SIMDs vs the live launch time"}
-        out = {
-            "metric": "msm_g1_scalar_pairs_per_s", "value": world * n * args.steps / elapsed, "unit": "pairs/s",
-            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (381-bit Fq as 14 x 29-bit limbs, Montgomery)",
-            "data": "synthetic",
-            "config": {"workload": f"standalone MSM, 2^{args.log_n} G1 x Fr pairs per GPU, BLS12-381 (BASELINE configs[1])",
-                       "curve": "bls12-381", "pairs_per_gpu": n, "window_bits": c_bits, "windows": n_win,
-                       "buckets_per_window": n_buckets, "sharding": "point-range" if world > 1 else "none",
-                       "srs_gen_s": round(t_srs, 3)},
-            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel<EcFx<BlsFqX>>", "achieved": round(achieved, 3),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(acc_avg_ms, 4),
-                         "valu_issue": valu,
-                         "note": "integer-ALU bound (381-bit Montgomery mixed adds), not HBM bound: see DESIGN.md"},
-            "phases_ms": {"sort": round(sort_ms / max(tot_cnt, 1), 4), "accumulate": round(acc_avg_ms, 4),
-                          "reduce": round(red_ms / max(tot_cnt, 1), 4), "device_total": round(tot_ms / max(tot_cnt, 1), 4)},
-            "cpu_baseline": cpu, "ntt": ntt, "plonk_round3": plonk, "batch_commit5": batch, "prove": prove, "prove_cpp_host": prove_cpp, "prove_sharded": prove_sharded, "prove_ultra_bn254": ultra,
-        }
-        print(json.dumps(out), flush=True)
+        out.update({"cpu_baseline": cpu, "ntt": ntt, "plonk_round3": plonk, "batch_commit5": batch, "prove": prove, "prove_cpp_host": prove_cpp,
+                    "prove_sharded": prove_sharded, "prove_ultra_bn254": ultra})
+        emit()
     if world > 1:
         dist.barrier()
+        if watchdog is not None:
+            watchdog.cancel()
         dist.destroy_process_group()
 
 

@@ -28,3 +28,30 @@ def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
     assert d["prove"]["quotient_degree_ok"] is True and d["prove_ultra_bn254"]["quotient_degree_ok"] is True
     assert d["prove_cpp_host"]["turbo_bls12_381"]["proof_bytes"] == d["prove"]["proof_bytes"]
     assert d["prove_cpp_host"]["ultra_bn254"]["proof_bytes"] == d["prove_ultra_bn254"]["proof_bytes"]
+
+
+def _two_ranks(extra_args, port):
+    env = dict(os.environ, MZK_BENCH_BACKEND="gloo", MZK_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-n", "14", "--plonk-log-n", "10", "--ultra-sharded-log-n", "10", "--steps", "2",
+           "--warmup", "1", "--no-cpu-baseline"] + extra_args
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
+    lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
+    return out, lines
+
+
+def test_bench_two_ranks_rehearsal_and_watchdog(gpu):
+    """The N > 1 launch of the contract, rehearsed with two ranks on the one GPU over gloo: one JSON line from rank 0 with the
+    whole-job value and the sharded proofs; and with a secondary section that cannot finish in time, the watchdog still prints
+    the headline line (the driver's SCALE run must never end without one)."""
+    out, lines = _two_ranks([], 29631)
+    assert out.returncode == 0, out.stderr[-3000:]
+    assert len(lines) == 1, lines
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
+    sh = d["prove_sharded"]
+    assert "error" not in sh and sh["turbo_bls12_381"]["ranks_agree_on_proof"] and sh["ultra_bn254"]["ranks_agree_on_proof"]
+    out, lines = _two_ranks(["--secondary-timeout", "1", "--plonk-log-n", "16", "--ultra-sharded-log-n", "16"], 29633)
+    assert len(lines) == 1, (lines, out.stderr[-2000:])
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["value"] > 0 and "watchdog" in d["prove_sharded"]["error"]
