@@ -418,8 +418,19 @@ def main():
             try:
                 r = subprocess.run([binp] + argv, capture_output=True, text=True, timeout=600)
                 d = json.loads(r.stdout.strip().splitlines()[-1])
-                d.pop("proof_hex", None)
+                proof_hex = d.pop("proof_hex", None)
+                d.pop("vk_hex", None)
                 d["ns_per_gate"] = round(d["prove_ms"] * 1e6 / d["num_gates"], 1)
+                # the printed proof is the first one after preprocess on a fresh `test_rng`: the Python mirror must emit the same bytes
+                crv = mj.params.CURVES[int(argv[0])]
+                csx = mj.snark.gen_circuit_for_bench(crv, int(argv[2]), "UltraPlonk" if argv[1] == "ultra" else "TurboPlonk")
+                rngx = mj.rng.test_rng()
+                ckx = mj.UnivariateProverParam.gen_srs_for_testing(crv, mj.rng.fr_rand(crv, rngx), csx.n + 2)
+                pkx = mj.snark.preprocess(ckx, csx)
+                d["proof_matches_python_mirror"] = bool(mj.snark.prove(rngx, csx, pkx)[1].hex() == proof_hex)
+                pkx.release()
+                ckx.release()
+                del csx
                 prove_cpp[name] = d
             except Exception as e:                      # noqa: BLE001  (the binary is optional for the headline)
                 prove_cpp[name] = {"error": repr(e)[:200]}

@@ -272,7 +272,7 @@ struct StandardTranscript {
     using E = Encoding<C>;
     using Fr = typename E::Fr;
     MerlinTranscript t;
-    StandardTranscript() : t("PlonkProof") {}
+    explicit StandardTranscript(const char* label = "PlonkProof") : t(label) {}
     void append_message(const std::string& label, const uint8_t* m, size_t n) { t.append_message(label, m, n); }
     void append_u64(const std::string& label, uint64_t v) { uint8_t b[8]; std::memcpy(b, &v, 8); t.append_message(label, b, 8); }
     void append_u32(const std::string& label, uint32_t v) { uint8_t b[4]; std::memcpy(b, &v, 4); t.append_message(label, b, 4); }
@@ -288,7 +288,11 @@ struct StandardTranscript {
         // reduce each 256-bit half: load as an integer < 2^256 and multiply by R2 (Montgomery conversion reduces mod r)
         Fr r2;
         for (int i = 0; i < 4; i++) { lo.l[i] = w[i]; hi.l[i] = w[4 + i]; r2.l[i] = Fr::c64(C::Fr::R2, i); }
-        const Fr lo_m = lo * r2, hi_m = hi * r2;                      // (x mod r) in Montgomery form (the product reduces any x < 2^256)
+        // the halves are raw 256-bit integers, up to 2.2 r (BLS12-381) / 5.3 r (BN254): bring them below r first -- the Montgomery
+        // product (no-carry CIOS) is only defined for reduced operands and drops a carry for larger ones
+        while (Fr::geq_mod(lo.l)) Fr::sub_mod(lo.l);
+        while (Fr::geq_mod(hi.l)) Fr::sub_mod(hi.l);
+        const Fr lo_m = lo * r2, hi_m = hi * r2;                      // (x mod r) in Montgomery form
         Fr two256 = Fr::one();                                        // Montgomery image of 1 is R = 2^256 mod r, i.e. the integer 2^256: as a field element it is r2 * 1
         two256 = r2;                                                  // value(r2 as Montgomery) = R2 / R = R = 2^256 mod r
         const Fr c = lo_m + hi_m * two256;

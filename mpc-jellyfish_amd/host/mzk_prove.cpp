@@ -2,6 +2,9 @@
 // include/mzk.h, no Python, no HIP in this translation unit (g++ builds it).
 //   mzk_prove <curve: 0 BLS12-381 | 1 BN254> <turbo|ultra> <num_gates> [reps] [range_bit_len]
 // Prints one JSON line: proof bytes (hex), wall time per proof, per-round times of one profiled proof.
+//   mzk_prove <curve> link <num_gates_1> <num_gates_2> <alignment> <offset> <size> [reps]
+// proves two TurboPlonk bench circuits of one domain size (wire 0 of the bench circuit holds 0, 1, 2, .. so any rows below both
+// gate counts are shared witnesses), then PlonkKzgSnark::link_proofs on their hints; prints both proofs and the LinkingProof.
 #include <chrono>
 #include <cstdlib>
 
@@ -44,7 +47,50 @@ int run(bool ultra, uint64_t num_gates, int reps, int range_bits) {
                 C::ID, ultra ? "UltraPlonk" : "TurboPlonk", (unsigned long long)num_gates, cs.log_n, bytes.size(), ms, circuit_s, preprocess_s);
     bool first = true;
     for (auto& kv : prover.timings_ms) { std::printf("%s\"%s\": %.3f", first ? "" : ", ", kv.first.c_str(), kv.second); first = false; }
-    std::printf("}, \"proof_hex\": \"%s\"}\n", hex.c_str());
+    std::vector<uint8_t> vk_bytes;                                      // VerifyingKey commitments (selectors, then sigmas), compressed
+    for (const auto* v : {&prover.selector_comms, &prover.sigma_comms})
+        for (const auto& cm : *v) { uint8_t b[48]; Encoding<C>::g1_bytes(cm, b); vk_bytes.insert(vk_bytes.end(), b, b + C::G1_BYTES); }
+    std::string vk_hex;
+    for (uint8_t b : vk_bytes) { vk_hex.push_back(d[b >> 4]); vk_hex.push_back(d[b & 15]); }
+    std::printf("}, \"vk_hex\": \"%s\", \"proof_hex\": \"%s\"}\n", vk_hex.c_str(), hex.c_str());
+    (void)mzk_srs_release(srs);
+    return 0;
+}
+
+static std::string to_hex(const std::vector<uint8_t>& bytes) {
+    std::string hex;
+    static const char* d = "0123456789abcdef";
+    for (uint8_t b : bytes) { hex.push_back(d[b >> 4]); hex.push_back(d[b & 15]); }
+    return hex;
+}
+
+template <class C>
+int run_link(uint64_t gates1, uint64_t gates2, const GroupLayout& layout, int reps) {
+    using Fr = Fp64<typename C::Fr>;
+    check(mzk_init(-1), "mzk_init");
+    BenchCircuit<C> cs1 = BenchCircuit<C>::generate(gates1, false, 8), cs2 = BenchCircuit<C>::generate(gates2, false, 8);
+    if (cs1.n != cs2.n) throw std::runtime_error("the two bench circuits must share one domain size");
+    ChaChaRng rng = test_rng();
+    const Fr beta = fr_rand<typename C::Fr>(rng);
+    const auto beta_c = canonical(beta);
+    uint64_t srs = 0;
+    check(mzk_srs_generate_for_testing(C::ID, beta_c.data(), cs1.n + 3, &srs), "mzk_srs_generate_for_testing");
+    Prover<C> p1(srs, cs1), p2(srs, cs2);
+    Proof<C> proof1 = p1.prove(rng, cs1);
+    LinkingHint<C> h1 = link_hint(p1, proof1);
+    Proof<C> proof2 = p2.prove(rng, cs2);
+    LinkingHint<C> h2 = link_hint(p2, proof2);
+    LinkingProof<C> link = link_proofs<C>(srs, h1, h2, layout);
+    double ms = 0;
+    if (reps > 0) {
+        check(mzk_dev_sync(), "sync");
+        auto t0 = std::chrono::steady_clock::now();
+        for (int i = 0; i < reps; i++) link_proofs<C>(srs, h1, h2, layout);
+        check(mzk_dev_sync(), "sync");
+        ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
+    }
+    std::printf("{\"curve\": %d, \"log_n\": %d, \"link_ms\": %.3f, \"proof1_hex\": \"%s\", \"proof2_hex\": \"%s\", \"link_proof_hex\": \"%s\"}\n", C::ID, cs1.log_n, ms,
+                to_hex(proof1.serialize_compressed()).c_str(), to_hex(proof2.serialize_compressed()).c_str(), to_hex(link.serialize_compressed()).c_str());
     (void)mzk_srs_release(srs);
     return 0;
 }
@@ -52,6 +98,18 @@ int run(bool ultra, uint64_t num_gates, int reps, int range_bits) {
 int main(int argc, char** argv) {
     if (argc < 4) { std::fprintf(stderr, "usage: %s <curve 0|1> <turbo|ultra> <num_gates> [reps] [range_bit_len]\n", argv[0]); return 2; }
     const int curve = std::atoi(argv[1]);
+    if (std::string(argv[2]) == "link") {
+        if (argc < 8) { std::fprintf(stderr, "usage: %s <curve 0|1> link <num_gates_1> <num_gates_2> <alignment> <offset> <size> [reps]\n", argv[0]); return 2; }
+        const GroupLayout layout{(uint32_t)std::atoi(argv[5]), std::strtoull(argv[6], nullptr, 10), std::strtoull(argv[7], nullptr, 10)};
+        const uint64_t g1 = std::strtoull(argv[3], nullptr, 10), g2 = std::strtoull(argv[4], nullptr, 10);
+        const int reps = argc > 8 ? std::atoi(argv[8]) : 0;
+        try {
+            return curve == 0 ? run_link<Bls12_381>(g1, g2, layout, reps) : run_link<Bn254>(g1, g2, layout, reps);
+        } catch (const std::exception& e) {
+            std::fprintf(stderr, "mzk_prove: %s\n", e.what());
+            return 1;
+        }
+    }
     const bool ultra = std::string(argv[2]) == "ultra";
     const uint64_t gates = std::strtoull(argv[3], nullptr, 10);
     const int reps = argc > 4 ? std::atoi(argv[4]) : 0, range_bits = argc > 5 ? std::atoi(argv[5]) : 8;

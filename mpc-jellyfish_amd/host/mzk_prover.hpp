@@ -3,6 +3,7 @@
 #pragma once
 #include <chrono>
 #include <map>
+#include <tuple>
 
 #include "mzk_host.hpp"
 
@@ -450,5 +451,91 @@ struct Prover {                                                        // Provin
         return proof;
     }
 };
+
+// ---- proof linking (plonk/src/proof_system/proof_linking.rs) -----------------------------------------------------------
+struct GroupLayout {                                                   // relation/src/proof_linking/mod.rs:16-54
+    uint32_t alignment;
+    uint64_t offset, size;
+};
+template <class C>
+struct LinkingHint {                                                   // structs.rs:88-97: the masked a(X) on the device + its commitment
+    DevBuf linking_wire_poly;
+    uint64_t len = 0;
+    typename Encoding<C>::Affine linking_wire_comm;
+};
+template <class C>
+struct LinkingProof {                                                  // proof_linking.rs:33-39
+    typename Encoding<C>::Affine quotient_commitment, opening_proof;
+    std::vector<uint8_t> serialize_compressed() const {
+        std::vector<uint8_t> out(2 * C::G1_BYTES);
+        Encoding<C>::g1_bytes(quotient_commitment, out.data());
+        Encoding<C>::g1_bytes(opening_proof, out.data() + C::G1_BYTES);
+        return out;
+    }
+};
+
+// the hint of PlonkKzgSnark::prove_with_link_hint (snark.rs:81-119), taken from the prover right after `prove`
+template <class C>
+LinkingHint<C> link_hint(const Prover<C>& prover, const Proof<C>& proof) {
+    LinkingHint<C> h;
+    h.len = prover.n + 2;
+    h.linking_wire_poly.alloc(h.len);
+    check(mzk_dev_copy(h.linking_wire_poly.p, prover.keep.p, h.len * EL, nullptr), "copy");            // keep row 0 = wire polynomial 0
+    h.linking_wire_comm = proof.wires_poly_comms[0];
+    return h;
+}
+
+// PlonkKzgSnark::link_proofs (proof_linking.rs:80-111)
+template <class C>
+LinkingProof<C> link_proofs(uint64_t srs, const LinkingHint<C>& lhs, const LinkingHint<C>& rhs, const GroupLayout& layout) {
+    using E = Encoding<C>;
+    using Fr = typename E::Fr;
+    using FrP = typename C::Fr;
+    using Affine = typename E::Affine;
+    constexpr int QL = E::QL;
+    if ((int)layout.alignment > FrP::TWO_ADICITY) throw std::runtime_error("field 2-adicity too small for layout");
+    const uint64_t len = std::max(lhs.len, rhs.len);
+    auto lincomb = [&](const std::vector<std::tuple<Fr, const void*, uint64_t>>& terms, void* out, uint64_t out_len) {
+        std::vector<const void*> ptrs;
+        std::vector<uint64_t> lens, sc;
+        for (auto& t : terms) { ptrs.push_back(std::get<1>(t)); lens.push_back(std::get<2>(t)); for (int i = 0; i < 4; i++) sc.push_back(std::get<0>(t).l[i]); }
+        check(mzk_poly_lincomb_dev(C::ID, (uint32_t)terms.size(), ptrs.data(), lens.data(), sc.data(), out, out_len, nullptr), "mzk_poly_lincomb_dev");
+    };
+    auto commit = [&](const void* poly, uint64_t n_coeffs) {
+        Affine out;
+        std::memset(out.data(), 0, sizeof(Affine));
+        if (n_coeffs == 0) return out;
+        uint64_t xyz[3 * QL];
+        const void* ptrs[1] = {poly};
+        const uint64_t lens[1] = {n_coeffs};
+        check(mzk_msm_batch_dev(srs, 1, ptrs, lens, nullptr, 1, xyz, nullptr), "mzk_msm_batch_dev");
+        check(mzk_g1_jacobian_to_affine(C::ID, xyz, 1, reinterpret_cast<uint64_t*>(out.data())), "mzk_g1_jacobian_to_affine");
+        return out;
+    };
+    const Fr one = Fr::one(), minus_one = Fr::zero() - Fr::one();
+    // quotient (a_1 - a_2) / Z_D (proof_linking.rs:119-134)
+    DevBuf diff(len), quotient(len > layout.size ? len - layout.size : 0), identity(len), witness(len - 1);
+    lincomb({{one, lhs.linking_wire_poly.p, lhs.len}, {minus_one, rhs.linking_wire_poly.p, rhs.len}}, diff.p, len);
+    const uint64_t q_len = quotient.elems;
+    if (q_len) check(mzk_poly_div_roots_dev(C::ID, diff.p, len, layout.alignment, layout.offset, layout.size, quotient.p, nullptr), "mzk_poly_div_roots_dev");
+    LinkingProof<C> proof;
+    proof.quotient_commitment = commit(quotient.p, q_len);
+    // eta (proof_linking.rs:185-197)
+    StandardTranscript<C> tr("PlonkLinkingProof");
+    tr.append_commitment("linking_wire_comms", lhs.linking_wire_comm);
+    tr.append_commitment("linking_wire_comms", rhs.linking_wire_comm);
+    tr.append_commitment("quotient_comm", proof.quotient_commitment);
+    const Fr eta = tr.get_and_append_challenge("eta");
+    // Z_D(eta) (proof_linking.rs:162-176)
+    const Fr g = root_of_unity<FrP>((int)layout.alignment);
+    Fr root = pow_u64(g, layout.offset), z_eta = Fr::one();
+    for (uint64_t i = 0; i < layout.size; i++) { z_eta = z_eta * (eta - root); root = root * g; }
+    // identity polynomial a_1 - a_2 - q Z_D(eta), opened at eta (proof_linking.rs:204-221, univariate_kzg/mod.rs:135-161)
+    if (q_len) lincomb({{one, diff.p, len}, {Fr::zero() - z_eta, quotient.p, q_len}}, identity.p, len);
+    else lincomb({{one, diff.p, len}}, identity.p, len);
+    check(mzk_poly_div_linear_dev(C::ID, identity.p, len, eta.l, witness.p, nullptr), "mzk_poly_div_linear_dev");
+    proof.opening_proof = commit(witness.p, len - 1);
+    return proof;
+}
 
 }  // namespace mzk_host

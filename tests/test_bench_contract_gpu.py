@@ -28,6 +28,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
     assert d["prove"]["quotient_degree_ok"] is True and d["prove_ultra_bn254"]["quotient_degree_ok"] is True
     assert d["prove_cpp_host"]["turbo_bls12_381"]["proof_bytes"] == d["prove"]["proof_bytes"]
     assert d["prove_cpp_host"]["ultra_bn254"]["proof_bytes"] == d["prove_ultra_bn254"]["proof_bytes"]
+    assert all(v.get("proof_matches_python_mirror") is True for v in d["prove_cpp_host"].values()), d["prove_cpp_host"]
 
 
 def _two_ranks(extra_args, port):

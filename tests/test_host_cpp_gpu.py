@@ -31,3 +31,61 @@ def test_cpp_host_prove_matches_python_mirror(gpu, mj, curve_id, plonk_type, num
     assert got["proof_hex"] == proof_bytes.hex()
     pk.release()
     ck.release()
+
+
+@pytest.mark.parametrize("curve_id,gates,layout_args", [(1, (100, 120), (7, 5, 60)), (0, (3000, 2500), (10, 40, 300))])
+def test_cpp_host_link_proofs_matches_python_mirror(gpu, mj, pyref, curve_id, gates, layout_args):
+    """PlonkKzgSnark::prove_with_link_hint twice + ::link_proofs from the compiled host (mzk_prove <curve> link ...): both proofs and
+    the LinkingProof byte for byte equal to the Python mirror's, and the restated link verifier accepts it."""
+    import pyref_linking as L
+    import pyref_verifier as V
+    if not os.path.exists(BIN):
+        subprocess.check_call(["make", "-C", os.path.join(ROOT, "mpc-jellyfish_amd", "host"), "-s"])
+    out = subprocess.run([BIN, str(curve_id), "link", str(gates[0]), str(gates[1])] + [str(x) for x in layout_args], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    c, pc = mj.params.CURVES[curve_id], pyref.CURVES[curve_id]
+    circuits = [mj.snark.gen_circuit_for_bench(c, g, "TurboPlonk") for g in gates]
+    assert circuits[0].n == circuits[1].n
+    rng = mj.rng.test_rng()
+    srs_beta = mj.rng.fr_rand(c, rng)
+    ck = mj.UnivariateProverParam.gen_srs_for_testing(c, srs_beta, circuits[0].n + 2)
+    pks = [mj.snark.preprocess(ck, cs) for cs in circuits]
+    _, bytes1, h1 = mj.snark.prove_with_link_hint(rng, circuits[0], pks[0])
+    _, bytes2, h2 = mj.snark.prove_with_link_hint(rng, circuits[1], pks[1])
+    link = mj.linking.link_proofs(h1, h2, mj.linking.GroupLayout(*layout_args), ck)
+    assert got["proof1_hex"] == bytes1.hex() and got["proof2_hex"] == bytes2.hex()
+    assert got["link_proof_hex"] == link.serialize_compressed().hex()
+    # the verifier's view: wire commitments out of the two proofs, the link proof out of its bytes
+    pr1, pr2 = V.deserialize_proof(pc, bytes1), V.deserialize_proof(pc, bytes2)
+    blob = bytes.fromhex(got["link_proof_hex"])
+    g1_len = len(blob) // 2
+    q, o = V.g1_decompress(pc, blob[:g1_len]), V.g1_decompress(pc, blob[g1_len:])
+    fresh = lambda: mj.transcript.StandardTranscript(c, b"PlonkLinkingProof")
+    assert L.verify_link_proof(pc, fresh(), pr1["wires_poly_comms"][0], pr2["wires_poly_comms"][0], q, o, L.GroupLayout(*layout_args), srs_beta)
+    al, off, size = layout_args
+    assert not L.verify_link_proof(pc, fresh(), pr1["wires_poly_comms"][0], pr2["wires_poly_comms"][0], q, o, L.GroupLayout(al, off + 1, size), srs_beta)
+    for pk in pks:
+        pk.release()
+    ck.release()
+
+
+@pytest.mark.parametrize("curve_id,plonk_type", [(0, "TurboPlonk"), (1, "TurboPlonk"), (0, "UltraPlonk"), (1, "UltraPlonk")])
+def test_cpp_host_matches_python_over_many_transcripts(gpu, mj, curve_id, plonk_type):
+    """Sixteen different circuits per curve and proof system: every one has its own six transcript challenges, each the
+    reduction of two raw 256-bit halves of up to 2.2 r (BLS12-381) / 5.3 r (BN254) -- the C++ transcript once multiplied the
+    unreduced halves (a dropped carry in roughly every second proof); identical proof bytes across many transcripts pin it."""
+    c = mj.params.CURVES[curve_id]
+    ultra = plonk_type == "UltraPlonk"
+    for gates in (17, 23, 40, 41, 77, 100, 129, 200, 255, 300, 511, 600, 1000, 1024, 2047, 2048):
+        out = subprocess.run([BIN, str(curve_id), "ultra" if ultra else "turbo", str(gates), "0", "5"], capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        got = json.loads(out.stdout.strip().splitlines()[-1])
+        cs = mj.snark.gen_circuit_for_bench(c, gates, plonk_type, range_bit_len=5)
+        rng = mj.rng.test_rng()
+        ck = mj.UnivariateProverParam.gen_srs_for_testing(c, mj.rng.fr_rand(c, rng), cs.n + 2)
+        pk = mj.snark.preprocess(ck, cs)
+        _, proof_bytes = mj.snark.prove(rng, cs, pk)
+        assert got["proof_hex"] == proof_bytes.hex(), gates
+        pk.release()
+        ck.release()
