@@ -33,9 +33,12 @@ def verifying_key(mj, pc, pk, num_inputs):
 
 
 @pytest.mark.parametrize("curve_id,plonk_type,num_gates,range_bits", [(0, "TurboPlonk", 1 << 12, 8), (1, "TurboPlonk", 100, 8),
-                                                                      (1, "UltraPlonk", 1 << 11, 8), (0, "UltraPlonk", 40, 4)])
+                                                                      (1, "UltraPlonk", 1 << 11, 8), (0, "UltraPlonk", 40, 4),
+                                                                      (1, "TurboPlonk", 1 << 16, 8), (0, "UltraPlonk", 1 << 17, 8),
+                                                                      (0, "TurboPlonk", 1 << 20, 8), (1, "UltraPlonk", 1 << 22, 8)])
 def test_bench_circuit_proof_verifies(gpu, mj, pyref, curve_id, plonk_type, num_gates, range_bits):
-    """PlonkKzgSnark::prove on the reference's bench circuit (plonk/benches/bench.rs:29-46), then PlonkKzgSnark::verify."""
+    """PlonkKzgSnark::prove on the reference's bench circuit (plonk/benches/bench.rs:29-46), then PlonkKzgSnark::verify -- up to
+    BASELINE.json's configurations C4 (TurboPlonk, BLS12-381, 2^20 gates) and C5 (UltraPlonk, BN254, 2^22 gates) (the verifier's work does not grow with the circuit: ~50 G1 scalar multiplications)."""
     import pyref_verifier as V
     c, pc = mj.params.CURVES[curve_id], pyref.CURVES[curve_id]
     cs = mj.snark.gen_circuit_for_bench(c, num_gates, plonk_type, range_bit_len=range_bits)
