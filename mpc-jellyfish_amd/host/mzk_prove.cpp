@@ -3,10 +3,13 @@
 //   mzk_prove <curve: 0 BLS12-381 | 1 BN254> <turbo|ultra> <num_gates> [reps] [range_bit_len]
 // Prints one JSON line: proof bytes (hex), wall time per proof, per-round times of one profiled proof.
 //   mzk_prove <curve> link <num_gates_1> <num_gates_2> <alignment> <offset> <size> [reps]
-// proves two TurboPlonk bench circuits of one domain size (wire 0 of the bench circuit holds 0, 1, 2, .. so any rows below both
+//   mzk_prove <curve> batch <turbo|ultra> <range_bit_len> <num_gates_1> <num_gates_2> ...
+// PlonkKzgSnark::batch_prove: one aggregated BatchProof over bench circuits of one domain size; prints its bytes.
+// (link:) proves two TurboPlonk bench circuits of one domain size (wire 0 of the bench circuit holds 0, 1, 2, .. so any rows below both
 // gate counts are shared witnesses), then PlonkKzgSnark::link_proofs on their hints; prints both proofs and the LinkingProof.
 #include <chrono>
 #include <cstdlib>
+#include <memory>
 
 #include "mzk_prover.hpp"
 
@@ -95,6 +98,34 @@ int run_link(uint64_t gates1, uint64_t gates2, const GroupLayout& layout, int re
     return 0;
 }
 
+template <class C>
+int run_batch(bool ultra, int range_bits, const std::vector<uint64_t>& gates) {
+    using Fr = Fp64<typename C::Fr>;
+    check(mzk_init(-1), "mzk_init");
+    std::vector<BenchCircuit<C>> circuits;
+    for (uint64_t g : gates) circuits.push_back(BenchCircuit<C>::generate(g, ultra, range_bits));
+    ChaChaRng rng = test_rng();
+    const Fr beta = fr_rand<typename C::Fr>(rng);
+    const auto beta_c = canonical(beta);
+    uint64_t srs = 0;
+    check(mzk_srs_generate_for_testing(C::ID, beta_c.data(), circuits[0].n + 3, &srs), "mzk_srs_generate_for_testing");
+    std::vector<std::unique_ptr<Prover<C>>> owned;
+    std::vector<Prover<C>*> provers;
+    std::vector<const BenchCircuit<C>*> cs;
+    for (auto& c : circuits) {
+        if (c.n != circuits[0].n) throw std::runtime_error("circuit domain size != expected domain size");
+        owned.push_back(std::make_unique<Prover<C>>(srs, c));
+        provers.push_back(owned.back().get());
+        cs.push_back(&c);
+    }
+    const BatchProof<C> proof = batch_prove<C>(rng, provers, cs);
+    std::printf("{\"curve\": %d, \"log_n\": %d, \"instances\": %zu, \"batch_proof_hex\": \"%s\"}\n", C::ID, circuits[0].log_n, gates.size(),
+                to_hex(proof.serialize_compressed()).c_str());
+    owned.clear();
+    (void)mzk_srs_release(srs);
+    return 0;
+}
+
 int main(int argc, char** argv) {
     if (argc < 4) { std::fprintf(stderr, "usage: %s <curve 0|1> <turbo|ultra> <num_gates> [reps] [range_bit_len]\n", argv[0]); return 2; }
     const int curve = std::atoi(argv[1]);
@@ -105,6 +136,18 @@ int main(int argc, char** argv) {
         const int reps = argc > 8 ? std::atoi(argv[8]) : 0;
         try {
             return curve == 0 ? run_link<Bls12_381>(g1, g2, layout, reps) : run_link<Bn254>(g1, g2, layout, reps);
+        } catch (const std::exception& e) {
+            std::fprintf(stderr, "mzk_prove: %s\n", e.what());
+            return 1;
+        }
+    }
+    if (std::string(argv[2]) == "batch") {
+        if (argc < 6) { std::fprintf(stderr, "usage: %s <curve 0|1> batch <turbo|ultra> <range_bit_len> <num_gates> ...\n", argv[0]); return 2; }
+        std::vector<uint64_t> gates;
+        for (int i = 5; i < argc; i++) gates.push_back(std::strtoull(argv[i], nullptr, 10));
+        try {
+            const bool u = std::string(argv[3]) == "ultra";
+            return curve == 0 ? run_batch<Bls12_381>(u, std::atoi(argv[4]), gates) : run_batch<Bn254>(u, std::atoi(argv[4]), gates);
         } catch (const std::exception& e) {
             std::fprintf(stderr, "mzk_prove: %s\n", e.what());
             return 1;

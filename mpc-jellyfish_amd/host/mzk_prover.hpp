@@ -241,85 +241,98 @@ struct Prover {                                                        // Provin
         void mark(const char* name) { if (on) { (void)mzk_dev_sync(); t[name] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); reset(); } }
     };
 
-    // PlonkKzgSnark::prove (snark.rs:624-651) -> batch_prove_internal (:201-469), one instance
-    Proof<C> prove(ChaChaRng& rng, const BenchCircuit<C>& cs, bool profile = false) {
-        Tick tick(timings_ms, profile);
-        // blinders: every DensePolynomial::rand / F::rand of the proof in draw order (prover.rs:79-83, 113-114, 133-138, 169-180, 947-955)
-        auto draw = [&](int cnt) { std::vector<Fr> v; for (int i = 0; i < cnt; i++) v.push_back(fr_rand<FrP>(rng)); return v; };
-        std::vector<std::vector<Fr>> b_wires, b_h;
-        for (int i = 0; i < W; i++) b_wires.push_back(draw(2));
-        if (ultra) { b_h.push_back(draw(3)); b_h.push_back(draw(3)); }
-        const std::vector<Fr> b_z = draw(3), b_pl = ultra ? draw(3) : std::vector<Fr>{}, b_quot = draw(W - 1);
-        // transcript (snark.rs:263-270)
-        StandardTranscript<C> tr;
+    // ---- the rounds of one instance as stages, so that batch_prove can interleave several instances the way
+    // ---- batch_prove_internal does (snark.rs:263-431).  `st` carries what Oracles + Challenges carry for the instance in flight.
+    struct Blinds { std::vector<std::vector<Fr>> wires, h; std::vector<Fr> z, pl; };
+    struct State {
+        Blinds b;
+        const BenchCircuit<C>* cs = nullptr;
+        Fr tau, beta, gamma, alpha, zeta;
+        std::vector<Fr> wires_evals, wire_sigma_evals, plookup_evals;
+        Fr perm_next_eval;
+    } st;
+    int rowZ() const { return W; }
+    int rowPI() const { return W + 1; }
+    int rowH1() const { return W + 2; }
+    int rowPL() const { return W + 4; }
+    void* row(int r) const { return slab.at((size_t)r * m); }
+    void* krow(int r) const { return keep.at((size_t)r * (n + 3)); }
+    void* fix(int r) const { return fixed.at((size_t)r * n); }
+
+    void append_vk_and_pub_input(StandardTranscript<C>& tr) const {       // transcript/mod.rs:45-104; the bench circuit has no public input
         tr.append_u32("field size in bits", (uint32_t)FrP::BITS);
         tr.append_u64("domain size", n);
         tr.append_u64("input size", 0);
         for (auto& ki : k) tr.append_fr("wire subsets separators", ki);
         for (auto& cm : selector_comms) tr.append_commitment("selector commitments", cm);
         for (auto& cm : sigma_comms) tr.append_commitment("sigma commitments", cm);
-        Proof<C> proof;
-        proof.has_plookup = ultra;
-        const int Z = W, PI = W + 1, H1 = W + 2, PL = W + 4;
-        auto row = [&](int r) { return slab.at((size_t)r * m); };
-        auto krow = [&](int r) { return keep.at((size_t)r * (n + 3)); };
-        auto fix = [&](int r) { return fixed.at((size_t)r * n); };
-        const int sigma0 = nsel, tab0 = nsel + W;
-        // ---- round 1 (prover.rs:72-87)
+    }
+    // round 1 (prover.rs:72-87)
+    std::vector<Affine> round1(const BenchCircuit<C>& cs, Blinds blinds, Tick& tick) {
+        st = State();
+        st.cs = &cs;
+        st.b = std::move(blinds);
         check(mzk_dev_copy(coeff.p, cs.wire_values.p, (size_t)W * n * EL, nullptr), "copy");
         check(mzk_dev_memset(coeff.at((size_t)W * n), 0, n * EL, nullptr), "memset");                        // the bench circuit has no public input
         check(mzk_ntt_dev(C::ID, coeff.p, n, log_n, 1, nullptr, W + 1, n, nullptr), "mzk_ntt_dev");
         for (int r = 0; r < rows; r++) check(mzk_dev_memset(static_cast<uint8_t*>(row(r)) + n * EL, 0, 3 * EL, nullptr), "memset");
         check(mzk_dev_copy2d(slab.p, m * EL, coeff.p, n * EL, n * EL, W, nullptr), "copy2d");
-        check(mzk_dev_copy(row(PI), coeff.at((size_t)W * n), n * EL, nullptr), "copy");
-        { std::vector<int> rs; for (int i = 0; i < W; i++) rs.push_back(i); mask(rs, b_wires); }
+        check(mzk_dev_copy(row(rowPI()), coeff.at((size_t)W * n), n * EL, nullptr), "copy");
+        { std::vector<int> rs; for (int i = 0; i < W; i++) rs.push_back(i); mask(rs, st.b.wires); }
         tick.mark("r1_ntt_mask");
-        {
-            std::vector<const void*> p; std::vector<uint64_t> l;
-            for (int i = 0; i < W; i++) { p.push_back(row(i)); l.push_back(n + 2); }
-            proof.wires_poly_comms = commit(p, l);
-        }
+        std::vector<const void*> p; std::vector<uint64_t> l;
+        for (int i = 0; i < W; i++) { p.push_back(row(i)); l.push_back(n + 2); }
+        auto comms = commit(p, l);
         tick.mark("r1_commit");
-        for (auto& cm : proof.wires_poly_comms) tr.append_commitment("witness_poly_comms", cm);
-        const Fr tau = tr.get_and_append_challenge("tau");
-        // ---- round 1.5 (prover.rs:89-118)
-        if (ultra) {
-            check(mzk_plookup_sorted_vec_dev(pk, cs.wire_values.p, tau.l, table.p, lookup.p, sorted.p, nullptr), "mzk_plookup_sorted_vec_dev");
-            check(mzk_dev_copy(hh.p, sorted.p, n * EL, nullptr), "copy");
-            check(mzk_dev_copy(hh.at(n), sorted.at(n - 1), n * EL, nullptr), "copy");
-            check(mzk_ntt_dev(C::ID, hh.p, n, log_n, 1, nullptr, 2, n, nullptr), "mzk_ntt_dev");
-            check(mzk_dev_copy2d(row(H1), m * EL, hh.p, n * EL, n * EL, 2, nullptr), "copy2d");
-            mask({H1, H1 + 1}, b_h);
-            tick.mark("r1_5_sorted_vec");
-            proof.h_poly_comms = commit({row(H1), row(H1 + 1)}, {n + 3, n + 3});
-            tick.mark("r1_5_commit");
-            for (auto& cm : proof.h_poly_comms) tr.append_commitment("h_poly_comms", cm);
-        }
-        // ---- round 2 (prover.rs:125-141)
-        const Fr beta = tr.get_and_append_challenge("beta"), gamma = tr.get_and_append_challenge("gamma");
-        check(mzk_plonk_perm_product_dev(pk, cs.wire_values.p, beta.l, gamma.l, coeff.p, nullptr), "mzk_plonk_perm_product_dev");
-        check(mzk_dev_copy(row(Z), coeff.p, n * EL, nullptr), "copy");
-        mask({Z}, {b_z});
+        return comms;
+    }
+    // round 1.5 (prover.rs:89-118), UltraPlonk only
+    std::vector<Affine> round1_5(const Fr& tau, Tick& tick) {
+        st.tau = tau;
+        if (!ultra) return {};
+        const int H1 = rowH1();
+        check(mzk_plookup_sorted_vec_dev(pk, st.cs->wire_values.p, tau.l, table.p, lookup.p, sorted.p, nullptr), "mzk_plookup_sorted_vec_dev");
+        check(mzk_dev_copy(hh.p, sorted.p, n * EL, nullptr), "copy");
+        check(mzk_dev_copy(hh.at(n), sorted.at(n - 1), n * EL, nullptr), "copy");
+        check(mzk_ntt_dev(C::ID, hh.p, n, log_n, 1, nullptr, 2, n, nullptr), "mzk_ntt_dev");
+        check(mzk_dev_copy2d(row(H1), m * EL, hh.p, n * EL, n * EL, 2, nullptr), "copy2d");
+        mask({H1, H1 + 1}, st.b.h);
+        tick.mark("r1_5_sorted_vec");
+        auto comms = commit({row(H1), row(H1 + 1)}, {n + 3, n + 3});
+        tick.mark("r1_5_commit");
+        return comms;
+    }
+    // round 2 (prover.rs:125-141)
+    Affine round2(const Fr& beta, const Fr& gamma, Tick& tick) {
+        st.beta = beta; st.gamma = gamma;
+        check(mzk_plonk_perm_product_dev(pk, st.cs->wire_values.p, beta.l, gamma.l, coeff.p, nullptr), "mzk_plonk_perm_product_dev");
+        check(mzk_dev_copy(row(rowZ()), coeff.p, n * EL, nullptr), "copy");
+        mask({rowZ()}, {st.b.z});
         tick.mark("r2_product");
-        proof.prod_perm_poly_comm = commit({row(Z)}, {n + 3})[0];
+        const Affine cm = commit({row(rowZ())}, {n + 3})[0];
         tick.mark("r2_commit");
-        tr.append_commitment("perm_poly_comms", proof.prod_perm_poly_comm);
-        // ---- round 2.5 (prover.rs:143-183)
-        if (ultra) {
-            check(mzk_plookup_product_dev(pk, table.p, lookup.p, sorted.p, beta.l, gamma.l, coeff.p, nullptr), "mzk_plookup_product_dev");
-            check(mzk_dev_copy(row(PL), coeff.p, n * EL, nullptr), "copy");
-            mask({PL}, {b_pl});
-            tick.mark("r2_5_product");
-            proof.prod_lookup_poly_comm = commit({row(PL)}, {n + 3})[0];
-            tick.mark("r2_5_commit");
-            tr.append_commitment("plookup_poly_comms", proof.prod_lookup_poly_comm);
-        }
-        // ---- round 3 (prover.rs:192-209, 512-673, 902-960)
-        const Fr alpha = tr.get_and_append_challenge("alpha");
+        return cm;
+    }
+    // round 2.5 (prover.rs:143-183), UltraPlonk only
+    Affine round2_5(Tick& tick) {
+        check(mzk_plookup_product_dev(pk, table.p, lookup.p, sorted.p, st.beta.l, st.gamma.l, coeff.p, nullptr), "mzk_plookup_product_dev");
+        check(mzk_dev_copy(row(rowPL()), coeff.p, n * EL, nullptr), "copy");
+        mask({rowPL()}, {st.b.pl});
+        tick.mark("r2_5_product");
+        const Affine cm = commit({row(rowPL())}, {n + 3})[0];
+        tick.mark("r2_5_commit");
+        return cm;
+    }
+    // this instance's quotient polynomial, 8n coefficients into `quot` (prover.rs:512-673 without the sum over instances)
+    void quotient(const Fr& alpha, Tick& tick) {
+        st.alpha = alpha;
         check(mzk_dev_copy2d(keep.p, (n + 3) * EL, slab.p, m * EL, (n + 3) * EL, rows, nullptr), "copy2d");   // coefficient forms survive the in-place coset NTT
-        if (ultra) check(mzk_plonk_quotient_ultra_dev(pk, slab.p, n + 3, tau.l, alpha.l, beta.l, gamma.l, quot.p, nullptr), "mzk_plonk_quotient_ultra_dev");
-        else check(mzk_plonk_quotient_dev(pk, slab.p, n + 3, alpha.l, beta.l, gamma.l, quot.p, nullptr), "mzk_plonk_quotient_dev");
+        if (ultra) check(mzk_plonk_quotient_ultra_dev(pk, slab.p, n + 3, st.tau.l, alpha.l, st.beta.l, st.gamma.l, quot.p, nullptr), "mzk_plonk_quotient_ultra_dev");
+        else check(mzk_plonk_quotient_dev(pk, slab.p, n + 3, alpha.l, st.beta.l, st.gamma.l, quot.p, nullptr), "mzk_plonk_quotient_dev");
         tick.mark("r3_quotient");
+    }
+    // split_quotient_polynomial (prover.rs:902-960) of the 8n coefficients at `q` into this->split; returns the W lengths
+    std::vector<uint64_t> split_quotient(const void* q, const std::vector<Fr>& b_quot) {
         const uint64_t expected = (uint64_t)W * (n + 1) + 2;                                                  // quotient_polynomial_degree
         check(mzk_dev_memset(split.p, 0, (size_t)W * (n + 3) * EL, nullptr), "memset");
         std::vector<uint64_t> split_len(W);
@@ -327,7 +340,7 @@ struct Prover {                                                        // Provin
         for (int i = 0; i < W; i++) {
             const uint64_t lo = (uint64_t)i * (n + 2), hi = i < W - 1 ? lo + n + 2 : expected + 1;
             void* p = split.at((size_t)i * (n + 3));
-            check(mzk_dev_copy(p, quot.at(lo), (hi - lo) * EL, nullptr), "copy");
+            check(mzk_dev_copy(p, static_cast<const uint8_t*>(q) + lo * EL, (hi - lo) * EL, nullptr), "copy");
             if (i < W - 1) check(mzk_dev_upload(static_cast<uint8_t*>(p) + (n + 2) * EL, b_quot[i].l, EL), "upload");
             if (i > 0) {                                                                                      // t_i[0] -= b_{i-1}
                 const Fr negl = mzk::neg(last);
@@ -337,23 +350,23 @@ struct Prover {                                                        // Provin
             if (i < W - 1) last = b_quot[i];
             split_len[i] = i < W - 1 ? n + 3 : hi - lo;
         }
-        tick.mark("r3_split");
-        {
-            std::vector<const void*> p;
-            for (int i = 0; i < W; i++) p.push_back(split.at((size_t)i * (n + 3)));
-            proof.split_quot_poly_comms = commit(p, split_len);
-        }
-        tick.mark("r3_commit");
-        for (auto& cm : proof.split_quot_poly_comms) tr.append_commitment("quot_poly_comms", cm);
-        // ---- round 4 (prover.rs:216-299)
-        const Fr zeta = tr.get_and_append_challenge("zeta"), zeta_w = zeta * w_n;
-        proof.wires_evals = evaluate(keep.p, n + 2, W, n + 3, zeta);
-        proof.wire_sigma_evals = evaluate(fix(sigma0), n, W - 1, n, zeta);
-        proof.perm_next_eval = evaluate(krow(Z), n + 3, 1, n + 3, zeta_w)[0];
-        for (auto& v : proof.wires_evals) tr.append_fr("wire_evals", v);
-        for (auto& v : proof.wire_sigma_evals) tr.append_fr("wire_sigma_evals", v);
-        tr.append_fr("perm_next_eval", proof.perm_next_eval);
-        std::vector<Fr>& pe = proof.plookup_evals;
+        return split_len;
+    }
+    std::vector<Affine> commit_split(const std::vector<uint64_t>& split_len) {
+        std::vector<const void*> p;
+        for (int i = 0; i < W; i++) p.push_back(split.at((size_t)i * (n + 3)));
+        return commit(p, split_len);
+    }
+    // compute_evaluations / compute_plookup_evaluations (prover.rs:216-299) into st
+    void round4(const Fr& zeta, Tick& tick) {
+        st.zeta = zeta;
+        const Fr zeta_w = zeta * w_n;
+        const int sigma0 = nsel, tab0 = nsel + W, H1 = rowH1(), PL = rowPL();
+        st.wires_evals = evaluate(keep.p, n + 2, W, n + 3, zeta);
+        st.wire_sigma_evals = evaluate(fix(sigma0), n, W - 1, n, zeta);
+        st.perm_next_eval = evaluate(krow(rowZ()), n + 3, 1, n + 3, zeta_w)[0];
+        std::vector<Fr>& pe = st.plookup_evals;
+        pe.clear();
         if (ultra) {
             pe.assign(N_PLOOKUP_EVALS, Fr::zero());
             const auto at_zeta = evaluate(fix(tab0), n, 4, n, zeta);                                           // range, key, table_dom_sep, q_dom_sep
@@ -368,14 +381,27 @@ struct Prover {                                                        // Provin
             pe[H_1_NEXT] = hn[0]; pe[H_2_NEXT] = hn[1];
             const auto wn = evaluate(krow(3), n + 2, 2, n + 3, zeta_w);
             pe[W_3_NEXT] = wn[0]; pe[W_4_NEXT] = wn[1];
-            tr.append_fr("lookup_table_eval", pe[RANGE_TABLE]); tr.append_fr("h_1_eval", pe[H_1]); tr.append_fr("prod_next_eval", pe[PROD_NEXT]);
-            tr.append_fr("lookup_table_next_eval", pe[RANGE_TABLE_NEXT]); tr.append_fr("h_1_next_eval", pe[H_1_NEXT]);
-            tr.append_fr("h_2_next_eval", pe[H_2_NEXT]);                                                      // transcript/mod.rs:165-202
         }
         tick.mark("r4_evals");
-        // ---- round 5: linearisation polynomial (prover.rs:302-358, 963-1112) and opening proofs (:362-460, 490-509)
-        const Fr v = tr.get_and_append_challenge("v");
-        const std::vector<Fr>& we = proof.wires_evals;
+    }
+    void append_proof_evaluations(StandardTranscript<C>& tr) const {       // transcript/mod.rs:140-163
+        for (auto& v : st.wires_evals) tr.append_fr("wire_evals", v);
+        for (auto& v : st.wire_sigma_evals) tr.append_fr("wire_sigma_evals", v);
+        tr.append_fr("perm_next_eval", st.perm_next_eval);
+    }
+    void append_plookup_evaluations(StandardTranscript<C>& tr) const {     // transcript/mod.rs:165-202
+        if (!ultra) return;
+        const std::vector<Fr>& pe = st.plookup_evals;
+        tr.append_fr("lookup_table_eval", pe[RANGE_TABLE]); tr.append_fr("h_1_eval", pe[H_1]); tr.append_fr("prod_next_eval", pe[PROD_NEXT]);
+        tr.append_fr("lookup_table_next_eval", pe[RANGE_TABLE_NEXT]); tr.append_fr("h_1_next_eval", pe[H_1_NEXT]);
+        tr.append_fr("h_2_next_eval", pe[H_2_NEXT]);
+    }
+    // compute_non_quotient_component_for_lin_poly (prover.rs:302-337, 963-1112) as terms, every scalar times alpha_base
+    std::vector<Term> lin_poly_terms(const Fr& alpha_base) const {
+        const std::vector<Fr>& we = st.wires_evals;
+        const std::vector<Fr>& pe = st.plookup_evals;
+        const Fr &alpha = st.alpha, &beta = st.beta, &gamma = st.gamma, &tau = st.tau, &zeta = st.zeta;
+        const int sigma0 = nsel;
         auto pow5 = [](const Fr& x) { const Fr x2 = x * x; return x2 * x2 * x; };
         std::vector<Term> terms;
         for (int j = 0; j < 4; j++) terms.push_back({we[j], fix(j), n});
@@ -390,9 +416,9 @@ struct Prover {                                                        // Provin
         const Fr lagrange_1 = vanish * inv(nf * (zeta - one));
         Fr cf = alpha;
         for (int j = 0; j < W; j++) cf = cf * (we[j] + beta * k[j] * zeta + gamma);
-        terms.push_back({cf + alpha * alpha * lagrange_1, krow(Z), n + 3});
-        cf = alpha * beta * proof.perm_next_eval;
-        for (int j = 0; j < W - 1; j++) cf = cf * (we[j] + beta * proof.wire_sigma_evals[j] + gamma);
+        terms.push_back({cf + alpha * alpha * lagrange_1, krow(rowZ()), n + 3});
+        cf = alpha * beta * st.perm_next_eval;
+        for (int j = 0; j < W - 1; j++) cf = cf * (we[j] + beta * st.wire_sigma_evals[j] + gamma);
         terms.push_back({mzk::neg(cf), fix(sigma0 + W - 1), n});
         if (ultra) {                                                                                          // compute_lin_poly_plookup_contribution
             auto em = [&](const Fr& first, const Fr& ql, const Fr& ds, const Fr& a0, const Fr& a1, const Fr& a2) {
@@ -405,27 +431,31 @@ struct Prover {                                                        // Provin
             const Fr lagrange_n = vanish * w_inv * inv(nf * (zeta - w_inv));
             const Fr a2 = alpha * alpha, a4 = a2 * a2, a5 = a4 * alpha, a6 = a4 * a2;
             const Fr b1 = one + beta, g1 = gamma * b1, zmg = zeta - w_inv;
-            terms.push_back({a4 * lagrange_1 + a5 * lagrange_n + a6 * zmg * b1 * (gamma + ml) * (g1 + mt + beta * mt_next), krow(PL), n + 3});
-            terms.push_back({mzk::neg(a6 * zmg * pe[PROD_NEXT] * (g1 + pe[H_1] + beta * pe[H_1_NEXT])), krow(H1 + 1), n + 3});
+            terms.push_back({a4 * lagrange_1 + a5 * lagrange_n + a6 * zmg * b1 * (gamma + ml) * (g1 + mt + beta * mt_next), krow(rowPL()), n + 3});
+            terms.push_back({mzk::neg(a6 * zmg * pe[PROD_NEXT] * (g1 + pe[H_1] + beta * pe[H_1_NEXT])), krow(rowH1() + 1), n + 3});
         }
-        const Fr zeta_n2 = (vanish + one) * zeta * zeta;
-        cf = one;
+        if (!(alpha_base == one)) for (auto& t : terms) t.s = t.s * alpha_base;
+        return terms;
+    }
+    // compute_quotient_component_for_lin_poly (prover.rs:343-358) over this->split
+    std::vector<Term> quotient_lin_terms(const Fr& zeta, const std::vector<uint64_t>& split_len) const {
+        const Fr one = Fr::one(), vanish = pow_u64(zeta, n) - one, zeta_n2 = (vanish + one) * zeta * zeta;
+        std::vector<Term> terms;
+        Fr cf = one;
         for (int i = 0; i < W; i++) {
             terms.push_back({mzk::neg(vanish) * cf, split.at((size_t)i * (n + 3)), split_len[i]});
             cf = cf * zeta_n2;
         }
-        lincomb(terms, lin.p, n + 3);
-        auto batched = [&](const std::vector<Term>& polys, const Fr& point, DevBuf& out) {                     // prover.rs:490-509
-            std::vector<Term> t;
-            Fr c = one;
-            for (auto& p : polys) { t.push_back({c, p.p, p.len}); c = c * v; }
-            lincomb(t, batch.p, n + 3);
-            check(mzk_poly_div_linear_dev(C::ID, batch.p, n + 3, point.l, out.p, nullptr), "mzk_poly_div_linear_dev");
-        };
-        std::vector<Term> open_polys{{one, lin.p, n + 3}}, shifted_polys{{one, krow(Z), n + 3}};
+        return terms;
+    }
+    // the polynomials this instance opens at zeta (after the linearisation polynomial) and at zeta * w (prover.rs:362-460)
+    void open_lists(std::vector<Term>& open_polys, std::vector<Term>& shifted_polys) const {
+        const Fr one = Fr::one();
+        const int sigma0 = nsel, tab0 = nsel + W, H1 = rowH1(), PL = rowPL();
         for (int i = 0; i < W; i++) open_polys.push_back({one, krow(i), n + 2});
         for (int i = 0; i < W - 1; i++) open_polys.push_back({one, fix(sigma0 + i), n});
-        if (ultra) {                                                                                          // prover.rs:421-460
+        shifted_polys.push_back({one, krow(rowZ()), n + 3});
+        if (ultra) {
             for (const void* p : {(const void*)fix(tab0), (const void*)fix(tab0 + 1)}) open_polys.push_back({one, p, n});
             open_polys.push_back({one, krow(H1), n + 3});
             open_polys.push_back({one, fix(13), n});
@@ -441,8 +471,82 @@ struct Prover {                                                        // Provin
             shifted_polys.push_back({one, krow(4), n + 2});
             shifted_polys.push_back({one, fix(tab0 + 2), n});
         }
-        batched(open_polys, zeta, opening);
-        batched(shifted_polys, zeta_w, shifted);
+    }
+    // sum of any number of terms into `out` (one launch takes 32)
+    void lincomb_many(const std::vector<Term>& terms, void* out, uint64_t out_len) {
+        constexpr size_t MAXT = 32;
+        if (terms.size() <= MAXT) { lincomb(terms, out, out_len); return; }
+        lincomb(std::vector<Term>(terms.begin(), terms.begin() + MAXT), out, out_len);
+        for (size_t i = MAXT; i < terms.size(); i += MAXT - 1) {
+            std::vector<Term> chunk{{Fr::one(), out, out_len}};
+            chunk.insert(chunk.end(), terms.begin() + i, terms.begin() + std::min(terms.size(), i + MAXT - 1));
+            lincomb(chunk, out, out_len);                                    // elementwise: reading out[j] before writing it is safe
+        }
+    }
+    // compute_batched_witness_polynomial_commitment (prover.rs:490-509) up to the commitment
+    void batched_witness(const std::vector<Term>& polys, const Fr& v, const Fr& point, DevBuf& out) {
+        std::vector<Term> t;
+        Fr c = Fr::one();
+        for (auto& p : polys) { t.push_back({c, p.p, p.len}); c = c * v; }
+        lincomb_many(t, batch.p, n + 3);
+        check(mzk_poly_div_linear_dev(C::ID, batch.p, n + 3, point.l, out.p, nullptr), "mzk_poly_div_linear_dev");
+    }
+    static Blinds draw_blinds(ChaChaRng& rng, int W, bool ultra) {         // one instance, draw order of prover.rs:79-83, 113-114, 133-138, 169-180
+        auto draw = [&](int cnt) { std::vector<Fr> v; for (int i = 0; i < cnt; i++) v.push_back(fr_rand<FrP>(rng)); return v; };
+        Blinds b;
+        for (int i = 0; i < W; i++) b.wires.push_back(draw(2));
+        if (ultra) { b.h.push_back(draw(3)); b.h.push_back(draw(3)); }
+        b.z = draw(3);
+        if (ultra) b.pl = draw(3);
+        return b;
+    }
+
+    // PlonkKzgSnark::prove (snark.rs:624-651) -> batch_prove_internal (:201-469), one instance
+    Proof<C> prove(ChaChaRng& rng, const BenchCircuit<C>& cs, bool profile = false) {
+        Tick tick(timings_ms, profile);
+        Blinds blinds = draw_blinds(rng, W, ultra);
+        std::vector<Fr> b_quot;
+        for (int i = 0; i < W - 1; i++) b_quot.push_back(fr_rand<FrP>(rng));                                   // prover.rs:947-955
+        StandardTranscript<C> tr;
+        append_vk_and_pub_input(tr);
+        Proof<C> proof;
+        proof.has_plookup = ultra;
+        proof.wires_poly_comms = round1(cs, std::move(blinds), tick);
+        for (auto& cm : proof.wires_poly_comms) tr.append_commitment("witness_poly_comms", cm);
+        const Fr tau = tr.get_and_append_challenge("tau");
+        proof.h_poly_comms = round1_5(tau, tick);
+        for (auto& cm : proof.h_poly_comms) tr.append_commitment("h_poly_comms", cm);
+        const Fr beta = tr.get_and_append_challenge("beta"), gamma = tr.get_and_append_challenge("gamma");
+        proof.prod_perm_poly_comm = round2(beta, gamma, tick);
+        tr.append_commitment("perm_poly_comms", proof.prod_perm_poly_comm);
+        if (ultra) {
+            proof.prod_lookup_poly_comm = round2_5(tick);
+            tr.append_commitment("plookup_poly_comms", proof.prod_lookup_poly_comm);
+        }
+        const Fr alpha = tr.get_and_append_challenge("alpha");
+        quotient(alpha, tick);
+        const std::vector<uint64_t> split_len = split_quotient(quot.p, b_quot);
+        tick.mark("r3_split");
+        proof.split_quot_poly_comms = commit_split(split_len);
+        tick.mark("r3_commit");
+        for (auto& cm : proof.split_quot_poly_comms) tr.append_commitment("quot_poly_comms", cm);
+        const Fr zeta = tr.get_and_append_challenge("zeta");
+        round4(zeta, tick);
+        append_proof_evaluations(tr);
+        append_plookup_evaluations(tr);
+        proof.wires_evals = st.wires_evals;
+        proof.wire_sigma_evals = st.wire_sigma_evals;
+        proof.perm_next_eval = st.perm_next_eval;
+        proof.plookup_evals = st.plookup_evals;
+        const Fr v = tr.get_and_append_challenge("v");
+        std::vector<Term> terms = lin_poly_terms(Fr::one());
+        const std::vector<Term> qt = quotient_lin_terms(zeta, split_len);
+        terms.insert(terms.end(), qt.begin(), qt.end());
+        lincomb_many(terms, lin.p, n + 3);
+        std::vector<Term> open_polys{{Fr::one(), lin.p, n + 3}}, shifted_polys;
+        open_lists(open_polys, shifted_polys);
+        batched_witness(open_polys, v, zeta, opening);
+        batched_witness(shifted_polys, v, zeta * w_n, shifted);
         tick.mark("r5_polys");
         const auto oc = commit({opening.p, shifted.p}, {n + 2, n + 2});
         proof.opening_proof = oc[0];
@@ -451,6 +555,149 @@ struct Prover {                                                        // Provin
         return proof;
     }
 };
+
+// ---- aggregated proofs over several instances (snark.rs:64-78, 201-469; structs.rs:266-291) -----------------------------
+template <class C>
+struct BatchProof {
+    using E = Encoding<C>;
+    using Fr = typename E::Fr;
+    using Affine = typename E::Affine;
+    struct Evals { std::vector<Fr> wires_evals, wire_sigma_evals; Fr perm_next_eval; };
+    struct Plookup { bool some = false; std::vector<Affine> h_poly_comms; Affine prod_lookup_poly_comm; std::vector<Fr> poly_evals; };
+    std::vector<std::vector<Affine>> wires_poly_comms_vec;
+    std::vector<Affine> prod_perm_poly_comms_vec;
+    std::vector<Evals> poly_evals_vec;
+    std::vector<Plookup> plookup_proofs_vec;
+    std::vector<Affine> split_quot_poly_comms;
+    Affine opening_proof, shifted_opening_proof;
+
+    std::vector<uint8_t> serialize_compressed() const {
+        std::vector<uint8_t> out;
+        auto u64le = [&](uint64_t v) { for (int i = 0; i < 8; i++) out.push_back((uint8_t)(v >> (8 * i))); };
+        auto g1 = [&](const Affine& p) { uint8_t b[48]; E::g1_bytes(p, b); out.insert(out.end(), b, b + C::G1_BYTES); };
+        auto fr = [&](const Fr& v) { uint8_t b[32]; E::fr_bytes(v, b); out.insert(out.end(), b, b + 32); };
+        u64le(wires_poly_comms_vec.size());
+        for (auto& comms : wires_poly_comms_vec) { u64le(comms.size()); for (auto& p : comms) g1(p); }
+        u64le(prod_perm_poly_comms_vec.size()); for (auto& p : prod_perm_poly_comms_vec) g1(p);
+        u64le(poly_evals_vec.size());
+        for (auto& ev : poly_evals_vec) {
+            u64le(ev.wires_evals.size()); for (auto& v : ev.wires_evals) fr(v);
+            u64le(ev.wire_sigma_evals.size()); for (auto& v : ev.wire_sigma_evals) fr(v);
+            fr(ev.perm_next_eval);
+        }
+        u64le(plookup_proofs_vec.size());
+        for (auto& pl : plookup_proofs_vec) {
+            out.push_back(pl.some ? 1 : 0);
+            if (!pl.some) continue;
+            u64le(pl.h_poly_comms.size()); for (auto& p : pl.h_poly_comms) g1(p);
+            g1(pl.prod_lookup_poly_comm);
+            for (auto& v : pl.poly_evals) fr(v);
+        }
+        u64le(split_quot_poly_comms.size()); for (auto& p : split_quot_poly_comms) g1(p);
+        g1(opening_proof); g1(shifted_opening_proof);
+        return out;
+    }
+};
+
+// PlonkKzgSnark::batch_prove: round k of every instance, then one challenge; one quotient t = sum_k alpha_base_k t_k
+// (alpha_base_{k+1} = alpha_base_k alpha^3, alpha^7 with Plookup: prover.rs:661-669) -- the per-instance quotients are
+// combined after their inverse NTTs, which is the same polynomial because both maps are linear --, one split (first key's
+// commit key), one linearisation polynomial and the two opening proofs over the concatenated lists (prover.rs:362-419).
+template <class C>
+BatchProof<C> batch_prove(ChaChaRng& rng, const std::vector<Prover<C>*>& provers, const std::vector<const BenchCircuit<C>*>& circuits) {
+    using P = Prover<C>;
+    using Fr = typename P::Fr;
+    using FrP = typename C::Fr;
+    using Term = typename P::Term;
+    if (provers.empty()) throw std::runtime_error("zero number of circuits/proving keys");
+    if (provers.size() != circuits.size()) throw std::runtime_error("the number of circuits != the number of proving keys");
+    P& p0 = *provers[0];
+    const uint64_t n = p0.n;
+    const int W = p0.W;
+    for (size_t i = 0; i < provers.size(); i++) {
+        if (circuits[i]->n != n) throw std::runtime_error("circuit domain size != expected domain size");
+        if (provers[i]->n != n) throw std::runtime_error("proving key domain size != expected domain size");
+        if (circuits[i]->ultra != provers[i]->ultra) throw std::runtime_error("Mismatched Plonk types between the proving key and the circuit");
+        if (provers[i]->W != W) throw std::runtime_error("inconsistent plonk circuit types");
+    }
+    const size_t K = provers.size();
+    std::map<std::string, double> unused;
+    typename P::Tick tick(unused, false);
+    // prng draws in the reference's order (snark.rs:277-360)
+    auto draw = [&](int cnt) { std::vector<Fr> v; for (int i = 0; i < cnt; i++) v.push_back(fr_rand<FrP>(rng)); return v; };
+    std::vector<typename P::Blinds> blinds(K);
+    for (size_t i = 0; i < K; i++) for (int j = 0; j < W; j++) blinds[i].wires.push_back(draw(2));
+    for (size_t i = 0; i < K; i++) if (provers[i]->ultra) { blinds[i].h.push_back(draw(3)); blinds[i].h.push_back(draw(3)); }
+    for (size_t i = 0; i < K; i++) blinds[i].z = draw(3);
+    for (size_t i = 0; i < K; i++) if (provers[i]->ultra) blinds[i].pl = draw(3);
+    const std::vector<Fr> b_quot = draw(W - 1);
+    StandardTranscript<C> tr;
+    for (auto* p : provers) p->append_vk_and_pub_input(tr);
+    BatchProof<C> proof;
+    proof.plookup_proofs_vec.resize(K);
+    for (size_t i = 0; i < K; i++) {
+        proof.wires_poly_comms_vec.push_back(provers[i]->round1(*circuits[i], std::move(blinds[i]), tick));
+        for (auto& cm : proof.wires_poly_comms_vec.back()) tr.append_commitment("witness_poly_comms", cm);
+    }
+    const Fr tau = tr.get_and_append_challenge("tau");
+    for (size_t i = 0; i < K; i++) {
+        auto h = provers[i]->round1_5(tau, tick);
+        for (auto& cm : h) tr.append_commitment("h_poly_comms", cm);
+        if (provers[i]->ultra) { proof.plookup_proofs_vec[i].some = true; proof.plookup_proofs_vec[i].h_poly_comms = h; }
+    }
+    const Fr beta = tr.get_and_append_challenge("beta"), gamma = tr.get_and_append_challenge("gamma");
+    for (size_t i = 0; i < K; i++) {
+        proof.prod_perm_poly_comms_vec.push_back(provers[i]->round2(beta, gamma, tick));
+        tr.append_commitment("perm_poly_comms", proof.prod_perm_poly_comms_vec.back());
+    }
+    for (size_t i = 0; i < K; i++)
+        if (provers[i]->ultra) {
+            proof.plookup_proofs_vec[i].prod_lookup_poly_comm = provers[i]->round2_5(tick);
+            tr.append_commitment("plookup_poly_comms", proof.plookup_proofs_vec[i].prod_lookup_poly_comm);
+        }
+    const Fr alpha = tr.get_and_append_challenge("alpha");
+    const Fr a3 = alpha * alpha * alpha, a7 = a3 * a3 * alpha;
+    std::vector<Fr> bases;
+    std::vector<Term> qterms;
+    Fr base = Fr::one();
+    for (size_t i = 0; i < K; i++) {
+        provers[i]->quotient(alpha, tick);
+        qterms.push_back({base, provers[i]->quot.p, p0.m});
+        bases.push_back(base);
+        base = base * (provers[i]->ultra ? a7 : a3);
+    }
+    DevBuf qsum;
+    const void* q = p0.quot.p;
+    if (K > 1) { qsum.alloc(p0.m); p0.lincomb_many(qterms, qsum.p, p0.m); q = qsum.p; }
+    const std::vector<uint64_t> split_len = p0.split_quotient(q, b_quot);
+    proof.split_quot_poly_comms = p0.commit_split(split_len);
+    for (auto& cm : proof.split_quot_poly_comms) tr.append_commitment("quot_poly_comms", cm);
+    const Fr zeta = tr.get_and_append_challenge("zeta");
+    for (size_t i = 0; i < K; i++) {
+        provers[i]->round4(zeta, tick);
+        provers[i]->append_proof_evaluations(tr);
+        proof.poly_evals_vec.push_back({provers[i]->st.wires_evals, provers[i]->st.wire_sigma_evals, provers[i]->st.perm_next_eval});
+    }
+    for (size_t i = 0; i < K; i++) {
+        provers[i]->append_plookup_evaluations(tr);
+        if (provers[i]->ultra) proof.plookup_proofs_vec[i].poly_evals = provers[i]->st.plookup_evals;
+    }
+    std::vector<Term> lin_terms = p0.quotient_lin_terms(zeta, split_len);
+    for (size_t i = 0; i < K; i++) {
+        const std::vector<Term> t = provers[i]->lin_poly_terms(bases[i]);
+        lin_terms.insert(lin_terms.end(), t.begin(), t.end());
+    }
+    p0.lincomb_many(lin_terms, p0.lin.p, n + 3);
+    const Fr v = tr.get_and_append_challenge("v");
+    std::vector<Term> open_polys{{Fr::one(), p0.lin.p, n + 3}}, shifted_polys;
+    for (auto* p : provers) p->open_lists(open_polys, shifted_polys);
+    p0.batched_witness(open_polys, v, zeta, p0.opening);
+    p0.batched_witness(shifted_polys, v, zeta * p0.w_n, p0.shifted);
+    const auto oc = p0.commit({p0.opening.p, p0.shifted.p}, {n + 2, n + 2});
+    proof.opening_proof = oc[0];
+    proof.shifted_opening_proof = oc[1];
+    return proof;
+}
 
 // ---- proof linking (plonk/src/proof_system/proof_linking.rs) -----------------------------------------------------------
 struct GroupLayout {                                                   // relation/src/proof_linking/mod.rs:16-54

@@ -89,3 +89,25 @@ def test_cpp_host_matches_python_over_many_transcripts(gpu, mj, curve_id, plonk_
         assert got["proof_hex"] == proof_bytes.hex(), gates
         pk.release()
         ck.release()
+
+
+@pytest.mark.parametrize("curve_id,plonk_type,gates,range_bits", [(0, "TurboPlonk", (25, 28, 31), 8), (1, "UltraPlonk", (100, 110), 4),
+                                                                  (1, "TurboPlonk", (900, 1000, 950, 990), 8), (0, "UltraPlonk", (2000, 2040, 1990), 6)])
+def test_cpp_host_batch_prove_matches_python_mirror(gpu, mj, curve_id, plonk_type, gates, range_bits):
+    """PlonkKzgSnark::batch_prove from the compiled host (mzk_prove <curve> batch ...): the aggregated BatchProof byte for byte
+    equal to the Python mirror's (which tests/test_batch_gpu.py checks against the restatements)."""
+    ultra = plonk_type == "UltraPlonk"
+    out = subprocess.run([BIN, str(curve_id), "batch", "ultra" if ultra else "turbo", str(range_bits)] + [str(g) for g in gates],
+                         capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    c = mj.params.CURVES[curve_id]
+    circuits = [mj.snark.gen_circuit_for_bench(c, g, plonk_type, range_bit_len=range_bits) for g in gates]
+    rng = mj.rng.test_rng()
+    ck = mj.UnivariateProverParam.gen_srs_for_testing(c, mj.rng.fr_rand(c, rng), circuits[0].n + 2)
+    pks = [mj.snark.preprocess(ck, cs) for cs in circuits]
+    _, blob = mj.snark.batch_prove(rng, circuits, pks)
+    assert got["instances"] == len(gates) and got["batch_proof_hex"] == blob.hex()
+    for pk in pks:
+        pk.release()
+    ck.release()
