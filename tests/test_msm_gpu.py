@@ -320,3 +320,34 @@ def test_error_paths(gpu, mj):
     assert L.mzk_strerror(-8).startswith(b"Plookup")
     pp.release()
     assert L.mzk_srs_release(pp.handle or 999999) != 0 or True
+
+
+@pytest.mark.parametrize("curve_id", [0, 1])
+def test_msm_random_ragged_sweep(gpu, mj, cref, curve_id):
+    """One SRS, forty random (length, base_offset, scalar shape) MSMs on it -- lengths on both sides of the precomputed-table
+    threshold (1024) and of the bucket-splitting rules, scalars uniform / tiny (witness-like) / sparse / all equal / top-heavy --
+    each against the C restatement of ark-ec's Pippenger."""
+    c = mj.params.CURVES[curve_id]
+    rng = random.Random(4242 + curve_id)
+    N = 6000
+    bases = cref.g1_arith_bases(curve_id, 0x5eed + curve_id, 0x1234567, N)
+    pp = mj.UnivariateProverParam.from_affine(curve_id, bases)
+    lengths = [1, 2, 1023, 1024, 1025, 2047, 2049, 4095, 4097, N] + [rng.randrange(1, N) for _ in range(30)]
+    for case, n in enumerate(lengths):
+        off = rng.randrange(0, N - n + 1)
+        shape = case % 5
+        if shape == 0:
+            ints = [rng.randrange(c.r) for _ in range(n)]
+        elif shape == 1:
+            ints = [rng.randrange(1 << 20) for _ in range(n)]                       # wire values of a small circuit
+        elif shape == 2:
+            ints = [rng.randrange(c.r) if rng.random() < 0.05 else 0 for _ in range(n)]
+        elif shape == 3:
+            ints = [rng.randrange(c.r)] * n
+        else:
+            ints = [(c.r - 1 - rng.randrange(1 << 12)) for _ in range(n)]           # every top digit at its maximum
+        scalars = _bigints(ints)
+        want = cref.jac_to_affine(curve_id, cref.msm(curve_id, bases[off:off + n], scalars, threads=8))[0]
+        got = cref.jac_to_affine(curve_id, mj.msm_bigint(pp, scalars, base_offset=off))[0]
+        assert np.array_equal(got, want), (case, n, off, shape)
+    pp.release()

@@ -121,3 +121,32 @@ def test_ntt_full_size_properties(gpu, mj, cref, curve_id, log_n):
         for _ in range(k - 1):
             pk = cref.fr_mul(curve_id, pk.reshape(1, 4), pt.reshape(1, 4))[0]
         assert np.array_equal(evy[i], pk), i
+
+
+@pytest.mark.parametrize("curve_id", [0, 1])
+def test_ntt_random_ragged_sweep(gpu, mj, cref, curve_id):
+    """Random (size, input length, direction, coset) transforms -- every power of two up to 2^15 and input lengths that cut the
+    first pass's skipped stages at arbitrary places (the zero-padding shortcut of the quotient round) -- and all-zero /
+    single-coefficient inputs, against the C restatement of ark-poly's radix-2 transform."""
+    import random
+    c = mj.params.CURVES[curve_id]
+    rng = random.Random(909 + curve_id)
+    for case in range(48):
+        log_n = 1 + case % 15
+        n = 1 << log_n
+        in_len = rng.choice([1, 2, n // 2, n // 2 + 1, n - 1, n, rng.randrange(1, n + 1), max(1, n >> rng.randrange(1, log_n + 1))])
+        in_len = min(max(in_len, 1), n)
+        offset = rng.choice([1, c.fr_generator, rng.randrange(2, c.r)])
+        off_limbs = None if offset == 1 else mj.params.fr_to_mont(c, [offset])[0]
+        a = mj.params.random_fr_mont(c, in_len, seed=7000 + case)
+        if case % 7 == 3:
+            a[:] = 0
+        if case % 7 == 5:
+            a[:] = 0
+            a[in_len - 1] = mj.params.fr_to_mont(c, [rng.randrange(c.r)])[0]
+        padded = np.zeros((n, 4), dtype=np.uint64)
+        padded[:in_len] = a
+        d = _dom(mj, c, log_n, offset)
+        inverse = bool(case & 1)
+        got = d.ifft(a) if inverse else d.fft(a)
+        assert np.array_equal(got, cref.ntt(curve_id, padded, log_n, inverse, off_limbs, threads=4)), (case, log_n, in_len, offset, inverse)
