@@ -121,15 +121,21 @@ def link_proofs(c, a1, a2, a1_comm, a2_comm, layout: GroupLayout, srs_beta: int,
             "quotient": quotient, "identity": identity, "witness": witness}
 
 
-def verify_link_proof(c, transcript, a1_comm, a2_comm, quotient_comm, opening_proof, layout: GroupLayout, srs_beta: int) -> bool:
-    """proof_linking.rs:240-286: a1_comm / a2_comm are wires_poly_comms[PROOF_LINK_WIRE_IDX] of the two Plonk proofs."""
+def verify_link_proof(c, transcript, a1_comm, a2_comm, quotient_comm, opening_proof, layout: GroupLayout, srs_beta, open_key=None) -> bool:
+    """proof_linking.rs:240-286: a1_comm / a2_comm are wires_poly_comms[PROOF_LINK_WIRE_IDX] of the two Plonk proofs.
+    The KZG check at point eta with value 0 is the reference's pairing equation when `open_key` ({g, h, beta_h}) is given
+    (univariate_kzg/mod.rs:194-221: e(C - [v]g, h) == e(proof, beta_h - [eta]h)), else its trapdoor form C == (beta - eta) proof."""
     r = c.r
     eta = quotient_challenge(transcript, a1_comm, a2_comm, quotient_comm)
     z_eta = vanishing_eval(c, layout, eta)
     ident = P.g1_add(c, a1_comm, P.g1_neg(c, a2_comm) if a2_comm is not None else None)                # :275-286
     if quotient_comm is not None and z_eta:
         ident = P.g1_add(c, ident, P.g1_neg(c, P.g1_mul(c, z_eta, quotient_comm)))
-    # UnivariateKzgPCS::verify at point eta with value 0:  C == (beta - eta) * proof
+    if open_key is not None:
+        import pyref_pairing as PR
+        pc = PR.PAIRINGS[c.curve_id]
+        rhs_g2 = PR.ec_add(open_key["beta_h"], PR.ec_neg(pc.g2_mul(open_key["h"], eta)))
+        return pc.multi_pairing_is_one([(ident, open_key["h"]), (P.g1_neg(c, opening_proof), rhs_g2)])
     rhs = P.g1_mul(c, (srs_beta - eta) % r, opening_proof) if opening_proof is not None and (srs_beta - eta) % r else None
     return ident == rhs
 

@@ -11,9 +11,10 @@ several), from the compressed proof bytes:
 It shares no code with the restated provers (pyref_plonk / cref_prover) nor with the device path, so a proof it accepts is a
 proof the reference's verification equation accepts.
 
-The last step is a pairing check  e(A, [beta]_2) == e(B, [1]_2).  The test SRS is generated from a known beta (as the
-reference's own `gen_srs_for_testing` does), and for such an SRS that check is equivalent to  beta * A == B  in G1, which is
-what `verify` evaluates -- G1 arithmetic only (pyref.g1_*), no G2 / Fq12 tower needed.
+The last step is a pairing check  e(A, [beta]_2) == e(B, [1]_2).  Two evaluations of it are provided: the reference's own --
+the product of two pairings over the OpenKey {g, h, beta_h} (`open_key=`; oracle/pyref_pairing.py, seconds per call) -- and,
+because the test SRS is generated from a known beta (as the reference's `gen_srs_for_testing` does), the equivalent
+beta * A == B  in G1 (pyref.g1_* only), which most tests use for speed.
 
 The Fiat-Shamir transcript is passed in by the caller (an object with append_message / append_vk_and_pub_input /
 append_commitment(s) / append_field_elem / append_plookup_evaluations / get_and_append_challenge -- the product's
@@ -377,20 +378,46 @@ def batch_verify_opening_proof(c, g, srs_beta: int, info: dict) -> bool:
     return lhs == B
 
 
-def verify(c, transcript, vk: dict, pub_input, proof_bytes: bytes, g, srs_beta: int, extra_msg=None) -> bool:
-    """PlonkKzgSnark::verify (snark.rs:653-671 -> batch_verify :118-146) for one proof.
-    vk: {"domain_size", "num_inputs", "k", "selector_comms", "sigma_comms", "plookup": None | {"range_table_comm",
-    "key_table_comm", "table_dom_sep_comm", "q_dom_sep_comm"}} with commitments as canonical affine (x, y) or None.
-    g = powers_of_g[0]; srs_beta = the trapdoor of the test SRS."""
-    pr = deserialize_proof(c, proof_bytes)
-    ch = compute_challenges(transcript, vk, pub_input, pr, extra_msg)
-    info = prepare_pcs_info(c, vk, pub_input, pr, ch)
+def open_key_for_testing(c, srs_beta: int) -> dict:
+    """OpenKey {g, h, beta_h} of `gen_srs_for_testing` (srs.rs:118-153) with g, h the standard generators: beta_h = [beta]h."""
+    import pyref_pairing as PR
+    pc = PR.PAIRINGS[c.curve_id]
+    return {"g": P.g1_gen(c), "h": pc.g2, "beta_h": pc.g2_mul(pc.g2, srs_beta)}
+
+
+def batch_verify_opening_proof_pairing(c, open_key: dict, info: dict) -> bool:
+    """verifier.rs:195-251 with one PcsInfo, as the reference evaluates it: multi_pairing([A, -B], [beta_h, h]) == 1 -- no
+    trapdoor involved (oracle/pyref_pairing.py)."""
+    import pyref_pairing as PR
+    r = c.r
+    A = _msm(c, [(1, info["opening_proof"]), (info["u"], info["shifted_opening_proof"])])
+    B = _msm(c, info["comm_scalars_and_bases"] + [(info["eval_point"], info["opening_proof"]),
+                                                  (info["u"] * info["next_eval_point"] % r, info["shifted_opening_proof"]),
+                                                  (-info["eval"] % r, open_key["g"])])
+    return PR.PAIRINGS[c.curve_id].multi_pairing_is_one([(A, open_key["beta_h"]), (P.g1_neg(c, B), open_key["h"])])
+
+
+def _final_check(c, g, srs_beta, open_key, info) -> bool:
+    if open_key is not None:
+        return batch_verify_opening_proof_pairing(c, open_key, info)
     return batch_verify_opening_proof(c, g, srs_beta, info)
 
 
-def verify_batch_proof(c, transcript, vks, pubs, batch_proof_bytes: bytes, g, srs_beta: int, extra_msg=None) -> bool:
+def verify(c, transcript, vk: dict, pub_input, proof_bytes: bytes, g, srs_beta, extra_msg=None, open_key=None) -> bool:
+    """PlonkKzgSnark::verify (snark.rs:653-671 -> batch_verify :118-146) for one proof.
+    vk: {"domain_size", "num_inputs", "k", "selector_comms", "sigma_comms", "plookup": None | {"range_table_comm",
+    "key_table_comm", "table_dom_sep_comm", "q_dom_sep_comm"}} with commitments as canonical affine (x, y) or None.
+    Final check: with `open_key` ({g, h, beta_h}) the reference's pairing product; otherwise its trapdoor form with
+    g = powers_of_g[0] and srs_beta the trapdoor of the test SRS."""
+    pr = deserialize_proof(c, proof_bytes)
+    ch = compute_challenges(transcript, vk, pub_input, pr, extra_msg)
+    info = prepare_pcs_info(c, vk, pub_input, pr, ch)
+    return _final_check(c, g, srs_beta, open_key, info)
+
+
+def verify_batch_proof(c, transcript, vks, pubs, batch_proof_bytes: bytes, g, srs_beta, extra_msg=None, open_key=None) -> bool:
     """PlonkKzgSnark::verify_batch_proof (snark.rs:148-169): one aggregated BatchProof over several instances."""
     bp = deserialize_batch_proof(c, batch_proof_bytes)
     ch = compute_challenges_batch(transcript, vks, pubs, bp, extra_msg)
     info = prepare_pcs_info_batch(c, vks, pubs, bp, ch)
-    return batch_verify_opening_proof(c, g, srs_beta, info)
+    return _final_check(c, g, srs_beta, open_key, info)

@@ -226,3 +226,15 @@ def build_ultra_circuit(c, log_n, rng, range_bits=3):
             perm[cs[q]] = cs[(q + 1) % len(cs)]
     sigma_vals = [[ident[perm[(i, j)][0]][perm[(i, j)][1]] for j in range(n)] for i in range(6)]
     return sel, sigma_vals, k, w, pi, plookup
+
+
+def verifying_key(mj, pc, pk, num_inputs):
+    """VerifyingKey of preprocess (snark.rs:562-594) as the verifier restatement takes it."""
+    pt = lambda cm: None if cm.is_infinity() else affine_from_limbs(pc, cm.xy)
+    sel, sig = pk.vk_commitments()
+    vk = {"domain_size": pk.n, "num_inputs": num_inputs, "k": list(pk.k), "selector_comms": [pt(x) for x in sel],
+          "sigma_comms": [pt(x) for x in sig], "plookup": None}
+    if pk.ultra:
+        names = ("range_table_comm", "key_table_comm", "table_dom_sep_comm", "q_dom_sep_comm")
+        vk["plookup"] = dict(zip(names, [pt(x) for x in pk.plookup_vk_commitments()]))
+    return vk

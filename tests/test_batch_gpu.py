@@ -6,8 +6,7 @@ import random
 import numpy as np
 import pytest
 
-from conftest import affine_from_limbs, build_circuit, build_ultra_circuit, fr_mont_limbs
-from test_verifier_gpu import verifying_key
+from conftest import affine_from_limbs, build_circuit, build_ultra_circuit, fr_mont_limbs, verifying_key
 
 pytestmark = pytest.mark.gpu
 TABLES = ("range", "key", "table_dom_sep", "q_dom_sep")
@@ -34,6 +33,7 @@ def test_batch_prove_bench_circuits_verifies(gpu, mj, pyref, curve_id, plonk_typ
     G = pyref.g1_gen(pc)
     fresh = lambda: mj.transcript.StandardTranscript(c, b"PlonkProof")
     assert V.verify_batch_proof(pc, fresh(), vks, pubs, blob, G, srs_beta)
+    assert V.verify_batch_proof(pc, fresh(), vks, pubs, blob, None, None, open_key=V.open_key_for_testing(pc, srs_beta)), "pairing form"
     # the verifier re-derives the prover's challenges
     bp = V.deserialize_batch_proof(pc, blob)
     ch = V.compute_challenges_batch(fresh(), vks, pubs, bp)

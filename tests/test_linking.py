@@ -80,6 +80,12 @@ def test_link_proof_restatement_accepts_and_rejects(pyref, mj, curve_id):
     same = L.link_proofs(c, a1, a1, c1, c1, layout, srs_beta, fresh())
     assert same["quotient"] == [] and same["quotient_commitment"] is None and same["opening_proof"] is None
     assert accept(None, None, x=c1, y=c1)
+    # the KZG check as the reference evaluates it (pairings over the OpenKey), on an accepted and a rejected link
+    import pyref_verifier as V
+    open_key = V.open_key_for_testing(c, srs_beta)
+    assert L.verify_link_proof(c, fresh(), c1, c2, lp["quotient_commitment"], lp["opening_proof"], layout, None, open_key=open_key)
+    assert not L.verify_link_proof(c, fresh(), c1, c2, lp["quotient_commitment"], lp["opening_proof"], L.GroupLayout(3, 3, 5), None, open_key=open_key)
+    assert not L.verify_link_proof(c, fresh(), c1, c2, bad["quotient_commitment"], bad["opening_proof"], bad_layout, None, open_key=open_key)
     # serialized LinkingProof: two compressed G1 points
     g1 = lambda p: mj.transcript.g1_bytes(pc, p)
     blob = L.serialize_link_proof(g1, lp["quotient_commitment"], lp["opening_proof"])

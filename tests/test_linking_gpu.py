@@ -6,7 +6,7 @@ import random
 import numpy as np
 import pytest
 
-from conftest import affine_from_limbs, build_circuit, fr_from_mont_limbs, fr_mont_limbs
+from conftest import affine_from_limbs, build_circuit, fr_from_mont_limbs, fr_mont_limbs, verifying_key
 
 pytestmark = pytest.mark.gpu
 
@@ -37,7 +37,6 @@ def _prove_linked(mj, pyref, curve_id, log_n, layout, shared, rng, srs_beta, ck)
 def test_link_two_device_proofs(gpu, mj, pyref, curve_id, log_n1, log_n2, layout_args):
     import pyref_linking as L
     import pyref_verifier as V
-    from test_verifier_gpu import verifying_key
     c, pc = mj.params.CURVES[curve_id], pyref.CURVES[curve_id]
     r = c.r
     rng = random.Random(77 + curve_id + log_n1)
@@ -69,6 +68,8 @@ def test_link_two_device_proofs(gpu, mj, pyref, curve_id, log_n1, log_n2, layout
     # the verifier's side: commitments out of the two serialized Plonk proofs (proof_linking.rs:240-271)
     accept = lambda lp, lay=olayout: L.verify_link_proof(pc, fresh(), a1c, a2c, _pt(pc, lp.quotient_commitment), _pt(pc, lp.opening_proof), lay, srs_beta)
     assert accept(link)
+    open_key = V.open_key_for_testing(pc, srs_beta)                          # ... and as the reference's pairing equation
+    assert L.verify_link_proof(pc, fresh(), a1c, a2c, _pt(pc, link.quotient_commitment), _pt(pc, link.opening_proof), olayout, None, open_key=open_key)
     al, off, size = layout_args
     assert not accept(link, lay=L.GroupLayout(al + 1, off, size)), "wrong alignment"
     assert not accept(link, lay=L.GroupLayout(al, off + 1, size)), "wrong offset"

@@ -183,3 +183,22 @@ def test_restated_batch_verifier_accepts_the_restated_batch_prover(pyref, curve_
     assert V.batch_proof_from({"wires_poly_comms": 1, "prod_perm_poly_comm": 2, "wires_evals": 3, "wire_sigma_evals": 4, "perm_next_eval": 5,
                                "plookup": None, "split_quot_poly_comms": 6, "opening_proof": 7, "shifted_opening_proof": 8})["poly_evals_vec"] == \
         [{"wires_evals": 3, "wire_sigma_evals": 4, "perm_next_eval": 5}]
+
+
+@pytest.mark.parametrize("curve_id", [0, 1])
+def test_pairing_restatement_and_the_reference_final_check(pyref, curve_id):
+    """oracle/pyref_pairing.py checks itself (generators, twist, bilinearity, non-degeneracy); the verifier's final step
+    evaluated as the reference evaluates it -- multi_pairing([A, -B], [beta_h, h]) == 1 (verifier.rs:226-250) -- agrees with
+    its trapdoor form on an accepted and on a rejected proof."""
+    import pyref_pairing as PR
+    import pyref_verifier as V
+    PR.self_check(curve_id)
+    c, vk, pub, proof, ch, srs_beta = restated_instance(pyref, curve_id, curve_id == 1, 7100 + curve_id)
+    ok = V.open_key_for_testing(c, srs_beta)
+    assert PR.PAIRINGS[curve_id].on_twist(ok["beta_h"]) and ok["beta_h"] != ok["h"]
+    info = V.prepare_pcs_info(c, vk, pub, proof, ch)
+    assert V.batch_verify_opening_proof(c, ok["g"], srs_beta, info) and V.batch_verify_opening_proof_pairing(c, ok, info)
+    bad = V.prepare_pcs_info(c, vk, pub, dict(proof, perm_next_eval=(proof["perm_next_eval"] + 1) % c.r), ch)
+    assert not V.batch_verify_opening_proof(c, ok["g"], srs_beta, bad) and not V.batch_verify_opening_proof_pairing(c, ok, bad)
+    # an OpenKey of another trapdoor rejects what the right one accepts
+    assert not V.batch_verify_opening_proof_pairing(c, V.open_key_for_testing(c, srs_beta + 1), info)

@@ -1,13 +1,14 @@
 """GPU: proofs made by the device prover are ACCEPTED by the restated reference verifier (oracle/pyref_verifier.py:
 Proof::deserialize_compressed, Verifier::compute_challenges / prepare_pcs_info / batch_verify_opening_proofs,
 verifier.rs:68-733) -- from the serialized proof bytes alone, with the challenges recomputed from the transcript -- and
-rejected once a byte changes.  The verifier shares no code with the device path or with the restated provers."""
+rejected once a byte changes; the final check both as the reference's pairing product (oracle/pyref_pairing.py) and in its
+trapdoor form.  The verifier shares no code with the device path or with the restated provers."""
 import random
 
 import numpy as np
 import pytest
 
-from conftest import affine_from_limbs, build_circuit, build_ultra_circuit, fr_mont_limbs
+from conftest import affine_from_limbs, build_circuit, build_ultra_circuit, fr_mont_limbs, verifying_key
 
 pytestmark = pytest.mark.gpu
 
@@ -18,18 +19,6 @@ def rejects(V, *args, **kw):
         return not V.verify(*args, **kw)
     except V.VerifyError:
         return True
-
-
-def verifying_key(mj, pc, pk, num_inputs):
-    """VerifyingKey of preprocess (snark.rs:562-594) as the verifier restatement takes it."""
-    pt = lambda cm: None if cm.is_infinity() else affine_from_limbs(pc, cm.xy)
-    sel, sig = pk.vk_commitments()
-    vk = {"domain_size": pk.n, "num_inputs": num_inputs, "k": list(pk.k), "selector_comms": [pt(x) for x in sel],
-          "sigma_comms": [pt(x) for x in sig], "plookup": None}
-    if pk.ultra:
-        names = ("range_table_comm", "key_table_comm", "table_dom_sep_comm", "q_dom_sep_comm")
-        vk["plookup"] = dict(zip(names, [pt(x) for x in pk.plookup_vk_commitments()]))
-    return vk
 
 
 @pytest.mark.parametrize("curve_id,plonk_type,num_gates,range_bits", [(0, "TurboPlonk", 1 << 12, 8), (1, "TurboPlonk", 100, 8),
@@ -53,6 +42,10 @@ def test_bench_circuit_proof_verifies(gpu, mj, pyref, curve_id, plonk_type, num_
         fresh = lambda: mj.transcript.StandardTranscript(c, b"PlonkProof")
         assert V.verify(pc, fresh(), vk, [], proof_bytes, G, srs_beta, extra_msg=extra)
         assert not V.verify(pc, fresh(), vk, [], proof_bytes, G, srs_beta, extra_msg=b"another message")
+    # the final step as the reference evaluates it: the product of two pairings over the OpenKey, no trapdoor (verifier.rs:226-250)
+    open_key = V.open_key_for_testing(pc, srs_beta)
+    assert V.verify(pc, fresh(), vk, [], proof_bytes, None, None, extra_msg=extra, open_key=open_key)
+    assert not V.verify(pc, fresh(), vk, [], proof_bytes, None, None, extra_msg=extra, open_key=V.open_key_for_testing(pc, srs_beta + 1))
     # any altered scalar in the proof is rejected (evaluations sit behind the 3W + 3 commitments)
     g1_len = 48 if curve_id == 0 else 32
     W = cs.num_wire_types
