@@ -114,38 +114,47 @@ def test_link_proofs_with_different_witnesses_rejected(gpu, mj, pyref):
     p1.release(); p2.release(); ck.release()
 
 
-def test_link_large_polynomials(gpu, mj, pyref):
-    """2^16-coefficient wire polynomials that agree on a 300-point link domain: the device quotient is exact
-    (q * Z_D == a_1 - a_2 at a random point) and the restated verifier accepts through the trapdoor."""
+@pytest.mark.parametrize("curve_id,log_n,layout_args", [(0, 16, (12, 17, 300)), (1, 20, (18, 1000, 1000)), (0, 20, (20, 5, 64))])
+def test_link_large_polynomials(gpu, mj, pyref, curve_id, log_n, layout_args):
+    """Masked wire polynomials of 2^16 / 2^20 (+2) coefficients that agree on a link domain of up to 1000 points: the device
+    quotient is exact (q * Z_D == a_1 - a_2 at a random point) and the restated verifier accepts -- in its pairing form too."""
     import torch
     import pyref_linking as L
-    c, pc = mj.params.CURVES[0], pyref.CURVES[0]
+    import pyref_verifier as V
+    c, pc = mj.params.CURVES[curve_id], pyref.CURVES[curve_id]
     r = c.r
-    rng = random.Random(11)
-    n = 1 << 16
-    layout_args = (12, 17, 300)
+    rng = random.Random(11 + log_n)
+    n = 1 << log_n
     layout, olayout = mj.linking.GroupLayout(*layout_args), L.GroupLayout(*layout_args)
     srs_beta = rng.randrange(1, r)
     ck = mj.UnivariateProverParam.gen_srs_for_testing(c, srs_beta, n + 2)
-    dom = mj.Radix2EvaluationDomain(c, 16)
+    dom = mj.Radix2EvaluationDomain(c, log_n)
     v1 = mj.params.random_fr_mont(c, n, seed=3)
     v2 = mj.params.random_fr_mont(c, n, seed=4)
-    start, _ = layout.range_in_nth_roots(16)
-    rows = start + (1 << (16 - 12)) * np.arange(300)
+    al, _, size = layout_args
+    start, _ = layout.range_in_nth_roots(log_n)
+    rows = start + (1 << (log_n - al)) * np.arange(size)
     v2[rows] = v1[rows]
     dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int64)).cuda()
-    a1, a2 = dev(dom.ifft(v1)), dev(dom.ifft(v2))
-    cm = lambda t: mj.UnivariateKzgPCS.commit(ck, t.cpu().numpy().view(np.uint64))
+
+    def masked(vals, b):                                                     # a(X) + (b_0 + b_1 X)(X^n - 1): n + 2 coefficients, same values on H
+        t = dev(np.concatenate([dom.ifft(vals), np.zeros((2, 4), dtype=np.uint64)]))
+        mj.poly.mask(c, [t], n, [b])
+        return t
+
+    a1, a2 = masked(v1, [rng.randrange(r), rng.randrange(r)]), masked(v2, [rng.randrange(r), rng.randrange(r)])
+    cm = lambda t: mj.UnivariateKzgPCS.commit(ck, t)
     h1, h2 = mj.linking.LinkingHint(a1, cm(a1)), mj.linking.LinkingHint(a2, cm(a2))
     link = mj.linking.link_proofs(h1, h2, layout, ck)
     diff, quotient = mj.linking.compute_linking_quotient(c, a1, a2, layout)
-    assert quotient.shape[0] == n - 300
+    assert quotient.shape[0] == n + 2 - size
     x = rng.randrange(r)
     assert mj.poly.evaluate(c, quotient, x)[0] * L.vanishing_eval(pc, olayout, x) % r == mj.poly.evaluate(c, diff, x)[0]
     fresh = lambda: mj.transcript.StandardTranscript(c, b"PlonkLinkingProof")
     args = (_pt(pc, h1.linking_wire_comm), _pt(pc, h2.linking_wire_comm), _pt(pc, link.quotient_commitment), _pt(pc, link.opening_proof))
     assert L.verify_link_proof(pc, fresh(), *args, olayout, srs_beta)
-    assert not L.verify_link_proof(pc, fresh(), *args, L.GroupLayout(12, 17, 301), srs_beta)
+    assert L.verify_link_proof(pc, fresh(), *args, olayout, None, open_key=V.open_key_for_testing(pc, srs_beta))
+    assert not L.verify_link_proof(pc, fresh(), *args, L.GroupLayout(al, layout_args[1], size + 1), srs_beta)
     ck.release()
 
 
