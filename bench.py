@@ -165,7 +165,7 @@ def main():
             "phases_ms": {"sort": round(sort_ms / max(tot_cnt, 1), 4), "accumulate": round(acc_avg_ms, 4),
                           "reduce": round(red_ms / max(tot_cnt, 1), 4), "device_total": round(tot_ms / max(tot_cnt, 1), 4)},
             "cpu_baseline": None, "ntt": None, "plonk_round3": None, "batch_commit5": None, "prove": None, "prove_cpp_host": None,
-            "prove_sharded": None, "prove_ultra_bn254": None,
+            "prove_sharded": None, "prove_ultra_bn254": None, "link_and_batch": None,
         }
 
     # The headline line is complete here; everything below is secondary.  With several ranks the secondary part holds collectives
@@ -402,6 +402,43 @@ def main():
         ck2.release()
         del cs, quot
 
+    # ---- secondary: proof linking and an aggregated proof (snark.rs:64-78, proof_linking.rs:80-221) ----------
+    link_batch = None
+    if not args.no_plonk and rank == 0 and world == 1:
+        ln = args.plonk_log_n
+        g1, g2 = (1 << ln) - 576, (1 << ln) - 76                          # two circuits of one domain size, sharing wire-0 rows
+        size = min(256, max(1, (1 << ln) // 8))
+        layout = mj.linking.GroupLayout(max(ln - 2, 1), 5, size)
+        cs_a, cs_b = (mj.snark.gen_circuit_for_bench(curve, g, "TurboPlonk") for g in (g1, g2))
+        if cs_a.n == cs_b.n == (1 << ln):
+            rngl = mj.rng.test_rng()
+            ckl = mj.UnivariateProverParam.gen_srs_for_testing(curve, beta, cs_a.n + 2)
+            pa, pb = mj.snark.preprocess(ckl, cs_a), mj.snark.preprocess(ckl, cs_b)
+            _, _, ha = mj.snark.prove_with_link_hint(rngl, cs_a, pa)
+            _, _, hb = mj.snark.prove_with_link_hint(rngl, cs_b, pb)
+            mj.linking.link_proofs(ha, hb, layout, ckl)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                lp = mj.linking.link_proofs(ha, hb, layout, ckl)
+            torch.cuda.synchronize()
+            link_ms = (time.perf_counter() - t1) / 3 * 1e3
+            mj.snark.batch_prove(rngl, [cs_a, cs_b], [pa, pb])
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(2):
+                _, blob = mj.snark.batch_prove(rngl, [cs_a, cs_b], [pa, pb])
+            torch.cuda.synchronize()
+            batch_ms = (time.perf_counter() - t1) / 2 * 1e3
+            link_batch = {"what": "two TurboPlonk bench circuits of 2^%d rows (%d and %d gates): PlonkKzgSnark::link_proofs over %d shared wire-0 "
+                                  "witnesses (alignment %d), and ONE aggregated proof of both (PlonkKzgSnark::batch_prove)" % (ln, g1, g2, size, layout.alignment),
+                          "link_proofs_ms": round(link_ms, 2), "link_proof_bytes": len(lp.serialize_compressed()),
+                          "batch_prove_2_instances_ms": round(batch_ms, 2), "batch_proof_bytes": len(blob)}
+            pa.release()
+            pb.release()
+            ckl.release()
+        del cs_a, cs_b
+
     # ---- secondary: the same proofs driven by the C++ host layer (mpc-jellyfish_amd/host/, g++, C ABI only; no Python in the loop) ----
     prove_cpp = None
     if not args.no_plonk and rank == 0 and world == 1:
@@ -484,7 +521,7 @@ def main():
 
     if rank == 0:
         out.update({"cpu_baseline": cpu, "ntt": ntt, "plonk_round3": plonk, "batch_commit5": batch, "prove": prove, "prove_cpp_host": prove_cpp,
-                    "prove_sharded": prove_sharded, "prove_ultra_bn254": ultra})
+                    "prove_sharded": prove_sharded, "prove_ultra_bn254": ultra, "link_and_batch": link_batch})
         emit()
     if world > 1:
         dist.barrier()
