@@ -55,6 +55,10 @@ def batch_prove(provers: list[TurboPlonkProver], wire_values: list, pub_input_va
         raise ValueError("zero number of circuits/proving keys")                                  # snark.rs:213-215
     if not (len(provers) == len(wire_values) == len(pub_input_values) == len(pub_inputs) == len(blinds)):
         raise ValueError("the number of circuits != the number of proving keys")                  # snark.rs:216-223
+    if len({id(p) for p in provers}) != len(provers):
+        # the device workspace (slab, coefficient forms, quotient) belongs to the TurboPlonkProver: two instances of one circuit
+        # need two provers (preprocess twice) -- the reference's `prove_keys` may repeat because its Oracles live on the host
+        raise ValueError("one TurboPlonkProver per instance: the same prover object was passed twice")
     p0 = provers[0]
     c, n, r, W = p0.curve, p0.n, p0.curve.r, p0.W
     for p in provers:

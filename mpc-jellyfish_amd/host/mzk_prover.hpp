@@ -611,6 +611,9 @@ BatchProof<C> batch_prove(ChaChaRng& rng, const std::vector<Prover<C>*>& provers
     using Term = typename P::Term;
     if (provers.empty()) throw std::runtime_error("zero number of circuits/proving keys");
     if (provers.size() != circuits.size()) throw std::runtime_error("the number of circuits != the number of proving keys");
+    for (size_t i = 0; i < provers.size(); i++)
+        for (size_t j = 0; j < i; j++)
+            if (provers[i] == provers[j]) throw std::runtime_error("one Prover per instance: the device workspace belongs to the Prover");
     P& p0 = *provers[0];
     const uint64_t n = p0.n;
     const int W = p0.W;

@@ -60,6 +60,8 @@ def test_batch_prove_bench_circuits_verifies(gpu, mj, pyref, curve_id, plonk_typ
         mj.snark.batch_prove(rng, [], [])
     with pytest.raises(ValueError):
         mj.snark.batch_prove(rng, circuits, pks[:-1])
+    with pytest.raises(ValueError):
+        mj.snark.batch_prove(rng, [circuits[0], circuits[0]], [pks[0], pks[0]])       # one prover (device workspace) per instance
     small = mj.snark.gen_circuit_for_bench(c, 17, plonk_type, range_bit_len=range_bits)
     if small.n != n:
         with pytest.raises(ValueError):
