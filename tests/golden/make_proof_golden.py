@@ -1,0 +1,59 @@
+"""tests/golden/make_proof_golden.py -- generates tests/golden/proof_vectors.json on the CPU.
+
+Whole proofs of the reference's bench circuit (plonk/benches/bench.rs:29-46) by the big-int restatements alone
+(oracle/pyref_circuit.py builds the circuit, oracle/pyref_snark.py proves it with schoolbook polynomial arithmetic), with the
+reference's deterministic randomness: `test_rng` (ChaCha12, zero seed) draws the SRS trapdoor first and then the blinders in
+the prover's order (mpc-jellyfish_amd/rng.py, pure Python, pinned by the ChaCha KATs of tests/test_transcript.py).
+The reference holds no proof vector and cannot be built here, so these are restatement vectors: the CPU suite checks that the
+restated verifier accepts them (pairing form), the GPU suite that the device prover emits exactly these bytes.
+
+    python tests/golden/make_proof_golden.py
+"""
+import json
+import os
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.join(HERE, "..", "..")
+sys.path.insert(0, os.path.join(ROOT, "oracle"))
+sys.path.insert(0, ROOT)
+import pyref as P  # noqa: E402
+import pyref_circuit as PC  # noqa: E402
+import pyref_snark as PS  # noqa: E402
+import mpc_jellyfish_amd as mj  # noqa: E402  (params / rng / transcript: pure Python, no GPU)
+
+CASES = [(0, "TurboPlonk", 20, 8), (1, "TurboPlonk", 20, 8), (1, "UltraPlonk", 20, 3), (0, "UltraPlonk", 24, 4)]
+
+
+def build(curve_id, plonk_type, num_gates, range_bits):
+    c, pc = mj.params.CURVES[curve_id], P.CURVES[curve_id]
+    ultra = plonk_type == "UltraPlonk"
+    W = 6 if ultra else 5
+    # k depends on the domain size: build once to learn n, then with the real representatives
+    n = PC.bench_circuit(pc, num_gates, ultra, range_bits, list(range(1, W + 1)))[0]
+    k = mj.rng.compute_coset_representatives(c, W, n)
+    n, wires, witness, sel, sigma, tables = PC.bench_circuit(pc, num_gates, ultra, range_bits, k)
+    rng = mj.rng.test_rng()
+    srs_beta = mj.rng.fr_rand(c, rng)
+    bl = mj.snark.draw_blinders(c, rng, W, ultra)
+    blind = {"wires": bl.wires, "z": bl.z, "quot": bl.quot, "h": bl.h, "prod_lookup": bl.prod_lookup}
+    w_vals = [[witness[v] for v in wires[i]] for i in range(W)]
+    g1 = lambda p: mj.transcript.g1_bytes(c, p)
+    fr = lambda x: mj.transcript.fr_bytes(c, x)
+    out = PS.prove(pc, n.bit_length() - 1, sel, sigma, k, w_vals, [0] * n, [], blind, srs_beta, mj.transcript.StandardTranscript(c, b"PlonkProof"),
+                   g1, fr, plookup=tables)
+    vk = out["vk"]
+    rec = {"curve": curve_id, "plonk_type": plonk_type, "num_gates": num_gates, "range_bit_len": range_bits, "domain_size": n,
+           "srs_beta": "%x" % srs_beta, "k": ["%x" % x for x in k],
+           "selector_comms": [g1(p).hex() for p in vk["selector_comms"]], "sigma_comms": [g1(p).hex() for p in vk["sigma_comms"]],
+           "plookup_comms": None, "challenges": {name: "%x" % v for name, v in out["challenges"].items()}, "proof": out["proof"].hex()}
+    if ultra:
+        rec["plookup_comms"] = {name: g1(p).hex() for name, p in vk["plookup"].items()}
+    return rec
+
+
+if __name__ == "__main__":
+    vectors = [build(*case) for case in CASES]
+    with open(os.path.join(HERE, "proof_vectors.json"), "w") as f:
+        json.dump(vectors, f, indent=1)
+    print("wrote", len(vectors), "proof vectors:", [len(v["proof"]) // 2 for v in vectors], "bytes")

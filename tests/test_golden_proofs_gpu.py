@@ -1,0 +1,30 @@
+"""GPU: the device prover emits, byte for byte, the committed whole-proof vectors (tests/golden/proof_vectors.json: bench
+circuit, `test_rng` blinders, Merlin transcript, by the big-int restatements alone) -- proof and verifying-key commitments."""
+import pytest
+
+from conftest import load_golden
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("index", [0, 1, 2, 3])
+def test_device_prover_reproduces_the_golden_proof(gpu, mj, index):
+    vec = load_golden("proof_vectors")[index]
+    c = mj.params.CURVES[vec["curve"]]
+    cs = mj.snark.gen_circuit_for_bench(c, vec["num_gates"], vec["plonk_type"], range_bit_len=vec["range_bit_len"])
+    assert cs.n == vec["domain_size"] and ["%x" % x for x in cs.k] == vec["k"]
+    rng = mj.rng.test_rng()
+    srs_beta = mj.rng.fr_rand(c, rng)
+    assert "%x" % srs_beta == vec["srs_beta"]
+    ck = mj.UnivariateProverParam.gen_srs_for_testing(c, srs_beta, cs.n + 2)
+    pk = mj.snark.preprocess(ck, cs)
+    sel, sig = pk.vk_commitments()
+    assert [mj.snark._g1(c, x).hex() for x in sel] == vec["selector_comms"] and [mj.snark._g1(c, x).hex() for x in sig] == vec["sigma_comms"]
+    if pk.ultra:
+        names = ("range_table_comm", "key_table_comm", "table_dom_sep_comm", "q_dom_sep_comm")
+        assert dict(zip(names, [mj.snark._g1(c, x).hex() for x in pk.plookup_vk_commitments()])) == vec["plookup_comms"]
+    _, proof_bytes = mj.snark.prove(rng, cs, pk)
+    assert proof_bytes.hex() == vec["proof"]
+    assert {name: "%x" % v for name, v in pk.last_challenges.items()} == vec["challenges"]
+    pk.release()
+    ck.release()
