@@ -25,7 +25,7 @@ import mpc_jellyfish_amd as mj  # noqa: E402  (params / rng / transcript: pure P
 CASES = [(0, "TurboPlonk", 20, 8), (1, "TurboPlonk", 20, 8), (1, "UltraPlonk", 20, 3), (0, "UltraPlonk", 24, 4)]
 
 
-def build(curve_id, plonk_type, num_gates, range_bits):
+def build(curve_id, plonk_type, num_gates, range_bits, rng=None, want_core=False):
     c, pc = mj.params.CURVES[curve_id], P.CURVES[curve_id]
     ultra = plonk_type == "UltraPlonk"
     W = 6 if ultra else 5
@@ -33,8 +33,12 @@ def build(curve_id, plonk_type, num_gates, range_bits):
     n = PC.bench_circuit(pc, num_gates, ultra, range_bits, list(range(1, W + 1)))[0]
     k = mj.rng.compute_coset_representatives(c, W, n)
     n, wires, witness, sel, sigma, tables = PC.bench_circuit(pc, num_gates, ultra, range_bits, k)
-    rng = mj.rng.test_rng()
-    srs_beta = mj.rng.fr_rand(c, rng)
+    if rng is None:
+        rng = mj.rng.test_rng()
+        srs_beta = mj.rng.fr_rand(c, rng)
+    else:                                                                 # a later proof on the same stream: the trapdoor was its first draw
+        first = mj.rng.test_rng()
+        srs_beta = mj.rng.fr_rand(c, first)
     bl = mj.snark.draw_blinders(c, rng, W, ultra)
     blind = {"wires": bl.wires, "z": bl.z, "quot": bl.quot, "h": bl.h, "prod_lookup": bl.prod_lookup}
     w_vals = [[witness[v] for v in wires[i]] for i in range(W)]
@@ -49,7 +53,29 @@ def build(curve_id, plonk_type, num_gates, range_bits):
            "plookup_comms": None, "challenges": {name: "%x" % v for name, v in out["challenges"].items()}, "proof": out["proof"].hex()}
     if ultra:
         rec["plookup_comms"] = {name: g1(p).hex() for name, p in vk["plookup"].items()}
-    return rec
+    return (rec, out) if want_core else rec
+
+
+LINK_CASES = [(1, (20, 22), (4, 3, 9)), (0, (40, 30), (5, 6, 14))]
+
+
+def build_link(curve_id, gates, layout_args):
+    """prove_with_link_hint on two TurboPlonk bench circuits of one domain size (consecutive draws of one `test_rng`), then
+    PlonkKzgSnark::link_proofs over the given GroupLayout (wire 0 of the bench circuit holds the running sums 0, 1, 2, ..:
+    rows below both gate counts carry the same witnesses), all by the restatements (oracle/pyref_linking.py)."""
+    import pyref_linking as L
+    c, pc = mj.params.CURVES[curve_id], P.CURVES[curve_id]
+    rng = mj.rng.test_rng()
+    srs_beta = mj.rng.fr_rand(c, rng)
+    recs, cores = zip(*[build(curve_id, "TurboPlonk", g, 8, rng=rng, want_core=True) for g in gates])
+    assert recs[0]["domain_size"] == recs[1]["domain_size"]
+    G = P.g1_gen(pc)
+    a = [core["core"]["wire_polys"][0] for core in cores]
+    comms = [P.g1_mul(pc, core["core"]["commit_dlogs"]["wires"][0], G) for core in cores]
+    lp = L.link_proofs(pc, a[0], a[1], comms[0], comms[1], L.GroupLayout(*layout_args), srs_beta, mj.transcript.StandardTranscript(c, b"PlonkLinkingProof"))
+    g1 = lambda p: mj.transcript.g1_bytes(c, p)
+    return {"curve": curve_id, "gates": list(gates), "layout": list(layout_args), "srs_beta": "%x" % srs_beta, "proofs": [r["proof"] for r in recs],
+            "eta": "%x" % lp["eta"], "link_proof": L.serialize_link_proof(g1, lp["quotient_commitment"], lp["opening_proof"]).hex()}
 
 
 if __name__ == "__main__":
@@ -57,3 +83,7 @@ if __name__ == "__main__":
     with open(os.path.join(HERE, "proof_vectors.json"), "w") as f:
         json.dump(vectors, f, indent=1)
     print("wrote", len(vectors), "proof vectors:", [len(v["proof"]) // 2 for v in vectors], "bytes")
+    links = [build_link(*case) for case in LINK_CASES]
+    with open(os.path.join(HERE, "link_vectors.json"), "w") as f:
+        json.dump(links, f, indent=1)
+    print("wrote", len(links), "link vectors")

@@ -46,3 +46,28 @@ def test_golden_proof_vectors(pyref, mj, index):
     bad = bytearray(proof)
     bad[-40 if vec["plookup_comms"] is None else -2] ^= 1
     assert not V.verify(pc, fresh(), vk, [], bytes(bad), pyref.g1_gen(pc), srs_beta)
+
+
+@pytest.mark.parametrize("index", [0, 1])
+def test_golden_link_vectors(pyref, mj, index):
+    """tests/golden/link_vectors.json: two proofs on one `test_rng` stream and their LinkingProof, all by the restatements --
+    regenerated identically and accepted by the restated link verifier in its pairing form (proof_linking.rs:240-286)."""
+    import pyref_linking as L
+    import pyref_verifier as V
+    vec = load_golden("link_vectors")[index]
+    gen = _generator()
+    assert gen.build_link(*gen.LINK_CASES[index]) == vec, "tests/golden/link_vectors.json is stale: run tests/golden/make_proof_golden.py"
+    c, pc = mj.params.CURVES[vec["curve"]], pyref.CURVES[vec["curve"]]
+    srs_beta = int(vec["srs_beta"], 16)
+    wire0 = [V.deserialize_proof(pc, bytes.fromhex(p))["wires_poly_comms"][0] for p in vec["proofs"]]
+    blob = bytes.fromhex(vec["link_proof"])
+    half = len(blob) // 2
+    q, o = V.g1_decompress(pc, blob[:half]), V.g1_decompress(pc, blob[half:])
+    fresh = lambda: mj.transcript.StandardTranscript(c, b"PlonkLinkingProof")
+    layout = L.GroupLayout(*vec["layout"])
+    open_key = V.open_key_for_testing(pc, srs_beta)
+    assert L.verify_link_proof(pc, fresh(), wire0[0], wire0[1], q, o, layout, None, open_key=open_key)
+    assert L.quotient_challenge(fresh(), wire0[0], wire0[1], q) == int(vec["eta"], 16)
+    al, off, size = vec["layout"]
+    assert not L.verify_link_proof(pc, fresh(), wire0[0], wire0[1], q, o, L.GroupLayout(al, off, size + 1), srs_beta)
+    assert not L.verify_link_proof(pc, fresh(), wire0[1], wire0[0], q, o, layout, srs_beta)

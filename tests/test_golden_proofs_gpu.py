@@ -28,3 +28,26 @@ def test_device_prover_reproduces_the_golden_proof(gpu, mj, index):
     assert {name: "%x" % v for name, v in pk.last_challenges.items()} == vec["challenges"]
     pk.release()
     ck.release()
+
+
+@pytest.mark.parametrize("index", [0, 1])
+def test_device_link_proofs_reproduce_the_golden_link(gpu, mj, index):
+    """prove_with_link_hint twice + link_proofs on the device: both proofs and the LinkingProof of tests/golden/link_vectors.json."""
+    vec = load_golden("link_vectors")[index]
+    c = mj.params.CURVES[vec["curve"]]
+    circuits = [mj.snark.gen_circuit_for_bench(c, g, "TurboPlonk") for g in vec["gates"]]
+    rng = mj.rng.test_rng()
+    srs_beta = mj.rng.fr_rand(c, rng)
+    assert "%x" % srs_beta == vec["srs_beta"]
+    ck = mj.UnivariateProverParam.gen_srs_for_testing(c, srs_beta, circuits[0].n + 2)
+    pks = [mj.snark.preprocess(ck, cs) for cs in circuits]
+    hints = []
+    for cs, pk, want in zip(circuits, pks, vec["proofs"]):
+        _, proof_bytes, hint = mj.snark.prove_with_link_hint(rng, cs, pk)
+        assert proof_bytes.hex() == want
+        hints.append(hint)
+    link = mj.linking.link_proofs(hints[0], hints[1], mj.linking.GroupLayout(*vec["layout"]), ck)
+    assert link.serialize_compressed().hex() == vec["link_proof"]
+    for pk in pks:
+        pk.release()
+    ck.release()
