@@ -51,3 +51,22 @@ def test_device_link_proofs_reproduce_the_golden_link(gpu, mj, index):
     for pk in pks:
         pk.release()
     ck.release()
+
+
+def test_cpp_host_reproduces_the_golden_proofs(gpu):
+    """The compiled host (mzk_prove) against the same CPU-made vectors: proofs, verifying keys and the LinkingProof."""
+    import json
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    binp = os.path.join(root, "mpc-jellyfish_amd", "mzk_prove")
+    if not os.path.exists(binp):
+        subprocess.check_call(["make", "-C", os.path.join(root, "mpc-jellyfish_amd", "host"), "-s"])
+    run = lambda args: json.loads(subprocess.run([binp] + [str(a) for a in args], capture_output=True, text=True, timeout=600, check=True).stdout.strip().splitlines()[-1])
+    for vec in load_golden("proof_vectors"):
+        got = run([vec["curve"], "ultra" if vec["plonk_type"] == "UltraPlonk" else "turbo", vec["num_gates"], 0, vec["range_bit_len"]])
+        assert got["proof_hex"] == vec["proof"], (vec["curve"], vec["plonk_type"])
+        assert got["vk_hex"] == "".join(vec["selector_comms"] + vec["sigma_comms"])
+    for vec in load_golden("link_vectors"):
+        got = run([vec["curve"], "link"] + vec["gates"] + vec["layout"])
+        assert [got["proof1_hex"], got["proof2_hex"]] == vec["proofs"] and got["link_proof_hex"] == vec["link_proof"]
