@@ -93,3 +93,86 @@ def prove(c, log_n, selector_vals, sigma_vals, k, wire_vals, pi_vals, pub_input,
     else:
         blob += b"\x00"
     return {"proof": blob, "vk": vk, "challenges": dict(ch), "core": out}
+
+
+def batch_prove(c, log_n, instances, pub_inputs, quot_blind, srs_beta, transcript, g1_bytes, fr_bytes, extra_msg=None):
+    """`PlonkKzgSnark::batch_prove` (snark.rs:64-78, 201-469) restated around pyref_plonk.batch_prove_core, by the same re-run
+    scheme as `prove`.  instances: the dicts batch_prove_core takes.  Returns {"proof": compressed BatchProof bytes
+    (structs.rs:266-291), "vks", "challenges"}."""
+    r = c.r
+    n = 1 << log_n
+    G = P.g1_gen(c)
+    pt = lambda dlog: P.g1_mul(c, dlog % r, G) if dlog % r else None
+    commit = lambda poly: pt(P.poly_eval(c, poly, srs_beta))
+    ch = {x: 0x9e3779b97f4a7c15f39cc0605cedc835 + 0x1000003 * i for i, x in enumerate(("tau", "beta", "gamma", "alpha", "zeta", "v"))}
+    run = lambda: PP.batch_prove_core(c, log_n, instances, ch, quot_blind, srs_beta)
+    out = run()
+    K = len(instances)
+    ultra = [inst.get("plookup") is not None for inst in instances]
+    vks = []
+    for inst, o, u in zip(instances, out["instances"], ultra):
+        vk = {"domain_size": n, "num_inputs": 0, "k": list(inst["k"]), "selector_comms": [commit(p) for p in o["selectors"]],
+              "sigma_comms": [commit(p) for p in o["sigmas"]], "plookup": None}
+        if u:
+            tab = o["table_polys"]
+            vk["plookup"] = {"range_table_comm": commit(tab["range"]), "key_table_comm": commit(tab["key"]),
+                             "table_dom_sep_comm": commit(tab["table_dom_sep"]), "q_dom_sep_comm": commit(tab["q_dom_sep"])}
+        vks.append(vk)
+    t = transcript
+    if extra_msg is not None:
+        t.append_message(b"extra info", extra_msg)
+    for vk, pub in zip(vks, pub_inputs):
+        vk["num_inputs"] = len(pub)
+        t.append_vk_and_pub_input(n, len(pub), vk["k"], vk["selector_comms"], vk["sigma_comms"], pub)
+    dl = out["commit_dlogs"]
+    wires = [[pt(d) for d in ws] for ws in dl["wires"]]
+    for ws in wires:
+        t.append_commitments(b"witness_poly_comms", ws)
+    ch["tau"] = t.get_and_append_challenge(b"tau")
+    dl = run()["commit_dlogs"]
+    h = [[pt(d) for d in hs] if hs is not None else None for hs in dl["h"]]
+    for hs in h:
+        if hs is not None:
+            t.append_commitments(b"h_poly_comms", hs)
+    ch["beta"] = t.get_and_append_challenge(b"beta")
+    ch["gamma"] = t.get_and_append_challenge(b"gamma")
+    dl = run()["commit_dlogs"]
+    z = [pt(d) for d in dl["z"]]
+    for cm in z:
+        t.append_commitment(b"perm_poly_comms", cm)
+    pl = [pt(d) if d is not None else None for d in dl["prod_lookup"]]
+    for cm, u in zip(pl, ultra):
+        if u:
+            t.append_commitment(b"plookup_poly_comms", cm)
+    ch["alpha"] = t.get_and_append_challenge(b"alpha")
+    out = run()
+    assert out["divisible"] and out["quot_degree_ok"]
+    split = [pt(d) for d in out["commit_dlogs"]["split"]]
+    t.append_commitments(b"quot_poly_comms", split)
+    ch["zeta"] = t.get_and_append_challenge(b"zeta")
+    out = run()
+    for o in out["instances"]:
+        for e in o["wires_evals"]:
+            t.append_field_elem(b"wire_evals", e)
+        for e in o["wire_sigma_evals"]:
+            t.append_field_elem(b"wire_sigma_evals", e)
+        t.append_field_elem(b"perm_next_eval", o["perm_next_eval"])
+    for o, u in zip(out["instances"], ultra):
+        if u:
+            t.append_plookup_evaluations(o["plookup_evals"])
+    ch["v"] = t.get_and_append_challenge(b"v")
+    out = run()
+    dl = out["commit_dlogs"]
+    vec = lambda items, enc: struct.pack("<Q", len(items)) + b"".join(enc(x) for x in items)
+    blob = vec(wires, lambda ws: vec(ws, g1_bytes)) + vec(z, g1_bytes)
+    blob += vec(out["instances"], lambda o: vec(o["wires_evals"], fr_bytes) + vec(o["wire_sigma_evals"], fr_bytes) + fr_bytes(o["perm_next_eval"]))
+
+    def plookup(i):
+        if not ultra[i]:
+            return b"\x00"
+        ev = out["instances"][i]["plookup_evals"]
+        return b"\x01" + vec(h[i], g1_bytes) + g1_bytes(pl[i]) + b"".join(fr_bytes(ev[name]) for name in PLOOKUP_EVAL_FIELDS)
+
+    blob += vec(list(range(K)), plookup)
+    blob += vec(split, g1_bytes) + g1_bytes(pt(dl["opening"])) + g1_bytes(pt(dl["shifted_opening"]))
+    return {"proof": blob, "vks": vks, "challenges": dict(ch)}

@@ -56,6 +56,33 @@ def build(curve_id, plonk_type, num_gates, range_bits, rng=None, want_core=False
     return (rec, out) if want_core else rec
 
 
+BATCH_CASES = [(0, "TurboPlonk", (25, 28, 31), 8), (1, "UltraPlonk", (36, 40), 4)]
+
+
+def build_batch(curve_id, plonk_type, gates, range_bits):
+    """PlonkKzgSnark::batch_prove over bench circuits of one domain size, `test_rng` draws in batch_prove_internal's order
+    (snark.draw_batch_blinders), by the restatements (oracle/pyref_snark.py::batch_prove)."""
+    c, pc = mj.params.CURVES[curve_id], P.CURVES[curve_id]
+    ultra = plonk_type == "UltraPlonk"
+    W = 6 if ultra else 5
+    n = PC.bench_circuit(pc, gates[0], ultra, range_bits, list(range(1, W + 1)))[0]
+    k = mj.rng.compute_coset_representatives(c, W, n)
+    rng = mj.rng.test_rng()
+    srs_beta = mj.rng.fr_rand(c, rng)
+    blinds, quot = mj.snark.draw_batch_blinders(c, rng, W, [ultra] * len(gates))
+    instances = []
+    for g, bl in zip(gates, blinds):
+        n_g, wires, witness, sel, sigma, tables = PC.bench_circuit(pc, g, ultra, range_bits, k)
+        assert n_g == n
+        instances.append({"selector_vals": sel, "sigma_vals": sigma, "k": k, "wire_vals": [[witness[v] for v in wires[i]] for i in range(W)],
+                          "pi_vals": [0] * n, "blind": {"wires": bl.wires, "z": bl.z, "h": bl.h, "prod_lookup": bl.prod_lookup}, "plookup": tables})
+    g1 = lambda p: mj.transcript.g1_bytes(c, p)
+    out = PS.batch_prove(pc, n.bit_length() - 1, instances, [[] for _ in gates], quot, srs_beta, mj.transcript.StandardTranscript(c, b"PlonkProof"),
+                         g1, lambda x: mj.transcript.fr_bytes(c, x))
+    return {"curve": curve_id, "plonk_type": plonk_type, "gates": list(gates), "range_bit_len": range_bits, "domain_size": n, "srs_beta": "%x" % srs_beta,
+            "challenges": {name: "%x" % v for name, v in out["challenges"].items()}, "batch_proof": out["proof"].hex()}
+
+
 LINK_CASES = [(1, (20, 22), (4, 3, 9)), (0, (40, 30), (5, 6, 14))]
 
 
@@ -87,3 +114,7 @@ if __name__ == "__main__":
     with open(os.path.join(HERE, "link_vectors.json"), "w") as f:
         json.dump(links, f, indent=1)
     print("wrote", len(links), "link vectors")
+    batches = [build_batch(*case) for case in BATCH_CASES]
+    with open(os.path.join(HERE, "batch_vectors.json"), "w") as f:
+        json.dump(batches, f, indent=1)
+    print("wrote", len(batches), "batch vectors:", [len(v["batch_proof"]) // 2 for v in batches], "bytes")

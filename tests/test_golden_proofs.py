@@ -71,3 +71,39 @@ def test_golden_link_vectors(pyref, mj, index):
     al, off, size = vec["layout"]
     assert not L.verify_link_proof(pc, fresh(), wire0[0], wire0[1], q, o, L.GroupLayout(al, off, size + 1), srs_beta)
     assert not L.verify_link_proof(pc, fresh(), wire0[1], wire0[0], q, o, layout, srs_beta)
+
+
+@pytest.mark.parametrize("index", [0, 1])
+def test_golden_batch_vectors(pyref, mj, index):
+    """tests/golden/batch_vectors.json: one aggregated BatchProof over several bench circuits by the restatements -- regenerated
+    identically; the restated batch verifier accepts it (vks recomputed through the trapdoor from the restated circuits)."""
+    import pyref_circuit as PC
+    import pyref_verifier as V
+    vec = load_golden("batch_vectors")[index]
+    gen = _generator()
+    assert gen.build_batch(*gen.BATCH_CASES[index]) == vec, "tests/golden/batch_vectors.json is stale: run tests/golden/make_proof_golden.py"
+    c, pc = mj.params.CURVES[vec["curve"]], pyref.CURVES[vec["curve"]]
+    ultra = vec["plonk_type"] == "UltraPlonk"
+    W = 6 if ultra else 5
+    n = vec["domain_size"]
+    srs_beta = int(vec["srs_beta"], 16)
+    k = mj.rng.compute_coset_representatives(c, W, n)
+    G = pyref.g1_gen(pc)
+    log_n = n.bit_length() - 1
+    def commit_vals(vals):
+        return pyref.g1_mul(pc, pyref.poly_eval(pc, pyref.ntt_fast(pc, list(vals), log_n, 1, inverse=True), srs_beta), G) if any(vals) else None
+
+    vks = []
+    for g in vec["gates"]:
+        _, _, _, sel, sigma, tables = PC.bench_circuit(pc, g, ultra, vec["range_bit_len"], k)
+        vk = {"domain_size": n, "num_inputs": 0, "k": k, "selector_comms": [commit_vals(s) for s in sel], "sigma_comms": [commit_vals(s) for s in sigma],
+              "plookup": None}
+        if ultra:
+            vk["plookup"] = {"range_table_comm": commit_vals(tables["range"]), "key_table_comm": commit_vals(tables["key"]),
+                             "table_dom_sep_comm": commit_vals(tables["table_dom_sep"]), "q_dom_sep_comm": commit_vals(tables["q_dom_sep"])}
+        vks.append(vk)
+    pubs = [[] for _ in vec["gates"]]
+    blob = bytes.fromhex(vec["batch_proof"])
+    fresh = lambda: mj.transcript.StandardTranscript(c, b"PlonkProof")
+    assert V.verify_batch_proof(pc, fresh(), vks, pubs, blob, None, None, open_key=V.open_key_for_testing(pc, srs_beta))
+    assert not V.verify_batch_proof(pc, fresh(), vks[::-1], pubs, blob, G, srs_beta)

@@ -70,3 +70,26 @@ def test_cpp_host_reproduces_the_golden_proofs(gpu):
     for vec in load_golden("link_vectors"):
         got = run([vec["curve"], "link"] + vec["gates"] + vec["layout"])
         assert [got["proof1_hex"], got["proof2_hex"]] == vec["proofs"] and got["link_proof_hex"] == vec["link_proof"]
+
+
+@pytest.mark.parametrize("index", [0, 1])
+def test_device_and_cpp_batch_prove_reproduce_the_golden_batch_proof(gpu, mj, index):
+    import json
+    import os
+    import subprocess
+    vec = load_golden("batch_vectors")[index]
+    c = mj.params.CURVES[vec["curve"]]
+    circuits = [mj.snark.gen_circuit_for_bench(c, g, vec["plonk_type"], range_bit_len=vec["range_bit_len"]) for g in vec["gates"]]
+    rng = mj.rng.test_rng()
+    ck = mj.UnivariateProverParam.gen_srs_for_testing(c, mj.rng.fr_rand(c, rng), circuits[0].n + 2)
+    pks = [mj.snark.preprocess(ck, cs) for cs in circuits]
+    core, blob = mj.snark.batch_prove(rng, circuits, pks)
+    assert blob.hex() == vec["batch_proof"]
+    assert {name: "%x" % v for name, v in core.challenges.items()} == vec["challenges"]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([os.path.join(root, "mpc-jellyfish_amd", "mzk_prove"), str(vec["curve"]), "batch", "ultra" if vec["plonk_type"] == "UltraPlonk" else "turbo",
+                          str(vec["range_bit_len"])] + [str(g) for g in vec["gates"]], capture_output=True, text=True, timeout=600, check=True)
+    assert json.loads(out.stdout.strip().splitlines()[-1])["batch_proof_hex"] == vec["batch_proof"]
+    for pk in pks:
+        pk.release()
+    ck.release()
