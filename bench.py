@@ -46,6 +46,7 @@ def main():
     ap.add_argument("--log-n", type=int, default=20, help="log2 of the MSM size per GPU (default 2^20 = config C2)")
     ap.add_argument("--ntt-log-n", type=int, default=22, help="log2 of the NTT size for the secondary measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-prove-log-n", type=int, default=16, help="log2 gates of the CPU-vs-device whole-proof comparison (0 disables; ~5 s of CPU at 16)")
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-plonk", action="store_true", help="skip the TurboPlonk round-3 (quotient) measurement")
     ap.add_argument("--plonk-log-n", type=int, default=20)
@@ -509,6 +510,38 @@ def main():
                        and core1.wires_evals == c1["wires_evals"])
         pk1.release()
         ck1.release()
+        # ... and a mid-size proof on all the host threads, next to the device at the same size: the prove-time ratio the
+        # north star asks for, at the largest size that keeps this leg within its time bound (the CPU side grows ~ n log n)
+        lgm = args.cpu_prove_log_n
+        prove_mid = None
+        if lgm:
+            csm = mj.snark.gen_circuit_for_bench(curve, 1 << lgm, "TurboPlonk")
+            rngm = mj.rng.test_rng()
+            ckm = mj.UnivariateProverParam.gen_srs_for_testing(curve, mj.rng.fr_rand(curve, rngm), csm.n + 2)
+            pkm = mj.snark.preprocess(ckm, csm)
+            blm = mj.snark.draw_blinders(curve, rngm, 5, False)
+            for _ in range(3):
+                pkm.prove(csm.wire_values, csm.pub_input_values, mj.prover.TranscriptChallenges(pkm, []), blm)
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(3):
+                srcm = mj.prover.TranscriptChallenges(pkm, [])
+                corem = pkm.prove(csm.wire_values, csm.pub_input_values, srcm, blm)
+            torch.cuda.synchronize()
+            gpu_ms = (time.perf_counter() - t1) / 3 * 1e3
+            cm_ = cref_prover.prove_turbo(0, curve.r, curve.fr_generator, lgm, hostv(csm.selector_values), hostv(csm.sigma_values), csm.k,
+                                          hostv(csm.wire_values), hostv(csm.pub_input_values), {"wires": blm.wires, "z": blm.z, "quot": blm.quot},
+                                          dict(srcm.challenges), ckm.powers_of_g(), threads=threads)
+            mid_same = bool(np.array_equal(corem.opening_proof.xy, cm_["opening"]) and np.array_equal(corem.shifted_opening_proof.xy, cm_["shifted"])
+                            and corem.wires_evals == cm_["wires_evals"])
+            prove_mid = {"log_n": lgm, "ms": round(cm_["seconds"] * 1e3, 1), "cores": threads, "gpu_ms": round(gpu_ms, 2),
+                         "gpu_over_cpu": round(cm_["seconds"] * 1e3 / gpu_ms, 1), "matches_gpu": mid_same,
+                         "sample": "one TurboPlonk proof of the 2^%d-gate bench circuit over BLS12-381, the C restatement (oracle/cref_prover.py: ark-poly "
+                                   "style FFTs, ark-ec style Pippenger, serial grand product) on %d threads vs the device prover (Python-orchestrated) "
+                                   "on the same circuit, blinders and transcript" % (lgm, threads)}
+            pkm.release()
+            ckm.release()
+            del csm
         cpu = {"value": n / cpu_s, "unit": "pairs/s", "cores": threads, "kind": "port",
                "sample": f"one full 2^{args.log_n}-pair MSM (same bases and scalars as the GPU step), oracle/cpu_ref.c "
                          f"Pippenger with the ark-ec window rule, {threads} threads; restatement of ark-ec, not the Rust binary",
@@ -516,6 +549,7 @@ def main():
                "prove_c1": {"ms": round(c1["seconds"] * 1e3, 1), "cores": 1, "matches_gpu": c1_same,
                             "sample": "one TurboPlonk proof of the 2^10-gate bench circuit over BLS12-381 (BASELINE configs[0]) by the C "
                                       "restatement on one thread (oracle/cref_prover.py); GPU figure: prove_cpp_host.turbo_bls12_381_1024_gates"},
+               "prove_mid": prove_mid,
                "ntt_2^22": {"ms": round(ntt_cpu_s * 1e3, 1), "cores": threads, "matches_gpu": ntt_same,
                             "sample": "one forward 2^22-point NTT, oracle/cpu_ref.c in-order radix-2 (ark-poly's algorithm restated)"}}
 

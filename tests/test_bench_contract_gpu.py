@@ -11,7 +11,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
-    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log-n", "14", "--plonk-log-n", "10", "--ultra-log-n", "10",
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--log-n", "14", "--plonk-log-n", "10", "--ultra-log-n", "10", "--cpu-prove-log-n", "11",
                           "--steps", "2", "--warmup", "1"], capture_output=True, text=True, timeout=600, cwd=ROOT)
     assert out.returncode == 0, out.stderr[-2000:]
     lines = [l for l in out.stdout.splitlines() if l.strip()]
@@ -25,6 +25,7 @@ def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
     assert d["roofline"]["bound"] in ("hbm", "mfma") and "workload" in d["config"]
     cb = d["cpu_baseline"]
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(cb) and cb["kind"] in ("port", "reference") and cb["matches_gpu"] is True
+    assert cb["prove_mid"]["matches_gpu"] is True and cb["prove_c1"]["matches_gpu"] is True
     assert d["prove"]["quotient_degree_ok"] is True and d["prove_ultra_bn254"]["quotient_degree_ok"] is True
     assert d["prove_cpp_host"]["turbo_bls12_381"]["proof_bytes"] == d["prove"]["proof_bytes"]
     assert d["prove_cpp_host"]["ultra_bn254"]["proof_bytes"] == d["prove_ultra_bn254"]["proof_bytes"]

@@ -1,6 +1,5 @@
 """GPU: the PlonkKzgSnark::prove mirror on the reference's own benchmark circuit (plonk/benches/bench.rs:29-46) --
 vectorised circuit builder vs the loop restatement, blinders from the ChaCha `test_rng`, Merlin transcript, proof bytes."""
-import random
 import struct
 
 import numpy as np

@@ -8,7 +8,7 @@ import random
 import numpy as np
 import pytest
 
-from conftest import affine_from_limbs, build_circuit, build_ultra_circuit, fr_mont_limbs, verifying_key
+from conftest import build_circuit, build_ultra_circuit, fr_mont_limbs, verifying_key
 
 pytestmark = pytest.mark.gpu
 
