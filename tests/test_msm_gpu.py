@@ -149,11 +149,13 @@ def test_commit_api_behaviour(gpu, mj, cref):
     pp_full.release()
 
 
-def test_msm_full_size_trapdoor(gpu, mj, cref):
-    """BASELINE config C2 (2^20 pairs, BLS12-381): commit(p) over [beta^i]G equals [p(beta)]G --
-    one oracle scalar multiplication pins an MSM of any size."""
+@pytest.mark.parametrize("curve_id,log_n", [(0, 20), (1, 22), (0, 24)])
+def test_msm_full_size_trapdoor(gpu, mj, cref, curve_id, log_n):
+    """BASELINE config C2 (2^20 pairs, BLS12-381), C5's commitment size (2^22, BN254) and a 2^24-pair MSM (a 24 GB table of
+    precomputed multiples): commit(p) over [beta^i]G equals [p(beta)]G -- one oracle scalar multiplication pins an MSM of any
+    size."""
     import torch
-    curve_id, n = 0, 1 << 20
+    n = 1 << log_n
     c = mj.params.CURVES[curve_id]
     beta = 0x1f3a5c7e9b2d4f6081a3c5e7092b4d6f8091a2b3c4d5e6f708192a3b4c5d6e7f % c.r
     pp = mj.UnivariateProverParam.gen_srs_for_testing(curve_id, beta, n - 1)

@@ -88,9 +88,9 @@ def test_ntt_device_resident_batch_and_stream(gpu, mj, cref):
         assert np.array_equal(back[b], padded)
 
 
-@pytest.mark.parametrize("curve_id,log_n", [(0, 22), (0, 23), (1, 25)])
+@pytest.mark.parametrize("curve_id,log_n", [(0, 22), (0, 23), (1, 25), (0, 27)])
 def test_ntt_full_size_properties(gpu, mj, cref, curve_id, log_n):
-    """BASELINE sizes (C3: 2^22; C4 quotient domain 2^23; C5 quotient domain 2^25, BN254):
+    """BASELINE sizes (C3: 2^22; C4 quotient domain 2^23; C5 quotient domain 2^25, BN254) and the largest supported transform (2^27, three passes of 9-bit radices, 4 GiB per vector):
     inverse(forward(x)) == x bit-exactly on the Fr::GENERATOR coset, linearity, and spot
     evaluations against Horner's rule on the oracle."""
     import torch
