@@ -9,6 +9,7 @@
 #include <hip/hip_runtime.h>
 
 #include "fp.cuh"
+#include "fx.cuh"
 
 namespace mzk {
 
@@ -217,50 +218,84 @@ __global__ void poly_mask_kernel(MaskArgs a) {
 
 // ---- division by the vanishing polynomial of a proof-linking domain (proof_linking.rs:119-158) -------------------------
 // Z_D(X) = prod_{i < count} (X - rho g^i).  When Z_D divides p, the quotient is p(x) / Z_D(x) pointwise on a coset that
-// avoids the roots; this kernel multiplies the coset evaluations by 1 / Z_D(x): thread t owns the K points
-// t, t + T, .., reads the roots from a table and inverts its K products with one field inversion (K = 8 on large domains,
-// fewer points per thread when the domain alone would not fill the chip).
+// avoids the roots; the kernel below multiplies the coset evaluations by 1 / Z_D(x): thread t owns the K points
+// t, t + T, .., reads the roots from a table and inverts its K products with one field inversion.
 struct DivRootsArgs {
     uint32_t* evals;
-    const uint32_t* roots;                                   // [count] rho g^i, Montgomery
+    const uint32_t* roots;                                   // [count] rho g^i, internal form
     unsigned long long threads;                              // T: n_points = K * T
     unsigned int count;
-    uint32_t h[8], w[8], w_step[8];                          // coset offset, domain generator, w^T (Montgomery)
+    uint32_t h[8], w[8], w_step[8];                          // coset offset, domain generator, w^T (internal form; the fold kernel borrows h for its multiplier)
 };
-template <class P, int K>
-__global__ __launch_bounds__(POLY_THREADS) void poly_div_roots_pointwise_kernel(DivRootsArgs a) {
-    using F = Fp<P>;
+// The kernel runs on the reduced-radix field (fx.cuh): the coset evaluations arrive in the INTERNAL form x * R' of the quotient kernels
+// (forward NTT with scale = 1, ntt.hip), constants and roots are passed in that form, and the inverse NTT takes the factor back
+// (scale = 2).  A product is one v_mad_u64_u32 per limb pair instead of a multiply-add + carry-add pair.
+// Bounds (H = HEADROOM_BITS >= 6): z is class M (< 2p), x - r + 2p < 4p: fx_mul wants 2 * 4 <= 2^H and gives < 1.13 p.
+template <class X>
+__device__ __forceinline__ Fx<X> fx_inverse(const Fx<X>& a) {              // a^(p-2), a class M
+    Fx<X> out = Fx<X>::one();
+    bool started = false;
+    uint32_t ex[X::N];                                                       // p - 2 (BLS12-381's r ends in ...00000001: the borrow runs one word up)
+    uint32_t borrow = 2;
+#pragma unroll
+    for (int w = 0; w < X::N; w++) {
+        ex[w] = X::MOD[w] - borrow;
+        borrow = X::MOD[w] < borrow ? 1u : 0u;
+    }
+    for (int w = X::N - 1; w >= 0; w--) {
+        const uint32_t e = ex[w];
+        for (int b = 31; b >= 0; b--) {
+            if (started) out = fx_sqr(out);
+            if ((e >> b) & 1u) { out = started ? fx_mul(out, a) : a; started = true; }
+        }
+    }
+    return out;
+}
+template <class X, int K>
+__device__ __forceinline__ void poly_div_roots_pointwise_fx_body(const DivRootsArgs& a) {
+    using F = Fx<X>;
     const unsigned long long t = (unsigned long long)blockIdx.x * POLY_THREADS + threadIdx.x;
     if (t >= a.threads) return;
-    auto cst = [](const uint32_t* c) { F r; for (int q = 0; q < 8; q++) r.l[q] = c[q]; return r; };
     F x[K], z[K];
-    const F step = cst(a.w_step);
-    x[0] = cst(a.h) * pow_u64(cst(a.w), t);
+    const F step = fx_unpack<X>(a.w_step);
+    {
+        F acc = fx_unpack<X>(a.h), base = fx_unpack<X>(a.w);                  // h * w^t
+        for (unsigned long long e = t; e; e >>= 1) {
+            if (e & 1) acc = fx_mul(acc, base);
+            base = fx_sqr(base);
+        }
+        x[0] = acc;
+    }
     z[0] = F::one();
 #pragma unroll
-    for (int k = 1; k < K; k++) { x[k] = x[k - 1] * step; z[k] = F::one(); }
+    for (int k = 1; k < K; k++) { x[k] = fx_mul(x[k - 1], step); z[k] = F::one(); }
     for (unsigned int i = 0; i < a.count; i++) {
-        const F r = load_fp<P>(a.roots + (size_t)i * 8);                 // same address in every lane
+        const F r = fx_load_packed<X>(a.roots + (size_t)i * 8);               // canonical, same address in every lane
 #pragma unroll
-        for (int k = 0; k < K; k++) z[k] = z[k] * (x[k] - r);
+        for (int k = 0; k < K; k++) z[k] = fx_mul(z[k], fx_norm(fx_sub2(x[k], r)));
     }
-    // x[k] := z[0] .. z[k]; one inversion; unwind
     x[0] = z[0];
 #pragma unroll
-    for (int k = 1; k < K; k++) x[k] = x[k - 1] * z[k];
-    F iv = inv(x[K - 1]);
+    for (int k = 1; k < K; k++) x[k] = fx_mul(x[k - 1], z[k]);
+    F iv = fx_inverse<X>(x[K - 1]);
 #pragma unroll
     for (int k = K - 1; k > 0; k--) {
-        const F zi = iv * x[k - 1];
-        iv = iv * z[k];
+        const F zi = fx_mul(iv, x[k - 1]);
+        iv = fx_mul(iv, z[k]);
         z[k] = zi;
     }
     z[0] = iv;
 #pragma unroll
     for (int k = 0; k < K; k++) {
         uint32_t* e = a.evals + (t + (unsigned long long)k * a.threads) * 8;
-        store_fp<P>(e, load_fp<P>(e) * z[k]);
+        fx_store_packed<X>(e, fx_canonical(fx_mul(fx_load_packed<X>(e), z[k])));
     }
+}
+// K = 1 or 2 points per thread on small domains (many waves per SIMD hide the dependent chain), 4 on large ones (the eight
+// 9-limb values stay in registers at two waves per SIMD; at 8 points the arrays go to scratch)
+template <class X, int K>
+__global__ __launch_bounds__(POLY_THREADS) void poly_div_roots_pointwise_fx_kernel(DivRootsArgs a) {
+    poly_div_roots_pointwise_fx_body<X, K>(a);
 }
 // out[j] = sum_k c^k p[j + k N], j < N:  p mod (X^N - c) -- p on the N points x with x^N = c is this polynomial on them
 template <class P>

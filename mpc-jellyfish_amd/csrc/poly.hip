@@ -67,6 +67,10 @@ int32_t div_run(const uint32_t* d_poly, uint64_t len, const uint32_t* z_mont, ui
     return MZK_OK;
 }
 
+template <class P> struct FrXOf;
+template <> struct FrXOf<BlsFr> { using type = BlsFrX; };
+template <> struct FrXOf<BnFr> { using type = BnFrX; };
+
 // floor(p / prod_{i<count} (X - w^(first+i))), w the primitive 2^log_order-th root of unity.  Fast path (the roots are distinct
 // and p vanishes on all of them, i.e. the remainder is zero): coset NTT, pointwise 1/Z_D, inverse coset NTT.  Otherwise the
 // linear factors are divided out one at a time -- floor division by a product is the composition of the floor divisions.
@@ -100,8 +104,9 @@ int32_t div_roots_run(int curve, const uint32_t* d_poly, uint64_t len, uint32_t 
     std::vector<uint32_t> roots;
     if (fast) {
         roots.resize(count * 8);
+        const F to_int = from_u64<P>(32);                              // x * R -> x * R' (the internal form of the fx kernels)
         F cur = root0;
-        for (uint64_t i = 0; i < count; i++) { std::memcpy(&roots[i * 8], cur.l, 32); cur = cur * g; }
+        for (uint64_t i = 0; i < count; i++) { const F ri = cur * to_int; std::memcpy(&roots[i * 8], ri.l, 32); cur = cur * g; }
         HIP_TRY(hipMemcpyAsync(d_roots, roots.data(), count * 32, hipMemcpyHostToDevice, st));
         std::memcpy(a.h, P::R1, 32);
         hipLaunchKernelGGL((poly_fold_kernel<P>), dim3((unsigned)((Ne + POLY_THREADS - 1) / POLY_THREADS)), dim3(POLY_THREADS), 0, st, d_poly, len, Ne, a, T);
@@ -119,24 +124,26 @@ int32_t div_roots_run(int curve, const uint32_t* d_poly, uint64_t len, uint32_t 
         const F h_n = pow_u64(h, Nq);
         std::memcpy(a.h, h_n.l, 32);
         hipLaunchKernelGGL((poly_fold_kernel<P>), dim3((unsigned)((Nq + POLY_THREADS - 1) / POLY_THREADS)), dim3(POLY_THREADS), 0, st, d_poly, len, Nq, a, T);
-        MZK_TRY(ntt_dispatch(curve, T, Nq, log_q, false, P::GENERATOR, 1, Nq, st));
-        const int K = log_q >= 20 ? 8 : log_q >= 18 ? 2 : 1;            // points per thread: keep >= 2^17 threads where the domain allows
+        MZK_TRY(ntt_dispatch(curve, T, Nq, log_q, false, P::GENERATOR, 1, Nq, st, 1));      // evaluations left in the internal form
+        using X = typename FrXOf<P>::type;
+        const int K = log_q >= 19 ? 4 : log_q >= 18 ? 2 : 1;            // points per thread: keep >= 2^17 threads where the domain allows
         a.evals = T;
         a.roots = d_roots;
         a.threads = Nq / K;
         a.count = (unsigned)count;
         F w = F::from_const(P::ROOT);
         for (int i = log_q; i < P::TWO_ADICITY; i++) w = sqr(w);
-        const F w_step = pow_u64(w, a.threads);
-        std::memcpy(a.h, h.l, 32);
-        std::memcpy(a.w, w.l, 32);
+        const F to_int = from_u64<P>(32);
+        const F w_step = pow_u64(w, a.threads) * to_int, h_int = h * to_int, w_int = w * to_int;
+        std::memcpy(a.h, h_int.l, 32);
+        std::memcpy(a.w, w_int.l, 32);
         std::memcpy(a.w_step, w_step.l, 32);
         const dim3 grid((unsigned)((a.threads + POLY_THREADS - 1) / POLY_THREADS));
-        if (K == 8) hipLaunchKernelGGL((poly_div_roots_pointwise_kernel<P, 8>), grid, dim3(POLY_THREADS), 0, st, a);
-        else if (K == 2) hipLaunchKernelGGL((poly_div_roots_pointwise_kernel<P, 2>), grid, dim3(POLY_THREADS), 0, st, a);
-        else hipLaunchKernelGGL((poly_div_roots_pointwise_kernel<P, 1>), grid, dim3(POLY_THREADS), 0, st, a);
+        if (K == 4) hipLaunchKernelGGL((poly_div_roots_pointwise_fx_kernel<X, 4>), grid, dim3(POLY_THREADS), 0, st, a);
+        else if (K == 2) hipLaunchKernelGGL((poly_div_roots_pointwise_fx_kernel<X, 2>), grid, dim3(POLY_THREADS), 0, st, a);
+        else hipLaunchKernelGGL((poly_div_roots_pointwise_fx_kernel<X, 1>), grid, dim3(POLY_THREADS), 0, st, a);
         HIP_TRY(hipGetLastError());
-        MZK_TRY(ntt_dispatch(curve, T, Nq, log_q, true, P::GENERATOR, 1, Nq, st));
+        MZK_TRY(ntt_dispatch(curve, T, Nq, log_q, true, P::GENERATOR, 1, Nq, st, 2));       // internal form in, boundary form out
         HIP_TRY(hipMemcpyAsync(d_out, T, out_len * 32, hipMemcpyDeviceToDevice, st));
     } else {
         uint32_t* buf[2] = {T, T + len * 8};
