@@ -328,10 +328,14 @@ class TurboPlonkProver:
         return quot
 
     def _split_quotient(self, quot, blind_quot):
-        """split_quotient_polynomial (prover.rs:902-960): W slices of n + 2 coefficients, masked by W - 1 scalars."""
+        """split_quotient_polynomial (prover.rs:902-960): W slices of n + 2 coefficients, masked by W - 1 scalars.  The scalars
+        travel as kernel arguments of mzk_poly_lincomb_dev (times a resident one): no host-to-device copy, hence no stream
+        synchronisation between the quotient kernels and the commitments."""
         import torch
         c, n, r, W = self.curve, self.n, self.curve.r, self.W
         dev = self.fixed.device
+        if getattr(self, "_one", None) is None:
+            self._one = torch.from_numpy(fr_to_mont(c, [1]).view(np.int64)).to(dev)
         expected = W * (n + 1) + 2                                       # quotient_polynomial_degree, prover.rs:1125-1128
         split = []
         last = 0
@@ -341,10 +345,9 @@ class TurboPlonkProver:
             p = torch.zeros((n + 3, 4), dtype=torch.int64, device=dev)
             p[:hi - lo] = quot[lo:hi]
             if i < W - 1:
-                p[n + 2] = torch.from_numpy(fr_to_mont(c, [blind_quot[i]]).view(np.int64)).to(dev)[0]
+                poly.lincomb(c, [(blind_quot[i] % r, self._one)], out=p[n + 2:n + 3])
             if last:
-                negl = torch.from_numpy(fr_to_mont(c, [(-last) % r]).view(np.int64)).to(dev)
-                poly.lincomb(c, [(1, p[:1].clone()), (1, negl)], out=p[:1])
+                poly.lincomb(c, [(1, p[:1].clone()), ((-last) % r, self._one)], out=p[:1])
             last = blind_quot[i] if i < W - 1 else 0
             split.append(p if i < W - 1 else p[:hi - lo])
         return split
