@@ -220,6 +220,12 @@ MZK_API int32_t mzk_poly_mask_dev(int32_t curve_id, uint32_t n_polys, void* cons
 /* quotient of p(X) / (X - z), len - 1 coefficients into d_out (remainder dropped, as ark-poly's `/` does at
  * prover.rs:504-506).  d_out must not alias d_poly.  Asynchronous. */
 MZK_API int32_t mzk_poly_div_linear_dev(int32_t curve_id, const void* d_poly, uint64_t len, const uint64_t* z_mont, void* d_out, void* stream);
+/* *d_out_len (a u64 in DEVICE memory) = number of coefficients up to and including the highest non-zero one, 0 for the zero
+ * polynomial: `DensePolynomial::degree` + 1 after `from_coefficients_vec` has stripped the trailing zeros.  The prover's only
+ * guard against an unsatisfied witness is `quot_poly.degree() != expected_degree => WrongQuotientPolyDegree`
+ * (plonk/src/proof_system/prover.rs:915-918).  Field-independent (an element is zero iff its 32 bytes are).  Asynchronous:
+ * read the word back (mzk_dev_download) once the stream has been synchronised anyway. */
+MZK_API int32_t mzk_poly_degree_dev(const void* d_poly, uint64_t len, uint64_t* d_out_len, void* stream);
 /* floor quotient of p(X) by the vanishing polynomial of a proof-linking domain, Z_D(X) = prod_{i < count} (X - w^(first + i))
  * with w the primitive 2^log_order-th root of unity (GroupLayout{alignment = log_order, offset = first, size = count},
  * relation/src/proof_linking/mod.rs:16-54): len - count coefficients into d_out, remainder dropped.  Replaces

@@ -554,6 +554,13 @@ int32_t mzk_poly_div_linear_dev(int32_t curve_id, const void* d_poly, uint64_t l
     return poly_div_dispatch(curve_id, reinterpret_cast<const uint32_t*>(d_poly), len, reinterpret_cast<const uint32_t*>(z_mont),
                              reinterpret_cast<uint32_t*>(d_out), (hipStream_t)stream);
 }
+int32_t mzk_poly_degree_dev(const void* d_poly, uint64_t len, uint64_t* d_out_len, void* stream) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    if ((!d_poly && len) || !d_out_len) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    if (len >= (1ull << 40)) { set_error("polynomial too long"); return MZK_ERR_INVALID_ARG; }
+    return poly_degree_dispatch(reinterpret_cast<const uint32_t*>(d_poly), len, reinterpret_cast<unsigned long long*>(d_out_len), (hipStream_t)stream);
+}
 int32_t mzk_poly_div_roots_dev(int32_t curve_id, const void* d_poly, uint64_t len, uint32_t log_order, uint64_t first, uint64_t count, void* d_out,
                                void* stream) {
     std::lock_guard<std::mutex> lk(g_lock);

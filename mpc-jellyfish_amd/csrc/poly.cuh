@@ -196,6 +196,22 @@ __global__ __launch_bounds__(POLY_THREADS) void poly_div_finish_kernel(const uin
 // p has n coefficients (an iNTT output) in a row of at least n + h + 1 slots: p[j] -= b_j, p[n + j] = b_j.
 constexpr int MASK_MAX_ROWS = 8;
 constexpr int MASK_MAX_BLIND = 4;
+// number of coefficients up to and including the highest non-zero one (0 for the zero polynomial) -> *out, which must be zero
+// on entry; one 32-byte element per thread, one atomic per workgroup that sees a non-zero element.  The prover's only guard
+// against an unsatisfied witness is the quotient's degree (prover.rs:915-918, `WrongQuotientPolyDegree`).
+static __global__ __launch_bounds__(POLY_THREADS) void poly_degree_kernel(const uint32_t* __restrict__ c, unsigned long long len, unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long best;
+    if (threadIdx.x == 0) best = 0;
+    __syncthreads();
+    const unsigned long long i = (unsigned long long)blockIdx.x * POLY_THREADS + threadIdx.x;
+    if (i < len) {
+        const uint4 a = reinterpret_cast<const uint4*>(c + i * 8)[0], b = reinterpret_cast<const uint4*>(c + i * 8)[1];
+        if (a.x | a.y | a.z | a.w | b.x | b.y | b.z | b.w) atomicMax(&best, i + 1);
+    }
+    __syncthreads();
+    if (threadIdx.x == 0 && best) atomicMax(out, best);
+}
+
 struct MaskArgs {
     uint32_t* rows[MASK_MAX_ROWS];
     unsigned long long n;

@@ -211,6 +211,13 @@ int32_t poly_lincomb_dispatch(int curve, uint32_t n_terms, const uint32_t* const
     return MZK_ERR_INVALID_ARG;
 }
 
+int32_t poly_degree_dispatch(const uint32_t* d_poly, uint64_t len, unsigned long long* d_out, hipStream_t st) {
+    HIP_TRY(hipMemsetAsync(d_out, 0, 8, st));
+    if (len) hipLaunchKernelGGL(poly_degree_kernel, dim3((unsigned)((len + POLY_THREADS - 1) / POLY_THREADS)), dim3(POLY_THREADS), 0, st, d_poly, len, d_out);
+    HIP_TRY(hipGetLastError());
+    return MZK_OK;
+}
+
 int32_t poly_mask_dispatch(int curve, uint32_t n_rows, uint32_t* const* d_rows, uint64_t n, uint32_t n_blind, const uint32_t* blind_mont, hipStream_t st) {
     if (n_rows == 0) return MZK_OK;
     if (n_rows > MASK_MAX_ROWS || n_blind == 0 || n_blind > MASK_MAX_BLIND || n_blind > n) { set_error("mask: at most 8 polynomials, 1..4 blinders each"); return MZK_ERR_INVALID_ARG; }

@@ -22,6 +22,8 @@ int run(bool ultra, uint64_t num_gates, int reps, int range_bits) {
     auto t0 = std::chrono::steady_clock::now();
     BenchCircuit<C> cs = BenchCircuit<C>::generate(num_gates, ultra, range_bits);
     const double circuit_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    if (std::getenv("MZK_PROVE_CORRUPT_WITNESS"))                       // test hook: wire 0 of row 5 takes the value of row 6 -> gate 5 no longer holds
+        check(mzk_dev_copy(cs.wire_values.at(5), cs.wire_values.at(6), EL, nullptr), "corrupt");
     ChaChaRng rng = test_rng();
     const Fr beta = fr_rand<typename C::Fr>(rng);                       // the SRS trapdoor: first draw of the bench's rng (bench.rs:50-54)
     const auto beta_c = canonical(beta);

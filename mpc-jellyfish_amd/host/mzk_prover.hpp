@@ -163,7 +163,7 @@ struct Prover {                                                        // Provin
     std::vector<Fr> k;
     uint64_t srs = 0, pk = 0;
     DevBuf fixed;                                                      // (nsel + W [+ 4]) x n coefficient forms
-    DevBuf slab, quot, keep, coeff, split, lin, batch, opening, shifted, hh, table, lookup, sorted, tmp;
+    DevBuf slab, quot, keep, coeff, split, lin, batch, opening, shifted, hh, table, lookup, sorted, tmp, deg;
     std::vector<Affine> selector_comms, sigma_comms;
     std::map<std::string, double> timings_ms;
     Fr w_n, gen;
@@ -334,6 +334,8 @@ struct Prover {                                                        // Provin
     // split_quotient_polynomial (prover.rs:902-960) of the 8n coefficients at `q` into this->split; returns the W lengths
     std::vector<uint64_t> split_quotient(const void* q, const std::vector<Fr>& b_quot) {
         const uint64_t expected = (uint64_t)W * (n + 1) + 2;                                                  // quotient_polynomial_degree
+        if (!deg.p) deg.alloc(1);
+        check(mzk_poly_degree_dev(q, m, static_cast<uint64_t*>(deg.p), nullptr), "mzk_poly_degree_dev");      // read in check_quotient_degree
         check(mzk_dev_memset(split.p, 0, (size_t)W * (n + 3) * EL, nullptr), "memset");
         std::vector<uint64_t> split_len(W);
         Fr last = Fr::zero();
@@ -351,6 +353,16 @@ struct Prover {                                                        // Provin
             split_len[i] = i < W - 1 ? n + 3 : hi - lo;
         }
         return split_len;
+    }
+    // quot_poly.degree() != expected_degree => WrongQuotientPolyDegree (prover.rs:915-918): the reference's only guard against an
+    // unsatisfied witness.  Call after commit_split (the commitments have synchronised the stream; this reads 8 bytes).
+    void check_quotient_degree() {
+        uint64_t len = 0;
+        check(mzk_dev_download(&len, deg.p, 8), "download");
+        const uint64_t expected = (uint64_t)W * (n + 1) + 2;
+        if (len != expected + 1)
+            throw std::runtime_error("WrongQuotientPolyDegree: quotient polynomial of degree " + std::to_string((long long)len - 1) + ", expected " +
+                                     std::to_string(expected) + " (the witness does not satisfy the circuit)");
     }
     std::vector<Affine> commit_split(const std::vector<uint64_t>& split_len) {
         std::vector<const void*> p;
@@ -529,6 +541,7 @@ struct Prover {                                                        // Provin
         tick.mark("r3_split");
         proof.split_quot_poly_comms = commit_split(split_len);
         tick.mark("r3_commit");
+        check_quotient_degree();
         for (auto& cm : proof.split_quot_poly_comms) tr.append_commitment("quot_poly_comms", cm);
         const Fr zeta = tr.get_and_append_challenge("zeta");
         round4(zeta, tick);
@@ -674,6 +687,7 @@ BatchProof<C> batch_prove(ChaChaRng& rng, const std::vector<Prover<C>*>& provers
     if (K > 1) { qsum.alloc(p0.m); p0.lincomb_many(qterms, qsum.p, p0.m); q = qsum.p; }
     const std::vector<uint64_t> split_len = p0.split_quotient(q, b_quot);
     proof.split_quot_poly_comms = p0.commit_split(split_len);
+    p0.check_quotient_degree();
     for (auto& cm : proof.split_quot_poly_comms) tr.append_commitment("quot_poly_comms", cm);
     const Fr zeta = tr.get_and_append_challenge("zeta");
     for (size_t i = 0; i < K; i++) {

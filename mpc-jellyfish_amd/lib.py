@@ -57,6 +57,7 @@ _SIGS = {
     "mzk_poly_lincomb_dev": [C.c_int32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p],
     "mzk_poly_mask_dev": [C.c_int32, C.c_uint32, C.POINTER(C.c_void_p), C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p],
     "mzk_poly_div_linear_dev": [C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p],
+    "mzk_poly_degree_dev": [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p],
     "mzk_poly_div_roots_dev": [C.c_int32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p],
     "mzk_dev_alloc": [C.c_uint64, C.POINTER(C.c_void_p)],
     "mzk_dev_free": [C.c_void_p],

@@ -86,6 +86,18 @@ def div_by_roots_of_unity(curve, poly_dev, log_order: int, first: int, count: in
     return out
 
 
+def degree_len_async(poly_dev, stream=None):
+    """Number of coefficients up to and including the highest non-zero one (0 for the zero polynomial), as a one-element
+    int64 CUDA tensor written asynchronously: read it (`int(t.item())`) after a point where the stream is synchronised
+    anyway.  `DensePolynomial::degree` + 1 of the stripped vector (prover.rs:915-918)."""
+    import torch
+    assert poly_dev.is_cuda and poly_dev.is_contiguous() and poly_dev.shape[-1] == 4
+    out = torch.empty((1,), dtype=torch.int64, device=poly_dev.device)
+    _lib.check(_lib.ensure_init().mzk_poly_degree_dev(poly_dev.data_ptr(), poly_dev.shape[0], out.data_ptr(), _stream(poly_dev, stream)),
+               "mzk_poly_degree_dev")
+    return out
+
+
 def mask(curve, rows, n: int, blinders, stream=None):
     """`Prover::mask_polynomial` (prover.rs:463-486) on device rows, in place: rows[i] (a CUDA tensor view of at least
     n + h slots holding n coefficients) += (b_0 + b_1 X + .. )(X^n - 1) with blinders[i] = [b_0, .., b_{h-1}] (Python ints)."""

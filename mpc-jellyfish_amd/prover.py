@@ -28,6 +28,14 @@ from .domain import Radix2EvaluationDomain
 from .params import CurveParams, curve as _curve, fr_to_mont
 
 
+class PlonkError(Exception):
+    """plonk/src/errors.rs `PlonkError`; `kind` names the variant."""
+
+    def __init__(self, kind: str, msg: str):
+        super().__init__("%s: %s" % (kind, msg))
+        self.kind = kind
+
+
 @dataclass
 class Blinders:
     """DensePolynomial::rand draws, in the reference's order (SURVEY.md Appendix C): W x 2 for the wires,
@@ -320,12 +328,24 @@ class TurboPlonkProver:
             local = plonk.compute_quotient_chunked_dev(self.pk, ch, slab, n + 3)
             every = self.quotient_gather(local) if self.quotient_gather is not None else local
             plonk.combine_quotient_classes(c, n, every.contiguous(), out_dev=quot)
+        # quot_poly.degree() != expected_degree => WrongQuotientPolyDegree (prover.rs:915-918): the reference's only guard against an
+        # unsatisfied witness (batch_prove_internal never runs check_circuit_satisfiability).  The length is computed on the
+        # device now and read in check_quotient_degree, after the round's commitments have synchronised the stream anyway.
+        st.quot_len = poly.degree_len_async(quot)
         tick("r3_quotient", t0)
         st.wire_polys = [keep[i, :n + 2] for i in range(self.W)]
         st.z_poly = keep[st.Z]
         if self.ultra:
             st.h1, st.h2, st.pl_poly = keep[st.H1], keep[st.H1 + 1], keep[st.PL]
         return quot
+
+    def check_quotient_degree(self, quot_len, num_instances: int = 1):
+        """prover.rs:915-918 on the length produced by poly.degree_len_async (one 8-byte read; call it after a synchronising step)."""
+        got = int(quot_len.item()) - 1
+        expected = self.W * (self.n + 1) + 2
+        if got != expected:
+            raise PlonkError("WrongQuotientPolyDegree", "quotient polynomial of degree %d, expected %d (the witness does not satisfy the circuit)"
+                             % (got, expected))
 
     def _split_quotient(self, quot, blind_quot):
         """split_quotient_polynomial (prover.rs:902-960): W slices of n + 2 coefficients, masked by W - 1 scalars.  The scalars
@@ -493,6 +513,7 @@ class TurboPlonkProver:
         t0 = time.perf_counter()
         split_comms = self._commit(split)
         tick("r3_commit", t0)
+        self.check_quotient_degree(st.quot_len)
         # ---- round 4 (prover.rs:216-299)
         t0 = time.perf_counter()
         zeta = src.after_round3(split_comms)

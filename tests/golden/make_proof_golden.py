@@ -2,10 +2,13 @@
 
 Whole proofs of the reference's bench circuit (plonk/benches/bench.rs:29-46) by the big-int restatements alone
 (oracle/pyref_circuit.py builds the circuit, oracle/pyref_snark.py proves it with schoolbook polynomial arithmetic), with the
-reference's deterministic randomness: `test_rng` (ChaCha12, zero seed) draws the SRS trapdoor first and then the blinders in
-the prover's order (mpc-jellyfish_amd/rng.py, pure Python, pinned by the ChaCha KATs of tests/test_transcript.py).
-The reference holds no proof vector and cannot be built here, so these are restatement vectors: the CPU suite checks that the
-restated verifier accepts them (pairing form), the GPU suite that the device prover emits exactly these bytes.
+reference's deterministic randomness: `test_rng` (ChaCha12, fixed seed) draws the SRS trapdoor first and then the blinders in
+the prover's order.  Everything used here lives under oracle/ -- circuit, prover, ChaCha `test_rng` / `Fr::rand` /
+`compute_coset_representatives` (oracle/pyref_rng.py), Merlin transcript and ark-serialize encoders (oracle/pyref_fs.py), each
+written from the crates' published definitions: NOTHING is imported from the product package, so "the device prover emits
+these bytes" (tests/test_golden_proofs_gpu.py) checks the product's transcript, rng and serialisation against a second text.
+The reference holds no proof vector and cannot be built here, so these are restatement vectors (integration/rust/ holds the
+Rust program that prints the reference's own bytes for the same inputs; tests/golden/ref_*.json, when present, are compared too).
 
     python tests/golden/make_proof_golden.py
 """
@@ -16,35 +19,34 @@ import sys
 HERE = os.path.dirname(os.path.abspath(__file__))
 ROOT = os.path.join(HERE, "..", "..")
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
-sys.path.insert(0, ROOT)
 import pyref as P  # noqa: E402
 import pyref_circuit as PC  # noqa: E402
 import pyref_snark as PS  # noqa: E402
-import mpc_jellyfish_amd as mj  # noqa: E402  (params / rng / transcript: pure Python, no GPU)
+import pyref_fs as FS  # noqa: E402
+import pyref_rng as RNG  # noqa: E402
 
 CASES = [(0, "TurboPlonk", 20, 8), (1, "TurboPlonk", 20, 8), (1, "UltraPlonk", 20, 3), (0, "UltraPlonk", 24, 4)]
 
 
 def build(curve_id, plonk_type, num_gates, range_bits, rng=None, want_core=False):
-    c, pc = mj.params.CURVES[curve_id], P.CURVES[curve_id]
+    pc = P.CURVES[curve_id]
     ultra = plonk_type == "UltraPlonk"
     W = 6 if ultra else 5
     # k depends on the domain size: build once to learn n, then with the real representatives
     n = PC.bench_circuit(pc, num_gates, ultra, range_bits, list(range(1, W + 1)))[0]
-    k = mj.rng.compute_coset_representatives(c, W, n)
+    k = RNG.compute_coset_representatives(pc, W, n)
     n, wires, witness, sel, sigma, tables = PC.bench_circuit(pc, num_gates, ultra, range_bits, k)
     if rng is None:
-        rng = mj.rng.test_rng()
-        srs_beta = mj.rng.fr_rand(c, rng)
+        rng = RNG.test_rng()
+        srs_beta = RNG.fr_rand(pc, rng)
     else:                                                                 # a later proof on the same stream: the trapdoor was its first draw
-        first = mj.rng.test_rng()
-        srs_beta = mj.rng.fr_rand(c, first)
-    bl = mj.snark.draw_blinders(c, rng, W, ultra)
-    blind = {"wires": bl.wires, "z": bl.z, "quot": bl.quot, "h": bl.h, "prod_lookup": bl.prod_lookup}
+        first = RNG.test_rng()
+        srs_beta = RNG.fr_rand(pc, first)
+    blind = RNG.draw_blinders(pc, rng, W, ultra)
     w_vals = [[witness[v] for v in wires[i]] for i in range(W)]
-    g1 = lambda p: mj.transcript.g1_bytes(c, p)
-    fr = lambda x: mj.transcript.fr_bytes(c, x)
-    out = PS.prove(pc, n.bit_length() - 1, sel, sigma, k, w_vals, [0] * n, [], blind, srs_beta, mj.transcript.StandardTranscript(c, b"PlonkProof"),
+    g1 = lambda p: FS.g1_bytes(pc, p)
+    fr = lambda x: FS.fr_bytes(pc, x)
+    out = PS.prove(pc, n.bit_length() - 1, sel, sigma, k, w_vals, [0] * n, [], blind, srs_beta, FS.StandardTranscript(pc, b"PlonkProof"),
                    g1, fr, plookup=tables)
     vk = out["vk"]
     rec = {"curve": curve_id, "plonk_type": plonk_type, "num_gates": num_gates, "range_bit_len": range_bits, "domain_size": n,
@@ -61,24 +63,24 @@ BATCH_CASES = [(0, "TurboPlonk", (25, 28, 31), 8), (1, "UltraPlonk", (36, 40), 4
 
 def build_batch(curve_id, plonk_type, gates, range_bits):
     """PlonkKzgSnark::batch_prove over bench circuits of one domain size, `test_rng` draws in batch_prove_internal's order
-    (snark.draw_batch_blinders), by the restatements (oracle/pyref_snark.py::batch_prove)."""
-    c, pc = mj.params.CURVES[curve_id], P.CURVES[curve_id]
+    (oracle/pyref_rng.py::draw_batch_blinders), by the restatements (oracle/pyref_snark.py::batch_prove)."""
+    pc = P.CURVES[curve_id]
     ultra = plonk_type == "UltraPlonk"
     W = 6 if ultra else 5
     n = PC.bench_circuit(pc, gates[0], ultra, range_bits, list(range(1, W + 1)))[0]
-    k = mj.rng.compute_coset_representatives(c, W, n)
-    rng = mj.rng.test_rng()
-    srs_beta = mj.rng.fr_rand(c, rng)
-    blinds, quot = mj.snark.draw_batch_blinders(c, rng, W, [ultra] * len(gates))
+    k = RNG.compute_coset_representatives(pc, W, n)
+    rng = RNG.test_rng()
+    srs_beta = RNG.fr_rand(pc, rng)
+    blinds, quot = RNG.draw_batch_blinders(pc, rng, W, [ultra] * len(gates))
     instances = []
     for g, bl in zip(gates, blinds):
         n_g, wires, witness, sel, sigma, tables = PC.bench_circuit(pc, g, ultra, range_bits, k)
         assert n_g == n
         instances.append({"selector_vals": sel, "sigma_vals": sigma, "k": k, "wire_vals": [[witness[v] for v in wires[i]] for i in range(W)],
-                          "pi_vals": [0] * n, "blind": {"wires": bl.wires, "z": bl.z, "h": bl.h, "prod_lookup": bl.prod_lookup}, "plookup": tables})
-    g1 = lambda p: mj.transcript.g1_bytes(c, p)
-    out = PS.batch_prove(pc, n.bit_length() - 1, instances, [[] for _ in gates], quot, srs_beta, mj.transcript.StandardTranscript(c, b"PlonkProof"),
-                         g1, lambda x: mj.transcript.fr_bytes(c, x))
+                          "pi_vals": [0] * n, "blind": bl, "plookup": tables})
+    g1 = lambda p: FS.g1_bytes(pc, p)
+    out = PS.batch_prove(pc, n.bit_length() - 1, instances, [[] for _ in gates], quot, srs_beta, FS.StandardTranscript(pc, b"PlonkProof"),
+                         g1, lambda x: FS.fr_bytes(pc, x))
     return {"curve": curve_id, "plonk_type": plonk_type, "gates": list(gates), "range_bit_len": range_bits, "domain_size": n, "srs_beta": "%x" % srs_beta,
             "challenges": {name: "%x" % v for name, v in out["challenges"].items()}, "batch_proof": out["proof"].hex()}
 
@@ -91,16 +93,16 @@ def build_link(curve_id, gates, layout_args):
     PlonkKzgSnark::link_proofs over the given GroupLayout (wire 0 of the bench circuit holds the running sums 0, 1, 2, ..:
     rows below both gate counts carry the same witnesses), all by the restatements (oracle/pyref_linking.py)."""
     import pyref_linking as L
-    c, pc = mj.params.CURVES[curve_id], P.CURVES[curve_id]
-    rng = mj.rng.test_rng()
-    srs_beta = mj.rng.fr_rand(c, rng)
+    pc = P.CURVES[curve_id]
+    rng = RNG.test_rng()
+    srs_beta = RNG.fr_rand(pc, rng)
     recs, cores = zip(*[build(curve_id, "TurboPlonk", g, 8, rng=rng, want_core=True) for g in gates])
     assert recs[0]["domain_size"] == recs[1]["domain_size"]
     G = P.g1_gen(pc)
     a = [core["core"]["wire_polys"][0] for core in cores]
     comms = [P.g1_mul(pc, core["core"]["commit_dlogs"]["wires"][0], G) for core in cores]
-    lp = L.link_proofs(pc, a[0], a[1], comms[0], comms[1], L.GroupLayout(*layout_args), srs_beta, mj.transcript.StandardTranscript(c, b"PlonkLinkingProof"))
-    g1 = lambda p: mj.transcript.g1_bytes(c, p)
+    lp = L.link_proofs(pc, a[0], a[1], comms[0], comms[1], L.GroupLayout(*layout_args), srs_beta, FS.StandardTranscript(pc, b"PlonkLinkingProof"))
+    g1 = lambda p: FS.g1_bytes(pc, p)
     return {"curve": curve_id, "gates": list(gates), "layout": list(layout_args), "srs_beta": "%x" % srs_beta, "proofs": [r["proof"] for r in recs],
             "eta": "%x" % lp["eta"], "link_proof": L.serialize_link_proof(g1, lp["quotient_commitment"], lp["opening_proof"]).hex()}
 

@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import affine_from_limbs, build_circuit, build_ultra_circuit, fr_mont_limbs, verifying_key
+import pyref_fs as FS
 
 pytestmark = pytest.mark.gpu
 TABLES = ("range", "key", "table_dom_sep", "q_dom_sep")
@@ -31,7 +32,7 @@ def test_batch_prove_bench_circuits_verifies(gpu, mj, pyref, curve_id, plonk_typ
     vks = [verifying_key(mj, pc, pk, 0) for pk in pks]
     pubs = [[] for _ in gates]
     G = pyref.g1_gen(pc)
-    fresh = lambda: mj.transcript.StandardTranscript(c, b"PlonkProof")
+    fresh = lambda: FS.StandardTranscript(pc, b"PlonkProof")
     assert V.verify_batch_proof(pc, fresh(), vks, pubs, blob, G, srs_beta)
     assert V.verify_batch_proof(pc, fresh(), vks, pubs, blob, None, None, open_key=V.open_key_for_testing(pc, srs_beta)), "pairing form"
     # the verifier re-derives the prover's challenges
@@ -127,7 +128,7 @@ def test_batch_prove_matches_the_restated_batch_prover(gpu, mj, pyref, curve_id,
     # ... and the serialized aggregate verifies under the three keys and public inputs
     blob = mj.batch.serialize_batch_proof(c, core)
     vks = [verifying_key(mj, pc, p, 4) for p in provers]
-    fresh = lambda: mj.transcript.StandardTranscript(c, b"PlonkProof")
+    fresh = lambda: FS.StandardTranscript(pc, b"PlonkProof")
     assert V.verify_batch_proof(pc, fresh(), vks, pubs, blob, G, srs_beta, extra_msg=b"batch")
     assert not V.verify_batch_proof(pc, fresh(), vks, pubs, blob, G, srs_beta)
     other = [pubs[0], pubs[1][:3] + [(pubs[1][3] + 1) % r], pubs[2]]

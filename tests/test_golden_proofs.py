@@ -8,6 +8,8 @@ import os
 import pytest
 
 from conftest import load_golden
+import pyref_fs as FS
+import pyref_rng as RNG
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 
@@ -39,7 +41,7 @@ def test_golden_proof_vectors(pyref, mj, index):
     vk = golden_vk(V, pc, vec)
     proof = bytes.fromhex(vec["proof"])
     srs_beta = int(vec["srs_beta"], 16)
-    fresh = lambda: mj.transcript.StandardTranscript(c, b"PlonkProof")
+    fresh = lambda: FS.StandardTranscript(pc, b"PlonkProof")
     assert V.verify(pc, fresh(), vk, [], proof, None, None, open_key=V.open_key_for_testing(pc, srs_beta))
     ch = V.compute_challenges(fresh(), vk, [], V.deserialize_proof(pc, proof))
     assert {name: "%x" % ch[name] for name in vec["challenges"]} == vec["challenges"]
@@ -63,7 +65,7 @@ def test_golden_link_vectors(pyref, mj, index):
     blob = bytes.fromhex(vec["link_proof"])
     half = len(blob) // 2
     q, o = V.g1_decompress(pc, blob[:half]), V.g1_decompress(pc, blob[half:])
-    fresh = lambda: mj.transcript.StandardTranscript(c, b"PlonkLinkingProof")
+    fresh = lambda: FS.StandardTranscript(pc, b"PlonkLinkingProof")
     layout = L.GroupLayout(*vec["layout"])
     open_key = V.open_key_for_testing(pc, srs_beta)
     assert L.verify_link_proof(pc, fresh(), wire0[0], wire0[1], q, o, layout, None, open_key=open_key)
@@ -87,7 +89,7 @@ def test_golden_batch_vectors(pyref, mj, index):
     W = 6 if ultra else 5
     n = vec["domain_size"]
     srs_beta = int(vec["srs_beta"], 16)
-    k = mj.rng.compute_coset_representatives(c, W, n)
+    k = RNG.compute_coset_representatives(pc, W, n)
     G = pyref.g1_gen(pc)
     log_n = n.bit_length() - 1
     def commit_vals(vals):
@@ -104,6 +106,6 @@ def test_golden_batch_vectors(pyref, mj, index):
         vks.append(vk)
     pubs = [[] for _ in vec["gates"]]
     blob = bytes.fromhex(vec["batch_proof"])
-    fresh = lambda: mj.transcript.StandardTranscript(c, b"PlonkProof")
+    fresh = lambda: FS.StandardTranscript(pc, b"PlonkProof")
     assert V.verify_batch_proof(pc, fresh(), vks, pubs, blob, None, None, open_key=V.open_key_for_testing(pc, srs_beta))
     assert not V.verify_batch_proof(pc, fresh(), vks[::-1], pubs, blob, G, srs_beta)

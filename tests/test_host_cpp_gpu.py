@@ -5,6 +5,7 @@ import os
 import subprocess
 
 import pytest
+import pyref_fs as FS
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -61,7 +62,7 @@ def test_cpp_host_link_proofs_matches_python_mirror(gpu, mj, pyref, curve_id, ga
     blob = bytes.fromhex(got["link_proof_hex"])
     g1_len = len(blob) // 2
     q, o = V.g1_decompress(pc, blob[:g1_len]), V.g1_decompress(pc, blob[g1_len:])
-    fresh = lambda: mj.transcript.StandardTranscript(c, b"PlonkLinkingProof")
+    fresh = lambda: FS.StandardTranscript(pc, b"PlonkLinkingProof")
     assert L.verify_link_proof(pc, fresh(), pr1["wires_poly_comms"][0], pr2["wires_poly_comms"][0], q, o, L.GroupLayout(*layout_args), srs_beta)
     al, off, size = layout_args
     assert not L.verify_link_proof(pc, fresh(), pr1["wires_poly_comms"][0], pr2["wires_poly_comms"][0], q, o, L.GroupLayout(al, off + 1, size), srs_beta)
@@ -111,3 +112,34 @@ def test_cpp_host_batch_prove_matches_python_mirror(gpu, mj, curve_id, plonk_typ
     for pk in pks:
         pk.release()
     ck.release()
+
+
+def test_unsatisfied_witness_is_rejected_by_both_hosts(gpu, mj):
+    """`quot_poly.degree() != expected_degree => WrongQuotientPolyDegree` (prover.rs:915-918) is the reference's only guard against a
+    witness that does not satisfy the circuit (batch_prove_internal never calls check_circuit_satisfiability): with one wire value
+    changed, the Python mirror raises PlonkError, `batch_prove` too, and the compiled host exits non-zero -- no proof bytes."""
+    import torch
+    c = mj.params.BLS12_381
+    cs = mj.snark.gen_circuit_for_bench(c, 64, "TurboPlonk")
+    rng = mj.rng.test_rng()
+    ck = mj.UnivariateProverParam.gen_srs_for_testing(c, mj.rng.fr_rand(c, rng), cs.n + 2)
+    pk = mj.snark.preprocess(ck, cs)
+    mj.snark.prove(rng, cs, pk)                                                        # the honest witness proves
+    good = cs.wire_values
+    bad = good.clone() if hasattr(good, "clone") else torch.from_numpy(good.copy())
+    bad[0, 5] = bad[0, 6]                                                              # gate 5: a + 1 = out no longer holds
+    cs.wire_values = bad
+    with pytest.raises(mj.prover.PlonkError) as e:
+        mj.snark.prove(rng, cs, pk)
+    assert e.value.kind == "WrongQuotientPolyDegree"
+    pk2 = mj.snark.preprocess(ck, cs)
+    with pytest.raises(mj.prover.PlonkError):
+        mj.snark.batch_prove(rng, [cs, cs], [pk, pk2])
+    cs.wire_values = good
+    mj.snark.prove(rng, cs, pk)                                                        # and the prover is still usable afterwards
+    for p in (pk, pk2):
+        p.release()
+    ck.release()
+    env = dict(os.environ, MZK_PROVE_CORRUPT_WITNESS="1")
+    out = subprocess.run([BIN, "0", "turbo", "64", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 1 and "WrongQuotientPolyDegree" in out.stderr and "proof_hex" not in out.stdout

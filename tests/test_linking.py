@@ -6,6 +6,7 @@ import random
 import pytest
 
 from conftest import build_circuit
+import pyref_fs as FS
 
 
 def two_linked_proofs(pyref, curve_id, layout, seed, log_n1=4, log_n2=5, tamper=None):
@@ -48,7 +49,7 @@ def test_link_proof_restatement_accepts_and_rejects(pyref, mj, curve_id):
     layout = L.GroupLayout(3, 2, 5)                                       # 5 of the 8th roots of unity, from the third one on
     c, (a1, a2), (c1, c2), srs_beta = two_linked_proofs(pyref, curve_id, layout, 99 + curve_id)
     pc = mj.params.CURVES[curve_id]
-    fresh = lambda: mj.transcript.StandardTranscript(pc, b"PlonkLinkingProof")
+    fresh = lambda: FS.StandardTranscript(c, b"PlonkLinkingProof")
     lp = L.link_proofs(c, a1, a2, c1, c2, layout, srs_beta, fresh())
     assert len(a1) == 16 + 2 and len(a2) == 32 + 2 and len(lp["quotient"]) == len(a2) - layout.size
     # the dropped remainder is zero, i.e. the wire polynomials agree on the link domain
@@ -87,7 +88,7 @@ def test_link_proof_restatement_accepts_and_rejects(pyref, mj, curve_id):
     assert not L.verify_link_proof(c, fresh(), c1, c2, lp["quotient_commitment"], lp["opening_proof"], L.GroupLayout(3, 3, 5), None, open_key=open_key)
     assert not L.verify_link_proof(c, fresh(), c1, c2, bad["quotient_commitment"], bad["opening_proof"], bad_layout, None, open_key=open_key)
     # serialized LinkingProof: two compressed G1 points
-    g1 = lambda p: mj.transcript.g1_bytes(pc, p)
+    g1 = lambda p: FS.g1_bytes(c, p)
     blob = L.serialize_link_proof(g1, lp["quotient_commitment"], lp["opening_proof"])
     assert len(blob) == 2 * (48 if curve_id == 0 else 32)
 
@@ -98,7 +99,7 @@ def test_link_proof_with_different_witnesses_is_rejected(pyref, mj):
     layout = L.GroupLayout(3, 2, 5)
     c, (a1, a2), (c1, c2), srs_beta = two_linked_proofs(pyref, 1, layout, 123, tamper=4)
     pc = mj.params.CURVES[1]
-    fresh = lambda: mj.transcript.StandardTranscript(pc, b"PlonkLinkingProof")
+    fresh = lambda: FS.StandardTranscript(c, b"PlonkLinkingProof")
     lp = L.link_proofs(c, a1, a2, c1, c2, layout, srs_beta, fresh())
     assert not L.verify_link_proof(c, fresh(), c1, c2, lp["quotient_commitment"], lp["opening_proof"], layout, srs_beta)
     # ... while the first four values alone still link

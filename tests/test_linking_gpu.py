@@ -7,6 +7,7 @@ import numpy as np
 import pytest
 
 from conftest import affine_from_limbs, build_circuit, fr_from_mont_limbs, fr_mont_limbs, verifying_key
+import pyref_fs as FS
 
 pytestmark = pytest.mark.gpu
 
@@ -50,7 +51,7 @@ def test_link_two_device_proofs(gpu, mj, pyref, curve_id, log_n1, log_n2, layout
     for log_n in (log_n1, log_n2):
         proof_bytes, pub, hint, prover = _prove_linked(mj, pyref, curve_id, log_n, layout, shared, rng, srs_beta, ck)
         vk = verifying_key(mj, pc, prover, len(pub))
-        assert V.verify(pc, mj.transcript.StandardTranscript(c, b"PlonkProof"), vk, pub, proof_bytes, G, srs_beta), "the linked circuit's own proof"
+        assert V.verify(pc, FS.StandardTranscript(pc, b"PlonkProof"), vk, pub, proof_bytes, G, srs_beta), "the linked circuit's own proof"
         proofs.append((V.deserialize_proof(pc, proof_bytes), hint))
         prover.release()
     (pr1, h1), (pr2, h2) = proofs
@@ -58,13 +59,13 @@ def test_link_two_device_proofs(gpu, mj, pyref, curve_id, log_n1, log_n2, layout
     # the restatement on the downloaded polynomials
     ints = lambda t: fr_from_mont_limbs(c, t.cpu().numpy().view(np.uint64).reshape(-1, 4))
     a1, a2 = ints(h1.linking_wire_poly), ints(h2.linking_wire_poly)
-    fresh = lambda: mj.transcript.StandardTranscript(c, b"PlonkLinkingProof")
+    fresh = lambda: FS.StandardTranscript(pc, b"PlonkLinkingProof")
     a1c, a2c = pr1["wires_poly_comms"][0], pr2["wires_poly_comms"][0]
     assert a1c == _pt(pc, h1.linking_wire_comm) and a2c == _pt(pc, h2.linking_wire_comm)
     want = L.link_proofs(pc, a1, a2, a1c, a2c, olayout, srs_beta, fresh())
     assert _pt(pc, link.quotient_commitment) == want["quotient_commitment"]
     assert _pt(pc, link.opening_proof) == want["opening_proof"]
-    assert link.serialize_compressed() == L.serialize_link_proof(lambda p: mj.transcript.g1_bytes(c, p), want["quotient_commitment"], want["opening_proof"])
+    assert link.serialize_compressed() == L.serialize_link_proof(lambda p: FS.g1_bytes(pc, p), want["quotient_commitment"], want["opening_proof"])
     # the verifier's side: commitments out of the two serialized Plonk proofs (proof_linking.rs:240-271)
     accept = lambda lp, lay=olayout: L.verify_link_proof(pc, fresh(), a1c, a2c, _pt(pc, lp.quotient_commitment), _pt(pc, lp.opening_proof), lay, srs_beta)
     assert accept(link)
@@ -106,7 +107,7 @@ def test_link_proofs_with_different_witnesses_rejected(gpu, mj, pyref):
     other[7] = (other[7] + 1) % c.r
     _, _, h2, p2 = _prove_linked(mj, pyref, 1, 7, layout, other, rng, srs_beta, ck)
     link = mj.linking.link_proofs(h1, h2, layout, ck)
-    fresh = lambda: mj.transcript.StandardTranscript(c, b"PlonkLinkingProof")
+    fresh = lambda: FS.StandardTranscript(pc, b"PlonkLinkingProof")
     args = (_pt(pc, h1.linking_wire_comm), _pt(pc, h2.linking_wire_comm), _pt(pc, link.quotient_commitment), _pt(pc, link.opening_proof))
     assert not L.verify_link_proof(pc, fresh(), *args, L.GroupLayout(4, 2, 9), srs_beta)
     sub = mj.linking.link_proofs(h1, h2, mj.linking.GroupLayout(4, 2, 7), ck)                  # the first seven values alone do link
@@ -150,7 +151,7 @@ def test_link_large_polynomials(gpu, mj, pyref, curve_id, log_n, layout_args):
     assert quotient.shape[0] == n + 2 - size
     x = rng.randrange(r)
     assert mj.poly.evaluate(c, quotient, x)[0] * L.vanishing_eval(pc, olayout, x) % r == mj.poly.evaluate(c, diff, x)[0]
-    fresh = lambda: mj.transcript.StandardTranscript(c, b"PlonkLinkingProof")
+    fresh = lambda: FS.StandardTranscript(pc, b"PlonkLinkingProof")
     args = (_pt(pc, h1.linking_wire_comm), _pt(pc, h2.linking_wire_comm), _pt(pc, link.quotient_commitment), _pt(pc, link.opening_proof))
     assert L.verify_link_proof(pc, fresh(), *args, olayout, srs_beta)
     assert L.verify_link_proof(pc, fresh(), *args, olayout, None, open_key=V.open_key_for_testing(pc, srs_beta))

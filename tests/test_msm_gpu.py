@@ -320,8 +320,10 @@ def test_error_paths(gpu, mj):
     assert L.mzk_ntt(1, sc.ctypes.data_as(C.c_void_p), 4, 29, 0, None) == -1                                         # beyond BN254's two-adicity
     assert L.mzk_plonk_pk_release(12345) == -4
     assert L.mzk_strerror(-8).startswith(b"Plookup")
+    released = pp.handle
     pp.release()
-    assert L.mzk_srs_release(pp.handle or 999999) != 0 or True
+    assert L.mzk_srs_release(released) == -4, "releasing a handle twice is an error, not a crash"              # MZK_ERR_BAD_HANDLE
+    assert L.mzk_msm(released, 0, sc.ctypes.data_as(C.c_void_p), 4, 0, out.ctypes.data_as(C.c_void_p)) == -4        # and so is using it
 
 
 @pytest.mark.parametrize("curve_id", [0, 1])

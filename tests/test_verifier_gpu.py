@@ -9,6 +9,7 @@ import numpy as np
 import pytest
 
 from conftest import build_circuit, build_ultra_circuit, fr_mont_limbs, verifying_key
+import pyref_fs as FS
 
 pytestmark = pytest.mark.gpu
 
@@ -39,7 +40,7 @@ def test_bench_circuit_proof_verifies(gpu, mj, pyref, curve_id, plonk_type, num_
     G = pyref.g1_gen(pc)
     for extra in (None, b"extra message"):
         _, proof_bytes = mj.snark.prove(rng, cs, pk, extra_transcript_init_msg=extra)
-        fresh = lambda: mj.transcript.StandardTranscript(c, b"PlonkProof")
+        fresh = lambda: FS.StandardTranscript(pc, b"PlonkProof")
         assert V.verify(pc, fresh(), vk, [], proof_bytes, G, srs_beta, extra_msg=extra)
         assert not V.verify(pc, fresh(), vk, [], proof_bytes, G, srs_beta, extra_msg=b"another message")
     # the final step as the reference evaluates it: the product of two pairings over the OpenKey, no trapdoor (verifier.rs:226-250)
@@ -89,7 +90,7 @@ def test_proof_with_public_input_and_copy_constraints_verifies(gpu, mj, pyref, c
     proof_bytes = mj.snark.serialize_proof(c, core)
     vk = verifying_key(mj, pc, prover, len(pub))
     G = pyref.g1_gen(pc)
-    fresh = lambda: mj.transcript.StandardTranscript(c, b"PlonkProof")
+    fresh = lambda: FS.StandardTranscript(pc, b"PlonkProof")
     assert V.verify(pc, fresh(), vk, pub, proof_bytes, G, srs_beta)
     # the verifier's transcript reproduces the prover's challenges (and draws u after the opening proofs)
     pr = V.deserialize_proof(pc, proof_bytes)
