@@ -1,13 +1,20 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the jf-plonk hot path on MI355X.
 
-Workload (BASELINE.json configs[1], "Standalone MSM"): 2^20 G1 points x Fr scalars on BLS12-381,
-SRS and scalars resident in HBM when the timed region starts; one step = one MSM of 2^20 pairs
-per GPU through the C ABI (mzk_msm_dev).  With N > 1 ranks the N*2^20 pairs are sharded by point
-range (one shard per GPU, weak scaling) and each step ends with the all-gather + local EC sum of
-the N partial points (mpc-jellyfish_amd/sharding.py).  Alongside, untimed by `value`, the same
-process measures BASELINE.json configs[2] (NTT 2^22 forward + inverse) and reports it under
-"ntt".
+Workload (BASELINE.json configs[1], "Standalone MSM"): 2^20 G1 points x Fr scalars on BLS12-381, SRS and scalars resident in
+HBM when the timed region starts; one step = one MSM of 2^20 pairs per GPU through the C ABI (mzk_msm_dev).  With N > 1 ranks
+the N*2^20 pairs are sharded by point range (one shard per GPU, weak scaling) and each step ends with the all-gather + local EC
+sum of the N partial points (mpc-jellyfish_amd/sharding.py).
+
+The headline runs on the library's default path for a registered SRS: a FIXED-BASE table of precomputed multiples (KZG commit
+keys never change).  `config.precompute` states what that table costs (levels, bytes of HBM, build time -- paid once per SRS,
+outside the timed region) and `variable_base` repeats the same steps with the table switched off, which is the like-for-like
+figure against ark-ec's VariableBaseMSM (and against `cpu_baseline`, which has no table either).
+
+Alongside, untimed by `value`: NTT 2^22 (configs[2]), round 3, batch commit, PlonkKzgSnark::prove on the reference's bench
+circuit (configs[3]; 10 timed repetitions as plonk/benches/bench.rs:25), the same proof in shim-only mode (host pointers,
+INTEGRATION.md section 2), UltraPlonk/BN254, the C++ host, and the CPU restatement on the host cores -- including ONE CPU proof
+of the same 2^20-gate circuit, so that the line itself carries the GPU/CPU ratio the north star is quoted on.
 
     python bench.py [--gpus N --steps K --warmup W] [--log-n 20] [--no-cpu-baseline]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
@@ -15,27 +22,39 @@ process measures BASELINE.json configs[2] (NTT 2^22 forward + inverse) and repor
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import hashlib
 import json
 import os
 import sys
+import threading
 import time
 
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import srchash  # noqa: E402  (tools/srchash.py: hash of the kernel sources a PMC pass was collected on)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")
+VOP3_NS = 1.9                  # measured cost of one VOP3 wave-instruction per SIMD (profiles/r01_valu_ubench2.txt); 1024 SIMDs
 
 
-def _profile_value(key):
-    """HBM bytes per launch from the committed PMC passes (profiles/r01_msm_traffic.json, collected
-    with tools/pmc_passes.sh: PMC counters cannot be read inside the timed run)."""
-    tp = os.path.join(ROOT, "profiles", "r01_msm_traffic.json")
+def _pmc(key, sources):
+    """(value, note) of one figure of the committed PMC passes (profiles/r02_traffic.json, written by tools/pmc_passes.sh +
+    tools/pmc_aggregate.py: PMC counters cannot be read inside the timed run).  The file carries the hash of the kernel sources
+    it was collected on; when those sources have changed since, the stale number is NOT quoted: None and a note saying so."""
     try:
-        return json.load(open(tp)).get(key)
+        d = json.load(open(TRAFFIC_JSON))
     except Exception:
-        return None
+        return None, "no committed PMC pass (profiles/r02_traffic.json missing)"
+    name = "msm" if sources is srchash.MSM_SOURCES else "ntt"
+    want = (d.get("source_sha16") or {}).get(name)
+    have = srchash.sha16(sources)
+    if want != have:
+        return None, "PMC pass is stale: collected on %s sources %s, the tree has %s (re-run tools/pmc_passes.sh)" % (name, want, have)
+    return d.get(key), "%s, collected on %s sources %s" % (os.path.basename(TRAFFIC_JSON), name, have)
 
 
 def main():
@@ -46,13 +65,18 @@ def main():
     ap.add_argument("--log-n", type=int, default=20, help="log2 of the MSM size per GPU (default 2^20 = config C2)")
     ap.add_argument("--ntt-log-n", type=int, default=22, help="log2 of the NTT size for the secondary measurement")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-prove-log-n", type=int, default=16, help="log2 gates of the CPU-vs-device whole-proof comparison (0 disables; ~5 s of CPU at 16)")
+    ap.add_argument("--cpu-prove-log-n", type=int, default=20, help="log2 gates of the CPU-vs-device whole-proof comparison (0 disables; "
+                    "~60-70 s of CPU on 16 threads at 20 = the north star's configuration, ~4 s at 16)")
     ap.add_argument("--no-ntt", action="store_true")
-    ap.add_argument("--no-plonk", action="store_true", help="skip the TurboPlonk round-3 (quotient) measurement")
+    ap.add_argument("--no-plonk", action="store_true", help="skip the proof-level legs (round 3, prove, drop-in, UltraPlonk, C++ host)")
+    ap.add_argument("--no-variable-base", action="store_true", help="skip the table-off repetition of the headline steps")
     ap.add_argument("--plonk-log-n", type=int, default=20)
+    ap.add_argument("--prove-reps", type=int, default=10, help="timed repetitions of PlonkKzgSnark::prove (plonk/benches/bench.rs:25 uses 10)")
     ap.add_argument("--ultra-log-n", type=int, default=20, help="UltraPlonk/BN254 prove leg (0 disables; config C5 is 22)")
+    ap.add_argument("--no-dropin", action="store_true", help="skip the shim-only (host-pointer) leg")
+    ap.add_argument("--link-batch", action="store_true", help="also time link_proofs / batch_prove (outside SURVEY.md section 8; off by default)")
     ap.add_argument("--secondary-timeout", type=int, default=420, help="N > 1: seconds after which a stalled secondary (sharded prove) section "
-                    "is abandoned and the headline line printed as it stands (0 disables)")
+                    "is abandoned, the headline line printed as it stands and the process ended with a non-zero code (0 disables)")
     ap.add_argument("--ultra-sharded-log-n", type=int, default=22, help="N > 1: UltraPlonk/BN254 sharded prove leg (config C5: 22; 0 disables)")
     args = ap.parse_args()
 
@@ -82,6 +106,7 @@ def main():
 
     import mpc_jellyfish_amd as mj
     from importlib import import_module
+    import ctypes as C
     mlib = import_module("mpc-jellyfish_amd.lib")
     L = mlib.init(local_rank)
     coll_dev = dev if backend == "nccl" else None
@@ -99,6 +124,15 @@ def main():
     scalars = mj.params.random_fr_mont(curve, n, seed=0x6d7a6b5f + rank)      # uniform in [0, r)
     d_scalars = torch.from_numpy(scalars.view(np.int64)).to(dev)
     torch.cuda.synchronize()
+    # the fixed-base table of this SRS, built explicitly (the library would otherwise build it inside the first MSM) and timed
+    pc_bits, pc_levels, pc_bytes, pc_ms = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_double()
+    mlib.check(L.mzk_srs_precompute(pp.handle, C.byref(pc_bits), C.byref(pc_levels), C.byref(pc_bytes), C.byref(pc_ms)), "mzk_srs_precompute")
+    precompute = {"window_bits": pc_bits.value, "levels": pc_levels.value, "table_bytes": pc_bytes.value, "build_ms": round(pc_ms.value, 2),
+                  "note": "fixed-base table table[w][i] = 2^(c*w) * P_i of the registered SRS, built once per SRS by pre_next_level_kernel "
+                          "OUTSIDE the timed region; `variable_base` is the same workload without it"}
+
+    if os.environ.get("MZK_BENCH_TABLE") == "0":      # tools/pmc_passes.sh only: PMC passes of the plain path (headline steps with the table off)
+        L.mzk_msm_set_precompute(0)
 
     def step():
         jac = mj.msm_bigint(pp, d_scalars, scalars_are_mont=True)            # one Pippenger MSM, result on host
@@ -106,105 +140,132 @@ def main():
             jac = mj.sharding.all_gather_sum(curve, jac, device=coll_dev)
         return jac
 
-    for _ in range(args.warmup):
-        step()
-    L.mzk_profile_reset()
-    L.mzk_profile_enable(1)
-    if world > 1:
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        result = step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-    L.mzk_profile_enable(0)
-    if world > 1:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        elapsed = float(tmax.item())
-    acc_ms, acc_cnt = mlib.profile_get("msm_accumulate")
-    tot_ms, tot_cnt = mlib.profile_get("msm_total")
-    sort_ms, _ = mlib.profile_get("msm_sort")
-    red_ms, _ = mlib.profile_get("msm_reduce")
-    c_bits, n_win, n_buckets = mlib.msm_last_shape()
+    def timed_steps():
+        """W warm-ups, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
+        for _ in range(args.warmup):
+            step()
+        L.mzk_profile_reset()
+        L.mzk_profile_enable(1)
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            res = step()
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+        el = time.perf_counter() - t0
+        L.mzk_profile_enable(0)
+        if world > 1:
+            tmax = torch.tensor([el], dtype=torch.float64, device=cdev)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            el = float(tmax.item())
+        acc_ms, acc_cnt = mlib.profile_get("msm_accumulate")
+        tot_ms, tot_cnt = mlib.profile_get("msm_total")
+        sort_ms, _ = mlib.profile_get("msm_sort")
+        red_ms, _ = mlib.profile_get("msm_reduce")
+        phases = {"sort": round(sort_ms / max(tot_cnt, 1), 4), "accumulate": round(acc_ms / max(acc_cnt, 1), 4),
+                  "reduce": round(red_ms / max(tot_cnt, 1), 4), "device_total": round(tot_ms / max(tot_cnt, 1), 4)}
+        return el, res, acc_ms / max(acc_cnt, 1), phases, mlib.msm_last_shape()
+
+    elapsed, result, acc_avg_ms, phases, (c_bits, n_win, n_buckets) = timed_steps()
+    alg_bytes = 128.0 * n                          # SURVEY.md 8(d): N * (2*|Fq| + 32) bytes per BLS12-381 MSM
+
+    def msm_roofline(acc_ms, windows, pmc_prefix):
+        achieved = alg_bytes / (acc_ms * 1e-3) / 1e9
+        traffic, note = _pmc(pmc_prefix + "_hbm_bytes_per_launch", srchash.MSM_SOURCES)
+        insts, _ = _pmc(pmc_prefix + "_SQ_INSTS_VALU", srchash.MSM_SOURCES)
+        valu = None
+        if insts and args.log_n == 20:
+            bound_ms = insts / 1024 * VOP3_NS * 1e-6
+            # 32-bit integer multiply-adds (v_mad_u64_u32) the launch retires: windows x n mixed adds x (8 products of 2 * 14^2 MADs
+            # + 2 squarings of 14 * 15 / 2 + 14^2), SURVEY.md 8(d)'s second figure; peak = 64 lanes / 1.9 ns on 1024 SIMDs
+            mads = windows * n * (8 * 2 * 196 + 2 * (105 + 196))
+            valu = {"wave_insts_per_launch": insts, "issue_bound_ms": round(bound_ms, 3), "util": round(bound_ms / acc_ms, 3),
+                    "int_mad_per_s": round(mads / (acc_ms * 1e-3), -9), "int_mad_peak_per_s": round(1024 * 64 / (VOP3_NS * 1e-9), -9),
+                    "note": "SQ_INSTS_VALU of the committed PMC pass x 1.9 ns / 1024 SIMDs vs the live launch time"}
+        return {"bound": "hbm", "kernel": "msm_accumulate_kernel<EcFx<BlsFqX>>", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": note, "algorithmic_bytes_per_launch": alg_bytes,
+                "avg_launch_ms": round(acc_ms, 4), "valu_issue": valu,
+                "note": "integer-ALU bound (381-bit Montgomery mixed adds), not HBM bound: see DESIGN.md"}
 
     out = None
     if rank == 0:
-        acc_avg_ms = acc_ms / max(acc_cnt, 1)
-        alg_bytes = 128.0 * n                      # N * (2*|Fq| + 32) bytes per BLS12-381 MSM
-        achieved = alg_bytes / (acc_avg_ms * 1e-3) / 1e9
-        traffic = _profile_value("msm_accumulate_hbm_bytes_per_launch")
-        # the kernel's real ceiling: VALU issue.  Wave-instructions per launch from the committed SQ counters, priced at the
-        # measured 1.9 ns per VOP3 wave-instruction per SIMD (profiles/r01_valu_ubench2.txt), 1024 SIMDs
-        valu = None
-        kern = (_profile_value("kernels") or {}).get(_profile_value("msm_accumulate_kernel") or "")
-        if kern and kern.get("SQ_INSTS_VALU") and args.log_n == 20:
-            bound_ms = kern["SQ_INSTS_VALU"] / 1024 * 1.9e-6
-            # 32-bit integer multiply-adds (v_mad_u64_u32) the launch retires: 13 windows x n mixed adds x (8 products of 2 * 14^2
-            # MADs + 2 squarings of 14 * 15 / 2 + 14^2), SURVEY.md 8(d)'s second figure; peak = 64 lanes / 1.9 ns on 1024 SIMDs
-            mads = n_win * n * (8 * 2 * 196 + 2 * (105 + 196))
-            valu = {"wave_insts_per_launch": kern["SQ_INSTS_VALU"], "issue_bound_ms": round(bound_ms, 3), "util": round(bound_ms / acc_avg_ms, 3),
-                    "int_mad_per_s": round(mads / (acc_avg_ms * 1e-3), -9), "int_mad_peak_per_s": round(1024 * 64 / 1.9e-9, -9),
-                    "note": "SQ_INSTS_VALU of the committed PMC pass (2^20 pairs) x 1.9 ns / 1024 SIMDs vs the live launch time"}
         out = {
             "metric": "msm_g1_scalar_pairs_per_s", "value": world * n * args.steps / elapsed, "unit": "pairs/s",
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (381-bit Fq as 14 x 29-bit limbs, Montgomery)",
             "data": "synthetic",
-            "config": {"workload": f"standalone MSM, 2^{args.log_n} G1 x Fr pairs per GPU, BLS12-381 (BASELINE configs[1])",
+            "config": {"workload": f"standalone MSM, 2^{args.log_n} G1 x Fr pairs per GPU, BLS12-381 (BASELINE configs[1]); fixed-base table path "
+                                   "(see config.precompute; `variable_base` = table off)",
                        "curve": "bls12-381", "pairs_per_gpu": n, "window_bits": c_bits, "windows": n_win,
                        "buckets_per_window": n_buckets, "sharding": "point-range" if world > 1 else "none",
-                       "srs_gen_s": round(t_srs, 3)},
-            "roofline": {"bound": "hbm", "kernel": "msm_accumulate_kernel<EcFx<BlsFqX>>", "achieved": round(achieved, 3),
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic,
-                         "algorithmic_bytes_per_launch": alg_bytes, "avg_launch_ms": round(acc_avg_ms, 4),
-                         "valu_issue": valu,
-                         "note": "integer-ALU bound (381-bit Montgomery mixed adds), not HBM bound: see DESIGN.md"},
-            "phases_ms": {"sort": round(sort_ms / max(tot_cnt, 1), 4), "accumulate": round(acc_avg_ms, 4),
-                          "reduce": round(red_ms / max(tot_cnt, 1), 4), "device_total": round(tot_ms / max(tot_cnt, 1), 4)},
-            "cpu_baseline": None, "ntt": None, "plonk_round3": None, "batch_commit5": None, "prove": None, "prove_cpp_host": None,
-            "prove_sharded": None, "prove_ultra_bn254": None, "link_and_batch": None,
+                       "srs_gen_s": round(t_srs, 3), "precompute": precompute},
+            "roofline": msm_roofline(acc_avg_ms, n_win, "msm_accumulate"),
+            "phases_ms": phases,
+            "cpu_baseline": None, "variable_base": None, "ntt": None, "plonk_round3": None, "batch_commit5": None, "prove": None,
+            "prove_dropin": None, "prove_cpp_host": None, "prove_sharded": None, "prove_ultra_bn254": None, "link_and_batch": None,
         }
 
     # The headline line is complete here; everything below is secondary.  With several ranks the secondary part holds collectives
     # (the sharded proofs): if a rank fails or stalls there, the others would wait for ever and the line would never be printed --
-    # a watchdog prints the headline as it stands and ends the process instead.
+    # a watchdog prints the headline as it stands and ends the process with a NON-ZERO code (a stalled section is not a success).
+    emit_lock = threading.Lock()
     state = {"printed": False}
 
     def emit():
-        if rank == 0 and not state["printed"]:
-            state["printed"] = True
-            print(json.dumps(out), flush=True)
+        with emit_lock:
+            if rank == 0 and not state["printed"]:
+                state["printed"] = True
+                print(json.dumps(out), flush=True)
 
     def bail():
-        if rank == 0 and not state["printed"]:
-            out["prove_sharded"] = {"error": "watchdog: the secondary multi-rank section did not finish in %d s" % args.secondary_timeout}
-            emit()
-        os._exit(0)
+        if rank == 0:
+            with emit_lock:
+                if not state["printed"]:
+                    out["prove_sharded"] = {"error": "watchdog: the secondary multi-rank section did not finish in %d s" % args.secondary_timeout}
+                    state["printed"] = True
+                    print(json.dumps(out), flush=True)
+        os._exit(3)
 
     watchdog = None
     if world > 1 and args.secondary_timeout > 0:
-        import threading
         watchdog = threading.Timer(args.secondary_timeout, bail)
         watchdog.daemon = True
         watchdog.start()
+
+    # ---- secondary: the same K steps with the fixed-base table switched off (ark-ec's VariableBaseMSM is the like-for-like) -----
+    variable_base = None
+    if not args.no_variable_base:
+        L.mzk_msm_set_precompute(0)
+        try:
+            vb_el, vb_res, vb_acc, vb_phases, (vc, vw, vm) = timed_steps()
+        finally:
+            L.mzk_msm_set_precompute(1)
+        if rank == 0:
+            variable_base = {"what": "the headline's steps with mzk_msm_set_precompute(0): plain Pippenger, every window on its own bucket set, "
+                                     "no per-SRS set-up -- what `VariableBaseMSM::msm_bigint` (univariate_kzg/mod.rs:109-111) is",
+                             "value": world * n * args.steps / vb_el, "unit": "pairs/s", "ms_per_step": vb_el / args.steps * 1e3,
+                             "window_bits": vc, "windows": vw, "buckets_per_window": vm, "phases_ms": vb_phases,
+                             "same_point_as_table_path": bool(np.array_equal(np.asarray(vb_res), np.asarray(result))) if world == 1 else None,
+                             "roofline": msm_roofline(vb_acc, vw, "msm_accumulate_plain")}
 
     # ---- secondary: batch_commit of 5 polynomials (round 1 / round 3 of a proof) in one fused call -----
     batch = None
     if rank == 0 and world == 1:
         sets = [d_scalars] * 5
-        mj.msm_bigint_batch(pp, sets, scalars_are_mont=True)
-        torch.cuda.synchronize()
-        reps = 3
-        t1 = time.perf_counter()
-        for _ in range(reps):
+        for _ in range(2):
             mj.msm_bigint_batch(pp, sets, scalars_are_mont=True)
         torch.cuda.synchronize()
-        bt = (time.perf_counter() - t1) / reps
-        batch = {"what": "5 MSMs of 2^%d pairs in one mzk_msm_batch_dev call (shared bucket reduction, one sync)" % args.log_n,
+        times = []
+        for _ in range(3):
+            t1 = time.perf_counter()
+            mj.msm_bigint_batch(pp, sets, scalars_are_mont=True)
+            torch.cuda.synchronize()
+            times.append(time.perf_counter() - t1)
+        bt = sorted(times)[1]
+        batch = {"what": "5 MSMs of 2^%d pairs in one mzk_msm_batch_dev call (shared bucket reduction, one sync); median of 3" % args.log_n,
                  "ms_per_batch": round(bt * 1e3, 3), "pairs_per_s": 5 * n / bt}
 
     # ---- secondary: NTT 2^22 forward + inverse on the Fr::GENERATOR coset (config C3) ---------------
@@ -232,13 +293,16 @@ def main():
         nt_ms, nt_cnt = mlib.profile_get("ntt_total")
         L.mzk_profile_reset()
         per_transform_ms = nt_ms / max(nt_cnt, 1)
+        ntt_traffic, ntt_note = _pmc("ntt_pass_hbm_bytes_per_launch", srchash.NTT_SOURCES)
         ntt = {"log_n": nl, "fwd_plus_inv_ms": round(ntt_wall * 1e3, 4), "transform_ms": round(per_transform_ms, 4),
-               "passes_per_transform": pass_cnt // max(nt_cnt, 1),
+               "passes_per_transform": pass_cnt // max(nt_cnt, 1), "pass_ms": round(pass_ms / max(pass_cnt, 1), 4),
                "butterflies_per_s": (N // 2 * nl) / (per_transform_ms * 1e-3),
-               "roofline": {"bound": "hbm", "achieved": round(64.0 * N / (per_transform_ms * 1e-3) / 1e9, 2),
-                            "peak": HBM_PEAK_GBS, "unit": "GB/s",
+               "roofline": {"bound": "hbm", "kernel": "nttx_pass_kernel<BlsFrX>, per transform (all passes)",
+                            "achieved": round(64.0 * N / (per_transform_ms * 1e-3) / 1e9, 2), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                             "frac": round(64.0 * N / (per_transform_ms * 1e-3) / 1e9 / HBM_PEAK_GBS, 5),
-                            "traffic": _profile_value("ntt_pass_hbm_bytes_per_launch")}}
+                            "traffic": ntt_traffic, "traffic_source": ntt_note,
+                            "traffic_is": "HBM bytes of ONE pass launch (a transform is %d)" % (pass_cnt // max(nt_cnt, 1))}}
+        del x
 
     # ---- secondary: TurboPlonk round 3 on the device at 2^20 gates (config C4's heaviest round) -------
     plonk = None
@@ -255,6 +319,7 @@ def main():
         d_polys = torch.zeros((7, pm, 4), dtype=torch.int64, device=dev)
         d_out = torch.empty((pm, 4), dtype=torch.int64, device=dev)
         ch = mj.plonk.Challenges(0x1234567, 0x89abcde, 0xf012345)
+
         def round3():
             d_polys[:, :pn + 3] = d_coeffs            # fresh coefficients (the call overwrites them)
             mj.plonk.compute_quotient_polynomial_dev(pk, ch, d_polys, pn + 3, d_out)
@@ -262,7 +327,7 @@ def main():
         torch.cuda.synchronize()
         L.mzk_profile_reset()
         L.mzk_profile_enable(1)
-        reps = 3
+        reps = 5
         t1 = time.perf_counter()
         for _ in range(reps):
             round3()
@@ -272,12 +337,11 @@ def main():
         qk_ms, qk_cnt = mlib.profile_get("plonk_quotient_kernel")
         qt_ms, qt_cnt = mlib.profile_get("plonk_quotient_total")
         L.mzk_profile_reset()
-        plonk = {"what": "TurboPlonk round 3 without commitments: 7 coset NTT(8n) + fused quotient kernel + coset iNTT(8n); "
+        plonk = {"what": "TurboPlonk round 3 without commitments: 7 coset NTTs + fused quotient kernel + inverse coset NTT(s); "
                          "selector/sigma coset evaluations resident per proving key",
                  "log_n": pl, "quotient_domain_log": pl + 3, "round3_ms": round(r3_wall * 1e3, 3),
                  "quotient_kernel_ms": round(qk_ms / max(qk_cnt, 1), 3), "device_ms": round(qt_ms / max(qt_cnt, 1), 3),
-                 "pk_register_s": round(t_pk, 3),
-                 "quotient_kernel_GBps": round(27 * 32.0 * pm / (qk_ms / max(qk_cnt, 1) * 1e-3) / 1e9, 1)}
+                 "pk_register_s": round(t_pk, 3)}
         pk.release()
         del d_polys, d_out, d_coeffs
 
@@ -298,30 +362,50 @@ def main():
         for _ in range(3):                                  # warm-up: plans, precomputed SRS table, allocator steady state
             mj.snark.prove(rng, cs, prover)
         torch.cuda.synchronize()
-        reps = 3
+        reps = args.prove_reps                              # plonk/benches/bench.rs:25: `let rep = 10`
+        each = []
         t1 = time.perf_counter()
         for _ in range(reps):
+            t2 = time.perf_counter()
             core, proof_bytes = mj.snark.prove(rng, cs, prover)
+            each.append((time.perf_counter() - t2) * 1e3)
         torch.cuda.synchronize()
         prove_ms = (time.perf_counter() - t1) / reps * 1e3
         core, proof_bytes = mj.snark.prove(rng, cs, prover, profile=True)
-        quot = prover.last["quot"]
-        deg = 5 * (pn + 1) + 2
-        satisfied = bool(quot[deg].any().item()) and not bool(quot[deg + 1:].any().item())       # prover.rs:916-919
         prove = {"what": "PlonkKzgSnark::prove of one TurboPlonk proof on the reference's bench circuit (bench.rs:29-46: a = a + 1, "
-                         "gates - 10 times): 7 iNTT(n), grand product, 7+1 NTT(8n), quotient, 13 MSM, evaluations, linearisation, "
-                         "openings, ChaCha test_rng blinders, Merlin transcript, compressed proof bytes; proving key resident",
-                 "log_n": pl, "prove_ms": round(prove_ms, 2), "ns_per_gate": round(prove_ms * 1e6 / pn, 1),
-                 "rounds_ms": core.timings_ms, "proof_bytes": len(proof_bytes), "quotient_degree_ok": satisfied,
+                         "gates - 10 times): 7 iNTT(n), grand product, coset NTTs, quotient, 13 MSM, evaluations, linearisation, "
+                         "openings, ChaCha test_rng blinders, Merlin transcript, compressed proof bytes; proving key resident; "
+                         "the quotient's degree is checked as the reference checks it (a wrong witness raises)",
+                 "log_n": pl, "prove_ms": round(prove_ms, 2), "reps": reps, "min_ms": round(min(each), 2), "max_ms": round(max(each), 2),
+                 "ns_per_gate": round(prove_ms * 1e6 / pn, 1), "rounds_ms": core.timings_ms, "proof_bytes": len(proof_bytes),
                  "circuit_build_s": round(t_circ, 3), "preprocess_s": round(t_pre, 3),
                  "reference_published": "29591 ns/gate at 2^15 gates, 24 threads of a 5900X (bench.md:16); not comparable hardware"}
         prover.release()
-        del cs, quot
+        del cs
         if ck is not pp:
             ck.release()
 
-    # ---- secondary, N > 1: the same proof with every commitment's MSM split by point range over the ranks;
-    #      NTTs, quotient and polynomial work are replicated, so this is the strong-scaling figure of the commit half only
+    # ---- secondary: the same proof's NTTs and MSMs in SHIM-ONLY mode: host pointers through the two call-site swaps of
+    #      INTEGRATION.md section 2, nothing else of the Rust prover changed (tools/dropin_time.py) --------------------------------
+    dropin = None
+    if not args.no_plonk and not args.no_dropin and rank == 0 and world == 1:
+        import dropin_time
+        try:
+            modes = {}
+            for mode in ("pageable", "pinned", "batch"):
+                modes[mode] = dropin_time.measure(mj, L, curve, args.plonk_log_n, mode, reps=2,
+                                                  srs=pp if pp.length >= (1 << args.plonk_log_n) + 3 else None)
+            dropin = {"what": "library time of ONE TurboPlonk proof in shim-only mode: 7 ifft(n) + 25 coset fft(8n) + 1 coset ifft(8n) through "
+                              "host-pointer mzk_ntt, 13 commits through host-pointer mzk_msm; the quotient closure (prover.rs:605-659) stays on the "
+                              "CPU in this mode and is NOT in the figure.  pageable: ordinary host memory, one call per polynomial; pinned: "
+                              "buffers from mzk_host_alloc; batch: pinned + mzk_ntt_batch / mzk_msm_batch (upload k+1 | transform k | download k-1)",
+                      "log_n": args.plonk_log_n, "pcie_gb_per_proof": modes["batch"]["pcie_gb"],
+                      "ms": {k: v["ms"] for k, v in modes.items()}, "pcie_gb_per_s": {k: v["pcie_gb_per_s"] for k, v in modes.items()},
+                      "device_resident_prove_ms": prove["prove_ms"] if prove else None}
+        except Exception as e:                              # noqa: BLE001  (secondary: the headline must still be printed)
+            dropin = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
+
+    # ---- secondary, N > 1: the same proof sharded over the ranks
     prove_sharded = None
     if not args.no_plonk and world > 1 and not os.environ.get("MZK_BENCH_NO_SHARDED_PROVE"):
         def sharded_prove(crv, log_gates, plonk_type):
@@ -339,7 +423,7 @@ def main():
                 mj.snark.prove(rng, cs, prover)
             torch.cuda.synchronize()
             dist.barrier()
-            reps = 3
+            reps = 5
             t1 = time.perf_counter()
             for _ in range(reps):
                 core, proof_bytes = mj.snark.prove(rng, cs, prover)
@@ -347,22 +431,23 @@ def main():
             dist.barrier()
             tmax = torch.tensor([(time.perf_counter() - t1) / reps * 1e3], dtype=torch.float64, device=cdev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            digest = torch.tensor([int.from_bytes(proof_bytes[8:15], "little")], dtype=torch.int64, device=cdev)
+            # every rank must hold the SAME proof: a digest of all its bytes (round 1 to the openings), min == max over the ranks
+            digest = torch.tensor([int.from_bytes(hashlib.sha256(proof_bytes).digest()[:7], "little")], dtype=torch.int64, device=cdev)
             lo, hi = digest.clone(), digest.clone()
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
             core, _ = mj.snark.prove(rng, cs, prover, profile=True)
-            out = {"plonk_type": plonk_type, "curve": crv.name, "log_n": cs.n.bit_length() - 1, "chunked_quotient": chunked,
+            res = {"plonk_type": plonk_type, "curve": crv.name, "log_n": cs.n.bit_length() - 1, "chunked_quotient": chunked,
                    "prove_ms": round(float(tmax.item()), 2), "ranks_agree_on_proof": bool(lo.item() == hi.item()),
                    "proof_bytes": len(proof_bytes), "rounds_ms_rank0": core.timings_ms}
             prover.release()
             ck.release()
-            return out
+            return res
 
         prove_sharded = {"what": "PlonkKzgSnark::prove on the bench circuit, strong scaling: commitments sharded by point range over the ranks "
                                  "(all-gather of Jacobian partials + local EC sum, 8(e).1), quotient domain split into residue classes with one "
-                                 "all-gather (8(e).3) when the world size divides 8; iNTTs, grand products, evaluations, openings' polynomials "
-                                 "replicated.  Python-orchestrated (compare with `prove` of the 1-GPU line, not with `prove_cpp_host`)",
+                                 "all-gather (8(e).3) when the world size divides 8.  Python-orchestrated (compare with `prove` of the 1-GPU line); "
+                                 "profiles/r02_scale_model.json holds the model this is to be checked against",
                          }
         try:
             prove_sharded["turbo_bls12_381"] = sharded_prove(curve, args.plonk_log_n, "TurboPlonk")
@@ -386,26 +471,23 @@ def main():
         for _ in range(3):
             mj.snark.prove(rng, cs, prover)
         torch.cuda.synchronize()
-        reps = 3
+        reps = args.prove_reps
         t1 = time.perf_counter()
         for _ in range(reps):
             core, proof_bytes = mj.snark.prove(rng, cs, prover)
         torch.cuda.synchronize()
         prove_ms = (time.perf_counter() - t1) / reps * 1e3
         core, proof_bytes = mj.snark.prove(rng, cs, prover, profile=True)
-        quot = prover.last["quot"]
-        deg = 6 * (un + 1) + 2
-        satisfied = bool(quot[deg].any().item()) and not bool(quot[deg + 1:].any().item())
         ultra = {"what": "PlonkKzgSnark::prove, UltraPlonk (Plookup, range_bit_len 8) bench circuit over BN254 on ONE GPU",
-                 "log_n": ul, "prove_ms": round(prove_ms, 2), "ns_per_gate": round(prove_ms * 1e6 / un, 1), "rounds_ms": core.timings_ms,
-                 "proof_bytes": len(proof_bytes), "quotient_degree_ok": satisfied, "preprocess_s": round(t_pre, 3)}
+                 "log_n": ul, "prove_ms": round(prove_ms, 2), "reps": reps, "ns_per_gate": round(prove_ms * 1e6 / un, 1), "rounds_ms": core.timings_ms,
+                 "proof_bytes": len(proof_bytes), "preprocess_s": round(t_pre, 3)}
         prover.release()
         ck2.release()
-        del cs, quot
+        del cs
 
-    # ---- secondary: proof linking and an aggregated proof (snark.rs:64-78, proof_linking.rs:80-221) ----------
+    # ---- optional (outside SURVEY.md section 8): proof linking and an aggregated proof --------------------------------------------
     link_batch = None
-    if not args.no_plonk and rank == 0 and world == 1:
+    if args.link_batch and not args.no_plonk and rank == 0 and world == 1:
         ln = args.plonk_log_n
         g1, g2 = (1 << ln) - 576, (1 << ln) - 76                          # two circuits of one domain size, sharing wire-0 rows
         size = min(256, max(1, (1 << ln) // 8))
@@ -424,7 +506,7 @@ def main():
                 lp = mj.linking.link_proofs(ha, hb, layout, ckl)
             torch.cuda.synchronize()
             link_ms = (time.perf_counter() - t1) / 3 * 1e3
-            for _ in range(2):                                          # allocator steady state (a 268 MB quotient sum per call)
+            for _ in range(2):
                 mj.snark.batch_prove(rngl, [cs_a, cs_b], [pa, pb])
             times = []
             for _ in range(3):
@@ -433,11 +515,8 @@ def main():
                 _, blob = mj.snark.batch_prove(rngl, [cs_a, cs_b], [pa, pb])
                 torch.cuda.synchronize()
                 times.append((time.perf_counter() - t1) * 1e3)
-            batch_ms = sorted(times)[1]                                  # median of three
-            link_batch = {"what": "two TurboPlonk bench circuits of 2^%d rows (%d and %d gates): PlonkKzgSnark::link_proofs over %d shared wire-0 "
-                                  "witnesses (alignment %d), and ONE aggregated proof of both (PlonkKzgSnark::batch_prove)" % (ln, g1, g2, size, layout.alignment),
-                          "link_proofs_ms": round(link_ms, 2), "link_proof_bytes": len(lp.serialize_compressed()),
-                          "batch_prove_2_instances_ms": round(batch_ms, 2), "batch_proof_bytes": len(blob)}
+            link_batch = {"link_proofs_ms": round(link_ms, 2), "link_proof_bytes": len(lp.serialize_compressed()),
+                          "batch_prove_2_instances_ms": round(sorted(times)[1], 2), "batch_proof_bytes": len(blob)}
             pa.release()
             pb.release()
             ckl.release()
@@ -451,8 +530,8 @@ def main():
         prove_cpp = {}
         # ... and at the reference's own bench size (NUM_GATES_LARGE = 32768, plonk/benches/bench.rs:26), whose published CPU figures
         # are 29 591 (TurboPlonk, BLS12-381) and 33 701 (UltraPlonk, BN254) ns per constraint on 24 threads of a 5900X (bench.md)
-        for name, argv in (("turbo_bls12_381", ["0", "turbo", str(1 << args.plonk_log_n), "5"]),
-                           ("ultra_bn254", ["1", "ultra", str(1 << (args.ultra_log_n or args.plonk_log_n)), "5"]),
+        for name, argv in (("turbo_bls12_381", ["0", "turbo", str(1 << args.plonk_log_n), "10"]),
+                           ("ultra_bn254", ["1", "ultra", str(1 << (args.ultra_log_n or args.plonk_log_n)), "10"]),
                            ("turbo_bls12_381_1024_gates", ["0", "turbo", "1024", "20"]),
                            ("turbo_bls12_381_32768_gates", ["0", "turbo", "32768", "20"]),
                            ("ultra_bn254_32768_gates", ["1", "ultra", "32768", "20"])):
@@ -476,11 +555,12 @@ def main():
             except Exception as e:                      # noqa: BLE001  (the binary is optional for the headline)
                 prove_cpp[name] = {"error": repr(e)[:200]}
 
-    # ---- CPU baseline: the C oracle ("port" of the ark-ec algorithm) on this host, rank 0 only -------
+    # ---- CPU baseline: the C oracle ("port" of the ark-ec / ark-poly algorithms) on this host, rank 0 only -------
     cpu = None
     if not args.no_cpu_baseline and rank == 0 and world == 1:
         sys.path.insert(0, os.path.join(ROOT, "oracle"))
         import cref
+        import cref_prover
         threads = max(1, min(16, os.cpu_count() or 1))
         bases = pp.powers_of_g()
         canon = cref.fr_convert(0, scalars, False)
@@ -488,6 +568,7 @@ def main():
         want = cref.msm(0, bases, canon, threads=threads)
         cpu_s = time.perf_counter() - t1
         same = np.array_equal(cref.jac_to_affine(0, want)[0], cref.jac_to_affine(0, result)[0])
+        del bases, canon
         # the same host's figure for config C3 (NTT 2^22), beside the MSM one
         xs = mj.params.random_fr_mont(curve, 1 << 22, seed=11)
         t1 = time.perf_counter()
@@ -495,75 +576,63 @@ def main():
         ntt_cpu_s = time.perf_counter() - t1
         ntt_same = bool(np.array_equal(ev_cpu[:4096], mj.Radix2EvaluationDomain(curve, 22).fft(xs)[:4096]))
         del xs, ev_cpu
-        # config C1 (BASELINE.json configs[0]): TurboPlonk over BLS12-381 at 2^10 constraints on ONE CPU thread -- the C restatement
-        # assembled into a prover (oracle/cref_prover.py), with the challenges and blinders of a device proof, compared piece by piece
-        import cref_prover
-        cs1 = mj.snark.gen_circuit_for_bench(curve, 1 << 10, "TurboPlonk")
-        rng1 = mj.rng.test_rng()
-        ck1 = mj.UnivariateProverParam.gen_srs_for_testing(curve, mj.rng.fr_rand(curve, rng1), cs1.n + 2)
-        pk1 = mj.snark.preprocess(ck1, cs1)
-        bl1 = mj.snark.draw_blinders(curve, rng1, 5, False)
-        src1 = mj.prover.TranscriptChallenges(pk1, [])
-        core1 = pk1.prove(cs1.wire_values, cs1.pub_input_values, src1, bl1)
         hostv = lambda t: t.cpu().numpy().view(np.uint64)
-        c1 = cref_prover.prove_turbo(0, curve.r, curve.fr_generator, 10, hostv(cs1.selector_values), hostv(cs1.sigma_values), cs1.k, hostv(cs1.wire_values),
-                                     hostv(cs1.pub_input_values), {"wires": bl1.wires, "z": bl1.z, "quot": bl1.quot}, dict(src1.challenges),
-                                     ck1.powers_of_g(), threads=1)
-        c1_same = bool(np.array_equal(core1.opening_proof.xy, c1["opening"]) and np.array_equal(core1.shifted_opening_proof.xy, c1["shifted"])
-                       and core1.wires_evals == c1["wires_evals"])
-        pk1.release()
-        ck1.release()
-        # ... and a mid-size proof on all the host threads, next to the device at the same size: the prove-time ratio the
-        # north star asks for, at the largest size that keeps this leg within its time bound (the CPU side grows ~ n log n)
-        lgm = args.cpu_prove_log_n
-        prove_mid = None
-        if lgm:
-            csm = mj.snark.gen_circuit_for_bench(curve, 1 << lgm, "TurboPlonk")
+
+        def cpu_vs_device(lg, cpu_threads, gpu_reps):
+            """One TurboPlonk proof of the 2^lg-gate bench circuit by the C restatement (oracle/cref_prover.py) and by the device
+            prover, on the same circuit, SRS, blinders and transcript challenges; compared commitment by commitment."""
+            csm = mj.snark.gen_circuit_for_bench(curve, 1 << lg, "TurboPlonk")
             rngm = mj.rng.test_rng()
             ckm = mj.UnivariateProverParam.gen_srs_for_testing(curve, mj.rng.fr_rand(curve, rngm), csm.n + 2)
             pkm = mj.snark.preprocess(ckm, csm)
             blm = mj.snark.draw_blinders(curve, rngm, 5, False)
-            for _ in range(3):
+            for _ in range(2):
                 pkm.prove(csm.wire_values, csm.pub_input_values, mj.prover.TranscriptChallenges(pkm, []), blm)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
-            for _ in range(3):
+            for _ in range(gpu_reps):
                 srcm = mj.prover.TranscriptChallenges(pkm, [])
                 corem = pkm.prove(csm.wire_values, csm.pub_input_values, srcm, blm)
             torch.cuda.synchronize()
-            gpu_ms = (time.perf_counter() - t1) / 3 * 1e3
-            cm_ = cref_prover.prove_turbo(0, curve.r, curve.fr_generator, lgm, hostv(csm.selector_values), hostv(csm.sigma_values), csm.k,
-                                          hostv(csm.wire_values), hostv(csm.pub_input_values), {"wires": blm.wires, "z": blm.z, "quot": blm.quot},
-                                          dict(srcm.challenges), ckm.powers_of_g(), threads=threads)
-            mid_same = bool(np.array_equal(corem.opening_proof.xy, cm_["opening"]) and np.array_equal(corem.shifted_opening_proof.xy, cm_["shifted"])
-                            and corem.wires_evals == cm_["wires_evals"])
-            prove_mid = {"log_n": lgm, "ms": round(cm_["seconds"] * 1e3, 1), "cores": threads, "gpu_ms": round(gpu_ms, 2),
-                         "gpu_over_cpu": round(cm_["seconds"] * 1e3 / gpu_ms, 1), "matches_gpu": mid_same,
-                         "sample": "one TurboPlonk proof of the 2^%d-gate bench circuit over BLS12-381, the C restatement (oracle/cref_prover.py: ark-poly "
-                                   "style FFTs, ark-ec style Pippenger, serial grand product) on %d threads vs the device prover (Python-orchestrated) "
-                                   "on the same circuit, blinders and transcript" % (lgm, threads)}
-            pkm.release()
+            gpu_ms = (time.perf_counter() - t1) / gpu_reps * 1e3
+            srs_xy = ckm.powers_of_g()
+            sel, sig, wv, pv = hostv(csm.selector_values), hostv(csm.sigma_values), hostv(csm.wire_values), hostv(csm.pub_input_values)
+            pkm.release()                                                 # the CPU proof needs the host's memory and cores, not the device
+            cm_ = cref_prover.prove_turbo(0, curve.r, curve.fr_generator, lg, sel, sig, csm.k, wv, pv, {"wires": blm.wires, "z": blm.z, "quot": blm.quot},
+                                          dict(srcm.challenges), srs_xy, threads=cpu_threads)
+            ok = bool(np.array_equal(corem.opening_proof.xy, cm_["opening"]) and np.array_equal(corem.shifted_opening_proof.xy, cm_["shifted"])
+                      and all(np.array_equal(a.xy, b) for a, b in zip(corem.split_quot_poly_comms, cm_["split_comms"]))
+                      and corem.wires_evals == cm_["wires_evals"] and corem.perm_next_eval == cm_["perm_next_eval"])
             ckm.release()
-            del csm
+            return {"log_n": lg, "ms": round(cm_["prove_seconds"] * 1e3, 1), "cores": cpu_threads, "gpu_ms": round(gpu_ms, 2),
+                    "gpu_over_cpu": round(cm_["prove_seconds"] * 1e3 / gpu_ms, 1), "matches_gpu": ok,
+                    "sample": "ONE TurboPlonk proof of the 2^%d-gate bench circuit over BLS12-381 by the C restatement (oracle/cref_prover.py: ark-poly "
+                              "style FFTs, ark-ec style Pippenger with its window rule, the reference's serial grand product and per-point quotient "
+                              "closure; `preprocess` work excluded) on %d threads, vs the device prover (Python-orchestrated, proving key resident) on the "
+                              "same circuit, SRS, blinders and transcript; restatement of the ark-* algorithms, not the Rust binary" % (lg, cpu_threads)}
+
+        c1 = cpu_vs_device(10, 1, 3)                                      # config C1 (BASELINE.json configs[0]): 2^10 gates, ONE CPU thread
+        big = cpu_vs_device(args.cpu_prove_log_n, threads, 3) if args.cpu_prove_log_n else None
         cpu = {"value": n / cpu_s, "unit": "pairs/s", "cores": threads, "kind": "port",
                "sample": f"one full 2^{args.log_n}-pair MSM (same bases and scalars as the GPU step), oracle/cpu_ref.c "
-                         f"Pippenger with the ark-ec window rule, {threads} threads; restatement of ark-ec, not the Rust binary",
+                         f"Pippenger with the ark-ec window rule, {threads} threads; restatement of ark-ec's VariableBaseMSM, not the Rust binary "
+                         "(compare with `variable_base`, which has no fixed-base table either)",
                "seconds": round(cpu_s, 3), "matches_gpu": bool(same),
-               "prove_c1": {"ms": round(c1["seconds"] * 1e3, 1), "cores": 1, "matches_gpu": c1_same,
-                            "sample": "one TurboPlonk proof of the 2^10-gate bench circuit over BLS12-381 (BASELINE configs[0]) by the C "
-                                      "restatement on one thread (oracle/cref_prover.py); GPU figure: prove_cpp_host.turbo_bls12_381_1024_gates"},
-               "prove_mid": prove_mid,
+               "gpu_variable_base_over_cpu": round(variable_base["value"] / (n / cpu_s), 1) if variable_base else None,
+               "prove_c1": c1,
+               ("prove_2p%d" % args.cpu_prove_log_n): big,
                "ntt_2^22": {"ms": round(ntt_cpu_s * 1e3, 1), "cores": threads, "matches_gpu": ntt_same,
                             "sample": "one forward 2^22-point NTT, oracle/cpu_ref.c in-order radix-2 (ark-poly's algorithm restated)"}}
 
+    if watchdog is not None:
+        watchdog.cancel()
     if rank == 0:
-        out.update({"cpu_baseline": cpu, "ntt": ntt, "plonk_round3": plonk, "batch_commit5": batch, "prove": prove, "prove_cpp_host": prove_cpp,
-                    "prove_sharded": prove_sharded, "prove_ultra_bn254": ultra, "link_and_batch": link_batch})
+        out.update({"cpu_baseline": cpu, "variable_base": variable_base, "ntt": ntt, "plonk_round3": plonk, "batch_commit5": batch, "prove": prove,
+                    "prove_dropin": dropin, "prove_cpp_host": prove_cpp, "prove_sharded": prove_sharded, "prove_ultra_bn254": ultra,
+                    "link_and_batch": link_batch})
         emit()
     if world > 1:
         dist.barrier()
-        if watchdog is not None:
-            watchdog.cancel()
         dist.destroy_process_group()
 
 

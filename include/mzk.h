@@ -15,7 +15,10 @@
  *   return value    0 on success, < 0 on error (mzk_strerror); never unwinds, never aborts.
  *   threading       every entry point may be called concurrently (the reference calls commit and
  *                   fft from Rayon workers: univariate_kzg/mod.rs:125-127, prover.rs:552-562);
- *                   calls are serialised on an internal lock and run on one HIP stream.
+ *                   the kernels of all calls are enqueued under one internal lock (shared plan cache
+ *                   and workspace), but the host-pointer entry points move their operands on
+ *                   per-call I/O streams outside it, so one caller's transfers overlap another's
+ *                   kernels (see mzk_host_alloc).
  *   memory          host buffers are borrowed for the duration of the call; the library owns all
  *                   device memory it allocates, including the registered SRS copy.
  *   "_dev" variants take device pointers (hipMalloc / torch tensors) and a hipStream_t passed as
@@ -236,6 +239,17 @@ MZK_API int32_t mzk_poly_degree_dev(const void* d_poly, uint64_t len, uint64_t* 
 MZK_API int32_t mzk_poly_div_roots_dev(int32_t curve_id, const void* d_poly, uint64_t len, uint32_t log_order, uint64_t first, uint64_t count,
                                        void* d_out, void* stream);
 
+/* ---- page-locked host memory for the host-pointer entry points (mzk_ntt, mzk_ntt_batch, mzk_msm, mzk_msm_batch) ----
+ * A shim that swaps only the two third-party call sites moves every operand over PCIe.  From memory
+ * obtained here (hipHostMalloc), or registered in place (hipHostRegister: worth it for long-lived buffers only), the transfers
+ * are DMA at link rate and asynchronous, so that inside a batch call -- and between concurrent callers, the reference's Rayon
+ * `par_iter`s (plonk/src/proof_system/prover.rs:552-562, primitives/src/pcs/univariate_kzg/mod.rs:125-127) -- the upload of
+ * polynomial k+1 and the download of k-1 overlap the transform of k.  Pageable memory works too, staged by the runtime. */
+MZK_API int32_t mzk_host_alloc(uint64_t bytes, void** out_ptr);
+MZK_API int32_t mzk_host_free(void* ptr);
+MZK_API int32_t mzk_host_register(void* ptr, uint64_t bytes);
+MZK_API int32_t mzk_host_unregister(void* ptr);
+
 /* ---- device memory helpers for bindings without HIP of their own ---- */
 MZK_API int32_t mzk_dev_alloc(uint64_t bytes, void** out_dptr);
 MZK_API int32_t mzk_dev_free(void* dptr);
@@ -258,6 +272,13 @@ MZK_API int32_t mzk_profile_reset(void);
 /* MSMs of >= 2^17 pairs over a BLS12-381 SRS use a table of precomputed multiples 2^(c*w) * P_i built in HBM on
  * the first such call (13 x the SRS size for 2^20 points); on != 0 (default) enables it.  Results are identical. */
 MZK_API int32_t mzk_msm_set_precompute(int32_t on);
+/* Builds the table of precomputed multiples of an SRS now (instead of lazily on its first MSM of >= 1024 pairs) and reports it:
+ * window bits c, levels W = ceil(256 / c), bytes of HBM it occupies (W x n x 112 B for BLS12-381, x 80 B for BN254) and the wall
+ * time the build took (W - 1 launches of c doublings per point, synchronised).  A fixed-base table is legitimate for KZG -- the
+ * commit key never changes (primitives/src/pcs/univariate_kzg/srs.rs:77-93) -- but it is a set-up cost ark-ec's
+ * VariableBaseMSM does not pay: bench.py prints it beside the headline.  All zeros when the table is disabled or did not fit. */
+MZK_API int32_t mzk_srs_precompute(uint64_t srs_handle, uint32_t* out_window_bits, uint32_t* out_levels, uint64_t* out_table_bytes,
+                                   double* out_build_ms);
 /* Last MSM's shape: window bits, windows, buckets per window (for DESIGN.md's op counts). */
 MZK_API int32_t mzk_msm_last_shape(uint32_t* out_window_bits, uint32_t* out_windows, uint32_t* out_buckets);
 

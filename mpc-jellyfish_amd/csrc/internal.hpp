@@ -71,6 +71,8 @@ struct Srs {
     uint32_t* d_int;  // internal reduced-radix table used by the MSM (29-bit limbs, R'-Montgomery form: ecx.cuh)
     uint32_t* d_pre = nullptr;  // [W][n] precomputed multiples 2^(c*w) P_i (msm_pre.cuh), built on first large MSM
     int pre_c = 0;              // window bits of d_pre; -1 = do not build
+    int pre_levels = 0;         // W: levels of d_pre
+    double pre_build_ms = 0;    // wall time of the build (pre_next_level launches, synchronised)
 };
 inline int fq_words(int curve) { return curve == MZK_CURVE_BLS12_381 ? 12 : 8; }
 
@@ -85,6 +87,7 @@ int32_t msm_dispatch(const Srs& s, uint64_t base_offset, const uint32_t* d_scala
 int32_t msm_batch_dispatch(const Srs& s, uint32_t n_polys, const uint32_t* const* d_scalars, const uint64_t* lens, const uint64_t* base_offsets,
                            int is_mont, uint32_t* out_xyz, hipStream_t st);
 int32_t srs_build_internal(Srs& s, hipStream_t st);
+int32_t srs_build_pre(Srs& s, hipStream_t st);
 int32_t srs_generate_dispatch(int curve, const uint32_t* beta_canon, uint64_t n, uint32_t* d_out);
 void jac_to_affine_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uint64_t* xy);
 void jac_sum_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uint64_t* out);

@@ -1,5 +1,6 @@
 // msm.hip -- host side of the MSM: pipeline launches, the host Horner tail, testing SRS.
 #include <algorithm>
+#include <chrono>
 #include <thread>
 #include <vector>
 
@@ -300,6 +301,8 @@ int32_t srs_build_pre_t(Srs& s, hipStream_t st) {
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
     if ((size_t)W * level * 4 > free_b / 2) { s.pre_c = -1; return MZK_OK; }      // not worth half the free HBM
     HIP_TRY(hipMalloc((void**)&s.d_pre, (size_t)W * level * 4));
+    HIP_TRY(hipStreamSynchronize(st));
+    const auto t_build = std::chrono::steady_clock::now();
     HIP_TRY(hipMemcpyAsync(s.d_pre, s.d_int, level * 4, hipMemcpyDeviceToDevice, st));
     const unsigned long long threads = (s.n + 3) / 4;
     for (int w = 1; w < W; w++)
@@ -307,15 +310,16 @@ int32_t srs_build_pre_t(Srs& s, hipStream_t st) {
                            s.d_pre + (size_t)(w - 1) * level, s.d_pre + (size_t)w * level, (unsigned long long)s.n, c);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipStreamSynchronize(st));
+    s.pre_build_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_build).count();
     s.pre_c = c;
+    s.pre_levels = W;
     return MZK_OK;
 }
+}  // namespace
 int32_t srs_build_pre(Srs& s, hipStream_t st) {
     if (s.d_pre || s.pre_c < 0 || !s.d_int) return MZK_OK;
     return s.curve == MZK_CURVE_BLS12_381 ? srs_build_pre_t<BlsFqX>(s, st) : srs_build_pre_t<BnFqX>(s, st);
 }
-
-}  // namespace
 
 int32_t msm_dispatch(const Srs& s, uint64_t base_offset, const uint32_t* d_scalars, uint64_t n, int is_mont, uint32_t* out, hipStream_t st) {
     const uint32_t* sc[1] = {d_scalars};

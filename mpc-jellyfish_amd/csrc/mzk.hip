@@ -1,5 +1,6 @@
 // mzk.hip -- libmi355zk: the C ABI (include/mzk.h) and the state shared by ntt.hip / msm.hip.
 // One process drives one GPU; entry points are serialised on a lock and enqueue on one stream.
+#include <condition_variable>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -75,27 +76,68 @@ int g_device = -1;
 std::map<uint64_t, Srs> g_srs;
 uint64_t g_next_handle = 1;
 
-int32_t msm_host_locked(const Srs& s, uint64_t base_offset, const uint64_t* scalars, uint64_t n, int32_t is_mont, uint64_t* out) {
-    if (!out || (!scalars && n)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
-    if (base_offset > s.n || n > s.n - base_offset) {
-        set_error("MSM longer than the registered SRS (poly degree larger than allowed)");
-        return MZK_ERR_INVALID_ARG;
-    }
-    hipStream_t st = nullptr;
-    if (n) {
-        // the upload buffer is private to host-pointer calls; it is consumed before ws_release
-        MZK_TRY(ws_acquire(st));
-        MZK_TRY(g_ws.scalars.reserve(n * 32));
-        HIP_TRY(hipMemcpyAsync(g_ws.scalars.p, scalars, n * 32, hipMemcpyHostToDevice, st));
-        MZK_TRY(ws_release(st));
-    }
-    return msm_dispatch(s, base_offset, g_ws.scalars.as<uint32_t>(), n, is_mont != 0, reinterpret_cast<uint32_t*>(out), st);
-}
-
 int32_t require_init() {
     if (!g_init) { set_error("mzk_init has not been called"); return MZK_ERR_NOT_INIT; }
     HIP_TRY(hipSetDevice(g_device));
     return MZK_OK;
+}
+
+// ---- host-pointer I/O slots ------------------------------------------------------------------------
+// The host-pointer entry points (mzk_ntt, mzk_ntt_batch, mzk_msm, mzk_msm_batch: what a shim that swaps only the two
+// third-party call sites uses) move their operands over PCIe.  Each call -- or each polynomial of a
+// batch -- takes one of IO_SLOTS slots: a non-blocking stream plus a device buffer.  Upload, kernels and download of one
+// polynomial are enqueued on its slot's stream; the global lock is held only while the kernels are ENQUEUED (plan cache and
+// shared workspace; ws_acquire / ws_release order the kernels of different streams on the shared scratch), never across a
+// transfer or a wait.  So the upload of polynomial k+1 and the download of k-1 overlap the transform of k -- inside one batch
+// call and between concurrent callers (the reference commits and transforms from a Rayon par_iter, prover.rs:552-562,
+// univariate_kzg/mod.rs:125-127).  Transfers are asynchronous when the host memory is page-locked (mzk_host_alloc /
+// mzk_host_register); from pageable memory the runtime stages them and the enqueue blocks, which is still correct.
+constexpr int IO_SLOTS = 4;
+struct IoSlot {
+    hipStream_t st = nullptr;
+    DevBuf buf;
+    bool busy = false;
+};
+IoSlot g_io[IO_SLOTS];
+std::mutex g_io_lock;
+std::condition_variable g_io_cv;
+
+int32_t io_acquire(int* out_idx) {
+    std::unique_lock<std::mutex> lk(g_io_lock);
+    int idx = -1;
+    g_io_cv.wait(lk, [&] {
+        for (int i = 0; i < IO_SLOTS; i++)
+            if (!g_io[i].busy) { idx = i; return true; }
+        return false;
+    });
+    g_io[idx].busy = true;
+    lk.unlock();
+    if (!g_io[idx].st) {
+        hipError_t e = hipStreamCreateWithFlags(&g_io[idx].st, hipStreamNonBlocking);
+        if (e != hipSuccess) {
+            { std::lock_guard<std::mutex> g(g_io_lock); g_io[idx].busy = false; }
+            g_io_cv.notify_one();
+            set_error(std::string("hipStreamCreate: ") + hipGetErrorString(e));
+            return MZK_ERR_HIP;
+        }
+    }
+    *out_idx = idx;
+    return MZK_OK;
+}
+void io_release(int idx) {
+    { std::lock_guard<std::mutex> g(g_io_lock); g_io[idx].busy = false; }
+    g_io_cv.notify_one();
+}
+struct IoGuard {                      // releases the slot on every return path
+    int idx = -1;
+    ~IoGuard() { if (idx >= 0) io_release(idx); }
+};
+void io_release_all() {
+    for (auto& sl : g_io) {
+        if (sl.st) { (void)hipStreamSynchronize(sl.st); (void)hipStreamDestroy(sl.st); sl.st = nullptr; }
+        sl.buf.release();
+        sl.busy = false;
+    }
 }
 
 }  // namespace
@@ -132,6 +174,7 @@ int32_t mzk_shutdown(void) {
     (void)hipDeviceSynchronize();
     for (auto& kv : g_srs) { (void)hipFree(kv.second.d_xy); if (kv.second.d_int) (void)hipFree(kv.second.d_int); if (kv.second.d_pre) (void)hipFree(kv.second.d_pre); }
     g_srs.clear();
+    io_release_all();
     ntt_release_plans();
     plonk_release_all();
     for (auto& r : g_prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
@@ -250,12 +293,38 @@ int32_t mzk_msm_dev(uint64_t srs_handle, uint64_t base_offset, const void* d_sca
                         reinterpret_cast<uint32_t*>(out_xyz_mont), (hipStream_t)stream);
 }
 
-int32_t mzk_msm(uint64_t srs_handle, uint64_t base_offset, const uint64_t* scalars, uint64_t n, int32_t scalars_are_mont, uint64_t* out_xyz_mont) {
-    std::lock_guard<std::mutex> lk(g_lock);
+// host scalars: upload on an I/O slot outside the lock (it overlaps whatever MSM or NTT another caller is running), compute under it
+static int32_t msm_host(uint64_t srs_handle, uint64_t base_offset, const uint64_t* scalars, uint64_t n, int32_t is_mont, uint64_t* out, int* out_curve) {
     MZK_TRY(require_init());
-    auto it = g_srs.find(srs_handle);
-    if (it == g_srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
-    return msm_host_locked(it->second, base_offset, scalars, n, scalars_are_mont, out_xyz_mont);
+    if (!out || (!scalars && n)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    {   // nothing is read from `scalars` before the range has been checked against the SRS
+        std::lock_guard<std::mutex> lk(g_lock);
+        auto it = g_srs.find(srs_handle);
+        if (it == g_srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+        if (base_offset > it->second.n || n > it->second.n - base_offset) {
+            set_error("MSM longer than the registered SRS (poly degree larger than allowed)");
+            return MZK_ERR_INVALID_ARG;
+        }
+        if (n >= (1ull << 27)) { set_error("MSM size must be < 2^27"); return MZK_ERR_INVALID_ARG; }
+    }
+    IoGuard slot;
+    MZK_TRY(io_acquire(&slot.idx));
+    IoSlot& io = g_io[slot.idx];
+    if (n) {
+        MZK_TRY(io.buf.reserve(n * 32));
+        HIP_TRY(hipMemcpyAsync(io.buf.p, scalars, n * 32, hipMemcpyHostToDevice, io.st));
+    }
+    std::lock_guard<std::mutex> lk(g_lock);
+    auto it = g_srs.find(srs_handle);                                // released by another thread meanwhile?
+    if (it == g_srs.end()) { (void)hipStreamSynchronize(io.st); set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+    if (out_curve) *out_curve = it->second.curve;
+    const int32_t rc = msm_dispatch(it->second, base_offset, io.buf.as<uint32_t>(), n, is_mont != 0, reinterpret_cast<uint32_t*>(out), io.st);
+    if (rc != MZK_OK) (void)hipStreamSynchronize(io.st);          // the slot's buffer must be idle before it is handed on
+    return rc;
+}
+
+int32_t mzk_msm(uint64_t srs_handle, uint64_t base_offset, const uint64_t* scalars, uint64_t n, int32_t scalars_are_mont, uint64_t* out_xyz_mont) {
+    return msm_host(srs_handle, base_offset, scalars, n, scalars_are_mont, out_xyz_mont, nullptr);
 }
 
 int32_t mzk_msm_batch_dev(uint64_t srs_handle, uint32_t n_polys, const void* const* d_scalars, const uint64_t* lens, const uint64_t* base_offsets,
@@ -271,43 +340,51 @@ int32_t mzk_msm_batch_dev(uint64_t srs_handle, uint32_t n_polys, const void* con
 
 int32_t mzk_msm_batch(uint64_t srs_handle, uint32_t n_polys, const uint64_t* const* scalars, const uint64_t* lens, const uint64_t* base_offsets,
                       int32_t scalars_are_mont, uint64_t* out_xyz_mont) {
-    std::lock_guard<std::mutex> lk(g_lock);
     MZK_TRY(require_init());
-    auto it = g_srs.find(srs_handle);
-    if (it == g_srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
     if (n_polys && (!scalars || !lens || !out_xyz_mont)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
-    // one upload slab, then the fused batch
-    hipStream_t st = nullptr;
     uint64_t total = 0;
     for (uint32_t i = 0; i < n_polys; i++) {
         if (lens[i] && !scalars[i]) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+        if (lens[i] >= (1ull << 27)) { set_error("MSM size must be < 2^27"); return MZK_ERR_INVALID_ARG; }
         total += lens[i];
     }
-    MZK_TRY(ws_acquire(st));
-    MZK_TRY(g_ws.scalars.reserve((total ? total : 1) * 32));
+    {   // nothing is read from the scalar arrays before the ranges have been checked against the SRS
+        std::lock_guard<std::mutex> lk(g_lock);
+        auto it = g_srs.find(srs_handle);
+        if (it == g_srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+        for (uint32_t i = 0; i < n_polys; i++) {
+            const uint64_t off = base_offsets ? base_offsets[i] : 0;
+            if (off > it->second.n || lens[i] > it->second.n - off) {
+                set_error("MSM longer than the registered SRS (poly degree larger than allowed)");
+                return MZK_ERR_INVALID_ARG;
+            }
+        }
+    }
+    // one upload slab on an I/O slot (outside the lock), then the fused batch
+    IoGuard slot;
+    MZK_TRY(io_acquire(&slot.idx));
+    IoSlot& io = g_io[slot.idx];
+    MZK_TRY(io.buf.reserve((total ? total : 1) * 32));
     std::vector<const uint32_t*> dptr(n_polys);
     uint64_t off = 0;
     for (uint32_t i = 0; i < n_polys; i++) {
-        dptr[i] = g_ws.scalars.as<uint32_t>() + off * 8;
-        if (lens[i]) HIP_TRY(hipMemcpyAsync(const_cast<uint32_t*>(dptr[i]), scalars[i], lens[i] * 32, hipMemcpyHostToDevice, st));
+        dptr[i] = io.buf.as<uint32_t>() + off * 8;
+        if (lens[i]) HIP_TRY(hipMemcpyAsync(const_cast<uint32_t*>(dptr[i]), scalars[i], lens[i] * 32, hipMemcpyHostToDevice, io.st));
         off += lens[i];
     }
-    MZK_TRY(ws_release(st));
-    return msm_batch_dispatch(it->second, n_polys, dptr.data(), lens, base_offsets, scalars_are_mont != 0, reinterpret_cast<uint32_t*>(out_xyz_mont), st);
+    std::lock_guard<std::mutex> lk(g_lock);
+    auto it = g_srs.find(srs_handle);
+    if (it == g_srs.end()) { (void)hipStreamSynchronize(io.st); set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+    const int32_t rc = msm_batch_dispatch(it->second, n_polys, dptr.data(), lens, base_offsets, scalars_are_mont != 0, reinterpret_cast<uint32_t*>(out_xyz_mont), io.st);
+    if (rc != MZK_OK) (void)hipStreamSynchronize(io.st);
+    return rc;
 }
 
 int32_t mzk_msm_affine(uint64_t srs_handle, uint64_t base_offset, const uint64_t* scalars, uint64_t n, int32_t scalars_are_mont, uint64_t* out_xy_mont) {
     uint64_t xyz[18];
-    int curve;
-    {
-        std::lock_guard<std::mutex> lk(g_lock);
-        MZK_TRY(require_init());
-        auto it = g_srs.find(srs_handle);
-        if (it == g_srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
-        if (!out_xy_mont) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
-        curve = it->second.curve;
-        MZK_TRY(msm_host_locked(it->second, base_offset, scalars, n, scalars_are_mont, xyz));
-    }
+    int curve = 0;
+    if (!out_xy_mont) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    MZK_TRY(msm_host(srs_handle, base_offset, scalars, n, scalars_are_mont, xyz, &curve));
     jac_to_affine_host_dispatch(curve, xyz, 1, out_xy_mont);
     return MZK_OK;
 }
@@ -338,24 +415,38 @@ int32_t mzk_ntt_dev(int32_t curve_id, void* d_data_mont, uint64_t in_len, uint32
 
 int32_t mzk_ntt_batch(int32_t curve_id, uint32_t n_polys, uint64_t* const* data_mont, const uint64_t* in_lens, uint32_t log_n, int32_t inverse,
                       const uint64_t* coset_offset_mont) {
-    std::lock_guard<std::mutex> lk(g_lock);
     MZK_TRY(require_init());
     if (log_n > 30) { set_error("log_n out of range"); return MZK_ERR_INVALID_ARG; }
     if (n_polys && (!data_mont || !in_lens)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    for (uint32_t i = 0; i < n_polys; i++)
+        if (!data_mont[i]) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     const uint64_t N = 1ull << log_n;
-    hipStream_t st = nullptr;
-    for (uint32_t i = 0; i < n_polys; i++) {
-        const uint64_t len = in_lens[i] < N ? in_lens[i] : N;
-        MZK_TRY(ws_acquire(st));
-        MZK_TRY(g_ws.io.reserve(N * 32));
-        if (len) HIP_TRY(hipMemcpyAsync(g_ws.io.p, data_mont[i], len * 32, hipMemcpyHostToDevice, st));
-        MZK_TRY(ws_release(st));
-        MZK_TRY(ntt_dispatch(curve_id, g_ws.io.as<uint32_t>(), len, (int)log_n, inverse != 0,
-                             reinterpret_cast<const uint32_t*>(coset_offset_mont), 1, N, st));
-        HIP_TRY(hipMemcpyAsync(data_mont[i], g_ws.io.p, N * 32, hipMemcpyDeviceToHost, st));
-        HIP_TRY(hipStreamSynchronize(st));
+    // polynomial i runs on slot i mod (slots this call could get): upload, passes and download are enqueued on the slot's stream,
+    // the lock is taken for the enqueue of the passes only, and a slot is waited for only when it comes round again
+    constexpr int PIPE = 3;
+    IoGuard slot[PIPE];
+    const int n_slots = (int)(n_polys < (uint32_t)PIPE ? n_polys : (uint32_t)PIPE);
+    for (int k = 0; k < n_slots; k++) {
+        MZK_TRY(io_acquire(&slot[k].idx));
+        MZK_TRY(g_io[slot[k].idx].buf.reserve(N * 32));
     }
-    return MZK_OK;
+    int32_t rc = MZK_OK;
+    for (uint32_t i = 0; i < n_polys && rc == MZK_OK; i++) {
+        IoSlot& io = g_io[slot[i % n_slots].idx];
+        if (i >= (uint32_t)n_slots) HIP_TRY(hipStreamSynchronize(io.st));               // its previous polynomial has left the device
+        const uint64_t len = in_lens[i] < N ? in_lens[i] : N;
+        if (len) HIP_TRY(hipMemcpyAsync(io.buf.p, data_mont[i], len * 32, hipMemcpyHostToDevice, io.st));
+        {
+            std::lock_guard<std::mutex> lk(g_lock);
+            rc = ntt_dispatch(curve_id, io.buf.as<uint32_t>(), len, (int)log_n, inverse != 0, reinterpret_cast<const uint32_t*>(coset_offset_mont), 1, N, io.st);
+        }
+        if (rc == MZK_OK) HIP_TRY(hipMemcpyAsync(data_mont[i], io.buf.p, N * 32, hipMemcpyDeviceToHost, io.st));
+    }
+    for (int k = 0; k < n_slots; k++) {
+        const hipError_t e = hipStreamSynchronize(g_io[slot[k].idx].st);
+        if (e != hipSuccess && rc == MZK_OK) { set_error(std::string("hipStreamSynchronize: ") + hipGetErrorString(e)); rc = MZK_ERR_HIP; }
+    }
+    return rc;
 }
 
 int32_t mzk_ntt(int32_t curve_id, uint64_t* data_mont, uint64_t in_len, uint32_t log_n, int32_t inverse, const uint64_t* coset_offset_mont) {
@@ -570,6 +661,31 @@ int32_t mzk_poly_div_roots_dev(int32_t curve_id, const void* d_poly, uint64_t le
                                    (hipStream_t)stream);
 }
 
+// ---- page-locked host memory for the host-pointer entry points ------------------------------------------
+int32_t mzk_host_alloc(uint64_t bytes, void** out_ptr) {
+    MZK_TRY(require_init());
+    if (!out_ptr) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    HIP_TRY(hipHostMalloc(out_ptr, bytes ? bytes : 1, hipHostMallocDefault));
+    return MZK_OK;
+}
+int32_t mzk_host_free(void* ptr) {
+    MZK_TRY(require_init());
+    if (ptr) HIP_TRY(hipHostFree(ptr));
+    return MZK_OK;
+}
+int32_t mzk_host_register(void* ptr, uint64_t bytes) {
+    MZK_TRY(require_init());
+    if (!ptr || !bytes) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
+    return MZK_OK;
+}
+int32_t mzk_host_unregister(void* ptr) {
+    MZK_TRY(require_init());
+    if (!ptr) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    HIP_TRY(hipHostUnregister(ptr));
+    return MZK_OK;
+}
+
 // ---- device memory helpers --------------------------------------------------------------------------
 int32_t mzk_dev_alloc(uint64_t bytes, void** out_dptr) {
     std::lock_guard<std::mutex> lk(g_lock);
@@ -657,6 +773,21 @@ int32_t mzk_profile_reset(void) {
 int32_t mzk_msm_set_precompute(int32_t on) {
     std::lock_guard<std::mutex> lk(g_lock);
     g_msm_precompute = on != 0;
+    return MZK_OK;
+}
+int32_t mzk_srs_precompute(uint64_t srs_handle, uint32_t* out_window_bits, uint32_t* out_levels, uint64_t* out_table_bytes, double* out_build_ms) {
+    std::lock_guard<std::mutex> lk(g_lock);
+    MZK_TRY(require_init());
+    auto it = g_srs.find(srs_handle);
+    if (it == g_srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+    Srs& s = it->second;
+    MZK_TRY(srs_build_pre(s, nullptr));
+    const bool have = s.d_pre != nullptr && s.pre_c > 0;
+    const uint64_t aff_bytes = (s.curve == MZK_CURVE_BLS12_381 ? 28u : 20u) * 4u;       // EcFx::AFF_WORDS: 2 x 14 / 2 x 10 limbs of 29 bits
+    if (out_window_bits) *out_window_bits = have ? (uint32_t)s.pre_c : 0u;
+    if (out_levels) *out_levels = have ? (uint32_t)s.pre_levels : 0u;
+    if (out_table_bytes) *out_table_bytes = have ? (uint64_t)s.pre_levels * s.n * aff_bytes : 0u;
+    if (out_build_ms) *out_build_ms = have ? s.pre_build_ms : 0.0;
     return MZK_OK;
 }
 int32_t mzk_msm_last_shape(uint32_t* out_window_bits, uint32_t* out_windows, uint32_t* out_buckets) {

@@ -70,7 +70,12 @@ _SIGS = {
     "mzk_profile_enable": [C.c_int32],
     "mzk_profile_get": [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
     "mzk_profile_reset": [],
+    "mzk_host_alloc": [C.c_uint64, C.POINTER(C.c_void_p)],
+    "mzk_host_free": [C.c_void_p],
+    "mzk_host_register": [C.c_void_p, C.c_uint64],
+    "mzk_host_unregister": [C.c_void_p],
     "mzk_msm_set_precompute": [C.c_int32],
+    "mzk_srs_precompute": [C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_double)],
     "mzk_msm_last_shape": [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
 }
 _STR_FUNCS = ("mzk_strerror", "mzk_last_error", "mzk_version")

@@ -38,6 +38,7 @@ def prove_turbo(curve: int, r: int, fr_generator: int, log_n: int, selector_vals
     bm, gm, am = (_mont(curve, r, [x])[0] for x in (beta, gamma, alpha))
     sel = np.stack([ntt(selector_vals[i], True) for i in range(13)])
     sig = np.stack([ntt(sigma_vals[i], True) for i in range(W)])
+    t_prove = time.perf_counter()                                        # what precedes is `preprocess` (snark.rs:529-617), not `prove`
 
     def mask(poly, b):                                                   # prover.rs:463-486
         out = np.zeros((n + len(b), 4), dtype=np.uint64)
@@ -113,7 +114,8 @@ def prove_turbo(curve: int, r: int, fr_generator: int, log_n: int, selector_vals
     opening = cref.poly_div_linear(curve, lincomb(bt), _mont(curve, r, [zeta])[0])
     shifted = cref.poly_div_linear(curve, z_poly, _mont(curve, r, [zeta * w_n % r])[0])
     return {"wires_comms": wires_comms, "z_comm": z_comm, "split_comms": split_comms, "opening": commit(opening), "shifted": commit(shifted),
-            "wires_evals": we, "wire_sigma_evals": se, "perm_next_eval": perm_next, "seconds": time.perf_counter() - t_start}
+            "wires_evals": we, "wire_sigma_evals": se, "perm_next_eval": perm_next, "seconds": time.perf_counter() - t_start,
+            "prove_seconds": time.perf_counter() - t_prove}
 
 
 def prove_ultra(curve: int, r: int, fr_generator: int, log_n: int, selector_vals, sigma_vals, table_vals, k, wire_vals, pi_vals, blind, ch, srs_xy, threads: int = 1):
