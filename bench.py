@@ -248,7 +248,8 @@ def main():
                                      "no per-SRS set-up -- what `VariableBaseMSM::msm_bigint` (univariate_kzg/mod.rs:109-111) is",
                              "value": world * n * args.steps / vb_el, "unit": "pairs/s", "ms_per_step": vb_el / args.steps * 1e3,
                              "window_bits": vc, "windows": vw, "buckets_per_window": vm, "phases_ms": vb_phases,
-                             "same_point_as_table_path": bool(np.array_equal(np.asarray(vb_res), np.asarray(result))) if world == 1 else None,
+                             "same_point_as_table_path": bool(np.array_equal(mj.kzg.jacobian_to_affine(curve, np.asarray(vb_res).reshape(1, -1)),
+                                                                             mj.kzg.jacobian_to_affine(curve, np.asarray(result).reshape(1, -1)))),
                              "roofline": msm_roofline(vb_acc, vw, "msm_accumulate_plain")}
 
     # ---- secondary: batch_commit of 5 polynomials (round 1 / round 3 of a proof) in one fused call -----
@@ -606,6 +607,7 @@ def main():
             ckm.release()
             return {"log_n": lg, "ms": round(cm_["prove_seconds"] * 1e3, 1), "cores": cpu_threads, "gpu_ms": round(gpu_ms, 2),
                     "gpu_over_cpu": round(cm_["prove_seconds"] * 1e3 / gpu_ms, 1), "matches_gpu": ok,
+                    "cpu_spent_s": cm_.get("spent_seconds"),
                     "sample": "ONE TurboPlonk proof of the 2^%d-gate bench circuit over BLS12-381 by the C restatement (oracle/cref_prover.py: ark-poly "
                               "style FFTs, ark-ec style Pippenger with its window rule, the reference's serial grand product and per-point quotient "
                               "closure; `preprocess` work excluded) on %d threads, vs the device prover (Python-orchestrated, proving key resident) on the "

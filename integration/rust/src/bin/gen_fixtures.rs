@@ -1,0 +1,194 @@
+//! gen_fixtures -- reference-side fixtures for the parity tests of mi355-zk.
+//!
+//! Reads the INPUTS of the committed vectors `tests/golden/{ntt,msm,kzg,proof}_vectors.json` (made by
+//! `tests/golden/make_golden.py` / `make_proof_golden.py` from the big-int restatements under `oracle/`), runs the
+//! REFERENCE's own code on them -- ark-poly `Radix2EvaluationDomain::{fft, ifft}`, ark-ec `VariableBaseMSM::msm_bigint`,
+//! `UnivariateKzgPCS::commit`, `PlonkKzgSnark::{preprocess, prove}` with `jf_utils::test_rng` and `StandardTranscript` --
+//! and writes `tests/golden/ref_{ntt,msm,kzg,proof}_vectors.json` in the same schema.  When those files exist,
+//! `tests/test_oracle.py::test_reference_fixtures_*` and `tests/test_golden_proofs.py` compare the restatements' vectors with
+//! them field by field; that comparison is what pins the oracle to the reference's outputs.
+//!
+//!     cd integration/rust && cargo run --release --features fixtures --bin gen_fixtures -- ../../tests/golden
+//!
+//! SRS of the proof cases: the repo's vectors use `powers_of_g[i] = beta^i * G` with G the curve's standard generator and
+//! beta = the FIRST draw of `test_rng`.  `universal_setup_for_testing` (plonk/src/proof_system/snark.rs:485-526) draws beta the
+//! same way but then takes g = G1::rand(rng), h = G2::rand(rng): a different SRS and two more groups of draws before the
+//! blinders.  `prove` is the path under test, the testing setup is not, so the SRS is rebuilt here from (beta, G) and the same
+//! rng continues into `prove` -- exactly the sequence of `make_proof_golden.py`.
+//!
+//! NOT COMPILED in this repository's build image (no Rust toolchain); see README.md.
+use ark_ec::{pairing::Pairing, AffineRepr, CurveGroup, VariableBaseMSM};
+use ark_ff::{BigInt, BigInteger, PrimeField, UniformRand, Zero};
+use ark_poly::{univariate::DensePolynomial, DenseUVPolynomial, EvaluationDomain, Radix2EvaluationDomain};
+use ark_serialize::CanonicalSerialize;
+use jf_primitives::pcs::{
+    prelude::{UnivariateKzgPCS, UnivariateProverParam, UnivariateUniversalParams},
+    PolynomialCommitmentScheme,
+};
+use mpc_plonk::{
+    proof_system::{PlonkKzgSnark, UniversalSNARK},
+    transcript::StandardTranscript,
+};
+use mpc_relation::{traits::*, PlonkCircuit};
+use num_bigint::BigUint;
+use serde_json::{json, Value};
+use std::{fs, path::Path};
+
+fn big(hex: &str) -> BigUint {
+    BigUint::parse_bytes(hex.as_bytes(), 16).expect("hex integer")
+}
+fn fe<F: PrimeField>(hex: &str) -> F {
+    F::from(big(hex))
+}
+fn hx<F: PrimeField>(x: &F) -> String {
+    let b: BigUint = x.into_bigint().into();
+    format!("{:x}", b)
+}
+/// a plain 256-bit integer (msm_bigint takes integers, not field elements: a scalar may exceed r)
+fn bigint4(hex: &str) -> BigInt<4> {
+    let digits = big(hex).to_u64_digits();
+    let mut l = [0u64; 4];
+    l[..digits.len()].copy_from_slice(&digits);
+    BigInt::new(l)
+}
+fn strs(v: &Value) -> Vec<&str> {
+    v.as_array().unwrap().iter().map(|s| s.as_str().unwrap()).collect()
+}
+
+macro_rules! curve_fixtures {
+    ($modname:ident, $engine:ty, $fr:ty, $fq:ty, $g1a:ty, $g1:ty, $g2:ty) => {
+        mod $modname {
+            use super::*;
+            type E = $engine;
+            type Fr = $fr;
+            type Fq = $fq;
+            type G1Affine = $g1a;
+            type G1 = $g1;
+            type G2 = $g2;
+
+            fn point(v: &Value) -> G1Affine {
+                if v.is_null() {
+                    return G1Affine::identity();
+                }
+                let xy = strs(v);
+                G1Affine::new_unchecked(fe::<Fq>(xy[0]), fe::<Fq>(xy[1]))
+            }
+            fn point_json(p: &G1Affine) -> Value {
+                match p.xy() {
+                    Some((x, y)) => json!([hx(x), hx(y)]),
+                    None => Value::Null,
+                }
+            }
+            fn g1_hex(p: &G1Affine) -> String {
+                let mut b = Vec::new();
+                p.serialize_compressed(&mut b).unwrap();
+                hex::encode(b)
+            }
+
+            /// `Radix2EvaluationDomain::{fft, ifft}` on the generator coset or on H itself
+            pub fn ntt(case: &Value) -> Value {
+                let log_n = case["log_n"].as_u64().unwrap() as usize;
+                let offset: Fr = fe(case["offset"].as_str().unwrap());
+                let input: Vec<Fr> = strs(&case["input"]).into_iter().map(fe::<Fr>).collect();
+                let h = Radix2EvaluationDomain::<Fr>::new(1 << log_n).unwrap();
+                let d = if offset == Fr::from(1u64) { h } else { h.get_coset(offset).unwrap() };
+                let fwd = d.fft(&input);
+                let inv = d.ifft(&input);
+                let mut out = case.clone();
+                out["forward"] = json!(fwd.iter().map(hx).collect::<Vec<_>>());
+                out["inverse"] = json!(inv.iter().map(hx).collect::<Vec<_>>());
+                out
+            }
+
+            /// `VariableBaseMSM::msm_bigint`, then `into_affine` as the call sites do (univariate_kzg/mod.rs:109-111)
+            pub fn msm(case: &Value) -> Value {
+                let bases: Vec<G1Affine> = case["bases"].as_array().unwrap().iter().map(point).collect();
+                let scalars: Vec<BigInt<4>> = strs(&case["scalars"]).into_iter().map(bigint4).collect();
+                let res = <G1 as VariableBaseMSM>::msm_bigint(&bases, &scalars).into_affine();
+                let mut out = case.clone();
+                out["result"] = point_json(&res);
+                out
+            }
+
+            /// `UnivariateKzgPCS::commit` over the vector's SRS
+            pub fn kzg(case: &Value) -> Value {
+                let srs: Vec<G1Affine> = case["srs"].as_array().unwrap().iter().map(point).collect();
+                let coeffs: Vec<Fr> = strs(&case["coeffs"]).into_iter().map(fe::<Fr>).collect();
+                let pp = UnivariateProverParam::<E> { powers_of_g: srs };
+                let poly = DensePolynomial::from_coefficients_vec(coeffs);
+                let com = UnivariateKzgPCS::<E>::commit(&pp, &poly).unwrap();
+                let mut out = case.clone();
+                out["commitment"] = point_json(&com.0);
+                out
+            }
+
+            /// bench.rs:29-46 with the range_bit_len of the vector; `test_rng`: SRS trapdoor first, then `prove`'s own draws
+            pub fn proof(case: &Value) -> Value {
+                let num_gates = case["num_gates"].as_u64().unwrap() as usize;
+                let ultra = case["plonk_type"].as_str().unwrap() == "UltraPlonk";
+                let range_bits = case["range_bit_len"].as_u64().unwrap() as usize;
+                let mut cs: PlonkCircuit<Fr> = if ultra { PlonkCircuit::new_ultra_plonk(range_bits) } else { PlonkCircuit::new_turbo_plonk() };
+                let mut a = cs.zero();
+                for _ in 0..num_gates - 10 {
+                    a = cs.add(a, cs.one()).unwrap();
+                }
+                cs.finalize_for_arithmetization().unwrap();
+                let n = cs.eval_domain_size().unwrap();
+                assert_eq!(n as u64, case["domain_size"].as_u64().unwrap(), "domain size");
+
+                let rng = &mut jf_utils::test_rng();
+                let beta = Fr::rand(rng);
+                assert_eq!(hx(&beta), case["srs_beta"].as_str().unwrap(), "first draw of test_rng");
+                let (g, h) = (G1::generator(), G2::generator());
+                let mut powers = Vec::with_capacity(n + 3);
+                let mut cur = g;
+                for _ in 0..n + 3 {
+                    powers.push(cur);
+                    cur *= beta;
+                }
+                let srs = UnivariateUniversalParams::<E> {
+                    powers_of_g: G1::normalize_batch(&powers),
+                    h: h.into_affine(),
+                    beta_h: (h * beta).into_affine(),
+                };
+                let (pk, vk) = PlonkKzgSnark::<E>::preprocess(&srs, &cs).unwrap();
+                let proof = PlonkKzgSnark::<E>::prove::<_, _, StandardTranscript>(rng, &cs, &pk, None).unwrap();
+                let mut bytes = Vec::new();
+                proof.serialize_compressed(&mut bytes).unwrap();
+                let mut vk_bytes = Vec::new();
+                vk.serialize_compressed(&mut vk_bytes).unwrap();
+                let mut out = case.clone();
+                out["k"] = json!(vk.k.iter().map(hx).collect::<Vec<_>>());
+                out["selector_comms"] = json!(vk.selector_comms.iter().map(|c| g1_hex(&c.0)).collect::<Vec<_>>());
+                out["sigma_comms"] = json!(vk.sigma_comms.iter().map(|c| g1_hex(&c.0)).collect::<Vec<_>>());
+                out["proof"] = json!(hex::encode(bytes));
+                out["vk_serialized"] = json!(hex::encode(vk_bytes));
+                out.as_object_mut().unwrap().remove("challenges");       // not observable through the reference's public API
+                out.as_object_mut().unwrap().remove("plookup_comms");    // PlookupVerifyingKey's fields are pub(crate): see vk_serialized
+                out
+            }
+        }
+    };
+}
+
+curve_fixtures!(bls, ark_bls12_381::Bls12_381, ark_bls12_381::Fr, ark_bls12_381::Fq, ark_bls12_381::G1Affine, ark_bls12_381::G1Projective,
+                ark_bls12_381::G2Projective);
+curve_fixtures!(bn, ark_bn254::Bn254, ark_bn254::Fr, ark_bn254::Fq, ark_bn254::G1Affine, ark_bn254::G1Projective, ark_bn254::G2Projective);
+
+fn run(dir: &Path, name: &str, f0: fn(&Value) -> Value, f1: fn(&Value) -> Value) {
+    let text = fs::read_to_string(dir.join(format!("{name}.json"))).expect("golden vector file");
+    let cases: Vec<Value> = serde_json::from_str(&text).unwrap();
+    let out: Vec<Value> = cases.iter().map(|c| if c["curve"].as_u64().unwrap() == 0 { f0(c) } else { f1(c) }).collect();
+    fs::write(dir.join(format!("ref_{name}.json")), serde_json::to_string(&out).unwrap()).unwrap();
+    println!("ref_{name}.json: {} cases", out.len());
+}
+
+fn main() {
+    let dir = std::env::args().nth(1).unwrap_or_else(|| "../../tests/golden".to_string());
+    let dir = Path::new(&dir);
+    run(dir, "ntt_vectors", bls::ntt, bn::ntt);
+    run(dir, "msm_vectors", bls::msm, bn::msm);
+    run(dir, "kzg_vectors", bls::kzg, bn::kzg);
+    run(dir, "proof_vectors", bls::proof, bn::proof);
+    let _ = BigInt::<4>::zero().is_zero();
+}

@@ -32,7 +32,14 @@ def prove_turbo(curve: int, r: int, fr_generator: int, log_n: int, selector_vals
     t_start = time.perf_counter()
     n = 1 << log_n
     W = 5
-    ntt = lambda a, inverse, coset=None, lg=log_n: cref.ntt(curve, a, lg, inverse, coset, threads=threads)
+    spent = {"ntt": 0.0, "msm": 0.0, "quotient_round": 0.0, "grand_product": 0.0}
+
+    def timed(key, fn, *a, **kw):
+        t0 = time.perf_counter()
+        out = fn(*a, **kw)
+        spent[key] += time.perf_counter() - t0
+        return out
+    ntt = lambda a, inverse, coset=None, lg=log_n: timed("ntt", cref.ntt, curve, a, lg, inverse, coset, threads=threads)
     k_m = _mont(curve, r, k)
     beta, gamma, alpha, zeta, v = (ch[x] for x in ("beta", "gamma", "alpha", "zeta", "v"))
     bm, gm, am = (_mont(curve, r, [x])[0] for x in (beta, gamma, alpha))
@@ -48,13 +55,14 @@ def prove_turbo(curve: int, r: int, fr_generator: int, log_n: int, selector_vals
         out[n:] = _mont(curve, r, b)
         return out
 
-    commit = lambda p: cref.jac_to_affine(curve, cref.msm(curve, srs_xy[:p.shape[0]], p, scalars_are_mont=True, threads=threads))[0]
+    commit = lambda p: cref.jac_to_affine(curve, timed("msm", cref.msm, curve, srs_xy[:p.shape[0]], p, scalars_are_mont=True, threads=threads))[0]
     # round 1
     wire_polys = [mask(ntt(wire_vals[i], True), blind["wires"][i]) for i in range(W)]
     pi_poly = ntt(pi_vals, True)
     wires_comms = [commit(p) for p in wire_polys]
     # round 2 (constraint_system.rs:1197-1223)
-    z_poly = mask(cref.plonk_perm_product(curve, log_n, np.stack(wire_vals), np.stack(sigma_vals), k_m, bm, gm, threads=threads), blind["z"])
+    z_poly = mask(timed("grand_product", cref.plonk_perm_product, curve, log_n, np.stack(wire_vals), np.stack(sigma_vals), k_m, bm, gm, threads=threads),
+                  blind["z"])
     z_comm = commit(z_poly)
     # round 3 (prover.rs:512-673, 902-960)
     slab = np.zeros((25, n + 3, 4), dtype=np.uint64)
@@ -64,7 +72,7 @@ def prove_turbo(curve: int, r: int, fr_generator: int, log_n: int, selector_vals
         slab[18 + i, :n + 2] = wire_polys[i]
     slab[23] = z_poly
     slab[24, :n] = pi_poly
-    quot = cref.plonk_quotient(curve, log_n, slab, k_m, am, bm, gm, threads=threads)
+    quot = timed("quotient_round", cref.plonk_quotient, curve, log_n, slab, k_m, am, bm, gm, threads=threads)    # 25 coset FFTs + closure + coset iFFT
     expected = W * (n + 1) + 2
     assert not quot[expected + 1:].any() and quot[expected].any(), "quotient degree (prover.rs:916-919)"
     split, last = [], 0
@@ -115,7 +123,8 @@ def prove_turbo(curve: int, r: int, fr_generator: int, log_n: int, selector_vals
     shifted = cref.poly_div_linear(curve, z_poly, _mont(curve, r, [zeta * w_n % r])[0])
     return {"wires_comms": wires_comms, "z_comm": z_comm, "split_comms": split_comms, "opening": commit(opening), "shifted": commit(shifted),
             "wires_evals": we, "wire_sigma_evals": se, "perm_next_eval": perm_next, "seconds": time.perf_counter() - t_start,
-            "prove_seconds": time.perf_counter() - t_prove}
+            "prove_seconds": time.perf_counter() - t_prove,
+            "spent_seconds": {k: round(v, 3) for k, v in spent.items()}}
 
 
 def prove_ultra(curve: int, r: int, fr_generator: int, log_n: int, selector_vals, sigma_vals, table_vals, k, wire_vals, pi_vals, blind, ch, srs_xy, threads: int = 1):

@@ -70,7 +70,9 @@ def measure(mj, L, curve, log_n, mode, reps=2, srs=None):
     coset = mj.params.fr_to_mont(c, [c.fr_generator])[0]
     cos_p = coset.ctypes.data_as(C.c_void_p)
     small = [HostBuf(L, n + 3, pinned) for _ in range(7)]                 # wires, pi, z coefficient buffers
-    big = [HostBuf(L, m, pinned) for _ in range(4)]                       # evaluation buffers (the shim reuses a few; 25 x 268 MB would not fit caches anyway)
+    # evaluation buffers: the reference holds all 25 coset-evaluation vectors of round 3 at once (prover.rs:552-567), and so does a
+    # shim that batches them; the one-call-per-polynomial modes cycle through a few
+    big = [HostBuf(L, m, pinned) for _ in range(25 if mode == "batch" else 4)]
     for b in small:
         b.a[:] = rnd
     out = np.zeros(18, dtype=np.uint64)
@@ -102,13 +104,9 @@ def measure(mj, L, curve, log_n, mode, reps=2, srs=None):
             ntt_batch(small[6:7], [n], log_n, 1, None)
             msm_batch(small[6:7], [n + 3])
             # 25 forward coset NTTs: the shim copies each polynomial's coefficients into an evaluation buffer first
-            done = 0
-            while done < 25:
-                k = min(len(big), 25 - done)
-                for j in range(k):
-                    big[j].a[:n + 3] = small[(done + j) % 7].a
-                ntt_batch(big[:k], [n + 3] * k, log_n + 3, 0, cos_p)
-                done += k
+            for j in range(25):
+                big[j].a[:n + 3] = small[j % 7].a
+            ntt_batch(big, [n + 3] * 25, log_n + 3, 0, cos_p)
             ntt_batch(big[:1], [m], log_n + 3, 1, cos_p)
             msm_batch(small[:5], [n + 3] * 5)
             msm_batch(small[:2], [n + 2] * 2)
