@@ -413,10 +413,9 @@ def main():
             pn = 1 << log_gates
             ck = mj.UnivariateProverParam.gen_srs_for_testing(crv, beta, pn + 2)          # the same SRS on every rank
             cs = mj.snark.gen_circuit_for_bench(crv, pn, plonk_type)
-            chunked = 8 % world == 0                                                     # 8(e).3 needs a world size dividing 8
-            gather = lambda local: mj.sharding.gather_quotient_classes(local, via_host=(backend != "nccl"))
-            prover = (mj.snark.preprocess(ck, cs, quotient_classes=mj.sharding.class_range(rank, world), quotient_gather=gather) if chunked
-                      else mj.snark.preprocess(ck, cs))
+            chunked = True                                                               # 8(e).3: the needed classes (6 / 7 of 8) split over the ranks
+            gather = lambda local, n_classes: mj.sharding.gather_quotient_classes(local, via_host=(backend != "nccl"), n_classes=n_classes)
+            prover = mj.snark.preprocess(ck, cs, quotient_shard=(rank, world), quotient_gather=gather)
             prover.vk_commitments()
             prover.committer = mj.sharding.ShardedCommitter(crv, ck, device=coll_dev)
             rng = mj.rng.test_rng()

@@ -194,6 +194,15 @@ MZK_API int32_t mzk_plonk_quotient_chunked_dev(uint64_t pk_handle, const void* d
                                                const uint64_t* tau_mont, const uint64_t* alpha_mont, const uint64_t* beta_mont,
                                                const uint64_t* gamma_mont, void* d_out, void* stream);
 MZK_API int32_t mzk_plonk_quotient_combine_dev(int32_t curve_id, uint32_t log_n, const void* d_class_remainders, void* d_out, void* stream);
+/* The same recovery from FEWER classes.  The quotient has degree W (n + 1) + 2 (`quotient_polynomial_degree`,
+ * plonk/src/proof_system/prover.rs:916-919, 1126-1128), below (W + 1) n once n > W + 2: the remainders modulo X^n - h_k^n on any
+ * W + 1 classes -- 6 of the 8 for TurboPlonk, 7 for UltraPlonk -- determine it (Chinese remainder theorem), so the other classes
+ * need neither be evaluated nor be resident in the proving key.  d_class_remainders: n_classes x n elements, class-major in the
+ * order of `classes` (strictly increasing, each < 8); per coefficient index an n_classes x n_classes inverse Vandermonde system in
+ * h_k^n is applied (for all 8 classes it is the 8-point inverse DFT above).  d_out: 8n coefficients, the slabs above n_classes
+ * zero: the polynomial `coset.ifft` returns at prover.rs:672, provided its degree is below n_classes * n. */
+MZK_API int32_t mzk_plonk_quotient_combine_classes_dev(int32_t curve_id, uint32_t log_n, const uint32_t* classes, uint32_t n_classes,
+                                                       const void* d_class_remainders, void* d_out, void* stream);
 
 /* Round 2: replaces Arithmetization::compute_prod_permutation_polynomial
  * (relation/src/constraint_system.rs:1197-1223), whose loop performs one field division per gate.

@@ -108,7 +108,8 @@ int32_t plonk_pk_register(int curve, int log_n, int W, const uint32_t* sel, cons
                           uint64_t* out_handle);
 int32_t plonk_quotient_chunked_dev(uint64_t handle, const uint32_t* d_polys, uint64_t in_stride, uint64_t in_len, const uint32_t* tau, const uint32_t* alpha,
                                    const uint32_t* beta, const uint32_t* gamma, uint32_t* d_out, hipStream_t st);
-int32_t plonk_quotient_combine_dev(int curve, int log_n, const uint32_t* d_r, uint32_t* d_out, hipStream_t st);
+int32_t plonk_quotient_combine_dev(int curve, int log_n, const uint32_t* classes /* NULL: all 8 */, uint32_t n_classes, const uint32_t* d_r, uint32_t* d_out,
+                                   hipStream_t st);
 int32_t plonk_pk_release(uint64_t handle);
 void plonk_release_all();
 int32_t plonk_quotient_dev(uint64_t handle, uint32_t* d_polys, uint64_t in_len, const uint32_t* tau /* NULL: TurboPlonk */, const uint32_t* alpha,

@@ -521,10 +521,15 @@ int32_t mzk_plonk_quotient_chunked_dev(uint64_t pk_handle, const void* d_polys, 
                                       reinterpret_cast<const uint32_t*>(gamma_mont), reinterpret_cast<uint32_t*>(d_out), (hipStream_t)stream);
 }
 int32_t mzk_plonk_quotient_combine_dev(int32_t curve_id, uint32_t log_n, const void* d_class_remainders, void* d_out, void* stream) {
+    return mzk_plonk_quotient_combine_classes_dev(curve_id, log_n, nullptr, 0, d_class_remainders, d_out, stream);
+}
+int32_t mzk_plonk_quotient_combine_classes_dev(int32_t curve_id, uint32_t log_n, const uint32_t* classes, uint32_t n_classes, const void* d_class_remainders,
+                                               void* d_out, void* stream) {
     std::lock_guard<std::mutex> lk(g_lock);
     MZK_TRY(require_init());
-    return plonk_quotient_combine_dev(curve_id, (int)log_n, reinterpret_cast<const uint32_t*>(d_class_remainders), reinterpret_cast<uint32_t*>(d_out),
-                                      (hipStream_t)stream);
+    if (!d_class_remainders || !d_out || log_n > 27) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
+    return plonk_quotient_combine_dev(curve_id, (int)log_n, classes, n_classes, reinterpret_cast<const uint32_t*>(d_class_remainders),
+                                      reinterpret_cast<uint32_t*>(d_out), (hipStream_t)stream);
 }
 int32_t mzk_plonk_pk_release(uint64_t pk_handle) {
     std::lock_guard<std::mutex> lk(g_lock);

@@ -13,16 +13,34 @@ namespace {
 struct NttPlanDev {
     NttxPlanHost h;
     uint32_t* d_stage[NTT_MAX_PASSES] = {nullptr, nullptr, nullptr, nullptr};
-    uint32_t *d_tlo = nullptr, *d_thi = nullptr, *d_flo = nullptr, *d_fhi = nullptr, *d_fone = nullptr;
+    uint32_t *d_flo = nullptr, *d_fhi = nullptr, *d_fone = nullptr;
+    uint64_t last_used = 0;
     uint32_t* d_tfull[NTT_MAX_PASSES] = {nullptr, nullptr, nullptr, nullptr};
 };
 struct PlanKey {
     int curve, log_n, inverse, scale;
     uint32_t coset[8];
     bool has_coset;
-    bool operator<(const PlanKey& o) const { return std::memcmp(this, &o, sizeof(PlanKey)) < 0; }
+    bool operator<(const PlanKey& o) const {
+        if (curve != o.curve) return curve < o.curve;
+        if (log_n != o.log_n) return log_n < o.log_n;
+        if (inverse != o.inverse) return inverse < o.inverse;
+        if (scale != o.scale) return scale < o.scale;
+        if (has_coset != o.has_coset) return has_coset < o.has_coset;
+        return has_coset && std::memcmp(coset, o.coset, sizeof coset) < 0;
+    }
 };
 std::map<PlanKey, std::unique_ptr<NttPlanDev>> g_plans;
+uint64_t g_plan_clock = 0;
+// A plan holds device tables (up to tens of MB for the largest domains) and is keyed by the coset offset: a caller sweeping
+// offsets (per-proof random cosets, the multiprover's public-polynomial FFTs) must not grow the cache without bound.
+constexpr size_t NTT_MAX_PLANS = 48;
+
+void free_plan(NttPlanDev* p) {
+    for (auto* d : p->d_stage) if (d) (void)hipFree(d);
+    for (auto* d : {p->d_flo, p->d_fhi, p->d_fone}) if (d) (void)hipFree(d);
+    for (auto* d : p->d_tfull) if (d) (void)hipFree(d);
+}
 
 int32_t upload_words(uint32_t** d, const std::vector<uint32_t>& v) {
     if (v.empty()) { *d = nullptr; return MZK_OK; }
@@ -39,16 +57,26 @@ int32_t get_plan(int curve, int log_n, bool inverse, const uint32_t* coset, int 
     key.has_coset = coset != nullptr;
     if (coset) std::memcpy(key.coset, coset, 32);
     auto it = g_plans.find(key);
-    if (it != g_plans.end()) { *out = it->second.get(); return MZK_OK; }
+    if (it != g_plans.end()) { it->second->last_used = ++g_plan_clock; *out = it->second.get(); return MZK_OK; }
+    if (g_plans.size() >= NTT_MAX_PLANS) {                       // evict the least recently used plan (its kernels may still be in flight)
+        auto victim = g_plans.begin();
+        for (auto p = g_plans.begin(); p != g_plans.end(); ++p)
+            if (p->second->last_used < victim->second->last_used) victim = p;
+        HIP_TRY(hipDeviceSynchronize());
+        free_plan(victim->second.get());
+        g_plans.erase(victim);
+    }
     auto pl = std::make_unique<NttPlanDev>();
     nttx_build_plan<X>(pl->h, log_n, inverse, coset, scale);
+    if (!nttx_growth_ok<X>(pl->h)) { set_error("NTT plan violates the lazy-value bound"); return MZK_ERR_UNSUPPORTED; }
     for (int k = 0; k < pl->h.n_pass; k++) MZK_TRY(upload_words(&pl->d_stage[k], pl->h.stage_tw[k]));
     for (int k = 0; k < pl->h.n_pass; k++) MZK_TRY(upload_words(&pl->d_tfull[k], pl->h.t_full[k]));
-    MZK_TRY(upload_words(&pl->d_tlo, pl->h.t_lo));
-    MZK_TRY(upload_words(&pl->d_thi, pl->h.t_hi));
     MZK_TRY(upload_words(&pl->d_flo, pl->h.f_lo));
     MZK_TRY(upload_words(&pl->d_fhi, pl->h.f_hi));
     MZK_TRY(upload_words(&pl->d_fone, pl->h.f_one));
+    for (int k = 0; k < NTT_MAX_PASSES; k++) { pl->h.stage_tw[k] = {}; pl->h.t_full[k] = {}; }     // the host copies are not needed again
+    pl->h.f_lo = {}; pl->h.f_hi = {};
+    pl->last_used = ++g_plan_clock;
     *out = pl.get();
     g_plans[key] = std::move(pl);
     return MZK_OK;
@@ -84,7 +112,7 @@ int32_t ntt_dev(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool in
     NttPlanDev* pl;
     MZK_TRY(get_plan<X>(curve, log_n, inverse, coset, scale, &pl));
     MZK_TRY(ws_acquire(st));
-    MZK_TRY(g_ws.ntt_scratch.reserve((size_t)batch * N * 32));
+    MZK_TRY(g_ws.ntt_scratch.reserve((size_t)batch * N * 36));          // 9-limb planes between passes
     uint32_t* scratch = g_ws.ntt_scratch.as<uint32_t>();
     ProfScope total("ntt_total", st);
     const int K = pl->h.n_pass;
@@ -98,13 +126,12 @@ int32_t ntt_dev(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool in
         for (int q = 0; q < K; q++) a.log_radix[q] = pl->h.log_radix[q];
         a.log_lb = pl->h.log_lb;
         a.stage_tw = pl->d_stage[k];
-        a.t_lo = pl->d_tlo;
-        a.t_hi = pl->d_thi;
         a.t_full = pl->d_tfull[k];
         a.f_lo = pl->d_flo;             // non-null only for an inverse coset transform
         a.f_hi = pl->d_fhi;
-        a.f_one = pl->d_fone;
+        a.f_one = pl->h.final_factor ? pl->d_fone : nullptr;
         a.in_len = in_len;
+        a.n = N;
         if (a.is_first && !a.is_final)                                  // zero-padded input: leading stages of pass 1 are copies
             while (a.skip < lr && in_len <= (N >> (a.skip + 1))) a.skip++;
         int lc = NTT_TILE_LOG - lr;
@@ -117,8 +144,10 @@ int32_t ntt_dev(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool in
         const bool from_data = k == 0, to_data = (k == K - 1) && K > 1;
         a.in = from_data ? d_data : scratch;
         a.in_stride = from_data ? stride : N;
+        a.in_planes = from_data ? 0 : 1;
         a.out = to_data ? d_data : scratch;
         a.out_stride = to_data ? stride : N;
+        a.out_planes = (to_data || K == 1) ? 0 : 1;
         const unsigned long long n_tiles = N >> (lr + lc);
         MZK_TRY((launch_pass<X>(a, n_tiles, batch, st)));
         log_p += lr;
@@ -140,12 +169,7 @@ int32_t ntt_dispatch(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bo
 }
 
 void ntt_release_plans() {
-    for (auto& kv : g_plans) {
-        NttPlanDev* p = kv.second.get();
-        for (auto* d : p->d_stage) if (d) (void)hipFree(d);
-        for (auto* d : {p->d_tlo, p->d_thi, p->d_flo, p->d_fhi, p->d_fone}) if (d) (void)hipFree(d);
-        for (auto* d : p->d_tfull) if (d) (void)hipFree(d);
-    }
+    for (auto& kv : g_plans) free_plan(kv.second.get());
     g_plans.clear();
 }
 

@@ -1,104 +1,132 @@
-// ntt_fx.cuh -- the multi-pass NTT of ntt.cuh on the reduced-radix field (fx.cuh): butterflies cost one
-// v_mad_u64_u32 per partial product and carry-free additions.
+// ntt_fx.cuh -- the multi-pass NTT of ntt.cuh on signed, lazily reduced 29-bit limbs (fs.cuh): every product of the transform has a
+// plan-time constant operand, so it is a Barrett product with a precomputed quotient (143 multiply-adds) rather than a Montgomery
+// product (162), data never change form, and the twiddle between pass 1 and pass 2 costs no product at all.
 //
-// Same decomposition, tile geometry, coalescing and natural-order scatter as ntt.cuh (see there for the
-// index algebra and the reference call sites it replaces: prover.rs:545-567, 672;
-// constraint_system.rs:1172-1257).  What changes:
-//   * data stay in the boundary's Montgomery form (x*R, R = 2^256) as integers, but are held as 9 limbs of
-//     29 bits inside the kernel; twiddles are stored in R'-form (w*R', R' = 2^261), so
-//     fx_mul(data, twiddle) = data*w keeps the boundary form and no conversion is ever needed;
-//   * values are lazily reduced: a butterfly adds at most 2p to a value, a pass has at most 9 stages and
-//     every pass ends in a multiplication (inter-pass twiddle, or the final scaling), so values stay
-//     below 20p < 2^260 and every product comes out below 1.3p.  Between passes the 8-word image may hold
-//     a non-canonical value < 2^256; only the last pass canonicalises;
-//   * both directions run decimation-in-time (a DIF butterfly would double lazy values at every stage).
-//     Forward coset scaling is folded into the stage twiddles as before (g_k = h^(S_k), free); the inverse
-//     applies N^-1 * h^-j in the final pass -- N^-1 rides in the one multiplication every final pass does
-//     anyway, a coset costs one more (the prover has one coset iNTT per proof, prover.rs:672).
-// LDS: 9 words per element in three planes (b128, b128, b32): a 2048-element tile is 72 KiB, so two
-// 512-thread workgroups share a CU (one loads/stores while the other computes); the <= 511 stage twiddles
-// of a pass (24 KiB) are read through L1 -- lanes of a wave share them.
+// Same decomposition, tile geometry, coalescing and natural-order scatter as ntt.cuh (see there for the index algebra and the
+// reference call sites it replaces: prover.rs:545-567, 672; constraint_system.rs:1172-1257).  What this file adds:
+//
+//   * Folded first boundary.  With i = i1 S_1 + i2 and k = k1 + R_1 k2,
+//         X[k] = sum_i2 (h w^k1)^i2  w_S1^(i2 k2)  ( sum_i1 x[i1 S_1 + i2] (h^S_1)^i1 w_R1^(i1 k1) ):
+//     after pass 1, block k1 is a size-S_1 COSET transform with offset e_k1 = h w^k1, and a coset offset rides in the stage
+//     twiddles for free (pass k uses g = e_k1^(S_k)).  So passes k >= 2 read their stage twiddles from a table indexed by k1
+//     (R_1 x (R_k - 1) records; in the final pass k1 is the tile COLUMN) and the N-entry twiddle w^(k1 i2) -- two products per
+//     element from a two-level table before -- disappears.  The boundaries after pass 2 keep an explicit product from a table of
+//     N / R_1 or fewer entries (a per-element table for them would be N entries).
+//   * Signed lazy limbs.  A butterfly is  t = hi * W (fs_mulc, |t| < 3p, limbs in [0, 2^29));  lo' = lo + t;  hi' = lo - t  with no
+//     multiple-of-p pad and ONE normalisation (of lo) per butterfly: limbs stay within 2^30, which is what fs_mulc accepts.
+//     Values grow by less than 3p per stage and nothing reduces them between pass 1 and pass 2: |v| < 2^256 + (9 + 9) 3p < 60p, and
+//     2^261 / p is 70 (BLS12-381) / 169 (BN254); every later pass starts from a product (|v| < 3p).  nttx_build_plan asserts it.
+//   * Between passes the data live in the scratch buffer as the 9 limbs themselves (planes of 16 + 16 + 4 bytes per element, the
+//     LDS layout): no packing, no unpacking, and lazy signed values need no reduction to be stored.  Only the last pass
+//     canonicalises (fs_canonical: quotient by p from the top limb) and packs into the boundary's 32-byte form.
+//   * Both directions run decimation-in-time; the forward coset offset is in the stage twiddles, the inverse applies N^-1 h^-j
+//     (and the internal-form factors 32 / 1/32 of the quotient kernels, plonk.cuh) as final products; a plain forward transform
+//     has no final product at all.
+// LDS: 9 words per element in three planes (b128, b128, b32): a 2048-element tile is 72 KiB, so two 512-thread workgroups share
+// a CU (one loads/stores while the other computes).
 #pragma once
 #include <hip/hip_runtime.h>
 
 #include <vector>
 
-#include "fx.cuh"
+#include "fs.cuh"
 #include "ntt.cuh"
 
 namespace mzk {
 
 constexpr int NTTX_THREADS = 512;
-constexpr int NTTX_TW_WORDS = 12;        // a 9-limb twiddle padded to three 16-byte words in global memory
 
 struct NttxPassArgs {
     uint32_t* in;
     uint32_t* out;
-    const uint32_t* stage_tw;  // (R-1) entries of NTTX_TW_WORDS words, entry (half-1+j)
-    const uint32_t* t_lo;      // inter-pass twiddles, low LB bits of the exponent (R'-form)
-    const uint32_t* t_hi;      // high bits
-    const uint32_t* t_full;    // middle passes: the whole table w_N^(P r s), entry (r << log_s) + s  (N / P entries: small); else null
-    const uint32_t* f_lo;      // final pass: N^-1 h^-j = f_lo[j & mask] * f_hi[j >> LB]   (inverse coset), else null
+    const uint32_t* stage_tw;  // records of FS_TW_WORDS words.  pass 1: entry (half-1+j); pass k >= 2: entry k1 (R-1) + (half-1+j)
+    const uint32_t* t_full;    // middle passes k >= 2: w_N^(P r s), entry (r << log_s) + s  (N / P entries); else null
+    const uint32_t* f_lo;      // final pass, inverse coset: N^-1 h^-j = f_lo[j & mask] * f_hi[j >> LB]; else null
     const uint32_t* f_hi;
-    const uint32_t* f_one;     // final pass without coset: the single multiplier (R' mod p, or N^-1 R')
-    unsigned long long in_stride, out_stride;
+    const uint32_t* f_one;     // final pass with a single factor (N^-1 and / or the internal-form factor); null: no final product
+    unsigned long long in_stride, out_stride;      // elements between the polynomials of a batch (packed: 8 words each; planes: 9)
     unsigned long long in_len;
+    unsigned long long n;                          // plane length of the scratch layout
     int log_n, log_r, log_c, log_s, log_p;
     int log_lb;
     int is_first, is_final, n_pass;
     int skip;                  // first pass of a zero-padded input (in_len <= N >> skip): the first `skip` stages are copies
+    int in_planes, out_planes; // 1: the 9-limb plane layout of the scratch buffer; 0: the boundary's packed 8 words
     int log_radix[NTT_MAX_PASSES];
 };
 
 template <class X>
-__device__ __forceinline__ Fx<X> ldsx_load(const uint4* pa, const uint4* pb, const uint32_t* pc, int idx) {
-    Fx<X> r;
-    const uint4 a = pa[idx], b = pb[idx];
+__device__ __forceinline__ Fs<X> ldss_load(const int4* pa, const int4* pb, const int32_t* pc, int idx) {
+    Fs<X> r;
+    const int4 a = pa[idx], b = pb[idx];
     r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
     r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
     r.l[8] = pc[idx];
     return r;
 }
 template <class X>
-__device__ __forceinline__ void ldsx_store(uint4* pa, uint4* pb, uint32_t* pc, int idx, const Fx<X>& v) {
-    pa[idx] = make_uint4(v.l[0], v.l[1], v.l[2], v.l[3]);
-    pb[idx] = make_uint4(v.l[4], v.l[5], v.l[6], v.l[7]);
+__device__ __forceinline__ void ldss_store(int4* pa, int4* pb, int32_t* pc, int idx, const Fs<X>& v) {
+    pa[idx] = make_int4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    pb[idx] = make_int4(v.l[4], v.l[5], v.l[6], v.l[7]);
     pc[idx] = v.l[8];
 }
+// scratch planes of one polynomial: limbs 0-3 at word 4g, limbs 4-7 at word 4n + 4g, limb 8 at word 8n + g
 template <class X>
-__device__ __forceinline__ Fx<X> twx_load(const uint32_t* __restrict__ table, unsigned long long idx) {
-    const uint4* src = reinterpret_cast<const uint4*>(table + idx * NTTX_TW_WORDS);
-    const uint4 a = src[0], b = src[1], c = src[2];
-    Fx<X> r;
+__device__ __forceinline__ Fs<X> planes_get(const uint32_t* __restrict__ base, unsigned long long n, unsigned long long g) {
+    Fs<X> r;
+    const int4 a = reinterpret_cast<const int4*>(base)[g], b = reinterpret_cast<const int4*>(base + 4 * n)[g];
     r.l[0] = a.x; r.l[1] = a.y; r.l[2] = a.z; r.l[3] = a.w;
     r.l[4] = b.x; r.l[5] = b.y; r.l[6] = b.z; r.l[7] = b.w;
-    r.l[8] = c.x;
+    r.l[8] = reinterpret_cast<const int32_t*>(base + 8 * n)[g];
     return r;
+}
+template <class X>
+__device__ __forceinline__ void planes_put(uint32_t* __restrict__ base, unsigned long long n, unsigned long long g, const Fs<X>& v) {
+    reinterpret_cast<int4*>(base)[g] = make_int4(v.l[0], v.l[1], v.l[2], v.l[3]);
+    reinterpret_cast<int4*>(base + 4 * n)[g] = make_int4(v.l[4], v.l[5], v.l[6], v.l[7]);
+    reinterpret_cast<int32_t*>(base + 8 * n)[g] = v.l[8];
+}
+template <class X>
+__device__ __forceinline__ Fs<X> fs_load_packed(const uint32_t* __restrict__ p) {
+    const Fp<X> t = load_fp<X>(p);
+    return fs_unpack<X>(t.l);
+}
+__device__ __forceinline__ FsTw tws_load(const uint32_t* __restrict__ table, unsigned long long idx) {
+    const uint4* src = reinterpret_cast<const uint4*>(table + idx * FS_TW_WORDS);
+    const uint4 a = src[0], b = src[1], c = src[2], d = src[3], e = src[4];
+    FsTw t;
+    t.w[0] = a.x; t.w[1] = a.y; t.w[2] = a.z; t.w[3] = a.w;
+    t.w[4] = b.x; t.w[5] = b.y; t.w[6] = b.z; t.w[7] = b.w;
+    t.w[8] = c.x; t.q[0] = c.y; t.q[1] = c.z; t.q[2] = c.w;
+    t.q[3] = d.x; t.q[4] = d.y; t.q[5] = d.z; t.q[6] = d.w;
+    t.q[7] = e.x; t.q[8] = e.y;
+    return t;
 }
 
 // grid = (N / (R*C), batch), block = NTTX_THREADS
 template <class X>
 __global__ __launch_bounds__(NTTX_THREADS) void nttx_pass_kernel(NttxPassArgs a) {
     static_assert(X::XN == 9 && X::N == 8, "256-bit scalar fields: 8 boundary words, 9 limbs of 29 bits");
-    extern __shared__ uint4 ldsx[];
+    extern __shared__ int4 ldsx[];
     const int R = 1 << a.log_r, C = 1 << a.log_c, TILE = R * C;
-    uint4* da = ldsx;
-    uint4* db = da + TILE;
-    uint32_t* dc = reinterpret_cast<uint32_t*>(db + TILE);
+    int4* da = ldsx;
+    int4* db = da + TILE;
+    int32_t* dc = reinterpret_cast<int32_t*>(db + TILE);
     const int tid = threadIdx.x;
     const unsigned long long tile = blockIdx.x;
-    uint32_t* in = a.in + (unsigned long long)blockIdx.y * a.in_stride * 8;
-    uint32_t* out = a.out + (unsigned long long)blockIdx.y * a.out_stride * 8;
+    const uint32_t* in = a.in + (unsigned long long)blockIdx.y * a.in_stride * (a.in_planes ? 9 : 8);
+    uint32_t* out = a.out + (unsigned long long)blockIdx.y * a.out_stride * (a.out_planes ? 9 : 8);
 
     // ---- tile geometry (as ntt.cuh) --------------------------------------------------------------------
-    unsigned long long base = 0, c0 = 0, p1 = 1, i1_0 = 0, rest = 0, rev_rest = 0;
+    const int log_r1 = a.n_pass > 1 ? a.log_radix[0] : 0;
+    unsigned long long base = 0, c0 = 0, p1 = 1, i1_0 = 0, rest = 0, rev_rest = 0, k1_blk = 0;
     if (!a.is_final) {
         const unsigned long long tiles_per_blk = 1ull << (a.log_s - a.log_c);
         const unsigned long long blk = tile >> (a.log_s - a.log_c);
         c0 = (tile & (tiles_per_blk - 1)) << a.log_c;
         base = (blk << (a.log_r + a.log_s)) + c0;
+        k1_blk = a.is_first ? 0 : (blk >> (a.log_p - log_r1));        // the pass-1 output index of this block
     } else {
-        const int log_r1 = a.n_pass > 1 ? a.log_radix[0] : 0;
         const int log_p1 = a.log_p - log_r1;
         p1 = 1ull << log_p1;
         rest = tile & (p1 - 1);
@@ -111,7 +139,7 @@ __global__ __launch_bounds__(NTTX_THREADS) void nttx_pass_kernel(NttxPassArgs a)
         }
     }
 
-    // ---- load: boundary words -> 29-bit limbs, bit-reversed rows (decimation in time) --------------------
+    // ---- load: bit-reversed rows (decimation in time) ------------------------------------------------------
     // Zero-padded input (the quotient round transforms polynomials of degree n + 2 on 8n points): rows r >= R >> skip are
     // zero for every tile, so in bit-reversed order each run of 2^skip positions holds one non-zero value first, and the
     // first `skip` stages -- butterflies whose multiplied operand is zero -- merely copy it across the run.
@@ -120,10 +148,10 @@ __global__ __launch_bounds__(NTTX_THREADS) void nttx_pass_kernel(NttxPassArgs a)
         for (int e = tid; e < rows * C; e += NTTX_THREADS) {
             const int c = e & (C - 1), r = e >> a.log_c;
             const unsigned long long g = base + ((unsigned long long)r << a.log_s) + c;
-            Fx<X> v = Fx<X>::zero();
-            if (g < a.in_len) v = fx_load_packed<X>(in + g * 8);
+            Fs<X> v = Fs<X>::zero();
+            if (g < a.in_len) v = fs_load_packed<X>(in + g * 8);
             const int pos = (int)bitrev((unsigned)r, a.log_r) * C + c;
-            for (int t = 0; t < reps; t++) ldsx_store<X>(da, db, dc, pos + t * C, v);
+            for (int t = 0; t < reps; t++) ldss_store<X>(da, db, dc, pos + t * C, v);
         }
     } else
     for (int e = tid; e < TILE; e += NTTX_THREADS) {
@@ -138,26 +166,34 @@ __global__ __launch_bounds__(NTTX_THREADS) void nttx_pass_kernel(NttxPassArgs a)
             c = e >> a.log_r;
             g = (((i1_0 + c) * p1 + rest) << a.log_r) + r;
         }
-        Fx<X> v = Fx<X>::zero();
-        if (!(a.is_first && g >= a.in_len)) v = fx_load_packed<X>(in + g * 8);
-        ldsx_store<X>(da, db, dc, (int)bitrev((unsigned)r, a.log_r) * C + c, v);
+        Fs<X> v;
+        if (a.in_planes) v = planes_get<X>(in, a.n, g);                                  // lazy: |limbs| <= 2^30
+        else if (a.is_first && g >= a.in_len) v = Fs<X>::zero();
+        else v = fs_load_packed<X>(in + g * 8);                                        // fresh: limbs in [0, 2^29)
+        ldss_store<X>(da, db, dc, (int)bitrev((unsigned)r, a.log_r) * C + c, v);
     }
     __syncthreads();
 
     // ---- R-point transforms: one butterfly per thread per stage -------------------------------------------
+    // Invariant: every LDS value has |limbs| <= 2^30.  lo is normalised (limbs in [-4, 2^29 + 4)) unless it is fresh data,
+    // t = hi W is class C, so both outputs stay within 2^30.
     const int nbf = TILE >> 1;
+    const int tw_rows = R - 1;
     for (int s = a.skip; s < a.log_r; s++) {
         const int half = 1 << s;
+        const bool fresh = !a.in_planes && s == a.skip;
         for (int bt = tid; bt < nbf; bt += NTTX_THREADS) {
             const int c = bt & (C - 1);
             const int jj = bt >> a.log_c;
             const int j = jj & (half - 1);
             const int lo_i = (((jj >> s) << (s + 1)) + j) * C + c, hi_i = lo_i + half * C;
-            const Fx<X> lo = fx_norm(ldsx_load<X>(da, db, dc, lo_i));               // limbs < 2^29 + 8
-            const Fx<X> hi = fx_norm(ldsx_load<X>(da, db, dc, hi_i));
-            const Fx<X> t = fx_mul(hi, twx_load<X>(a.stage_tw, half - 1 + j));       // class M, value < 1.3p; the table is L1-resident
-            ldsx_store<X>(da, db, dc, lo_i, fx_add(lo, t));                          // value + 1.3p, limbs < 2^30 + 8
-            ldsx_store<X>(da, db, dc, hi_i, fx_sub2(lo, t));                         // value + 2p,  limbs < 2^31
+            Fs<X> lo = ldss_load<X>(da, db, dc, lo_i);
+            const Fs<X> hi = ldss_load<X>(da, db, dc, hi_i);
+            if (!fresh) lo = fs_norm(lo);
+            const unsigned long long k1 = a.is_first ? 0ull : (a.is_final ? i1_0 + c : k1_blk);
+            const Fs<X> t = fs_mulc<X>(hi, tws_load(a.stage_tw, k1 * tw_rows + (half - 1 + j)));
+            ldss_store<X>(da, db, dc, lo_i, fs_add(lo, t));
+            ldss_store<X>(da, db, dc, hi_i, fs_sub(lo, t));
         }
         __syncthreads();
     }
@@ -166,50 +202,44 @@ __global__ __launch_bounds__(NTTX_THREADS) void nttx_pass_kernel(NttxPassArgs a)
     for (int e = tid; e < TILE; e += NTTX_THREADS) {
         const int c = e & (C - 1);
         const int r = e >> a.log_c;
-        const Fx<X> v = fx_norm(ldsx_load<X>(da, db, dc, r * C + c));
+        Fs<X> v = ldss_load<X>(da, db, dc, r * C + c);
         if (!a.is_final) {
-            Fx<X> tw;
-            if (a.t_full) {                                                          // one product instead of two
-                tw = twx_load<X>(a.t_full, ((unsigned long long)r << a.log_s) + c0 + c);
-            } else {
-                const unsigned long long ex = ((unsigned long long)r * (c0 + c)) << a.log_p;
-                tw = fx_mul(twx_load<X>(a.t_lo, ex & ((1ull << a.log_lb) - 1)), twx_load<X>(a.t_hi, ex >> a.log_lb));
-            }
             const unsigned long long g = base + ((unsigned long long)r << a.log_s) + c;
-            fx_store_packed<X>(out + g * 8, fx_mul(v, tw));                          // < 1.3p < 2^256: fully carried limbs
+            if (!a.is_first) v = fs_mulc<X>(v, tws_load(a.t_full, ((unsigned long long)r << a.log_s) + c0 + c));   // boundaries after pass 2
+            planes_put<X>(out, a.n, g, v);                                           // pass 1: stored as it is (folded boundary)
         } else {
-            const unsigned long long rev = (i1_0 + c) + (rev_rest << (a.n_pass > 1 ? a.log_radix[0] : 0));
+            const unsigned long long rev = (i1_0 + c) + (rev_rest << log_r1);
             const unsigned long long g = rev + ((unsigned long long)r << a.log_p);
-            Fx<X> f;
-            if (a.f_lo) f = fx_mul(twx_load<X>(a.f_lo, g & ((1ull << a.log_lb) - 1)), twx_load<X>(a.f_hi, g >> a.log_lb));
-            else f = twx_load<X>(a.f_one, 0);
-            fx_store_packed<X>(out + g * 8, fx_canonical(fx_mul(v, f)));
+            if (a.f_lo) {
+                v = fs_mulc<X>(v, tws_load(a.f_lo, g & ((1ull << a.log_lb) - 1)));
+                v = fs_mulc<X>(v, tws_load(a.f_hi, g >> a.log_lb));
+            } else if (a.f_one) {
+                v = fs_mulc<X>(v, tws_load(a.f_one, 0));
+            }
+            fx_store_packed<X>(out + g * 8, fs_canonical<X>(v));
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------------
-// host side: plan tables in R'-form
+// host side: plan tables
 // ------------------------------------------------------------------------------------------------
 struct NttxPlanHost {
     int log_n = 0, n_pass = 0, log_lb = 0;
-    bool inverse = false, coset = false;
+    bool inverse = false, coset = false, final_factor = false;
     int log_radix[NTT_MAX_PASSES] = {0, 0, 0, 0};
     std::vector<uint32_t> stage_tw[NTT_MAX_PASSES];
-    std::vector<uint32_t> t_lo, t_hi, f_lo, f_hi, f_one;
-    std::vector<uint32_t> t_full[NTT_MAX_PASSES];       // middle passes only
+    std::vector<uint32_t> f_lo, f_hi, f_one;
+    std::vector<uint32_t> t_full[NTT_MAX_PASSES];       // middle passes k >= 2 only
 };
 
-// boundary-form field element (x*R) -> twiddle record (x*R' as 9 limbs, padded)
+// boundary-form field element (x*R) -> constant-operand record (x and floor(x 2^261 / p) as 9 limbs each, padded)
 template <class X>
 inline void nttx_put(std::vector<uint32_t>& dst, size_t idx, const Fp<X>& a) {
-    // (x*R) * (R' mod p) / R = x*R' as a canonical integer
-    Fp<X> rp;
-    fx_pack<X>(rp.l, Fx<X>::from_const(X::XONE));
-    const Fp<X> v = a * rp;
-    const Fx<X> f = fx_unpack<X>(v.l);
-    for (int i = 0; i < 9; i++) dst[idx * NTTX_TW_WORDS + i] = f.l[i];
-    for (int i = 9; i < NTTX_TW_WORDS; i++) dst[idx * NTTX_TW_WORDS + i] = 0;
+    const FsTw t = fs_make_tw<X>(a);
+    uint32_t* d = dst.data() + idx * FS_TW_WORDS;
+    for (int i = 0; i < FS_N; i++) { d[i] = (uint32_t)t.w[i]; d[FS_N + i] = (uint32_t)t.q[i]; }
+    d[2 * FS_N] = d[2 * FS_N + 1] = 0;
 }
 
 template <class X>
@@ -225,34 +255,43 @@ void nttx_build_plan(NttxPlanHost& pl, int log_n, bool inverse, const uint32_t* 
     F w = F::from_const(X::ROOT);
     for (int i = log_n; i < X::TWO_ADICITY; i++) w = sqr(w);
     const F w_dir = inverse ? inv(w) : w;
+    const F h_fwd = inverse ? F::one() : h;                 // the inverse applies h^-j at the end instead
+    const int lr1 = pl.log_radix[0];
     int log_p = 0;
     for (int k = 0; k < pl.n_pass; k++) {
         const int lr = pl.log_radix[k];
         const int R = 1 << lr;
         const int log_s = log_n - log_p - lr;
-        // forward: inputs pre-scaled by h^j  =>  stage twiddles W_M[j] = w_M^j g^(R/M), g = h^(S_k); inverse: plain
-        const F g = inverse ? F::one() : pow_u64(h, 1ull << log_s);
-        pl.stage_tw[k].assign((size_t)(R > 1 ? R - 1 : 1) * NTTX_TW_WORDS, 0);
-        for (int s = 0; s < lr; s++) {
-            const int half = 1 << s, M = 2 * half;
-            const F wm = pow_u64(w_dir, 1ull << (log_n - (s + 1)));
-            F cur = pow_u64(g, (uint64_t)(R / M));
-            for (int j = 0; j < half; j++) {
-                nttx_put<X>(pl.stage_tw[k], (size_t)(half - 1 + j), cur);
-                cur = cur * wm;
+        const size_t rows = (size_t)(R > 1 ? R - 1 : 1);
+        // Pass 1: g = h^(S_1).  Pass k >= 2, block k1: the sub-transform's offset is e_k1 = h w^k1, so g = e_k1^(S_k) =
+        // h^(S_k) (w^(S_k))^k1; stage twiddles W_M[j] = w_M^j g^(R/M) (inputs pre-scaled by g^j: decimation in time).
+        const size_t blocks = k == 0 ? 1 : (size_t)1 << lr1;
+        pl.stage_tw[k].assign(blocks * rows * FS_TW_WORDS, 0);
+        const F g0 = pow_u64(h_fwd, 1ull << log_s);
+        const F gstep = k == 0 ? F::one() : pow_u64(w_dir, 1ull << log_s);
+        F g = g0;
+        for (size_t k1 = 0; k1 < blocks; k1++) {
+            for (int s = 0; s < lr; s++) {
+                const int half = 1 << s, M = 2 * half;
+                const F wm = pow_u64(w_dir, 1ull << (log_n - (s + 1)));
+                F cur = pow_u64(g, (uint64_t)(R / M));
+                for (int j = 0; j < half; j++) {
+                    nttx_put<X>(pl.stage_tw[k], k1 * rows + (size_t)(half - 1 + j), cur);
+                    cur = cur * wm;
+                }
             }
+            g = g * gstep;
         }
         log_p += lr;
     }
-    // Inter-pass twiddles of pass k: w_N^(P_k r s), r < R_k, s < S_k -- the same for every block, so the table has N / P_k
-    // entries.  For the first pass that is N entries (kept two-level: t_lo, t_hi, one extra product per element); for the
-    // middle passes it is N / R_1 or less (<= 3 MB), read through L2: one product per element.
-    log_p = pl.log_radix[0];
+    // Boundaries after pass 2: w_N^(P_k r s), r < R_k, s < S_k -- the same for every block, N / P_k <= N / R_1 entries, one
+    // product per element.  (The boundary after pass 1 is folded into the tables above.)
+    log_p = lr1;
     for (int k = 1; k + 1 < pl.n_pass; k++) {
         const int lr = pl.log_radix[k];
         const int log_s = log_n - log_p - lr;
         const size_t R = (size_t)1 << lr, S = (size_t)1 << log_s;
-        pl.t_full[k].assign(R * S * NTTX_TW_WORDS, 0);
+        pl.t_full[k].assign(R * S * FS_TW_WORDS, 0);
         const F wp = pow_u64(w_dir, 1ull << log_p);                 // w_N^P
         F row = F::one();                                           // (w_N^P)^r
         for (size_t r = 0; r < R; r++) {
@@ -262,33 +301,37 @@ void nttx_build_plan(NttxPlanHost& pl, int log_n, bool inverse, const uint32_t* 
         }
         log_p += lr;
     }
-    pl.log_lb = (log_n + 1) / 2;
-    const size_t nlo = (size_t)1 << pl.log_lb, nhi = (size_t)1 << (log_n - pl.log_lb);
-    pl.t_lo.assign(nlo * NTTX_TW_WORDS, 0);
-    pl.t_hi.assign(nhi * NTTX_TW_WORDS, 0);
-    F cur = F::one();
-    for (size_t i = 0; i < nlo; i++) { nttx_put<X>(pl.t_lo, i, cur); cur = cur * w_dir; }
-    const F step = cur;
-    cur = F::one();
-    for (size_t i = 0; i < nhi; i++) { nttx_put<X>(pl.t_hi, i, cur); cur = cur * step; }
-    // final-pass multiplier(s)
-    // scale: 1 = leave the output in the internal form x * R' (R' = 32 R), 2 = take an internal-form input back to x * R;
-    // folded into the multiplication the final pass performs anyway (plonk.cuh)
+    // final-pass factor(s)
+    // scale: 1 = leave the output in the internal form x * R' (R' = 32 R), 2 = take an internal-form input back to x * R
+    // (plonk.cuh); a plain forward transform has none: the final pass only canonicalises
     F ninv = inverse ? inv(from_u64<X>(1ull << log_n)) : F::one();
     if (scale == 1) ninv = ninv * from_u64<X>(32);
     if (scale == 2) ninv = ninv * inv(from_u64<X>(32));
-    pl.f_one.assign(NTTX_TW_WORDS, 0);
+    pl.final_factor = inverse || scale != 0;
+    pl.f_one.assign(FS_TW_WORDS, 0);
     nttx_put<X>(pl.f_one, 0, ninv);
+    pl.log_lb = (log_n + 1) / 2;
     if (inverse && pl.coset) {
+        const size_t nlo = (size_t)1 << pl.log_lb, nhi = (size_t)1 << (log_n - pl.log_lb);
         const F hi = inv(h);
-        pl.f_lo.assign(nlo * NTTX_TW_WORDS, 0);
-        pl.f_hi.assign(nhi * NTTX_TW_WORDS, 0);
-        cur = F::one();
+        pl.f_lo.assign(nlo * FS_TW_WORDS, 0);
+        pl.f_hi.assign(nhi * FS_TW_WORDS, 0);
+        F cur = F::one();
         for (size_t i = 0; i < nlo; i++) { nttx_put<X>(pl.f_lo, i, cur); cur = cur * hi; }
         const F hstep = cur;
         cur = ninv;
         for (size_t i = 0; i < nhi; i++) { nttx_put<X>(pl.f_hi, i, cur); cur = cur * hstep; }
     }
+}
+
+// |v| < 2^256 + 3p * (stages of pass 1 + stages of pass 2) must stay below 2^261 (fs_mulc's contract): true for every size the
+// radix chooser produces (at most 9 + 9 stages); checked when a plan is built
+template <class X>
+inline bool nttx_growth_ok(const NttxPlanHost& pl) {
+    const int stages = pl.log_radix[0] + (pl.n_pass > 1 ? pl.log_radix[1] : 0);
+    // p > 2^(BITS-1): 2^256 / p < 2^(257 - BITS); the bound (2^(257-BITS) + 3 stages) p < 2^261 holds if the factor < 2^(261-BITS)
+    const double factor = (double)(1ull << (257 - X::BITS)) + 3.0 * stages;
+    return factor < (double)(1ull << (261 - X::BITS));
 }
 
 }  // namespace mzk

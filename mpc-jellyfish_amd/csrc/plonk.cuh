@@ -221,13 +221,16 @@ __global__ __launch_bounds__(PLK_THREADS) void plonk_fold_kernel(const uint32_t*
     store_fp<P>(dst + t * 8, v);
 }
 
-// r_k = t mod (X^n - c_k), c_k = g^n w_8^k, for the 8 classes k  ->  the 8 coefficient slabs T_q of t = sum_q X^(qn) T_q:
-//   r_k[j] = sum_q c_k^q T_q[j]   =>   T_q[j] = g^(-nq) / 8 * sum_k w_8^(-kq) r_k[j]      (an 8-point inverse DFT per j)
+// r_k = t mod (X^n - c_k), c_k = g^n w_8^k, for s of the 8 classes k  ->  the s coefficient slabs T_q of t = sum_{q<s} X^(qn) T_q:
+//   r_k[j] = sum_q c_k^q T_q[j]   =>   T_q[j] = sum_k (V^-1)[q][k] r_k[j],  V[k][q] = c_k^q  (an s x s Vandermonde system per j).
+// deg t = W (n + 1) + 2 (prover.rs:916-919, 1126-1128) is below (W + 1) n, so s = W + 1 classes determine it: 6 of 8 for TurboPlonk,
+// 7 of 8 for UltraPlonk; with all 8 classes V^-1 is the 8-point inverse DFT scaled by g^(-nq) / 8.
 struct CombineArgs {
-    const uint32_t* r;         // [8][n] class-major
-    uint32_t* out;             // [8n]
+    const uint32_t* r;         // [ncl][n] class-major
+    uint32_t* out;             // [ncl * n]  (the caller zeroes the slabs above)
     unsigned long long n;
-    uint32_t mat[8][8][8];     // mat[q][k] = g^(-nq) / 8 * w_8^(-kq), Montgomery
+    int ncl;
+    uint32_t mat[8][8][8];     // mat[q][k] = (V^-1)[q][k], Montgomery
 };
 template <class P>
 __global__ __launch_bounds__(PLK_THREADS) void plonk_combine_kernel(CombineArgs a) {
@@ -236,12 +239,13 @@ __global__ __launch_bounds__(PLK_THREADS) void plonk_combine_kernel(CombineArgs 
     if (j >= a.n) return;
     F r[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) r[k] = load_fp<P>(a.r + ((size_t)k * a.n + j) * 8);
+    for (int k = 0; k < 8; k++) r[k] = k < a.ncl ? load_fp<P>(a.r + ((size_t)k * a.n + j) * 8) : F::zero();
 #pragma unroll 1
-    for (int q = 0; q < 8; q++) {
+    for (int q = 0; q < a.ncl; q++) {
         F acc = arg_fp<P>(a.mat[q][0]) * r[0];
 #pragma unroll
-        for (int k = 1; k < 8; k++) acc = acc + arg_fp<P>(a.mat[q][k]) * r[k];
+        for (int k = 1; k < 8; k++)
+            if (k < a.ncl) acc = acc + arg_fp<P>(a.mat[q][k]) * r[k];
         store_fp<P>(a.out + ((size_t)q * a.n + j) * 8, acc);
     }
 }

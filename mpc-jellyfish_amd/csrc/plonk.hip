@@ -490,27 +490,41 @@ int32_t quotient_chunked_run(const PlonkPk& pk, const uint32_t* d_polys, uint64_
     return MZK_OK;
 }
 
-// the 8 class remainders (class-major, all resident here after the exchange) -> the 8n quotient coefficients
+// the class remainders (class-major in the order of `classes`, all resident here after the exchange) -> the 8n quotient
+// coefficients (slabs above the number of classes are zero: the classes given must determine t, i.e. deg t < ncl * n)
 template <class P>
-int32_t quotient_combine_run(int log_n, const uint32_t* d_r, uint32_t* d_out, hipStream_t st) {
+int32_t quotient_combine_run(int log_n, const uint32_t* classes, int ncl, const uint32_t* d_r, uint32_t* d_out, hipStream_t st) {
     using F = Fp<P>;
     const uint64_t n = 1ull << log_n;
     F w8 = F::from_const(P::ROOT);
     for (int i = 3; i < P::TWO_ADICITY; i++) w8 = sqr(w8);                   // primitive 8th root of unity = w_8n^n
-    const F g = F::from_const(P::GENERATOR);
-    const F gn_inv = inv(pow_u64(g, n)), w8_inv = inv(w8), eighth = inv(from_u64<P>(8));
+    const F gn = pow_u64(F::from_const(P::GENERATOR), n);
+    F c[8];
+    for (int k = 0; k < ncl; k++) c[k] = gn * pow_u64(w8, (uint64_t)classes[k]);      // c_k = h_k^n
     CombineArgs a;
-    a.r = d_r; a.out = d_out; a.n = n;
-    F sq = eighth;                                                            // g^(-nq) / 8
-    for (int q = 0; q < 8; q++) {
-        const F step = pow_u64(w8_inv, (uint64_t)q);                          // w_8^(-q)
-        F e = sq;
-        for (int k = 0; k < 8; k++) {
-            std::memcpy(a.mat[q][k], e.l, 32);
-            e = e * step;
+    std::memset(&a, 0, sizeof a);
+    a.r = d_r; a.out = d_out; a.n = n; a.ncl = ncl;
+    // inverse Vandermonde by Lagrange: column k of V^-1 holds the coefficients of L_k(X) = prod_{m != k} (X - c_m) / (c_k - c_m)
+    for (int k = 0; k < ncl; k++) {
+        F poly[9];
+        poly[0] = F::one();
+        int deg = 0;
+        F den = F::one();
+        for (int m = 0; m < ncl; m++) {
+            if (m == k) continue;
+            poly[deg + 1] = F::zero();
+            for (int d = deg + 1; d >= 1; d--) poly[d] = poly[d - 1] - c[m] * poly[d];        // times (X - c_m)
+            poly[0] = F::zero() - c[m] * poly[0];
+            deg++;
+            den = den * (c[k] - c[m]);
         }
-        sq = sq * gn_inv;
+        const F dinv = inv(den);
+        for (int q = 0; q < ncl; q++) {
+            const F e = poly[q] * dinv;
+            std::memcpy(a.mat[q][k], e.l, 32);
+        }
     }
+    if (ncl < PLK_RATIO) HIP_TRY(hipMemsetAsync(d_out + (size_t)ncl * n * 8, 0, (size_t)(PLK_RATIO - ncl) * n * 32, st));
     hipLaunchKernelGGL((plonk_combine_kernel<P>), dim3((unsigned)((n + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st, a);
     HIP_TRY(hipGetLastError());
     return MZK_OK;
@@ -620,9 +634,15 @@ int32_t plonk_quotient_chunked_dev(uint64_t handle, const uint32_t* d_polys, uin
     return pk->curve == 0 ? quotient_chunked_run<BlsFr>(*pk, d_polys, in_stride, in_len, tau, alpha, beta, gamma, d_out, st)
                           : quotient_chunked_run<BnFr>(*pk, d_polys, in_stride, in_len, tau, alpha, beta, gamma, d_out, st);
 }
-int32_t plonk_quotient_combine_dev(int curve, int log_n, const uint32_t* d_r, uint32_t* d_out, hipStream_t st) {
-    if ((curve != 0 && curve != 1) || log_n < 1 || log_n + 3 > (curve == 0 ? 32 : 28) || !d_r || !d_out) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
-    return curve == 0 ? quotient_combine_run<BlsFr>(log_n, d_r, d_out, st) : quotient_combine_run<BnFr>(log_n, d_r, d_out, st);
+int32_t plonk_quotient_combine_dev(int curve, int log_n, const uint32_t* classes, uint32_t n_classes, const uint32_t* d_r, uint32_t* d_out, hipStream_t st) {
+    if (curve != 0 && curve != 1) { set_error("unknown curve_id"); return MZK_ERR_INVALID_ARG; }
+    static const uint32_t all8[8] = {0, 1, 2, 3, 4, 5, 6, 7};
+    if (!classes) { classes = all8; n_classes = 8; }
+    bool ok = n_classes >= 1 && n_classes <= PLK_RATIO;
+    for (uint32_t i = 0; ok && i < n_classes; i++) ok = classes[i] < PLK_RATIO && (i == 0 || classes[i] > classes[i - 1]);
+    if (!ok) { set_error("combine: 1..8 strictly increasing residue classes < 8"); return MZK_ERR_INVALID_ARG; }
+    return curve == 0 ? quotient_combine_run<BlsFr>(log_n, classes, (int)n_classes, d_r, d_out, st)
+                      : quotient_combine_run<BnFr>(log_n, classes, (int)n_classes, d_r, d_out, st);
 }
 int plonk_pk_log_n(uint64_t handle) {
     auto it = g_pks.find(handle);

@@ -49,6 +49,7 @@ _SIGS = {
                                       C.POINTER(C.c_uint64)],
     "mzk_plonk_quotient_chunked_dev": [C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "mzk_plonk_quotient_combine_dev": [C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p],
+    "mzk_plonk_quotient_combine_classes_dev": [C.c_int32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p],
     "mzk_plookup_sorted_vec_dev": [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "mzk_plookup_product_dev": [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "mzk_plonk_perm_product_dev": [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],

@@ -157,18 +157,29 @@ def compute_quotient_chunked_dev(pk: ProvingKeyDevice, challenges: Challenges, p
     return out
 
 
-def combine_quotient_classes(curve, domain_size: int, class_remainders, out_dev=None, stream=None):
-    """SURVEY.md 8(e).3, after the exchange: (8, n, 4) class remainders (class-major) -> (8n, 4) quotient coefficients,
-    what `coset.ifft` returns at prover.rs:672.  Asynchronous."""
+def quotient_classes_needed(num_wire_types: int, domain_size: int) -> list[int]:
+    """The residue classes of the quotient domain that have to be evaluated: deg t = W (n + 1) + 2 (prover.rs:916-919) is below
+    (W + 1) n as soon as n > W + 2, so W + 1 of the 8 classes determine the quotient -- 6 for TurboPlonk, 7 for UltraPlonk;
+    tiny domains keep all 8."""
+    W, n = num_wire_types, domain_size
+    return list(range(W + 1)) if W * (n + 1) + 2 < (W + 1) * n and W + 1 <= 8 else list(range(8))
+
+
+def combine_quotient_classes(curve, domain_size: int, class_remainders, classes=None, out_dev=None, stream=None):
+    """SURVEY.md 8(e).3, after the exchange: (len(classes), n, 4) class remainders (class-major, in the order of `classes`;
+    default all 8) -> (8n, 4) quotient coefficients, what `coset.ifft` returns at prover.rs:672 (slabs above len(classes) zero).
+    Asynchronous."""
     import torch
     c = _curve(curve)
     n = domain_size
     r = class_remainders
-    assert tuple(r.shape) == (8, n, 4) and r.is_cuda and r.is_contiguous()
+    cl = list(range(8)) if classes is None else list(classes)
+    assert tuple(r.shape) == (len(cl), n, 4) and r.is_cuda and r.is_contiguous()
     out = torch.empty((8 * n, 4), dtype=torch.int64, device=r.device) if out_dev is None else out_dev
     st = torch.cuda.current_stream(r.device).cuda_stream if stream is None else stream
-    _lib.check(_lib.ensure_init().mzk_plonk_quotient_combine_dev(c.curve_id, n.bit_length() - 1, r.data_ptr(), out.data_ptr(), st),
-               "mzk_plonk_quotient_combine_dev")
+    ca = np.ascontiguousarray(cl, dtype=np.uint32)
+    _lib.check(_lib.ensure_init().mzk_plonk_quotient_combine_classes_dev(c.curve_id, n.bit_length() - 1, ca.ctypes.data_as(C.c_void_p), len(cl),
+                                                                         r.data_ptr(), out.data_ptr(), st), "mzk_plonk_quotient_combine_classes_dev")
     return out
 
 

@@ -162,10 +162,13 @@ class TurboPlonkProver:
     PlookupProvingKey) it is the UltraPlonk prover: 14 selectors, 6 wire types."""
 
     def __init__(self, curve, domain_size: int, selector_polys, sigma_polys, k, commit_key: kzg.UnivariateProverParam, plookup=None,
-                 quotient_classes=None, quotient_gather=None):
-        """quotient_classes / quotient_gather: the coset-chunked quotient of SURVEY.md 8(e).3 -- this rank keeps the listed residue
-        classes of the quotient domain (sharding.class_range) and `quotient_gather(local) -> (8, n, 4)` performs the one exchange
-        (sharding.gather_quotient_classes); with all 8 classes and no gather it is the single-GPU rehearsal of that path."""
+                 quotient_classes=None, quotient_gather=None, quotient_shard=None):
+        """quotient_classes / quotient_gather: the coset-chunked quotient of SURVEY.md 8(e).3.  The quotient is evaluated on the
+        residue classes plonk.quotient_classes_needed(W, n) only (6 of 8 for TurboPlonk, 7 for UltraPlonk: its degree needs no more).
+        quotient_classes = None (default): this GPU evaluates all of them; "whole": the un-chunked path over all 8n points (kept
+        for comparison).  quotient_shard = (rank, world): this rank keeps sharding.class_range(rank, world, needed) -- possibly no
+        class at all (8 GPUs, 6 classes) -- and `quotient_gather(local, n_classes) -> (n_classes, n, 4)` performs the one exchange
+        (sharding.gather_quotient_classes)."""
         import torch
         self.curve: CurveParams = _curve(curve)
         self.n = domain_size
@@ -177,7 +180,20 @@ class TurboPlonkProver:
         self.W = len(sigma_polys)
         self.nsel = len(selector_polys)
         self.quotient_gather = quotient_gather
-        self.pk = plonk.ProvingKeyDevice.register(self.curve, domain_size, selector_polys, sigma_polys, k, plookup, classes=quotient_classes)
+        self.W = len(sigma_polys)
+        self.classes_needed = plonk.quotient_classes_needed(self.W, domain_size)
+        if quotient_shard is not None:
+            from . import sharding as _sharding
+            quotient_classes = _sharding.class_range(quotient_shard[0], quotient_shard[1], len(self.classes_needed))
+        elif quotient_classes is None:
+            quotient_classes = self.classes_needed
+        elif isinstance(quotient_classes, str):
+            assert quotient_classes == "whole"
+            quotient_classes = None
+        self.own_classes = None if quotient_classes is None else list(quotient_classes)
+        # a rank that owns no class still registers one (the key cannot be empty); what it computes there is dropped
+        resident = quotient_classes if quotient_classes is None or len(quotient_classes) else [self.classes_needed[-1]]
+        self.pk = plonk.ProvingKeyDevice.register(self.curve, domain_size, selector_polys, sigma_polys, k, plookup, classes=resident)
         pad = lambda p: np.concatenate([np.asarray(p, dtype=np.uint64).reshape(-1, 4),
                                         np.zeros((domain_size - np.asarray(p).reshape(-1, 4).shape[0], 4), dtype=np.uint64)])
         tabs = [plookup[x] for x in plonk.PLOOKUP_TABLE_POLYS] if self.ultra else []
@@ -325,9 +341,13 @@ class TurboPlonkProver:
         if self.pk.classes is None:
             plonk.compute_quotient_polynomial_dev(self.pk, ch, slab, n + 3, quot)
         else:                                                            # local classes, one exchange, 8-point iDFT per coefficient
-            local = plonk.compute_quotient_chunked_dev(self.pk, ch, slab, n + 3)
-            every = self.quotient_gather(local) if self.quotient_gather is not None else local
-            plonk.combine_quotient_classes(c, n, every.contiguous(), out_dev=quot)
+            local = plonk.compute_quotient_chunked_dev(self.pk, ch, slab, n + 3) if self.own_classes else None
+            if local is None:                                            # this rank owns no class: it only takes part in the exchange
+                import torch
+                local = torch.empty((0, n, 4), dtype=torch.int64, device=slab.device)
+            every = self.quotient_gather(local, len(self.classes_needed)) if self.quotient_gather is not None else local
+            resident = self.classes_needed if self.quotient_gather is not None else self.own_classes
+            plonk.combine_quotient_classes(c, n, every.contiguous(), classes=resident, out_dev=quot)
         # quot_poly.degree() != expected_degree => WrongQuotientPolyDegree (prover.rs:915-918): the reference's only guard against an
         # unsatisfied witness (batch_prove_internal never runs check_circuit_satisfiability).  The length is computed on the
         # device now and read in check_quotient_degree, after the round's commitments have synchronised the stream anyway.

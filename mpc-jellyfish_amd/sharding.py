@@ -101,30 +101,39 @@ class ShardedCommitter:
         return np.stack([sum_jacobian(self.c, stacked[:, i]) for i in range(k)])
 
 
-def class_range(rank: int, world: int) -> list[int]:
-    """Residue classes mod 8 of the quotient domain owned by `rank`: contiguous blocks of 8 / world, so
-    that an all-gather in rank order is already class-major.  world must divide 8."""
-    if 8 % world:
-        raise ValueError("the coset-chunked quotient needs a world size dividing 8")
-    per = 8 // world
-    return list(range(rank * per, (rank + 1) * per))
+def class_range(rank: int, world: int, n_classes: int = 8) -> list[int]:
+    """Residue classes of the quotient domain owned by `rank` when the first `n_classes` classes are evaluated
+    (plonk.quotient_classes_needed: 6 for TurboPlonk, 7 for UltraPlonk, 8 for tiny domains): contiguous blocks of
+    ceil(n_classes / world), so that an all-gather in rank order is class-major; the last ranks may own fewer classes, or none."""
+    if world < 1 or not 0 <= rank < world:
+        raise ValueError("rank outside the world")
+    per = -(-n_classes // world)
+    return list(range(min(rank * per, n_classes), min((rank + 1) * per, n_classes)))
 
 
-def gather_quotient_classes(local, group=None, via_host: bool = False):
-    """The one exchange step of the chunked quotient: every rank contributes its (8 / G, n, 4) class remainders and
-    receives all (8, n, 4).  RCCL: all_gather_into_tensor on device tensors (n * 32 * 8 / G bytes per rank over xGMI);
-    gloo (CPU rehearsal): staged through host memory."""
+def gather_quotient_classes(local, group=None, via_host: bool = False, n_classes: int | None = None, per_rank: int | None = None):
+    """The one exchange step of the chunked quotient: every rank contributes its class remainders and receives all of them,
+    (n_classes, n, 4) class-major.  Ranks own ceil(n_classes / G) classes (class_range) except the last ones, which pad their
+    contribution to that size so that one fixed-size all-gather serves (the padding is dropped on arrival).
+    RCCL: all_gather_into_tensor on device tensors (n * 32 * per_rank bytes per rank over xGMI); gloo (CPU rehearsal): staged
+    through host memory.  n_classes defaults to (classes per rank) x G -- the even split."""
     import torch
     import torch.distributed as dist
     world = dist.get_world_size(group)
     if world == 1:
         return local
-    out_shape = (local.shape[0] * world,) + tuple(local.shape[1:])
+    if n_classes is None:
+        n_classes = local.shape[0] * world
+    per = -(-n_classes // world) if per_rank is None else per_rank
+    if local.shape[0] < per:                                              # a rank with fewer classes (or none) pads
+        pad = torch.zeros((per - local.shape[0],) + tuple(local.shape[1:]), dtype=local.dtype, device=local.device)
+        local = torch.cat([local, pad]) if local.shape[0] else pad
+    out_shape = (per * world,) + tuple(local.shape[1:])
     if via_host:
         h = local.cpu()
         parts = [torch.empty_like(h) for _ in range(world)]
         dist.all_gather(parts, h, group=group)
-        return torch.cat(parts).to(local.device)
+        return torch.cat(parts)[:n_classes].to(local.device)
     out = torch.empty(out_shape, dtype=local.dtype, device=local.device)
     dist.all_gather_into_tensor(out, local.contiguous(), group=group)
-    return out
+    return out[:n_classes]

@@ -109,7 +109,8 @@ def gen_circuit_for_bench(curve, num_gates: int, plonk_type: str = TURBO, range_
     return BenchCircuit(c, plonk_type, n, k, wire_values, sel, sigma, torch.zeros((n, 4), dtype=torch.int64, device=dev), [], tables)
 
 
-def preprocess(commit_key: kzg.UnivariateProverParam, circuit: BenchCircuit, quotient_classes=None, quotient_gather=None) -> _prover.TurboPlonkProver:
+def preprocess(commit_key: kzg.UnivariateProverParam, circuit: BenchCircuit, quotient_classes=None, quotient_gather=None,
+               quotient_shard=None) -> _prover.TurboPlonkProver:
     """snark.rs:529-617: interpolate selectors, sigmas (and Plookup tables), keep them with the commit key.  The
     verifying-key commitments are produced on demand by `TurboPlonkProver.vk_commitments()`."""
     c, n = circuit.curve, circuit.n
@@ -128,7 +129,7 @@ def preprocess(commit_key: kzg.UnivariateProverParam, circuit: BenchCircuit, quo
         tab_h = host(tab)
         plookup = {name: tab_h[i] for i, name in enumerate(("range_table_poly", "key_table_poly", "table_dom_sep_poly", "q_dom_sep_poly"))}
     return _prover.TurboPlonkProver(c, n, list(host(sel)), list(host(sig)), circuit.k, commit_key, plookup=plookup,
-                                    quotient_classes=quotient_classes, quotient_gather=quotient_gather)
+                                    quotient_classes=quotient_classes, quotient_gather=quotient_gather, quotient_shard=quotient_shard)
 
 
 def draw_blinders(curve, rng: _rng.ChaChaRng, num_wire_types: int, ultra: bool) -> _prover.Blinders:

@@ -1,6 +1,8 @@
-"""GPU: SURVEY.md 8(e).1 end to end -- two ranks (both on the box's one GPU, gloo for the 144-byte collectives) run
-PlonkKzgSnark::prove with every commitment's MSM split by point range (8(e).1) and the quotient domain split into residue
-classes with one exchange (8(e).3); both must emit exactly the proof bytes of the single-process run."""
+"""GPU: SURVEY.md 8(e) end to end -- 2, 4 and 6 ranks (all on the box's one GPU, gloo for the collectives; the pool allows at most
+six processes on a card, so a world of 8 is rehearsed on the CPU side only: tests/test_sharding.py) run PlonkKzgSnark::prove with
+every commitment's MSM split by point range (8(e).1) and the needed residue classes of the quotient domain -- 6 of 8 for
+TurboPlonk, 7 for UltraPlonk -- split over the ranks with one exchange (8(e).3; with 4 ranks and 6 classes one rank owns none);
+every rank must emit exactly the proof bytes of the single-process run."""
 import os
 import sys
 
@@ -23,8 +25,8 @@ def _worker(rank, world, port, curve_id, plonk_type, num_gates, out_dir):
         rng = mj.rng.test_rng()
         ck = mj.UnivariateProverParam.gen_srs_for_testing(c, mj.rng.fr_rand(c, rng), cs.n + 2)
         if world > 1:
-            gather = lambda local: mj.sharding.gather_quotient_classes(local, via_host=True)
-            pk = mj.snark.preprocess(ck, cs, quotient_classes=mj.sharding.class_range(rank, world), quotient_gather=gather)
+            gather = lambda local, n_classes: mj.sharding.gather_quotient_classes(local, via_host=True, n_classes=n_classes)
+            pk = mj.snark.preprocess(ck, cs, quotient_shard=(rank, world), quotient_gather=gather)
             pk.committer = mj.sharding.ShardedCommitter(c, ck)
         else:
             pk = mj.snark.preprocess(ck, cs)
@@ -35,36 +37,43 @@ def _worker(rank, world, port, curve_id, plonk_type, num_gates, out_dir):
         dist.destroy_process_group()
 
 
-@pytest.mark.parametrize("curve_id,plonk_type,num_gates", [(0, "TurboPlonk", 1 << 12), (1, "UltraPlonk", 1 << 11)])
-def test_sharded_prove_matches_single_process(gpu, tmp_path, curve_id, plonk_type, num_gates):
+@pytest.mark.parametrize("curve_id,plonk_type,num_gates,worlds", [(0, "TurboPlonk", 1 << 12, (2, 4)), (1, "UltraPlonk", 1 << 11, (2, 6)),
+                                                                 (0, "TurboPlonk", 1 << 10, (6,))])
+def test_sharded_prove_matches_single_process(gpu, tmp_path, curve_id, plonk_type, num_gates, worlds):
     import torch.multiprocessing as mp
     port = 29500 + (os.getpid() + num_gates) % 2000
-    ctx = mp.get_context("spawn")
-    for world in (1, 2):
+    for world in (1,) + tuple(worlds):
         mp.spawn(_worker, args=(world, port + world, curve_id, plonk_type, num_gates, str(tmp_path)), nprocs=world, join=True)
     single = (tmp_path / "proof_1_0.bin").read_bytes()
     assert len(single) > 500
-    for rank in range(2):
-        assert (tmp_path / f"proof_2_{rank}.bin").read_bytes() == single, rank
+    for world in worlds:
+        for rank in range(world):
+            assert (tmp_path / f"proof_{world}_{rank}.bin").read_bytes() == single, (world, rank)
 
 
 @pytest.mark.parametrize("curve_id,plonk_type,num_gates,classes", [(0, "TurboPlonk", 1 << 10, list(range(8))), (1, "UltraPlonk", 1 << 9, list(range(8))),
+                                                                  (0, "TurboPlonk", 1 << 10, None), (1, "UltraPlonk", 1 << 9, None),
+                                                                  (1, "TurboPlonk", 1 << 7, [0, 2, 3, 5, 6, 7]), (0, "UltraPlonk", 1 << 8, [1, 2, 3, 4, 5, 6, 7]),
                                                                   (0, "TurboPlonk", 64, [1, 4, 6])])
 def test_chunked_quotient_single_process(gpu, mj, curve_id, plonk_type, num_gates, classes):
-    """All 8 residue classes on one GPU: class-wise size-n coset NTTs + fused kernel + local inverse + 8-point iDFT must give
-    the very coefficients of the whole-domain quotient (coset FFT(8n) path).  A key holding 3 classes must produce those
-    classes' remainders t mod (X^n - h_k^n) of the same quotient."""
+    """Residue classes on one GPU: class-wise size-n coset NTTs + fused kernel + local inverse + the inverse Vandermonde per
+    coefficient must give the very coefficients of the whole-domain quotient (coset FFT(8n) path, `quotient_classes="whole"`) --
+    from all 8 classes (an 8-point iDFT), from the default reduced set (6 of 8 for TurboPlonk, 7 for UltraPlonk: deg t =
+    W (n + 1) + 2 needs no more, prover.rs:916-919) and from other class sets of that size.  A key holding 3 classes must produce
+    those classes' remainders t mod (X^n - h_k^n) of the same quotient."""
     import torch
     c = mj.params.CURVES[curve_id]
     cs = mj.snark.gen_circuit_for_bench(c, num_gates, plonk_type)
     n = cs.n
     rng = mj.rng.test_rng()
     ck = mj.UnivariateProverParam.gen_srs_for_testing(c, mj.rng.fr_rand(c, rng), n + 2)
-    pk0 = mj.snark.preprocess(ck, cs)
+    pk0 = mj.snark.preprocess(ck, cs, quotient_classes="whole")
     core0, bytes0 = mj.snark.prove(mj.rng.test_rng(), cs, pk0)
     quot0 = pk0.last["quot"].clone()
     pk1 = mj.snark.preprocess(ck, cs, quotient_classes=classes)
-    if len(classes) == 8:
+    if classes is None:
+        assert pk1.own_classes == list(range(7 if plonk_type == "UltraPlonk" else 6))
+    if classes is None or len(classes) >= 6:
         core1, bytes1 = mj.snark.prove(mj.rng.test_rng(), cs, pk1)
         assert torch.equal(pk1.last["quot"], quot0)
         assert bytes1 == bytes0

@@ -125,3 +125,52 @@ def test_host_batch_normalisation(mj, cref, curve_id):
     for i in range(batch.shape[0]):
         assert np.array_equal(got[i], cref.jac_to_affine(curve_id, batch[i])[0]), i
     assert mj.jacobian_to_affine(c, batch[:1]).any() == False and mj.jacobian_to_affine(c, batch[:0]).shape[0] == 0
+
+
+def test_class_range_covers_the_needed_classes_for_every_world():
+    """sharding.class_range: the 6 (TurboPlonk) / 7 (UltraPlonk) / 8 needed residue classes over 1..8 ranks -- contiguous, disjoint,
+    in rank order, every class owned exactly once; ranks beyond the classes own none (8 GPUs, 6 classes)."""
+    from importlib import import_module
+    sh = import_module("mpc-jellyfish_amd.sharding")
+    pl = import_module("mpc-jellyfish_amd.plonk")
+    assert pl.quotient_classes_needed(5, 1 << 20) == list(range(6)) and pl.quotient_classes_needed(6, 1 << 22) == list(range(7))
+    assert pl.quotient_classes_needed(5, 8) == list(range(6)) and pl.quotient_classes_needed(5, 4) == list(range(8))      # n <= W + 2: all 8
+    for ncl in (6, 7, 8):
+        for world in range(1, 9):
+            owned = [sh.class_range(r, world, ncl) for r in range(world)]
+            assert sum(owned, []) == list(range(ncl)), (ncl, world)
+            per = -(-ncl // world)
+            assert all(len(o) <= per for o in owned) and all(o == list(range(o[0], o[0] + len(o))) for o in owned if o)
+    assert sh.class_range(7, 8, 6) == [] and sh.class_range(3, 4, 6) == [] and sh.class_range(3, 4, 7) == [6]
+    with pytest.raises(ValueError):
+        sh.class_range(2, 2)
+
+
+def _gather_worker(rank, world, port, n_classes, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch
+    import torch.distributed as dist
+    from importlib import import_module
+    sh = import_module("mpc-jellyfish_amd.sharding")
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        own = sh.class_range(rank, world, n_classes)
+        local = torch.stack([torch.full((5, 4), 100 * k + 1, dtype=torch.int64) for k in own]) if own else torch.empty((0, 5, 4), dtype=torch.int64)
+        every = sh.gather_quotient_classes(local, via_host=True, n_classes=n_classes)
+        torch.save(every, os.path.join(out_dir, f"classes_{rank}.pt"))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_classes", [(4, 6), (8, 6), (8, 7), (2, 7)])
+def test_gather_of_unevenly_owned_classes(tmp_path, world, n_classes):
+    """The one exchange of the chunked quotient when the classes do not divide evenly (4 ranks x 6 classes: 2, 2, 2, 0;
+    8 ranks x 6 classes: two ranks own nothing): every rank receives the n_classes remainders, class-major, padding dropped."""
+    import torch
+    import torch.multiprocessing as mp
+    port = 29500 + (os.getpid() + 13 * world + n_classes) % 2000
+    mp.spawn(_gather_worker, args=(world, port, n_classes, str(tmp_path)), nprocs=world, join=True)
+    want = torch.stack([torch.full((5, 4), 100 * k + 1, dtype=torch.int64) for k in range(n_classes)])
+    for rank in range(world):
+        assert torch.equal(torch.load(tmp_path / f"classes_{rank}.pt"), want), rank

@@ -7,7 +7,7 @@ import os
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "mpc-jellyfish_amd", "csrc")
 MSM_SOURCES = ("msm.cuh", "msm_pre.cuh", "ecx.cuh", "fx.cuh")
-NTT_SOURCES = ("ntt_fx.cuh", "ntt.cuh", "fx.cuh")
+NTT_SOURCES = ("ntt_fx.cuh", "ntt.cuh", "fs.cuh", "fx.cuh")
 
 
 def sha16(files) -> str:
