@@ -35,7 +35,12 @@
 namespace mzk {
 
 constexpr int NTT_MAX_PASSES = 4;
-constexpr int NTT_TILE_LOG = 11;        // R*C <= 2048 elements = 72 KiB of LDS at 9 limbs (ntt_fx.cuh)
+#ifndef MZK_NTT_TILE_LOG
+#define MZK_NTT_TILE_LOG 10                            // (a -D override exists for A/B builds: profiles/r02_ntt_tile_ab.txt)
+#endif
+// R*C <= 1024 elements = 36 KiB of LDS at 9 limbs (ntt_fx.cuh): three 512-thread workgroups per CU, one butterfly per thread per
+// stage.  2048-element tiles (two workgroups per CU) run the same at 2^22 and above and 25 % slower at 2^16..2^18.
+constexpr int NTT_TILE_LOG = MZK_NTT_TILE_LOG;
 constexpr int NTT_MAX_LOG_R = 9;
 
 __device__ __forceinline__ unsigned bitrev(unsigned x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }

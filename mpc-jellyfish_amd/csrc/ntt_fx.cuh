@@ -22,8 +22,9 @@
 //   * Both directions run decimation-in-time; the forward coset offset is in the stage twiddles, the inverse applies N^-1 h^-j
 //     (and the internal-form factors 32 / 1/32 of the quotient kernels, plonk.cuh) as final products; a plain forward transform
 //     has no final product at all.
-// LDS: 9 words per element in three planes (b128, b128, b32): a 2048-element tile is 72 KiB, so two 512-thread workgroups share
-// a CU (one loads/stores while the other computes).
+// LDS: 9 words per element in three planes (b128, b128, b32): a 1024-element tile is 36 KiB, three 512-thread workgroups share a CU
+// (one butterfly per thread per stage).  Measured (profiles/r02_nttprof_*): 80 M VALU wave-instructions per pass at 2^22 (114 M for
+// the Montgomery version), 190 us per pass = ~85 % of the issue rate of that instruction mix.
 #pragma once
 #include <hip/hip_runtime.h>
 

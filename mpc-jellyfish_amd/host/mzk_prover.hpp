@@ -163,7 +163,8 @@ struct Prover {                                                        // Provin
     std::vector<Fr> k;
     uint64_t srs = 0, pk = 0;
     DevBuf fixed;                                                      // (nsel + W [+ 4]) x n coefficient forms
-    DevBuf slab, quot, keep, coeff, split, lin, batch, opening, shifted, hh, table, lookup, sorted, tmp, deg;
+    DevBuf slab, quot, keep, coeff, split, lin, batch, opening, shifted, hh, table, lookup, sorted, tmp, deg, rem;
+    std::vector<uint32_t> classes;
     std::vector<Affine> selector_comms, sigma_comms;
     std::map<std::string, double> timings_ms;
     Fr w_n, gen;
@@ -186,8 +187,14 @@ struct Prover {                                                        // Provin
         for (int i = 0; i < W; i++) std::memcpy(&kk[4 * i], k[i].l, 32);
         const uint64_t* sel = host.data();
         const uint64_t* sig = sel + (size_t)nsel * n * 4;
-        if (ultra) check(mzk_plonk_pk_register_ultra(C::ID, log_n, sel, sig, sig + (size_t)W * n * 4, n, kk.data(), &pk), "mzk_plonk_pk_register_ultra");
-        else check(mzk_plonk_pk_register(C::ID, log_n, W, sel, sig, n, kk.data(), &pk), "mzk_plonk_pk_register");
+        // The quotient has degree W (n + 1) + 2 < (W + 1) n (prover.rs:916-919): W + 1 of the 8 residue classes of the quotient domain
+        // determine it -- 6 for TurboPlonk, 7 for UltraPlonk -- so only those are resident and evaluated (tiny domains keep all 8)
+        classes.clear();
+        const uint32_t needed = ((uint64_t)W * (n + 1) + 2 < (uint64_t)(W + 1) * n && W + 1 <= 8) ? (uint32_t)W + 1 : 8u;
+        for (uint32_t kcl = 0; kcl < needed; kcl++) classes.push_back(kcl);
+        check(mzk_plonk_pk_register_chunked(C::ID, log_n, W, sel, sig, ultra ? sig + (size_t)W * n * 4 : nullptr, n, kk.data(), classes.data(),
+                                            (uint32_t)classes.size(), &pk), "mzk_plonk_pk_register_chunked");
+        rem.alloc(classes.size() * n);
         slab.alloc((size_t)rows * m); quot.alloc(m); keep.alloc((size_t)rows * (n + 3)); coeff.alloc((size_t)(W + 1) * n);
         split.alloc((size_t)W * (n + 3)); lin.alloc(n + 3); batch.alloc(n + 3); opening.alloc(n + 3); shifted.alloc(n + 3); tmp.alloc(64);
         if (ultra) { hh.alloc(2 * n); table.alloc(n); lookup.alloc(n); sorted.alloc(2 * n); }
@@ -327,8 +334,11 @@ struct Prover {                                                        // Provin
     void quotient(const Fr& alpha, Tick& tick) {
         st.alpha = alpha;
         check(mzk_dev_copy2d(keep.p, (n + 3) * EL, slab.p, m * EL, (n + 3) * EL, rows, nullptr), "copy2d");   // coefficient forms survive the in-place coset NTT
-        if (ultra) check(mzk_plonk_quotient_ultra_dev(pk, slab.p, n + 3, st.tau.l, alpha.l, st.beta.l, st.gamma.l, quot.p, nullptr), "mzk_plonk_quotient_ultra_dev");
-        else check(mzk_plonk_quotient_dev(pk, slab.p, n + 3, alpha.l, st.beta.l, st.gamma.l, quot.p, nullptr), "mzk_plonk_quotient_dev");
+        // per class: fold mod X^n - h_k^n, size-n coset NTTs, the fused kernel, size-n inverse coset NTT; then the inverse Vandermonde
+        check(mzk_plonk_quotient_chunked_dev(pk, slab.p, m, n + 3, ultra ? st.tau.l : nullptr, alpha.l, st.beta.l, st.gamma.l, rem.p, nullptr),
+              "mzk_plonk_quotient_chunked_dev");
+        check(mzk_plonk_quotient_combine_classes_dev(C::ID, log_n, classes.data(), (uint32_t)classes.size(), rem.p, quot.p, nullptr),
+              "mzk_plonk_quotient_combine_classes_dev");
         tick.mark("r3_quotient");
     }
     // split_quotient_polynomial (prover.rs:902-960) of the 8n coefficients at `q` into this->split; returns the W lengths

@@ -16,7 +16,7 @@ class MzkError(RuntimeError):
 
 
 def lib_path() -> str:
-    return os.path.join(_HERE, "libmi355zk.so")
+    return os.environ.get("MZK_LIB_PATH") or os.path.join(_HERE, "libmi355zk.so")      # (MZK_LIB_PATH: A/B builds of the library, tools/ only)
 
 
 _SIGS = {

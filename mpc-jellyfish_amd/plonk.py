@@ -40,7 +40,11 @@ class Challenges:
 
 
 class PlonkError(Exception):
-    """plonk/src/errors.rs:16-50."""
+    """plonk/src/errors.rs:16-50; `kind` names the variant when the reference has a dedicated one (e.g. WrongQuotientPolyDegree)."""
+
+    def __init__(self, msg: str, kind: str | None = None):
+        super().__init__(msg if kind is None else "%s: %s" % (kind, msg))
+        self.kind = kind
 
 
 class ProvingKeyDevice:

@@ -28,12 +28,7 @@ from .domain import Radix2EvaluationDomain
 from .params import CurveParams, curve as _curve, fr_to_mont
 
 
-class PlonkError(Exception):
-    """plonk/src/errors.rs `PlonkError`; `kind` names the variant."""
-
-    def __init__(self, kind: str, msg: str):
-        super().__init__("%s: %s" % (kind, msg))
-        self.kind = kind
+PlonkError = plonk.PlonkError
 
 
 @dataclass
@@ -206,9 +201,11 @@ class TurboPlonkProver:
         # the caching allocator would otherwise re-acquire gigabytes per proof
         rows = self.W + 2 + (3 if self.ultra else 0)
         dev = self.fixed.device
-        self._slab = torch.empty((rows, 8 * domain_size, 4), dtype=torch.int64, device=dev)
+        # the class-wise quotient reads the coefficient rows without overwriting them: n + 3 columns do, and no second copy is kept
+        chunked = self.pk.classes is not None
+        self._slab = torch.empty((rows, domain_size + 3 if chunked else 8 * domain_size, 4), dtype=torch.int64, device=dev)
         self._quot = torch.empty((8 * domain_size, 4), dtype=torch.int64, device=dev)
-        self._keep = torch.empty((rows, domain_size + 3, 4), dtype=torch.int64, device=dev)
+        self._keep = self._slab if chunked else torch.empty((rows, domain_size + 3, 4), dtype=torch.int64, device=dev)
         self._coeff = torch.empty((self.W + 1, domain_size, 4), dtype=torch.int64, device=dev)
 
     def vk_commitments(self):
@@ -336,7 +333,8 @@ class TurboPlonkProver:
         st.alpha = alpha
         t0 = time.perf_counter()
         slab, keep, quot = self._slab, self._keep, self._quot
-        keep.copy_(slab[:, :n + 3])                                      # coefficient forms survive the in-place coset NTT
+        if keep is not slab:
+            keep.copy_(slab[:, :n + 3])                                  # whole-domain path: coefficient forms survive the in-place coset NTT
         ch = plonk.Challenges(alpha, st.beta, st.gamma, st.tau)
         if self.pk.classes is None:
             plonk.compute_quotient_polynomial_dev(self.pk, ch, slab, n + 3, quot)
@@ -364,8 +362,8 @@ class TurboPlonkProver:
         got = int(quot_len.item()) - 1
         expected = self.W * (self.n + 1) + 2
         if got != expected:
-            raise PlonkError("WrongQuotientPolyDegree", "quotient polynomial of degree %d, expected %d (the witness does not satisfy the circuit)"
-                             % (got, expected))
+            raise PlonkError("quotient polynomial of degree %d, expected %d (the witness does not satisfy the circuit)" % (got, expected),
+                             kind="WrongQuotientPolyDegree")
 
     def _split_quotient(self, quot, blind_quot):
         """split_quotient_polynomial (prover.rs:902-960): W slices of n + 2 coefficients, masked by W - 1 scalars.  The scalars

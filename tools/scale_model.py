@@ -1,0 +1,151 @@
+#!/usr/bin/env python3
+"""tools/scale_model.py -- what `PlonkKzgSnark::prove` should take on G = 1, 2, 4, 8 GPUs, from components MEASURED ON ONE GPU.
+
+The driver measures the real 1 -> 8 curve on a node this builder never sees; this model is what that curve is to be checked
+against ("Next round" 6a).  Per configuration (C4: TurboPlonk / BLS12-381 / 2^20 gates; C5: UltraPlonk / BN254 / 2^22)
+and per G it measures, on this one GPU, exactly what rank 0 of a G-rank run executes:
+
+  commits      every batch_commit of the proof (round 1: W wires; 1.5: h_1, h_2; 2: z; 2.5: Plookup product; 3: W split-quotient
+               parts; 5: two openings) as ONE mzk_msm_batch_dev over the rank's point range [0, len / G) of every polynomial
+               (sharding.ShardedCommitter), on the SRS's fixed-base table;
+  quotient     the rank's ceil(needed / G) residue classes (needed = W + 1 of the 8) through mzk_plonk_quotient_chunked_dev, and
+               the inverse-Vandermonde combine every rank runs after the exchange;
+  replicated   everything else of a proof, which every rank repeats: wire / z iNTTs and masking, grand products, the Plookup
+               sorted vector, quotient split, evaluations, linearisation and opening polynomials, transcript -- taken from the
+               profiled rounds of a real single-GPU proof;
+and it ADDS, from stated constants (not measurable on one GPU):
+  collectives  one small all-gather per commit group (k x 144 / 96 bytes per rank) at SMALL_COLLECTIVE_US each, and the one
+               exchange of class remainders: (G - 1) x classes_per_rank x n x 32 bytes received per rank at XGMI_GBPS.
+
+    python tools/scale_model.py [--c5-log-n 22] > profiles/r02_scale_model.json
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+SMALL_COLLECTIVE_US = 40.0        # RCCL all-gather of a few hundred bytes over xGMI, incl. the device->host hop of the result
+XGMI_GBPS = 300.0                 # all-gather receive rate per GPU: 7 links x ~45 GB/s achieved of 64 GB/s per direction (MI355X_MICROARCH.md)
+
+
+def median_ms(fn, reps=5, warm=2):
+    import torch
+    for _ in range(warm):
+        fn()
+    torch.cuda.synchronize()
+    ts = []
+    for _ in range(reps):
+        t0 = time.perf_counter()
+        fn()
+        torch.cuda.synchronize()
+        ts.append((time.perf_counter() - t0) * 1e3)
+    return sorted(ts)[len(ts) // 2]
+
+
+def model(mj, curve, plonk_type, log_n):
+    import torch
+    c = curve
+    n = 1 << log_n
+    ultra = plonk_type == "UltraPlonk"
+    W = 6 if ultra else 5
+    cs = mj.snark.gen_circuit_for_bench(c, n, plonk_type)
+    rng = mj.rng.test_rng()
+    ck = mj.UnivariateProverParam.gen_srs_for_testing(c, mj.rng.fr_rand(c, rng), n + 2)
+    # ---- one real proof on one GPU: total and per-round times ----
+    pk = mj.snark.preprocess(ck, cs)
+    for _ in range(3):
+        mj.snark.prove(rng, cs, pk)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(5):
+        mj.snark.prove(rng, cs, pk)
+    torch.cuda.synchronize()
+    prove1_ms = (time.perf_counter() - t0) / 5 * 1e3
+    core, _ = mj.snark.prove(rng, cs, pk, profile=True)
+    rounds = dict(core.timings_ms)
+    needed = list(pk.classes_needed)
+    pk.release()
+    del pk
+    torch.cuda.empty_cache()
+    replicated_keys = [k for k in rounds if not k.endswith("_commit") and k != "r3_quotient"]
+    replicated_ms = sum(rounds[k] for k in replicated_keys)
+    # ---- commit groups: (number of polynomials, length) in proof order ----
+    groups = [("r1_wires", W, n + 2)]
+    if ultra:
+        groups.append(("r1_5_h", 2, n + 3))
+    groups.append(("r2_z", 1, n + 3))
+    if ultra:
+        groups.append(("r2_5_prod_lookup", 1, n + 3))
+    groups += [("r3_split_quotient", W, n + 3), ("r5_openings", 2, n + 2)]
+    scal = torch.from_numpy(mj.params.random_fr_mont(c, n + 3, seed=5).view(np.int64)).cuda()
+    out = {"config": {"plonk_type": plonk_type, "curve": c.name, "log_n": log_n, "classes_needed": len(needed)},
+           "measured_one_gpu": {"prove_ms": round(prove1_ms, 2), "rounds_ms": rounds, "replicated_ms": round(replicated_ms, 2),
+                                "replicated_stages": replicated_keys},
+           "per_G": {}}
+    # ---- quotient: chunked keys holding 1, 2, .. classes ----
+    class_ms = {}
+    slab = None
+    for per in sorted({-(-len(needed) // G) for G in (1, 2, 4, 8)}):
+        key = mj.snark.preprocess(ck, cs, quotient_classes=needed[:per])
+        if slab is None:
+            rows = W + 2 + (3 if ultra else 0)
+            slab = torch.from_numpy(mj.params.random_fr_mont(c, rows * (n + 3), seed=6).view(np.int64).reshape(rows, n + 3, 4)).cuda()
+        ch = mj.plonk.Challenges(0x1234567, 0x89abcde, 0xf012345, 0x1357911)
+        res = torch.empty((per, n, 4), dtype=torch.int64, device="cuda")
+        class_ms[per] = median_ms(lambda: mj.plonk.compute_quotient_chunked_dev(key.pk, ch, slab, n + 3, out_dev=res))
+        key.release()
+        del key, res
+        torch.cuda.empty_cache()
+    rem = torch.from_numpy(mj.params.random_fr_mont(c, len(needed) * n, seed=7).view(np.int64).reshape(len(needed), n, 4)).cuda()
+    quot = torch.empty((8 * n, 4), dtype=torch.int64, device="cuda")
+    combine_ms = median_ms(lambda: mj.plonk.combine_quotient_classes(c, n, rem, classes=needed, out_dev=quot))
+    del rem, quot
+    point_bytes = 3 * c.fq_limbs * 8
+    for G in (1, 2, 4, 8):
+        commits = {}
+        for name, k, length in groups:
+            hi = length // G if G > 1 else length                       # rank 0's point range [0, len / G)
+            sets = [scal[:hi]] * k
+            commits[name] = round(median_ms(lambda: mj.msm_bigint_batch(ck, sets, scalars_are_mont=True)), 3)
+        per = -(-len(needed) // G)
+        gather_bytes = (G - 1) * per * n * 32
+        exchange_ms = 0.0 if G == 1 else SMALL_COLLECTIVE_US / 1e3 + gather_bytes / (XGMI_GBPS * 1e9) * 1e3
+        small_ms = 0.0 if G == 1 else len(groups) * SMALL_COLLECTIVE_US / 1e3
+        total = sum(commits.values()) + class_ms[per] + combine_ms + exchange_ms + small_ms + replicated_ms
+        out["per_G"][str(G)] = {"commits_ms": commits, "commit_total_ms": round(sum(commits.values()), 2),
+                                "quotient_classes_per_rank": per, "quotient_local_ms": round(class_ms[per], 3), "combine_ms": round(combine_ms, 3),
+                                "class_exchange_ms": round(exchange_ms, 3), "class_exchange_bytes_received": gather_bytes,
+                                "small_collectives_ms": round(small_ms, 3), "replicated_ms": round(replicated_ms, 2),
+                                "predicted_prove_ms": round(total, 2)}
+    base = out["per_G"]["1"]["predicted_prove_ms"]
+    for G in ("1", "2", "4", "8"):
+        out["per_G"][G]["speedup_vs_1"] = round(base / out["per_G"][G]["predicted_prove_ms"], 2)
+    out["model_vs_measured_at_G1"] = round(base / prove1_ms, 3)
+    ck.release()
+    return out
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--c4-log-n", type=int, default=20)
+    ap.add_argument("--c5-log-n", type=int, default=22)
+    args = ap.parse_args()
+    import mpc_jellyfish_amd as mj
+    from importlib import import_module
+    import_module("mpc-jellyfish_amd.lib").init(0)
+    res = {"what": "predicted PlonkKzgSnark::prove time on G GPUs from single-GPU measurements of each rank's share (tools/scale_model.py)",
+           "constants": {"small_collective_us": SMALL_COLLECTIVE_US, "xgmi_allgather_GBps_per_gpu": XGMI_GBPS},
+           "C4_turbo_bls12_381": model(mj, mj.params.BLS12_381, "TurboPlonk", args.c4_log_n)}
+    if args.c5_log_n:
+        res["C5_ultra_bn254"] = model(mj, mj.params.BN254, "UltraPlonk", args.c5_log_n)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()
