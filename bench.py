@@ -185,7 +185,8 @@ def main():
             valu = {"wave_insts_per_launch": insts, "issue_bound_ms": round(bound_ms, 3), "util": round(bound_ms / acc_ms, 3),
                     "int_mad_per_s": round(mads / (acc_ms * 1e-3), -9), "int_mad_peak_per_s": round(1024 * 64 / (VOP3_NS * 1e-9), -9),
                     "note": "SQ_INSTS_VALU of the committed PMC pass x 1.9 ns / 1024 SIMDs vs the live launch time"}
-        return {"bound": "hbm", "kernel": "msm_accumulate_kernel<EcFx<BlsFqX>>", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
+        kname, _ = _pmc(pmc_prefix + "_kernel", srchash.MSM_SOURCES)
+        return {"bound": "hbm", "kernel": kname or "msm_accumulate_kernel<EcFx<BlsFqX>>", "achieved": round(achieved, 3), "peak": HBM_PEAK_GBS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 6), "traffic": traffic, "traffic_source": note, "algorithmic_bytes_per_launch": alg_bytes,
                 "avg_launch_ms": round(acc_ms, 4), "valu_issue": valu,
                 "note": "integer-ALU bound (381-bit Montgomery mixed adds), not HBM bound: see DESIGN.md"}

@@ -5,6 +5,7 @@
 #include <vector>
 
 #include <cmath>
+#include <cstdlib>
 
 #include "internal.hpp"
 #include "hostfp.hpp"
@@ -295,6 +296,10 @@ int32_t srs_build_pre_t(Srs& s, hipStream_t st) {
     int c;
     if (s.curve == MZK_CURVE_BLS12_381) c = lg <= 16 ? 16 : 20;
     else c = lg <= 15 ? 15 : (lg <= 18 ? 17 : 20);
+    if (const char* force = std::getenv("MZK_PRE_C")) {            // tuning only (tools/msm_window_sweep.py): force the table's window
+        const int f = std::atoi(force);
+        if (f >= 8 && f <= 22) c = f;
+    }
     const int W = msm_num_windows(256, c);
     const size_t level = (size_t)s.n * EC::AFF_WORDS;
     size_t free_b = 0, total_b = 0;

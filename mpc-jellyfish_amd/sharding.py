@@ -66,15 +66,24 @@ class ShardedCommitter:
     `msm_batch(ck, scalars_list, base_offsets) -> (k, 3, fq_limbs)` defaults to the device path; the CPU tests inject
     the oracle there."""
 
-    def __init__(self, curve, ck, group=None, device=None, msm_batch=None):
+    def __init__(self, curve, ck, group=None, device=None, msm_batch=None, slice_srs: bool = False):
+        """slice_srs: register this rank's point range of the SRS as an SRS of its own.  The fixed-base table's window is chosen
+        by SRS size (csrc/msm.hip srs_build_pre_t): a 2^17-point slice gets a small window and 2^15 buckets per MSM instead of the
+        full SRS's 2^19 -- at 8 GPUs the bucket reduction, not the accumulation, is what a shard's MSM costs -- and the rank
+        holds 1 / G of the table."""
         self.c = _curve(curve)
         self.ck, self.group, self.device = ck, group, device
         self.msm_batch = msm_batch
+        self.slice_srs = slice_srs and ck is not None and msm_batch is None
+        self._slice = None
 
     def _local(self, slices, offsets):
         if self.msm_batch is not None:
             return self.msm_batch(self.ck, slices, offsets)
         from . import kzg
+        if self._slice is not None:
+            lo = self._slice_lo
+            return kzg.msm_bigint_batch(self._slice, slices, [o - lo for o in offsets], scalars_are_mont=True)
         return kzg.msm_bigint_batch(self.ck, slices, offsets, scalars_are_mont=True)
 
     def commit_jacobian(self, polys) -> np.ndarray:
@@ -85,12 +94,20 @@ class ShardedCommitter:
         world = dist.get_world_size(self.group)
         rank = dist.get_rank(self.group)
         k, L = len(polys), self.c.fq_limbs
+        # ONE partition of the point indices for all polynomials -- by the SRS length when there is an SRS (so that a rank always
+        # works on the same points and can keep just those), else by the longest polynomial of the call
+        total = self.ck.length if self.ck is not None else max([int(p.shape[0]) for p in polys] + [1])
+        lo_r, hi_r = shard_range(total, rank, world)
+        if self.slice_srs and self._slice is None and hi_r > lo_r:
+            from . import kzg
+            self._slice = kzg.UnivariateProverParam.from_affine(self.c, self.ck.powers_of_g(lo_r, hi_r - lo_r))
+            self._slice_lo = lo_r
         slices, offsets = [], []
         for p in polys:
-            lo, hi = shard_range(int(p.shape[0]), rank, world)
+            lo, hi = min(lo_r, int(p.shape[0])), min(hi_r, int(p.shape[0]))
             s = p[lo:hi]
             slices.append(s.contiguous() if hasattr(s, "contiguous") else np.ascontiguousarray(s))
-            offsets.append(lo)
+            offsets.append(lo if hi > lo else lo_r)
         part = np.ascontiguousarray(self._local(slices, offsets), dtype=np.uint64).reshape(k, 3, L)
         t = torch.from_numpy(part.view(np.int64).reshape(-1).copy())
         if self.device is not None:
@@ -99,6 +116,11 @@ class ShardedCommitter:
         dist.all_gather(parts, t, group=self.group)
         stacked = torch.stack(parts).cpu().numpy().view(np.uint64).reshape(world, k, 3, L)
         return np.stack([sum_jacobian(self.c, stacked[:, i]) for i in range(k)])
+
+    def release(self):
+        if self._slice is not None:
+            self._slice.release()
+            self._slice = None
 
 
 def class_range(rank: int, world: int, n_classes: int = 8) -> list[int]:

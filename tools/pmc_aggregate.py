@@ -43,13 +43,20 @@ def hbm(k, double_fetch):
     return int((k.get("FETCH_SIZE_KB_raw", 0) * (2 if double_fetch else 1) + k.get("WRITE_SIZE_KB", 0)) * 1024)
 
 
+# the hash written on the GPU box when the counters were collected (tools/pmc_passes.sh); an older run without it is stamped
+# with the tree as it stands, which is only right if nothing changed in between
+try:
+    w = open(os.path.join(tag_dir, "srchash.txt")).read().split()
+    stamp = {w[0]: w[1], w[2]: w[3]}
+except Exception:
+    stamp = {"msm": srchash.sha16(srchash.MSM_SOURCES), "ntt": srchash.sha16(srchash.NTT_SOURCES)}
 table, plain = collect(("p1", "p2", "p3")), collect(("q1", "q2", "q3"))
 acc_name = next(k for k in table if "msm_accumulate_kernel" in k)
 ntt_name = next(k for k in table if "nttx_pass_kernel" in k)
 out = {"source": "tools/pmc_passes.sh + tools/pmc_aggregate.py: rocprofv3 --kernel-trace --pmc <one group per pass> -- python3 bench.py "
                  "--steps 2 --warmup 1 --no-cpu-baseline --no-plonk --no-variable-base; separate passes (SQ group, FETCH_SIZE, WRITE_SIZE), "
                  "p* with the fixed-base table, q* with MZK_BENCH_TABLE=0",
-       "source_sha16": {"msm": srchash.sha16(srchash.MSM_SOURCES), "ntt": srchash.sha16(srchash.NTT_SOURCES)},
+       "source_sha16": stamp,
        "units": "FETCH_SIZE / WRITE_SIZE in KB per launch (mean over launches).  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports 1/2 of the "
                 "bytes of a wide coalesced streaming read (NTT passes: 16 B/lane) -- doubled below for the NTT; the MSM gather (16-B loads at "
                 "random rows of the SRS / its table) is uncalibrated and taken as reported.",
@@ -57,8 +64,11 @@ out = {"source": "tools/pmc_passes.sh + tools/pmc_aggregate.py: rocprofv3 --kern
        "msm_accumulate_SQ_INSTS_VALU": table[acc_name].get("SQ_INSTS_VALU"),
        "ntt_pass_kernel": ntt_name, "ntt_pass_hbm_bytes_per_launch": hbm(table[ntt_name], True),
        "ntt_pass_SQ_INSTS_VALU": table[ntt_name].get("SQ_INSTS_VALU"), "kernels": table}
-if acc_name in plain:
-    out.update({"msm_accumulate_plain_hbm_bytes_per_launch": hbm(plain[acc_name], False),
-                "msm_accumulate_plain_SQ_INSTS_VALU": plain[acc_name].get("SQ_INSTS_VALU"), "kernels_table_off": plain})
+# table off: 16 windows of 2^15 buckets at 2^20 pairs -- mean load 32, so every bucket is split over several threads
+# (msm_accumulate_split_kernel + msm_split_combine_kernel); the accumulation launch is the one quoted
+pname = next((k for k in plain if "msm_accumulate" in k), None)
+if pname:
+    out.update({"msm_accumulate_plain_kernel": pname, "msm_accumulate_plain_hbm_bytes_per_launch": hbm(plain[pname], False),
+                "msm_accumulate_plain_SQ_INSTS_VALU": plain[pname].get("SQ_INSTS_VALU"), "kernels_table_off": plain})
 json.dump(out, open(out_path, "w"), indent=1)
 print(out_path, out["msm_accumulate_hbm_bytes_per_launch"], out.get("msm_accumulate_plain_hbm_bytes_per_launch"), out["ntt_pass_hbm_bytes_per_launch"])

@@ -5,6 +5,7 @@
 # p1..p3: the headline on its default (fixed-base table) path + the NTT; q1..q3: the headline with the table off (plain Pippenger).
 export TMPDIR=/tmp; R=$PWD; TAG=${1:-pmc}
 mkdir -p gpurun_out/$TAG
+python3 tools/srchash.py > gpurun_out/$TAG/srchash.txt      # the kernel sources these counters are collected on
 ARGS="--steps 2 --warmup 1 --no-cpu-baseline --no-plonk --no-variable-base"
 SQ="SQ_WAVES SQ_INSTS_VALU SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_VALU SQ_WAIT_INST_ANY SQ_WAIT_ANY GRBM_GUI_ACTIVE"
 rocprofv3 --kernel-trace --pmc $SQ --output-format csv -d $R/gpurun_out/$TAG/p1 -- python3 bench.py $ARGS > gpurun_out/$TAG/p1.log 2>&1 &&
