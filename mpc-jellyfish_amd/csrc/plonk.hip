@@ -477,11 +477,14 @@ int32_t quotient_chunked_run(const PlonkPk& pk, const uint32_t* d_polys, uint64_
         a.out = d_out + lc * n * 8;
         a.zh_class = k;
         const dim3 grid((unsigned)((n + PLK_THREADS - 1) / PLK_THREADS));
-        if (pk.ultra) {
-            hipLaunchKernelGGL((plonk_quotient_kernel<typename FxOf<P>::type, true>), grid, dim3(PLK_THREADS), 0, st, a);
-            hipLaunchKernelGGL((plonk_quotient_lookup_kernel<typename FxOf<P>::type>), grid, dim3(PLK_THREADS), 0, st, a);
-        } else {
-            hipLaunchKernelGGL((plonk_quotient_kernel<typename FxOf<P>::type, false>), grid, dim3(PLK_THREADS), 0, st, a);
+        {
+            ProfScope ps("plonk_quotient_kernel", st);
+            if (pk.ultra) {
+                hipLaunchKernelGGL((plonk_quotient_kernel<typename FxOf<P>::type, true>), grid, dim3(PLK_THREADS), 0, st, a);
+                hipLaunchKernelGGL((plonk_quotient_lookup_kernel<typename FxOf<P>::type>), grid, dim3(PLK_THREADS), 0, st, a);
+            } else {
+                hipLaunchKernelGGL((plonk_quotient_kernel<typename FxOf<P>::type, false>), grid, dim3(PLK_THREADS), 0, st, a);
+            }
         }
         HIP_TRY(hipGetLastError());
         MZK_TRY(ntt_dispatch(pk.curve, d_out + lc * n * 8, n, pk.log_n, true, pk.h_cls[k], 1, n, st, 2));  // back to the boundary form
