@@ -98,7 +98,7 @@ MZK_HD XYZZX<X> xyzzx_dbl(const XYZZX<X>& p) {
     return r;
 }
 
-// P +- Q, Q affine and canonical; `negate` adds -Q.  10 products, 5 fx_norm.
+// P +- Q, Q affine and canonical; `negate` adds -Q.  10 products -- the two of Y3 share one Montgomery reduction (fx_mul2) --, 4 fx_norm.
 template <class X>
 MZK_HD XYZZX<X> xyzzx_madd(const XYZZX<X>& p, const AffineX<X>& q, bool negate) {
     if (q.is_inf()) return p;
@@ -128,13 +128,13 @@ MZK_HD XYZZX<X> xyzzx_madd(const XYZZX<X>& p, const AffineX<X>& q, bool negate) 
     const Fx<X> qv = fx_mul(p.x, pp);                                       // M
     r.x = fx_norm(fx_sub32(rr2, fx_add(ppp, fx_add(qv, qv))));              // R^2 - PPP - 2Q: N, < 34p
     const Fx<X> d = fx_norm(fx_sub_pad<X>(qv, r.x, X::XSUB64));             // Q - X3, N
-    r.y = fx_norm(fx_sub2(fx_mul(rr_, d), fx_mul(p.y, ppp)));               // N, < 4p
+    r.y = fx_mul2(rr_, d, p.y, fx_neg_m(ppp));                              // R (Q - X3) - Y1 PPP in ONE reduction: M, < 2p
     r.zz = fx_mul(p.zz, pp);                                                // M
     r.zzz = fx_mul(p.zzz, ppp);                                             // M
     return r;
 }
 
-// P + Q, both accumulators.  14 products.
+// P + Q, both accumulators.  14 products (two of them fused into one reduction).
 template <class X>
 MZK_HD XYZZX<X> xyzzx_add(const XYZZX<X>& p, const XYZZX<X>& q) {
     if (q.is_inf()) return p;
@@ -154,7 +154,7 @@ MZK_HD XYZZX<X> xyzzx_add(const XYZZX<X>& p, const XYZZX<X>& q) {
     const Fx<X> qv = fx_mul(u1, pp);
     r.x = fx_norm(fx_sub32(rr2, fx_add(ppp, fx_add(qv, qv))));
     const Fx<X> d = fx_norm(fx_sub_pad<X>(qv, r.x, X::XSUB64));
-    r.y = fx_norm(fx_sub2(fx_mul(rr_, d), fx_mul(s1, ppp)));
+    r.y = fx_mul2(rr_, d, s1, fx_neg_m(ppp));
     r.zz = fx_mul(fx_mul(p.zz, q.zz), pp);
     r.zzz = fx_mul(fx_mul(p.zzz, q.zzz), ppp);
     return r;

@@ -75,6 +75,44 @@ MZK_HD Fx<X> fx_mul(const Fx<X>& x, const Fx<X>& y) {
     t.l[N - 1] = (uint32_t)acc;
     return t;
 }
+// (x*y + u*v)/R' mod p with ONE Montgomery reduction: 3 N^2 multiply-adds instead of the 4 N^2 of two products (the m*p half is
+// shared), and the sum needs no pad, subtraction or normalisation.  Column sums must stay below 2^64: with N <= 14,
+//   14 * max|x_i y_j| + 14 * max|u_i v_j| + 14 * 2^58 < 2^64,
+// e.g. x, y, u weakly normalised (< 2^29 + 2^27) and v < 2^30 (a negated class-M value, fx_neg_m): 14 (1.57 + 2.5 + 1) 2^58 < 2^64 -- or
+// x, y, u in N (< 2^29 + 8) and v < 2^30: 56 * 2^58.  Value bound: result < p (A B + C D) / 2^HEADROOM + p.
+template <class X>
+MZK_HD Fx<X> fx_mul2(const Fx<X>& x, const Fx<X>& y, const Fx<X>& u, const Fx<X>& v) {
+    constexpr int N = X::XN;
+    uint32_t m[N];
+    Fx<X> t;
+    uint64_t acc = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++) {
+#pragma unroll
+        for (int i = 0; i <= k; i++) {
+            acc += (uint64_t)x.l[i] * y.l[k - i];
+            acc += (uint64_t)u.l[i] * v.l[k - i];
+        }
+#pragma unroll
+        for (int i = 0; i < k; i++) acc += (uint64_t)m[i] * X::XP[k - i];
+        m[k] = ((uint32_t)acc * X::XINV) & XMASK;
+        acc += (uint64_t)m[k] * X::XP[0];
+        acc >>= XL;
+    }
+#pragma unroll
+    for (int k = N; k < 2 * N - 1; k++) {
+#pragma unroll
+        for (int i = k - N + 1; i < N; i++) {
+            acc += (uint64_t)x.l[i] * y.l[k - i];
+            acc += (uint64_t)u.l[i] * v.l[k - i];
+            acc += (uint64_t)m[i] * X::XP[k - i];
+        }
+        t.l[k - N] = (uint32_t)acc & XMASK;
+        acc >>= XL;
+    }
+    t.l[N - 1] = (uint32_t)acc;
+    return t;
+}
 // x^2/R': the off-diagonal products x_i*x_j (i < j) are taken once against the doubled operand 2*x_j
 // (limbs < 2^30: no overflow, and a column still sums to < 2^64), so the x*x half needs N(N+1)/2
 // multiply-adds instead of N^2 -- 23 % fewer v_mad_u64_u32 per squaring at 14 limbs.  Same contract as fx_mul.

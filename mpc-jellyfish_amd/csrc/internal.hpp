@@ -121,6 +121,8 @@ int32_t plookup_product_dev(uint64_t handle, const uint32_t* d_table, const uint
 int plonk_pk_is_ultra(uint64_t handle);
 int32_t plonk_perm_product_dev(uint64_t handle, const uint32_t* d_wires, const uint32_t* beta, const uint32_t* gamma, uint32_t* d_out, hipStream_t st);
 int plonk_pk_log_n(uint64_t handle);
+int plonk_pk_curve(uint64_t handle);
+int plonk_pk_classes(uint64_t handle, uint32_t* out);
 int plonk_pk_wires(uint64_t handle);
 
 }  // namespace mzk

@@ -578,14 +578,33 @@ int32_t mzk_plonk_quotient(uint64_t pk_handle, const uint64_t* polys, uint64_t i
     if (log_n < 0) { set_error("unknown proving-key handle"); return MZK_ERR_BAD_HANDLE; }
     if (plonk_pk_is_ultra(pk_handle) == 1) { set_error("UltraPlonk proving key: use mzk_plonk_quotient_ultra_dev"); return MZK_ERR_INVALID_ARG; }
     if (!polys || !out || in_len == 0 || in_len > (8ull << log_n)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
-    const uint64_t m = 8ull << log_n;
+    const uint64_t n = 1ull << log_n, m = 8 * n;
     hipStream_t st = nullptr;
-    MZK_TRY(g_ws.plonk_polys.reserve((size_t)(W + 2) * m * 32));
     MZK_TRY(g_ws.plonk_out.reserve(m * 32));
-    HIP_TRY(hipMemcpy2DAsync(g_ws.plonk_polys.p, m * 32, polys, in_len * 32, in_len * 32, W + 2, hipMemcpyHostToDevice, st));
-    MZK_TRY(plonk_quotient_dev(pk_handle, g_ws.plonk_polys.as<uint32_t>(), in_len, nullptr, reinterpret_cast<const uint32_t*>(alpha_mont),
-                               reinterpret_cast<const uint32_t*>(beta_mont), reinterpret_cast<const uint32_t*>(gamma_mont),
-                               g_ws.plonk_out.as<uint32_t>(), st));
+    uint32_t classes[8];
+    const int ncl = plonk_pk_classes(pk_handle, classes);
+    if (ncl > 0) {
+        // a key holding residue classes of the quotient domain (the default of both hosts): the rows are read in place (stride in_len),
+        // class remainders, then the inverse Vandermonde -- valid when the classes determine the quotient: deg t < ncl * n
+        if ((uint64_t)W * (n + 1) + 2 >= (uint64_t)ncl * n || in_len > 2 * n) {
+            set_error("chunked proving key: its classes do not determine the quotient (or a polynomial of degree >= 2n)");
+            return MZK_ERR_INVALID_ARG;
+        }
+        MZK_TRY(g_ws.io.reserve((size_t)(W + 2) * in_len * 32));
+        MZK_TRY(g_ws.link_tmp.reserve((size_t)ncl * n * 32));
+        HIP_TRY(hipMemcpyAsync(g_ws.io.p, polys, (size_t)(W + 2) * in_len * 32, hipMemcpyHostToDevice, st));
+        MZK_TRY(plonk_quotient_chunked_dev(pk_handle, g_ws.io.as<uint32_t>(), in_len, in_len, nullptr, reinterpret_cast<const uint32_t*>(alpha_mont),
+                                           reinterpret_cast<const uint32_t*>(beta_mont), reinterpret_cast<const uint32_t*>(gamma_mont),
+                                           g_ws.link_tmp.as<uint32_t>(), st));
+        MZK_TRY(plonk_quotient_combine_dev(plonk_pk_curve(pk_handle), log_n, classes, (uint32_t)ncl, g_ws.link_tmp.as<uint32_t>(),
+                                           g_ws.plonk_out.as<uint32_t>(), st));
+    } else {
+        MZK_TRY(g_ws.plonk_polys.reserve((size_t)(W + 2) * m * 32));
+        HIP_TRY(hipMemcpy2DAsync(g_ws.plonk_polys.p, m * 32, polys, in_len * 32, in_len * 32, W + 2, hipMemcpyHostToDevice, st));
+        MZK_TRY(plonk_quotient_dev(pk_handle, g_ws.plonk_polys.as<uint32_t>(), in_len, nullptr, reinterpret_cast<const uint32_t*>(alpha_mont),
+                                   reinterpret_cast<const uint32_t*>(beta_mont), reinterpret_cast<const uint32_t*>(gamma_mont),
+                                   g_ws.plonk_out.as<uint32_t>(), st));
+    }
     HIP_TRY(hipMemcpyAsync(out, g_ws.plonk_out.p, m * 32, hipMemcpyDeviceToHost, st));
     HIP_TRY(hipStreamSynchronize(st));
     return MZK_OK;

@@ -647,6 +647,17 @@ int32_t plonk_quotient_combine_dev(int curve, int log_n, const uint32_t* classes
     return curve == 0 ? quotient_combine_run<BlsFr>(log_n, classes, (int)n_classes, d_r, d_out, st)
                       : quotient_combine_run<BnFr>(log_n, classes, (int)n_classes, d_r, d_out, st);
 }
+// number of resident residue classes of a chunked key (0: whole-domain key, -1: unknown handle); `out` receives them
+int plonk_pk_classes(uint64_t handle, uint32_t* out /* 8 slots, nullable */) {
+    auto it = g_pks.find(handle);
+    if (it == g_pks.end()) return -1;
+    if (out) for (size_t i = 0; i < it->second->cls.size(); i++) out[i] = (uint32_t)it->second->cls[i];
+    return (int)it->second->cls.size();
+}
+int plonk_pk_curve(uint64_t handle) {
+    auto it = g_pks.find(handle);
+    return it == g_pks.end() ? -1 : it->second->curve;
+}
 int plonk_pk_log_n(uint64_t handle) {
     auto it = g_pks.find(handle);
     return it == g_pks.end() ? -1 : it->second->log_n;

@@ -39,7 +39,7 @@ def big_keys(d):
     vb = d["variable_base"]
     assert vb["value"] > 0 and vb["same_point_as_table_path"] is True and vb["roofline"]["bound"] == "hbm"
     assert d["cpu_baseline"]["gpu_variable_base_over_cpu"] > 0
-    assert set(d["prove_dropin"]["ms"]) == {"pageable", "pinned", "batch"} and all(v > 0 for v in d["prove_dropin"]["ms"].values())
+    assert set(d["prove_dropin"]["ms"]) == {"pageable", "pinned", "batch", "four_site"} and all(v > 0 for v in d["prove_dropin"]["ms"].values())
     assert d["prove"]["reps"] == 10 and d["prove"]["min_ms"] <= d["prove"]["prove_ms"] <= d["prove"]["max_ms"] * 1.5
     return True
 

@@ -90,11 +90,23 @@ def test_quotient_of_a_satisfied_circuit_is_a_low_degree_polynomial(gpu, mj, cre
     gate = (S[11] + sum(S[j] * W[j] for j in range(4)) + S[4] * W[0] * W[1] + S[5] * W[2] * W[3]
             + S[12] * W[0] * W[1] * W[2] * W[3] * W[4] + sum(S[6 + j] * pow(W[j], 5, r) for j in range(4)) - S[10] * W[4]) % r
     assert ev(t) * (pow(x, n, r) - 1) % r == gate
+    # the host-pointer entry point over a key that holds only the 6 needed residue classes (the hosts' default) returns the same
+    # 8n coefficients as over the whole-domain key; over 5 classes -- which cannot determine a degree-(5n + 7) quotient -- it refuses
+    pk6 = mj.plonk.ProvingKeyDevice.register(c, n, sel_polys, sigma_polys, k, classes=mj.plonk.quotient_classes_needed(5, n))
+    assert np.array_equal(mj.plonk.compute_quotient_polynomial(pk6, ch, wire_polys, z_poly, pi_poly), t)
+    pk5 = mj.plonk.ProvingKeyDevice.register(c, n, sel_polys, sigma_polys, k, classes=[0, 1, 2, 3, 4])
+    with pytest.raises(Exception):
+        mj.plonk.compute_quotient_polynomial(pk5, ch, wire_polys, z_poly, pi_poly)
+    pk5.release()
     # an unsatisfied gate breaks divisibility
     w[4][5] = (w[4][5] + 1) % r
-    bad = mj.plonk.compute_quotient_polynomial(pk, ch, [_interpolate(mj, c, log_n, col) for col in w], z_poly, pi_poly)
+    bad_polys = [_interpolate(mj, c, log_n, col) for col in w]
+    bad = mj.plonk.compute_quotient_polynomial(pk, ch, bad_polys, z_poly, pi_poly)
     assert bad[5 * n:].any()
+    bad6 = mj.plonk.compute_quotient_polynomial(pk6, ch, bad_polys, z_poly, pi_poly)
+    assert bad6[5 * n + 8:6 * n].any() and not bad6[6 * n:].any(), "from 6 classes the interpolant has degree < 6n, and not 5n + 7"
     pk.release()
+    pk6.release()
 
 
 def test_quotient_device_resident_and_errors(gpu, mj, cref):

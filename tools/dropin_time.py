@@ -13,7 +13,11 @@ Bytes over PCIe: 7 x 64n + 25 x (32(n + 3) + 256n) + 512n + 13 x 32(n + 3).
 
 Modes:  "pageable"  ordinary host memory (numpy), one call per polynomial (mzk_ntt / mzk_msm) -- the naive shim;
         "pinned"    the shim allocates its evaluation buffers with mzk_host_alloc (page-locked): same calls, DMA without staging;
-        "batch"     pinned buffers + mzk_ntt_batch / mzk_msm_batch, which pipeline upload k+1 | transform k | download k-1.
+        "batch"     pinned buffers + mzk_ntt_batch / mzk_msm_batch, which pipeline upload k+1 | transform k | download k-1;
+        "four_site" two MORE call sites swapped, still host pointers: compute_prod_permutation_polynomial -> mzk_plonk_perm_product
+                    (constraint_system.rs:1197-1223) and compute_quotient_polynomial -> mzk_plonk_quotient (prover.rs:512-673) over a
+                    proving key registered once -- the 25 coset FFTs and their 6.7 GB of evaluation vectors never exist on the host:
+                    6 ifft(n) + product + quotient + 13 commits, 1.5 GB over PCIe, and the two CPU-heavy loops are gone too.
 
     python tools/dropin_time.py [--log-n 20] [--reps 3]
 """
@@ -56,13 +60,17 @@ class HostBuf:
             self.ptr = 0
 
 
-def measure(mj, L, curve, log_n, mode, reps=2, srs=None):
+def four_site_bytes(n):
+    return 6 * 64 * n + (5 * 32 * n + 32 * n) + (7 * 32 * (n + 3) + 256 * n) + 13 * 32 * (n + 3)
+
+
+def measure(mj, L, curve, log_n, mode, reps=2, srs=None, pk=None):
     """Returns {"ms": library wall time of the calls listed above, ...}.  The data are random field elements: the timing does not
     depend on their values."""
     c = curve
     n = 1 << log_n
     m = 8 * n
-    pinned = mode in ("pinned", "batch")
+    pinned = mode in ("pinned", "batch", "four_site")
     own = srs is None
     if own:
         srs = mj.UnivariateProverParam.gen_srs_for_testing(c, 0x1234567, n + 2)
@@ -72,7 +80,20 @@ def measure(mj, L, curve, log_n, mode, reps=2, srs=None):
     small = [HostBuf(L, n + 3, pinned) for _ in range(7)]                 # wires, pi, z coefficient buffers
     # evaluation buffers: the reference holds all 25 coset-evaluation vectors of round 3 at once (prover.rs:552-567), and so does a
     # shim that batches them; the one-call-per-polynomial modes cycle through a few
-    big = [HostBuf(L, m, pinned) for _ in range(25 if mode == "batch" else 4)]
+    big = [HostBuf(L, m, pinned) for _ in range(25 if mode == "batch" else (1 if mode == "four_site" else 4))]
+    own_pk = False
+    if mode == "four_site":
+        if pk is None:
+            own_pk = True
+            fixed = mj.params.random_fr_mont(c, 18 * n, seed=31).reshape(18, n, 4)
+            pk = mj.plonk.ProvingKeyDevice.register(c, n, list(fixed[:13]), list(fixed[13:]), [1, 2, 3, 4, 5], classes=mj.plonk.quotient_classes_needed(5, n))
+            del fixed
+        wires = HostBuf(L, 5 * n, pinned)
+        wires.a[:] = np.tile(rnd[:n], (5, 1))
+        polys = HostBuf(L, 7 * (n + 3), pinned)
+        polys.a[:] = np.tile(rnd, (7, 1))
+        chal = mj.params.fr_to_mont(c, [0x1234567, 0x89abcde, 0xf012345])
+        cp = lambda i: chal[i].ctypes.data_as(C.c_void_p)
     for b in small:
         b.a[:] = rnd
     out = np.zeros(18, dtype=np.uint64)
@@ -98,6 +119,19 @@ def measure(mj, L, curve, log_n, mode, reps=2, srs=None):
         chk(L.mzk_msm_batch(srs.handle, k, ptrs, lens, None, 1, outs.ctypes.data_as(C.c_void_p)), "mzk_msm_batch")
 
     def one_proof():
+        if mode == "four_site":
+            for i in range(6):
+                ntt(small[i], n, log_n, 1, None)
+            for i in range(5):
+                msm(small[i], n + 2)
+            chk(L.mzk_plonk_perm_product(pk.handle, C.c_void_p(wires.ptr), cp(1), cp(2), C.c_void_p(small[6].ptr)), "mzk_plonk_perm_product")
+            msm(small[6], n + 3)
+            chk(L.mzk_plonk_quotient(pk.handle, C.c_void_p(polys.ptr), n + 3, cp(0), cp(1), cp(2), C.c_void_p(big[0].ptr)), "mzk_plonk_quotient")
+            for i in range(5):
+                msm(small[i], n + 3)
+            for i in range(2):
+                msm(small[i], n + 2)
+            return
         if mode == "batch":
             ntt_batch(small[:6], [n] * 6, log_n, 1, None)
             msm_batch(small[:5], [n + 2] * 5)
@@ -135,18 +169,24 @@ def measure(mj, L, curve, log_n, mode, reps=2, srs=None):
     # the shim's own coefficient copies into the evaluation buffers (25 x 32(n+3) bytes of memcpy) are inside the figure: small
     for b in small + big:
         b.free()
+    if mode == "four_site":
+        wires.free()
+        polys.free()
+        if own_pk:
+            pk.release()
     if own:
         srs.release()
-    gb = pcie_bytes(n) / 1e9
+    gb = (four_site_bytes(n) if mode == "four_site" else pcie_bytes(n)) / 1e9
     return {"mode": mode, "log_n": log_n, "ms": round(ms, 1), "pcie_gb": round(gb, 2), "pcie_gb_per_s": round(gb / (ms * 1e-3), 1),
-            "calls": "7 ifft(n) + 25 coset fft(8n) + 1 coset ifft(8n) through host pointers, 13 msm with host scalars"}
+            "calls": ("6 ifft(n) + mzk_plonk_perm_product + mzk_plonk_quotient + 13 msm, host pointers" if mode == "four_site" else
+                      "7 ifft(n) + 25 coset fft(8n) + 1 coset ifft(8n) through host pointers, 13 msm with host scalars")}
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--log-n", type=int, default=20)
     ap.add_argument("--reps", type=int, default=2)
-    ap.add_argument("--modes", default="pageable,pinned,batch")
+    ap.add_argument("--modes", default="pageable,pinned,batch,four_site")
     args = ap.parse_args()
     import mpc_jellyfish_amd as mj
     from importlib import import_module
