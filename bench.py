@@ -322,14 +322,17 @@ def main():
         def round3():
             d_polys[:, :pn + 3] = d_coeffs            # fresh coefficients (the call overwrites them)
             mj.plonk.compute_quotient_polynomial_dev(pk, ch, d_polys, pn + 3, d_out)
+        def median_ms(fn, reps=5):                     # (a release of gigabytes just before can stall one call by tens of ms: median, not mean)
+            ts = []
+            for _ in range(reps):
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                fn()
+                torch.cuda.synchronize()
+                ts.append((time.perf_counter() - t1) * 1e3)
+            return sorted(ts)[len(ts) // 2]
         round3()
-        torch.cuda.synchronize()
-        reps = 5
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            round3()
-        torch.cuda.synchronize()
-        whole_ms = (time.perf_counter() - t1) / reps * 1e3
+        whole_ms = median_ms(round3)
         pk.release()
         # the default path of both hosts: the W + 1 = 6 needed residue classes, class by class, then the inverse Vandermonde
         needed = mj.plonk.quotient_classes_needed(5, pn)
@@ -343,12 +346,7 @@ def main():
             mj.plonk.compute_quotient_chunked_dev(pk, ch, d_rows, pn + 3, out_dev=d_rem)
             mj.plonk.combine_quotient_classes(curve, pn, d_rem, classes=needed, out_dev=d_out)
         round3_classes()
-        torch.cuda.synchronize()
-        t1 = time.perf_counter()
-        for _ in range(reps):
-            round3_classes()
-        torch.cuda.synchronize()
-        r3_wall = (time.perf_counter() - t1) / reps
+        r3_wall = median_ms(round3_classes) * 1e-3
         L.mzk_profile_reset()                          # one more pass with the library's event timers on (they cost time: not in round3_ms)
         L.mzk_profile_enable(1)
         round3_classes()

@@ -117,7 +117,7 @@ def batch_prove(provers: list[TurboPlonkProver], wire_values: list, pub_input_va
         bases.append(base)
         base = base * (a7 if p.ultra else a3) % r
     quot = terms[0][1] if K == 1 else poly.lincomb(c, terms)
-    quot_len = poly.degree_len_async(quot)                              # of the aggregated quotient (prover.rs:915-918)
+    quot_len = poly.degree_len_async(quot[p0.W * (n + 1) + 2:])          # of the aggregated quotient, from the expected degree up (prover.rs:915-918)
     split = p0._split_quotient(quot, quot_blinders)
     split_comms = p0._commit(split)
     p0.check_quotient_degree(quot_len)

@@ -345,7 +345,8 @@ struct Prover {                                                        // Provin
     std::vector<uint64_t> split_quotient(const void* q, const std::vector<Fr>& b_quot) {
         const uint64_t expected = (uint64_t)W * (n + 1) + 2;                                                  // quotient_polynomial_degree
         if (!deg.p) deg.alloc(1);
-        check(mzk_poly_degree_dev(q, m, static_cast<uint64_t*>(deg.p), nullptr), "mzk_poly_degree_dev");      // read in check_quotient_degree
+        // only what lies at and above the expected degree is scanned: its length must be exactly 1 (read in check_quotient_degree)
+        check(mzk_poly_degree_dev(static_cast<const uint8_t*>(q) + expected * EL, m - expected, static_cast<uint64_t*>(deg.p), nullptr), "mzk_poly_degree_dev");
         check(mzk_dev_memset(split.p, 0, (size_t)W * (n + 3) * EL, nullptr), "memset");
         std::vector<uint64_t> split_len(W);
         Fr last = Fr::zero();
@@ -367,11 +368,12 @@ struct Prover {                                                        // Provin
     // quot_poly.degree() != expected_degree => WrongQuotientPolyDegree (prover.rs:915-918): the reference's only guard against an
     // unsatisfied witness.  Call after commit_split (the commitments have synchronised the stream; this reads 8 bytes).
     void check_quotient_degree() {
-        uint64_t len = 0;
-        check(mzk_dev_download(&len, deg.p, 8), "download");
+        uint64_t tail = 0;                                                                                   // length of quot[expected..]
+        check(mzk_dev_download(&tail, deg.p, 8), "download");
         const uint64_t expected = (uint64_t)W * (n + 1) + 2;
-        if (len != expected + 1)
-            throw std::runtime_error("WrongQuotientPolyDegree: quotient polynomial of degree " + std::to_string((long long)len - 1) + ", expected " +
+        if (tail != 1)
+            throw std::runtime_error("WrongQuotientPolyDegree: quotient polynomial of degree " +
+                                     (tail ? std::to_string(expected + tail - 1) : "below " + std::to_string(expected)) + ", expected " +
                                      std::to_string(expected) + " (the witness does not satisfy the circuit)");
     }
     std::vector<Affine> commit_split(const std::vector<uint64_t>& split_len) {

@@ -349,7 +349,8 @@ class TurboPlonkProver:
         # quot_poly.degree() != expected_degree => WrongQuotientPolyDegree (prover.rs:915-918): the reference's only guard against an
         # unsatisfied witness (batch_prove_internal never runs check_circuit_satisfiability).  The length is computed on the
         # device now and read in check_quotient_degree, after the round's commitments have synchronised the stream anyway.
-        st.quot_len = poly.degree_len_async(quot)
+        expected = self.W * (n + 1) + 2
+        st.quot_len = poly.degree_len_async(quot[expected:])             # only what lies at and above the expected degree is scanned
         tick("r3_quotient", t0)
         st.wire_polys = [keep[i, :n + 2] for i in range(self.W)]
         st.z_poly = keep[st.Z]
@@ -359,9 +360,10 @@ class TurboPlonkProver:
 
     def check_quotient_degree(self, quot_len, num_instances: int = 1):
         """prover.rs:915-918 on the length produced by poly.degree_len_async (one 8-byte read; call it after a synchronising step)."""
-        got = int(quot_len.item()) - 1
         expected = self.W * (self.n + 1) + 2
-        if got != expected:
+        tail_len = int(quot_len.item())                                  # of quot[expected:]: 1 <=> degree exactly `expected`
+        got = expected + tail_len - 1 if tail_len else expected - 1      # (below `expected`: reported as expected - 1)
+        if tail_len != 1:
             raise PlonkError("quotient polynomial of degree %d, expected %d (the witness does not satisfy the circuit)" % (got, expected),
                              kind="WrongQuotientPolyDegree")
 
