@@ -102,14 +102,18 @@ IoSlot g_io[IO_SLOTS];
 std::mutex g_io_lock;
 std::condition_variable g_io_cv;
 
-int32_t io_acquire(int* out_idx) {
+// block: wait for a free slot; !block: take one only if one is free right now (a caller that already holds a slot must never wait
+// for another: two batch calls doing so would deadlock), *out_idx = -1 otherwise
+int32_t io_acquire(int* out_idx, bool block = true) {
     std::unique_lock<std::mutex> lk(g_io_lock);
     int idx = -1;
-    g_io_cv.wait(lk, [&] {
+    auto find = [&] {
         for (int i = 0; i < IO_SLOTS; i++)
             if (!g_io[i].busy) { idx = i; return true; }
         return false;
-    });
+    };
+    if (block) g_io_cv.wait(lk, find);
+    else if (!find()) { *out_idx = -1; return MZK_OK; }
     g_io[idx].busy = true;
     lk.unlock();
     if (!g_io[idx].st) {
@@ -425,26 +429,36 @@ int32_t mzk_ntt_batch(int32_t curve_id, uint32_t n_polys, uint64_t* const* data_
     // the lock is taken for the enqueue of the passes only, and a slot is waited for only when it comes round again
     constexpr int PIPE = 3;
     IoGuard slot[PIPE];
-    const int n_slots = (int)(n_polys < (uint32_t)PIPE ? n_polys : (uint32_t)PIPE);
-    for (int k = 0; k < n_slots; k++) {
-        MZK_TRY(io_acquire(&slot[k].idx));
-        MZK_TRY(g_io[slot[k].idx].buf.reserve(N * 32));
+    const int want = (int)(n_polys < (uint32_t)PIPE ? n_polys : (uint32_t)PIPE);
+    int n_slots = 0;
+    for (int k = 0; k < want; k++) {
+        MZK_TRY(io_acquire(&slot[n_slots].idx, /*block=*/k == 0));          // wait for the first slot only; take more if they are free
+        if (slot[n_slots].idx < 0) break;
+        MZK_TRY(g_io[slot[n_slots].idx].buf.reserve(N * 32));
+        n_slots++;
     }
+    if (n_polys == 0) return MZK_OK;
+    // (a failed HIP call must not hand a slot on while its stream still owns the buffer: every exit path drains the slots first)
+    auto hip_ok = [](hipError_t e, const char* what) -> int32_t {
+        if (e == hipSuccess) return MZK_OK;
+        set_error(std::string(what) + ": " + hipGetErrorString(e));
+        return e == hipErrorOutOfMemory ? MZK_ERR_OOM : MZK_ERR_HIP;
+    };
     int32_t rc = MZK_OK;
     for (uint32_t i = 0; i < n_polys && rc == MZK_OK; i++) {
         IoSlot& io = g_io[slot[i % n_slots].idx];
-        if (i >= (uint32_t)n_slots) HIP_TRY(hipStreamSynchronize(io.st));               // its previous polynomial has left the device
+        if (i >= (uint32_t)n_slots) rc = hip_ok(hipStreamSynchronize(io.st), "hipStreamSynchronize");   // its previous polynomial has left the device
         const uint64_t len = in_lens[i] < N ? in_lens[i] : N;
-        if (len) HIP_TRY(hipMemcpyAsync(io.buf.p, data_mont[i], len * 32, hipMemcpyHostToDevice, io.st));
-        {
+        if (rc == MZK_OK && len) rc = hip_ok(hipMemcpyAsync(io.buf.p, data_mont[i], len * 32, hipMemcpyHostToDevice, io.st), "hipMemcpyAsync");
+        if (rc == MZK_OK) {
             std::lock_guard<std::mutex> lk(g_lock);
             rc = ntt_dispatch(curve_id, io.buf.as<uint32_t>(), len, (int)log_n, inverse != 0, reinterpret_cast<const uint32_t*>(coset_offset_mont), 1, N, io.st);
         }
-        if (rc == MZK_OK) HIP_TRY(hipMemcpyAsync(data_mont[i], io.buf.p, N * 32, hipMemcpyDeviceToHost, io.st));
+        if (rc == MZK_OK) rc = hip_ok(hipMemcpyAsync(data_mont[i], io.buf.p, N * 32, hipMemcpyDeviceToHost, io.st), "hipMemcpyAsync");
     }
     for (int k = 0; k < n_slots; k++) {
-        const hipError_t e = hipStreamSynchronize(g_io[slot[k].idx].st);
-        if (e != hipSuccess && rc == MZK_OK) { set_error(std::string("hipStreamSynchronize: ") + hipGetErrorString(e)); rc = MZK_ERR_HIP; }
+        const int32_t r2 = hip_ok(hipStreamSynchronize(g_io[slot[k].idx].st), "hipStreamSynchronize");
+        if (rc == MZK_OK) rc = r2;
     }
     return rc;
 }

@@ -355,3 +355,32 @@ def test_msm_random_ragged_sweep(gpu, mj, cref, curve_id):
         got = cref.jac_to_affine(curve_id, mj.msm_bigint(pp, scalars, base_offset=off))[0]
         assert np.array_equal(got, want), (case, n, off, shape)
     pp.release()
+
+
+@pytest.mark.parametrize("curve_id", [0, 1])
+def test_srs_precompute_report_and_same_points(gpu, mj, cref, curve_id):
+    """mzk_srs_precompute builds the fixed-base table at once and reports its size; MSMs with the table and with it switched off
+    (mzk_msm_set_precompute) return the same group element."""
+    import ctypes as C
+    L = mj.load()
+    c = mj.params.CURVES[curve_id]
+    n = 3000
+    bases = cref.g1_arith_bases(curve_id, 0x1d + curve_id, 0x99, n)
+    pp = mj.UnivariateProverParam.from_affine(curve_id, bases)
+    bits, levels, nbytes, ms = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_double()
+    assert L.mzk_srs_precompute(pp.handle, C.byref(bits), C.byref(levels), C.byref(nbytes), C.byref(ms)) == 0
+    assert bits.value in (15, 16, 17, 20) and levels.value == (256 + bits.value) // bits.value      # signed digits of a 256-bit integer
+    assert nbytes.value == levels.value * n * (112 if curve_id == 0 else 80) and ms.value > 0
+    first = ms.value
+    assert L.mzk_srs_precompute(pp.handle, None, None, None, C.byref(ms)) == 0 and ms.value == first, "built once"
+    assert L.mzk_srs_precompute(0xdead, None, None, None, None) == -4
+    sc = mj.params.random_fr_mont(c, n, seed=8)
+    with_table = cref.jac_to_affine(curve_id, mj.msm_bigint(pp, sc, scalars_are_mont=True))[0]
+    L.mzk_msm_set_precompute(0)
+    try:
+        without = cref.jac_to_affine(curve_id, mj.msm_bigint(pp, sc, scalars_are_mont=True))[0]
+    finally:
+        L.mzk_msm_set_precompute(1)
+    want = cref.jac_to_affine(curve_id, cref.msm(curve_id, bases, sc, scalars_are_mont=True, threads=4))[0]
+    assert np.array_equal(with_table, want) and np.array_equal(without, want)
+    pp.release()

@@ -76,3 +76,22 @@ def test_lincomb_matches_oracle(gpu, mj, cref, curve_id):
     assert np.array_equal(acc.cpu().numpy().view(np.uint64), want)
     with pytest.raises(mj.MzkError):
         mj.poly.lincomb(c, [(1, d[0])] * 33)
+
+
+def test_degree_len(gpu, mj):
+    """mzk_poly_degree_dev: number of coefficients up to the highest non-zero one (`DensePolynomial::degree` + 1 after trailing zeros
+    are stripped), the guard behind WrongQuotientPolyDegree (prover.rs:915-918)."""
+    import torch
+    c = mj.params.BLS12_381
+    for n, top in ((1, 0), (5, 4), (4097, 0), (4097, 4096), (100000, 77777), (1 << 20, (1 << 20) - 3)):
+        a = np.zeros((n, 4), dtype=np.uint64)
+        a[:top + 1] = mj.params.random_fr_mont(c, top + 1, seed=n)
+        a[top] = mj.params.fr_to_mont(c, [3])[0]                       # make sure the top coefficient is non-zero
+        t = torch.from_numpy(a.view(np.int64)).cuda()
+        assert int(mj.poly.degree_len_async(t).item()) == top + 1
+        assert int(mj.poly.degree_len_async(t[top + 1:]).item()) == 0 if top + 1 < n else True
+    z = torch.zeros((1000, 4), dtype=torch.int64, device="cuda")
+    assert int(mj.poly.degree_len_async(z).item()) == 0
+    z[999, 3] = 1                                                       # any non-zero limb counts
+    assert int(mj.poly.degree_len_async(z).item()) == 1000
+    assert int(mj.poly.degree_len_async(z[:0]).item()) == 0
