@@ -25,20 +25,22 @@ def _stream(t, stream):
     return torch.cuda.current_stream(t.device).cuda_stream if stream is None else stream
 
 
-def evaluate(curve, polys_dev, x: int, length: int | None = None) -> list[int]:
+def evaluate(curve, polys_dev, x: int, length: int | None = None, offset: int = 0) -> list[int]:
     """polys_dev: (len, 4) or (batch, stride, 4) CUDA tensor; every polynomial is evaluated at x over its
-    first `length` coefficients.  Returns canonical Python ints (the call synchronises)."""
+    first `length` coefficients.  offset: evaluate sum_{j < length} c[offset + j] x^j instead -- the coefficient range
+    [offset, offset + length) read as a polynomial of its own (a rank's share of an evaluation: times x^offset it is that
+    range's contribution, sharding.py).  Returns canonical Python ints (the call synchronises)."""
     c = _curve(curve)
     t = polys_dev
     if t.dim() == 2:
         batch, stride = 1, t.shape[0]
     else:
         batch, stride = t.shape[0], t.shape[1]
-    n = stride if length is None else length
-    assert t.is_cuda and t.is_contiguous() and t.shape[-1] == 4 and n <= stride
+    n = stride - offset if length is None else length
+    assert t.is_cuda and t.is_contiguous() and t.shape[-1] == 4 and 0 <= offset and n >= 0 and offset + n <= stride
     xm = fr_to_mont(c, [x])[0]
     out = np.empty((batch, 4), dtype=np.uint64)
-    _lib.check(_lib.ensure_init().mzk_poly_eval_dev(c.curve_id, t.data_ptr(), n, batch, stride, xm.ctypes.data_as(C.c_void_p),
+    _lib.check(_lib.ensure_init().mzk_poly_eval_dev(c.curve_id, t.data_ptr() + 32 * offset, n, batch, stride, xm.ctypes.data_as(C.c_void_p),
                                                     out.ctypes.data_as(C.c_void_p), _stream(t, None)), "mzk_poly_eval_dev")
     return fr_from_mont(c, out)
 

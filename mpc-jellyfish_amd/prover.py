@@ -151,6 +151,50 @@ class ProofCore:
     plookup_evals: dict | None = None
 
 
+class _Evals:
+    """Evaluations of device polynomials, collected and finished together.  Single process: evaluated at once."""
+
+    def __init__(self, prover):
+        self.p, self.vals = prover, []
+
+    def add(self, polys, x: int, length: int | None = None):
+        v = poly.evaluate(self.p.curve, polys, x, length=length)
+        self.vals += v
+        return (len(self.vals) - len(v), len(v))
+
+    def finish(self):
+        pass
+
+    def get(self, h):
+        return self.vals[h[0]:h[0] + h[1]]
+
+
+class _RangeEvals(_Evals):
+    """The same over several ranks: every rank evaluates its coefficient range [lo, hi) of each polynomial --
+    sum_{j in range} c_j x^j = x^lo * (the range read as a polynomial of its own) -- and ONE all-gather of the partial values
+    (32 bytes each) at the end of the round gives every rank all the sums."""
+
+    def __init__(self, prover):
+        super().__init__(prover)
+        self.lo, self.hi = prover.committer.point_range()
+
+    def add(self, polys, x: int, length: int | None = None):
+        r = self.p.curve.r
+        stride = polys.shape[0] if polys.dim() == 2 else polys.shape[1]
+        batch = 1 if polys.dim() == 2 else polys.shape[0]
+        L = stride if length is None else length
+        a, b = min(self.lo, L), min(self.hi, L)
+        v = poly.evaluate(self.p.curve, polys, x, length=b - a, offset=a) if b > a else [0] * batch
+        xlo = pow(x, a, r)
+        self.vals += [t * xlo % r for t in v]
+        return (len(self.vals) - len(v), len(v))
+
+    def finish(self):
+        r = self.p.curve.r
+        every = self.p.committer.all_gather_fr(self.vals)
+        self.vals = [sum(col) % r for col in zip(*every)]
+
+
 class TurboPlonkProver:
     """Holds a proving key on the device: coefficient forms (for rounds 4-5), the resident coset
     evaluations (round 3) and the commit key.  With `plookup` (the four table polynomials of
@@ -172,6 +216,7 @@ class TurboPlonkProver:
         self.ck = commit_key
         self.ultra = plookup is not None
         self.committer = None                        # set to a sharding.ShardedCommitter for multi-GPU commits
+        self.range_mode = True                       # several ranks: rounds 4 and 5 work on this rank's coefficient range only
         self.W = len(sigma_polys)
         self.nsel = len(selector_polys)
         self.quotient_gather = quotient_gather
@@ -232,6 +277,9 @@ class TurboPlonkProver:
     def _mask(self, t, rows, blinders):
         """poly + (b_0 + b_1 X + ..)(X^n - 1) on the device rows (prover.rs:463-486), one launch for all of them."""
         poly.mask(self.curve, [t[r] for r in rows], self.n, [list(b) for b in blinders])
+
+    def _ranged(self) -> bool:
+        return self.range_mode and self.committer is not None and hasattr(self.committer, "point_range") and self.committer.world() > 1
 
     def _commit(self, polys):
         """batch_commit (mod.rs:119-131); with `self.committer` (sharding.ShardedCommitter) the MSMs are split by point
@@ -393,34 +441,34 @@ class TurboPlonkProver:
         return split
 
     def _stage_round4(self, st, zeta, tick):
-        """compute_evaluations / compute_plookup_evaluations (prover.rs:216-299)"""
+        """compute_evaluations / compute_plookup_evaluations (prover.rs:216-299).  Over several ranks every evaluation is the sum of
+        the ranks' coefficient-range contributions (one exchange of 32-byte partial values per call of this stage)."""
         import time
         c, n, r, W = self.curve, self.n, self.curve.r, self.W
         keep = self._keep
         st.zeta = zeta
         t0 = time.perf_counter()
         zeta_w = zeta * self.w_n % r
-        st.wires_evals = poly.evaluate(c, keep[:W], zeta, length=n + 2)
-        st.wire_sigma_evals = poly.evaluate(c, self.fixed[self.sigma0:self.sigma0 + W - 1], zeta)
-        st.perm_next_eval = poly.evaluate(c, st.z_poly, zeta_w)[0]
-        st.pe = None
+        ev = _RangeEvals(self) if self._ranged() else _Evals(self)
+        h_w = ev.add(keep[:W], zeta, length=n + 2)
+        h_s = ev.add(self.fixed[self.sigma0:self.sigma0 + W - 1], zeta)
+        h_z = ev.add(st.z_poly, zeta_w)
         if self.ultra:
-            tick("r4_evals", t0)
-            t0 = time.perf_counter()
             tabs = self.fixed[self.tab0:self.tab0 + 4]                    # range, key, table_dom_sep, q_dom_sep
             q_lookup = self.fixed[13]
-            at_zeta = poly.evaluate(c, tabs, zeta)
-            at_next = poly.evaluate(c, tabs[:3], zeta_w)
-            pe = {"range_table_eval": at_zeta[0], "key_table_eval": at_zeta[1], "table_dom_sep_eval": at_zeta[2], "q_dom_sep_eval": at_zeta[3],
-                  "range_table_next_eval": at_next[0], "key_table_next_eval": at_next[1], "table_dom_sep_next_eval": at_next[2],
-                  "h_1_eval": poly.evaluate(c, st.h1, zeta)[0], "q_lookup_eval": poly.evaluate(c, q_lookup, zeta)[0],
-                  "q_lookup_next_eval": poly.evaluate(c, q_lookup, zeta_w)[0]}
-            nx = poly.evaluate(c, keep[[st.PL, st.H1, st.H1 + 1, 3, 4]], zeta_w)
-            pe.update({"prod_next_eval": nx[0], "h_1_next_eval": nx[1], "h_2_next_eval": nx[2], "w_3_next_eval": nx[3], "w_4_next_eval": nx[4]})
-            st.pe = pe
-            tick("r4_5_plookup_evals", t0)
-        else:
-            tick("r4_evals", t0)
+            h_tz, h_tn = ev.add(tabs, zeta), ev.add(tabs[:3], zeta_w)
+            h_h1, h_ql, h_qln = ev.add(st.h1, zeta), ev.add(q_lookup, zeta), ev.add(q_lookup, zeta_w)
+            h_nx = ev.add(keep[[st.PL, st.H1, st.H1 + 1, 3, 4]], zeta_w)
+        ev.finish()
+        st.wires_evals, st.wire_sigma_evals, st.perm_next_eval = ev.get(h_w), ev.get(h_s), ev.get(h_z)[0]
+        st.pe = None
+        if self.ultra:
+            at_zeta, at_next, nx = ev.get(h_tz), ev.get(h_tn), ev.get(h_nx)
+            st.pe = {"range_table_eval": at_zeta[0], "key_table_eval": at_zeta[1], "table_dom_sep_eval": at_zeta[2], "q_dom_sep_eval": at_zeta[3],
+                     "range_table_next_eval": at_next[0], "key_table_next_eval": at_next[1], "table_dom_sep_next_eval": at_next[2],
+                     "h_1_eval": ev.get(h_h1)[0], "q_lookup_eval": ev.get(h_ql)[0], "q_lookup_next_eval": ev.get(h_qln)[0],
+                     "prod_next_eval": nx[0], "h_1_next_eval": nx[1], "h_2_next_eval": nx[2], "w_3_next_eval": nx[3], "w_4_next_eval": nx[4]}
+        tick("r4_evals", t0)
         return st.wires_evals, st.wire_sigma_evals, st.perm_next_eval, st.pe
 
     def _lin_poly_terms(self, st, alpha_base: int = 1):
@@ -505,6 +553,76 @@ class TurboPlonkProver:
             acc = poly.lincomb(c, [(1, acc)] + bterms[i:i + poly.MAX_TERMS - 1], out_len=n + 3)
         return poly.div_by_linear(c, acc, point)
 
+    def _lincomb_many(self, terms, out_len):
+        """sum of (scalar, polynomial) terms, more than one launch's worth if need be"""
+        c = self.curve
+        if len(terms) <= poly.MAX_TERMS:
+            return poly.lincomb(c, terms, out_len=out_len)
+        acc = poly.lincomb(c, terms[:poly.MAX_TERMS], out_len=out_len)
+        for i in range(poly.MAX_TERMS, len(terms), poly.MAX_TERMS - 1):
+            acc = poly.lincomb(c, [(1, acc)] + terms[i:i + poly.MAX_TERMS - 1], out_len=out_len)
+        return acc
+
+    def _openings_ranged(self, lin_terms, open_polys, shifted_polys, v_ch, zeta, tick, t0):
+        """Round 5 over several ranks.  The opening witness of a batch polynomial b at a point z is
+        w_j = sum_{i > j} b_i z^(i-j-1).  A rank needs w on its own coefficient range [lo, hi) only -- that is its MSM shard -- and
+        w_j = (the same sum over i < hi) + z^(hi-1-j) S_hi with S_hi = sum_{i >= hi} b_i z^(i-hi): the higher ranks' contribution enters
+        as ONE field element.  So: linear combinations on the range only (they are pointwise); e = the range read as a polynomial,
+        evaluated at z; one all-gather of the e's; S_hi appended as an extra top coefficient, after which the ordinary division by
+        (X - z) of the extended range returns exactly w on the range; commit over the range.  Returns (lin range, opening range,
+        shifted range, commitments)."""
+        import time
+        import torch
+        c, r, n = self.curve, self.curve.r, self.n
+        com = self.committer
+        lo, hi = com.point_range()
+        hi = min(hi, n + 3)
+        width = max(hi - lo, 0)
+        dev = self.fixed.device
+
+        def cut(terms):
+            out = []
+            for s_, p_ in terms:
+                a, b = min(lo, int(p_.shape[0])), min(hi, int(p_.shape[0]))
+                if b > a:
+                    out.append((s_, p_[a:b]))
+            return out
+
+        zw = zeta * self.w_n % r
+        vs = [pow(v_ch, i, r) for i in range(max(len(open_polys) + 1, len(shifted_polys)))]
+        open_terms = cut(lin_terms + [(vs[i + 1], p_) for i, p_ in enumerate(open_polys)])       # 1 * lin + sum_i v^(i+1) p_i
+        shift_terms = cut([(vs[i], p_) for i, p_ in enumerate(shifted_polys)])
+        zero = torch.zeros((max(width, 1), 4), dtype=torch.int64, device=dev)
+        lin = self._lincomb_many(cut(lin_terms), width) if width and cut(lin_terms) else zero[:width]
+        b_open = self._lincomb_many(open_terms, width) if width and open_terms else zero[:width]
+        b_shift = self._lincomb_many(shift_terms, width) if width and shift_terms else zero[:width]
+        e_open = poly.evaluate(c, b_open, zeta)[0] if width else 0
+        e_shift = poly.evaluate(c, b_shift, zw)[0] if width else 0
+        every = com.all_gather_fr([e_open, e_shift])
+        import torch.distributed as dist
+        from .sharding import shard_range
+        rank, world = dist.get_rank(com.group), dist.get_world_size(com.group)
+        carry = [0, 0]
+        for q in range(rank + 1, world):                                 # S_hi: the ranges above, shifted down to start at hi
+            lo_q = min(shard_range(com.ck.length, q, world)[0], n + 3)
+            carry[0] = (carry[0] + pow(zeta, lo_q - hi, r) * every[q][0]) % r
+            carry[1] = (carry[1] + pow(zw, lo_q - hi, r) * every[q][1]) % r
+        wit = []
+        for b_, cy, z_ in ((b_open, carry[0], zeta), (b_shift, carry[1], zw)):
+            if not width:
+                wit.append(zero[:0])
+                continue
+            ext = torch.empty((width + 1, 4), dtype=torch.int64, device=dev)
+            ext[:width] = b_
+            ext[width:] = torch.from_numpy(fr_to_mont(c, [cy]).view(np.int64)).to(dev)
+            wit.append(poly.div_by_linear(c, ext, z_))                   # width coefficients: w on [lo, hi)
+        tick("r5_polys", t0)
+        t0 = time.perf_counter()
+        jac = com.commit_jacobian_slices(wit)
+        open_comms = [kzg.Commitment(c, xy) for xy in kzg.jacobian_to_affine(c, jac)]
+        tick("r5_commit", t0)
+        return lin, wit[0], wit[1], open_comms
+
     def prove(self, wire_values, pub_input_values, ch, blind: Blinders, profile: bool = False) -> ProofCore:
         """ch: ProverChallenges (fixed) or a challenge source (FixedChallenges / TranscriptChallenges)."""
         src = FixedChallenges(ch) if isinstance(ch, ProverChallenges) else ch
@@ -542,14 +660,18 @@ class TurboPlonkProver:
         # ---- round 5: linearisation polynomial (prover.rs:963-1112, 343-358) and openings (362-460, 490-509)
         t0 = time.perf_counter()
         v_ch = src.after_round4(wires_evals, wire_sigma_evals, perm_next_eval, pe)
-        lin = poly.lincomb(c, self._lin_poly_terms(st) + self._quotient_lin_terms(zeta, split), out_len=n + 3)
         open_polys, shifted_polys = self._open_lists(st)
-        opening = self._batched_witness([lin] + open_polys, v_ch, zeta)
-        shifted = self._batched_witness(shifted_polys, v_ch, zeta * self.w_n % r)
-        tick("r5_polys", t0)
-        t0 = time.perf_counter()
-        open_comms = self._commit([opening, shifted])
-        tick("r5_commit", t0)
+        if self._ranged():                                               # this rank's coefficient range of both witness polynomials only
+            lin, opening, shifted, open_comms = self._openings_ranged(self._lin_poly_terms(st) + self._quotient_lin_terms(zeta, split),
+                                                                      open_polys, shifted_polys, v_ch, zeta, tick, t0)
+        else:
+            lin = poly.lincomb(c, self._lin_poly_terms(st) + self._quotient_lin_terms(zeta, split), out_len=n + 3)
+            opening = self._batched_witness([lin] + open_polys, v_ch, zeta)
+            shifted = self._batched_witness(shifted_polys, v_ch, zeta * self.w_n % r)
+            tick("r5_polys", t0)
+            t0 = time.perf_counter()
+            open_comms = self._commit([opening, shifted])
+            tick("r5_commit", t0)
         self.last_challenges = {"tau": tau, "beta": beta, "gamma": gamma, "alpha": alpha, "zeta": zeta, "v": v_ch}
         self.last = {"wire_polys": st.wire_polys, "z_poly": st.z_poly, "quot": quot, "split": split, "lin": lin, "opening": opening, "shifted": shifted}
         if ultra:
