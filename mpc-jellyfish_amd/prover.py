@@ -599,9 +599,8 @@ class TurboPlonkProver:
         e_open = poly.evaluate(c, b_open, zeta)[0] if width else 0
         e_shift = poly.evaluate(c, b_shift, zw)[0] if width else 0
         every = com.all_gather_fr([e_open, e_shift])
-        import torch.distributed as dist
         from .sharding import shard_range
-        rank, world = dist.get_rank(com.group), dist.get_world_size(com.group)
+        rank, world = com.rank(), com.world()
         carry = [0, 0]
         for q in range(rank + 1, world):                                 # S_hi: the ranges above, shifted down to start at hi
             lo_q = min(shard_range(com.ck.length, q, world)[0], n + 3)

@@ -123,6 +123,10 @@ class ShardedCommitter:
         import torch.distributed as dist
         return dist.get_world_size(self.group)
 
+    def rank(self) -> int:
+        import torch.distributed as dist
+        return dist.get_rank(self.group)
+
     def point_range(self):
         """[lo, hi) of the SRS indices this rank commits over (the fixed partition commit_jacobian uses)."""
         import torch.distributed as dist

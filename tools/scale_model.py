@@ -10,9 +10,12 @@ and per G it measures, on this one GPU, exactly what rank 0 of a G-rank run exec
                (sharding.ShardedCommitter), on the SRS's fixed-base table;
   quotient     the rank's ceil(needed / G) residue classes (needed = W + 1 of the 8) through mzk_plonk_quotient_chunked_dev, and
                the inverse-Vandermonde combine every rank runs after the exchange;
+  ranged       rounds 4 and 5 (evaluations; linearisation + batch polynomials, their division by (X - z)) on the rank's
+               coefficient range only (prover.py _RangeEvals / _openings_ranged): timed in a real proof whose committer reports
+               world = G and rank 0's range (RankZero below; the exchanged values are then not the true ones, which no later
+               prover stage checks);
   replicated   everything else of a proof, which every rank repeats: wire / z iNTTs and masking, grand products, the Plookup
-               sorted vector, quotient split, evaluations, linearisation and opening polynomials, transcript -- taken from the
-               profiled rounds of a real single-GPU proof;
+               sorted vector, quotient split, transcript -- taken from the profiled rounds of a real single-GPU proof;
 and it ADDS, from stated constants (not measurable on one GPU):
   collectives  one small all-gather per commit group (k x 144 / 96 bytes per rank) at SMALL_COLLECTIVE_US each, and the one
                exchange of class remainders: (G - 1) x classes_per_rank x n x 32 bytes received per rank at XGMI_GBPS.
@@ -48,6 +51,32 @@ def median_ms(fn, reps=5, warm=2):
     return sorted(ts)[len(ts) // 2]
 
 
+class RankZero:
+    """Stands in for sharding.ShardedCommitter on ONE GPU: commits are whole (so the proof's quotient is the true one and passes the
+    degree check), but it reports `world` ranks and rank 0's point range, so rounds 4 and 5 do what rank 0 of a G-rank run does."""
+
+    def __init__(self, mj, ck, world):
+        self.mj, self.ck, self.G, self.group = mj, ck, world, None
+
+    def world(self):
+        return self.G
+
+    def rank(self):
+        return 0
+
+    def point_range(self):
+        return 0, self.ck.length // self.G
+
+    def commit_jacobian(self, polys):
+        return self.mj.msm_bigint_batch(self.ck, [p.contiguous() for p in polys], scalars_are_mont=True)
+
+    def all_gather_fr(self, values):
+        return [list(values)] * self.G
+
+    def commit_jacobian_slices(self, slices):
+        return self.mj.msm_bigint_batch(self.ck, [s.contiguous() for s in slices], scalars_are_mont=True)
+
+
 def model(mj, curve, plonk_type, log_n):
     import torch
     c = curve
@@ -70,10 +99,20 @@ def model(mj, curve, plonk_type, log_n):
     core, _ = mj.snark.prove(rng, cs, pk, profile=True)
     rounds = dict(core.timings_ms)
     needed = list(pk.classes_needed)
+    ranged_keys = ["r4_evals", "r5_polys"]
+    ranged_ms = {1: sum(rounds[k] for k in ranged_keys)}
+    for G in (2, 4, 8):
+        pk.committer = RankZero(mj, ck, G)
+        samples = []
+        for _ in range(5):
+            core, _ = mj.snark.prove(rng, cs, pk, profile=True)
+            samples.append(sum(dict(core.timings_ms)[k] for k in ranged_keys))
+        ranged_ms[G] = sorted(samples)[2]
+    pk.committer = None
     pk.release()
     del pk
     torch.cuda.empty_cache()
-    replicated_keys = [k for k in rounds if not k.endswith("_commit") and k != "r3_quotient"]
+    replicated_keys = [k for k in rounds if not k.endswith("_commit") and k != "r3_quotient" and k not in ("r4_evals", "r5_polys")]
     replicated_ms = sum(rounds[k] for k in replicated_keys)
     # ---- commit groups: (number of polynomials, length) in proof order ----
     groups = [("r1_wires", W, n + 2)]
@@ -116,13 +155,13 @@ def model(mj, curve, plonk_type, log_n):
         per = -(-len(needed) // G)
         gather_bytes = (G - 1) * per * n * 32
         exchange_ms = 0.0 if G == 1 else SMALL_COLLECTIVE_US / 1e3 + gather_bytes / (XGMI_GBPS * 1e9) * 1e3
-        small_ms = 0.0 if G == 1 else len(groups) * SMALL_COLLECTIVE_US / 1e3
-        total = sum(commits.values()) + class_ms[per] + combine_ms + exchange_ms + small_ms + replicated_ms
+        small_ms = 0.0 if G == 1 else (len(groups) + 2) * SMALL_COLLECTIVE_US / 1e3      # + the round-4 and round-5 exchanges of partial values
+        total = sum(commits.values()) + class_ms[per] + combine_ms + exchange_ms + small_ms + replicated_ms + ranged_ms[G]
         out["per_G"][str(G)] = {"commits_ms": commits, "commit_total_ms": round(sum(commits.values()), 2),
                                 "quotient_classes_per_rank": per, "quotient_local_ms": round(class_ms[per], 3), "combine_ms": round(combine_ms, 3),
                                 "class_exchange_ms": round(exchange_ms, 3), "class_exchange_bytes_received": gather_bytes,
                                 "small_collectives_ms": round(small_ms, 3), "replicated_ms": round(replicated_ms, 2),
-                                "predicted_prove_ms": round(total, 2)}
+                                "ranged_rounds_4_5_ms": round(ranged_ms[G], 3), "predicted_prove_ms": round(total, 2)}
     base = out["per_G"]["1"]["predicted_prove_ms"]
     for G in ("1", "2", "4", "8"):
         out["per_G"][G]["speedup_vs_1"] = round(base / out["per_G"][G]["predicted_prove_ms"], 2)
