@@ -350,9 +350,9 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(const u
     EC::store_pt(buckets, t, acc);
 }
 
-// Small and medium MSMs are latency bound: few buckets, each a chain of dependent mixed adds (~5 us apiece when a wave runs
+// Small and medium MSMs are latency bound: few buckets, each a chain of dependent mixed adds (~12 us apiece when a wave runs
 // alone).  There every bucket is split over S = 2^log_split threads -- thread s takes entries s, s + S, ... of the run -- and
-// msm_split_combine_kernel adds the S partial sums: chains S times shorter for (S - 1) M extra additions.
+// msm_split_combine_kernel adds the S partial sums as a tree: chains S times shorter for (S - 1) M extra additions, log_split deep.
 template <class EC>
 __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_split_kernel(const uint32_t* __restrict__ bases, unsigned long long n,
                                                                                 const uint32_t* __restrict__ offs, const uint32_t* __restrict__ hist,
@@ -374,14 +374,60 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_split_kernel(c
     }
     EC::store_pt(sub, (t << log_split) + part, acc);
 }
+// A workgroup takes 2 * MSM_ACC_THREADS consecutive partial sums (2 * MSM_ACC_THREADS / S whole buckets).  Level 0: every thread adds
+// one adjacent pair; level l: the first MSM_ACC_THREADS >> l threads add the pairs of the level before, which they find in LDS
+// (word-major, so lanes touch consecutive banks) -- the active lanes stay dense and idle waves skip the addition altogether.
+template <class EC>
+__device__ __forceinline__ void pt_lds_put(uint32_t* lds, int slot, const typename EC::Pt& p) {
+    constexpr int N = EC::Field::XN;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        lds[i * MSM_ACC_THREADS + slot] = p.x.l[i];
+        lds[(N + i) * MSM_ACC_THREADS + slot] = p.y.l[i];
+        lds[(2 * N + i) * MSM_ACC_THREADS + slot] = p.zz.l[i];
+        lds[(3 * N + i) * MSM_ACC_THREADS + slot] = p.zzz.l[i];
+    }
+}
+template <class EC>
+__device__ __forceinline__ typename EC::Pt pt_lds_get(const uint32_t* lds, int slot) {
+    constexpr int N = EC::Field::XN;
+    typename EC::Pt p;
+#pragma unroll
+    for (int i = 0; i < N; i++) {
+        p.x.l[i] = lds[i * MSM_ACC_THREADS + slot];
+        p.y.l[i] = lds[(N + i) * MSM_ACC_THREADS + slot];
+        p.zz.l[i] = lds[(2 * N + i) * MSM_ACC_THREADS + slot];
+        p.zzz.l[i] = lds[(3 * N + i) * MSM_ACC_THREADS + slot];
+    }
+    return p;
+}
 template <class EC>
 __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_split_combine_kernel(const uint32_t* __restrict__ sub, unsigned long long n_buckets, int log_split,
                                                                              uint32_t* __restrict__ buckets) {
-    const unsigned long long t = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
-    if (t >= n_buckets) return;
-    typename EC::Pt acc = EC::load_pt(sub, t << log_split);
-    for (uint32_t s = 1; s < (1u << log_split); s++) acc = EC::add(acc, EC::load_pt(sub, (t << log_split) + s));
-    EC::store_pt(buckets, t, acc);
+    __shared__ uint32_t lds[MSM_ACC_THREADS * EC::PT_WORDS];
+    const int tid = threadIdx.x;
+    const unsigned long long total = n_buckets << log_split;                 // partial sums in all (even)
+    const unsigned long long base = (unsigned long long)blockIdx.x * (2 * MSM_ACC_THREADS);
+    typename EC::Pt acc = EC::inf();
+    // ONE call site of EC::add for all levels: a second copy of its ~50 KB of straight-line code would evict the first from the
+    // 64 KB instruction cache, and a lone wave then waits for every line of it
+#pragma unroll 1
+    for (int lvl = 0; lvl < log_split; lvl++) {
+        const bool mine = tid < (MSM_ACC_THREADS >> lvl) && base + ((unsigned long long)(2 * tid) << lvl) < total;
+        typename EC::Pt a = EC::inf(), b = EC::inf();
+        if (lvl == 0) {
+            if (mine) { a = EC::load_pt(sub, base + 2ull * tid); b = EC::load_pt(sub, base + 2ull * tid + 1); }
+        } else {
+            __syncthreads();
+            if (mine) { a = pt_lds_get<EC>(lds, 2 * tid); b = pt_lds_get<EC>(lds, 2 * tid + 1); }
+            __syncthreads();
+        }
+        if (mine) {
+            acc = EC::add(a, b);
+            if (lvl == log_split - 1) EC::store_pt(buckets, (base >> log_split) + tid, acc);
+            else pt_lds_put<EC>(lds, tid, acc);
+        }
+    }
 }
 
 // ---- over-long buckets (skewed scalars) ------------------------------------------------------------

@@ -207,8 +207,8 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                     uint32_t* sub = g_ws.split.as<uint32_t>();
                     hipLaunchKernelGGL((msm_accumulate_split_kernel<EC>), dim3((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS),
                                        0, st, d_bases, n_sorted, offs, hist, sorted, order, M, n_win, cap, log_split, sub);
-                    hipLaunchKernelGGL((msm_split_combine_kernel<EC>), dim3((unsigned)((wm + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
-                                       sub, (unsigned long long)wm, log_split, buckets);
+                    hipLaunchKernelGGL((msm_split_combine_kernel<EC>), dim3((unsigned)((threads + 2 * MSM_ACC_THREADS - 1) / (2 * MSM_ACC_THREADS))), dim3(MSM_ACC_THREADS),
+                                       0, st, sub, (unsigned long long)wm, log_split, buckets);
                 }
             }
             {

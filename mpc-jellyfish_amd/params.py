@@ -33,6 +33,23 @@ class CurveParams:
     def fq_R(self) -> int:
         return 1 << (64 * self.fq_limbs)
 
+    @property
+    def fr_Rinv(self) -> int:
+        return _inverse_of_R(self.r, 256)
+
+    @property
+    def fq_Rinv(self) -> int:
+        return _inverse_of_R(self.q, 64 * self.fq_limbs)
+
+
+_RINV: dict = {}
+
+
+def _inverse_of_R(p: int, bits: int) -> int:
+    if (p, bits) not in _RINV:
+        _RINV[(p, bits)] = pow(1 << bits, -1, p)
+    return _RINV[(p, bits)]
+
 
 BLS12_381 = CurveParams(
     "bls12-381", 0,
@@ -55,38 +72,49 @@ def curve(c) -> CurveParams:
 
 
 def int_to_limbs(x: int, n_limbs: int) -> np.ndarray:
-    return np.array([(x >> (64 * i)) & 0xFFFFFFFFFFFFFFFF for i in range(n_limbs)], dtype=np.uint64)
+    return np.frombuffer(x.to_bytes(8 * n_limbs, "little"), dtype="<u8").copy()
 
 
 def limbs_to_int(a) -> int:
-    v = 0
-    for i, l in enumerate(np.asarray(a, dtype=np.uint64).reshape(-1)):
-        v |= int(l) << (64 * i)
-    return v
+    return int.from_bytes(np.ascontiguousarray(a, dtype="<u8").tobytes(), "little")
+
+
+def _ints_to_limbs(values, n_limbs: int) -> np.ndarray:
+    """little-endian 64-bit limbs of each value, through one bytes object (these conversions sit between the kernels of a proof)"""
+    nb = 8 * n_limbs
+    return np.frombuffer(b"".join(v.to_bytes(nb, "little") for v in values), dtype="<u8").reshape(-1, n_limbs).copy()
+
+
+def _limbs_to_ints(a, n_limbs: int) -> list[int]:
+    raw = np.ascontiguousarray(a, dtype="<u8").reshape(-1, n_limbs).tobytes()
+    nb = 8 * n_limbs
+    return [int.from_bytes(raw[i:i + nb], "little") for i in range(0, len(raw), nb)]
 
 
 def fr_to_mont(c: CurveParams, values) -> np.ndarray:
     """Python ints (canonical) -> (n,4) uint64 Montgomery."""
-    return np.stack([int_to_limbs(v % c.r * c.fr_R % c.r, 4) for v in values]) if len(values) else np.zeros((0, 4), np.uint64)
+    r, R = c.r, c.fr_R
+    return _ints_to_limbs([int(v) % r * R % r for v in values], 4) if len(values) else np.zeros((0, 4), np.uint64)
 
 
 def fr_from_mont(c: CurveParams, a: np.ndarray) -> list[int]:
-    rinv = pow(c.fr_R, -1, c.r)
-    return [limbs_to_int(row) * rinv % c.r for row in np.asarray(a, dtype=np.uint64).reshape(-1, 4)]
+    rinv, r = c.fr_Rinv, c.r
+    return [v * rinv % r for v in _limbs_to_ints(a, 4)]
 
 
 def fr_bigints(values) -> np.ndarray:
     """Python ints -> (n,4) uint64 canonical integers (msm_bigint scalars)."""
-    return np.stack([int_to_limbs(v, 4) for v in values]) if len(values) else np.zeros((0, 4), np.uint64)
+    return _ints_to_limbs([int(v) for v in values], 4) if len(values) else np.zeros((0, 4), np.uint64)
 
 
 def fq_to_mont(c: CurveParams, values) -> np.ndarray:
-    return np.stack([int_to_limbs(v % c.q * c.fq_R % c.q, c.fq_limbs) for v in values])
+    q, R = c.q, c.fq_R
+    return _ints_to_limbs([int(v) % q * R % q for v in values], c.fq_limbs)
 
 
 def fq_from_mont(c: CurveParams, a: np.ndarray) -> list[int]:
-    rinv = pow(c.fq_R, -1, c.q)
-    return [limbs_to_int(row) * rinv % c.q for row in np.asarray(a, dtype=np.uint64).reshape(-1, c.fq_limbs)]
+    rinv, q = c.fq_Rinv, c.q
+    return [v * rinv % q for v in _limbs_to_ints(a, c.fq_limbs)]
 
 
 def random_fr_mont(c: CurveParams, n: int, seed: int) -> np.ndarray:

@@ -174,3 +174,78 @@ def test_gather_of_unevenly_owned_classes(tmp_path, world, n_classes):
     want = torch.stack([torch.full((5, 4), 100 * k + 1, dtype=torch.int64) for k in range(n_classes)])
     for rank in range(world):
         assert torch.equal(torch.load(tmp_path / f"classes_{rank}.pt"), want), rank
+
+
+class _Srs:
+    """what ShardedCommitter needs of a commit key on the CPU: its length (the fixed partition of the point indices)"""
+
+    def __init__(self, length):
+        self.length = length
+
+
+def _range_worker(rank, world, port, curve_id, srs_len, poly_len, out_dir):
+    """Rounds 4-5 by coefficient range (prover.py _RangeEvals / _openings_ranged) with Python integers in place of the device
+    kernels: partial evaluations, the one carried coefficient per opening, the division on the extended range, the range commit."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "oracle"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    import torch.distributed as dist
+    import cref
+    import mpc_jellyfish_amd as mj
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        c = mj.params.CURVES[curve_id]
+        r = c.r
+        bases = cref.g1_arith_bases(curve_id, 31, 7, srs_len)
+        oracle_batch = lambda ck, slices, offs: np.stack([cref.msm(curve_id, bases[o:o + len(s)], np.asarray(s), scalars_are_mont=True) for s, o in zip(slices, offs)])
+        com = mj.sharding.ShardedCommitter(c, _Srs(srs_len), msm_batch=oracle_batch)
+        assert com.rank() == rank and com.world() == world
+        b = mj.params.fr_from_mont(c, mj.params.random_fr_mont(c, poly_len, seed=5))       # the batch polynomial, same on every rank
+        z = 0x1234567890abcdef % r
+        lo, hi = com.point_range()
+        hi = min(hi, poly_len)
+        width = max(hi - lo, 0)
+        own = b[lo:hi] if width else []
+        e = sum(v * pow(z, j, r) for j, v in enumerate(own)) % r                       # the range read as a polynomial, at z
+        every = com.all_gather_fr([e, e * pow(z, min(lo, poly_len), r) % r])
+        value = sum(col[1] for col in every) % r                                      # round 4: p(z) from the partial values
+        carry = 0
+        for q in range(rank + 1, world):
+            lo_q = min(mj.sharding.shard_range(srs_len, q, world)[0], poly_len)
+            carry = (carry + pow(z, lo_q - hi, r) * every[q][0]) % r
+        ext = own + [carry]
+        wit, acc = [0] * width, 0
+        for j in range(width, 0, -1):                                                  # synthetic division of the extended range by X - z
+            acc = (ext[j] + z * acc) % r
+            wit[j - 1] = acc
+        jac = com.commit_jacobian_slices([mj.params.fr_to_mont(c, wit)])
+        np.save(os.path.join(out_dir, f"open_{rank}.npy"), jac)
+        np.save(os.path.join(out_dir, f"value_{rank}.npy"), mj.params.fr_to_mont(c, [value]))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,srs_len,poly_len", [(2, 23, 19), (3, 23, 23), (3, 40, 9)])
+def test_openings_by_coefficient_range(tmp_path, cref, mj, world, srs_len, poly_len):
+    """Every rank divides only its coefficient range (plus one carried coefficient) and commits only that range; the summed
+    commitment is the commitment of the whole witness polynomial b(X) / (X - z), and the partial evaluations add up to b(z).
+    (3, 40, 9): the upper ranks' ranges lie beyond the polynomial."""
+    import torch.multiprocessing as mp
+    curve_id = 1
+    port = 29500 + (os.getpid() + 17 * world + poly_len) % 2000
+    mp.spawn(_range_worker, args=(world, port, curve_id, srs_len, poly_len, str(tmp_path)), nprocs=world, join=True)
+    c = mj.params.CURVES[curve_id]
+    r = c.r
+    b = mj.params.fr_from_mont(c, mj.params.random_fr_mont(c, poly_len, seed=5))
+    z = 0x1234567890abcdef % r
+    wit, acc = [0] * (poly_len - 1), 0
+    for j in range(poly_len - 1, 0, -1):
+        acc = (b[j] + z * acc) % r
+        wit[j - 1] = acc
+    bases = cref.g1_arith_bases(curve_id, 31, 7, srs_len)
+    want = cref.jac_to_affine(curve_id, cref.msm(curve_id, bases[:poly_len - 1], mj.params.fr_to_mont(c, wit), scalars_are_mont=True))[0]
+    want_value = sum(v * pow(z, j, r) for j, v in enumerate(b)) % r
+    for rank in range(world):
+        got = np.load(tmp_path / f"open_{rank}.npy")[0]
+        assert np.array_equal(cref.jac_to_affine(curve_id, got)[0], want), rank
+        assert mj.params.fr_from_mont(c, np.load(tmp_path / f"value_{rank}.npy")) == [want_value], rank
