@@ -160,17 +160,6 @@ MZK_HD XYZZX<X> xyzzx_add(const XYZZX<X>& p, const XYZZX<X>& q) {
     return r;
 }
 
-// boundary <-> internal
-template <class X>
-MZK_HD Fx<X> fx_from_boundary(const Fp<X>& a) {                // x*R (packed) -> x*R' canonical
-    return fx_canonical(fx_mul(fx_unpack<X>(a.l), Fx<X>::from_const(X::XTO)));
-}
-template <class X>
-MZK_HD Fp<X> fx_to_boundary(const Fx<X>& a) {                  // lazy x*R' (limbs N) -> x*R canonical, packed
-    Fp<X> r;
-    fx_pack<X>(r.l, fx_canonical(fx_mul(a, Fx<X>::from_const(X::XFROM))));
-    return r;
-}
 template <class X>
 MZK_HD XYZZ<Fp<X>> xyzzx_to_boundary(const XYZZX<X>& p) {
     XYZZ<Fp<X>> r;

@@ -254,6 +254,48 @@ MZK_HD void fx_pack(uint32_t* w, const Fx<X>& a) {
     }
 }
 
+// boundary <-> internal
+template <class X>
+MZK_HD Fx<X> fx_from_boundary(const Fp<X>& a) {                // x*R (packed) -> x*R' canonical
+    return fx_canonical(fx_mul(fx_unpack<X>(a.l), Fx<X>::from_const(X::XTO)));
+}
+template <class X>
+MZK_HD Fp<X> fx_to_boundary(const Fx<X>& a) {                  // lazy x*R' (limbs N) -> x*R canonical, packed
+    Fp<X> r;
+    fx_pack<X>(r.l, fx_canonical(fx_mul(a, Fx<X>::from_const(X::XFROM))));
+    return r;
+}
+
+// 1/a in the internal form (a R' -> a^-1 R'), fx_inv(0) = 0: a^(p-2) with 4-bit windows taken from the top -- 32 X::N squarings
+// and at most 8 X::N products against a^1 .. a^15 -- on the reduced-radix product: about half the time of the bitwise Fermat
+// power on 32-bit limbs (fp.cuh inv) that a lone wave spends on the one inversion of a batch.  The loops keep ONE call site each of
+// fx_sqr and fx_mul (code size: the instruction cache), the table is indexed at run time (on the device it lives in scratch).
+// a: any lazy value fx_mul accepts (limbs < 2^29 + 2^27, value < 2^HEADROOM p).
+template <class X>
+MZK_HD Fx<X> fx_inv(const Fx<X>& a) {
+    Fx<X> tab[16];
+    tab[0] = Fx<X>::one();
+    tab[1] = fx_mul(a, tab[0]);                                  // class M
+#pragma unroll 1
+    for (int i = 2; i < 16; i++) tab[i] = fx_mul(tab[i - 1], tab[1]);
+    uint32_t e[X::N];                                            // p - 2 (p is odd and > 2: no borrow beyond word 0 unless it is 1)
+#pragma unroll
+    for (int i = 0; i < X::N; i++) e[i] = X::MOD[i];
+    uint32_t borrow = e[0] < 2 ? 1u : 0u;
+    e[0] -= 2;
+#pragma unroll
+    for (int i = 1; i < X::N; i++) { const uint32_t t = e[i]; e[i] = t - borrow; borrow = (borrow && t == 0) ? 1u : 0u; }
+    Fx<X> acc = tab[0];
+#pragma unroll 1
+    for (int d = 8 * X::N - 1; d >= 0; d--) {
+#pragma unroll 1
+        for (int k = 0; k < 4; k++) acc = fx_sqr(acc);
+        const uint32_t nib = (e[d >> 3] >> ((d & 7) * 4)) & 15u;
+        if (nib) acc = fx_mul(acc, tab[nib]);
+    }
+    return acc;
+}
+
 #if defined(__HIPCC__)
 template <class X>
 MZK_D Fx<X> fx_load_packed(const uint32_t* __restrict__ p) {

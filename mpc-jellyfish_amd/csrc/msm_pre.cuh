@@ -226,19 +226,6 @@ __global__ __launch_bounds__(1024) void pre_fine_kernel(const uint32_t* __restri
 
 // ---- table construction: next[i] = 2^c * cur[i], affine, 8 points per thread share one inversion ----
 template <class X>
-__device__ __forceinline__ Fx<X> fx_inv(const Fx<X>& a) {          // a^(p-2), a weakly normalised, result class M
-    Fx<X> acc = Fx<X>::one(), base = a;
-    for (int i = 0; i < X::N; i++) {
-        uint32_t e = X::MOD[i] - (i == 0 ? 2u : 0u);                // p - 2: every modulus here ends in ...1 or ...b, no borrow
-        for (int b = 0; b < 32; b++) {
-            if ((e >> b) & 1) acc = fx_mul(acc, base);
-            base = fx_sqr(base);
-        }
-    }
-    return acc;
-}
-
-template <class X>
 __global__ __launch_bounds__(128) void pre_next_level_kernel(const uint32_t* __restrict__ cur, uint32_t* __restrict__ next, unsigned long long n, int c) {
     constexpr int B = 4;
     using EC = EcFx<X>;

@@ -254,8 +254,8 @@ __global__ __launch_bounds__(PLK_THREADS) void plonk_combine_kernel(CombineArgs 
 // Replaces the serial loop of Arithmetization::compute_prod_permutation_polynomial
 // (relation/src/constraint_system.rs:1197-1223), which performs one field division per gate:
 //   z[0] = 1,  z[j+1] = z[j] * prod_i (w_ij + gamma + beta k_i w^j) / prod_i (w_ij + gamma + beta sigma_ij),  j < n-1.
-// Here: ratios with one shared inversion per 8 gates, then a three-phase parallel prefix product.
-constexpr int PERM_B = 8;             // gates per thread in the ratio kernel
+// Here: numerators and denominators gate by gate, the n denominators inverted with one Fermat power per `chunk` of them, then a
+// three-phase parallel prefix product.
 constexpr int SCAN_T = 256;           // threads per scan workgroup
 constexpr int SCAN_E = 8;             // elements per thread
 constexpr int SCAN_BLOCK = SCAN_T * SCAN_E;
@@ -264,50 +264,74 @@ struct PermArgs {
     const uint32_t* wire;      // [W][n] wire values (evaluations on H)
     const uint32_t* sigma;     // [W][n] extended permutation values sigma_i(w^j)
     const uint32_t* omega;     // [n] w^j
-    uint32_t* ratio;           // [n] out: ratio[j] for j < n-1, ratio[n-1] = 1
+    uint32_t* ratio;           // [n] out: numerator of ratio[j] for j < n-1, 1 at n-1
+    uint32_t* den;             // [n] out: its denominator
     unsigned long long n;
     int W;                     // 5 (TurboPlonk) or 6 (UltraPlonk)
     uint32_t k[PLK_MAX_WIRES][8];
     uint32_t beta[8], gamma[8];
 };
 
+// one gate per thread (coalesced): prod_i (w_ij + gamma + beta k_i w^j) and prod_i (w_ij + gamma + beta sigma_ij)
 template <class P>
-__global__ __launch_bounds__(PLK_THREADS) void plonk_perm_ratio_kernel(PermArgs a) {
+__global__ __launch_bounds__(PLK_THREADS) void plonk_perm_terms_kernel(PermArgs a) {
+    using F = Fp<P>;
+    const unsigned long long j = (unsigned long long)blockIdx.x * PLK_THREADS + threadIdx.x;
+    if (j >= a.n) return;
+    F nu = F::one(), de = F::one();
+    if (j + 1 < a.n) {
+        const F beta = arg_fp<P>(a.beta), gamma = arg_fp<P>(a.gamma);
+        const F bw = beta * load_fp<P>(a.omega + j * 8);
+#pragma unroll 1
+        for (int i = 0; i < a.W; i++) {
+            const F wg = load_fp<P>(a.wire + ((size_t)i * a.n + j) * 8) + gamma;
+            nu = nu * (wg + bw * arg_fp<P>(a.k[i]));
+            de = de * (wg + beta * load_fp<P>(a.sigma + ((size_t)i * a.n + j) * 8));
+        }
+    }
+    store_fp<P>(a.ratio + j * 8, nu);
+    store_fp<P>(a.den + j * 8, de);
+}
+
+// io[j] = io[j] / den[j] for all j < n.  Thread t of T owns the elements t, t + T, t + 2T, .. (coalesced across the wave) and
+// inverts their product once (Montgomery's trick; the prefix products are parked in `pref`): 3 products per element and one
+// Fermat power (fx_inv: ~210 product-equivalents) per n / T elements.  The host picks T so that the chip has a wave per SIMD
+// before chunks grow.  A zero denominator -- probability ~ n / r; the reference would panic on 1 / 0 -- zeroes its chunk.
+template <class P, class X>
+__global__ __launch_bounds__(PLK_THREADS) void fr_batch_div_kernel(uint32_t* __restrict__ io, const uint32_t* __restrict__ den, unsigned long long n,
+                                                                   unsigned long long T, uint32_t* __restrict__ pref) {
     using F = Fp<P>;
     const unsigned long long t = (unsigned long long)blockIdx.x * PLK_THREADS + threadIdx.x;
-    const unsigned long long start = t * PERM_B;
-    if (start >= a.n) return;
-    const F beta = arg_fp<P>(a.beta), gamma = arg_fp<P>(a.gamma);
-    F num[PERM_B], pref[PERM_B];
+    if (t >= T) return;
     F run = F::one();
-#pragma unroll
-    for (int q = 0; q < PERM_B; q++) {
-        const unsigned long long j = start + q;
-        F nu = F::one(), de = F::one();
-        if (j + 1 < a.n) {
-            const F bw = beta * load_fp<P>(a.omega + j * 8);
-#pragma unroll
-            for (int i = 0; i < PLK_MAX_WIRES; i++) {
-                if (i >= a.W) break;
-                const F wg = load_fp<P>(a.wire + ((size_t)i * a.n + j) * 8) + gamma;
-                nu = nu * (wg + bw * arg_fp<P>(a.k[i]));
-                de = de * (wg + beta * load_fp<P>(a.sigma + ((size_t)i * a.n + j) * 8));
-            }
-        }
-        num[q] = nu;
-        pref[q] = run;
-        run = run * de;
-        if (j < a.n) store_fp<P>(a.ratio + j * 8, de);      // parked
+    unsigned long long j = t;
+#pragma unroll 1
+    for (; j < n; j += T) {
+        store_fp<P>(pref + j * 8, run);
+        run = run * load_fp<P>(den + j * 8);
     }
-    F inv_run = inv(run);            // a zero denominator (probability ~ n/r) yields 0, as 1/0 would panic in the reference
+    Fp<X> rx;
 #pragma unroll
-    for (int q = PERM_B - 1; q >= 0; q--) {
-        const unsigned long long j = start + q;
-        if (j >= a.n) continue;
-        const F de = load_fp<P>(a.ratio + j * 8);
-        store_fp<P>(a.ratio + j * 8, num[q] * (inv_run * pref[q]));
-        inv_run = inv_run * de;
+    for (int q = 0; q < 8; q++) rx.l[q] = run.l[q];
+    const Fp<X> ix = fx_to_boundary<X>(fx_inv<X>(fx_from_boundary<X>(rx)));
+    F inv_run;
+#pragma unroll
+    for (int q = 0; q < 8; q++) inv_run.l[q] = ix.l[q];
+#pragma unroll 1
+    for (j -= T;; j -= T) {                                     // the elements again, last to first (j ends at t)
+        const F x = inv_run * load_fp<P>(pref + j * 8);
+        inv_run = inv_run * load_fp<P>(den + j * 8);
+        store_fp<P>(io + j * 8, load_fp<P>(io + j * 8) * x);
+        if (j < T) break;
     }
+}
+// threads of fr_batch_div_kernel for n elements: chunks of 4 until every SIMD has a wave (2^16 threads), then longer chunks up to 64
+inline unsigned long long batch_div_threads(unsigned long long n) {
+    unsigned long long chunk = n >> 16;
+    if (chunk < 4) chunk = 4;
+    if (chunk > 64) chunk = 64;
+    const unsigned long long T = (n + chunk - 1) / chunk;
+    return T ? T : 1;
 }
 
 // phase 1: inclusive products inside each 2048-element block (in place), block total to totals[block]

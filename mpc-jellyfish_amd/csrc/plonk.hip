@@ -161,6 +161,10 @@ int32_t pk_build(PlonkPk& pk, const uint32_t* sel_coeffs, const uint32_t* sig_co
 }
 
 // prefix product of ratio[0..n) into d_out: out[0] = 1, out[j+1] = prod_{i<=j} ratio[i]; then iFFT
+template <class P> struct FxOf;
+template <> struct FxOf<BlsFr> { using type = BlsFrX; };
+template <> struct FxOf<BnFr> { using type = BnFrX; };
+
 template <class P>
 int32_t scan_and_interpolate(const PlonkPk& pk, uint32_t* ratio, uint32_t* totals, unsigned n_blocks, bool last_one, uint32_t* d_out, hipStream_t st) {
     const uint64_t n = 1ull << pk.log_n;
@@ -179,16 +183,20 @@ int32_t perm_product_run(const PlonkPk& pk, const uint32_t* d_wires, const uint3
     ProfScope total("plonk_perm_product", st);
     MZK_TRY(ws_acquire(st));
     const unsigned n_blocks = (unsigned)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
-    MZK_TRY(g_ws.io.reserve(n * 32 + (size_t)n_blocks * 32));
+    MZK_TRY(g_ws.io.reserve(3 * n * 32 + (size_t)n_blocks * 32));
     uint32_t* ratio = g_ws.io.as<uint32_t>();
-    uint32_t* totals = ratio + n * 8;
+    uint32_t* den = ratio + n * 8;
+    uint32_t* pref = den + n * 8;
+    uint32_t* totals = pref + n * 8;
     PermArgs a;
-    a.wire = d_wires; a.sigma = pk.d_sigma_n; a.omega = pk.d_omega_n; a.ratio = ratio; a.n = n; a.W = pk.W;
+    a.wire = d_wires; a.sigma = pk.d_sigma_n; a.omega = pk.d_omega_n; a.ratio = ratio; a.den = den; a.n = n; a.W = pk.W;
     std::memcpy(a.k, pk.k, sizeof a.k);
     std::memcpy(a.beta, beta, 32);
     std::memcpy(a.gamma, gamma, 32);
-    const uint64_t rthreads = (n + PERM_B - 1) / PERM_B;
-    hipLaunchKernelGGL((plonk_perm_ratio_kernel<P>), dim3((unsigned)((rthreads + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st, a);
+    hipLaunchKernelGGL((plonk_perm_terms_kernel<P>), dim3((unsigned)((n + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st, a);
+    const unsigned long long T = batch_div_threads(n);
+    hipLaunchKernelGGL((fr_batch_div_kernel<P, typename FxOf<P>::type>), dim3((unsigned)((T + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st,
+                       ratio, den, n, T, pref);
     MZK_TRY(scan_and_interpolate<P>(pk, ratio, totals, n_blocks, false, d_out, st));
     MZK_TRY(ws_release(st));
     return ntt_dispatch(pk.curve, d_out, n, pk.log_n, true, nullptr, 1, n, st);
@@ -252,23 +260,23 @@ int32_t lookup_product_run(const PlonkPk& pk, const uint32_t* d_table, const uin
     ProfScope total("plookup_product", st);
     MZK_TRY(ws_acquire(st));
     const unsigned n_blocks = (unsigned)((n + SCAN_BLOCK - 1) / SCAN_BLOCK);
-    MZK_TRY(g_ws.io.reserve(n * 32 + (size_t)n_blocks * 32));
+    MZK_TRY(g_ws.io.reserve(3 * n * 32 + (size_t)n_blocks * 32));
     uint32_t* ratio = g_ws.io.as<uint32_t>();
-    uint32_t* totals = ratio + n * 8;
+    uint32_t* den = ratio + n * 8;
+    uint32_t* pref = den + n * 8;
+    uint32_t* totals = pref + n * 8;
     LookupProdArgs a;
-    a.table = d_table; a.lookup = d_lookup; a.sorted = d_sorted; a.ratio = ratio; a.n = n;
+    a.table = d_table; a.lookup = d_lookup; a.sorted = d_sorted; a.ratio = ratio; a.den = den; a.n = n;
     std::memcpy(a.beta, beta, 32);
     std::memcpy(a.gamma, gamma, 32);
-    const uint64_t rthreads = (n + PERM_B - 1) / PERM_B;
-    hipLaunchKernelGGL((plookup_ratio_kernel<P>), dim3((unsigned)((rthreads + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st, a);
+    hipLaunchKernelGGL((plookup_terms_kernel<P>), dim3((unsigned)((n + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st, a);
+    const unsigned long long T = batch_div_threads(n);
+    hipLaunchKernelGGL((fr_batch_div_kernel<P, typename FxOf<P>::type>), dim3((unsigned)((T + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st,
+                       ratio, den, n, T, pref);
     MZK_TRY(scan_and_interpolate<P>(pk, ratio, totals, n_blocks, true, d_out, st));
     MZK_TRY(ws_release(st));
     return ntt_dispatch(pk.curve, d_out, n, pk.log_n, true, nullptr, 1, n, st);
 }
-
-template <class P> struct FxOf;
-template <> struct FxOf<BlsFr> { using type = BlsFrX; };
-template <> struct FxOf<BnFr> { using type = BnFrX; };
 
 // challenges and per-key constants of QuotientArgs, converted to the internal form x * R' (x32)
 template <class P>

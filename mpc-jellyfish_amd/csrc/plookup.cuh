@@ -185,44 +185,28 @@ struct LookupProdArgs {
     const uint32_t* table;     // [n] merged table
     const uint32_t* lookup;    // [n] merged lookup witness
     const uint32_t* sorted;    // [2n-1]
-    uint32_t* ratio;           // [n] out: a_j / b_j for j < n-2, 1 beyond
+    uint32_t* ratio;           // [n] out: a_j for j < n-2, 1 beyond
+    uint32_t* den;             // [n] out: b_j (fr_batch_div_kernel then forms a_j / b_j)
     unsigned long long n;
     uint32_t beta[8], gamma[8];
 };
 
+// one row per thread: the numerator and denominator of the Plookup product's step j (constraint_system.rs:1340-1362)
 template <class P>
-__global__ __launch_bounds__(PLK_THREADS) void plookup_ratio_kernel(LookupProdArgs a) {
+__global__ __launch_bounds__(PLK_THREADS) void plookup_terms_kernel(LookupProdArgs a) {
     using F = Fp<P>;
-    const unsigned long long t = (unsigned long long)blockIdx.x * PLK_THREADS + threadIdx.x;
-    const unsigned long long start = t * PERM_B;
-    if (start >= a.n) return;
-    const F beta = arg_fp<P>(a.beta), gamma = arg_fp<P>(a.gamma);
-    const F b1 = beta + F::one(), g1 = gamma * b1;
-    F num[PERM_B], pref[PERM_B];
-    F run = F::one();
-#pragma unroll
-    for (int q = 0; q < PERM_B; q++) {
-        const unsigned long long j = start + q;
-        F nu = F::one(), de = F::one();
-        if (j + 2 < a.n) {
-            nu = b1 * (gamma + load_fp<P>(a.lookup + j * 8)) * (g1 + load_fp<P>(a.table + j * 8) + beta * load_fp<P>(a.table + (j + 1) * 8));
-            de = (g1 + load_fp<P>(a.sorted + j * 8) + beta * load_fp<P>(a.sorted + (j + 1) * 8)) *
-                 (g1 + load_fp<P>(a.sorted + (a.n - 1 + j) * 8) + beta * load_fp<P>(a.sorted + (a.n + j) * 8));
-        }
-        num[q] = nu;
-        pref[q] = run;
-        run = run * de;
-        if (j < a.n) store_fp<P>(a.ratio + j * 8, de);
+    const unsigned long long j = (unsigned long long)blockIdx.x * PLK_THREADS + threadIdx.x;
+    if (j >= a.n) return;
+    F nu = F::one(), de = F::one();
+    if (j + 2 < a.n) {
+        const F beta = arg_fp<P>(a.beta), gamma = arg_fp<P>(a.gamma);
+        const F b1 = beta + F::one(), g1 = gamma * b1;
+        nu = b1 * (gamma + load_fp<P>(a.lookup + j * 8)) * (g1 + load_fp<P>(a.table + j * 8) + beta * load_fp<P>(a.table + (j + 1) * 8));
+        de = (g1 + load_fp<P>(a.sorted + j * 8) + beta * load_fp<P>(a.sorted + (j + 1) * 8)) *
+             (g1 + load_fp<P>(a.sorted + (a.n - 1 + j) * 8) + beta * load_fp<P>(a.sorted + (a.n + j) * 8));
     }
-    F inv_run = inv(run);
-#pragma unroll
-    for (int q = PERM_B - 1; q >= 0; q--) {
-        const unsigned long long j = start + q;
-        if (j >= a.n) continue;
-        const F de = load_fp<P>(a.ratio + j * 8);
-        store_fp<P>(a.ratio + j * 8, num[q] * (inv_run * pref[q]));
-        inv_run = inv_run * de;
-    }
+    store_fp<P>(a.ratio + j * 8, nu);
+    store_fp<P>(a.den + j * 8, de);
 }
 
 // product_vec.push(F::one()) after the loop (constraint_system.rs:1364): the last value is the literal one

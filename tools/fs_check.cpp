@@ -43,8 +43,29 @@ void run(const char* tag, int cases) {
     }
 }
 
+// fx_inv (windowed Fermat inverse on the reduced-radix product, fx.cuh) against the bitwise power on 32-bit limbs (fp.cuh inv)
+template <class X>
+int check_inv(const char* tag, int cases) {
+    std::mt19937_64 rng(777);
+    int bad = 0;
+    for (int c = 0; c < cases; c++) {
+        Fp<X> a;
+        for (int i = 0; i < 8; i++) a.l[i] = (uint32_t)rng();
+        a.l[7] &= X::MOD[7] >> 1;
+        if (c == 0) for (int i = 0; i < 8; i++) a.l[i] = 0;                                   // inv(0) = 0
+        if (c == 1) for (int i = 0; i < 8; i++) a.l[i] = X::R1[i];                            // 1
+        if (c == 2) { for (int i = 0; i < 8; i++) a.l[i] = X::MOD[i]; a.l[0] -= 1; }          // image p - 1
+        const Fp<X> want = inv(a);
+        const Fp<X> got = fx_to_boundary<X>(fx_inv<X>(fx_from_boundary<X>(a)));
+        for (int i = 0; i < 8; i++) if (want.l[i] != got.l[i]) { bad++; break; }
+    }
+    if (bad) std::fprintf(stderr, "%s: fx_inv differs from inv in %d of %d cases\n", tag, bad, cases);
+    return bad;
+}
+
 int main(int argc, char** argv) {
     const int cases = argc > 1 ? std::atoi(argv[1]) : 20000;
+    if (check_inv<BlsFrX>("bls", 300) + check_inv<BnFrX>("bn", 300)) return 1;
     run<BlsFrX>("bls", cases);
     run<BnFrX>("bn", cases);
     return 0;

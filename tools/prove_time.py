@@ -23,3 +23,4 @@ for _ in range(reps):
 core, _ = mj.snark.prove(rng, cs, pk, profile=True)
 print(kind, c.name, "2^%d" % lg, "prove ms: min %.2f median %.2f max %.2f" % (min(ts), sorted(ts)[len(ts) // 2], max(ts)))
 print(dict(core.timings_ms))
+print("all reps:", [round(t, 1) for t in ts])
