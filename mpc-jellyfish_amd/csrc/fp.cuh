@@ -204,9 +204,13 @@ MZK_HD Fp<P> pow_limbs(const Fp<P>& a, const uint32_t* e, int ne) {
     return acc;
 }
 template <class P>
-MZK_HD Fp<P> pow_u64(const Fp<P>& a, uint64_t e) {
-    uint32_t w[2] = {(uint32_t)e, (uint32_t)(e >> 32)};
-    return pow_limbs(a, w, 2);
+MZK_HD Fp<P> pow_u64(const Fp<P>& a, uint64_t e) {               // as many squarings as e has bits (the power tables' threads wait on this)
+    Fp<P> acc = Fp<P>::one(), base = a;
+    for (; e; e >>= 1) {
+        if (e & 1) acc = acc * base;
+        if (e > 1) base = sqr(base);
+    }
+    return acc;
 }
 // Fermat inverse a^(p-2); inv(0) = 0
 template <class P>
