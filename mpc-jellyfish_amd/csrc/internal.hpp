@@ -82,6 +82,7 @@ inline int fq_words(int curve) { return curve == MZK_CURVE_BLS12_381 ? 12 : 8; }
 int32_t ntt_dispatch(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool inverse, const uint32_t* coset,
                      uint32_t batch, uint64_t stride, hipStream_t st, int scale = 0);
 void ntt_release_plans();
+void msm_release_streams();
 // msm.hip
 int32_t msm_dispatch(const Srs& s, uint64_t base_offset, const uint32_t* d_scalars, uint64_t n, int is_mont, uint32_t* out, hipStream_t st);
 int32_t msm_batch_dispatch(const Srs& s, uint32_t n_polys, const uint32_t* const* d_scalars, const uint64_t* lens, const uint64_t* base_offsets,

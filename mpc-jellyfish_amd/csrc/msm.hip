@@ -55,6 +55,24 @@ struct MsmItem {
 constexpr unsigned long long MSM_MIN_CAP = 48;
 struct PreInfo { int c = 0; uint64_t tab_stride = 0; };      // c == 0: plain path
 
+// A batch of MSMs sorts on a second stream: the sort of MSM p + 1 (memory- and LDS-bound, few registers) runs under the
+// accumulation of MSM p (VALU-bound at two waves per SIMD, which leaves register file and LDS for it).  SORT_SETS sets of sort buffers.
+hipStream_t g_sort_stream = nullptr;
+constexpr int SORT_SETS = 3;                                       // sorts run up to two MSMs ahead of the accumulation
+hipEvent_t g_ev_start = nullptr, g_ev_sorted[SORT_SETS] = {}, g_ev_acc[SORT_SETS] = {};
+int32_t sort_stream_init() {
+    if (g_sort_stream) return MZK_OK;
+    int prio_least = 0, prio_greatest = 0;                               // the short sort kernels go first whenever a slot frees up
+    HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+    HIP_TRY(hipStreamCreateWithPriority(&g_sort_stream, hipStreamNonBlocking, std::getenv("MZK_MSM_SORT_PRIO_LOW") ? prio_least : prio_greatest));
+    HIP_TRY(hipEventCreateWithFlags(&g_ev_start, hipEventDisableTiming));
+    for (int i = 0; i < SORT_SETS; i++) {
+        HIP_TRY(hipEventCreateWithFlags(&g_ev_sorted[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&g_ev_acc[i], hipEventDisableTiming));
+    }
+    return MZK_OK;
+}
+
 template <class FQ>
 void write_infinity(uint32_t* out_xyz) {
     using F64 = Fp64<FQ>;
@@ -80,15 +98,18 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     for (int p = 0; p < count; p++) n_max = std::max<uint64_t>(n_max, items[p].n);
     const uint64_t sorted_max = pre.c ? n_max * n_dig : n_max;           // entries per bucket set
     MZK_TRY(ws_acquire(st));
-    MZK_TRY(g_ws.hist.reserve(wm * 4));
-    MZK_TRY(g_ws.offs.reserve(wm * 4));
-    MZK_TRY(g_ws.cursor.reserve(wm * 4));                                // bucket order by load
+    const bool overlap = count > 1 && std::getenv("MZK_MSM_NO_OVERLAP") == nullptr;
+    const size_t nb = overlap ? (size_t)std::min(count, SORT_SETS) : 1;   // sets of sort buffers
+    MZK_TRY(g_ws.hist.reserve(nb * wm * 4));
+    MZK_TRY(g_ws.offs.reserve(nb * wm * 4));
+    MZK_TRY(g_ws.cursor.reserve(nb * wm * 4));                           // bucket order by load
     const uint32_t desc_cap_max = (uint32_t)(sorted_max / MSM_MIN_CAP + 1);          // cap >= MSM_MIN_CAP below
     MZK_TRY(g_ws.long_desc.reserve((size_t)n_win * desc_cap_max * sizeof(LongDesc) + (size_t)n_win * 4));
     MZK_TRY(g_ws.long_parts.reserve((size_t)n_win * desc_cap_max * EC::PT_WORDS * 4));
     const unsigned long long dstride_max = (n_max + 7) & ~7ull;
-    MZK_TRY(g_ws.digits.reserve((size_t)n_dig * dstride_max * (pre.c ? 4 : 2)));
-    MZK_TRY(g_ws.sorted.reserve((size_t)n_dig * n_max * 4));
+    const size_t digits_bytes = (size_t)n_dig * dstride_max * (pre.c ? 4 : 2), sorted_words = ((size_t)n_dig * n_max + 3) & ~(size_t)3;
+    MZK_TRY(g_ws.digits.reserve(nb * digits_bytes));
+    MZK_TRY(g_ws.sorted.reserve(nb * sorted_words * 4));
     // coarse bins of the table path: the low 2^top_bits buckets also receive the short top digit of every scalar, so they
     // are binned finer by the density ratio 1 + M / (2^top_bits (n_dig - 1)) (msm_pre.cuh PreBins)
     PreBins pb{0, PRE_FINE_LOG, 0};
@@ -102,10 +123,11 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
         }
     }
     const uint32_t n_bins = pre.c ? std::max<uint32_t>(1u, pb.count(M)) : 0u;
-    MZK_TRY(g_ws.pre_cnt.reserve((2048 + (size_t)n_win * 1024) * 4));     // bin totals, bin cursors, order keys
+    const size_t cnt_words = 2048 + (size_t)n_win * 1024;                // bin totals, bin cursors, order keys
+    MZK_TRY(g_ws.pre_cnt.reserve(nb * cnt_words * 4));
     if (pre.c) {
-        MZK_TRY(g_ws.pre_off.reserve(2048 * 4));
-        MZK_TRY(g_ws.pre_ce.reserve((size_t)n_dig * n_max * 8));
+        MZK_TRY(g_ws.pre_off.reserve(nb * 2048 * 4));
+        MZK_TRY(g_ws.pre_ce.reserve(nb * sorted_words * 8));
     }
     MZK_TRY(g_ws.buckets.reserve((size_t)count * wm * EC::PT_WORDS * 4));
     const int n_out_one = n_win * (log_m + 1);
@@ -118,17 +140,25 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
         HIP_TRY(hipHostMalloc(&g_ws.h_collect, out_bytes, hipHostMallocDefault));
         g_ws.h_collect_cap = out_bytes;
     }
-    uint32_t* hist = g_ws.hist.as<uint32_t>();
-    uint32_t* offs = g_ws.offs.as<uint32_t>();
-    uint32_t* order = g_ws.cursor.as<uint32_t>();
-    uint32_t* sorted = g_ws.sorted.as<uint32_t>();
     uint32_t* collect = g_ws.collect.as<uint32_t>();
     LongDesc* desc = g_ws.long_desc.as<LongDesc>();
     uint32_t* parts = g_ws.long_parts.as<uint32_t>();
+    hipStream_t sst = st;                                                // the stream the sorts run on
+    if (overlap) {
+        MZK_TRY(sort_stream_init());
+        sst = g_sort_stream;
+        HIP_TRY(hipEventRecord(g_ev_start, st));                         // scalars and workspace are ready on st
+        HIP_TRY(hipStreamWaitEvent(sst, g_ev_start, 0));
+    }
     {
         ProfScope total("msm_total", st);
         const unsigned n_ranges = M >> MSM_RANGE_LOG ? M >> MSM_RANGE_LOG : 1u;
         for (int p = 0; p < count; p++) {
+            const size_t b = overlap ? (size_t)p % nb : 0;               // this MSM's set of sort buffers
+            uint32_t* hist = g_ws.hist.as<uint32_t>() + b * wm;
+            uint32_t* offs = g_ws.offs.as<uint32_t>() + b * wm;
+            uint32_t* order = g_ws.cursor.as<uint32_t>() + b * wm;
+            uint32_t* sorted = g_ws.sorted.as<uint32_t>() + b * sorted_words;
             const uint64_t n = items[p].n;
             const uint32_t* d_scalars = items[p].d_scalars;
             const uint32_t* d_bases = items[p].d_bases;
@@ -150,40 +180,45 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
             uint32_t* desc_count = reinterpret_cast<uint32_t*>(desc + (size_t)n_win * desc_cap);
             const unsigned long long dstride = (n + 7) & ~7ull;
             const unsigned gs = (unsigned)((n + MSM_THREADS - 1) / MSM_THREADS);
+            if (overlap && (size_t)p >= nb) HIP_TRY(hipStreamWaitEvent(sst, g_ev_acc[b], 0));     // MSM p - nb has read this set
             if (!pre.c) {
-                ProfScope ps("msm_sort", st);
-                uint16_t* digits = g_ws.digits.as<uint16_t>();
-                hipLaunchKernelGGL((msm_digits_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, st, d_scalars, n, is_mont, c, n_win, digits, dstride);
-                hipLaunchKernelGGL((msm_sort_kernel<false>), dim3(n_ranges, n_win), dim3(MSM_SORT_THREADS), 0, st, digits, n, dstride, M, hist, offs, sorted);
-                hipLaunchKernelGGL(msm_scan_kernel, dim3(n_win), dim3(1024), 0, st, hist, offs, M);
-                hipLaunchKernelGGL((msm_sort_kernel<true>), dim3(n_ranges, n_win), dim3(MSM_SORT_THREADS), 0, st, digits, n, dstride, M, hist, offs, sorted);
+                ProfScope ps("msm_sort", sst);
+                uint16_t* digits = reinterpret_cast<uint16_t*>(g_ws.digits.as<char>() + b * digits_bytes);
+                hipLaunchKernelGGL((msm_digits_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, sst, d_scalars, n, is_mont, c, n_win, digits, dstride);
+                hipLaunchKernelGGL((msm_sort_kernel<false>), dim3(n_ranges, n_win), dim3(MSM_SORT_THREADS), 0, sst, digits, n, dstride, M, hist, offs, sorted);
+                hipLaunchKernelGGL(msm_scan_kernel, dim3(n_win), dim3(1024), 0, sst, hist, offs, M);
+                hipLaunchKernelGGL((msm_sort_kernel<true>), dim3(n_ranges, n_win), dim3(MSM_SORT_THREADS), 0, sst, digits, n, dstride, M, hist, offs, sorted);
             } else {
-                ProfScope ps("msm_sort", st);
-                uint32_t* dig32 = g_ws.digits.as<uint32_t>();
-                uint32_t* cnt = g_ws.pre_cnt.as<uint32_t>();
-                uint32_t* coff = g_ws.pre_off.as<uint32_t>();
-                unsigned long long* coarse = g_ws.pre_ce.as<unsigned long long>();
+                ProfScope ps("msm_sort", sst);
+                uint32_t* dig32 = reinterpret_cast<uint32_t*>(g_ws.digits.as<char>() + b * digits_bytes);
+                uint32_t* cnt = g_ws.pre_cnt.as<uint32_t>() + b * cnt_words;
+                uint32_t* coff = g_ws.pre_off.as<uint32_t>() + b * 2048;
+                unsigned long long* coarse = g_ws.pre_ce.as<unsigned long long>() + b * sorted_words;
                 const uint32_t n_chunks = (uint32_t)((n + PRE_CHUNK - 1) / PRE_CHUNK);
                 uint32_t* bin_total = cnt;                       // [n_bins]
                 uint32_t* bin_cursor = cnt + 1024;               // [n_bins]
                 uint32_t* bin_start = coff;                      // [n_bins + 1]
-                hipLaunchKernelGGL((pre_digits_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, st, d_scalars, n, is_mont, c, n_dig, dig32, dstride);
-                HIP_TRY(hipMemsetAsync(bin_total, 0, n_bins * 4, st));
-                hipLaunchKernelGGL(pre_coarse_count_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, st, dig32, n, dstride, n_dig, (int)n_bins, pb, bin_total);
-                hipLaunchKernelGGL(pre_bin_scan_kernel, dim3(1), dim3(1024), 0, st, bin_total, (int)n_bins, bin_start, bin_cursor);
-                hipLaunchKernelGGL(pre_coarse_scatter_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, st, dig32, n, dstride, n_dig, (int)n_bins, pb,
+                hipLaunchKernelGGL((pre_digits_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, sst, d_scalars, n, is_mont, c, n_dig, dig32, dstride);
+                HIP_TRY(hipMemsetAsync(bin_total, 0, n_bins * 4, sst));
+                hipLaunchKernelGGL(pre_coarse_count_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, sst, dig32, n, dstride, n_dig, (int)n_bins, pb, bin_total);
+                hipLaunchKernelGGL(pre_bin_scan_kernel, dim3(1), dim3(1024), 0, sst, bin_total, (int)n_bins, bin_start, bin_cursor);
+                hipLaunchKernelGGL(pre_coarse_scatter_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, sst, dig32, n, dstride, n_dig, (int)n_bins, pb,
                                    pre.tab_stride, items[p].base_off, bin_cursor, coarse);
-                hipLaunchKernelGGL(pre_fine_kernel, dim3(n_bins), dim3(1024), 0, st, bin_start, coarse, M, pb, hist, offs, sorted);
+                hipLaunchKernelGGL(pre_fine_kernel, dim3(n_bins), dim3(1024), 0, sst, bin_start, coarse, M, pb, hist, offs, sorted);
             }
             {
                 // buckets ranked by load within each bucket set
-                ProfScope ps("msm_sort", st);
-                uint32_t* keycnt = g_ws.pre_cnt.as<uint32_t>() + 2048;       // [n_win][1024]
+                ProfScope ps("msm_sort", sst);
+                uint32_t* keycnt = g_ws.pre_cnt.as<uint32_t>() + b * cnt_words + 2048;       // [n_win][1024]
                 const unsigned slices = (M + MSM_ORDER_SLICE - 1) / MSM_ORDER_SLICE;
-                HIP_TRY(hipMemsetAsync(keycnt, 0, (size_t)n_win * 1024 * 4, st));
-                hipLaunchKernelGGL(msm_order_hist_kernel, dim3(slices, n_win), dim3(1024), 0, st, hist, M, keycnt);
-                hipLaunchKernelGGL(msm_order_scan_kernel, dim3(n_win), dim3(1024), 0, st, keycnt);
-                hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(slices, n_win), dim3(1024), 0, st, hist, M, keycnt, order);
+                HIP_TRY(hipMemsetAsync(keycnt, 0, (size_t)n_win * 1024 * 4, sst));
+                hipLaunchKernelGGL(msm_order_hist_kernel, dim3(slices, n_win), dim3(1024), 0, sst, hist, M, keycnt);
+                hipLaunchKernelGGL(msm_order_scan_kernel, dim3(n_win), dim3(1024), 0, sst, keycnt);
+                hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(slices, n_win), dim3(1024), 0, sst, hist, M, keycnt, order);
+            }
+            if (overlap) {
+                HIP_TRY(hipEventRecord(g_ev_sorted[b], sst));
+                HIP_TRY(hipStreamWaitEvent(st, g_ev_sorted[b], 0));
             }
             {
                 ProfScope ps("msm_accumulate", st);
@@ -220,6 +255,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                                    d_bases, n_sorted, sorted, desc, desc_count, desc_cap, parts);
                 hipLaunchKernelGGL((msm_long_combine_kernel<EC>), dim3(n_win), dim3(1024), 0, st, desc, desc_count, desc_cap, M, parts, buckets);
             }
+            if (overlap) HIP_TRY(hipEventRecord(g_ev_acc[b], st));
         }
         {
             ProfScope ps("msm_reduce", st);
@@ -473,6 +509,14 @@ int32_t srs_generate_dispatch(int curve, const uint32_t* beta_canon, uint64_t n,
 void jac_to_affine_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uint64_t* xy) {
     if (curve == 0) jac_to_affine_host<BlsFq>(xyz, n, xy);
     else jac_to_affine_host<BnFq>(xyz, n, xy);
+}
+
+void msm_release_streams() {
+    if (!g_sort_stream) return;
+    (void)hipStreamDestroy(g_sort_stream);
+    g_sort_stream = nullptr;
+    (void)hipEventDestroy(g_ev_start);
+    for (int i = 0; i < SORT_SETS; i++) { (void)hipEventDestroy(g_ev_sorted[i]); (void)hipEventDestroy(g_ev_acc[i]); }
 }
 
 }  // namespace mzk

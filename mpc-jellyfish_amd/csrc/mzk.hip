@@ -180,6 +180,7 @@ int32_t mzk_shutdown(void) {
     g_srs.clear();
     io_release_all();
     ntt_release_plans();
+    msm_release_streams();
     plonk_release_all();
     for (auto& r : g_prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
     g_prof_recs.clear();
