@@ -70,6 +70,8 @@ def main():
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-plonk", action="store_true", help="skip the proof-level legs (round 3, prove, drop-in, UltraPlonk, C++ host)")
     ap.add_argument("--no-variable-base", action="store_true", help="skip the table-off repetition of the headline steps")
+    ap.add_argument("--no-batch", action="store_true", help="skip the batch_commit5 leg (with the other --no-* switches the run is the headline's "
+                    "launches alone: what the rocprofv3 --stats average of msm_accumulate_kernel is compared with)")
     ap.add_argument("--plonk-log-n", type=int, default=20)
     ap.add_argument("--prove-reps", type=int, default=10, help="timed repetitions of PlonkKzgSnark::prove (plonk/benches/bench.rs:25 uses 10)")
     ap.add_argument("--ultra-log-n", type=int, default=20, help="UltraPlonk/BN254 prove leg (0 disables; config C5 is 22)")
@@ -255,7 +257,7 @@ def main():
 
     # ---- secondary: batch_commit of 5 polynomials (round 1 / round 3 of a proof) in one fused call -----
     batch = None
-    if rank == 0 and world == 1:
+    if rank == 0 and world == 1 and not args.no_batch:
         sets = [d_scalars] * 5
         for _ in range(2):
             mj.msm_bigint_batch(pp, sets, scalars_are_mont=True)
