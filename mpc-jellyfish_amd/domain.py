@@ -51,7 +51,7 @@ class Radix2EvaluationDomain:
 
     # ---- transforms --------------------------------------------------------------------------
     def _offset_ptr(self):
-        return None if self.offset_mont is None else self.offset_mont.ctypes.data_as(C.c_void_p)
+        return None if self.offset_mont is None else self.C.c_void_p(offset_mont.ctypes.data)
 
     def _run_host(self, data: np.ndarray, inverse: bool) -> np.ndarray:
         a = np.ascontiguousarray(data, dtype=np.uint64)
@@ -62,7 +62,7 @@ class Radix2EvaluationDomain:
         buf = np.zeros((self.size, 4), dtype=np.uint64)
         buf[:a.shape[0]] = a
         L = _lib.ensure_init()
-        _lib.check(L.mzk_ntt(self.curve.curve_id, buf.ctypes.data_as(C.c_void_p), a.shape[0], self.log_size_of_group,
+        _lib.check(L.mzk_ntt(self.curve.curve_id, C.c_void_p(buf.ctypes.data), a.shape[0], self.log_size_of_group,
                              int(inverse), self._offset_ptr()), "mzk_ntt")
         return buf
 

@@ -53,7 +53,7 @@ class UnivariateProverParam:
         a = np.ascontiguousarray(powers_of_g, dtype=np.uint64).reshape(-1, 2, c.fq_limbs)
         L = _lib.ensure_init()
         h = C.c_uint64()
-        _lib.check(L.mzk_srs_register(c.curve_id, a.ctypes.data_as(C.c_void_p), a.shape[0], C.byref(h)), "mzk_srs_register")
+        _lib.check(L.mzk_srs_register(c.curve_id, C.c_void_p(a.ctypes.data), a.shape[0], C.byref(h)), "mzk_srs_register")
         return cls(c, h.value, a.shape[0])
 
     @classmethod
@@ -63,7 +63,7 @@ class UnivariateProverParam:
         L = _lib.ensure_init()
         h = C.c_uint64()
         b = int_to_limbs(beta % c.r, 4)
-        _lib.check(L.mzk_srs_generate_for_testing(c.curve_id, b.ctypes.data_as(C.c_void_p), max_degree + 1, C.byref(h)),
+        _lib.check(L.mzk_srs_generate_for_testing(c.curve_id, C.c_void_p(b.ctypes.data), max_degree + 1, C.byref(h)),
                    "mzk_srs_generate_for_testing")
         return cls(c, h.value, max_degree + 1)
 
@@ -76,7 +76,7 @@ class UnivariateProverParam:
     def powers_of_g(self, first: int = 0, count: int | None = None) -> np.ndarray:
         count = self.length - first if count is None else count
         out = np.empty((count, 2, self.curve.fq_limbs), dtype=np.uint64)
-        _lib.check(_lib.ensure_init().mzk_srs_download(self.handle, self.offset + first, count, out.ctypes.data_as(C.c_void_p)),
+        _lib.check(_lib.ensure_init().mzk_srs_download(self.handle, self.offset + first, count, C.c_void_p(out.ctypes.data)),
                    "mzk_srs_download")
         return out
 
@@ -111,12 +111,12 @@ def msm_bigint(pp: UnivariateProverParam, bigints, base_offset: int = 0, scalars
         n = min(bigints.shape[0], avail)
         st = torch.cuda.current_stream(bigints.device).cuda_stream
         _lib.check(L.mzk_msm_dev(pp.handle, pp.offset + base_offset, bigints.data_ptr(), n, int(scalars_are_mont),
-                                 out.ctypes.data_as(C.c_void_p), st), "mzk_msm_dev")
+                                 C.c_void_p(out.ctypes.data), st), "mzk_msm_dev")
         return out
     s = np.ascontiguousarray(bigints, dtype=np.uint64).reshape(-1, 4)
     n = min(s.shape[0], avail)
-    _lib.check(L.mzk_msm(pp.handle, pp.offset + base_offset, s.ctypes.data_as(C.c_void_p), n, int(scalars_are_mont),
-                         out.ctypes.data_as(C.c_void_p)), "mzk_msm")
+    _lib.check(L.mzk_msm(pp.handle, pp.offset + base_offset, C.c_void_p(s.ctypes.data), n, int(scalars_are_mont),
+                         C.c_void_p(out.ctypes.data)), "mzk_msm")
     return out
 
 
@@ -145,8 +145,8 @@ class UnivariateKzgPCS:
             lead = 0                                                       # the zero polynomial (ark-poly keeps no coefficients for it)
         L = _lib.ensure_init()
         out = np.empty((2, pp.curve.fq_limbs), dtype=np.uint64)
-        _lib.check(L.mzk_msm_affine(pp.handle, pp.offset + lead, body.ctypes.data_as(C.c_void_p) if body.size else None,
-                                    body.shape[0], 1, out.ctypes.data_as(C.c_void_p)), "mzk_msm_affine")
+        _lib.check(L.mzk_msm_affine(pp.handle, pp.offset + lead, C.c_void_p(body.ctypes.data) if body.size else None,
+                                    body.shape[0], 1, C.c_void_p(out.ctypes.data)), "mzk_msm_affine")
         return Commitment(pp.curve, out)
 
     @staticmethod
@@ -202,7 +202,7 @@ def jacobian_to_affine(curve, xyz: np.ndarray) -> np.ndarray:
     c = _curve(curve)
     a = np.ascontiguousarray(xyz, dtype=np.uint64).reshape(-1, 3, c.fq_limbs)
     out = np.empty((a.shape[0], 2, c.fq_limbs), dtype=np.uint64)
-    _lib.check(_lib.load().mzk_g1_jacobian_to_affine(c.curve_id, a.ctypes.data_as(C.c_void_p), a.shape[0], out.ctypes.data_as(C.c_void_p)),
+    _lib.check(_lib.load().mzk_g1_jacobian_to_affine(c.curve_id, C.c_void_p(a.ctypes.data), a.shape[0], C.c_void_p(out.ctypes.data)),
                "mzk_g1_jacobian_to_affine")
     return out
 
@@ -231,7 +231,7 @@ def msm_bigint_batch(pp: UnivariateProverParam, scalar_sets, base_offsets=None, 
             lens[i] = min(t.shape[0], max(0, limit - offs[i]))
             ptrs[i] = t.data_ptr()
         st = torch.cuda.current_stream(scalar_sets[0].device).cuda_stream
-        _lib.check(L.mzk_msm_batch_dev(pp.handle, k, ptrs, lens, offa, int(scalars_are_mont), out.ctypes.data_as(C.c_void_p), st),
+        _lib.check(L.mzk_msm_batch_dev(pp.handle, k, ptrs, lens, offa, int(scalars_are_mont), C.c_void_p(out.ctypes.data), st),
                    "mzk_msm_batch_dev")
         return out
     keep = []
@@ -240,5 +240,5 @@ def msm_bigint_batch(pp: UnivariateProverParam, scalar_sets, base_offsets=None, 
         keep.append(a)
         lens[i] = min(a.shape[0], max(0, limit - offs[i]))
         ptrs[i] = a.ctypes.data if a.size else None
-    _lib.check(L.mzk_msm_batch(pp.handle, k, ptrs, lens, offa, int(scalars_are_mont), out.ctypes.data_as(C.c_void_p)), "mzk_msm_batch")
+    _lib.check(L.mzk_msm_batch(pp.handle, k, ptrs, lens, offa, int(scalars_are_mont), C.c_void_p(out.ctypes.data)), "mzk_msm_batch")
     return out

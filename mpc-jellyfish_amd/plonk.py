@@ -84,7 +84,7 @@ class ProvingKeyDevice:
             tab_a = np.ascontiguousarray(slab[nsel + W:]) if ultra else None
             ca = np.ascontiguousarray(list(classes), dtype=np.uint32)
             _lib.check(L.mzk_plonk_pk_register_chunked(c.curve_id, domain_size.bit_length() - 1, W, ptr(sel_a), ptr(sig_a), ptr(tab_a) if ultra else None, plen,
-                                                       ptr(kk), ca.ctypes.data_as(C.c_void_p), len(ca), C.byref(h)), "mzk_plonk_pk_register_chunked")
+                                                       ptr(kk), C.c_void_p(ca.ctypes.data), len(ca), C.byref(h)), "mzk_plonk_pk_register_chunked")
         elif ultra:
             tab_a = np.ascontiguousarray(slab[nsel + W:])
             _lib.check(L.mzk_plonk_pk_register_ultra(c.curve_id, domain_size.bit_length() - 1, ptr(sel_a), ptr(sig_a), ptr(tab_a), plen, ptr(kk), C.byref(h)),
@@ -115,9 +115,9 @@ def compute_quotient_polynomial(pk: ProvingKeyDevice, challenges: Challenges, wi
         slab[i, :p.shape[0]] = p
     ch = fr_to_mont(pk.curve, [challenges.alpha, challenges.beta, challenges.gamma])
     out = np.empty((m, 4), dtype=np.uint64)
-    _lib.check(_lib.ensure_init().mzk_plonk_quotient(pk.handle, slab.ctypes.data_as(C.c_void_p), plen, ch[0].ctypes.data_as(C.c_void_p),
-                                                     ch[1].ctypes.data_as(C.c_void_p), ch[2].ctypes.data_as(C.c_void_p),
-                                                     out.ctypes.data_as(C.c_void_p)), "mzk_plonk_quotient")
+    _lib.check(_lib.ensure_init().mzk_plonk_quotient(pk.handle, C.c_void_p(slab.ctypes.data), plen, C.c_void_p(ch[0].ctypes.data),
+                                                     C.c_void_p(ch[1].ctypes.data), C.c_void_p(ch[2].ctypes.data),
+                                                     C.c_void_p(out.ctypes.data)), "mzk_plonk_quotient")
     return out
 
 
@@ -133,7 +133,7 @@ def compute_quotient_polynomial_dev(pk: ProvingKeyDevice, challenges: Challenges
     assert polys_dev.is_cuda and polys_dev.is_contiguous() and out_dev.is_contiguous() and polys_dev.dtype == torch.int64
     st = torch.cuda.current_stream(polys_dev.device).cuda_stream if stream is None else stream
     ch = fr_to_mont(pk.curve, [challenges.alpha, challenges.beta, challenges.gamma, challenges.tau])
-    p = lambda i: ch[i].ctypes.data_as(C.c_void_p)
+    p = lambda i: C.c_void_p(ch[i].ctypes.data)
     if pk.ultra:
         _lib.check(_lib.ensure_init().mzk_plonk_quotient_ultra_dev(pk.handle, polys_dev.data_ptr(), in_len, p(3), p(0), p(1), p(2), out_dev.data_ptr(), st),
                    "mzk_plonk_quotient_ultra_dev")
@@ -155,7 +155,7 @@ def compute_quotient_chunked_dev(pk: ProvingKeyDevice, challenges: Challenges, p
     out = torch.empty((len(pk.classes), n, 4), dtype=torch.int64, device=polys_dev.device) if out_dev is None else out_dev
     st = torch.cuda.current_stream(polys_dev.device).cuda_stream if stream is None else stream
     ch = fr_to_mont(pk.curve, [challenges.alpha, challenges.beta, challenges.gamma, challenges.tau])
-    p = lambda i: ch[i].ctypes.data_as(C.c_void_p)
+    p = lambda i: C.c_void_p(ch[i].ctypes.data)
     _lib.check(_lib.ensure_init().mzk_plonk_quotient_chunked_dev(pk.handle, polys_dev.data_ptr(), polys_dev.shape[1], in_len, p(3) if pk.ultra else None,
                                                                  p(0), p(1), p(2), out.data_ptr(), st), "mzk_plonk_quotient_chunked_dev")
     return out
@@ -182,7 +182,7 @@ def combine_quotient_classes(curve, domain_size: int, class_remainders, classes=
     out = torch.empty((8 * n, 4), dtype=torch.int64, device=r.device) if out_dev is None else out_dev
     st = torch.cuda.current_stream(r.device).cuda_stream if stream is None else stream
     ca = np.ascontiguousarray(cl, dtype=np.uint32)
-    _lib.check(_lib.ensure_init().mzk_plonk_quotient_combine_classes_dev(c.curve_id, n.bit_length() - 1, ca.ctypes.data_as(C.c_void_p), len(cl),
+    _lib.check(_lib.ensure_init().mzk_plonk_quotient_combine_classes_dev(c.curve_id, n.bit_length() - 1, C.c_void_p(ca.ctypes.data), len(cl),
                                                                          r.data_ptr(), out.data_ptr(), st), "mzk_plonk_quotient_combine_classes_dev")
     return out
 
@@ -201,8 +201,8 @@ def compute_prod_permutation_polynomial_dev(pk: ProvingKeyDevice, beta: int, gam
     assert wire_values_dev.shape == (pk.num_wire_types, n, 4) and wire_values_dev.is_contiguous()
     out = torch.empty((n, 4), dtype=torch.int64, device=wire_values_dev.device) if out_dev is None else out_dev
     ch = fr_to_mont(pk.curve, [beta, gamma])
-    _lib.check(_lib.ensure_init().mzk_plonk_perm_product_dev(pk.handle, wire_values_dev.data_ptr(), ch[0].ctypes.data_as(C.c_void_p),
-                                                             ch[1].ctypes.data_as(C.c_void_p), out.data_ptr(),
+    _lib.check(_lib.ensure_init().mzk_plonk_perm_product_dev(pk.handle, wire_values_dev.data_ptr(), C.c_void_p(ch[0].ctypes.data),
+                                                             C.c_void_p(ch[1].ctypes.data), out.data_ptr(),
                                                              torch.cuda.current_stream(wire_values_dev.device).cuda_stream), "mzk_plonk_perm_product_dev")
     return out
 
@@ -223,7 +223,7 @@ def compute_lookup_sorted_vec(pk: ProvingKeyDevice, tau: int, wire_values):
     lookup = torch.empty((n, 4), dtype=torch.int64, device=w.device)
     sorted_vec = torch.empty((2 * n - 1, 4), dtype=torch.int64, device=w.device)
     t = fr_to_mont(pk.curve, [tau])
-    rc = _lib.ensure_init().mzk_plookup_sorted_vec_dev(pk.handle, w.data_ptr(), t[0].ctypes.data_as(C.c_void_p), table.data_ptr(), lookup.data_ptr(),
+    rc = _lib.ensure_init().mzk_plookup_sorted_vec_dev(pk.handle, w.data_ptr(), C.c_void_p(t[0].ctypes.data), table.data_ptr(), lookup.data_ptr(),
                                                        sorted_vec.data_ptr(), torch.cuda.current_stream(w.device).cuda_stream)
     if rc == -8:
         raise PlonkError("The sorted vector has wrong length, some lookup variables might be outside the table")
@@ -242,8 +242,8 @@ def compute_lookup_prod_polynomial(pk: ProvingKeyDevice, beta: int, gamma: int, 
         raise PlonkError("The sorted vector has wrong length")                                      # constraint_system.rs:1334-1336
     out = torch.empty((n, 4), dtype=torch.int64, device=t.device) if out_dev is None else out_dev
     ch = fr_to_mont(pk.curve, [beta, gamma])
-    _lib.check(_lib.ensure_init().mzk_plookup_product_dev(pk.handle, t.data_ptr(), l.data_ptr(), s.data_ptr(), ch[0].ctypes.data_as(C.c_void_p),
-                                                          ch[1].ctypes.data_as(C.c_void_p), out.data_ptr(), torch.cuda.current_stream(t.device).cuda_stream),
+    _lib.check(_lib.ensure_init().mzk_plookup_product_dev(pk.handle, t.data_ptr(), l.data_ptr(), s.data_ptr(), C.c_void_p(ch[0].ctypes.data),
+                                                          C.c_void_p(ch[1].ctypes.data), out.data_ptr(), torch.cuda.current_stream(t.device).cuda_stream),
                "mzk_plookup_product_dev")
     return out
 
@@ -256,6 +256,6 @@ def compute_prod_permutation_polynomial(pk: ProvingKeyDevice, beta: int, gamma: 
         raise PlonkError("expected (%d, n, 4) wire values" % pk.num_wire_types)
     ch = fr_to_mont(pk.curve, [beta, gamma])
     out = np.empty((pk.domain_size, 4), dtype=np.uint64)
-    _lib.check(_lib.ensure_init().mzk_plonk_perm_product(pk.handle, w.ctypes.data_as(C.c_void_p), ch[0].ctypes.data_as(C.c_void_p),
-                                                         ch[1].ctypes.data_as(C.c_void_p), out.ctypes.data_as(C.c_void_p)), "mzk_plonk_perm_product")
+    _lib.check(_lib.ensure_init().mzk_plonk_perm_product(pk.handle, C.c_void_p(w.ctypes.data), C.c_void_p(ch[0].ctypes.data),
+                                                         C.c_void_p(ch[1].ctypes.data), C.c_void_p(out.ctypes.data)), "mzk_plonk_perm_product")
     return out

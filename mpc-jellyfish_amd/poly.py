@@ -40,8 +40,8 @@ def evaluate(curve, polys_dev, x: int, length: int | None = None, offset: int = 
     assert t.is_cuda and t.is_contiguous() and t.shape[-1] == 4 and 0 <= offset and n >= 0 and offset + n <= stride
     xm = fr_to_mont(c, [x])[0]
     out = np.empty((batch, 4), dtype=np.uint64)
-    _lib.check(_lib.ensure_init().mzk_poly_eval_dev(c.curve_id, t.data_ptr() + 32 * offset, n, batch, stride, xm.ctypes.data_as(C.c_void_p),
-                                                    out.ctypes.data_as(C.c_void_p), _stream(t, None)), "mzk_poly_eval_dev")
+    _lib.check(_lib.ensure_init().mzk_poly_eval_dev(c.curve_id, t.data_ptr() + 32 * offset, n, batch, stride, C.c_void_p(xm.ctypes.data),
+                                                    C.c_void_p(out.ctypes.data), _stream(t, None)), "mzk_poly_eval_dev")
     return fr_from_mont(c, out)
 
 
@@ -58,7 +58,7 @@ def lincomb(curve, terms, out_len: int | None = None, out=None, stream=None):
     ptrs = (C.c_void_p * k)(*[p.data_ptr() for p in polys])
     lens = (C.c_uint64 * k)(*[p.shape[0] for p in polys])
     sc = fr_to_mont(c, [s for s, _ in terms])
-    _lib.check(_lib.ensure_init().mzk_poly_lincomb_dev(c.curve_id, k, ptrs, lens, sc.ctypes.data_as(C.c_void_p), out.data_ptr(), n_out,
+    _lib.check(_lib.ensure_init().mzk_poly_lincomb_dev(c.curve_id, k, ptrs, lens, C.c_void_p(sc.ctypes.data), out.data_ptr(), n_out,
                                                        _stream(out, stream)), "mzk_poly_lincomb_dev")
     return out
 
@@ -70,7 +70,7 @@ def div_by_linear(curve, poly_dev, z: int, stream=None):
     n = poly_dev.shape[0]
     out = torch.zeros((max(n - 1, 0), 4), dtype=torch.int64, device=poly_dev.device)
     zm = fr_to_mont(c, [z])[0]
-    _lib.check(_lib.ensure_init().mzk_poly_div_linear_dev(c.curve_id, poly_dev.data_ptr(), n, zm.ctypes.data_as(C.c_void_p), out.data_ptr(),
+    _lib.check(_lib.ensure_init().mzk_poly_div_linear_dev(c.curve_id, poly_dev.data_ptr(), n, C.c_void_p(zm.ctypes.data), out.data_ptr(),
                                                           _stream(poly_dev, stream)), "mzk_poly_div_linear_dev")
     return out
 
@@ -108,4 +108,4 @@ def mask(curve, rows, n: int, blinders, stream=None):
     assert k == len(blinders) and all(len(b) == h for b in blinders) and all(r.is_cuda and r.shape[0] >= n + h for r in rows)
     bm = fr_to_mont(c, [x for b in blinders for x in b])
     ptrs = (C.c_void_p * k)(*[r.data_ptr() for r in rows])
-    _lib.check(_lib.ensure_init().mzk_poly_mask_dev(c.curve_id, k, ptrs, n, h, bm.ctypes.data_as(C.c_void_p), _stream(rows[0], stream)), "mzk_poly_mask_dev")
+    _lib.check(_lib.ensure_init().mzk_poly_mask_dev(c.curve_id, k, ptrs, n, h, C.c_void_p(bm.ctypes.data), _stream(rows[0], stream)), "mzk_poly_mask_dev")

@@ -33,8 +33,8 @@ def sum_jacobian(curve, points: np.ndarray) -> np.ndarray:
     c = _curve(curve)
     pts = np.ascontiguousarray(points, dtype=np.uint64).reshape(-1, 3, c.fq_limbs)
     out = np.empty((3, c.fq_limbs), dtype=np.uint64)
-    _lib.check(_lib.load().mzk_g1_sum_jacobian(c.curve_id, pts.ctypes.data_as(C.c_void_p), pts.shape[0],
-                                                out.ctypes.data_as(C.c_void_p)), "mzk_g1_sum_jacobian")
+    _lib.check(_lib.load().mzk_g1_sum_jacobian(c.curve_id, C.c_void_p(pts.ctypes.data), pts.shape[0],
+                                                C.c_void_p(out.ctypes.data)), "mzk_g1_sum_jacobian")
     return out
 
 

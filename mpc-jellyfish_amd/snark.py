@@ -116,6 +116,8 @@ def preprocess(commit_key: kzg.UnivariateProverParam, circuit: BenchCircuit, quo
     c, n = circuit.curve, circuit.n
     if commit_key.length < n + 3:
         raise ValueError("SRS too small: need domain size + 3 powers (srs.rs:88)")          # snark.rs:535-541
+    if commit_key.length > n + 3:       # snark.rs:535, 561: the proving key keeps trim(srs_size) = n + 3 powers -- a view of the same registration;
+        commit_key = commit_key.trim(n + 2)   # the sharded commits partition THIS length over the ranks (sharding.ShardedCommitter)
     dom = Radix2EvaluationDomain(c, n.bit_length() - 1)
     sel = circuit.selector_values.clone()
     sig = circuit.sigma_values.clone()
