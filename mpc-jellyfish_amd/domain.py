@@ -51,7 +51,7 @@ class Radix2EvaluationDomain:
 
     # ---- transforms --------------------------------------------------------------------------
     def _offset_ptr(self):
-        return None if self.offset_mont is None else self.C.c_void_p(offset_mont.ctypes.data)
+        return None if self.offset_mont is None else C.c_void_p(self.offset_mont.ctypes.data)
 
     def _run_host(self, data: np.ndarray, inverse: bool) -> np.ndarray:
         a = np.ascontiguousarray(data, dtype=np.uint64)
