@@ -39,16 +39,43 @@ struct FsTw {                            // one constant operand: w canonical (l
 // |value(a)| < 2^261.  Returns class C with value in (-2p, 3p):
 //   q^ = floor(a wq / 2^261) computed from columns 7..16 of the product differs from floor(a w / p) by -2 .. +1
 //   (wq's own rounding contributes less than 1 in absolute value because |a| < 2^261; the dropped columns 0..6 less than 2^-24).
+// -p's limbs as values the compiler cannot see through: both scalar fields have limbs of special shape (BLS12-381: 1 and 2^29 - 8;
+// BN254: 2^28 + 1), and clang turns q * (-1) or q * (8 - 2^29) into 64-bit shift / subtract sequences of two to four VOP3
+// instructions where one v_mad_i64_i32 does (26 of a product's 143 multiply-adds on BLS12-381, profiles/r02_ntt_isa.txt).
+template <class X>
+MZK_HD int32_t fs_neg_p_limb(int i) {
+    int32_t v = -(int32_t)X::XP[i];
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("" : "+s"(v));
+#endif
+    return v;
+}
+// acc += x * y as ONE v_mad_i64_i32 whose addend is the running accumulator.  Left to itself clang starts every column's sum from
+// zero (for instruction-level parallelism) and then needs a 64-bit add per column to bring the carry in: 18 extra VOP3 instructions
+// per product.  The transform runs 6 waves per SIMD, so a serial chain of multiply-adds per wave costs nothing.
+#if defined(__HIP_DEVICE_COMPILE__) && !defined(MZK_FS_NO_ASM)
+__device__ __forceinline__ void fs_mad(int64_t& acc, int32_t x, int32_t y) {
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "v"(y) : "vcc");
+}
+__device__ __forceinline__ void fs_mad_s(int64_t& acc, int32_t x, int32_t y_sgpr) {
+    asm("v_mad_i64_i32 %0, vcc, %1, %2, %0" : "+v"(acc) : "v"(x), "s"(y_sgpr) : "vcc");
+}
+#else
+MZK_HD void fs_mad(int64_t& acc, int32_t x, int32_t y) { acc += (int64_t)x * y; }
+MZK_HD void fs_mad_s(int64_t& acc, int32_t x, int32_t y) { acc += (int64_t)x * y; }
+#endif
 template <class X>
 MZK_HD Fs<X> fs_mulc(const Fs<X>& a, const FsTw& t) {
     static_assert(X::XN == FS_N, "9 limbs of 29 bits");
     constexpr int N = FS_N;
-    int32_t q[N];
+    int32_t q[N], np[N];
+#pragma unroll
+    for (int i = 0; i < N; i++) np[i] = fs_neg_p_limb<X>(i);
     int64_t acc = 0;
 #pragma unroll
     for (int k = N - 2; k <= 2 * N - 2; k++) {                     // columns 7 .. 16 of a x wq
 #pragma unroll
-        for (int i = (k - (N - 1) > 0 ? k - (N - 1) : 0); i <= (k < N - 1 ? k : N - 1); i++) acc += (int64_t)a.l[i] * t.q[k - i];
+        for (int i = (k - (N - 1) > 0 ? k - (N - 1) : 0); i <= (k < N - 1 ? k : N - 1); i++) fs_mad(acc, a.l[i], t.q[k - i]);
         if (k >= N) q[k - N] = (int32_t)((uint32_t)acc & XMASK);  // units of 2^261 start at column 9
         acc >>= XL;
     }
@@ -59,8 +86,8 @@ MZK_HD Fs<X> fs_mulc(const Fs<X>& a, const FsTw& t) {
     for (int k = 0; k < N; k++) {                                   // low 261 bits of a w - q^ p
 #pragma unroll
         for (int i = 0; i <= k; i++) {
-            acc += (int64_t)a.l[i] * t.w[k - i];
-            acc += (int64_t)q[i] * (-(int32_t)X::XP[k - i]);
+            fs_mad(acc, a.l[i], t.w[k - i]);
+            fs_mad_s(acc, q[i], np[k - i]);
         }
         if (k < N - 1) {
             r.l[k] = (int32_t)((uint32_t)acc & XMASK);
