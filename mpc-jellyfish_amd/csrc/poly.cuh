@@ -14,7 +14,8 @@
 namespace mzk {
 
 constexpr int POLY_THREADS = 256;
-constexpr int POLY_EVAL_T = 16384;           // threads (= stride) per polynomial in the strided Horner
+constexpr int POLY_EVAL_T = 16384;           // least number of threads (= stride) per polynomial in the strided Horner
+constexpr int POLY_EVAL_T_MAX = 1 << 18;     // ... grown while a thread's chain of dependent products would exceed 32 (poly.hip eval_run)
 constexpr int POLY_MAX_TERMS = 32;
 
 template <class P>
@@ -36,7 +37,7 @@ __device__ __forceinline__ Fp<P> block_sum(Fp<P> v, uint4* sh) {
 template <class P>
 __global__ __launch_bounds__(POLY_THREADS) void poly_eval_partial_kernel(const uint32_t* __restrict__ coeffs, unsigned long long stride, unsigned long long len,
                                                                           const uint32_t* __restrict__ xpow /* [T] */, const uint32_t* __restrict__ y_mont,
-                                                                          uint32_t* __restrict__ partial) {
+                                                                          unsigned long long T, uint32_t* __restrict__ partial) {
     using F = Fp<P>;
     __shared__ uint4 sh[2 * POLY_THREADS];
     const unsigned long long t = (unsigned long long)blockIdx.x * POLY_THREADS + threadIdx.x;
@@ -44,9 +45,9 @@ __global__ __launch_bounds__(POLY_THREADS) void poly_eval_partial_kernel(const u
     const F y = load_fp<P>(y_mont);
     F acc = F::zero();
     if (t < len) {
-        const unsigned long long kmax = (len - 1 - t) / POLY_EVAL_T;             // highest k with t + k T < len
-        acc = load_fp<P>(c + (t + kmax * POLY_EVAL_T) * 8);
-        for (unsigned long long k = kmax; k-- > 0;) acc = acc * y + load_fp<P>(c + (t + k * POLY_EVAL_T) * 8);
+        const unsigned long long kmax = (len - 1 - t) / T;                       // highest k with t + k T < len
+        acc = load_fp<P>(c + (t + kmax * T) * 8);
+        for (unsigned long long k = kmax; k-- > 0;) acc = acc * y + load_fp<P>(c + (t + k * T) * 8);
         acc = acc * load_fp<P>(xpow + t * 8);
     }
     const F s = block_sum<P>(acc, sh);

@@ -11,20 +11,25 @@ int32_t eval_run(const uint32_t* d_coeffs, uint64_t stride, uint64_t len, uint32
     if (len == 0) { std::memset(out_host, 0, (size_t)batch * 32); return MZK_OK; }
     F x;
     std::memcpy(x.l, x_mont, 32);
-    const F y = pow_u64(x, POLY_EVAL_T);
-    const int blocks = POLY_EVAL_T / POLY_THREADS;
+    // stride T of the strided Horner: a thread's chain is len / T dependent products long and a polynomial gets T / 256 workgroups --
+    // at 2^22 coefficients the fixed 16384 meant 256-deep chains on 64 workgroups (170 us for a single polynomial)
+    uint64_t T = POLY_EVAL_T;
+    while (T * 32 < len && T < (uint64_t)POLY_EVAL_T_MAX) T <<= 1;
+    const F y = pow_u64(x, T);
+    const int blocks = (int)(T / POLY_THREADS);
     MZK_TRY(ws_acquire(st));
-    MZK_TRY(g_ws.poly_tmp.reserve((size_t)POLY_EVAL_T * 32 + 64 + (size_t)batch * blocks * 32 + (size_t)batch * 32));
+    MZK_TRY(g_ws.poly_tmp.reserve((size_t)T * 32 + 64 + (size_t)batch * blocks * 32 + (size_t)batch * 32));
     uint32_t* xpow = g_ws.poly_tmp.as<uint32_t>();
-    uint32_t* d_xy = xpow + (size_t)POLY_EVAL_T * 8;               // x, y
+    uint32_t* d_xy = xpow + (size_t)T * 8;                         // x, y
     uint32_t* partial = d_xy + 16;
     uint32_t* d_out = partial + (size_t)batch * blocks * 8;
     HIP_TRY(hipMemcpyAsync(d_xy, x.l, 32, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_xy + 8, y.l, 32, hipMemcpyHostToDevice, st));
-    const uint64_t tlen = len < POLY_EVAL_T ? len : POLY_EVAL_T;
+    const uint64_t tlen = len < T ? len : T;
     hipLaunchKernelGGL((fr_powers_mont_kernel<P>), dim3((unsigned)(((tlen + 15) / 16 + POLY_THREADS - 1) / POLY_THREADS)), dim3(POLY_THREADS), 0, st,
                        d_xy, tlen, xpow);
-    hipLaunchKernelGGL((poly_eval_partial_kernel<P>), dim3(blocks, batch), dim3(POLY_THREADS), 0, st, d_coeffs, stride, len, xpow, d_xy + 8, partial);
+    hipLaunchKernelGGL((poly_eval_partial_kernel<P>), dim3(blocks, batch), dim3(POLY_THREADS), 0, st, d_coeffs, stride, len, xpow, d_xy + 8,
+                       (unsigned long long)T, partial);
     hipLaunchKernelGGL((poly_eval_final_kernel<P>), dim3(batch), dim3(POLY_THREADS), 0, st, partial, blocks, d_out);
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_host, d_out, (size_t)batch * 32, hipMemcpyDeviceToHost, st));
