@@ -237,7 +237,8 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 // additions stay under ~5 % of the work (S - 1 <= mean / 32)
                 int log_split = 0;
                 const unsigned long long mean = n_sorted / M;
-                while (log_split < 3) {
+                static const int max_split = std::getenv("MZK_MSM_MAX_SPLIT") ? std::atoi(std::getenv("MZK_MSM_MAX_SPLIT")) : 3;   // (tuning switch)
+                while (log_split < max_split) {
                     const int nx = log_split + 1;
                     const bool small_grid = (wm << nx) <= (1ull << 18);
                     if (small_grid ? (mean >> (nx + 1)) == 0 : ((1ull << nx) - 1) * 32 > mean) break;
