@@ -292,11 +292,16 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     HIP_TRY(hipStreamSynchronize(st));
     const uint32_t* h = reinterpret_cast<const uint32_t*>(g_ws.h_collect);
     const size_t per = (size_t)n_out_one * 4 * FQ::N;
-    if (count == 1) {
-        host_horner<FQ>(h, n_win, c, items[0].out_xyz);
+    // a Horner tail is c doublings + c additions on one core, ~14 us on the table path (one bucket set): starting a thread costs more
+    // than running it (measured: 5 tails on 5 fresh threads 130-250 us, in sequence 70 us).  Threads only for many-window plain-path
+    // batches (n_win tails of work each).
+    if (count * n_win <= 16) {
+        for (int p = 0; p < count; p++) host_horner<FQ>(h + p * per, n_win, c, items[p].out_xyz);
     } else {
+        const int n_thr = std::min(count, 4);
         std::vector<std::thread> th;
-        for (int p = 0; p < count; p++) th.emplace_back([=] { host_horner<FQ>(h + p * per, n_win, c, items[p].out_xyz); });
+        for (int q = 0; q < n_thr; q++)
+            th.emplace_back([=] { for (int p = q; p < count; p += n_thr) host_horner<FQ>(h + p * per, n_win, c, items[p].out_xyz); });
         for (auto& t : th) t.join();
     }
     return MZK_OK;
