@@ -334,7 +334,9 @@ template <class EC>
 __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(const uint32_t* __restrict__ bases, unsigned long long n,
                                                                           const uint32_t* __restrict__ offs, const uint32_t* __restrict__ hist,
                                                                           const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ order,
-                                                                          uint32_t M, int n_win, uint32_t cap, uint32_t* __restrict__ buckets) {
+                                                                          uint32_t M, int n_win, uint32_t cap, uint32_t* __restrict__ long_count,
+                                                                          uint32_t* __restrict__ buckets) {
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)n_win) long_count[threadIdx.x] = 0u;     // what msm_long_find_kernel counts into (saves a fill)
     const unsigned long long t0 = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
     if (t0 >= (unsigned long long)n_win * M) return;
     const unsigned long long w = t0 / M;
@@ -357,7 +359,9 @@ template <class EC>
 __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_split_kernel(const uint32_t* __restrict__ bases, unsigned long long n,
                                                                                 const uint32_t* __restrict__ offs, const uint32_t* __restrict__ hist,
                                                                                 const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ order,
-                                                                                uint32_t M, int n_win, uint32_t cap, int log_split, uint32_t* __restrict__ sub) {
+                                                                                uint32_t M, int n_win, uint32_t cap, int log_split, uint32_t* __restrict__ long_count,
+                                                                                uint32_t* __restrict__ sub) {
+    if (blockIdx.x == 0 && threadIdx.x < (unsigned)n_win) long_count[threadIdx.x] = 0u;
     const unsigned long long t1 = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
     const unsigned long long t0 = t1 >> log_split;
     if (t0 >= (unsigned long long)n_win * M) return;

@@ -209,7 +209,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 uint32_t* bin_cursor = cnt + 1024;               // [n_bins]
                 uint32_t* bin_start = coff;                      // [n_bins + 1]
                 hipLaunchKernelGGL((pre_digits_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, sst, d_scalars, n, is_mont, c, n_dig, dig32, dstride);
-                HIP_TRY(hipMemsetAsync(bin_total, 0, n_bins * 4, sst));
+                HIP_TRY(hipMemsetAsync(cnt, 0, cnt_words * 4, sst));              // bin totals and, further down, the order keys: one fill
                 hipLaunchKernelGGL(pre_coarse_count_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, sst, dig32, n, dstride, n_dig, (int)n_bins, pb, bin_total);
                 hipLaunchKernelGGL(pre_bin_scan_kernel, dim3(1), dim3(1024), 0, sst, bin_total, (int)n_bins, bin_start, bin_cursor);
                 hipLaunchKernelGGL(pre_coarse_scatter_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, sst, dig32, n, dstride, n_dig, (int)n_bins, pb,
@@ -221,7 +221,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 ProfScope ps("msm_sort", sst);
                 uint32_t* keycnt = g_ws.pre_cnt.as<uint32_t>() + b * cnt_words + 2048;       // [n_win][1024]
                 const unsigned slices = (M + MSM_ORDER_SLICE - 1) / MSM_ORDER_SLICE;
-                HIP_TRY(hipMemsetAsync(keycnt, 0, (size_t)n_win * 1024 * 4, sst));
+                if (!pre.c) HIP_TRY(hipMemsetAsync(keycnt, 0, (size_t)n_win * 1024 * 4, sst));   // (table path: zeroed with the bin totals above)
                 hipLaunchKernelGGL(msm_order_hist_kernel, dim3(slices, n_win), dim3(1024), 0, sst, hist, M, keycnt);
                 hipLaunchKernelGGL(msm_order_scan_kernel, dim3(n_win), dim3(1024), 0, sst, keycnt);
                 hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(slices, n_win), dim3(1024), 0, sst, hist, M, keycnt, order);
@@ -246,13 +246,13 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 }
                 if (log_split == 0) {
                     hipLaunchKernelGGL((msm_accumulate_kernel<EC>), dim3((unsigned)((wm + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
-                                       d_bases, n_sorted, offs, hist, sorted, order, M, n_win, cap, buckets);
+                                       d_bases, n_sorted, offs, hist, sorted, order, M, n_win, cap, desc_count, buckets);
                 } else {
                     const size_t threads = wm << log_split;
                     MZK_TRY(g_ws.split.reserve(threads * EC::PT_WORDS * 4));
                     uint32_t* sub = g_ws.split.as<uint32_t>();
                     hipLaunchKernelGGL((msm_accumulate_split_kernel<EC>), dim3((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS),
-                                       0, st, d_bases, n_sorted, offs, hist, sorted, order, M, n_win, cap, log_split, sub);
+                                       0, st, d_bases, n_sorted, offs, hist, sorted, order, M, n_win, cap, log_split, desc_count, sub);
                     hipLaunchKernelGGL((msm_split_combine_kernel<EC>), dim3((unsigned)((threads + 2 * MSM_ACC_THREADS - 1) / (2 * MSM_ACC_THREADS))), dim3(MSM_ACC_THREADS),
                                        0, st, sub, (unsigned long long)wm, log_split, buckets);
                 }
@@ -260,7 +260,6 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
             {
                 // over-long buckets (skewed scalars); no-ops for uniformly random scalars
                 ProfScope ps("msm_long", st);
-                HIP_TRY(hipMemsetAsync(desc_count, 0, (size_t)n_win * 4, st));
                 hipLaunchKernelGGL(msm_long_find_kernel, dim3((unsigned)((wm + 255) / 256)), dim3(256), 0, st, hist, offs, M, n_win, cap, desc_cap, desc, desc_count);
                 hipLaunchKernelGGL((msm_long_chunk_kernel<EC>), dim3((desc_cap + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, n_win), dim3(MSM_ACC_THREADS), 0, st,
                                    d_bases, n_sorted, sorted, desc, desc_count, desc_cap, parts);
