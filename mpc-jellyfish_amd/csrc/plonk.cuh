@@ -209,7 +209,7 @@ __global__ __launch_bounds__(PLK_THREADS) void plonk_domain_tables_kernel(const 
 //   folded[j] = p[j] + h_k^n * p[n + j].
 template <class P>
 __global__ __launch_bounds__(PLK_THREADS) void plonk_fold_kernel(const uint32_t* __restrict__ src, unsigned long long src_stride, unsigned long long in_len,
-                                                                  unsigned long long n, int rows, const uint32_t* __restrict__ c_mont,
+                                                                  unsigned long long n, int rows, FrArg c_mont,
                                                                   uint32_t* __restrict__ dst) {
     using F = Fp<P>;
     const unsigned long long t = (unsigned long long)blockIdx.x * PLK_THREADS + threadIdx.x;
@@ -217,7 +217,7 @@ __global__ __launch_bounds__(PLK_THREADS) void plonk_fold_kernel(const uint32_t*
     const unsigned long long row = t / n, j = t % n;
     const uint32_t* p = src + row * src_stride * 8;
     F v = j < in_len ? load_fp<P>(p + j * 8) : F::zero();
-    if (n + j < in_len) v = v + load_fp<P>(c_mont) * load_fp<P>(p + (n + j) * 8);
+    if (n + j < in_len) v = v + fr_arg<P>(c_mont) * load_fp<P>(p + (n + j) * 8);
     store_fp<P>(dst + t * 8, v);
 }
 

@@ -143,9 +143,8 @@ int32_t pk_build(PlonkPk& pk, const uint32_t* sel_coeffs, const uint32_t* sig_co
     HIP_TRY(hipMemsetAsync(pk.d_sigma_n, 0, (size_t)pk.W * n * 32, st));
     const uint64_t sl = poly_len < n ? poly_len : n;
     HIP_TRY(hipMemcpy2DAsync(pk.d_sigma_n, n * 32, sig_coeffs, poly_len * 32, sl * 32, pk.W, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_c + 8, wn.l, 32, hipMemcpyHostToDevice, st));
     hipLaunchKernelGGL((fr_powers_mont_kernel<P>), dim3((unsigned)(((n + 15) / 16 + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st,
-                       d_c + 8, n, pk.d_omega_n);
+                       to_fr_arg<P>(wn), n, pk.d_omega_n);
     HIP_TRY(hipGetLastError());
     MZK_TRY(ws_release(st));
     MZK_TRY(ntt_dispatch(pk.curve, pk.d_sigma_n, sl, pk.log_n, false, nullptr, pk.W, n, st));
@@ -428,7 +427,7 @@ int32_t pk_build_chunked(PlonkPk& pk, const uint32_t* sel_coeffs, const uint32_t
     HIP_TRY(hipMalloc((void**)&pk.d_omega_n, n * 32));
     HIP_TRY(hipMemsetAsync(pk.d_sigma_n, 0, (size_t)pk.W * n * 32, st));
     HIP_TRY(hipMemcpy2DAsync(pk.d_sigma_n, n * 32, sig_coeffs, poly_len * 32, sl * 32, pk.W, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL((fr_powers_mont_kernel<P>), dim3(tg), dim3(PLK_THREADS), 0, st, d_c, n, pk.d_omega_n);
+    hipLaunchKernelGGL((fr_powers_mont_kernel<P>), dim3(tg), dim3(PLK_THREADS), 0, st, to_fr_arg<P>(wn), n, pk.d_omega_n);
     HIP_TRY(hipGetLastError());
     MZK_TRY(ws_release(st));
     // class evaluations of the fixed polynomials: size-n coset NTTs with offset h_k, all polynomials of a class in one batch
@@ -459,16 +458,16 @@ int32_t quotient_chunked_run(const PlonkPk& pk, const uint32_t* d_polys, uint64_
     MZK_TRY(ws_acquire(st));
     MZK_TRY(g_ws.plonk_polys.reserve((size_t)rows * n * 32 + 64));
     uint32_t* work = g_ws.plonk_polys.as<uint32_t>();
-    uint32_t* d_c = work + (size_t)rows * n * 8;
     QuotientArgs a;
     a.m = n; a.fstride = ncl * n; a.ostride = n; a.next_off = 1;
     fill_quotient_constants<P>(a, pk, tau, alpha, beta, gamma);
     const unsigned long long fold_threads = n * (unsigned long long)rows;
     for (size_t lc = 0; lc < ncl; lc++) {
         const int k = pk.cls[lc];
-        HIP_TRY(hipMemcpyAsync(d_c, pk.c_cls[k], 32, hipMemcpyHostToDevice, st));
+        FrArg c_k;
+        std::memcpy(c_k.l, pk.c_cls[k], 32);
         hipLaunchKernelGGL((plonk_fold_kernel<P>), dim3((unsigned)((fold_threads + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st,
-                           d_polys, in_stride, in_len, n, rows, d_c, work);
+                           d_polys, in_stride, in_len, n, rows, c_k, work);
         HIP_TRY(hipGetLastError());
         MZK_TRY(ntt_dispatch(pk.curve, work, n, pk.log_n, false, pk.h_cls[k], rows, n, st, 1));          // evaluations in the internal form
         a.sel = pk.d_fixed + lc * n * 8;

@@ -32,17 +32,32 @@ __device__ __forceinline__ Fp<P> block_sum(Fp<P> v, uint4* sh) {
     return v;
 }
 
+// a field element as a kernel argument (no host-to-device copy in front of the launch)
+struct FrArg { uint32_t l[8]; };
+template <class P>
+__host__ __device__ inline Fp<P> fr_arg(const FrArg& a) {
+    Fp<P> r;
+    for (int i = 0; i < 8; i++) r.l[i] = a.l[i];
+    return r;
+}
+template <class P>
+inline FrArg to_fr_arg(const Fp<P>& v) {
+    FrArg a;
+    for (int i = 0; i < 8; i++) a.l[i] = v.l[i];
+    return a;
+}
+
 // partial[poly][block] = sum over the block's threads t of x^t * ( sum_k c[t + k T] y^k ),  y = x^T.
 // grid = (T / 256, batch)
 template <class P>
 __global__ __launch_bounds__(POLY_THREADS) void poly_eval_partial_kernel(const uint32_t* __restrict__ coeffs, unsigned long long stride, unsigned long long len,
-                                                                          const uint32_t* __restrict__ xpow /* [T] */, const uint32_t* __restrict__ y_mont,
+                                                                          const uint32_t* __restrict__ xpow /* [T] */, FrArg y_mont,
                                                                           unsigned long long T, uint32_t* __restrict__ partial) {
     using F = Fp<P>;
     __shared__ uint4 sh[2 * POLY_THREADS];
     const unsigned long long t = (unsigned long long)blockIdx.x * POLY_THREADS + threadIdx.x;
     const uint32_t* c = coeffs + (unsigned long long)blockIdx.y * stride * 8;
-    const F y = load_fp<P>(y_mont);
+    const F y = fr_arg<P>(y_mont);
     F acc = F::zero();
     if (t < len) {
         const unsigned long long kmax = (len - 1 - t) / T;                       // highest k with t + k T < len
@@ -66,11 +81,11 @@ __global__ __launch_bounds__(POLY_THREADS) void poly_eval_final_kernel(const uin
 
 // out[j] = w^j (Montgomery), 16 per thread
 template <class P>
-__global__ __launch_bounds__(POLY_THREADS) void fr_powers_mont_kernel(const uint32_t* __restrict__ w_mont, unsigned long long n, uint32_t* __restrict__ out) {
+__global__ __launch_bounds__(POLY_THREADS) void fr_powers_mont_kernel(FrArg w_mont, unsigned long long n, uint32_t* __restrict__ out) {
     using F = Fp<P>;
     const unsigned long long start = ((unsigned long long)blockIdx.x * POLY_THREADS + threadIdx.x) * 16;
     if (start >= n) return;
-    const F w = load_fp<P>(w_mont);
+    const F w = fr_arg<P>(w_mont);
     F x = pow_u64(w, start);
     for (int q = 0; q < 16 && start + q < n; q++) {
         store_fp<P>(out + (start + q) * 8, x);

@@ -18,17 +18,14 @@ int32_t eval_run(const uint32_t* d_coeffs, uint64_t stride, uint64_t len, uint32
     const F y = pow_u64(x, T);
     const int blocks = (int)(T / POLY_THREADS);
     MZK_TRY(ws_acquire(st));
-    MZK_TRY(g_ws.poly_tmp.reserve((size_t)T * 32 + 64 + (size_t)batch * blocks * 32 + (size_t)batch * 32));
+    MZK_TRY(g_ws.poly_tmp.reserve((size_t)T * 32 + (size_t)batch * blocks * 32 + (size_t)batch * 32));
     uint32_t* xpow = g_ws.poly_tmp.as<uint32_t>();
-    uint32_t* d_xy = xpow + (size_t)T * 8;                         // x, y
-    uint32_t* partial = d_xy + 16;
+    uint32_t* partial = xpow + (size_t)T * 8;
     uint32_t* d_out = partial + (size_t)batch * blocks * 8;
-    HIP_TRY(hipMemcpyAsync(d_xy, x.l, 32, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_xy + 8, y.l, 32, hipMemcpyHostToDevice, st));
     const uint64_t tlen = len < T ? len : T;
     hipLaunchKernelGGL((fr_powers_mont_kernel<P>), dim3((unsigned)(((tlen + 15) / 16 + POLY_THREADS - 1) / POLY_THREADS)), dim3(POLY_THREADS), 0, st,
-                       d_xy, tlen, xpow);
-    hipLaunchKernelGGL((poly_eval_partial_kernel<P>), dim3(blocks, batch), dim3(POLY_THREADS), 0, st, d_coeffs, stride, len, xpow, d_xy + 8,
+                       to_fr_arg<P>(x), tlen, xpow);                 // x and y travel as kernel arguments
+    hipLaunchKernelGGL((poly_eval_partial_kernel<P>), dim3(blocks, batch), dim3(POLY_THREADS), 0, st, d_coeffs, stride, len, xpow, to_fr_arg<P>(y),
                        (unsigned long long)T, partial);
     hipLaunchKernelGGL((poly_eval_final_kernel<P>), dim3(batch), dim3(POLY_THREADS), 0, st, partial, blocks, d_out);
     HIP_TRY(hipGetLastError());
@@ -51,18 +48,15 @@ int32_t div_run(const uint32_t* d_poly, uint64_t len, const uint32_t* z_mont, ui
     const F zi = inv(z);
     const unsigned n_blocks = (unsigned)((len + DIV_BLOCK - 1) / DIV_BLOCK);
     MZK_TRY(ws_acquire(st));
-    MZK_TRY(g_ws.poly_tmp.reserve(64 + (size_t)len * 32 * 3 + (size_t)n_blocks * 32));
-    uint32_t* d_c = g_ws.poly_tmp.as<uint32_t>();                  // z, z^-1
-    uint32_t* zpow = d_c + 16;
+    MZK_TRY(g_ws.poly_tmp.reserve((size_t)len * 32 * 3 + (size_t)n_blocks * 32));
+    uint32_t* zpow = g_ws.poly_tmp.as<uint32_t>();
     uint32_t* zinvpow = zpow + len * 8;
     uint32_t* t = zinvpow + len * 8;
     uint32_t* totals = t + len * 8;
-    HIP_TRY(hipMemcpyAsync(d_c, z.l, 32, hipMemcpyHostToDevice, st));
-    HIP_TRY(hipMemcpyAsync(d_c + 8, zi.l, 32, hipMemcpyHostToDevice, st));
     const unsigned pg = (unsigned)(((len + 15) / 16 + POLY_THREADS - 1) / POLY_THREADS);
     const unsigned eg = (unsigned)((len + POLY_THREADS - 1) / POLY_THREADS);
-    hipLaunchKernelGGL((fr_powers_mont_kernel<P>), dim3(pg), dim3(POLY_THREADS), 0, st, d_c, len, zpow);
-    hipLaunchKernelGGL((fr_powers_mont_kernel<P>), dim3(pg), dim3(POLY_THREADS), 0, st, d_c + 8, len, zinvpow);
+    hipLaunchKernelGGL((fr_powers_mont_kernel<P>), dim3(pg), dim3(POLY_THREADS), 0, st, to_fr_arg<P>(z), len, zpow);
+    hipLaunchKernelGGL((fr_powers_mont_kernel<P>), dim3(pg), dim3(POLY_THREADS), 0, st, to_fr_arg<P>(zi), len, zinvpow);
     hipLaunchKernelGGL((poly_div_scale_kernel<P>), dim3(eg), dim3(POLY_THREADS), 0, st, d_poly, zpow, len, t);
     hipLaunchKernelGGL((fr_suffix_add_block_kernel<P>), dim3(n_blocks), dim3(POLY_THREADS), 0, st, t, len, totals);
     hipLaunchKernelGGL((fr_suffix_add_totals_kernel<P>), dim3(1), dim3(1024), 0, st, totals, n_blocks);
