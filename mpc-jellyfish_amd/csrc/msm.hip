@@ -82,7 +82,7 @@ void write_infinity(uint32_t* out_xyz) {
 
 // `count` MSMs that share the window size: sort + accumulate run one after the other (they fill the
 // chip on their own), the latency-bound recursive halving runs ONCE over all bucket sets, one copy
-// brings every partial sum to the host, and the host Horner tails run on separate threads.
+// brings every partial sum to the host, and the host Horner tails run there in sequence (threads only when there are many).
 // Plain path: n_dig windows, each with its own 2^(c-1) buckets.  Pre path (msm_pre.cuh): the digits of
 // all windows index rows of the precomputed table and share one bucket set.
 template <class FR, class EC>
