@@ -113,6 +113,12 @@ MZK_API int32_t mzk_g1_jacobian_to_affine(int32_t curve_id, const uint64_t* xyz_
  * outside Rust (the Python prover mirror; a Rust caller keeps using merlin). */
 MZK_API int32_t mzk_keccak_f1600(uint8_t* state200);
 
+/* Host-only: n_blocks consecutive 64-byte ChaCha blocks (djb variant: 64-bit block counter in state words 12-13, stream id 0) as
+ * 16 little-endian u32 words each -- rand_chacha's ChaCha{8,12,20}Rng core, for hosts that mirror `jf_utils::test_rng()`
+ * (utilities/src/lib.rs:62-70: the blinders of mask_polynomial / split_quotient_polynomial) and
+ * `compute_coset_representatives` (relation/src/constants.rs:30-80) outside Rust. */
+MZK_API int32_t mzk_chacha_blocks(const uint32_t key[8], uint64_t counter, uint32_t rounds, uint32_t n_blocks, uint32_t* out_words);
+
 /* ---- NTT: replaces EvaluationDomain::{fft,ifft}_in_place on Radix2EvaluationDomain
  *      forward coset: plonk/src/proof_system/prover.rs:554,557,561,566,567,579-591
  *      inverse coset: plonk/src/proof_system/prover.rs:672

@@ -472,6 +472,29 @@ int32_t mzk_ntt(int32_t curve_id, uint64_t* data_mont, uint64_t in_len, uint32_t
 }
 
 // ---- host-only: Keccak-f[1600] for the Merlin/STROBE transcript mirror (plonk/src/transcript/standard.rs) ----------------
+int32_t mzk_chacha_blocks(const uint32_t key[8], uint64_t counter, uint32_t rounds, uint32_t n_blocks, uint32_t* out_words) {
+    if (!key || !out_words || (rounds != 8 && rounds != 12 && rounds != 20)) { mzk::set_error("mzk_chacha_blocks: bad argument"); return MZK_ERR_INVALID_ARG; }
+    auto rotl = [](uint32_t v, int n) { return (v << n) | (v >> (32 - n)); };
+    for (uint32_t b = 0; b < n_blocks; b++, counter++) {
+        uint32_t init[16] = {0x61707865u, 0x3320646Eu, 0x79622D32u, 0x6B206574u, key[0], key[1], key[2], key[3], key[4], key[5], key[6], key[7],
+                             (uint32_t)counter, (uint32_t)(counter >> 32), 0u, 0u};
+        uint32_t x[16];
+        for (int i = 0; i < 16; i++) x[i] = init[i];
+        auto qr = [&](int a, int bb, int c, int d) {
+            x[a] += x[bb]; x[d] = rotl(x[d] ^ x[a], 16);
+            x[c] += x[d]; x[bb] = rotl(x[bb] ^ x[c], 12);
+            x[a] += x[bb]; x[d] = rotl(x[d] ^ x[a], 8);
+            x[c] += x[d]; x[bb] = rotl(x[bb] ^ x[c], 7);
+        };
+        for (uint32_t r = 0; r < rounds / 2; r++) {
+            qr(0, 4, 8, 12); qr(1, 5, 9, 13); qr(2, 6, 10, 14); qr(3, 7, 11, 15);
+            qr(0, 5, 10, 15); qr(1, 6, 11, 12); qr(2, 7, 8, 13); qr(3, 4, 9, 14);
+        }
+        for (int i = 0; i < 16; i++) out_words[16 * b + i] = x[i] + init[i];
+    }
+    return MZK_OK;
+}
+
 int32_t mzk_keccak_f1600(uint8_t* state200) {
     if (!state200) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     static const uint64_t RC[24] = {0x0000000000000001ull, 0x0000000000008082ull, 0x800000000000808Aull, 0x8000000080008000ull, 0x000000000000808Bull,

@@ -43,6 +43,7 @@ _SIGS = {
     "mzk_plonk_quotient_dev": [C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "mzk_plonk_quotient": [C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "mzk_keccak_f1600": [C.c_void_p],
+    "mzk_chacha_blocks": [C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_void_p],
     "mzk_plonk_pk_register_ultra": [C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.POINTER(C.c_uint64)],
     "mzk_plonk_quotient_ultra_dev": [C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "mzk_plonk_pk_register_chunked": [C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32,

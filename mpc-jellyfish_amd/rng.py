@@ -55,10 +55,16 @@ class ChaChaRng:
         self.index = 0
 
     def _refill(self):
-        self.buf = []
-        for _ in range(4):                                   # rand_chacha produces four blocks per refill
-            self.buf += chacha_block(self.key, self.counter, self.rounds)
-            self.counter += 1
+        """rand_chacha produces four blocks per refill; the block function runs in the library (host-only mzk_chacha_blocks:
+        pure Python costs 0.5 ms of every proof's blinding draws); `chacha_block` above is the same function, kept as its
+        definition and checked against it by the tests."""
+        import ctypes as C
+        from . import lib as _lib
+        key = (C.c_uint32 * 8)(*self.key)
+        out = (C.c_uint32 * 64)()
+        _lib.check(_lib.load().mzk_chacha_blocks(C.addressof(key), self.counter, self.rounds, 4, C.addressof(out)), "mzk_chacha_blocks")
+        self.buf = list(out)
+        self.counter += 4
         self.index = 0
 
     def next_u32(self) -> int:
@@ -102,7 +108,7 @@ def fr_rand(curve, rng: ChaChaRng) -> int:
         limbs[3] &= (1 << (64 - shave)) - 1
         v = limbs[0] | (limbs[1] << 64) | (limbs[2] << 128) | (limbs[3] << 192)
         if v < c.r:
-            return v * _mont_r_inv(c) % c.r
+            return v * c.fr_Rinv % c.r
 
 
 def dense_poly_rand(curve, degree: int, rng: ChaChaRng) -> list[int]:
