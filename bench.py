@@ -1,15 +1,16 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the jf-plonk hot path on MI355X.
 
-Workload (BASELINE.json configs[1], "Standalone MSM"): 2^20 G1 points x Fr scalars on BLS12-381, SRS and scalars resident in
-HBM when the timed region starts; one step = one MSM of 2^20 pairs per GPU through the C ABI (mzk_msm_dev).  With N > 1 ranks
+Workload (BASELINE.json configs[1], "Standalone MSM"): 2^20 random G1 points x Fr scalars on BLS12-381, bases and scalars resident
+in HBM when the timed region starts; one step = one MSM of 2^20 pairs per GPU through the C ABI (mzk_msm_dev).  With N > 1 ranks
 the N*2^20 pairs are sharded by point range (one shard per GPU, weak scaling) and each step ends with the all-gather + local EC
 sum of the N partial points (mpc-jellyfish_amd/sharding.py).
 
-The headline runs on the library's default path for a registered SRS: a FIXED-BASE table of precomputed multiples (KZG commit
-keys never change).  `config.precompute` states what that table costs (levels, bytes of HBM, build time -- paid once per SRS,
-outside the timed region) and `variable_base` repeats the same steps with the table switched off, which is the like-for-like
-figure against ark-ec's VariableBaseMSM (and against `cpu_baseline`, which has no table either).
+`value`, `ms_per_step` and `roofline` are the VARIABLE-BASE path: plain Pippenger on the registered bases with nothing
+precomputed per base -- what configs[1] states, what ark-ec's VariableBaseMSM does and what `cpu_baseline` runs.  The library's
+default for a registered SRS (KZG commit keys never change) is a FIXED-BASE table of precomputed multiples; the same K steps on
+that path are the `fixed_base` object, with what the table costs (levels, bytes of HBM, build time -- paid once per SRS, outside
+its timed region) in `fixed_base.precompute`.
 
 Alongside, untimed by `value`: NTT 2^22 (configs[2]), round 3, batch commit, PlonkKzgSnark::prove on the reference's bench
 circuit (configs[3]; 10 timed repetitions as plonk/benches/bench.rs:25), the same proof in shim-only mode (host pointers,
@@ -18,6 +19,9 @@ of the same 2^20-gate circuit, so that the line itself carries the GPU/CPU ratio
 
     python bench.py [--gpus N --steps K --warmup W] [--log-n 20] [--no-cpu-baseline]
     python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+`--gpus N` with N > 1 and no launcher around it (WORLD_SIZE unset) starts its own N workers: this process touches no GPU, runs
+`python -m torch.distributed.run --nproc-per-node N bench.py ...` as a child, relays rank 0's line and exits with the child's code.
 
 Prints ONE JSON line on rank 0.
 """
@@ -37,24 +41,53 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import srchash  # noqa: E402  (tools/srchash.py: hash of the kernel sources a PMC pass was collected on)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r02_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r03_traffic.json")
 VOP3_NS = 1.9                  # measured cost of one VOP3 wave-instruction per SIMD (profiles/r01_valu_ubench2.txt); 1024 SIMDs
 
 
 def _pmc(key, sources):
-    """(value, note) of one figure of the committed PMC passes (profiles/r02_traffic.json, written by tools/pmc_passes.sh +
+    """(value, note) of one figure of the committed PMC passes (profiles/r03_traffic.json, written by tools/pmc_passes.sh +
     tools/pmc_aggregate.py: PMC counters cannot be read inside the timed run).  The file carries the hash of the kernel sources
     it was collected on; when those sources have changed since, the stale number is NOT quoted: None and a note saying so."""
     try:
         d = json.load(open(TRAFFIC_JSON))
     except Exception:
-        return None, "no committed PMC pass (profiles/r02_traffic.json missing)"
+        return None, "no committed PMC pass (profiles/r03_traffic.json missing)"
     name = "msm" if sources is srchash.MSM_SOURCES else "ntt"
     want = (d.get("source_sha16") or {}).get(name)
     have = srchash.sha16(sources)
     if want != have:
         return None, "PMC pass is stale: collected on %s sources %s, the tree has %s (re-run tools/pmc_passes.sh)" % (name, want, have)
     return d.get(key), "%s, collected on %s sources %s" % (os.path.basename(TRAFFIC_JSON), name, have)
+
+
+def self_launch(n_gpus):
+    """`python bench.py --gpus N` with no launcher around it: this process stays off the GPU (nothing below imports torch or the
+    library) and starts N FRESH worker processes -- `python -m torch.distributed.run --nnodes=1 --nproc-per-node N bench.py <same
+    arguments>`, one rank per GPU over RCCL -- as a child, relays their output (rank 0 prints the one JSON line) and returns the
+    child's exit code, non-zero if any worker failed.  A process that has initialised the GPU is never replaced by another."""
+    import socket
+    import subprocess
+    with socket.socket() as sk:                                       # a free rendezvous port on the loopback interface
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")                 # dmabuf IPC: what RCCL needs between the ranks of one node
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n_gpus), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.Popen(cmd, stdout=subprocess.PIPE, env=env, text=True)
+    lines = 0
+    for line in proc.stdout:                                          # stderr goes straight through; stdout is relayed line by line
+        if line.lstrip().startswith("{"):
+            lines += 1
+        sys.stdout.write(line)
+        sys.stdout.flush()
+    rc = proc.wait()
+    if rc == 0 and lines != 1:
+        print("bench.py: the workers printed %d JSON lines, expected 1" % lines, file=sys.stderr)
+        return 4
+    return rc
 
 
 def main():
@@ -69,7 +102,7 @@ def main():
                     "~60-70 s of CPU on 16 threads at 20 = the north star's configuration, ~4 s at 16)")
     ap.add_argument("--no-ntt", action="store_true")
     ap.add_argument("--no-plonk", action="store_true", help="skip the proof-level legs (round 3, prove, drop-in, UltraPlonk, C++ host)")
-    ap.add_argument("--no-variable-base", action="store_true", help="skip the table-off repetition of the headline steps")
+    ap.add_argument("--no-fixed-base", action="store_true", help="skip the fixed-base (precomputed table) repetition of the headline steps")
     ap.add_argument("--no-batch", action="store_true", help="skip the batch_commit5 leg (with the other --no-* switches the run is the headline's "
                     "launches alone: what the rocprofv3 --stats average of msm_accumulate_kernel is compared with)")
     ap.add_argument("--plonk-log-n", type=int, default=20)
@@ -82,6 +115,9 @@ def main():
     ap.add_argument("--ultra-sharded-log-n", type=int, default=22, help="N > 1: UltraPlonk/BN254 sharded prove leg (config C5: 22; 0 disables)")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args.gpus))                     # before torch or the library are even imported: no GPU call in this process
+
     import torch
     import torch.distributed as dist
 
@@ -89,7 +125,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node must equal --gpus")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (libmi355zk has no CPU fallback)")
     # rehearsal switches (not used by the driver): all ranks on GPU 0 with gloo collectives, to exercise the N > 1 code on a 1-GPU box
@@ -126,15 +162,8 @@ def main():
     scalars = mj.params.random_fr_mont(curve, n, seed=0x6d7a6b5f + rank)      # uniform in [0, r)
     d_scalars = torch.from_numpy(scalars.view(np.int64)).to(dev)
     torch.cuda.synchronize()
-    # the fixed-base table of this SRS, built explicitly (the library would otherwise build it inside the first MSM) and timed
-    pc_bits, pc_levels, pc_bytes, pc_ms = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_double()
-    mlib.check(L.mzk_srs_precompute(pp.handle, C.byref(pc_bits), C.byref(pc_levels), C.byref(pc_bytes), C.byref(pc_ms)), "mzk_srs_precompute")
-    precompute = {"window_bits": pc_bits.value, "levels": pc_levels.value, "table_bytes": pc_bytes.value, "build_ms": round(pc_ms.value, 2),
-                  "note": "fixed-base table table[w][i] = 2^(c*w) * P_i of the registered SRS, built once per SRS by pre_next_level_kernel "
-                          "OUTSIDE the timed region; `variable_base` is the same workload without it"}
-
-    if os.environ.get("MZK_BENCH_TABLE") == "0":      # tools/pmc_passes.sh only: PMC passes of the plain path (headline steps with the table off)
-        L.mzk_msm_set_precompute(0)
+    # the headline steps run with the fixed-base table OFF: nothing is precomputed per base (BASELINE configs[1], ark-ec's VariableBaseMSM)
+    L.mzk_msm_set_precompute(0)
 
     def step():
         jac = mj.msm_bigint(pp, d_scalars, scalars_are_mont=True)            # one Pippenger MSM, result on host
@@ -167,12 +196,15 @@ def main():
         tot_ms, tot_cnt = mlib.profile_get("msm_total")
         sort_ms, _ = mlib.profile_get("msm_sort")
         red_ms, _ = mlib.profile_get("msm_reduce")
+        comb_ms, _ = mlib.profile_get("msm_split_combine")
         phases = {"sort": round(sort_ms / max(tot_cnt, 1), 4), "accumulate": round(acc_ms / max(acc_cnt, 1), 4),
+                  "split_combine": round(comb_ms / max(tot_cnt, 1), 4),
                   "reduce": round(red_ms / max(tot_cnt, 1), 4), "device_total": round(tot_ms / max(tot_cnt, 1), 4)}
         return el, res, acc_ms / max(acc_cnt, 1), phases, mlib.msm_last_shape()
 
     elapsed, result, acc_avg_ms, phases, (c_bits, n_win, n_buckets) = timed_steps()
     alg_bytes = 128.0 * n                          # N * (2*|Fq| + 32) bytes per BLS12-381 MSM
+    table_off_only = os.environ.get("MZK_BENCH_TABLE") == "0"   # tools/pmc_passes.sh: PMC passes of the headline kernels alone
 
     def msm_roofline(acc_ms, windows, pmc_prefix):
         achieved = alg_bytes / (acc_ms * 1e-3) / 1e9
@@ -200,14 +232,16 @@ def main():
             "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": elapsed / args.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32 (381-bit Fq as 14 x 29-bit limbs, Montgomery)",
             "data": "synthetic",
-            "config": {"workload": f"standalone MSM, 2^{args.log_n} G1 x Fr pairs per GPU, BLS12-381 (BASELINE configs[1]); fixed-base table path "
-                                   "(see config.precompute; `variable_base` = table off)",
+            "config": {"workload": f"standalone MSM, 2^{args.log_n} G1 x Fr pairs per GPU, BLS12-381 (BASELINE configs[1]); VARIABLE-BASE path: plain "
+                                   "Pippenger over the registered bases, nothing precomputed per base (mzk_msm_set_precompute(0)) -- what "
+                                   "`VariableBaseMSM::msm_bigint` (univariate_kzg/mod.rs:109-111) is; `fixed_base` = the same steps on the "
+                                   "library's default path for a registered SRS",
                        "curve": "bls12-381", "pairs_per_gpu": n, "window_bits": c_bits, "windows": n_win,
                        "buckets_per_window": n_buckets, "sharding": "point-range" if world > 1 else "none",
-                       "srs_gen_s": round(t_srs, 3), "precompute": precompute},
-            "roofline": msm_roofline(acc_avg_ms, n_win, "msm_accumulate"),
+                       "srs_gen_s": round(t_srs, 3)},
+            "roofline": msm_roofline(acc_avg_ms, n_win, "msm_accumulate_plain"),
             "phases_ms": phases,
-            "cpu_baseline": None, "variable_base": None, "ntt": None, "plonk_round3": None, "batch_commit5": None, "prove": None,
+            "cpu_baseline": None, "fixed_base": None, "ntt": None, "plonk_round3": None, "batch_commit5": None, "prove": None,
             "prove_dropin": None, "prove_cpp_host": None, "prove_sharded": None, "prove_ultra_bn254": None, "link_and_batch": None,
         }
 
@@ -238,22 +272,28 @@ def main():
         watchdog.daemon = True
         watchdog.start()
 
-    # ---- secondary: the same K steps with the fixed-base table switched off (ark-ec's VariableBaseMSM is the like-for-like) -----
-    variable_base = None
-    if not args.no_variable_base:
-        L.mzk_msm_set_precompute(0)
-        try:
-            vb_el, vb_res, vb_acc, vb_phases, (vc, vw, vm) = timed_steps()
-        finally:
-            L.mzk_msm_set_precompute(1)
+    # ---- secondary: the same K steps on the library's default path for a registered SRS: a fixed-base table of precomputed multiples,
+    #      built here explicitly (the library would otherwise build it inside the first MSM) and timed -----
+    fixed_base = None
+    L.mzk_msm_set_precompute(1)
+    if not args.no_fixed_base and not table_off_only:
+        pc_bits, pc_levels, pc_bytes, pc_ms = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_double()
+        mlib.check(L.mzk_srs_precompute(pp.handle, C.byref(pc_bits), C.byref(pc_levels), C.byref(pc_bytes), C.byref(pc_ms)), "mzk_srs_precompute")
+        precompute = {"window_bits": pc_bits.value, "levels": pc_levels.value, "table_bytes": pc_bytes.value, "build_ms": round(pc_ms.value, 2),
+                      "note": "fixed-base table table[w][i] = 2^(c*w) * P_i of the registered SRS, built once per SRS by pre_next_level_kernel "
+                              "OUTSIDE the timed region of this leg"}
+        fb_el, fb_res, fb_acc, fb_phases, (fc, fw, fm) = timed_steps()
         if rank == 0:
-            variable_base = {"what": "the headline's steps with mzk_msm_set_precompute(0): plain Pippenger, every window on its own bucket set, "
-                                     "no per-SRS set-up -- what `VariableBaseMSM::msm_bigint` (univariate_kzg/mod.rs:109-111) is",
-                             "value": world * n * args.steps / vb_el, "unit": "pairs/s", "ms_per_step": vb_el / args.steps * 1e3,
-                             "window_bits": vc, "windows": vw, "buckets_per_window": vm, "phases_ms": vb_phases,
-                             "same_point_as_table_path": bool(np.array_equal(mj.kzg.jacobian_to_affine(curve, np.asarray(vb_res).reshape(1, -1)),
+            fixed_base = {"what": "the headline's steps with mzk_msm_set_precompute(1), the library default: the digits of all windows index rows of "
+                                  "the table and share ONE bucket set.  Legitimate for KZG (the commit key never changes, srs.rs:77-93) and what "
+                                  "`prove` below runs on, but a set-up ark-ec's VariableBaseMSM does not have: not `value`",
+                          "value": world * n * args.steps / fb_el, "unit": "pairs/s", "ms_per_step": fb_el / args.steps * 1e3,
+                          "window_bits": fc, "windows": fw, "buckets_per_window": fm, "phases_ms": fb_phases, "precompute": precompute,
+                          "same_point_as_variable_base": bool(np.array_equal(mj.kzg.jacobian_to_affine(curve, np.asarray(fb_res).reshape(1, -1)),
                                                                              mj.kzg.jacobian_to_affine(curve, np.asarray(result).reshape(1, -1)))),
-                             "roofline": msm_roofline(vb_acc, vw, "msm_accumulate_plain")}
+                          "roofline": msm_roofline(fb_acc, fw, "msm_accumulate")}
+    if table_off_only:
+        L.mzk_msm_set_precompute(0)
 
     # ---- secondary: batch_commit of 5 polynomials (round 1 / round 3 of a proof) in one fused call -----
     batch = None
@@ -394,6 +434,31 @@ def main():
         torch.cuda.synchronize()
         prove_ms = (time.perf_counter() - t1) / reps * 1e3
         core, proof_bytes = mj.snark.prove(rng, cs, prover, profile=True)
+
+        def timed_proofs(circuit, k):
+            for _ in range(2):
+                mj.snark.prove(rng, circuit, prover)
+            torch.cuda.synchronize()
+            ta = time.perf_counter()
+            for _ in range(k):
+                mj.snark.prove(rng, circuit, prover)
+            torch.cuda.synchronize()
+            return (time.perf_counter() - ta) / k * 1e3
+        # (i) the witness starts in page-locked HOST memory, as the reference holds it (constraint_system.rs:1225-1247 gathers it on the
+        # host): every proof uploads its 5 x n x 32 B, wire k + 1 under the iNTT of wire k (prover.py _stage_round1)
+        import dataclasses
+        host_cs = dataclasses.replace(cs, wire_values=cs.wire_values.cpu().pin_memory())
+        host_ms = timed_proofs(host_cs, reps)
+        host_bytes_same = bool(mj.snark.prove(mj.rng.test_rng(), host_cs, prover)[1] == mj.snark.prove(mj.rng.test_rng(), cs, prover)[1])
+        del host_cs
+        # (ii) the same gates with a DENSE witness: the bench circuit's wires are 0, 1, 2.. / ones / zeros / zeros / 1, 2, 3..
+        dense_cs = mj.snark.gen_circuit_for_bench(curve, pn, "TurboPlonk", dense_seed=77)
+        prover.release()
+        prover = mj.snark.preprocess(ck, dense_cs)                  # same selectors, another wire permutation
+        prover.vk_commitments()
+        dense_ms = timed_proofs(dense_cs, reps)
+        dense_core, _ = mj.snark.prove(rng, dense_cs, prover, profile=True)
+        del dense_cs
         prove = {"what": "PlonkKzgSnark::prove of one TurboPlonk proof on the reference's bench circuit (bench.rs:29-46: a = a + 1, "
                          "gates - 10 times): 7 iNTT(n), grand product, coset NTTs, quotient, 13 MSM, evaluations, linearisation, "
                          "openings, ChaCha test_rng blinders, Merlin transcript, compressed proof bytes; proving key resident; "
@@ -401,6 +466,12 @@ def main():
                  "log_n": pl, "prove_ms": round(prove_ms, 2), "reps": reps, "min_ms": round(min(each), 2), "median_ms": round(sorted(each)[len(each) // 2], 2),
                  "max_ms": round(max(each), 2),
                  "ns_per_gate": round(prove_ms * 1e6 / pn, 1), "rounds_ms": core.timings_ms, "proof_bytes": len(proof_bytes),
+                 "from_host_witness_ms": round(host_ms, 2), "from_host_witness_same_proof_bytes": host_bytes_same,
+                 "from_host_witness_note": "`prove_ms` has the 5 x n wire values already in HBM; here they start in page-locked host memory "
+                                           "(%.0f MB per proof over PCIe, wire k + 1 uploaded under the iNTT of wire k)" % (5 * pn * 32 / 1e6),
+                 "dense_witness_ms": round(dense_ms, 2), "dense_witness_rounds_ms": dense_core.timings_ms,
+                 "dense_witness_note": "same gates (selectors), random satisfying witness: all five wire polynomials dense (the bench circuit "
+                                       "commits two zero and two sparse wire polynomials in round 1)",
                  "circuit_build_s": round(t_circ, 3), "preprocess_s": round(t_pre, 3),
                  "reference_published": "29591 ns/gate at 2^15 gates, 24 threads of a 5900X (bench.md:16); not comparable hardware"}
         prover.release()
@@ -641,9 +712,9 @@ def main():
         cpu = {"value": n / cpu_s, "unit": "pairs/s", "cores": threads, "kind": "port",
                "sample": f"one full 2^{args.log_n}-pair MSM (same bases and scalars as the GPU step), oracle/cpu_ref.c "
                          f"Pippenger with the ark-ec window rule, {threads} threads; restatement of ark-ec's VariableBaseMSM, not the Rust binary "
-                         "(compare with `variable_base`, which has no fixed-base table either)",
+                         "(like for like with `value`: neither has a fixed-base table)",
                "seconds": round(cpu_s, 3), "matches_gpu": bool(same),
-               "gpu_variable_base_over_cpu": round(variable_base["value"] / (n / cpu_s), 1) if variable_base else None,
+               "gpu_over_cpu": round(out["value"] / (n / cpu_s), 1),
                "prove_c1": c1,
                ("prove_2p%d" % args.cpu_prove_log_n): big,
                "ntt_2^22": {"ms": round(ntt_cpu_s * 1e3, 1), "cores": threads, "matches_gpu": ntt_same,
@@ -652,7 +723,7 @@ def main():
     if watchdog is not None:
         watchdog.cancel()
     if rank == 0:
-        out.update({"cpu_baseline": cpu, "variable_base": variable_base, "ntt": ntt, "plonk_round3": plonk, "batch_commit5": batch, "prove": prove,
+        out.update({"cpu_baseline": cpu, "fixed_base": fixed_base, "ntt": ntt, "plonk_round3": plonk, "batch_commit5": batch, "prove": prove,
                     "prove_dropin": dropin, "prove_cpp_host": prove_cpp, "prove_sharded": prove_sharded, "prove_ultra_bn254": ultra,
                     "link_and_batch": link_batch})
         emit()

@@ -15,10 +15,10 @@
  *   return value    0 on success, < 0 on error (mzk_strerror); never unwinds, never aborts.
  *   threading       every entry point may be called concurrently (the reference calls commit and
  *                   fft from Rayon workers: univariate_kzg/mod.rs:125-127, prover.rs:552-562);
- *                   the kernels of all calls are enqueued under one internal lock (shared plan cache
- *                   and workspace), but the host-pointer entry points move their operands on
+ *                   the kernels of all calls ON ONE DEVICE are enqueued under that device's lock (its
+ *                   plan cache and workspace), but the host-pointer entry points move their operands on
  *                   per-call I/O streams outside it, so one caller's transfers overlap another's
- *                   kernels (see mzk_host_alloc).
+ *                   kernels (see mzk_host_alloc).  Calls on different devices never contend (mzk_init).
  *   memory          host buffers are borrowed for the duration of the call; the library owns all
  *                   device memory it allocates, including the registered SRS copy.
  *   "_dev" variants take device pointers (hipMalloc / torch tensors) and a hipStream_t passed as
@@ -52,9 +52,26 @@ extern "C" {
 #define MZK_CURVE_BLS12_381 0
 #define MZK_CURVE_BN254 1
 
-/* Bind the library to HIP device `device` (idempotent; -1 = current device).  Fails with
- * MZK_ERR_NO_DEVICE when no GPU is visible: there is no CPU fallback. */
+/* Create the library's context on HIP device `device` if it has none yet and bind the CALLING THREAD to it (idempotent;
+ * -1 = the thread's / the process's current binding, else the current HIP device).  Fails with MZK_ERR_NO_DEVICE when no GPU
+ * is visible: there is no CPU fallback.
+ *
+ * Several devices from one process (`mzk_init(n_devices)`, "copies to device(s) once"; 8(e)): call
+ * mzk_init(g) for every device g, one host thread per device.  Each device has its own context -- lock, workspace, NTT plan
+ * cache, I/O slots, SRS and proving-key registries -- so calls on different devices run concurrently and share nothing.
+ * SRS and proving-key handles carry their device: a call that takes one runs on that device whatever thread makes it.  Calls
+ * that take bare device pointers (mzk_ntt_dev, mzk_poly_*, mzk_dev_*, the register functions) run on the calling thread's
+ * device: the last mzk_init / mzk_set_device on that thread, or -- for threads that never bound one, e.g. the Rayon workers of a
+ * single-GPU prover -- the first device initialised.  Device memory belongs to the device it was allocated on; between devices
+ * it moves with mzk_dev_copy_peer.
+ * MZK_VIRTUAL_DEVICES=G (environment, read at mzk_init): devices 0..G-1 exist whatever the machine has, mapped round-robin onto
+ * the physical GPUs -- G full contexts on one card, to rehearse a multi-GPU host on a one-GPU box (results are identical). */
 MZK_API int32_t mzk_init(int32_t device);
+/* Rebind the calling thread to an initialised device / report its binding / number of devices mzk_init accepts. */
+MZK_API int32_t mzk_set_device(int32_t device);
+MZK_API int32_t mzk_get_device(int32_t* out_device);
+MZK_API int32_t mzk_device_count(int32_t* out_count);
+/* Releases every context (all devices). */
 MZK_API int32_t mzk_shutdown(void);
 MZK_API const char* mzk_strerror(int32_t code);
 MZK_API const char* mzk_last_error(void);
@@ -274,6 +291,11 @@ MZK_API int32_t mzk_dev_sync(void);
 /* device-to-device copy, 2-D copy (pitches and width in bytes) and byte fill, asynchronous on `stream`: what a host
  * orchestrating device-resident rounds needs between kernels (mpc-jellyfish_amd/host/mzk_host.hpp). */
 MZK_API int32_t mzk_dev_copy(void* dst, const void* src, uint64_t bytes, void* stream);
+/* bytes from device `src_device` to device `dst_device` (logical indices, both initialised), asynchronous on `stream`, a stream of
+ * the SOURCE device (NULL = its null stream): hipMemcpyPeerAsync -- over xGMI when the devices can access each other, which
+ * mzk_init enables -- or a plain device-to-device copy when both are virtual devices of one card.  The one exchange of a
+ * multi-GPU proof (class remainders of the quotient) goes through here. */
+MZK_API int32_t mzk_dev_copy_peer(void* dst, int32_t dst_device, const void* src, int32_t src_device, uint64_t bytes, void* stream);
 MZK_API int32_t mzk_dev_copy2d(void* dst, uint64_t dst_pitch, const void* src, uint64_t src_pitch, uint64_t width, uint64_t height, void* stream);
 MZK_API int32_t mzk_dev_memset(void* dptr, int32_t value, uint64_t bytes, void* stream);
 

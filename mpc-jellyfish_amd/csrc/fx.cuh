@@ -78,8 +78,10 @@ MZK_HD Fx<X> fx_mul(const Fx<X>& x, const Fx<X>& y) {
 // (x*y + u*v)/R' mod p with ONE Montgomery reduction: 3 N^2 multiply-adds instead of the 4 N^2 of two products (the m*p half is
 // shared), and the sum needs no pad, subtraction or normalisation.  Column sums must stay below 2^64: with N <= 14,
 //   14 * max|x_i y_j| + 14 * max|u_i v_j| + 14 * 2^58 < 2^64,
-// e.g. x, y, u weakly normalised (< 2^29 + 2^27) and v < 2^30 (a negated class-M value, fx_neg_m): 14 (1.57 + 2.5 + 1) 2^58 < 2^64 -- or
-// x, y, u in N (< 2^29 + 8) and v < 2^30: 56 * 2^58.  Value bound: result < p (A B + C D) / 2^HEADROOM + p.
+// which at N = 14 (BLS12-381 Fq) holds for x, y, u of class N / M (limbs < 2^29 + 8) and v < 2^30 (a negated class-M value,
+// fx_neg_m): 14 (1 + 2 + 1) 2^58 = 56 * 2^58 -- what ecx.cuh passes.  It does NOT hold for merely weakly normalised x, y, u
+// (< 2^29 + 2^27): 14 (1.57 + 2.5 + 1) 2^58 = 70.9 * 2^58 > 2^64; normalise such operands first (fx_norm).
+// Value bound: result < p (A B + C D) / 2^HEADROOM + p.
 template <class X>
 MZK_HD Fx<X> fx_mul2(const Fx<X>& x, const Fx<X>& y, const Fx<X>& u, const Fx<X>& v) {
     constexpr int N = X::XN;

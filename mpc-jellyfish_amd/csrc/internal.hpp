@@ -2,8 +2,11 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <condition_variable>
 #include <cstdint>
 #include <cstring>
+#include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -44,16 +47,10 @@ struct Workspace {
     hipEvent_t last_use = nullptr;
     void release();
 };
-extern Workspace g_ws;
 
-// a call on `st` must not start before the previous user of the shared workspace is done
-int32_t ws_acquire(hipStream_t st);
-int32_t ws_release(hipStream_t st);
-
-// HIP-event timing of named regions (mzk_profile_*)
+// HIP-event timing of named regions (mzk_profile_*): one switch for the library, records per device context
 extern bool g_prof;
 struct ProfRec { std::string name; hipEvent_t a, b; };
-extern std::vector<ProfRec> g_prof_recs;
 struct ProfScope {
     hipEvent_t a = nullptr, b = nullptr;
     hipStream_t st;
@@ -75,6 +72,42 @@ struct Srs {
     double pre_build_ms = 0;    // wall time of the build (pre_next_level launches, synchronised)
 };
 inline int fq_words(int curve) { return curve == MZK_CURVE_BLS12_381 ? 12 : 8; }
+
+// ---- device contexts ---------------------------------------------------------------------------------
+// One context per LOGICAL device: the HIP device it runs on, its lock, workspace, I/O slots, SRS registry; the NTT plan cache,
+// the MSM sort streams and the proving keys are kept per context by their translation units (arrays indexed by Ctx::logical).
+// A process may drive several devices, one host thread each (mzk_init(device) binds the calling thread; mzk_set_device rebinds
+// it): calls on different contexts share nothing and run concurrently.  SRS / proving-key handles carry their context in the
+// top 16 bits, so a handle-taking entry point needs no current device; entry points that take bare device pointers run on the
+// calling thread's context (threads that never bound one use the first context initialised: the single-GPU case, Rayon workers
+// included).  MZK_VIRTUAL_DEVICES=G maps logical devices 0..G-1 onto the physical ones round-robin -- G contexts on ONE card
+// rehearse the multi-GPU code paths of a compiled host (mpc-jellyfish_amd/host/) on a one-GPU box.
+constexpr int MAX_CTX = 16;
+constexpr int IO_SLOTS = 4;
+struct IoSlot {
+    hipStream_t st = nullptr;
+    DevBuf buf;
+    bool busy = false;
+};
+struct Ctx {
+    int logical = -1, device = -1;
+    bool init = false;
+    std::mutex lock;
+    Workspace ws;
+    std::vector<ProfRec> prof_recs;
+    std::map<uint64_t, Srs> srs;
+    uint64_t next_handle = 1;
+    IoSlot io[IO_SLOTS];
+    std::mutex io_lock;
+    std::condition_variable io_cv;
+};
+Ctx& cur();                                       // the context the running entry point is bound to (thread-local)
+#define g_ws (::mzk::cur().ws)
+// a call on `st` must not start before the previous user of the context's shared workspace is done
+int32_t ws_acquire(hipStream_t st);
+int32_t ws_release(hipStream_t st);
+inline uint64_t handle_make(int logical, uint64_t counter) { return ((uint64_t)(logical + 1) << 48) | counter; }
+inline int handle_ctx(uint64_t h) { return (int)(h >> 48) - 1; }
 
 // ntt.hip
 // scale: 0 = boundary form in and out; 1 = output left in the internal form x * R' (R' = 2^261 = 32 R) of the quotient kernels;

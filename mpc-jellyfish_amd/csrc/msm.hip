@@ -57,18 +57,21 @@ struct PreInfo { int c = 0; uint64_t tab_stride = 0; };      // c == 0: plain pa
 
 // A batch of MSMs sorts on a second stream: the sort of MSM p + 1 (memory- and LDS-bound, few registers) runs under the
 // accumulation of MSM p (VALU-bound at two waves per SIMD, which leaves register file and LDS for it).  SORT_SETS sets of sort buffers.
-hipStream_t g_sort_stream = nullptr;
 constexpr int SORT_SETS = 3;                                       // sorts run up to two MSMs ahead of the accumulation
-hipEvent_t g_ev_start = nullptr, g_ev_sorted[SORT_SETS] = {}, g_ev_acc[SORT_SETS] = {};
-int32_t sort_stream_init() {
-    if (g_sort_stream) return MZK_OK;
+struct SortStreams {                                               // one set per device context
+    hipStream_t stream = nullptr;
+    hipEvent_t ev_start = nullptr, ev_sorted[SORT_SETS] = {}, ev_acc[SORT_SETS] = {};
+};
+SortStreams g_sort[MAX_CTX];
+int32_t sort_stream_init(SortStreams& ss) {
+    if (ss.stream) return MZK_OK;
     int prio_least = 0, prio_greatest = 0;                               // the short sort kernels go first whenever a slot frees up
     HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    HIP_TRY(hipStreamCreateWithPriority(&g_sort_stream, hipStreamNonBlocking, std::getenv("MZK_MSM_SORT_PRIO_LOW") ? prio_least : prio_greatest));
-    HIP_TRY(hipEventCreateWithFlags(&g_ev_start, hipEventDisableTiming));
+    HIP_TRY(hipStreamCreateWithPriority(&ss.stream, hipStreamNonBlocking, std::getenv("MZK_MSM_SORT_PRIO_LOW") ? prio_least : prio_greatest));
+    HIP_TRY(hipEventCreateWithFlags(&ss.ev_start, hipEventDisableTiming));
     for (int i = 0; i < SORT_SETS; i++) {
-        HIP_TRY(hipEventCreateWithFlags(&g_ev_sorted[i], hipEventDisableTiming));
-        HIP_TRY(hipEventCreateWithFlags(&g_ev_acc[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ss.ev_sorted[i], hipEventDisableTiming));
+        HIP_TRY(hipEventCreateWithFlags(&ss.ev_acc[i], hipEventDisableTiming));
     }
     return MZK_OK;
 }
@@ -144,11 +147,12 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     LongDesc* desc = g_ws.long_desc.as<LongDesc>();
     uint32_t* parts = g_ws.long_parts.as<uint32_t>();
     hipStream_t sst = st;                                                // the stream the sorts run on
+    SortStreams& ss = g_sort[cur().logical];
     if (overlap) {
-        MZK_TRY(sort_stream_init());
-        sst = g_sort_stream;
-        HIP_TRY(hipEventRecord(g_ev_start, st));                         // scalars and workspace are ready on st
-        HIP_TRY(hipStreamWaitEvent(sst, g_ev_start, 0));
+        MZK_TRY(sort_stream_init(ss));
+        sst = ss.stream;
+        HIP_TRY(hipEventRecord(ss.ev_start, st));                        // scalars and workspace are ready on st
+        HIP_TRY(hipStreamWaitEvent(sst, ss.ev_start, 0));
     }
     {
         ProfScope total("msm_total", st);
@@ -190,7 +194,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
             uint32_t* desc_count = reinterpret_cast<uint32_t*>(desc + (size_t)n_win * desc_cap);
             const unsigned long long dstride = (n + 7) & ~7ull;
             const unsigned gs = (unsigned)((n + MSM_THREADS - 1) / MSM_THREADS);
-            if (overlap && (size_t)p >= nb) HIP_TRY(hipStreamWaitEvent(sst, g_ev_acc[b], 0));     // MSM p - nb has read this set
+            if (overlap && (size_t)p >= nb) HIP_TRY(hipStreamWaitEvent(sst, ss.ev_acc[b], 0));     // MSM p - nb has read this set
             if (!pre.c) {
                 ProfScope ps("msm_sort", sst);
                 uint16_t* digits = reinterpret_cast<uint16_t*>(g_ws.digits.as<char>() + b * digits_bytes);
@@ -227,11 +231,10 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(slices, n_win), dim3(1024), 0, sst, hist, M, keycnt, order);
             }
             if (overlap) {
-                HIP_TRY(hipEventRecord(g_ev_sorted[b], sst));
-                HIP_TRY(hipStreamWaitEvent(st, g_ev_sorted[b], 0));
+                HIP_TRY(hipEventRecord(ss.ev_sorted[b], sst));
+                HIP_TRY(hipStreamWaitEvent(st, ss.ev_sorted[b], 0));
             }
             {
-                ProfScope ps("msm_accumulate", st);
                 // latency-bound sizes: split every bucket over 2^log_split threads (msm.cuh), aiming at chains of ~4 adds
                 // -- as long as the grid stays below what fills the chip (2^18 threads); beyond that only while the (S - 1) M extra
                 // additions stay under ~5 % of the work (S - 1 <= mean / 32)
@@ -245,14 +248,19 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                     log_split = nx;
                 }
                 if (log_split == 0) {
+                    ProfScope ps("msm_accumulate", st);
                     hipLaunchKernelGGL((msm_accumulate_kernel<EC>), dim3((unsigned)((wm + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
                                        d_bases, n_sorted, offs, hist, sorted, order, M, n_win, cap, desc_count, buckets);
                 } else {
                     const size_t threads = wm << log_split;
                     MZK_TRY(g_ws.split.reserve(threads * EC::PT_WORDS * 4));
                     uint32_t* sub = g_ws.split.as<uint32_t>();
-                    hipLaunchKernelGGL((msm_accumulate_split_kernel<EC>), dim3((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS),
-                                       0, st, d_bases, n_sorted, offs, hist, sorted, order, M, n_win, cap, log_split, desc_count, sub);
+                    {
+                        ProfScope ps("msm_accumulate", st);               // the dominant launch alone: what rocprofv3 --stats averages
+                        hipLaunchKernelGGL((msm_accumulate_split_kernel<EC>), dim3((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)),
+                                           dim3(MSM_ACC_THREADS), 0, st, d_bases, n_sorted, offs, hist, sorted, order, M, n_win, cap, log_split, desc_count, sub);
+                    }
+                    ProfScope pc("msm_split_combine", st);
                     hipLaunchKernelGGL((msm_split_combine_kernel<EC>), dim3((unsigned)((threads + 2 * MSM_ACC_THREADS - 1) / (2 * MSM_ACC_THREADS))), dim3(MSM_ACC_THREADS),
                                        0, st, sub, (unsigned long long)wm, log_split, buckets);
                 }
@@ -265,7 +273,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                                    d_bases, n_sorted, sorted, desc, desc_count, desc_cap, parts);
                 hipLaunchKernelGGL((msm_long_combine_kernel<EC>), dim3(n_win), dim3(1024), 0, st, desc, desc_count, desc_cap, M, parts, buckets);
             }
-            if (overlap) HIP_TRY(hipEventRecord(g_ev_acc[b], st));
+            if (overlap) HIP_TRY(hipEventRecord(ss.ev_acc[b], st));
         }
         {
             ProfScope ps("msm_reduce", st);
@@ -527,11 +535,12 @@ void jac_to_affine_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uin
 }
 
 void msm_release_streams() {
-    if (!g_sort_stream) return;
-    (void)hipStreamDestroy(g_sort_stream);
-    g_sort_stream = nullptr;
-    (void)hipEventDestroy(g_ev_start);
-    for (int i = 0; i < SORT_SETS; i++) { (void)hipEventDestroy(g_ev_sorted[i]); (void)hipEventDestroy(g_ev_acc[i]); }
+    SortStreams& ss = g_sort[cur().logical];
+    if (!ss.stream) return;
+    (void)hipStreamDestroy(ss.stream);
+    (void)hipEventDestroy(ss.ev_start);
+    for (int i = 0; i < SORT_SETS; i++) { (void)hipEventDestroy(ss.ev_sorted[i]); (void)hipEventDestroy(ss.ev_acc[i]); }
+    ss = SortStreams();
 }
 
 }  // namespace mzk

@@ -1,6 +1,8 @@
-// mzk.hip -- libmi355zk: the C ABI (include/mzk.h) and the state shared by ntt.hip / msm.hip.
-// One process drives one GPU; entry points are serialised on a lock and enqueue on one stream.
+// mzk.hip -- libmi355zk: the C ABI (include/mzk.h) and the state shared by ntt.hip / msm.hip / plonk.hip / poly.hip.
+// One context per (logical) device; an entry point binds the calling thread to the context of its handle -- or, for calls on
+// bare device pointers, to the thread's current device -- and enqueues under that context's lock (internal.hpp).
 #include <condition_variable>
+#include <cstdlib>
 #include <map>
 #include <mutex>
 #include <vector>
@@ -11,8 +13,10 @@ namespace mzk {
 
 thread_local std::string g_last_error;
 std::string g_last_error_global;
+std::mutex g_last_error_lock;                 // the process-wide copy is written by any failing thread (the thread-local one needs no lock)
 void set_error(const std::string& s) {
     g_last_error = s;
+    std::lock_guard<std::mutex> g(g_last_error_lock);
     g_last_error_global = s;
 }
 
@@ -38,7 +42,6 @@ void Workspace::release() {
     if (last_use) (void)hipEventDestroy(last_use);
     last_use = nullptr;
 }
-Workspace g_ws;
 
 int32_t ws_acquire(hipStream_t st) {
     if (!g_ws.last_use) HIP_TRY(hipEventCreateWithFlags(&g_ws.last_use, hipEventDisableTiming));
@@ -51,7 +54,6 @@ int32_t ws_release(hipStream_t st) {
 }
 
 bool g_prof = false;
-std::vector<ProfRec> g_prof_recs;
 ProfScope::ProfScope(const char* n, hipStream_t s) : st(s), name(n) {
     if (!g_prof) return;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
@@ -60,9 +62,17 @@ ProfScope::ProfScope(const char* n, hipStream_t s) : st(s), name(n) {
 ProfScope::~ProfScope() {
     if (!a) return;
     (void)hipEventRecord(b, st);
-    g_prof_recs.push_back({name, a, b});
+    cur().prof_recs.push_back({name, a, b});
 }
 uint32_t g_last_c = 0, g_last_w = 0, g_last_m = 0;
+
+// ---- contexts ------------------------------------------------------------------------------------------
+Ctx g_ctx[MAX_CTX];
+std::mutex g_ctx_lock;                        // guards `init` / `device` of the table and g_default
+int g_default = -1;                           // first context initialised: what threads without a binding of their own use
+thread_local int t_dev = -1;                  // logical device this thread is bound to (mzk_init / mzk_set_device)
+thread_local Ctx* t_ctx = nullptr;            // context of the entry point now running on this thread
+Ctx& cur() { return *t_ctx; }
 
 }  // namespace mzk
 
@@ -70,57 +80,74 @@ using namespace mzk;
 
 namespace {
 
-std::mutex g_lock;
-bool g_init = false;
-int g_device = -1;
-std::map<uint64_t, Srs> g_srs;
-uint64_t g_next_handle = 1;
-
-int32_t require_init() {
-    if (!g_init) { set_error("mzk_init has not been called"); return MZK_ERR_NOT_INIT; }
-    HIP_TRY(hipSetDevice(g_device));
-    return MZK_OK;
+Ctx* ctx_for_thread() {
+    const int d = t_dev >= 0 ? t_dev : g_default;
+    if (d < 0 || !g_ctx[d].init) { set_error("mzk_init has not been called"); return nullptr; }
+    return &g_ctx[d];
 }
+Ctx* ctx_for_handle(uint64_t h) {
+    const int d = handle_ctx(h);
+    if (d < 0 || d >= MAX_CTX || !g_ctx[d].init) { set_error("unknown handle"); return nullptr; }
+    return &g_ctx[d];
+}
+// binds the calling thread to a context for the duration of an entry point (nested entry points restore the outer one)
+struct CtxBind {
+    Ctx* prev;
+    int32_t rc = MZK_OK;
+    explicit CtxBind(Ctx* c) : prev(t_ctx) {
+        t_ctx = c;
+        const hipError_t e = hipSetDevice(c->device);
+        if (e != hipSuccess) { set_error(std::string("hipSetDevice: ") + hipGetErrorString(e)); rc = MZK_ERR_HIP; }
+    }
+    ~CtxBind() { t_ctx = prev; }
+};
+#define BIND_CUR()                               \
+    Ctx* cx_ = ctx_for_thread();                 \
+    if (!cx_) return MZK_ERR_NOT_INIT;           \
+    CtxBind bind_(cx_);                          \
+    MZK_TRY(bind_.rc)
+#define BIND_HANDLE(h)                           \
+    Ctx* cx_ = ctx_for_handle(h);                \
+    if (!cx_) return MZK_ERR_BAD_HANDLE;         \
+    CtxBind bind_(cx_);                          \
+    MZK_TRY(bind_.rc)
+#define ENTER_CUR() \
+    BIND_CUR();     \
+    std::lock_guard<std::mutex> lk(cx_->lock)
+#define ENTER_HANDLE(h) \
+    BIND_HANDLE(h);     \
+    std::lock_guard<std::mutex> lk(cx_->lock)
 
 // ---- host-pointer I/O slots ------------------------------------------------------------------------
 // The host-pointer entry points (mzk_ntt, mzk_ntt_batch, mzk_msm, mzk_msm_batch: what a shim that swaps only the two
 // third-party call sites uses) move their operands over PCIe.  Each call -- or each polynomial of a
-// batch -- takes one of IO_SLOTS slots: a non-blocking stream plus a device buffer.  Upload, kernels and download of one
-// polynomial are enqueued on its slot's stream; the global lock is held only while the kernels are ENQUEUED (plan cache and
+// batch -- takes one of the context's IO_SLOTS slots: a non-blocking stream plus a device buffer.  Upload, kernels and download of
+// one polynomial are enqueued on its slot's stream; the context's lock is held only while the kernels are ENQUEUED (plan cache and
 // shared workspace; ws_acquire / ws_release order the kernels of different streams on the shared scratch), never across a
 // transfer or a wait.  So the upload of polynomial k+1 and the download of k-1 overlap the transform of k -- inside one batch
 // call and between concurrent callers (the reference commits and transforms from a Rayon par_iter, prover.rs:552-562,
 // univariate_kzg/mod.rs:125-127).  Transfers are asynchronous when the host memory is page-locked (mzk_host_alloc /
 // mzk_host_register); from pageable memory the runtime stages them and the enqueue blocks, which is still correct.
-constexpr int IO_SLOTS = 4;
-struct IoSlot {
-    hipStream_t st = nullptr;
-    DevBuf buf;
-    bool busy = false;
-};
-IoSlot g_io[IO_SLOTS];
-std::mutex g_io_lock;
-std::condition_variable g_io_cv;
 
 // block: wait for a free slot; !block: take one only if one is free right now (a caller that already holds a slot must never wait
 // for another: two batch calls doing so would deadlock), *out_idx = -1 otherwise
-int32_t io_acquire(int* out_idx, bool block = true) {
-    std::unique_lock<std::mutex> lk(g_io_lock);
+int32_t io_acquire(Ctx& cx, int* out_idx, bool block = true) {
+    std::unique_lock<std::mutex> lk(cx.io_lock);
     int idx = -1;
     auto find = [&] {
         for (int i = 0; i < IO_SLOTS; i++)
-            if (!g_io[i].busy) { idx = i; return true; }
+            if (!cx.io[i].busy) { idx = i; return true; }
         return false;
     };
-    if (block) g_io_cv.wait(lk, find);
+    if (block) cx.io_cv.wait(lk, find);
     else if (!find()) { *out_idx = -1; return MZK_OK; }
-    g_io[idx].busy = true;
+    cx.io[idx].busy = true;
     lk.unlock();
-    if (!g_io[idx].st) {
-        hipError_t e = hipStreamCreateWithFlags(&g_io[idx].st, hipStreamNonBlocking);
+    if (!cx.io[idx].st) {
+        hipError_t e = hipStreamCreateWithFlags(&cx.io[idx].st, hipStreamNonBlocking);
         if (e != hipSuccess) {
-            { std::lock_guard<std::mutex> g(g_io_lock); g_io[idx].busy = false; }
-            g_io_cv.notify_one();
+            { std::lock_guard<std::mutex> g(cx.io_lock); cx.io[idx].busy = false; }
+            cx.io_cv.notify_one();
             set_error(std::string("hipStreamCreate: ") + hipGetErrorString(e));
             return MZK_ERR_HIP;
         }
@@ -128,20 +155,28 @@ int32_t io_acquire(int* out_idx, bool block = true) {
     *out_idx = idx;
     return MZK_OK;
 }
-void io_release(int idx) {
-    { std::lock_guard<std::mutex> g(g_io_lock); g_io[idx].busy = false; }
-    g_io_cv.notify_one();
+void io_release(Ctx& cx, int idx) {
+    { std::lock_guard<std::mutex> g(cx.io_lock); cx.io[idx].busy = false; }
+    cx.io_cv.notify_one();
 }
 struct IoGuard {                      // releases the slot on every return path
+    Ctx* cx = nullptr;
     int idx = -1;
-    ~IoGuard() { if (idx >= 0) io_release(idx); }
+    ~IoGuard() { if (idx >= 0) io_release(*cx, idx); }
 };
-void io_release_all() {
-    for (auto& sl : g_io) {
+void io_release_all(Ctx& cx) {
+    for (auto& sl : cx.io) {
         if (sl.st) { (void)hipStreamSynchronize(sl.st); (void)hipStreamDestroy(sl.st); sl.st = nullptr; }
         sl.buf.release();
         sl.busy = false;
     }
+}
+
+// logical -> physical device.  MZK_VIRTUAL_DEVICES=G: logical devices 0..G-1 exist whatever the box has, spread round-robin
+int virtual_devices() {
+    const char* v = std::getenv("MZK_VIRTUAL_DEVICES");
+    const int g = v ? std::atoi(v) : 0;
+    return g > 0 ? (g < MAX_CTX ? g : MAX_CTX) : 0;
 }
 
 }  // namespace
@@ -150,42 +185,89 @@ void io_release_all() {
 extern "C" {
 
 int32_t mzk_init(int32_t device) {
-    std::lock_guard<std::mutex> lk(g_lock);
+    std::lock_guard<std::mutex> lk(g_ctx_lock);
     int count = 0;
     hipError_t e = hipGetDeviceCount(&count);
     if (e != hipSuccess || count == 0) {
         set_error("no HIP device visible (libmi355zk has no CPU fallback)");
         return MZK_ERR_NO_DEVICE;
     }
+    const int virt = virtual_devices();
     if (device < 0) {
-        if (g_init) return MZK_OK;
-        int cur = 0;
-        HIP_TRY(hipGetDevice(&cur));
-        device = cur;
+        if (t_dev >= 0 || g_default >= 0) return MZK_OK;     // already bound: idempotent
+        int curdev = 0;
+        HIP_TRY(hipGetDevice(&curdev));
+        device = curdev;
     }
-    if (device >= count) { set_error("device index out of range"); return MZK_ERR_INVALID_ARG; }
-    if (g_init && device != g_device) { set_error("already bound to another device (one process per GPU)"); return MZK_ERR_INVALID_ARG; }
-    HIP_TRY(hipSetDevice(device));
-    g_device = device;
-    g_init = true;
+    if (device >= (virt ? virt : count) || device >= MAX_CTX) { set_error("device index out of range"); return MZK_ERR_INVALID_ARG; }
+    Ctx& cx = g_ctx[device];
+    if (!cx.init) {
+        cx.logical = device;
+        cx.device = virt ? device % count : device;
+        HIP_TRY(hipSetDevice(cx.device));
+        for (int o = 0; o < MAX_CTX; o++)                        // peer access both ways where the hardware offers it (xGMI): the
+            if (g_ctx[o].init && g_ctx[o].device != cx.device) {  // class exchange of a multi-GPU proof is a device-to-device copy
+                int can = 0;
+                if (hipDeviceCanAccessPeer(&can, cx.device, g_ctx[o].device) == hipSuccess && can) {
+                    (void)hipDeviceEnablePeerAccess(g_ctx[o].device, 0);
+                    (void)hipSetDevice(g_ctx[o].device);
+                    (void)hipDeviceEnablePeerAccess(cx.device, 0);
+                    (void)hipSetDevice(cx.device);
+                }
+            }
+        (void)hipGetLastError();                                 // "peer access already enabled" is not an error
+        cx.init = true;
+    }
+    HIP_TRY(hipSetDevice(cx.device));
+    t_dev = device;
+    if (g_default < 0) g_default = device;
+    return MZK_OK;
+}
+
+int32_t mzk_set_device(int32_t device) {
+    std::lock_guard<std::mutex> lk(g_ctx_lock);
+    if (device < 0 || device >= MAX_CTX || !g_ctx[device].init) { set_error("mzk_set_device: mzk_init(device) has not been called"); return MZK_ERR_NOT_INIT; }
+    HIP_TRY(hipSetDevice(g_ctx[device].device));
+    t_dev = device;
+    return MZK_OK;
+}
+
+int32_t mzk_get_device(int32_t* out_device) {
+    if (!out_device) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    *out_device = t_dev >= 0 ? t_dev : g_default;
+    return *out_device >= 0 ? MZK_OK : MZK_ERR_NOT_INIT;
+}
+
+int32_t mzk_device_count(int32_t* out_count) {
+    if (!out_count) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count == 0) { set_error("no HIP device visible"); return MZK_ERR_NO_DEVICE; }
+    const int virt = virtual_devices();
+    *out_count = virt ? virt : (count < MAX_CTX ? count : MAX_CTX);
     return MZK_OK;
 }
 
 int32_t mzk_shutdown(void) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    if (!g_init) return MZK_OK;
-    (void)hipSetDevice(g_device);
-    (void)hipDeviceSynchronize();
-    for (auto& kv : g_srs) { (void)hipFree(kv.second.d_xy); if (kv.second.d_int) (void)hipFree(kv.second.d_int); if (kv.second.d_pre) (void)hipFree(kv.second.d_pre); }
-    g_srs.clear();
-    io_release_all();
-    ntt_release_plans();
-    msm_release_streams();
-    plonk_release_all();
-    for (auto& r : g_prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-    g_prof_recs.clear();
-    g_ws.release();
-    g_init = false;
+    std::lock_guard<std::mutex> lk(g_ctx_lock);
+    for (int d = 0; d < MAX_CTX; d++) {
+        Ctx& cx = g_ctx[d];
+        if (!cx.init) continue;
+        CtxBind bind(&cx);
+        std::lock_guard<std::mutex> lk2(cx.lock);
+        (void)hipDeviceSynchronize();
+        for (auto& kv : cx.srs) { (void)hipFree(kv.second.d_xy); if (kv.second.d_int) (void)hipFree(kv.second.d_int); if (kv.second.d_pre) (void)hipFree(kv.second.d_pre); }
+        cx.srs.clear();
+        io_release_all(cx);
+        ntt_release_plans();
+        msm_release_streams();
+        plonk_release_all();
+        for (auto& r : cx.prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        cx.prof_recs.clear();
+        cx.ws.release();
+        cx.init = false;
+    }
+    g_default = -1;
+    t_dev = -1;
     return MZK_OK;
 }
 
@@ -203,26 +285,30 @@ const char* mzk_strerror(int32_t code) {
         default: return "unknown error";
     }
 }
-const char* mzk_last_error(void) { return mzk::g_last_error.empty() ? mzk::g_last_error_global.c_str() : mzk::g_last_error.c_str(); }
-const char* mzk_version(void) { return "libmi355zk 0.1 (gfx950)"; }
+const char* mzk_last_error(void) {
+    if (!mzk::g_last_error.empty()) return mzk::g_last_error.c_str();
+    // no error on this thread yet: the latest one of the process, copied under its lock into this thread's own buffer
+    thread_local std::string copy;
+    { std::lock_guard<std::mutex> g(mzk::g_last_error_lock); copy = mzk::g_last_error_global; }
+    return copy.c_str();
+}
+const char* mzk_version(void) { return "libmi355zk 0.3 (gfx950)"; }
 
 // ---- SRS -----------------------------------------------------------------------------------------
 int32_t mzk_srs_register(int32_t curve_id, const uint64_t* xy_mont, uint64_t n_points, uint64_t* out_handle) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_CUR();
     if ((curve_id != 0 && curve_id != 1) || !out_handle || (!xy_mont && n_points)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
     Srs s{curve_id, n_points, nullptr, nullptr, nullptr, 0};
     const size_t bytes = (size_t)n_points * 2 * fq_words(curve_id) * 4;
     HIP_TRY(hipMalloc((void**)&s.d_xy, bytes ? bytes : 4));
     if (bytes) HIP_TRY(hipMemcpy(s.d_xy, xy_mont, bytes, hipMemcpyHostToDevice));
     MZK_TRY(srs_build_internal(s, nullptr));
-    *out_handle = g_next_handle++;
-    g_srs[*out_handle] = s;
+    *out_handle = handle_make(cx_->logical, cx_->next_handle++);
+    cx_->srs[*out_handle] = s;
     return MZK_OK;
 }
 int32_t mzk_srs_register_dev(int32_t curve_id, const void* d_xy_mont, uint64_t n_points, uint64_t* out_handle, void* stream) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_CUR();
     if ((curve_id != 0 && curve_id != 1) || !out_handle || (!d_xy_mont && n_points)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
     Srs s{curve_id, n_points, nullptr, nullptr, nullptr, 0};
     const size_t bytes = (size_t)n_points * 2 * fq_words(curve_id) * 4;
@@ -232,25 +318,23 @@ int32_t mzk_srs_register_dev(int32_t curve_id, const void* d_xy_mont, uint64_t n
         HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     }
     MZK_TRY(srs_build_internal(s, (hipStream_t)stream));
-    *out_handle = g_next_handle++;
-    g_srs[*out_handle] = s;
+    *out_handle = handle_make(cx_->logical, cx_->next_handle++);
+    cx_->srs[*out_handle] = s;
     return MZK_OK;
 }
 int32_t mzk_srs_release(uint64_t handle) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
-    auto it = g_srs.find(handle);
-    if (it == g_srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+    ENTER_HANDLE(handle);
+    auto it = cx_->srs.find(handle);
+    if (it == cx_->srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipFree(it->second.d_xy));
     if (it->second.d_int) HIP_TRY(hipFree(it->second.d_int));
     if (it->second.d_pre) HIP_TRY(hipFree(it->second.d_pre));
-    g_srs.erase(it);
+    cx_->srs.erase(it);
     return MZK_OK;
 }
 int32_t mzk_srs_generate_for_testing(int32_t curve_id, const uint64_t* beta_canonical, uint64_t n_points, uint64_t* out_handle) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_CUR();
     if ((curve_id != 0 && curve_id != 1) || !out_handle || !beta_canonical) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
     Srs s{curve_id, n_points, nullptr, nullptr, nullptr, 0};
     const size_t bytes = (size_t)n_points * 2 * fq_words(curve_id) * 4;
@@ -262,15 +346,14 @@ int32_t mzk_srs_generate_for_testing(int32_t curve_id, const uint64_t* beta_cano
     }
     if (rc == MZK_OK) rc = srs_build_internal(s, nullptr);
     if (rc != MZK_OK) { (void)hipFree(s.d_xy); return rc; }
-    *out_handle = g_next_handle++;
-    g_srs[*out_handle] = s;
+    *out_handle = handle_make(cx_->logical, cx_->next_handle++);
+    cx_->srs[*out_handle] = s;
     return MZK_OK;
 }
 int32_t mzk_srs_download(uint64_t handle, uint64_t first, uint64_t n_points, uint64_t* out_xy_mont) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
-    auto it = g_srs.find(handle);
-    if (it == g_srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+    ENTER_HANDLE(handle);
+    auto it = cx_->srs.find(handle);
+    if (it == cx_->srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
     const Srs& s = it->second;
     if (first > s.n || n_points > s.n - first) { set_error("range outside the SRS"); return MZK_ERR_INVALID_ARG; }
     const size_t pw = (size_t)2 * fq_words(s.curve);
@@ -279,9 +362,9 @@ int32_t mzk_srs_download(uint64_t handle, uint64_t first, uint64_t n_points, uin
     return MZK_OK;
 }
 int32_t mzk_srs_len(uint64_t handle, uint64_t* out_n_points) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    auto it = g_srs.find(handle);
-    if (it == g_srs.end() || !out_n_points) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+    ENTER_HANDLE(handle);
+    auto it = cx_->srs.find(handle);
+    if (it == cx_->srs.end() || !out_n_points) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
     *out_n_points = it->second.n;
     return MZK_OK;
 }
@@ -289,10 +372,9 @@ int32_t mzk_srs_len(uint64_t handle, uint64_t* out_n_points) {
 // ---- MSM -----------------------------------------------------------------------------------------
 int32_t mzk_msm_dev(uint64_t srs_handle, uint64_t base_offset, const void* d_scalars, uint64_t n, int32_t scalars_are_mont,
                     uint64_t* out_xyz_mont, void* stream) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
-    auto it = g_srs.find(srs_handle);
-    if (it == g_srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+    ENTER_HANDLE(srs_handle);
+    auto it = cx_->srs.find(srs_handle);
+    if (it == cx_->srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
     if (!out_xyz_mont || (!d_scalars && n)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     return msm_dispatch(it->second, base_offset, reinterpret_cast<const uint32_t*>(d_scalars), n, scalars_are_mont != 0,
                         reinterpret_cast<uint32_t*>(out_xyz_mont), (hipStream_t)stream);
@@ -300,12 +382,12 @@ int32_t mzk_msm_dev(uint64_t srs_handle, uint64_t base_offset, const void* d_sca
 
 // host scalars: upload on an I/O slot outside the lock (it overlaps whatever MSM or NTT another caller is running), compute under it
 static int32_t msm_host(uint64_t srs_handle, uint64_t base_offset, const uint64_t* scalars, uint64_t n, int32_t is_mont, uint64_t* out, int* out_curve) {
-    MZK_TRY(require_init());
+    BIND_HANDLE(srs_handle);
     if (!out || (!scalars && n)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     {   // nothing is read from `scalars` before the range has been checked against the SRS
-        std::lock_guard<std::mutex> lk(g_lock);
-        auto it = g_srs.find(srs_handle);
-        if (it == g_srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+        std::lock_guard<std::mutex> lk(cx_->lock);
+        auto it = cx_->srs.find(srs_handle);
+        if (it == cx_->srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
         if (base_offset > it->second.n || n > it->second.n - base_offset) {
             set_error("MSM longer than the registered SRS (poly degree larger than allowed)");
             return MZK_ERR_INVALID_ARG;
@@ -313,15 +395,16 @@ static int32_t msm_host(uint64_t srs_handle, uint64_t base_offset, const uint64_
         if (n >= (1ull << 27)) { set_error("MSM size must be < 2^27"); return MZK_ERR_INVALID_ARG; }
     }
     IoGuard slot;
-    MZK_TRY(io_acquire(&slot.idx));
-    IoSlot& io = g_io[slot.idx];
+    slot.cx = cx_;
+    MZK_TRY(io_acquire(*cx_, &slot.idx));
+    IoSlot& io = cx_->io[slot.idx];
     if (n) {
         MZK_TRY(io.buf.reserve(n * 32));
         HIP_TRY(hipMemcpyAsync(io.buf.p, scalars, n * 32, hipMemcpyHostToDevice, io.st));
     }
-    std::lock_guard<std::mutex> lk(g_lock);
-    auto it = g_srs.find(srs_handle);                                // released by another thread meanwhile?
-    if (it == g_srs.end()) { (void)hipStreamSynchronize(io.st); set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+    std::lock_guard<std::mutex> lk(cx_->lock);
+    auto it = cx_->srs.find(srs_handle);                                // released by another thread meanwhile?
+    if (it == cx_->srs.end()) { (void)hipStreamSynchronize(io.st); set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
     if (out_curve) *out_curve = it->second.curve;
     const int32_t rc = msm_dispatch(it->second, base_offset, io.buf.as<uint32_t>(), n, is_mont != 0, reinterpret_cast<uint32_t*>(out), io.st);
     if (rc != MZK_OK) (void)hipStreamSynchronize(io.st);          // the slot's buffer must be idle before it is handed on
@@ -334,10 +417,9 @@ int32_t mzk_msm(uint64_t srs_handle, uint64_t base_offset, const uint64_t* scala
 
 int32_t mzk_msm_batch_dev(uint64_t srs_handle, uint32_t n_polys, const void* const* d_scalars, const uint64_t* lens, const uint64_t* base_offsets,
                           int32_t scalars_are_mont, uint64_t* out_xyz_mont, void* stream) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
-    auto it = g_srs.find(srs_handle);
-    if (it == g_srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+    ENTER_HANDLE(srs_handle);
+    auto it = cx_->srs.find(srs_handle);
+    if (it == cx_->srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
     if (n_polys && (!d_scalars || !lens || !out_xyz_mont)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     return msm_batch_dispatch(it->second, n_polys, reinterpret_cast<const uint32_t* const*>(d_scalars), lens, base_offsets, scalars_are_mont != 0,
                               reinterpret_cast<uint32_t*>(out_xyz_mont), (hipStream_t)stream);
@@ -345,7 +427,7 @@ int32_t mzk_msm_batch_dev(uint64_t srs_handle, uint32_t n_polys, const void* con
 
 int32_t mzk_msm_batch(uint64_t srs_handle, uint32_t n_polys, const uint64_t* const* scalars, const uint64_t* lens, const uint64_t* base_offsets,
                       int32_t scalars_are_mont, uint64_t* out_xyz_mont) {
-    MZK_TRY(require_init());
+    BIND_HANDLE(srs_handle);
     if (n_polys && (!scalars || !lens || !out_xyz_mont)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     uint64_t total = 0;
     for (uint32_t i = 0; i < n_polys; i++) {
@@ -354,9 +436,9 @@ int32_t mzk_msm_batch(uint64_t srs_handle, uint32_t n_polys, const uint64_t* con
         total += lens[i];
     }
     {   // nothing is read from the scalar arrays before the ranges have been checked against the SRS
-        std::lock_guard<std::mutex> lk(g_lock);
-        auto it = g_srs.find(srs_handle);
-        if (it == g_srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+        std::lock_guard<std::mutex> lk(cx_->lock);
+        auto it = cx_->srs.find(srs_handle);
+        if (it == cx_->srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
         for (uint32_t i = 0; i < n_polys; i++) {
             const uint64_t off = base_offsets ? base_offsets[i] : 0;
             if (off > it->second.n || lens[i] > it->second.n - off) {
@@ -367,8 +449,9 @@ int32_t mzk_msm_batch(uint64_t srs_handle, uint32_t n_polys, const uint64_t* con
     }
     // one upload slab on an I/O slot (outside the lock), then the fused batch
     IoGuard slot;
-    MZK_TRY(io_acquire(&slot.idx));
-    IoSlot& io = g_io[slot.idx];
+    slot.cx = cx_;
+    MZK_TRY(io_acquire(*cx_, &slot.idx));
+    IoSlot& io = cx_->io[slot.idx];
     MZK_TRY(io.buf.reserve((total ? total : 1) * 32));
     std::vector<const uint32_t*> dptr(n_polys);
     uint64_t off = 0;
@@ -377,9 +460,9 @@ int32_t mzk_msm_batch(uint64_t srs_handle, uint32_t n_polys, const uint64_t* con
         if (lens[i]) HIP_TRY(hipMemcpyAsync(const_cast<uint32_t*>(dptr[i]), scalars[i], lens[i] * 32, hipMemcpyHostToDevice, io.st));
         off += lens[i];
     }
-    std::lock_guard<std::mutex> lk(g_lock);
-    auto it = g_srs.find(srs_handle);
-    if (it == g_srs.end()) { (void)hipStreamSynchronize(io.st); set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+    std::lock_guard<std::mutex> lk(cx_->lock);
+    auto it = cx_->srs.find(srs_handle);
+    if (it == cx_->srs.end()) { (void)hipStreamSynchronize(io.st); set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
     const int32_t rc = msm_batch_dispatch(it->second, n_polys, dptr.data(), lens, base_offsets, scalars_are_mont != 0, reinterpret_cast<uint32_t*>(out_xyz_mont), io.st);
     if (rc != MZK_OK) (void)hipStreamSynchronize(io.st);
     return rc;
@@ -411,8 +494,7 @@ int32_t mzk_g1_jacobian_to_affine(int32_t curve_id, const uint64_t* xyz_mont, ui
 // ---- NTT -----------------------------------------------------------------------------------------
 int32_t mzk_ntt_dev(int32_t curve_id, void* d_data_mont, uint64_t in_len, uint32_t log_n, int32_t inverse, const uint64_t* coset_offset_mont,
                     uint32_t batch, uint64_t batch_stride, void* stream) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_CUR();
     if (!d_data_mont) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     return ntt_dispatch(curve_id, reinterpret_cast<uint32_t*>(d_data_mont), in_len, (int)log_n, inverse != 0,
                         reinterpret_cast<const uint32_t*>(coset_offset_mont), batch, batch_stride, (hipStream_t)stream);
@@ -420,7 +502,7 @@ int32_t mzk_ntt_dev(int32_t curve_id, void* d_data_mont, uint64_t in_len, uint32
 
 int32_t mzk_ntt_batch(int32_t curve_id, uint32_t n_polys, uint64_t* const* data_mont, const uint64_t* in_lens, uint32_t log_n, int32_t inverse,
                       const uint64_t* coset_offset_mont) {
-    MZK_TRY(require_init());
+    BIND_CUR();
     if (log_n > 30) { set_error("log_n out of range"); return MZK_ERR_INVALID_ARG; }
     if (n_polys && (!data_mont || !in_lens)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     for (uint32_t i = 0; i < n_polys; i++)
@@ -433,9 +515,10 @@ int32_t mzk_ntt_batch(int32_t curve_id, uint32_t n_polys, uint64_t* const* data_
     const int want = (int)(n_polys < (uint32_t)PIPE ? n_polys : (uint32_t)PIPE);
     int n_slots = 0;
     for (int k = 0; k < want; k++) {
-        MZK_TRY(io_acquire(&slot[n_slots].idx, /*block=*/k == 0));          // wait for the first slot only; take more if they are free
+        slot[n_slots].cx = cx_;
+        MZK_TRY(io_acquire(*cx_, &slot[n_slots].idx, /*block=*/k == 0));    // wait for the first slot only; take more if they are free
         if (slot[n_slots].idx < 0) break;
-        MZK_TRY(g_io[slot[n_slots].idx].buf.reserve(N * 32));
+        MZK_TRY(cx_->io[slot[n_slots].idx].buf.reserve(N * 32));
         n_slots++;
     }
     if (n_polys == 0) return MZK_OK;
@@ -447,18 +530,18 @@ int32_t mzk_ntt_batch(int32_t curve_id, uint32_t n_polys, uint64_t* const* data_
     };
     int32_t rc = MZK_OK;
     for (uint32_t i = 0; i < n_polys && rc == MZK_OK; i++) {
-        IoSlot& io = g_io[slot[i % n_slots].idx];
+        IoSlot& io = cx_->io[slot[i % n_slots].idx];
         if (i >= (uint32_t)n_slots) rc = hip_ok(hipStreamSynchronize(io.st), "hipStreamSynchronize");   // its previous polynomial has left the device
         const uint64_t len = in_lens[i] < N ? in_lens[i] : N;
         if (rc == MZK_OK && len) rc = hip_ok(hipMemcpyAsync(io.buf.p, data_mont[i], len * 32, hipMemcpyHostToDevice, io.st), "hipMemcpyAsync");
         if (rc == MZK_OK) {
-            std::lock_guard<std::mutex> lk(g_lock);
+            std::lock_guard<std::mutex> lk(cx_->lock);
             rc = ntt_dispatch(curve_id, io.buf.as<uint32_t>(), len, (int)log_n, inverse != 0, reinterpret_cast<const uint32_t*>(coset_offset_mont), 1, N, io.st);
         }
         if (rc == MZK_OK) rc = hip_ok(hipMemcpyAsync(data_mont[i], io.buf.p, N * 32, hipMemcpyDeviceToHost, io.st), "hipMemcpyAsync");
     }
     for (int k = 0; k < n_slots; k++) {
-        const int32_t r2 = hip_ok(hipStreamSynchronize(g_io[slot[k].idx].st), "hipStreamSynchronize");
+        const int32_t r2 = hip_ok(hipStreamSynchronize(cx_->io[slot[k].idx].st), "hipStreamSynchronize");
         if (rc == MZK_OK) rc = r2;
     }
     return rc;
@@ -525,8 +608,7 @@ int32_t mzk_keccak_f1600(uint8_t* state200) {
 // ---- TurboPlonk quotient round ------------------------------------------------------------------------
 int32_t mzk_plonk_pk_register(int32_t curve_id, uint32_t log_n, uint32_t num_wire_types, const uint64_t* selector_coeffs,
                               const uint64_t* sigma_coeffs, uint64_t poly_len, const uint64_t* k_mont, uint64_t* out_handle) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_CUR();
     if (num_wire_types != 5) { set_error("TurboPlonk proving key: 5 wire types (UltraPlonk: mzk_plonk_pk_register_ultra)"); return MZK_ERR_INVALID_ARG; }
     return plonk_pk_register(curve_id, (int)log_n, (int)num_wire_types, reinterpret_cast<const uint32_t*>(selector_coeffs),
                              reinterpret_cast<const uint32_t*>(sigma_coeffs), nullptr, poly_len, reinterpret_cast<const uint32_t*>(k_mont), nullptr, 0,
@@ -534,8 +616,7 @@ int32_t mzk_plonk_pk_register(int32_t curve_id, uint32_t log_n, uint32_t num_wir
 }
 int32_t mzk_plonk_pk_register_ultra(int32_t curve_id, uint32_t log_n, const uint64_t* selector_coeffs, const uint64_t* sigma_coeffs,
                                     const uint64_t* table_coeffs, uint64_t poly_len, const uint64_t* k_mont, uint64_t* out_handle) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_CUR();
     if (!table_coeffs) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     return plonk_pk_register(curve_id, (int)log_n, 6, reinterpret_cast<const uint32_t*>(selector_coeffs), reinterpret_cast<const uint32_t*>(sigma_coeffs),
                              reinterpret_cast<const uint32_t*>(table_coeffs), poly_len, reinterpret_cast<const uint32_t*>(k_mont), nullptr, 0, out_handle);
@@ -543,8 +624,7 @@ int32_t mzk_plonk_pk_register_ultra(int32_t curve_id, uint32_t log_n, const uint
 int32_t mzk_plonk_pk_register_chunked(int32_t curve_id, uint32_t log_n, uint32_t num_wire_types, const uint64_t* selector_coeffs,
                                       const uint64_t* sigma_coeffs, const uint64_t* table_coeffs, uint64_t poly_len, const uint64_t* k_mont,
                                       const uint32_t* classes, uint32_t n_classes, uint64_t* out_handle) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_CUR();
     if (!classes || (num_wire_types == 6) != (table_coeffs != nullptr)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
     return plonk_pk_register(curve_id, (int)log_n, (int)num_wire_types, reinterpret_cast<const uint32_t*>(selector_coeffs),
                              reinterpret_cast<const uint32_t*>(sigma_coeffs), reinterpret_cast<const uint32_t*>(table_coeffs), poly_len,
@@ -552,8 +632,7 @@ int32_t mzk_plonk_pk_register_chunked(int32_t curve_id, uint32_t log_n, uint32_t
 }
 int32_t mzk_plonk_quotient_chunked_dev(uint64_t pk_handle, const void* d_polys, uint64_t in_stride, uint64_t in_len, const uint64_t* tau_mont,
                                        const uint64_t* alpha_mont, const uint64_t* beta_mont, const uint64_t* gamma_mont, void* d_out, void* stream) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_HANDLE(pk_handle);
     return plonk_quotient_chunked_dev(pk_handle, reinterpret_cast<const uint32_t*>(d_polys), in_stride, in_len, reinterpret_cast<const uint32_t*>(tau_mont),
                                       reinterpret_cast<const uint32_t*>(alpha_mont), reinterpret_cast<const uint32_t*>(beta_mont),
                                       reinterpret_cast<const uint32_t*>(gamma_mont), reinterpret_cast<uint32_t*>(d_out), (hipStream_t)stream);
@@ -563,21 +642,18 @@ int32_t mzk_plonk_quotient_combine_dev(int32_t curve_id, uint32_t log_n, const v
 }
 int32_t mzk_plonk_quotient_combine_classes_dev(int32_t curve_id, uint32_t log_n, const uint32_t* classes, uint32_t n_classes, const void* d_class_remainders,
                                                void* d_out, void* stream) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_CUR();
     if (!d_class_remainders || !d_out || log_n > 27) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
     return plonk_quotient_combine_dev(curve_id, (int)log_n, classes, n_classes, reinterpret_cast<const uint32_t*>(d_class_remainders),
                                       reinterpret_cast<uint32_t*>(d_out), (hipStream_t)stream);
 }
 int32_t mzk_plonk_pk_release(uint64_t pk_handle) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_HANDLE(pk_handle);
     return plonk_pk_release(pk_handle);
 }
 int32_t mzk_plonk_quotient_dev(uint64_t pk_handle, void* d_polys, uint64_t in_len, const uint64_t* alpha_mont, const uint64_t* beta_mont,
                                const uint64_t* gamma_mont, void* d_out, void* stream) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_HANDLE(pk_handle);
     if (plonk_pk_is_ultra(pk_handle) == 1) { set_error("UltraPlonk proving key: use mzk_plonk_quotient_ultra_dev"); return MZK_ERR_INVALID_ARG; }
     return plonk_quotient_dev(pk_handle, reinterpret_cast<uint32_t*>(d_polys), in_len, nullptr, reinterpret_cast<const uint32_t*>(alpha_mont),
                               reinterpret_cast<const uint32_t*>(beta_mont), reinterpret_cast<const uint32_t*>(gamma_mont),
@@ -585,8 +661,7 @@ int32_t mzk_plonk_quotient_dev(uint64_t pk_handle, void* d_polys, uint64_t in_le
 }
 int32_t mzk_plonk_quotient_ultra_dev(uint64_t pk_handle, void* d_polys, uint64_t in_len, const uint64_t* tau_mont, const uint64_t* alpha_mont,
                                      const uint64_t* beta_mont, const uint64_t* gamma_mont, void* d_out, void* stream) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_HANDLE(pk_handle);
     if (plonk_pk_is_ultra(pk_handle) == 0) { set_error("TurboPlonk proving key: use mzk_plonk_quotient_dev"); return MZK_ERR_INVALID_ARG; }
     return plonk_quotient_dev(pk_handle, reinterpret_cast<uint32_t*>(d_polys), in_len, reinterpret_cast<const uint32_t*>(tau_mont),
                               reinterpret_cast<const uint32_t*>(alpha_mont), reinterpret_cast<const uint32_t*>(beta_mont),
@@ -594,24 +669,21 @@ int32_t mzk_plonk_quotient_ultra_dev(uint64_t pk_handle, void* d_polys, uint64_t
 }
 int32_t mzk_plookup_sorted_vec_dev(uint64_t pk_handle, const void* d_wire_values, const uint64_t* tau_mont, void* d_merged_table, void* d_merged_lookup,
                                    void* d_sorted, void* stream) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_HANDLE(pk_handle);
     return plookup_sorted_vec_dev(pk_handle, reinterpret_cast<const uint32_t*>(d_wire_values), reinterpret_cast<const uint32_t*>(tau_mont),
                                   reinterpret_cast<uint32_t*>(d_merged_table), reinterpret_cast<uint32_t*>(d_merged_lookup),
                                   reinterpret_cast<uint32_t*>(d_sorted), (hipStream_t)stream);
 }
 int32_t mzk_plookup_product_dev(uint64_t pk_handle, const void* d_merged_table, const void* d_merged_lookup, const void* d_sorted, const uint64_t* beta_mont,
                                 const uint64_t* gamma_mont, void* d_out, void* stream) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_HANDLE(pk_handle);
     return plookup_product_dev(pk_handle, reinterpret_cast<const uint32_t*>(d_merged_table), reinterpret_cast<const uint32_t*>(d_merged_lookup),
                                reinterpret_cast<const uint32_t*>(d_sorted), reinterpret_cast<const uint32_t*>(beta_mont),
                                reinterpret_cast<const uint32_t*>(gamma_mont), reinterpret_cast<uint32_t*>(d_out), (hipStream_t)stream);
 }
 int32_t mzk_plonk_quotient(uint64_t pk_handle, const uint64_t* polys, uint64_t in_len, const uint64_t* alpha_mont, const uint64_t* beta_mont,
                            const uint64_t* gamma_mont, uint64_t* out) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_HANDLE(pk_handle);
     const int log_n = plonk_pk_log_n(pk_handle), W = plonk_pk_wires(pk_handle);
     if (log_n < 0) { set_error("unknown proving-key handle"); return MZK_ERR_BAD_HANDLE; }
     if (plonk_pk_is_ultra(pk_handle) == 1) { set_error("UltraPlonk proving key: use mzk_plonk_quotient_ultra_dev"); return MZK_ERR_INVALID_ARG; }
@@ -623,8 +695,9 @@ int32_t mzk_plonk_quotient(uint64_t pk_handle, const uint64_t* polys, uint64_t i
     const int ncl = plonk_pk_classes(pk_handle, classes);
     if (ncl > 0) {
         // a key holding residue classes of the quotient domain (the default of both hosts): the rows are read in place (stride in_len),
-        // class remainders, then the inverse Vandermonde -- valid when the classes determine the quotient: deg t < ncl * n
-        if ((uint64_t)W * (n + 1) + 2 >= (uint64_t)ncl * n || in_len > 2 * n) {
+        // class remainders, then the inverse Vandermonde -- valid when the classes determine the quotient with one coefficient to spare
+        // (deg t < ncl * n - 1: the caller's degree check must be able to fail for an unsatisfied witness)
+        if ((uint64_t)W * (n + 1) + 2 >= (uint64_t)ncl * n - 1 || in_len > 2 * n) {
             set_error("chunked proving key: its classes do not determine the quotient (or a polynomial of degree >= 2n)");
             return MZK_ERR_INVALID_ARG;
         }
@@ -650,14 +723,12 @@ int32_t mzk_plonk_quotient(uint64_t pk_handle, const uint64_t* polys, uint64_t i
 
 int32_t mzk_plonk_perm_product_dev(uint64_t pk_handle, const void* d_wire_values, const uint64_t* beta_mont, const uint64_t* gamma_mont, void* d_out,
                                    void* stream) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_HANDLE(pk_handle);
     return plonk_perm_product_dev(pk_handle, reinterpret_cast<const uint32_t*>(d_wire_values), reinterpret_cast<const uint32_t*>(beta_mont),
                                   reinterpret_cast<const uint32_t*>(gamma_mont), reinterpret_cast<uint32_t*>(d_out), (hipStream_t)stream);
 }
 int32_t mzk_plonk_perm_product(uint64_t pk_handle, const uint64_t* wire_values, const uint64_t* beta_mont, const uint64_t* gamma_mont, uint64_t* out) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_HANDLE(pk_handle);
     const int log_n = plonk_pk_log_n(pk_handle), W = plonk_pk_wires(pk_handle);
     if (log_n < 0) { set_error("unknown proving-key handle"); return MZK_ERR_BAD_HANDLE; }
     if (!wire_values || !out) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
@@ -676,8 +747,7 @@ int32_t mzk_plonk_perm_product(uint64_t pk_handle, const uint64_t* wire_values, 
 // ---- dense-polynomial primitives (prover rounds 4 and 5) ---------------------------------------------
 int32_t mzk_poly_eval_dev(int32_t curve_id, const void* d_coeffs, uint64_t len, uint32_t batch, uint64_t batch_stride, const uint64_t* x_mont,
                           uint64_t* out_mont, void* stream) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_CUR();
     if ((!d_coeffs && len) || !x_mont || !out_mont || (batch > 1 && batch_stride < len) || batch > 65535) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
     if (batch == 0) return MZK_OK;
     return poly_eval_dispatch(curve_id, reinterpret_cast<const uint32_t*>(d_coeffs), batch_stride, len, batch, reinterpret_cast<const uint32_t*>(x_mont),
@@ -685,39 +755,34 @@ int32_t mzk_poly_eval_dev(int32_t curve_id, const void* d_coeffs, uint64_t len, 
 }
 int32_t mzk_poly_lincomb_dev(int32_t curve_id, uint32_t n_terms, const void* const* d_polys, const uint64_t* lens, const uint64_t* scalars_mont,
                              void* d_out, uint64_t out_len, void* stream) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_CUR();
     if (n_terms && (!d_polys || !lens || !scalars_mont)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     if (!d_out && out_len) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     return poly_lincomb_dispatch(curve_id, n_terms, reinterpret_cast<const uint32_t* const*>(d_polys), lens, reinterpret_cast<const uint32_t*>(scalars_mont),
                                  reinterpret_cast<uint32_t*>(d_out), out_len, (hipStream_t)stream);
 }
 int32_t mzk_poly_mask_dev(int32_t curve_id, uint32_t n_polys, void* const* d_polys, uint64_t n, uint32_t n_blinders, const uint64_t* blinders_mont, void* stream) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_CUR();
     if (n_polys && (!d_polys || !blinders_mont)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     return poly_mask_dispatch(curve_id, n_polys, reinterpret_cast<uint32_t* const*>(d_polys), n, n_blinders, reinterpret_cast<const uint32_t*>(blinders_mont),
                               (hipStream_t)stream);
 }
 int32_t mzk_poly_div_linear_dev(int32_t curve_id, const void* d_poly, uint64_t len, const uint64_t* z_mont, void* d_out, void* stream) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_CUR();
     if ((!d_poly || !d_out) && len > 1) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     if (!z_mont) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     return poly_div_dispatch(curve_id, reinterpret_cast<const uint32_t*>(d_poly), len, reinterpret_cast<const uint32_t*>(z_mont),
                              reinterpret_cast<uint32_t*>(d_out), (hipStream_t)stream);
 }
 int32_t mzk_poly_degree_dev(const void* d_poly, uint64_t len, uint64_t* d_out_len, void* stream) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_CUR();
     if ((!d_poly && len) || !d_out_len) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     if (len >= (1ull << 40)) { set_error("polynomial too long"); return MZK_ERR_INVALID_ARG; }
     return poly_degree_dispatch(reinterpret_cast<const uint32_t*>(d_poly), len, reinterpret_cast<unsigned long long*>(d_out_len), (hipStream_t)stream);
 }
 int32_t mzk_poly_div_roots_dev(int32_t curve_id, const void* d_poly, uint64_t len, uint32_t log_order, uint64_t first, uint64_t count, void* d_out,
                                void* stream) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_CUR();
     if ((!d_poly || !d_out) && len > count) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     return poly_div_roots_dispatch(curve_id, reinterpret_cast<const uint32_t*>(d_poly), len, log_order, first, count, reinterpret_cast<uint32_t*>(d_out),
                                    (hipStream_t)stream);
@@ -725,24 +790,24 @@ int32_t mzk_poly_div_roots_dev(int32_t curve_id, const void* d_poly, uint64_t le
 
 // ---- page-locked host memory for the host-pointer entry points ------------------------------------------
 int32_t mzk_host_alloc(uint64_t bytes, void** out_ptr) {
-    MZK_TRY(require_init());
+    BIND_CUR();
     if (!out_ptr) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     HIP_TRY(hipHostMalloc(out_ptr, bytes ? bytes : 1, hipHostMallocDefault));
     return MZK_OK;
 }
 int32_t mzk_host_free(void* ptr) {
-    MZK_TRY(require_init());
+    BIND_CUR();
     if (ptr) HIP_TRY(hipHostFree(ptr));
     return MZK_OK;
 }
 int32_t mzk_host_register(void* ptr, uint64_t bytes) {
-    MZK_TRY(require_init());
+    BIND_CUR();
     if (!ptr || !bytes) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     HIP_TRY(hipHostRegister(ptr, bytes, hipHostRegisterDefault));
     return MZK_OK;
 }
 int32_t mzk_host_unregister(void* ptr) {
-    MZK_TRY(require_init());
+    BIND_CUR();
     if (!ptr) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     HIP_TRY(hipHostUnregister(ptr));
     return MZK_OK;
@@ -750,53 +815,60 @@ int32_t mzk_host_unregister(void* ptr) {
 
 // ---- device memory helpers --------------------------------------------------------------------------
 int32_t mzk_dev_alloc(uint64_t bytes, void** out_dptr) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_CUR();
     if (!out_dptr) return MZK_ERR_INVALID_ARG;
     HIP_TRY(hipMalloc(out_dptr, bytes ? bytes : 4));
     return MZK_OK;
 }
 int32_t mzk_dev_free(void* dptr) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_CUR();
     HIP_TRY(hipFree(dptr));
     return MZK_OK;
 }
 int32_t mzk_dev_upload(void* dptr, const void* host, uint64_t bytes) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_CUR();
     HIP_TRY(hipMemcpy(dptr, host, bytes, hipMemcpyHostToDevice));
     return MZK_OK;
 }
 int32_t mzk_dev_download(void* host, const void* dptr, uint64_t bytes) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_CUR();
     HIP_TRY(hipMemcpy(host, dptr, bytes, hipMemcpyDeviceToHost));
     return MZK_OK;
 }
 int32_t mzk_dev_sync(void) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_CUR();
     HIP_TRY(hipDeviceSynchronize());
     return MZK_OK;
 }
 int32_t mzk_dev_copy(void* dst, const void* src, uint64_t bytes, void* stream) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_CUR();
     if (bytes && (!dst || !src)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     if (bytes) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return MZK_OK;
 }
+int32_t mzk_dev_copy_peer(void* dst, int32_t dst_device, const void* src, int32_t src_device, uint64_t bytes, void* stream) {
+    if (dst_device < 0 || dst_device >= MAX_CTX || src_device < 0 || src_device >= MAX_CTX || !g_ctx[dst_device].init || !g_ctx[src_device].init) {
+        set_error("mzk_dev_copy_peer: both devices must have been initialised (mzk_init)");
+        return MZK_ERR_NOT_INIT;
+    }
+    if (bytes && (!dst || !src)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    Ctx* cx_ = &g_ctx[src_device];                                  // enqueued from the source device's side, on a stream of that device
+    CtxBind bind_(cx_);
+    MZK_TRY(bind_.rc);
+    if (!bytes) return MZK_OK;
+    const int pd = g_ctx[dst_device].device, ps = cx_->device;
+    if (pd == ps) HIP_TRY(hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream));     // virtual devices of one card
+    else HIP_TRY(hipMemcpyPeerAsync(dst, pd, src, ps, bytes, (hipStream_t)stream));                            // xGMI when peer access is on
+    return MZK_OK;
+}
 int32_t mzk_dev_copy2d(void* dst, uint64_t dst_pitch, const void* src, uint64_t src_pitch, uint64_t width, uint64_t height, void* stream) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_CUR();
     if (width && height && (!dst || !src || width > dst_pitch || width > src_pitch)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
     if (width && height) HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width, height, hipMemcpyDeviceToDevice, (hipStream_t)stream));
     return MZK_OK;
 }
 int32_t mzk_dev_memset(void* dptr, int32_t value, uint64_t bytes, void* stream) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_CUR();
     if (bytes && !dptr) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     if (bytes) HIP_TRY(hipMemsetAsync(dptr, value, bytes, (hipStream_t)stream));
     return MZK_OK;
@@ -804,17 +876,15 @@ int32_t mzk_dev_memset(void* dptr, int32_t value, uint64_t bytes, void* stream) 
 
 // ---- profiling ---------------------------------------------------------------------------------------
 int32_t mzk_profile_enable(int32_t on) {
-    std::lock_guard<std::mutex> lk(g_lock);
     g_prof = on != 0;
     return MZK_OK;
 }
 int32_t mzk_profile_get(const char* name, double* out_ms, uint64_t* out_count) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
+    ENTER_CUR();
     if (!name || !out_ms || !out_count) return MZK_ERR_INVALID_ARG;
     double ms = 0;
     uint64_t cnt = 0;
-    for (auto& r : g_prof_recs) {
+    for (auto& r : cx_->prof_recs) {
         if (r.name != name) continue;
         HIP_TRY(hipEventSynchronize(r.b));
         float t = 0;
@@ -827,21 +897,23 @@ int32_t mzk_profile_get(const char* name, double* out_ms, uint64_t* out_count) {
     return MZK_OK;
 }
 int32_t mzk_profile_reset(void) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    for (auto& r : g_prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
-    g_prof_recs.clear();
+    std::lock_guard<std::mutex> lk0(g_ctx_lock);
+    for (auto& cx : g_ctx) {
+        if (!cx.init) continue;
+        std::lock_guard<std::mutex> lk(cx.lock);
+        for (auto& r : cx.prof_recs) { (void)hipEventDestroy(r.a); (void)hipEventDestroy(r.b); }
+        cx.prof_recs.clear();
+    }
     return MZK_OK;
 }
 int32_t mzk_msm_set_precompute(int32_t on) {
-    std::lock_guard<std::mutex> lk(g_lock);
     g_msm_precompute = on != 0;
     return MZK_OK;
 }
 int32_t mzk_srs_precompute(uint64_t srs_handle, uint32_t* out_window_bits, uint32_t* out_levels, uint64_t* out_table_bytes, double* out_build_ms) {
-    std::lock_guard<std::mutex> lk(g_lock);
-    MZK_TRY(require_init());
-    auto it = g_srs.find(srs_handle);
-    if (it == g_srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+    ENTER_HANDLE(srs_handle);
+    auto it = cx_->srs.find(srs_handle);
+    if (it == cx_->srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
     Srs& s = it->second;
     MZK_TRY(srs_build_pre(s, nullptr));
     const bool have = s.d_pre != nullptr && s.pre_c > 0;
@@ -853,7 +925,6 @@ int32_t mzk_srs_precompute(uint64_t srs_handle, uint32_t* out_window_bits, uint3
     return MZK_OK;
 }
 int32_t mzk_msm_last_shape(uint32_t* out_window_bits, uint32_t* out_windows, uint32_t* out_buckets) {
-    std::lock_guard<std::mutex> lk(g_lock);
     if (out_window_bits) *out_window_bits = g_last_c;
     if (out_windows) *out_windows = g_last_w;
     if (out_buckets) *out_buckets = g_last_m;

@@ -30,7 +30,8 @@ struct PlanKey {
         return has_coset && std::memcmp(coset, o.coset, sizeof coset) < 0;
     }
 };
-std::map<PlanKey, std::unique_ptr<NttPlanDev>> g_plans;
+std::map<PlanKey, std::unique_ptr<NttPlanDev>> g_plans_of[MAX_CTX];      // one plan cache per device context
+#define g_plans (g_plans_of[cur().logical])
 uint64_t g_plan_clock = 0;
 // A plan holds device tables (up to tens of MB for the largest domains) and is keyed by the coset offset: a caller sweeping
 // offsets (per-proof random cosets, the multiprover's public-polynomial FFTs) must not grow the cache without bound.
@@ -87,10 +88,10 @@ int32_t launch_pass(const NttxPassArgs& a, unsigned long long n_tiles, uint32_t 
     const size_t tile = (size_t)1 << (a.log_r + a.log_c), r = (size_t)1 << a.log_r;
     const size_t lds = 2 * tile * 16 + tile * 4;
     (void)r;
-    static bool attr_set = false;
-    if (!attr_set) {
+    static bool attr_set[MAX_CTX] = {};                                  // per device (function attributes live in the device's code object)
+    if (!attr_set[cur().logical]) {
         HIP_TRY(hipFuncSetAttribute((const void*)nttx_pass_kernel<X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
-        attr_set = true;
+        attr_set[cur().logical] = true;
     }
     ProfScope ps("ntt_pass", st);
     hipLaunchKernelGGL((nttx_pass_kernel<X>), dim3((unsigned)n_tiles, batch), dim3(NTTX_THREADS), lds, st, a);

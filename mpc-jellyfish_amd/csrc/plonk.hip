@@ -33,7 +33,8 @@ struct PlonkPk {
     uint32_t c_cls[PLK_RATIO][8];       // h_k^n
     std::array<uint32_t*, 7> bufs() const { return {d_fixed, d_xs, d_inv_den, d_inv_den_n, d_sigma_n, d_omega_n, d_tab_n}; }
 };
-std::map<uint64_t, std::unique_ptr<PlonkPk>> g_pks;
+std::map<uint64_t, std::unique_ptr<PlonkPk>> g_pks_of[MAX_CTX];              // proving keys per device context; the handle names its context
+#define g_pks (g_pks_of[cur().logical])
 uint64_t g_next_pk = 1;
 
 // data[i] *= c (boundary form -> internal form x * R' with c = 32: plonk.cuh)
@@ -576,7 +577,7 @@ int32_t plonk_pk_register(int curve, int log_n, int W, const uint32_t* sel, cons
         for (auto* d : pk->bufs()) if (d) (void)hipFree(d);
         return rc;
     }
-    *out_handle = g_next_pk++;
+    *out_handle = handle_make(cur().logical, g_next_pk++);
     g_pks[*out_handle] = std::move(pk);
     return MZK_OK;
 }

@@ -188,9 +188,10 @@ struct Prover {                                                        // Provin
         const uint64_t* sel = host.data();
         const uint64_t* sig = sel + (size_t)nsel * n * 4;
         // The quotient has degree W (n + 1) + 2 < (W + 1) n (prover.rs:916-919): W + 1 of the 8 residue classes of the quotient domain
-        // determine it -- 6 for TurboPlonk, 7 for UltraPlonk -- so only those are resident and evaluated (tiny domains keep all 8)
+        // determine it -- 6 for TurboPlonk, 7 for UltraPlonk -- so only those are resident and evaluated (tiny domains keep all 8; one
+        // spare coefficient above the expected degree is required, or an unsatisfied witness could not trip WrongQuotientPolyDegree)
         classes.clear();
-        const uint32_t needed = ((uint64_t)W * (n + 1) + 2 < (uint64_t)(W + 1) * n && W + 1 <= 8) ? (uint32_t)W + 1 : 8u;
+        const uint32_t needed = ((uint64_t)W * (n + 1) + 2 < (uint64_t)(W + 1) * n - 1 && W + 1 <= 8) ? (uint32_t)W + 1 : 8u;
         for (uint32_t kcl = 0; kcl < needed; kcl++) classes.push_back(kcl);
         check(mzk_plonk_pk_register_chunked(C::ID, log_n, W, sel, sig, ultra ? sig + (size_t)W * n * 4 : nullptr, n, kk.data(), classes.data(),
                                             (uint32_t)classes.size(), &pk), "mzk_plonk_pk_register_chunked");

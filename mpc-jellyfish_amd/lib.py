@@ -21,6 +21,10 @@ def lib_path() -> str:
 
 _SIGS = {
     "mzk_init": [C.c_int32],
+    "mzk_set_device": [C.c_int32],
+    "mzk_get_device": [C.POINTER(C.c_int32)],
+    "mzk_device_count": [C.POINTER(C.c_int32)],
+    "mzk_dev_copy_peer": [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p],
     "mzk_shutdown": [],
     "mzk_srs_register": [C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)],
     "mzk_srs_register_dev": [C.c_int32, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64), C.c_void_p],

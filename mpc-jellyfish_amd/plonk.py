@@ -164,9 +164,12 @@ def compute_quotient_chunked_dev(pk: ProvingKeyDevice, challenges: Challenges, p
 def quotient_classes_needed(num_wire_types: int, domain_size: int) -> list[int]:
     """The residue classes of the quotient domain that have to be evaluated: deg t = W (n + 1) + 2 (prover.rs:916-919) is below
     (W + 1) n as soon as n > W + 2, so W + 1 of the 8 classes determine the quotient -- 6 for TurboPlonk, 7 for UltraPlonk;
-    tiny domains keep all 8."""
+    tiny domains keep all 8.  One SPARE coefficient is required above the expected degree (n >= W + 4): the interpolant through
+    (W + 1) n points has degree < (W + 1) n whatever the witness, so at n = W + 3, where that bound IS the expected degree, an
+    unsatisfied witness would pass the reference's only guard (`WrongQuotientPolyDegree`, prover.rs:915-918) that the whole-domain
+    path trips."""
     W, n = num_wire_types, domain_size
-    return list(range(W + 1)) if W * (n + 1) + 2 < (W + 1) * n and W + 1 <= 8 else list(range(8))
+    return list(range(W + 1)) if W * (n + 1) + 2 < (W + 1) * n - 1 and W + 1 <= 8 else list(range(8))
 
 
 def combine_quotient_classes(curve, domain_size: int, class_remainders, classes=None, out_dev=None, stream=None):

@@ -311,17 +311,42 @@ class TurboPlonkProver:
         n, W, ultra = self.n, self.W, self.ultra
         st = types.SimpleNamespace(blind=blind)
         dev = self.fixed.device
-        st.wv = wire_values if hasattr(wire_values, "is_cuda") else torch.from_numpy(np.ascontiguousarray(wire_values).view(np.int64)).to(dev)
-        pv = pub_input_values if hasattr(pub_input_values, "is_cuda") else torch.from_numpy(np.ascontiguousarray(pub_input_values).view(np.int64)).to(dev)
+        on_dev = lambda x: torch.is_tensor(x) and x.is_cuda
+        as_host = lambda x: x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x).view(np.int64))
+        pv = pub_input_values if on_dev(pub_input_values) else as_host(pub_input_values).to(dev)
         # one slab for round 3: rows 0..W-1 wires, W z, W+1 public input (, h_1, h_2, Plookup product); coefficients in the first n+3 columns
         st.Z, st.PI, st.H1, st.PL = W, W + 1, W + 2, W + 4
         t0 = time.perf_counter()
         slab = self._slab                                               # only the first n + 3 columns are read (in_len of the coset NTT)
         slab[:, n:n + 3] = 0
         coeff = self._coeff
-        coeff[:W] = st.wv
-        coeff[W] = pv
-        self.domain.ifft_in_place(coeff)
+        if on_dev(wire_values):
+            st.wv = wire_values
+            coeff[:W] = st.wv
+            coeff[W] = pv
+            self.domain.ifft_in_place(coeff)
+        else:
+            # HOST-resident witness: the reference gathers witness[wire_variable(i, j)] on the host and starts from there
+            # (constraint_system.rs:1225-1247).  Wire k + 1 crosses PCIe on a copy stream while wire k is transformed; from
+            # page-locked memory (torch pin_memory / mzk_host_alloc) the copies are asynchronous DMA.
+            hv = as_host(wire_values)
+            if getattr(self, "_wv", None) is None:
+                self._wv = torch.empty((W, n, 4), dtype=torch.int64, device=dev)
+                self._copy_stream = torch.cuda.Stream(device=dev)
+                self._wv_ev = [torch.cuda.Event() for _ in range(W)]
+            st.wv = self._wv
+            main = torch.cuda.current_stream(dev)
+            self._copy_stream.wait_stream(main)                          # the previous proof has finished with the buffer
+            with torch.cuda.stream(self._copy_stream):
+                for i in range(W):
+                    st.wv[i].copy_(hv[i], non_blocking=True)
+                    self._wv_ev[i].record(self._copy_stream)
+            coeff[W] = pv
+            self.domain.ifft_in_place(coeff[W:W + 1])
+            for i in range(W):
+                main.wait_event(self._wv_ev[i])
+                coeff[i] = st.wv[i]
+                self.domain.ifft_in_place(coeff[i:i + 1])
         slab[:W, :n] = coeff[:W]
         slab[st.PI, :n] = coeff[W]
         self._mask(slab, list(range(W)), blind.wires)

@@ -49,7 +49,12 @@ def _to_mont_dev(c: CurveParams, canon):
     return poly.lincomb(c, [((1 << 256) % c.r, canon)])
 
 
-def gen_circuit_for_bench(curve, num_gates: int, plonk_type: str = TURBO, range_bit_len: int = 8) -> BenchCircuit:
+def gen_circuit_for_bench(curve, num_gates: int, plonk_type: str = TURBO, range_bit_len: int = 8, dense_seed: int | None = None) -> BenchCircuit:
+    """dense_seed: not the reference's circuit but one with the SAME gates (the same selector polynomials: two constant gates, then
+    num_gates - 10 addition gates, padding) whose witness is dense -- the bench circuit's wires are 0, 1, 2, .. / all ones / all
+    zero / all zero / 1, 2, 3, ..: two of its five wire polynomials are zero and two are sparse, which flatters round 1.  Here row
+    t adds a + b = c with b, the unconstrained wires 2 and 3 and every second a drawn at random in [0, r) (a of an odd row is the
+    previous row's c, so the copy constraints still chain rows together): every wire polynomial has n random coefficients."""
     import torch
     c = _curve(curve)
     assert num_gates >= 16 and plonk_type in (TURBO, ULTRA)
@@ -61,18 +66,40 @@ def gen_circuit_for_bench(curve, num_gates: int, plonk_type: str = TURBO, range_
     n = 1 << (need - 1).bit_length()
     log_n = n.bit_length() - 1
     dev = torch.device("cuda")
-    # variable index on every (wire, row): 0 = zero, 1 = one, 2 + t = output of the t-th addition
     var = torch.zeros((W, n), dtype=torch.int64, device=dev)
     rows = torch.arange(2, 2 + n_add, device=dev)
-    var[0, 2:2 + n_add] = torch.where(rows == 2, torch.zeros_like(rows), rows - 1)          # a: previous sum (the first is `zero`)
-    var[1, 2:2 + n_add] = 1                                                                # b = one
     var[4, 1] = 1                                                                          # constant gate of `one`
-    var[4, 2:2 + n_add] = rows                                                             # c = 2 + t  (row 2 + t)
-    # witness: zero, one, then 1, 2, 3, ...
-    wit = torch.zeros((2 + n_add, 4), dtype=torch.int64, device=dev)
-    wit[1, 0] = 1
-    wit[2:, 0] = torch.arange(1, n_add + 1, device=dev)
-    wit = _to_mont_dev(c, wit)
+    if dense_seed is None:
+        # variable index on every (wire, row): 0 = zero, 1 = one, 2 + t = output of the t-th addition
+        var[0, 2:2 + n_add] = torch.where(rows == 2, torch.zeros_like(rows), rows - 1)      # a: previous sum (the first is `zero`)
+        var[1, 2:2 + n_add] = 1                                                            # b = one
+        var[4, 2:2 + n_add] = rows                                                         # c = 2 + t  (row 2 + t)
+        # witness: zero, one, then 1, 2, 3, ...
+        wit = torch.zeros((2 + n_add, 4), dtype=torch.int64, device=dev)
+        wit[1, 0] = 1
+        wit[2:, 0] = torch.arange(1, n_add + 1, device=dev)
+        wit = _to_mont_dev(c, wit)
+    else:
+        assert not ultra, "dense witness: TurboPlonk only"
+        from .params import random_fr_mont
+        t = torch.arange(n_add, device=dev)
+        C0, A0, B0, U0, V0 = 2, 2 + n_add, 2 + 2 * n_add, 2 + 3 * n_add, 2 + 4 * n_add     # variables c_t, a_t (even t), b_t, and the free wires 2, 3
+        odd = (t & 1) == 1
+        var[0, 2:2 + n_add] = torch.where(odd, C0 + t - 1, A0 + t)
+        var[1, 2:2 + n_add] = B0 + t
+        var[2, 2:2 + n_add] = U0 + t
+        var[3, 2:2 + n_add] = V0 + t
+        var[4, 2:2 + n_add] = C0 + t
+        rnd = torch.from_numpy(random_fr_mont(c, 4 * n_add, seed=dense_seed).view(np.int64)).to(dev).reshape(4, n_add, 4)
+        a_even, b = rnd[0], rnd[1]
+        c_even = poly.lincomb(c, [(1, a_even.contiguous()), (1, b.contiguous())])            # c_t = a_t + b_t where a_t is free ...
+        prev = torch.roll(c_even, 1, 0)
+        c_odd = poly.lincomb(c, [(1, prev.contiguous()), (1, b.contiguous())])              # ... and c_t = c_(t-1) + b_t on odd rows (t - 1 is even)
+        cc = torch.where(odd[:, None], c_odd, c_even)
+        wit = torch.zeros((2 + 5 * n_add, 4), dtype=torch.int64, device=dev)
+        wit[1:2] = torch.from_numpy(fr_to_mont(c, [1]).view(np.int64)).to(dev)
+        wit[C0:C0 + n_add], wit[A0:A0 + n_add], wit[B0:B0 + n_add] = cc, a_even, b
+        wit[U0:U0 + n_add], wit[V0:V0 + n_add] = rnd[2], rnd[3]
     wire_values = wit[var.reshape(-1)].reshape(W, n, 4).contiguous()
     one = torch.from_numpy(fr_to_mont(c, [1]).view(np.int64)).to(dev)[0]
     nsel = 14 if ultra else 13

@@ -33,22 +33,29 @@ def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
 
 
 def big_keys(d):
-    """what VERDICT r1 asked the line to carry: the fixed-base table's cost, the table-off figure, the shim-only figure, reps"""
-    pc = d["config"]["precompute"]
+    """what VERDICT r1 / r2 asked the line to carry: the headline on the variable-base path, the fixed-base table path with its
+    cost as a named secondary, the shim-only figure, reps, and a proof from a host-resident and from a dense witness"""
+    assert "VARIABLE-BASE" in d["config"]["workload"] and "precompute" not in d["config"]
+    fb = d["fixed_base"]
+    pc = fb["precompute"]
     assert pc["levels"] >= 1 and pc["table_bytes"] > 0 and pc["build_ms"] > 0
-    vb = d["variable_base"]
-    assert vb["value"] > 0 and vb["same_point_as_table_path"] is True and vb["roofline"]["bound"] == "hbm"
-    assert d["cpu_baseline"]["gpu_variable_base_over_cpu"] > 0
+    assert fb["value"] > 0 and fb["same_point_as_variable_base"] is True and fb["roofline"]["bound"] == "hbm"
+    assert d["cpu_baseline"]["gpu_over_cpu"] > 0
+    assert d["prove"]["from_host_witness_ms"] > 0 and d["prove"]["from_host_witness_same_proof_bytes"] is True and d["prove"]["dense_witness_ms"] > 0
     assert set(d["prove_dropin"]["ms"]) == {"pageable", "pinned", "batch", "four_site"} and all(v > 0 for v in d["prove_dropin"]["ms"].values())
     assert d["prove"]["reps"] == 10 and d["prove"]["min_ms"] <= d["prove"]["prove_ms"] <= d["prove"]["max_ms"] * 1.5
     return True
 
 
 def _two_ranks(extra_args, port):
+    """port = None: `python bench.py --gpus 2` with NO launcher around it, as the driver's command line reads -- bench.py starts its
+    own two workers (bench.self_launch); otherwise wrapped in torch.distributed.run, the contract's other form."""
     env = dict(os.environ, MZK_BENCH_BACKEND="gloo", MZK_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1", "--master-port", str(port),
-           os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-n", "14", "--plonk-log-n", "10", "--ultra-sharded-log-n", "10", "--steps", "2",
-           "--warmup", "1", "--no-cpu-baseline"] + extra_args
+    env.pop("WORLD_SIZE", None)
+    launcher = [] if port is None else ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                                        "--master-port", str(port)]
+    cmd = [sys.executable] + launcher + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-n", "14", "--plonk-log-n", "10", "--ultra-sharded-log-n", "10",
+                                        "--steps", "2", "--warmup", "1", "--no-cpu-baseline"] + extra_args
     out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=env)
     lines = [l for l in out.stdout.splitlines() if l.strip().startswith("{")]
     return out, lines
@@ -58,7 +65,7 @@ def test_bench_two_ranks_rehearsal_and_watchdog(gpu):
     """The N > 1 launch of the contract, rehearsed with two ranks on the one GPU over gloo: one JSON line from rank 0 with the
     whole-job value and the sharded proofs; and with a secondary section that cannot finish in time, the watchdog still prints
     the headline line (the driver's SCALE run must never end without one)."""
-    out, lines = _two_ranks([], 29631)
+    out, lines = _two_ranks([], None)                    # no launcher: bench.py --gpus 2 launches its own workers
     assert out.returncode == 0, out.stderr[-3000:]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])
@@ -69,3 +76,12 @@ def test_bench_two_ranks_rehearsal_and_watchdog(gpu):
     assert len(lines) == 1, (lines, out.stderr[-2000:])
     d = json.loads(lines[0])
     assert d["n_gpus"] == 2 and d["value"] > 0 and "watchdog" in d["prove_sharded"]["error"]
+
+
+def test_self_launch_reports_a_failed_worker(gpu):
+    """`bench.py --gpus 2` without a launcher must end non-zero when a worker does (here: an unknown rehearsal backend)."""
+    env = dict(os.environ, MZK_BENCH_BACKEND="no-such-backend", MZK_BENCH_SINGLE_DEVICE="1")
+    env.pop("WORLD_SIZE", None)
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-n", "12", "--steps", "1", "--warmup", "0", "--no-plonk",
+                          "--no-ntt", "--no-cpu-baseline", "--no-fixed-base", "--no-batch"], capture_output=True, text=True, timeout=300, cwd=ROOT, env=env)
+    assert out.returncode != 0

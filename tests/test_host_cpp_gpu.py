@@ -143,3 +143,30 @@ def test_unsatisfied_witness_is_rejected_by_both_hosts(gpu, mj):
     env = dict(os.environ, MZK_PROVE_CORRUPT_WITNESS="1")
     out = subprocess.run([BIN, "0", "turbo", "64", "0"], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 1 and "WrongQuotientPolyDegree" in out.stderr and "proof_hex" not in out.stdout
+
+
+def test_unsatisfied_witness_at_the_smallest_domain(gpu, mj):
+    """n = 8 = W + 3 (TurboPlonk): the expected quotient degree 5 (n + 1) + 2 = 47 is exactly 6 n - 1, so a polynomial recovered from
+    6 residue classes has degree <= 47 whatever the witness and `WrongQuotientPolyDegree` could never fire.  The class
+    rule therefore keeps all 8 classes there (one spare coefficient is required), and a corrupted witness is rejected by both hosts."""
+    import torch
+    c = mj.params.BLS12_381
+    assert mj.plonk.quotient_classes_needed(5, 8) == list(range(8)) and mj.plonk.quotient_classes_needed(5, 16) == list(range(6))
+    assert mj.plonk.quotient_classes_needed(6, 8) == list(range(8)) and mj.plonk.quotient_classes_needed(6, 16) == list(range(7))
+    cs = mj.snark.gen_circuit_for_bench(c, 16, "TurboPlonk")
+    assert cs.n == 8
+    rng = mj.rng.test_rng()
+    ck = mj.UnivariateProverParam.gen_srs_for_testing(c, mj.rng.fr_rand(c, rng), cs.n + 2)
+    pk = mj.snark.preprocess(ck, cs)
+    mj.snark.prove(rng, cs, pk)
+    bad = cs.wire_values.clone()
+    bad[0, 5] = bad[0, 6]
+    cs.wire_values = bad
+    with pytest.raises(mj.prover.PlonkError) as e:
+        mj.snark.prove(rng, cs, pk)
+    assert e.value.kind == "WrongQuotientPolyDegree"
+    pk.release()
+    ck.release()
+    env = dict(os.environ, MZK_PROVE_CORRUPT_WITNESS="1")
+    out = subprocess.run([BIN, "0", "turbo", "16", "0"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 1 and "WrongQuotientPolyDegree" in out.stderr and "proof_hex" not in out.stdout

@@ -54,8 +54,8 @@ table, plain = collect(("p1", "p2", "p3")), collect(("q1", "q2", "q3"))
 acc_name = next(k for k in table if "msm_accumulate_kernel" in k)
 ntt_name = next(k for k in table if "nttx_pass_kernel" in k)
 out = {"source": "tools/pmc_passes.sh + tools/pmc_aggregate.py: rocprofv3 --kernel-trace --pmc <one group per pass> -- python3 bench.py "
-                 "--steps 2 --warmup 1 --no-cpu-baseline --no-plonk --no-variable-base; separate passes (SQ group, FETCH_SIZE, WRITE_SIZE), "
-                 "p* with the fixed-base table, q* with MZK_BENCH_TABLE=0",
+                 "--steps 2 --warmup 1 --no-cpu-baseline --no-plonk --no-batch; separate passes (SQ group, FETCH_SIZE, WRITE_SIZE), "
+                 "p* = headline (variable base) + fixed_base leg + NTT, q* with MZK_BENCH_TABLE=0 = the variable-base headline alone",
        "source_sha16": stamp,
        "units": "FETCH_SIZE / WRITE_SIZE in KB per launch (mean over launches).  MI355X_MICROARCH.md: on gfx950 FETCH_SIZE reports 1/2 of the "
                 "bytes of a wide coalesced streaming read (NTT passes: 16 B/lane) -- doubled below for the NTT; the MSM gather (16-B loads at "

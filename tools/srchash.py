@@ -6,8 +6,9 @@ import os
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 CSRC = os.path.join(ROOT, "mpc-jellyfish_amd", "csrc")
-MSM_SOURCES = ("msm.cuh", "msm_pre.cuh", "ecx.cuh", "fx.cuh")
-NTT_SOURCES = ("ntt_fx.cuh", "ntt.cuh", "fs.cuh", "fx.cuh")
+# kernels AND what decides their launch geometry / pipeline (the .hip host sides, the generated constants, the build flags)
+MSM_SOURCES = ("msm.cuh", "msm_pre.cuh", "ecx.cuh", "fx.cuh", "msm.hip", "constants.cuh", "Makefile")
+NTT_SOURCES = ("ntt_fx.cuh", "ntt.cuh", "fs.cuh", "fx.cuh", "ntt.hip", "constants.cuh", "Makefile")
 
 
 def sha16(files) -> str:
