@@ -288,6 +288,16 @@ MZK_API int32_t mzk_dev_free(void* dptr);
 MZK_API int32_t mzk_dev_upload(void* dptr, const void* host, uint64_t bytes);
 MZK_API int32_t mzk_dev_download(void* host, const void* dptr, uint64_t bytes);
 MZK_API int32_t mzk_dev_sync(void);
+/* Non-blocking streams of the calling thread's device and asynchronous transfers on them (page-locked host memory: mzk_host_alloc),
+ * for a host that overlaps the upload of witness column k + 1 with the iNTT of column k (the reference gathers the witness on the
+ * host, relation/src/constraint_system.rs:1225-1247).  mzk_stream_wait_stream(waiter, signaller): work enqueued on `waiter` after
+ * this call starts once everything enqueued on `signaller` BEFORE this call has completed (NULL = the null stream). */
+MZK_API int32_t mzk_stream_create(void** out_stream);
+MZK_API int32_t mzk_stream_destroy(void* stream);
+MZK_API int32_t mzk_stream_sync(void* stream);
+MZK_API int32_t mzk_stream_wait_stream(void* waiter, void* signaller);
+MZK_API int32_t mzk_dev_upload_async(void* dptr, const void* host, uint64_t bytes, void* stream);
+MZK_API int32_t mzk_dev_download_async(void* host, const void* dptr, uint64_t bytes, void* stream);
 /* device-to-device copy, 2-D copy (pitches and width in bytes) and byte fill, asynchronous on `stream`: what a host
  * orchestrating device-resident rounds needs between kernels (mpc-jellyfish_amd/host/mzk_host.hpp). */
 MZK_API int32_t mzk_dev_copy(void* dst, const void* src, uint64_t bytes, void* stream);

@@ -835,6 +835,47 @@ int32_t mzk_dev_download(void* host, const void* dptr, uint64_t bytes) {
     HIP_TRY(hipMemcpy(host, dptr, bytes, hipMemcpyDeviceToHost));
     return MZK_OK;
 }
+// streams of the calling thread's device, for hosts that overlap transfers with kernels without HIP of their own
+int32_t mzk_stream_create(void** out_stream) {
+    BIND_CUR();
+    if (!out_stream) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    hipStream_t st = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    *out_stream = st;
+    return MZK_OK;
+}
+int32_t mzk_stream_destroy(void* stream) {
+    BIND_CUR();
+    if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return MZK_OK;
+}
+int32_t mzk_stream_sync(void* stream) {
+    BIND_CUR();
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
+    return MZK_OK;
+}
+int32_t mzk_stream_wait_stream(void* waiter, void* signaller) {
+    BIND_CUR();
+    hipEvent_t ev = nullptr;
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    hipError_t e = hipEventRecord(ev, (hipStream_t)signaller);
+    if (e == hipSuccess) e = hipStreamWaitEvent((hipStream_t)waiter, ev, 0);
+    (void)hipEventDestroy(ev);                                      // released by the runtime once the recorded work has completed
+    if (e != hipSuccess) { set_error(std::string("mzk_stream_wait_stream: ") + hipGetErrorString(e)); return MZK_ERR_HIP; }
+    return MZK_OK;
+}
+int32_t mzk_dev_upload_async(void* dptr, const void* host, uint64_t bytes, void* stream) {
+    BIND_CUR();
+    if (bytes && (!dptr || !host)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    if (bytes) HIP_TRY(hipMemcpyAsync(dptr, host, bytes, hipMemcpyHostToDevice, (hipStream_t)stream));
+    return MZK_OK;
+}
+int32_t mzk_dev_download_async(void* host, const void* dptr, uint64_t bytes, void* stream) {
+    BIND_CUR();
+    if (bytes && (!dptr || !host)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    if (bytes) HIP_TRY(hipMemcpyAsync(host, dptr, bytes, hipMemcpyDeviceToHost, (hipStream_t)stream));
+    return MZK_OK;
+}
 int32_t mzk_dev_sync(void) {
     ENTER_CUR();
     HIP_TRY(hipDeviceSynchronize());

@@ -1,7 +1,10 @@
 // mzk_prove -- PlonkKzgSnark::prove on the reference's bench circuit from a compiled host: C++ above the C ABI of
 // include/mzk.h, no Python, no HIP in this translation unit (g++ builds it).
-//   mzk_prove <curve: 0 BLS12-381 | 1 BN254> <turbo|ultra> <num_gates> [reps] [range_bit_len]
+//   mzk_prove <curve: 0 BLS12-381 | 1 BN254> <turbo|ultra> <num_gates> [reps] [range_bit_len] [--gpus G] [--host-witness] [--check-agree]
 // Prints one JSON line: proof bytes (hex), wall time per proof, per-round times of one profiled proof.
+// --gpus G: G devices driven from this ONE process, one host thread per device (ShardedProver, mzk_prover.hpp): commitments sharded by
+// point range, the quotient by residue class with one device-to-device exchange, rounds 4-5 by coefficient range; same proof bytes.
+// With MZK_VIRTUAL_DEVICES=G in the environment the G device contexts share one card (rehearsal on a one-GPU box).
 //   mzk_prove <curve> link <num_gates_1> <num_gates_2> <alignment> <offset> <size> [reps]
 //   mzk_prove <curve> batch <turbo|ultra> <range_bit_len> <num_gates_1> <num_gates_2> ...
 // PlonkKzgSnark::batch_prove: one aggregated BatchProof over bench circuits of one domain size; prints its bytes.
@@ -15,41 +18,48 @@
 
 using namespace mzk_host;
 
+struct Options {
+    int gpus = 1;                 // --gpus G: G devices from this one process, one host thread each (MZK_VIRTUAL_DEVICES=G: all on one card)
+    bool host_witness = false;    // --host-witness: every proof uploads its wire values from page-locked host memory
+    bool check_agree = false;     // --check-agree: every rank's proof bytes are compared (tests)
+};
+
 template <class C>
-int run(bool ultra, uint64_t num_gates, int reps, int range_bits) {
+int run(bool ultra, uint64_t num_gates, int reps, int range_bits, const Options& opt) {
     using Fr = Fp64<typename C::Fr>;
-    check(mzk_init(-1), "mzk_init");
+    if (opt.gpus == 1) check(mzk_init(-1), "mzk_init");                  // (with several devices each worker thread binds its own)
     auto t0 = std::chrono::steady_clock::now();
-    BenchCircuit<C> cs = BenchCircuit<C>::generate(num_gates, ultra, range_bits);
-    const double circuit_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    BenchCircuitHost<C> host = BenchCircuitHost<C>::generate(num_gates, ultra, range_bits);
     if (std::getenv("MZK_PROVE_CORRUPT_WITNESS"))                       // test hook: wire 0 of row 5 takes the value of row 6 -> gate 5 no longer holds
-        check(mzk_dev_copy(cs.wire_values.at(5), cs.wire_values.at(6), EL, nullptr), "corrupt");
+        host.wires[5] = host.wires[6];
     ChaChaRng rng = test_rng();
     const Fr beta = fr_rand<typename C::Fr>(rng);                       // the SRS trapdoor: first draw of the bench's rng (bench.rs:50-54)
     const auto beta_c = canonical(beta);
-    uint64_t srs = 0;
-    check(mzk_srs_generate_for_testing(C::ID, beta_c.data(), cs.n + 3, &srs), "mzk_srs_generate_for_testing");
+    ShardedProver<C> sp(opt.gpus);
+    double circuit_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     t0 = std::chrono::steady_clock::now();
-    Prover<C> prover(srs, cs);
+    sp.setup(host, beta_c, opt.host_witness);                           // SRS, circuit upload and PlonkKzgSnark::preprocess on every device
     const double preprocess_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
-    Proof<C> proof = prover.prove(rng, cs);                              // the proof whose bytes are printed (and warm-up)
+    Proof<C> proof = sp.prove(rng, false, opt.check_agree);             // the proof whose bytes are printed (and warm-up)
     const std::vector<uint8_t> bytes = proof.serialize_compressed();
     double ms = 0;
     if (reps > 0) {
-        for (int i = 0; i < 2; i++) prover.prove(rng, cs);
-        check(mzk_dev_sync(), "sync");
+        for (int i = 0; i < 2; i++) sp.prove(rng);
+        sp.sync();
         t0 = std::chrono::steady_clock::now();
-        for (int i = 0; i < reps; i++) prover.prove(rng, cs);
-        check(mzk_dev_sync(), "sync");
+        for (int i = 0; i < reps; i++) sp.prove(rng);
+        sp.sync();
         ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
-        prover.prove(rng, cs, true);
+        sp.prove(rng, true);
     }
+    Prover<C>& prover = *sp.prover[0];
     std::string hex;
     static const char* d = "0123456789abcdef";
     for (uint8_t b : bytes) { hex.push_back(d[b >> 4]); hex.push_back(d[b & 15]); }
-    std::printf("{\"curve\": %d, \"plonk_type\": \"%s\", \"num_gates\": %llu, \"log_n\": %d, \"proof_bytes\": %zu, \"prove_ms\": %.3f, "
-                "\"circuit_build_s\": %.3f, \"preprocess_s\": %.3f, \"rounds_ms\": {",
-                C::ID, ultra ? "UltraPlonk" : "TurboPlonk", (unsigned long long)num_gates, cs.log_n, bytes.size(), ms, circuit_s, preprocess_s);
+    std::printf("{\"curve\": %d, \"plonk_type\": \"%s\", \"num_gates\": %llu, \"log_n\": %d, \"gpus\": %d, \"host_witness\": %s, \"proof_bytes\": %zu, "
+                "\"prove_ms\": %.3f, \"circuit_build_s\": %.3f, \"preprocess_s\": %.3f, \"rounds_ms\": {",
+                C::ID, ultra ? "UltraPlonk" : "TurboPlonk", (unsigned long long)num_gates, host.log_n, opt.gpus, opt.host_witness ? "true" : "false",
+                bytes.size(), ms, circuit_s, preprocess_s);
     bool first = true;
     for (auto& kv : prover.timings_ms) { std::printf("%s\"%s\": %.3f", first ? "" : ", ", kv.first.c_str(), kv.second); first = false; }
     std::vector<uint8_t> vk_bytes;                                      // VerifyingKey commitments (selectors, then sigmas), compressed
@@ -58,7 +68,6 @@ int run(bool ultra, uint64_t num_gates, int reps, int range_bits) {
     std::string vk_hex;
     for (uint8_t b : vk_bytes) { vk_hex.push_back(d[b >> 4]); vk_hex.push_back(d[b & 15]); }
     std::printf("}, \"vk_hex\": \"%s\", \"proof_hex\": \"%s\"}\n", vk_hex.c_str(), hex.c_str());
-    (void)mzk_srs_release(srs);
     return 0;
 }
 
@@ -128,8 +137,21 @@ int run_batch(bool ultra, int range_bits, const std::vector<uint64_t>& gates) {
     return 0;
 }
 
-int main(int argc, char** argv) {
-    if (argc < 4) { std::fprintf(stderr, "usage: %s <curve 0|1> <turbo|ultra> <num_gates> [reps] [range_bit_len]\n", argv[0]); return 2; }
+int main(int argc_in, char** argv_in) {
+    // options anywhere on the line; what is left is positional
+    Options opt;
+    std::vector<char*> args;
+    for (int i = 0; i < argc_in; i++) {
+        const std::string a = argv_in[i];
+        if (a == "--gpus" && i + 1 < argc_in) opt.gpus = std::atoi(argv_in[++i]);
+        else if (a == "--host-witness") opt.host_witness = true;
+        else if (a == "--check-agree") opt.check_agree = true;
+        else args.push_back(argv_in[i]);
+    }
+    const int argc = (int)args.size();
+    char** argv = args.data();
+    if (opt.gpus < 1 || opt.gpus > 16) { std::fprintf(stderr, "mzk_prove: --gpus 1..16\n"); return 2; }
+    if (argc < 4) { std::fprintf(stderr, "usage: %s <curve 0|1> <turbo|ultra> <num_gates> [reps] [range_bit_len] [--gpus G] [--host-witness] [--check-agree]\n", argv[0]); return 2; }
     const int curve = std::atoi(argv[1]);
     if (std::string(argv[2]) == "link") {
         if (argc < 8) { std::fprintf(stderr, "usage: %s <curve 0|1> link <num_gates_1> <num_gates_2> <alignment> <offset> <size> [reps]\n", argv[0]); return 2; }
@@ -159,7 +181,7 @@ int main(int argc, char** argv) {
     const uint64_t gates = std::strtoull(argv[3], nullptr, 10);
     const int reps = argc > 4 ? std::atoi(argv[4]) : 0, range_bits = argc > 5 ? std::atoi(argv[5]) : 8;
     try {
-        return curve == 0 ? run<Bls12_381>(ultra, gates, reps, range_bits) : run<Bn254>(ultra, gates, reps, range_bits);
+        return curve == 0 ? run<Bls12_381>(ultra, gates, reps, range_bits, opt) : run<Bn254>(ultra, gates, reps, range_bits, opt);
     } catch (const std::exception& e) {
         std::fprintf(stderr, "mzk_prove: %s\n", e.what());
         return 1;

@@ -1,8 +1,15 @@
 // mzk_prover.hpp -- the reference's bench circuit, PlonkKzgSnark::preprocess and ::prove in C++ above the C ABI
 // (see mzk_host.hpp for the map to the reference).  One instance, TurboPlonk or UltraPlonk.
 #pragma once
+#include <atomic>
 #include <chrono>
+#include <condition_variable>
+#include <exception>
+#include <functional>
 #include <map>
+#include <memory>
+#include <mutex>
+#include <thread>
 #include <tuple>
 
 #include "mzk_host.hpp"
@@ -11,7 +18,7 @@ namespace mzk_host {
 
 constexpr size_t EL = 32;                                              // bytes per scalar-field element
 
-struct DevBuf {
+struct DevBuf {                                                        // memory of the device the allocating thread is bound to
     void* p = nullptr;
     size_t elems = 0;
     DevBuf() = default;
@@ -32,19 +39,74 @@ struct DevBuf {
     }
     void* at(size_t idx) const { return static_cast<uint8_t*>(p) + idx * EL; }
 };
+struct PinnedBuf {                                                     // page-locked host memory (mzk_host_alloc): asynchronous DMA
+    void* p = nullptr;
+    size_t bytes = 0;
+    PinnedBuf() = default;
+    PinnedBuf(const PinnedBuf&) = delete;
+    PinnedBuf& operator=(const PinnedBuf&) = delete;
+    PinnedBuf(PinnedBuf&& o) noexcept : p(o.p), bytes(o.bytes) { o.p = nullptr; o.bytes = 0; }
+    ~PinnedBuf() { if (p) (void)mzk_host_free(p); }
+    void alloc(size_t b) { if (p) (void)mzk_host_free(p); p = nullptr; bytes = b; check(mzk_host_alloc(b ? b : 1, &p), "mzk_host_alloc"); }
+};
+
+// ---- several GPUs from one process: one host thread per device, SPMD ---------------------------------
+// The reference is ONE process calling `prove` once, with Rayon inside (univariate_kzg/mod.rs:125-127, prover.rs:552-562).  Here
+// the G device threads of a ShardedProver all run the same `prove`, each on its own device context of libmi355zk, and meet in
+// this communicator -- barriers and all-gathers of a few hundred bytes through host memory (Jacobian partials of 144 B, field
+// elements of 32 B: no collective library needed); bulk data moves device to device (mzk_dev_copy_peer).
+inline std::pair<uint64_t, uint64_t> shard_range(uint64_t n, int rank, int world) {      // contiguous share of n points; the first n % world ranks take one more
+    const uint64_t base = n / world, extra = n % world, r = (uint64_t)rank;
+    const uint64_t lo = r * base + std::min(r, extra);
+    return {lo, lo + base + (r < extra ? 1 : 0)};
+}
+inline std::vector<uint32_t> class_range(int rank, int world, uint32_t n_classes) {      // residue classes of the quotient domain owned by `rank`
+    const uint32_t per = (n_classes + world - 1) / world;
+    std::vector<uint32_t> out;
+    for (uint32_t k = std::min<uint32_t>(rank * per, n_classes); k < std::min<uint32_t>((rank + 1) * per, n_classes); k++) out.push_back(k);
+    return out;
+}
+struct LocalComm {
+    const int G;
+    std::atomic<int> arrived{0};
+    std::atomic<uint64_t> gen{0};
+    std::atomic<bool> aborted{false};
+    std::vector<std::vector<uint8_t>> slot;
+    explicit LocalComm(int g) : G(g), slot(g) {}
+    void reset() { arrived = 0; aborted = false; }
+    void abort() { aborted = true; }
+    void barrier() {
+        if (G == 1) return;
+        const uint64_t my = gen.load();
+        if (arrived.fetch_add(1) + 1 == G) { arrived = 0; gen.fetch_add(1); return; }
+        for (int spins = 0; gen.load() == my; spins++) {
+            if (aborted.load()) throw std::runtime_error("another device thread failed");
+            if (spins > 4000) std::this_thread::yield();
+        }
+    }
+    // every rank's `bytes` bytes, concatenated in rank order
+    std::vector<uint8_t> all_gather(int rank, const void* data, size_t bytes) {
+        slot[rank].assign(static_cast<const uint8_t*>(data), static_cast<const uint8_t*>(data) + bytes);
+        barrier();
+        std::vector<uint8_t> out;
+        out.reserve(bytes * G);
+        for (int g = 0; g < G; g++) out.insert(out.end(), slot[g].begin(), slot[g].end());
+        barrier();                                                     // nobody overwrites a slot before everybody has read it
+        return out;
+    }
+};
 
 template <class C>
-struct BenchCircuit {                                                  // what Arithmetization exposes of the finalised circuit
+struct BenchCircuitHost {                                              // the finalised circuit in HOST memory (what Arithmetization holds)
     using Fr = Fp64<typename C::Fr>;
     bool ultra = false;
     int log_n = 0, W = 5, nsel = 13;
     uint64_t n = 0;
-    std::vector<Fr> k;
-    DevBuf wire_values, selector_values, sigma_values, table_values;   // W x n, nsel x n, W x n, 4 x n (UltraPlonk)
+    std::vector<Fr> k, wires, selectors, sigmas, tables;              // W x n, nsel x n, W x n, 4 x n (UltraPlonk)
 
     // plonk/benches/bench.rs:29-46 through PlonkCircuit::new, Circuit::add and finalize_for_arithmetization
-    static BenchCircuit generate(uint64_t num_gates, bool ultra, int range_bit_len = 8) {
-        BenchCircuit cs;
+    static BenchCircuitHost generate(uint64_t num_gates, bool ultra, int range_bit_len = 8) {
+        BenchCircuitHost cs;
         cs.ultra = ultra;
         cs.W = ultra ? 6 : 5;
         cs.nsel = ultra ? 14 : 13;
@@ -70,17 +132,14 @@ struct BenchCircuit {                                                  // what A
         witness[1] = one;
         if (n_vars > 2) witness[2] = one;
         for (size_t v = 3; v < n_vars; v++) witness[v] = witness[v - 1] + one;
-        std::vector<Fr> buf((size_t)W * n);
-        for (size_t i = 0; i < buf.size(); i++) buf[i] = witness[var[i]];
-        cs.wire_values.alloc(buf.size());
-        check(mzk_dev_upload(cs.wire_values.p, buf.data(), buf.size() * EL), "upload wires");
+        cs.wires.resize((size_t)W * n);
+        for (size_t i = 0; i < cs.wires.size(); i++) cs.wires[i] = witness[var[i]];
         // selectors: AdditionGate q_lc = [1,1,0,0], q_o = 1; ConstantGate q_c = value, q_o = 1; PaddingGate all zero
-        std::vector<Fr> sel((size_t)cs.nsel * n, Fr::zero());
+        std::vector<Fr>& sel = cs.selectors;
+        sel.assign((size_t)cs.nsel * n, Fr::zero());
         for (uint64_t row = 2; row < 2 + n_add; row++) sel[0 * n + row] = sel[1 * n + row] = one;
         for (uint64_t row = 0; row < 2 + n_add; row++) sel[10 * n + row] = one;
         sel[11 * n + 1] = one;
-        cs.selector_values.alloc(sel.size());
-        check(mzk_dev_upload(cs.selector_values.p, sel.data(), sel.size() * EL), "upload selectors");
         // wire permutation (constraint_system.rs:743-778): the occurrences of a variable, in (wire, row) order, form a cycle
         std::vector<uint32_t> cnt(n_vars + 1, 0);
         for (uint32_t v : var) cnt[v + 1]++;
@@ -98,17 +157,50 @@ struct BenchCircuit {                                                  // what A
         for (uint64_t j = 0; j < n; j++) { ext[j] = cur; cur = cur * w; }
         for (int i = 1; i < W; i++)
             for (uint64_t j = 0; j < n; j++) ext[(size_t)i * n + j] = cs.k[i] * ext[j];
-        for (size_t i = 0; i < buf.size(); i++) buf[i] = ext[perm[i]];
-        cs.sigma_values.alloc(buf.size());
-        check(mzk_dev_upload(cs.sigma_values.p, buf.data(), buf.size() * EL), "upload sigma");
+        cs.sigmas.resize((size_t)W * n);
+        for (size_t i = 0; i < cs.sigmas.size(); i++) cs.sigmas[i] = ext[perm[i]];
         if (ultra) {
-            std::vector<Fr> tab((size_t)4 * n, Fr::zero());
+            cs.tables.assign((size_t)4 * n, Fr::zero());
             Fr v = Fr::zero();
-            for (uint64_t i = 0; i < (1ull << range_bit_len); i++) { tab[i] = v; v = v + one; }       // compute_range_table (:1423-1438)
-            cs.table_values.alloc(tab.size());
-            check(mzk_dev_upload(cs.table_values.p, tab.data(), tab.size() * EL), "upload tables");
+            for (uint64_t i = 0; i < (1ull << range_bit_len); i++) { cs.tables[i] = v; v = v + one; }   // compute_range_table (:1423-1438)
         }
         return cs;
+    }
+};
+
+template <class C>
+struct BenchCircuit {                                                  // ... and on one device (the thread's current one)
+    using Fr = Fp64<typename C::Fr>;
+    bool ultra = false;
+    int log_n = 0, W = 5, nsel = 13;
+    uint64_t n = 0;
+    std::vector<Fr> k;
+    DevBuf wire_values, selector_values, sigma_values, table_values;   // W x n, nsel x n, W x n, 4 x n (UltraPlonk)
+    // host_witness: the wire values of every proof start in page-locked HOST memory, as the reference holds its witness
+    // (constraint_system.rs:1225-1247); round 1 uploads them, column k + 1 under the iNTT of column k
+    PinnedBuf host_wires;
+    bool host_witness = false;
+
+    static BenchCircuit upload(const BenchCircuitHost<C>& h, bool host_witness = false) {
+        BenchCircuit cs;
+        cs.ultra = h.ultra; cs.log_n = h.log_n; cs.W = h.W; cs.nsel = h.nsel; cs.n = h.n; cs.k = h.k;
+        auto up = [](DevBuf& d, const std::vector<Fr>& v, const char* what) {
+            d.alloc(v.size());
+            check(mzk_dev_upload(d.p, v.data(), v.size() * EL), what);
+        };
+        up(cs.wire_values, h.wires, "upload wires");
+        up(cs.selector_values, h.selectors, "upload selectors");
+        up(cs.sigma_values, h.sigmas, "upload sigma");
+        if (h.ultra) up(cs.table_values, h.tables, "upload tables");
+        if (host_witness) {
+            cs.host_witness = true;
+            cs.host_wires.alloc(h.wires.size() * EL);
+            std::memcpy(cs.host_wires.p, h.wires.data(), h.wires.size() * EL);
+        }
+        return cs;
+    }
+    static BenchCircuit generate(uint64_t num_gates, bool ultra, int range_bit_len = 8) {
+        return upload(BenchCircuitHost<C>::generate(num_gates, ultra, range_bit_len));
     }
 };
 
@@ -150,7 +242,7 @@ enum PlookupEval { RANGE_TABLE, KEY_TABLE, TABLE_DOM_SEP, Q_DOM_SEP, H_1, Q_LOOK
                    H_1_NEXT, H_2_NEXT, Q_LOOKUP_NEXT, W_3_NEXT, W_4_NEXT, N_PLOOKUP_EVALS };
 
 template <class C>
-struct Prover {                                                        // ProvingKey on the device + Prover of prover.rs
+struct Prover {                                                        // ProvingKey on ONE device + Prover of prover.rs
     using E = Encoding<C>;
     using Fr = typename E::Fr;
     using Affine = typename E::Affine;
@@ -162,19 +254,29 @@ struct Prover {                                                        // Provin
     uint64_t n, m;
     std::vector<Fr> k;
     uint64_t srs = 0, pk = 0;
+    // several devices: this prover is rank `rank` of `world`; it commits over the SRS points [lo, hi) of every
+    // polynomial (one fixed partition of the n + 3 powers), owns the residue classes `own` of the quotient domain, and runs rounds
+    // 4-5 on its coefficient range.  world == 1: lo = 0, hi = n + 3, every class.
+    int rank = 0, world = 1;
+    LocalComm* comm = nullptr;
+    uint64_t lo = 0, hi = 0;
     DevBuf fixed;                                                      // (nsel + W [+ 4]) x n coefficient forms
-    DevBuf slab, quot, keep, coeff, split, lin, batch, opening, shifted, hh, table, lookup, sorted, tmp, deg, rem;
-    std::vector<uint32_t> classes;
+    DevBuf slab, quot, coeff, split, lin, batch, opening, shifted, hh, table, lookup, sorted, tmp, deg, rem, wv;
+    std::vector<uint32_t> classes, own;                                // the classes that determine the quotient; this rank's share of them
+    std::vector<void*> peer_rem;                                       // `rem` of every rank (device pointers), for the one exchange
+    void* copy_stream = nullptr;
     std::vector<Affine> selector_comms, sigma_comms;
     std::map<std::string, double> timings_ms;
     Fr w_n, gen;
 
     // PlonkKzgSnark::preprocess (snark.rs:529-617)
-    Prover(uint64_t srs_handle, const BenchCircuit<C>& cs)
-        : ultra(cs.ultra), log_n(cs.log_n), W(cs.W), nsel(cs.nsel), rows(cs.W + 2 + (cs.ultra ? 3 : 0)), n(cs.n), m(8 * cs.n), k(cs.k), srs(srs_handle) {
+    Prover(uint64_t srs_handle, const BenchCircuit<C>& cs, int rank_ = 0, int world_ = 1, LocalComm* comm_ = nullptr)
+        : ultra(cs.ultra), log_n(cs.log_n), W(cs.W), nsel(cs.nsel), rows(cs.W + 2 + (cs.ultra ? 3 : 0)), n(cs.n), m(8 * cs.n), k(cs.k), srs(srs_handle),
+          rank(rank_), world(world_), comm(comm_) {
         uint64_t srs_len = 0;
         check(mzk_srs_len(srs, &srs_len), "mzk_srs_len");
         if (srs_len < n + 3) throw std::runtime_error("SRS too small: need domain size + 3 powers (srs.rs:88)");
+        std::tie(lo, hi) = shard_range(n + 3, rank, world);            // the proving key keeps trim(n + 2) = n + 3 powers (snark.rs:535, 561)
         const int nfix = nsel + W + (ultra ? 4 : 0);
         fixed.alloc((size_t)nfix * n);
         check(mzk_dev_copy(fixed.p, cs.selector_values.p, (size_t)nsel * n * EL, nullptr), "copy");
@@ -193,39 +295,118 @@ struct Prover {                                                        // Provin
         classes.clear();
         const uint32_t needed = ((uint64_t)W * (n + 1) + 2 < (uint64_t)(W + 1) * n - 1 && W + 1 <= 8) ? (uint32_t)W + 1 : 8u;
         for (uint32_t kcl = 0; kcl < needed; kcl++) classes.push_back(kcl);
-        check(mzk_plonk_pk_register_chunked(C::ID, log_n, W, sel, sig, ultra ? sig + (size_t)W * n * 4 : nullptr, n, kk.data(), classes.data(),
-                                            (uint32_t)classes.size(), &pk), "mzk_plonk_pk_register_chunked");
-        rem.alloc(classes.size() * n);
-        slab.alloc((size_t)rows * m); quot.alloc(m); keep.alloc((size_t)rows * (n + 3)); coeff.alloc((size_t)(W + 1) * n);
-        split.alloc((size_t)W * (n + 3)); lin.alloc(n + 3); batch.alloc(n + 3); opening.alloc(n + 3); shifted.alloc(n + 3); tmp.alloc(64);
+        own = class_range(rank, world, needed);                          // contiguous blocks of ceil(needed / world); the last ranks may own none
+        // a rank that owns no class still registers one (a key cannot be empty); it is never evaluated
+        const std::vector<uint32_t> resident = own.empty() ? std::vector<uint32_t>{classes.back()} : own;
+        check(mzk_plonk_pk_register_chunked(C::ID, log_n, W, sel, sig, ultra ? sig + (size_t)W * n * 4 : nullptr, n, kk.data(), resident.data(),
+                                            (uint32_t)resident.size(), &pk), "mzk_plonk_pk_register_chunked");
+        rem.alloc(classes.size() * n);                                   // the remainders of ALL needed classes: own ones computed here, the others received
+        // the class-wise quotient reads the coefficient rows without overwriting them: n + 3 columns per row, no second copy
+        slab.alloc((size_t)rows * (n + 3)); quot.alloc(m); coeff.alloc((size_t)(W + 1) * n);
+        split.alloc((size_t)W * (n + 3)); lin.alloc(n + 3); batch.alloc(n + 4); opening.alloc(n + 3); shifted.alloc(n + 3); tmp.alloc(64);
         if (ultra) { hh.alloc(2 * n); table.alloc(n); lookup.alloc(n); sorted.alloc(2 * n); }
         w_n = root_of_unity<FrP>(log_n);
         gen = Fr::from_words(FrP::GENERATOR);
-        // verifying-key commitments (snark.rs:562-594)
+        // verifying-key commitments (snark.rs:562-594): whole MSMs on this device (set-up work, replicated on every rank)
         std::vector<const void*> ptrs;
         std::vector<uint64_t> lens;
         for (int i = 0; i < nsel + W; i++) { ptrs.push_back(fixed.at((size_t)i * n)); lens.push_back(n); }
-        auto comms = commit(ptrs, lens);
+        auto comms = to_affine(msm_partials(ptrs, lens, 0, n + 3));
         selector_comms.assign(comms.begin(), comms.begin() + nsel);
         sigma_comms.assign(comms.begin() + nsel, comms.end());
     }
-    ~Prover() { if (pk) (void)mzk_plonk_pk_release(pk); }
+    ~Prover() {
+        if (pk) (void)mzk_plonk_pk_release(pk);
+        if (copy_stream) (void)mzk_stream_destroy(copy_stream);
+    }
 
-    // UnivariateKzgPCS::batch_commit (mod.rs:119-131) on device-resident coefficient vectors
-    std::vector<Affine> commit(const std::vector<const void*>& polys, const std::vector<uint64_t>& lens) {
+    // Jacobian sums of the coefficients [a, b) of every polynomial over the SRS points of the same indices
+    std::vector<uint64_t> msm_partials(const std::vector<const void*>& polys, const std::vector<uint64_t>& lens, uint64_t a, uint64_t b) {
         const uint32_t kpolys = (uint32_t)polys.size();
-        std::vector<uint64_t> xyz((size_t)kpolys * 3 * QL), xy((size_t)kpolys * 2 * QL);
-        check(mzk_msm_batch_dev(srs, kpolys, polys.data(), lens.data(), nullptr, 1, xyz.data(), nullptr), "mzk_msm_batch_dev");
+        std::vector<const void*> p(kpolys);
+        std::vector<uint64_t> l(kpolys), off(kpolys), xyz((size_t)kpolys * 3 * QL);
+        for (uint32_t i = 0; i < kpolys; i++) {
+            const uint64_t s0 = std::min(a, lens[i]), s1 = std::min(b, lens[i]);
+            p[i] = static_cast<const uint8_t*>(polys[i]) + s0 * EL;
+            l[i] = s1 - s0;
+            off[i] = s1 > s0 ? s0 : a;
+        }
+        check(mzk_msm_batch_dev(srs, kpolys, p.data(), l.data(), off.data(), 1, xyz.data(), nullptr), "mzk_msm_batch_dev");
+        return xyz;
+    }
+    std::vector<Affine> to_affine(const std::vector<uint64_t>& xyz) const {
+        const size_t kpolys = xyz.size() / (3 * QL);
+        std::vector<uint64_t> xy(kpolys * 2 * QL);
         check(mzk_g1_jacobian_to_affine(C::ID, xyz.data(), kpolys, xy.data()), "mzk_g1_jacobian_to_affine");
         std::vector<Affine> out(kpolys);
-        for (uint32_t i = 0; i < kpolys; i++) std::memcpy(out[i].data(), &xy[(size_t)i * 2 * QL], sizeof(Affine));
+        for (size_t i = 0; i < kpolys; i++) std::memcpy(out[i].data(), &xy[i * 2 * QL], sizeof(Affine));
         return out;
+    }
+    // the ranks' partial sums -> the commitments, identical on every rank: all-gather of k x 144 B (96 B on BN254) through host
+    // memory and <= 8 EC additions per commitment on the host (mzk_g1_sum_jacobian) -- the "all-reduce of partial EC sums"
+    std::vector<Affine> combine_partials(const std::vector<uint64_t>& part) {
+        if (world == 1) return to_affine(part);
+        const size_t kpolys = part.size() / (3 * QL), one = 3 * QL;
+        const std::vector<uint8_t> all = comm->all_gather(rank, part.data(), part.size() * 8);
+        const uint64_t* a = reinterpret_cast<const uint64_t*>(all.data());
+        std::vector<uint64_t> sum(kpolys * one), col((size_t)world * one);
+        for (size_t i = 0; i < kpolys; i++) {
+            for (int g = 0; g < world; g++) std::memcpy(&col[g * one], a + ((size_t)g * kpolys + i) * one, one * 8);
+            check(mzk_g1_sum_jacobian(C::ID, col.data(), world, &sum[i * one]), "mzk_g1_sum_jacobian");
+        }
+        return to_affine(sum);
+    }
+    // UnivariateKzgPCS::batch_commit (mod.rs:119-131) on device-resident coefficient vectors; over several ranks every MSM is
+    // sharded by point range (this rank: [lo, hi))
+    std::vector<Affine> commit(const std::vector<const void*>& polys, const std::vector<uint64_t>& lens) {
+        return combine_partials(msm_partials(polys, lens, lo, hi));
+    }
+    // ... of polynomials of which this rank holds ONLY the coefficients [lo, lo + lens[i])
+    std::vector<Affine> commit_slices(const std::vector<const void*>& slices, const std::vector<uint64_t>& lens) {
+        const uint32_t kpolys = (uint32_t)slices.size();
+        std::vector<uint64_t> off(kpolys, lo), xyz((size_t)kpolys * 3 * QL);
+        check(mzk_msm_batch_dev(srs, kpolys, slices.data(), lens.data(), off.data(), 1, xyz.data(), nullptr), "mzk_msm_batch_dev");
+        return combine_partials(xyz);
     }
     std::vector<Fr> evaluate(const void* d, uint64_t len, uint32_t batch_n, uint64_t stride, const Fr& x) {
         std::vector<Fr> out(batch_n);
         check(mzk_poly_eval_dev(C::ID, d, len, batch_n, stride, x.l, reinterpret_cast<uint64_t*>(out.data()), nullptr), "mzk_poly_eval_dev");
         return out;
     }
+    // evaluations of one round, collected and finished together.  Over several ranks every rank evaluates its coefficient range
+    // [lo, hi) of each polynomial -- sum_{j in range} c_j x^j = x^lo * (the range read as a polynomial of its own) -- and ONE
+    // all-gather of the partial values (32 bytes each) at the end of the round gives every rank all the sums.
+    struct EvalBatch {
+        Prover& P;
+        std::vector<Fr> vals;
+        explicit EvalBatch(Prover& p) : P(p) {}
+        size_t add(const void* d, uint64_t len, uint32_t batch_n, uint64_t stride, const Fr& x) {
+            const size_t at = vals.size();
+            if (P.world == 1) {
+                for (auto& v : P.evaluate(d, len, batch_n, stride, x)) vals.push_back(v);
+                return at;
+            }
+            const uint64_t a = std::min(P.lo, len), b = std::min(P.hi, len);
+            if (b > a) {
+                const Fr xa = pow_u64(x, a);
+                for (auto& v : P.evaluate(static_cast<const uint8_t*>(d) + a * EL, b - a, batch_n, stride, x)) vals.push_back(v * xa);
+            } else {
+                for (uint32_t i = 0; i < batch_n; i++) vals.push_back(Fr::zero());
+            }
+            return at;
+        }
+        void finish() {
+            if (P.world == 1) return;
+            const std::vector<uint8_t> all = P.comm->all_gather(P.rank, vals.data(), vals.size() * sizeof(Fr));
+            const Fr* a = reinterpret_cast<const Fr*>(all.data());
+            const size_t cnt = vals.size();
+            for (size_t i = 0; i < cnt; i++) {
+                Fr sum = Fr::zero();
+                for (int g = 0; g < P.world; g++) sum = sum + a[(size_t)g * cnt + i];
+                vals[i] = sum;
+            }
+        }
+    };
     struct Term { Fr s; const void* p; uint64_t len; };
     void lincomb(const std::vector<Term>& terms, void* out, uint64_t out_len) {
         std::vector<const void*> ptrs;
@@ -237,7 +418,7 @@ struct Prover {                                                        // Provin
         std::vector<void*> ptrs;
         std::vector<uint64_t> b;
         for (size_t i = 0; i < slab_rows.size(); i++) {
-            ptrs.push_back(slab.at((size_t)slab_rows[i] * m));
+            ptrs.push_back(row(slab_rows[i]));
             for (auto& v : blinders[i]) for (int q = 0; q < 4; q++) b.push_back(v.l[q]);
         }
         check(mzk_poly_mask_dev(C::ID, (uint32_t)ptrs.size(), ptrs.data(), n, (uint32_t)blinders[0].size(), b.data(), nullptr), "mzk_poly_mask_dev");
@@ -255,6 +436,7 @@ struct Prover {                                                        // Provin
     struct State {
         Blinds b;
         const BenchCircuit<C>* cs = nullptr;
+        const void* wire_values = nullptr;                               // W x n wire evaluations on this device
         Fr tau, beta, gamma, alpha, zeta;
         std::vector<Fr> wires_evals, wire_sigma_evals, plookup_evals;
         Fr perm_next_eval;
@@ -263,8 +445,10 @@ struct Prover {                                                        // Provin
     int rowPI() const { return W + 1; }
     int rowH1() const { return W + 2; }
     int rowPL() const { return W + 4; }
-    void* row(int r) const { return slab.at((size_t)r * m); }
-    void* krow(int r) const { return keep.at((size_t)r * (n + 3)); }
+    // one slab: rows 0..W-1 wires, W z, W+1 public input (, h_1, h_2, Plookup product), n + 3 coefficient slots each; the rounds read
+    // their polynomials from here from round 1 to the openings
+    void* row(int r) const { return slab.at((size_t)r * (n + 3)); }
+    void* krow(int r) const { return row(r); }
     void* fix(int r) const { return fixed.at((size_t)r * n); }
 
     void append_vk_and_pub_input(StandardTranscript<C>& tr) const {       // transcript/mod.rs:45-104; the bench circuit has no public input
@@ -280,11 +464,27 @@ struct Prover {                                                        // Provin
         st = State();
         st.cs = &cs;
         st.b = std::move(blinds);
-        check(mzk_dev_copy(coeff.p, cs.wire_values.p, (size_t)W * n * EL, nullptr), "copy");
         check(mzk_dev_memset(coeff.at((size_t)W * n), 0, n * EL, nullptr), "memset");                        // the bench circuit has no public input
-        check(mzk_ntt_dev(C::ID, coeff.p, n, log_n, 1, nullptr, W + 1, n, nullptr), "mzk_ntt_dev");
+        if (!cs.host_witness) {
+            st.wire_values = cs.wire_values.p;
+            check(mzk_dev_copy(coeff.p, cs.wire_values.p, (size_t)W * n * EL, nullptr), "copy");
+            check(mzk_ntt_dev(C::ID, coeff.p, n, log_n, 1, nullptr, W + 1, n, nullptr), "mzk_ntt_dev");
+        } else {
+            // host-resident witness (constraint_system.rs:1225-1247 gathers it on the host): column i + 1 crosses PCIe on a copy
+            // stream while column i is transformed on the null stream
+            if (!wv.p) { wv.alloc((size_t)W * n); check(mzk_stream_create(&copy_stream), "mzk_stream_create"); }
+            st.wire_values = wv.p;
+            check(mzk_stream_wait_stream(copy_stream, nullptr), "wait");                                     // the previous proof is done with `wv`
+            check(mzk_ntt_dev(C::ID, coeff.at((size_t)W * n), n, log_n, 1, nullptr, 1, n, nullptr), "mzk_ntt_dev");
+            for (int i = 0; i < W; i++) {
+                check(mzk_dev_upload_async(wv.at((size_t)i * n), static_cast<const uint8_t*>(cs.host_wires.p) + (size_t)i * n * EL, n * EL, copy_stream), "upload");
+                check(mzk_stream_wait_stream(nullptr, copy_stream), "wait");                                 // columns 0..i have arrived
+                check(mzk_dev_copy(coeff.at((size_t)i * n), wv.at((size_t)i * n), n * EL, nullptr), "copy");
+                check(mzk_ntt_dev(C::ID, coeff.at((size_t)i * n), n, log_n, 1, nullptr, 1, n, nullptr), "mzk_ntt_dev");
+            }
+        }
         for (int r = 0; r < rows; r++) check(mzk_dev_memset(static_cast<uint8_t*>(row(r)) + n * EL, 0, 3 * EL, nullptr), "memset");
-        check(mzk_dev_copy2d(slab.p, m * EL, coeff.p, n * EL, n * EL, W, nullptr), "copy2d");
+        check(mzk_dev_copy2d(slab.p, (n + 3) * EL, coeff.p, n * EL, n * EL, W, nullptr), "copy2d");
         check(mzk_dev_copy(row(rowPI()), coeff.at((size_t)W * n), n * EL, nullptr), "copy");
         { std::vector<int> rs; for (int i = 0; i < W; i++) rs.push_back(i); mask(rs, st.b.wires); }
         tick.mark("r1_ntt_mask");
@@ -299,11 +499,11 @@ struct Prover {                                                        // Provin
         st.tau = tau;
         if (!ultra) return {};
         const int H1 = rowH1();
-        check(mzk_plookup_sorted_vec_dev(pk, st.cs->wire_values.p, tau.l, table.p, lookup.p, sorted.p, nullptr), "mzk_plookup_sorted_vec_dev");
+        check(mzk_plookup_sorted_vec_dev(pk, st.wire_values, tau.l, table.p, lookup.p, sorted.p, nullptr), "mzk_plookup_sorted_vec_dev");
         check(mzk_dev_copy(hh.p, sorted.p, n * EL, nullptr), "copy");
         check(mzk_dev_copy(hh.at(n), sorted.at(n - 1), n * EL, nullptr), "copy");
         check(mzk_ntt_dev(C::ID, hh.p, n, log_n, 1, nullptr, 2, n, nullptr), "mzk_ntt_dev");
-        check(mzk_dev_copy2d(row(H1), m * EL, hh.p, n * EL, n * EL, 2, nullptr), "copy2d");
+        check(mzk_dev_copy2d(row(H1), (n + 3) * EL, hh.p, n * EL, n * EL, 2, nullptr), "copy2d");
         mask({H1, H1 + 1}, st.b.h);
         tick.mark("r1_5_sorted_vec");
         auto comms = commit({row(H1), row(H1 + 1)}, {n + 3, n + 3});
@@ -313,7 +513,7 @@ struct Prover {                                                        // Provin
     // round 2 (prover.rs:125-141)
     Affine round2(const Fr& beta, const Fr& gamma, Tick& tick) {
         st.beta = beta; st.gamma = gamma;
-        check(mzk_plonk_perm_product_dev(pk, st.cs->wire_values.p, beta.l, gamma.l, coeff.p, nullptr), "mzk_plonk_perm_product_dev");
+        check(mzk_plonk_perm_product_dev(pk, st.wire_values, beta.l, gamma.l, coeff.p, nullptr), "mzk_plonk_perm_product_dev");
         check(mzk_dev_copy(row(rowZ()), coeff.p, n * EL, nullptr), "copy");
         mask({rowZ()}, {st.b.z});
         tick.mark("r2_product");
@@ -334,10 +534,23 @@ struct Prover {                                                        // Provin
     // this instance's quotient polynomial, 8n coefficients into `quot` (prover.rs:512-673 without the sum over instances)
     void quotient(const Fr& alpha, Tick& tick) {
         st.alpha = alpha;
-        check(mzk_dev_copy2d(keep.p, (n + 3) * EL, slab.p, m * EL, (n + 3) * EL, rows, nullptr), "copy2d");   // coefficient forms survive the in-place coset NTT
-        // per class: fold mod X^n - h_k^n, size-n coset NTTs, the fused kernel, size-n inverse coset NTT; then the inverse Vandermonde
-        check(mzk_plonk_quotient_chunked_dev(pk, slab.p, m, n + 3, ultra ? st.tau.l : nullptr, alpha.l, st.beta.l, st.gamma.l, rem.p, nullptr),
-              "mzk_plonk_quotient_chunked_dev");
+        // per OWN class: fold mod X^n - h_k^n, size-n coset NTTs, the fused kernel, size-n inverse coset NTT -> t mod (X^n - h_k^n), straight
+        // into this class's slot of `rem` (the rows of the slab are read, not overwritten)
+        if (!own.empty())
+            check(mzk_plonk_quotient_chunked_dev(pk, slab.p, n + 3, n + 3, ultra ? st.tau.l : nullptr, alpha.l, st.beta.l, st.gamma.l,
+                                                 rem.at((size_t)own[0] * n), nullptr), "mzk_plonk_quotient_chunked_dev");
+        if (world > 1) {
+            // THE one exchange: every rank pushes its class remainders into the same slots of every other rank's
+            // `rem`, device to device (xGMI peer copies; n x 32 B per class and peer), then all ranks meet
+            if (!own.empty())
+                for (int q = 0; q < world; q++)
+                    if (q != rank)
+                        check(mzk_dev_copy_peer(static_cast<uint8_t*>(peer_rem[q]) + (size_t)own[0] * n * EL, q, rem.at((size_t)own[0] * n), rank,
+                                                own.size() * n * EL, nullptr), "mzk_dev_copy_peer");
+            check(mzk_dev_sync(), "mzk_dev_sync");
+            comm->barrier();
+        }
+        // the inverse Vandermonde per coefficient index (replicated: every rank needs the quotient's coefficients for the split)
         check(mzk_plonk_quotient_combine_classes_dev(C::ID, log_n, classes.data(), (uint32_t)classes.size(), rem.p, quot.p, nullptr),
               "mzk_plonk_quotient_combine_classes_dev");
         tick.mark("r3_quotient");
@@ -387,25 +600,38 @@ struct Prover {                                                        // Provin
         st.zeta = zeta;
         const Fr zeta_w = zeta * w_n;
         const int sigma0 = nsel, tab0 = nsel + W, H1 = rowH1(), PL = rowPL();
-        st.wires_evals = evaluate(keep.p, n + 2, W, n + 3, zeta);
-        st.wire_sigma_evals = evaluate(fix(sigma0), n, W - 1, n, zeta);
-        st.perm_next_eval = evaluate(krow(rowZ()), n + 3, 1, n + 3, zeta_w)[0];
+        EvalBatch ev(*this);
+        const size_t h_w = ev.add(krow(0), n + 2, W, n + 3, zeta);
+        const size_t h_s = ev.add(fix(sigma0), n, W - 1, n, zeta);
+        const size_t h_z = ev.add(krow(rowZ()), n + 3, 1, n + 3, zeta_w);
+        size_t h_tz = 0, h_tn = 0, h_h1 = 0, h_ql = 0, h_qln = 0, h_pl = 0, h_hn = 0, h_wn = 0;
+        if (ultra) {
+            h_tz = ev.add(fix(tab0), n, 4, n, zeta);                                                           // range, key, table_dom_sep, q_dom_sep
+            h_tn = ev.add(fix(tab0), n, 3, n, zeta_w);
+            h_h1 = ev.add(krow(H1), n + 3, 1, n + 3, zeta);
+            h_ql = ev.add(fix(13), n, 1, n, zeta);
+            h_qln = ev.add(fix(13), n, 1, n, zeta_w);
+            h_pl = ev.add(krow(PL), n + 3, 1, n + 3, zeta_w);
+            h_hn = ev.add(krow(H1), n + 3, 2, n + 3, zeta_w);
+            h_wn = ev.add(krow(3), n + 2, 2, n + 3, zeta_w);
+        }
+        ev.finish();
+        const std::vector<Fr>& v = ev.vals;
+        st.wires_evals.assign(v.begin() + h_w, v.begin() + h_w + W);
+        st.wire_sigma_evals.assign(v.begin() + h_s, v.begin() + h_s + W - 1);
+        st.perm_next_eval = v[h_z];
         std::vector<Fr>& pe = st.plookup_evals;
         pe.clear();
         if (ultra) {
             pe.assign(N_PLOOKUP_EVALS, Fr::zero());
-            const auto at_zeta = evaluate(fix(tab0), n, 4, n, zeta);                                           // range, key, table_dom_sep, q_dom_sep
-            const auto at_next = evaluate(fix(tab0), n, 3, n, zeta_w);
-            pe[RANGE_TABLE] = at_zeta[0]; pe[KEY_TABLE] = at_zeta[1]; pe[TABLE_DOM_SEP] = at_zeta[2]; pe[Q_DOM_SEP] = at_zeta[3];
-            pe[RANGE_TABLE_NEXT] = at_next[0]; pe[KEY_TABLE_NEXT] = at_next[1]; pe[TABLE_DOM_SEP_NEXT] = at_next[2];
-            pe[H_1] = evaluate(krow(H1), n + 3, 1, n + 3, zeta)[0];
-            pe[Q_LOOKUP] = evaluate(fix(13), n, 1, n, zeta)[0];
-            pe[Q_LOOKUP_NEXT] = evaluate(fix(13), n, 1, n, zeta_w)[0];
-            pe[PROD_NEXT] = evaluate(krow(PL), n + 3, 1, n + 3, zeta_w)[0];
-            const auto hn = evaluate(krow(H1), n + 3, 2, n + 3, zeta_w);
-            pe[H_1_NEXT] = hn[0]; pe[H_2_NEXT] = hn[1];
-            const auto wn = evaluate(krow(3), n + 2, 2, n + 3, zeta_w);
-            pe[W_3_NEXT] = wn[0]; pe[W_4_NEXT] = wn[1];
+            pe[RANGE_TABLE] = v[h_tz]; pe[KEY_TABLE] = v[h_tz + 1]; pe[TABLE_DOM_SEP] = v[h_tz + 2]; pe[Q_DOM_SEP] = v[h_tz + 3];
+            pe[RANGE_TABLE_NEXT] = v[h_tn]; pe[KEY_TABLE_NEXT] = v[h_tn + 1]; pe[TABLE_DOM_SEP_NEXT] = v[h_tn + 2];
+            pe[H_1] = v[h_h1];
+            pe[Q_LOOKUP] = v[h_ql];
+            pe[Q_LOOKUP_NEXT] = v[h_qln];
+            pe[PROD_NEXT] = v[h_pl];
+            pe[H_1_NEXT] = v[h_hn]; pe[H_2_NEXT] = v[h_hn + 1];
+            pe[W_3_NEXT] = v[h_wn]; pe[W_4_NEXT] = v[h_wn + 1];
         }
         tick.mark("r4_evals");
     }
@@ -516,6 +742,57 @@ struct Prover {                                                        // Provin
         lincomb_many(t, batch.p, n + 3);
         check(mzk_poly_div_linear_dev(C::ID, batch.p, n + 3, point.l, out.p, nullptr), "mzk_poly_div_linear_dev");
     }
+    // Round 5 over several ranks.  The opening witness of a batch polynomial b at a point z is
+    // w_j = sum_{i > j} b_i z^(i-j-1).  A rank needs w on its own coefficient range [lo, hi) only -- that is its MSM shard -- and
+    // w_j = (the same sum over i < hi) + z^(hi-1-j) S_hi with S_hi = sum_{i >= hi} b_i z^(i-hi): the higher ranks' contribution enters
+    // as ONE field element.  So: linear combinations on the range only (they are pointwise); e = the range read as a polynomial,
+    // evaluated at z; one all-gather of the e's; S_hi appended as an extra top coefficient, after which the ordinary division by
+    // (X - z) of the extended range returns exactly w on the range; commit over the range.
+    std::vector<Affine> openings_ranged(const std::vector<Term>& lin_terms, const std::vector<Term>& open_polys, const std::vector<Term>& shifted_polys,
+                                        const Fr& v, const Fr& zeta, Tick& tick) {
+        const uint64_t hi_c = std::min<uint64_t>(hi, n + 3), width = hi_c > lo ? hi_c - lo : 0;
+        auto cut = [&](const std::vector<Term>& terms) {
+            std::vector<Term> out;
+            for (auto& t : terms) {
+                const uint64_t a = std::min(lo, t.len), b = std::min(hi_c, t.len);
+                if (b > a) out.push_back({t.s, static_cast<const uint8_t*>(t.p) + a * EL, b - a});
+            }
+            return out;
+        };
+        const Fr zw = zeta * w_n;
+        std::vector<Term> open_terms = lin_terms, shift_terms;           // 1 * lin + sum_i v^(i+1) p_i
+        Fr c = v;
+        for (auto& p : open_polys) { open_terms.push_back({c, p.p, p.len}); c = c * v; }
+        c = Fr::one();
+        for (auto& p : shifted_polys) { shift_terms.push_back({c, p.p, p.len}); c = c * v; }
+        // batch.p: the open batch's range, then ONE carried coefficient; lin.p: the same for the shifted batch
+        void* bufs[2] = {batch.p, lin.p};
+        const std::vector<Term> cuts[2] = {cut(open_terms), cut(shift_terms)};
+        const Fr points[2] = {zeta, zw};
+        Fr e[2] = {Fr::zero(), Fr::zero()};
+        for (int j = 0; j < 2; j++) {
+            if (!width) continue;
+            if (cuts[j].empty()) check(mzk_dev_memset(bufs[j], 0, width * EL, nullptr), "memset");
+            else lincomb_many(cuts[j], bufs[j], width);
+            e[j] = evaluate(bufs[j], width, 1, width, points[j])[0];
+        }
+        const std::vector<uint8_t> all = comm->all_gather(rank, e, sizeof e);
+        const Fr* every = reinterpret_cast<const Fr*>(all.data());
+        Fr carry[2] = {Fr::zero(), Fr::zero()};
+        for (int q = rank + 1; q < world; q++) {                         // S_hi: the ranges above, shifted down to start at hi
+            const uint64_t lo_q = std::min<uint64_t>(shard_range(n + 3, q, world).first, n + 3);
+            for (int j = 0; j < 2; j++) carry[j] = carry[j] + pow_u64(points[j], lo_q - hi_c) * every[2 * q + j];
+        }
+        void* outs[2] = {opening.p, shifted.p};
+        for (int j = 0; j < 2 && width; j++) {
+            check(mzk_dev_upload(static_cast<uint8_t*>(bufs[j]) + width * EL, carry[j].l, EL), "upload");
+            check(mzk_poly_div_linear_dev(C::ID, bufs[j], width + 1, points[j].l, outs[j], nullptr), "mzk_poly_div_linear_dev");   // width coefficients: w on [lo, hi)
+        }
+        tick.mark("r5_polys");
+        const auto oc = commit_slices({opening.p, shifted.p}, {width, width});
+        tick.mark("r5_commit");
+        return oc;
+    }
     static Blinds draw_blinds(ChaChaRng& rng, int W, bool ultra) {         // one instance, draw order of prover.rs:79-83, 113-114, 133-138, 169-180
         auto draw = [&](int cnt) { std::vector<Fr> v; for (int i = 0; i < cnt; i++) v.push_back(fr_rand<FrP>(rng)); return v; };
         Blinds b;
@@ -528,10 +805,14 @@ struct Prover {                                                        // Provin
 
     // PlonkKzgSnark::prove (snark.rs:624-651) -> batch_prove_internal (:201-469), one instance
     Proof<C> prove(ChaChaRng& rng, const BenchCircuit<C>& cs, bool profile = false) {
-        Tick tick(timings_ms, profile);
         Blinds blinds = draw_blinds(rng, W, ultra);
         std::vector<Fr> b_quot;
         for (int i = 0; i < W - 1; i++) b_quot.push_back(fr_rand<FrP>(rng));                                   // prover.rs:947-955
+        return prove_with(std::move(blinds), b_quot, cs, profile);
+    }
+    // ... with the masking draws made by the caller: over several devices every rank runs this with the SAME draws (ShardedProver)
+    Proof<C> prove_with(Blinds blinds, const std::vector<Fr>& b_quot, const BenchCircuit<C>& cs, bool profile = false) {
+        Tick tick(timings_ms, profile);
         StandardTranscript<C> tr;
         append_vk_and_pub_input(tr);
         Proof<C> proof;
@@ -568,18 +849,140 @@ struct Prover {                                                        // Provin
         std::vector<Term> terms = lin_poly_terms(Fr::one());
         const std::vector<Term> qt = quotient_lin_terms(zeta, split_len);
         terms.insert(terms.end(), qt.begin(), qt.end());
-        lincomb_many(terms, lin.p, n + 3);
-        std::vector<Term> open_polys{{Fr::one(), lin.p, n + 3}}, shifted_polys;
-        open_lists(open_polys, shifted_polys);
-        batched_witness(open_polys, v, zeta, opening);
-        batched_witness(shifted_polys, v, zeta * w_n, shifted);
-        tick.mark("r5_polys");
-        const auto oc = commit({opening.p, shifted.p}, {n + 2, n + 2});
+        std::vector<Term> open_polys, shifted_polys;
+        std::vector<Affine> oc;
+        if (world > 1) {
+            open_lists(open_polys, shifted_polys);
+            oc = openings_ranged(terms, open_polys, shifted_polys, v, zeta, tick);
+        } else {
+            lincomb_many(terms, lin.p, n + 3);
+            open_polys.push_back({Fr::one(), lin.p, n + 3});
+            open_lists(open_polys, shifted_polys);
+            batched_witness(open_polys, v, zeta, opening);
+            batched_witness(shifted_polys, v, zeta * w_n, shifted);
+            tick.mark("r5_polys");
+            oc = commit({opening.p, shifted.p}, {n + 2, n + 2});
+            tick.mark("r5_commit");
+        }
         proof.opening_proof = oc[0];
         proof.shifted_opening_proof = oc[1];
-        tick.mark("r5_commit");
         return proof;
     }
+};
+
+// ---- G devices from one process: G host threads, each bound to its device's context of libmi355zk, all running Prover::prove_with
+// ---- on the same draws (SPMD); they end with identical proofs.  Every device-side object of rank g is created, used and destroyed
+// ---- on thread g.  world == 1 runs on the calling thread.
+template <class C>
+struct ShardedProver {
+    using P = Prover<C>;
+    using Fr = typename P::Fr;
+    const int G;
+    LocalComm comm;
+    std::vector<std::unique_ptr<BenchCircuit<C>>> circuit;             // per device
+    std::vector<std::unique_ptr<P>> prover;
+    std::vector<uint64_t> srs;
+    // worker threads
+    std::vector<std::thread> threads;
+    std::mutex mu;
+    std::condition_variable cv_job, cv_done;
+    std::function<void(int)> job;
+    uint64_t job_gen = 0;
+    int pending = 0;
+    bool stop = false;
+    std::vector<std::exception_ptr> errors;
+
+    explicit ShardedProver(int g) : G(g), comm(g), circuit(g), prover(g), srs(g, 0), errors(g) {
+        if (G > 1)
+            for (int r = 0; r < G; r++) threads.emplace_back([this, r] { worker(r); });
+    }
+    ~ShardedProver() {
+        try { each([&](int r) { prover[r].reset(); circuit[r].reset(); if (srs[r]) (void)mzk_srs_release(srs[r]); srs[r] = 0; }); } catch (...) {}
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            stop = true;
+        }
+        cv_job.notify_all();
+        for (auto& t : threads) t.join();
+    }
+    void worker(int r) {
+        bool bound = false;
+        uint64_t seen = 0;
+        for (;;) {
+            std::function<void(int)> f;
+            {
+                std::unique_lock<std::mutex> lk(mu);
+                cv_job.wait(lk, [&] { return stop || job_gen != seen; });
+                if (stop) return;
+                seen = job_gen;
+                f = job;
+            }
+            try {
+                if (!bound) { check(mzk_init(r), "mzk_init"); bound = true; }    // this thread drives device r from now on
+                f(r);
+            } catch (...) {
+                errors[r] = std::current_exception();
+                comm.abort();                                                 // ranks waiting in a barrier give up too
+            }
+            {
+                std::lock_guard<std::mutex> lk(mu);
+                if (--pending == 0) cv_done.notify_all();
+            }
+        }
+    }
+    // f(rank) on every device thread; returns when all are done; the first failure is rethrown
+    void each(const std::function<void(int)>& f) {
+        if (G == 1) { f(0); return; }
+        comm.reset();
+        for (auto& e : errors) e = nullptr;
+        {
+            std::lock_guard<std::mutex> lk(mu);
+            job = f;
+            pending = G;
+            job_gen++;
+        }
+        cv_job.notify_all();
+        {
+            std::unique_lock<std::mutex> lk(mu);
+            cv_done.wait(lk, [&] { return pending == 0; });
+        }
+        std::exception_ptr other = nullptr;
+        for (auto& e : errors) {                                          // prefer the root cause over "another device thread failed"
+            if (!e) continue;
+            try { std::rethrow_exception(e); }
+            catch (const std::runtime_error& x) { if (std::string(x.what()) != "another device thread failed") std::rethrow_exception(e); other = e; }
+            catch (...) { std::rethrow_exception(e); }
+        }
+        if (other) std::rethrow_exception(other);
+    }
+    // the testing SRS [beta^i] G on every device, the circuit uploaded to every device, PlonkKzgSnark::preprocess per device
+    void setup(const BenchCircuitHost<C>& host, const std::array<uint64_t, 4>& beta_canonical, bool host_witness = false) {
+        each([&](int r) {
+            check(mzk_srs_generate_for_testing(C::ID, beta_canonical.data(), host.n + 3, &srs[r]), "mzk_srs_generate_for_testing");
+            circuit[r] = std::make_unique<BenchCircuit<C>>(BenchCircuit<C>::upload(host, host_witness));
+            prover[r] = std::make_unique<P>(srs[r], *circuit[r], r, G, &comm);
+        });
+        for (int r = 0; r < G; r++) {                                     // where every rank receives the class remainders of the others
+            prover[r]->peer_rem.resize(G);
+            for (int q = 0; q < G; q++) prover[r]->peer_rem[q] = prover[q]->rem.p;
+        }
+    }
+    // PlonkKzgSnark::prove: the draws are made once, every rank proves with them; `check_agree`: all ranks must hold the same bytes
+    Proof<C> prove(ChaChaRng& rng, bool profile = false, bool check_agree = false) {
+        const typename P::Blinds blinds = P::draw_blinds(rng, prover[0]->W, prover[0]->ultra);
+        std::vector<Fr> b_quot;
+        for (int i = 0; i < prover[0]->W - 1; i++) b_quot.push_back(fr_rand<typename C::Fr>(rng));
+        std::vector<Proof<C>> proofs(check_agree ? G : 1);
+        each([&](int r) {
+            Proof<C> pr = prover[r]->prove_with(blinds, b_quot, *circuit[r], profile);
+            if (r == 0 || check_agree) proofs[check_agree ? r : 0] = std::move(pr);
+        });
+        if (check_agree)
+            for (int r = 1; r < G; r++)
+                if (proofs[r].serialize_compressed() != proofs[0].serialize_compressed()) throw std::runtime_error("the ranks disagree on the proof");
+        return std::move(proofs[0]);
+    }
+    void sync() { each([&](int) { check(mzk_dev_sync(), "sync"); }); }
 };
 
 // ---- aggregated proofs over several instances (snark.rs:64-78, 201-469; structs.rs:266-291) -----------------------------
@@ -757,7 +1160,7 @@ LinkingHint<C> link_hint(const Prover<C>& prover, const Proof<C>& proof) {
     LinkingHint<C> h;
     h.len = prover.n + 2;
     h.linking_wire_poly.alloc(h.len);
-    check(mzk_dev_copy(h.linking_wire_poly.p, prover.keep.p, h.len * EL, nullptr), "copy");            // keep row 0 = wire polynomial 0
+    check(mzk_dev_copy(h.linking_wire_poly.p, prover.krow(0), h.len * EL, nullptr), "copy");          // row 0 = wire polynomial 0
     h.linking_wire_comm = proof.wires_poly_comms[0];
     return h;
 }

@@ -70,6 +70,12 @@ _SIGS = {
     "mzk_dev_upload": [C.c_void_p, C.c_void_p, C.c_uint64],
     "mzk_dev_download": [C.c_void_p, C.c_void_p, C.c_uint64],
     "mzk_dev_sync": [],
+    "mzk_stream_create": [C.POINTER(C.c_void_p)],
+    "mzk_stream_destroy": [C.c_void_p],
+    "mzk_stream_sync": [C.c_void_p],
+    "mzk_stream_wait_stream": [C.c_void_p, C.c_void_p],
+    "mzk_dev_upload_async": [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p],
+    "mzk_dev_download_async": [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p],
     "mzk_dev_copy": [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p],
     "mzk_dev_copy2d": [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p],
     "mzk_dev_memset": [C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p],

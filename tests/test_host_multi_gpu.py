@@ -1,0 +1,92 @@
+"""GPU: several devices driven from ONE process by the compiled host (mpc-jellyfish_amd/host/: ShardedProver, one host thread per
+device context of libmi355zk) -- VERDICT r2 #2.  The reference is one process calling `prove` once with Rayon inside
+(univariate_kzg/mod.rs:125-127, prover.rs:545-673); here MZK_VIRTUAL_DEVICES=G puts G device contexts on the one card of the
+test box, and the proof bytes must equal the single-device ones: commitments sharded by point range (host sum of <= 8 Jacobian
+partials), the quotient by residue class with one device-to-device exchange, rounds 4-5 by coefficient range."""
+import ctypes as C
+import json
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "mpc-jellyfish_amd", "mzk_prove")
+
+
+def _prove(curve_id, kind, gates, gpus, extra=(), reps="0"):
+    env = dict(os.environ)
+    if gpus > 1:
+        env["MZK_VIRTUAL_DEVICES"] = str(gpus)
+    cmd = [BIN, str(curve_id), kind, str(gates), reps, "5" if kind == "ultra" else "8"] + (["--gpus", str(gpus), "--check-agree"] if gpus > 1 else []) + list(extra)
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env)
+    assert out.returncode == 0, out.stderr[-2000:]
+    return json.loads(out.stdout.strip().splitlines()[-1])
+
+
+@pytest.mark.parametrize("curve_id,kind,gates", [(0, "turbo", 1024), (1, "ultra", 600), (0, "turbo", 64), (1, "turbo", 8192)])
+def test_virtual_devices_emit_the_single_device_proof(gpu, curve_id, kind, gates):
+    one = _prove(curve_id, kind, gates, 1)
+    for g in (2, 3, 4, 8):                                   # 3: an uneven class split (2 + 2 + 2 of 6, 3 + 3 + 1 of 7); 8: ranks that own no class
+        many = _prove(curve_id, kind, gates, g)
+        assert many["gpus"] == g and many["proof_hex"] == one["proof_hex"] and many["vk_hex"] == one["vk_hex"], (curve_id, kind, gates, g)
+
+
+def test_host_resident_witness_same_bytes(gpu):
+    """--host-witness: every proof uploads its wire values from page-locked host memory, column k + 1 under the iNTT of column k
+    (the reference gathers the witness on the host, constraint_system.rs:1225-1247)."""
+    base = _prove(0, "turbo", 4096, 1)
+    assert _prove(0, "turbo", 4096, 1, ["--host-witness"], reps="2")["proof_hex"] == base["proof_hex"]
+    assert _prove(0, "turbo", 4096, 4, ["--host-witness"], reps="2")["proof_hex"] == base["proof_hex"]
+
+
+def test_unsatisfied_witness_rejected_on_every_device(gpu):
+    env = dict(os.environ, MZK_PROVE_CORRUPT_WITNESS="1", MZK_VIRTUAL_DEVICES="4")
+    out = subprocess.run([BIN, "0", "turbo", "256", "0", "--gpus", "4"], capture_output=True, text=True, timeout=600, env=env)
+    assert out.returncode == 1 and "WrongQuotientPolyDegree" in out.stderr and "proof_hex" not in out.stdout
+
+
+def test_contexts_from_one_python_process(gpu, mj):
+    """The C ABI itself: two device contexts in this process (MZK_VIRTUAL_DEVICES), handles carry their device, a thread rebinds with
+    mzk_set_device, device memory crosses with mzk_dev_copy_peer -- run in a child process because the variable is read at mzk_init."""
+    code = r'''
+import ctypes as C, os, sys
+import numpy as np
+sys.path.insert(0, %r)
+import mpc_jellyfish_amd as mj
+from importlib import import_module
+lib = import_module("mpc-jellyfish_amd.lib")
+L = lib.load()
+cnt = C.c_int32()
+lib.check(L.mzk_init(0), "init0"); lib.check(L.mzk_init(1), "init1")
+lib.check(L.mzk_device_count(C.byref(cnt)), "count"); assert cnt.value == 2
+assert L.mzk_init(2) != 0                                          # only two (virtual) devices exist
+c = mj.params.BLS12_381
+beta = np.array([0x1234567, 0, 0, 0], dtype=np.uint64)
+h = [C.c_uint64(), C.c_uint64()]
+for d in (0, 1):
+    lib.check(L.mzk_set_device(d), "set"); lib.check(L.mzk_srs_generate_for_testing(0, C.c_void_p(beta.ctypes.data), 300, C.byref(h[d])), "srs")
+assert (h[0].value >> 48) == 1 and (h[1].value >> 48) == 2         # the handle names its device
+x = mj.params.random_fr_mont(c, 300, seed=5)
+outs = []
+for d in (1, 0):                                                   # the thread is bound to device 0 at the end; handles still find their device
+    o = np.zeros(18, dtype=np.uint64)
+    lib.check(L.mzk_msm(h[d].value, 0, C.c_void_p(x.ctypes.data), 300, 1, C.c_void_p(o.ctypes.data)), "msm")
+    a = np.zeros(12, dtype=np.uint64)
+    lib.check(L.mzk_g1_jacobian_to_affine(0, C.c_void_p(o.ctypes.data), 1, C.c_void_p(a.ctypes.data)), "aff")
+    outs.append(a)
+assert np.array_equal(outs[0], outs[1])
+p0, p1 = C.c_void_p(), C.c_void_p()
+lib.check(L.mzk_set_device(0), "set"); lib.check(L.mzk_dev_alloc(x.nbytes, C.byref(p0)), "alloc"); lib.check(L.mzk_dev_upload(p0, C.c_void_p(x.ctypes.data), x.nbytes), "up")
+lib.check(L.mzk_set_device(1), "set"); lib.check(L.mzk_dev_alloc(x.nbytes, C.byref(p1)), "alloc")
+lib.check(L.mzk_dev_copy_peer(p1, 1, p0, 0, x.nbytes, None), "peer"); lib.check(L.mzk_set_device(0), "set"); lib.check(L.mzk_dev_sync(), "sync")
+y = np.zeros_like(x)
+lib.check(L.mzk_set_device(1), "set"); lib.check(L.mzk_dev_download(C.c_void_p(y.ctypes.data), p1, x.nbytes), "down")
+assert np.array_equal(x, y)
+lib.check(L.mzk_shutdown(), "shutdown")
+print("ok")
+''' % ROOT
+    out = subprocess.run([os.sys.executable, "-c", code], capture_output=True, text=True, timeout=600, env=dict(os.environ, MZK_VIRTUAL_DEVICES="2"))
+    assert out.returncode == 0 and out.stdout.strip().endswith("ok"), out.stderr[-3000:]
