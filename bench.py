@@ -242,7 +242,7 @@ def main():
             "roofline": msm_roofline(acc_avg_ms, n_win, "msm_accumulate_plain"),
             "phases_ms": phases,
             "cpu_baseline": None, "fixed_base": None, "ntt": None, "plonk_round3": None, "batch_commit5": None, "prove": None,
-            "prove_dropin": None, "prove_cpp_host": None, "prove_sharded": None, "prove_ultra_bn254": None, "link_and_batch": None,
+            "prove_dropin": None, "prove_cpp_host": None, "prove_sharded": None, "prove_cpp_host_multi_gpu": None, "prove_ultra_bn254": None, "link_and_batch": None,
         }
 
     # The headline line is complete here; everything below is secondary.  With several ranks the secondary part holds collectives
@@ -551,6 +551,37 @@ def main():
         except Exception as e:                                         # noqa: BLE001  (secondary: the headline must still be printed)
             prove_sharded["error"] = "%s: %s" % (type(e).__name__, str(e)[:300])
 
+    # ---- secondary, N > 1: the same proof from ONE process driving all N devices -- the compiled host, one host thread per device
+    #      context of libmi355zk (host/mzk_prover.hpp ShardedProver), no torch.distributed, no Python.  The ranks of this run keep
+    #      their GPUs but sit in the barrier below while rank 0's child process uses them.
+    prove_cpp_multi = None
+    if not args.no_plonk and world > 1 and not os.environ.get("MZK_BENCH_NO_CPP_MULTI"):
+        torch.cuda.synchronize()
+        dist.barrier()
+        if rank == 0:
+            import subprocess
+            binp = os.path.join(ROOT, "mpc-jellyfish_amd", "mzk_prove")
+            env = dict(os.environ)
+            if os.environ.get("MZK_BENCH_SINGLE_DEVICE"):                         # rehearsal on a one-GPU box: N device contexts on the one card
+                env["MZK_VIRTUAL_DEVICES"] = str(world)
+            prove_cpp_multi = {"what": "PlonkKzgSnark::prove from ONE process driving all N devices: mzk_prove --gpus N (C++ host, one host thread per "
+                                       "device, commitments sharded by point range and summed on the host, the quotient by residue class with one "
+                                       "device-to-device exchange, rounds 4-5 by coefficient range); strong scaling against `gpus_1`"}
+            for name, argv in (("gpus_%d" % world, ["0", "turbo", str(1 << args.plonk_log_n), "10", "--gpus", str(world), "--check-agree"]),
+                               ("gpus_1", ["0", "turbo", str(1 << args.plonk_log_n), "10"])):
+                try:
+                    r = subprocess.run([binp] + argv, capture_output=True, text=True, timeout=240, env=env)
+                    d = json.loads(r.stdout.strip().splitlines()[-1])
+                    prove_cpp_multi[name] = {"prove_ms": d["prove_ms"], "rounds_ms": d["rounds_ms"], "preprocess_s": d["preprocess_s"],
+                                             "proof_sha16": hashlib.sha256(d["proof_hex"].encode()).hexdigest()[:16]}
+                except Exception as e:                                            # noqa: BLE001
+                    prove_cpp_multi[name] = {"error": repr(e)[:200]}
+            a, b = prove_cpp_multi.get("gpus_%d" % world, {}), prove_cpp_multi.get("gpus_1", {})
+            if "prove_ms" in a and "prove_ms" in b:
+                prove_cpp_multi["same_proof_bytes"] = a["proof_sha16"] == b["proof_sha16"]
+                prove_cpp_multi["speedup"] = round(b["prove_ms"] / a["prove_ms"], 2)
+        dist.barrier()
+
     # ---- secondary: UltraPlonk (Plookup) on BN254, the shape of config C5 at --ultra-log-n gates, one GPU ---------------
     ultra = None
     if not args.no_plonk and rank == 0 and world == 1 and args.ultra_log_n:
@@ -626,6 +657,7 @@ def main():
         # ... and at the reference's own bench size (NUM_GATES_LARGE = 32768, plonk/benches/bench.rs:26), whose published CPU figures
         # are 29 591 (TurboPlonk, BLS12-381) and 33 701 (UltraPlonk, BN254) ns per constraint on 24 threads of a 5900X (bench.md)
         for name, argv in (("turbo_bls12_381", ["0", "turbo", str(1 << args.plonk_log_n), "10"]),
+                           ("turbo_bls12_381_host_witness", ["0", "turbo", str(1 << args.plonk_log_n), "10", "--host-witness"]),
                            ("ultra_bn254", ["1", "ultra", str(1 << (args.ultra_log_n or args.plonk_log_n)), "10"]),
                            ("turbo_bls12_381_1024_gates", ["0", "turbo", "1024", "20"]),
                            ("turbo_bls12_381_32768_gates", ["0", "turbo", "32768", "20"]),
@@ -724,7 +756,7 @@ def main():
         watchdog.cancel()
     if rank == 0:
         out.update({"cpu_baseline": cpu, "fixed_base": fixed_base, "ntt": ntt, "plonk_round3": plonk, "batch_commit5": batch, "prove": prove,
-                    "prove_dropin": dropin, "prove_cpp_host": prove_cpp, "prove_sharded": prove_sharded, "prove_ultra_bn254": ultra,
+                    "prove_dropin": dropin, "prove_cpp_host": prove_cpp, "prove_sharded": prove_sharded, "prove_cpp_host_multi_gpu": prove_cpp_multi, "prove_ultra_bn254": ultra,
                     "link_and_batch": link_batch})
         emit()
     if world > 1:

@@ -72,6 +72,8 @@ def test_bench_two_ranks_rehearsal_and_watchdog(gpu):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     sh = d["prove_sharded"]
     assert "error" not in sh and sh["turbo_bls12_381"]["ranks_agree_on_proof"] and sh["ultra_bn254"]["ranks_agree_on_proof"]
+    cm = d["prove_cpp_host_multi_gpu"]                    # the compiled host driving both (virtual) devices from one process
+    assert cm["same_proof_bytes"] is True and cm["gpus_2"]["prove_ms"] > 0, cm
     out, lines = _two_ranks(["--secondary-timeout", "1", "--plonk-log-n", "16", "--ultra-sharded-log-n", "16"], 29633)
     assert len(lines) == 1, (lines, out.stderr[-2000:])
     d = json.loads(lines[0])
