@@ -86,6 +86,11 @@ MZK_API int32_t mzk_srs_release(uint64_t handle);
 /* Testing SRS on the device: point i = beta^i * G (G = standard generator), beta canonical 4 limbs.
  * Mirrors gen_srs_for_testing (srs.rs:118-153) with g fixed to the generator. */
 MZK_API int32_t mzk_srs_generate_for_testing(int32_t curve_id, const uint64_t* beta_canonical, uint64_t n_points, uint64_t* out_handle);
+/* The same with a base point of the caller's: point i = beta^i * g, g affine x||y (mont), on the curve and in the subgroup (not
+ * checked).  `universal_setup_for_testing` (plonk/src/proof_system/snark.rs:495-517) draws beta = Fr::rand, then g = G1::rand and
+ * h = G2::rand from the same rng: a host that mirrors those draws passes its g here.  g_xy_mont = NULL: the standard generator. */
+MZK_API int32_t mzk_srs_generate_for_testing_g(int32_t curve_id, const uint64_t* beta_canonical, const uint64_t* g_xy_mont, uint64_t n_points,
+                                               uint64_t* out_handle);
 MZK_API int32_t mzk_srs_download(uint64_t handle, uint64_t first, uint64_t n_points, uint64_t* out_xy_mont);
 MZK_API int32_t mzk_srs_len(uint64_t handle, uint64_t* out_n_points);
 

@@ -10,11 +10,12 @@
 //!
 //!     cd integration/rust && cargo run --release --features fixtures --bin gen_fixtures -- ../../tests/golden
 //!
-//! SRS of the proof cases: the repo's vectors use `powers_of_g[i] = beta^i * G` with G the curve's standard generator and
-//! beta = the FIRST draw of `test_rng`.  `universal_setup_for_testing` (plonk/src/proof_system/snark.rs:485-526) draws beta the
-//! same way but then takes g = G1::rand(rng), h = G2::rand(rng): a different SRS and two more groups of draws before the
-//! blinders.  `prove` is the path under test, the testing setup is not, so the SRS is rebuilt here from (beta, G) and the same
-//! rng continues into `prove` -- exactly the sequence of `make_proof_golden.py`.
+//! SRS of the proof cases, two families.  `proof_vectors.json`: `powers_of_g[i] = beta^i * G` with G the curve's standard generator
+//! and beta = the FIRST draw of `test_rng`; the SRS is rebuilt here from (beta, G) and the same rng continues into `prove` -- the
+//! sequence of `make_proof_golden.py`.  `proof_vectors_refsetup.json` ("setup": "universal_setup_for_testing"): the reference's OWN
+//! `universal_setup_for_testing` (plonk/src/proof_system/snark.rs:485-526), which draws beta the same way and then g = G1::rand(rng),
+//! h = G2::rand(rng) before the blinders -- what plonk/benches/bench.rs and the reference's tests prove over; those vectors also pin
+//! the restated `G1::rand` (oracle/pyref_rng.py) and the product's mirror of it (mpc-jellyfish_amd/rng.py).
 //!
 //! NOT COMPILED in this repository's build image (no Rust toolchain); see README.md.
 use ark_ec::{pairing::Pairing, AffineRepr, CurveGroup, VariableBaseMSM};
@@ -137,19 +138,27 @@ macro_rules! curve_fixtures {
                 assert_eq!(n as u64, case["domain_size"].as_u64().unwrap(), "domain size");
 
                 let rng = &mut jf_utils::test_rng();
-                let beta = Fr::rand(rng);
-                assert_eq!(hx(&beta), case["srs_beta"].as_str().unwrap(), "first draw of test_rng");
-                let (g, h) = (G1::generator(), G2::generator());
-                let mut powers = Vec::with_capacity(n + 3);
-                let mut cur = g;
-                for _ in 0..n + 3 {
-                    powers.push(cur);
-                    cur *= beta;
-                }
-                let srs = UnivariateUniversalParams::<E> {
-                    powers_of_g: G1::normalize_batch(&powers),
-                    h: h.into_affine(),
-                    beta_h: (h * beta).into_affine(),
+                let srs = if case["setup"].as_str() == Some("universal_setup_for_testing") {
+                    // the reference's OWN testing setup (snark.rs:485-526): beta = Fr::rand, g = G1::rand, h = G2::rand from this rng,
+                    // which then continues into `prove`; the vector records beta and g as oracle/pyref_rng.py restates them
+                    let srs = PlonkKzgSnark::<E>::universal_setup_for_testing(n + 2, rng).unwrap();
+                    assert_eq!(point_json(&srs.powers_of_g[0]), case["srs_g"], "g = G1::rand(rng): the restated sampler disagrees");
+                    srs
+                } else {
+                    let beta = Fr::rand(rng);
+                    assert_eq!(hx(&beta), case["srs_beta"].as_str().unwrap(), "first draw of test_rng");
+                    let (g, h) = (G1::generator(), G2::generator());
+                    let mut powers = Vec::with_capacity(n + 3);
+                    let mut cur = g;
+                    for _ in 0..n + 3 {
+                        powers.push(cur);
+                        cur *= beta;
+                    }
+                    UnivariateUniversalParams::<E> {
+                        powers_of_g: G1::normalize_batch(&powers),
+                        h: h.into_affine(),
+                        beta_h: (h * beta).into_affine(),
+                    }
                 };
                 let (pk, vk) = PlonkKzgSnark::<E>::preprocess(&srs, &cs).unwrap();
                 let proof = PlonkKzgSnark::<E>::prove::<_, _, StandardTranscript>(rng, &cs, &pk, None).unwrap();
@@ -190,5 +199,6 @@ fn main() {
     run(dir, "msm_vectors", bls::msm, bn::msm);
     run(dir, "kzg_vectors", bls::kzg, bn::kzg);
     run(dir, "proof_vectors", bls::proof, bn::proof);
+    run(dir, "proof_vectors_refsetup", bls::proof, bn::proof);
     let _ = BigInt::<4>::zero().is_zero();
 }

@@ -41,7 +41,7 @@ struct DevBuf {
 };
 
 struct Workspace {
-    DevBuf ntt_scratch, scalars, hist, offs, cursor, sorted, buckets, collect, io, misc, digits, long_desc, long_parts, plonk_polys, plonk_out, pre_cnt, pre_off, pre_ce, pre_cb, poly_tmp, split, link_tmp;
+    DevBuf ntt_scratch, scalars, hist, offs, cursor, sorted, buckets, collect, io, misc, digits, long_desc, long_parts, plonk_polys, plonk_out, pre_cnt, pre_off, pre_ce, pre_cb, poly_tmp, split, link_tmp, occ;
     void* h_collect = nullptr;
     size_t h_collect_cap = 0;
     hipEvent_t last_use = nullptr;
@@ -122,7 +122,7 @@ int32_t msm_batch_dispatch(const Srs& s, uint32_t n_polys, const uint32_t* const
                            int is_mont, uint32_t* out_xyz, hipStream_t st);
 int32_t srs_build_internal(Srs& s, hipStream_t st);
 int32_t srs_build_pre(Srs& s, hipStream_t st);
-int32_t srs_generate_dispatch(int curve, const uint32_t* beta_canon, uint64_t n, uint32_t* d_out);
+int32_t srs_generate_dispatch(int curve, const uint32_t* beta_canon, const uint32_t* g_xy_mont /* NULL: the standard generator */, uint64_t n, uint32_t* d_out);
 void jac_to_affine_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uint64_t* xy);
 void jac_sum_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uint64_t* out);
 

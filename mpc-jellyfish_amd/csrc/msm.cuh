@@ -335,7 +335,7 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(const u
                                                                           const uint32_t* __restrict__ offs, const uint32_t* __restrict__ hist,
                                                                           const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ order,
                                                                           uint32_t M, int n_win, uint32_t cap, uint32_t* __restrict__ long_count,
-                                                                          uint32_t* __restrict__ buckets) {
+                                                                          uint32_t* __restrict__ buckets, uint8_t* __restrict__ occ) {
     if (blockIdx.x == 0 && threadIdx.x < (unsigned)n_win) long_count[threadIdx.x] = 0u;     // what msm_long_find_kernel counts into (saves a fill)
     const unsigned long long t0 = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
     if (t0 >= (unsigned long long)n_win * M) return;
@@ -349,7 +349,11 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(const u
         const uint32_t e = list[k];
         acc = EC::madd(acc, EC::load_aff(bases, e & 0x7fffffffu), (e >> 31) != 0);
     }
-    EC::store_pt(buckets, t, acc);
+    // occ[t] == 0: the bucket holds infinity and its 224 bytes are NOT written (nor read by the reduction): a sparse polynomial -- the
+    // bench circuit commits two zero wires -- then costs what its few occupied buckets cost, not 2^19 bucket writes and their folding
+    const bool empty = acc.is_inf();
+    occ[t] = empty ? 0 : 1;
+    if (!empty) EC::store_pt(buckets, t, acc);
 }
 
 // Small and medium MSMs are latency bound: few buckets, each a chain of dependent mixed adds (~12 us apiece when a wave runs
@@ -407,7 +411,7 @@ __device__ __forceinline__ typename EC::Pt pt_lds_get(const uint32_t* lds, int s
 }
 template <class EC>
 __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_split_combine_kernel(const uint32_t* __restrict__ sub, unsigned long long n_buckets, int log_split,
-                                                                             uint32_t* __restrict__ buckets) {
+                                                                             uint32_t* __restrict__ buckets, uint8_t* __restrict__ occ) {
     __shared__ uint32_t lds[MSM_ACC_THREADS * EC::PT_WORDS];
     const int tid = threadIdx.x;
     const unsigned long long total = n_buckets << log_split;                 // partial sums in all (even)
@@ -428,8 +432,11 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_split_combine_kernel(cons
         }
         if (mine) {
             acc = EC::add(a, b);
-            if (lvl == log_split - 1) EC::store_pt(buckets, (base >> log_split) + tid, acc);
-            else pt_lds_put<EC>(lds, tid, acc);
+            if (lvl == log_split - 1) {
+                const bool empty = acc.is_inf();
+                occ[(base >> log_split) + tid] = empty ? 0 : 1;
+                if (!empty) EC::store_pt(buckets, (base >> log_split) + tid, acc);
+            } else pt_lds_put<EC>(lds, tid, acc);
         }
     }
 }
@@ -491,7 +498,7 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_long_chunk_kernel(const u
 template <class EC>
 __global__ __launch_bounds__(1024) void msm_long_combine_kernel(const LongDesc* __restrict__ desc, const uint32_t* __restrict__ desc_count,
                                                                 uint32_t desc_cap, uint32_t M, uint32_t* __restrict__ parts,
-                                                                uint32_t* __restrict__ buckets) {
+                                                                uint32_t* __restrict__ buckets, uint8_t* __restrict__ occ) {
     const uint32_t w = blockIdx.x, t = threadIdx.x;
     const uint32_t cnt = min(desc_count[w], desc_cap);
     if (cnt == 0) return;
@@ -521,32 +528,45 @@ __global__ __launch_bounds__(1024) void msm_long_combine_kernel(const LongDesc* 
         const LongDesc d = dw[i];
         if (d.idx_in_run == 0) {
             const size_t bi = (size_t)w * M + d.bucket;
-            typename EC::Pt a = EC::load_pt(buckets, bi), b = EC::load_pt(parts, pbase + i);
+            typename EC::Pt a = occ[bi] ? EC::load_pt(buckets, bi) : EC::inf(), b = EC::load_pt(parts, pbase + i);      // (the first `cap` points may sum to infinity)
             EC::store_pt(buckets, bi, EC::add(a, b));
+            occ[bi] = 1;
         }
     }
 }
 
 // level with half-size h: segment 0 is the main array (base 0), segment j >= 1 is T_j (base M>>j);
-// X[base+i] += X[base+h+i].  grid covers n_win * nseg * h threads.
+// X[base+i] += X[base+h+i].  grid covers n_win * nseg * h threads.  occ[] (one byte per bucket slot, set by the accumulation) says
+// which slots hold a point: an empty right operand costs nothing, an empty left one a copy -- the reduction of a sparse bucket set
+// moves and adds only what is there.
 template <class EC>
-__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_fold_kernel(uint32_t* __restrict__ buckets, uint32_t M, uint32_t h, int nseg, int n_win) {
+__device__ __forceinline__ void fold_one(uint32_t* __restrict__ buckets, uint8_t* __restrict__ occ, unsigned long long ia, unsigned long long ib) {
+    if (!occ[ib]) return;
+    typename EC::Pt b = EC::load_pt(buckets, ib);
+    if (!occ[ia]) {
+        EC::store_pt(buckets, ia, b);
+        occ[ia] = 1;
+        return;
+    }
+    typename EC::Pt a = EC::load_pt(buckets, ia);
+    EC::store_pt(buckets, ia, EC::add(a, b));
+}
+template <class EC>
+__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_fold_kernel(uint32_t* __restrict__ buckets, uint8_t* __restrict__ occ, uint32_t M, uint32_t h, int nseg, int n_win) {
     const unsigned long long t = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
     const unsigned long long per_win = (unsigned long long)nseg * h;
     if (t >= per_win * n_win) return;
     const unsigned long long w = t / per_win, r = t % per_win;
     const uint32_t seg = (uint32_t)(r / h), i = (uint32_t)(r % h);
     const unsigned long long base = w * M + (seg ? (M >> seg) : 0u);
-    typename EC::Pt a = EC::load_pt(buckets, base + i);
-    typename EC::Pt b = EC::load_pt(buckets, base + h + i);
-    EC::store_pt(buckets, base + i, EC::add(a, b));
+    fold_one<EC>(buckets, occ, base + i, base + h + i);
 }
 
 // the last levels of the recursive halving in ONE launch: a 256-thread workgroup per
 // bucket set walks the levels with a workgroup barrier between them (each level is one EC add deep,
 // so separate launches would pay a launch gap per level for a few hundred threads of work)
 template <class EC>
-__global__ __launch_bounds__(256) void msm_fold_tail_kernel(uint32_t* __restrict__ buckets, uint32_t M, int log_m, int first_lvl) {
+__global__ __launch_bounds__(256) void msm_fold_tail_kernel(uint32_t* __restrict__ buckets, uint8_t* __restrict__ occ, uint32_t M, int log_m, int first_lvl) {
     const unsigned long long w = blockIdx.x;
     for (int lvl = first_lvl; lvl <= log_m; lvl++) {
         const uint32_t h = M >> lvl;
@@ -554,9 +574,7 @@ __global__ __launch_bounds__(256) void msm_fold_tail_kernel(uint32_t* __restrict
         for (uint32_t r = threadIdx.x; r < items; r += 256) {
             const uint32_t seg = r / h, i = r % h;
             const unsigned long long base = w * M + (seg ? (M >> seg) : 0u);
-            typename EC::Pt a = EC::load_pt(buckets, base + i);
-            typename EC::Pt b = EC::load_pt(buckets, base + h + i);
-            EC::store_pt(buckets, base + i, EC::add(a, b));
+            fold_one<EC>(buckets, occ, base + i, base + h + i);
         }
         __threadfence_block();
         __syncthreads();
@@ -565,12 +583,13 @@ __global__ __launch_bounds__(256) void msm_fold_tail_kernel(uint32_t* __restrict
 
 // out[w][0] = X[w*M], out[w][j] = X[w*M + (M>>j)], j = 1..log2 M, converted to the boundary form
 template <class EC>
-__global__ void msm_collect_kernel(const uint32_t* __restrict__ buckets, uint32_t M, int log_m, int n_win, uint32_t* __restrict__ out) {
+__global__ void msm_collect_kernel(const uint32_t* __restrict__ buckets, const uint8_t* __restrict__ occ, uint32_t M, int log_m, int n_win, uint32_t* __restrict__ out) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     const int per = log_m + 1;
     if (t >= n_win * per) return;
     const int w = t / per, j = t % per;
-    typename EC::Pt p = EC::load_pt(buckets, (unsigned long long)w * M + (j ? (M >> j) : 0u));
+    const unsigned long long slot = (unsigned long long)w * M + (j ? (M >> j) : 0u);
+    typename EC::Pt p = occ[slot] ? EC::load_pt(buckets, slot) : EC::inf();
     store_xyzz<typename EC::Field>(out, t, EC::to_boundary(p));
 }
 
@@ -579,12 +598,17 @@ __global__ void msm_collect_kernel(const uint32_t* __restrict__ buckets, uint32_
 // ------------------------------------------------------------------------------------------------
 // table[k] = 2^k * G, k < 256: one thread walks the doublings (XYZZ), then 256 threads normalise
 template <class FQ>
-__global__ void g1_pow2_table_kernel(uint32_t* __restrict__ table_xyzz) {
+__global__ void g1_pow2_table_kernel(uint32_t* __restrict__ table_xyzz, const uint32_t* __restrict__ g_xy = nullptr) {
     if (threadIdx.x != 0 || blockIdx.x != 0) return;
     using F = Fp<FQ>;
     Affine<F> g;
-    g.x = F::from_const(FQ::GEN_X);
-    g.y = F::from_const(FQ::GEN_Y);
+    if (g_xy) {                                            // a base point of the caller's (universal_setup_for_testing draws g = G1::rand)
+        g.x = load_fp<FQ>(g_xy);
+        g.y = load_fp<FQ>(g_xy + FQ::N);
+    } else {
+        g.x = F::from_const(FQ::GEN_X);
+        g.y = F::from_const(FQ::GEN_Y);
+    }
     XYZZ<F> cur = XYZZ<F>::from_affine(g);
     for (int k = 0; k < 256; k++) {
         store_xyzz<FQ>(table_xyzz, k, cur);

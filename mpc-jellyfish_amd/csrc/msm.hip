@@ -56,8 +56,8 @@ constexpr unsigned long long MSM_MIN_CAP = 48;
 struct PreInfo { int c = 0; uint64_t tab_stride = 0; };      // c == 0: plain path
 
 // A batch of MSMs sorts on a second stream: the sort of MSM p + 1 (memory- and LDS-bound, few registers) runs under the
-// accumulation of MSM p (VALU-bound at two waves per SIMD, which leaves register file and LDS for it).  SORT_SETS sets of sort buffers.
-constexpr int SORT_SETS = 3;                                       // sorts run up to two MSMs ahead of the accumulation
+// accumulation of MSM p (VALU-bound at two waves per SIMD, which leaves register file and LDS for it).  SORT_SETS sets of sort buffers (~220 MB each at 2^20).
+constexpr int SORT_SETS = 6;                                       // sorts run up to five MSMs ahead of the accumulation (3 sets left the sort of a dense MSM that follows two sparse ones exposed: round 1 of the bench circuit)
 struct SortStreams {                                               // one set per device context
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_sorted[SORT_SETS] = {}, ev_acc[SORT_SETS] = {};
@@ -97,8 +97,13 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     const int n_win = pre.c ? 1 : n_dig;                                 // bucket sets per MSM
     g_last_c = c; g_last_w = n_dig; g_last_m = M;
     const size_t wm = (size_t)n_win * M;
-    uint64_t n_max = 0;
-    for (int p = 0; p < count; p++) n_max = std::max<uint64_t>(n_max, items[p].n);
+    uint64_t n_max = 0, n_min = ~0ull;
+    for (int p = 0; p < count; p++) { n_max = std::max<uint64_t>(n_max, items[p].n); n_min = std::min<uint64_t>(n_min, items[p].n); }
+    // Large plain-path MSMs (no fixed-base table: what bench.py's headline runs) sort with the table path's two-level LDS sort over
+    // the COMBINED bucket range of their windows (window w owns buckets [w M, (w + 1) M)): one coalesced pass over the digits per
+    // level instead of msm_sort_kernel's one scan of a window's digits per 2048-bucket range.
+    static const bool no_sort2 = std::getenv("MZK_MSM_PLAIN_SORT1") != nullptr;                   // (A/B switch)
+    const bool sort2 = !pre.c && !no_sort2 && n_min >= (1ull << 16) && wm >= (1u << 14) && (wm >> PRE_FINE_LOG) <= 1024;
     const uint64_t sorted_max = pre.c ? n_max * n_dig : n_max;           // entries per bucket set
     MZK_TRY(ws_acquire(st));
     const bool overlap = count > 1 && std::getenv("MZK_MSM_NO_OVERLAP") == nullptr;
@@ -110,7 +115,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     MZK_TRY(g_ws.long_desc.reserve((size_t)n_win * desc_cap_max * sizeof(LongDesc) + (size_t)n_win * 4));
     MZK_TRY(g_ws.long_parts.reserve((size_t)n_win * desc_cap_max * EC::PT_WORDS * 4));
     const unsigned long long dstride_max = (n_max + 7) & ~7ull;
-    const size_t digits_bytes = (size_t)n_dig * dstride_max * (pre.c ? 4 : 2), sorted_words = ((size_t)n_dig * n_max + 3) & ~(size_t)3;
+    const size_t digits_bytes = (size_t)n_dig * dstride_max * ((pre.c || sort2) ? 4 : 2), sorted_words = ((size_t)n_dig * n_max + 3) & ~(size_t)3;
     MZK_TRY(g_ws.digits.reserve(nb * digits_bytes));
     MZK_TRY(g_ws.sorted.reserve(nb * sorted_words * 4));
     // coarse bins of the table path: the low 2^top_bits buckets also receive the short top digit of every scalar, so they
@@ -125,14 +130,15 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
             if (shrink > 0) { pb.low = 1u << top_bits; pb.low_log = PRE_FINE_LOG - shrink; pb.low_bins = pb.low >> pb.low_log; }
         }
     }
-    const uint32_t n_bins = pre.c ? std::max<uint32_t>(1u, pb.count(M)) : 0u;
+    const uint32_t n_bins = pre.c ? std::max<uint32_t>(1u, pb.count(M)) : (sort2 ? pb.count((uint32_t)wm) : 0u);
     const size_t cnt_words = 2048 + (size_t)n_win * 1024;                // bin totals, bin cursors, order keys
     MZK_TRY(g_ws.pre_cnt.reserve(nb * cnt_words * 4));
-    if (pre.c) {
+    if (pre.c || sort2) {
         MZK_TRY(g_ws.pre_off.reserve(nb * 2048 * 4));
         MZK_TRY(g_ws.pre_ce.reserve(nb * sorted_words * 8));
     }
     MZK_TRY(g_ws.buckets.reserve((size_t)count * wm * EC::PT_WORDS * 4));
+    MZK_TRY(g_ws.occ.reserve((size_t)count * wm));                        // one byte per bucket slot: does it hold a point?
     const int n_out_one = n_win * (log_m + 1);
     const int n_out = n_out_one * count;
     const size_t out_bytes = (size_t)n_out * 4 * FQ::N * 4;
@@ -167,6 +173,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
             const uint32_t* d_scalars = items[p].d_scalars;
             const uint32_t* d_bases = items[p].d_bases;
             uint32_t* buckets = g_ws.buckets.as<uint32_t>() + (size_t)p * wm * EC::PT_WORDS;
+            uint8_t* occ = g_ws.occ.as<uint8_t>() + (size_t)p * wm;
             const uint64_t n_sorted = pre.c ? n * (uint64_t)n_dig : n;
             // per-thread cap on a bucket's run (a chain of dependent mixed adds, ~5 us each when a wave runs alone): the
             // expected peak load plus six standard deviations.  On the table path the short top digit (scalar bits above
@@ -195,7 +202,8 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
             const unsigned long long dstride = (n + 7) & ~7ull;
             const unsigned gs = (unsigned)((n + MSM_THREADS - 1) / MSM_THREADS);
             if (overlap && (size_t)p >= nb) HIP_TRY(hipStreamWaitEvent(sst, ss.ev_acc[b], 0));     // MSM p - nb has read this set
-            if (!pre.c) {
+            const unsigned long long list_stride = (pre.c || sort2) ? 0ull : n;     // window w's entries start at sorted + w * list_stride (+ offs)
+            if (!pre.c && !sort2) {
                 ProfScope ps("msm_sort", sst);
                 uint16_t* digits = reinterpret_cast<uint16_t*>(g_ws.digits.as<char>() + b * digits_bytes);
                 hipLaunchKernelGGL((msm_digits_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, sst, d_scalars, n, is_mont, c, n_win, digits, dstride);
@@ -212,20 +220,21 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 uint32_t* bin_total = cnt;                       // [n_bins]
                 uint32_t* bin_cursor = cnt + 1024;               // [n_bins]
                 uint32_t* bin_start = coff;                      // [n_bins + 1]
+                const uint32_t bstride = pre.c ? 0u : M;                 // plain path: window w sorts into buckets [w M, (w + 1) M)
                 hipLaunchKernelGGL((pre_digits_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, sst, d_scalars, n, is_mont, c, n_dig, dig32, dstride);
                 HIP_TRY(hipMemsetAsync(cnt, 0, cnt_words * 4, sst));              // bin totals and, further down, the order keys: one fill
-                hipLaunchKernelGGL(pre_coarse_count_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, sst, dig32, n, dstride, n_dig, (int)n_bins, pb, bin_total);
+                hipLaunchKernelGGL(pre_coarse_count_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, sst, dig32, n, dstride, n_dig, (int)n_bins, pb, bstride, bin_total);
                 hipLaunchKernelGGL(pre_bin_scan_kernel, dim3(1), dim3(1024), 0, sst, bin_total, (int)n_bins, bin_start, bin_cursor);
-                hipLaunchKernelGGL(pre_coarse_scatter_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, sst, dig32, n, dstride, n_dig, (int)n_bins, pb,
-                                   pre.tab_stride, items[p].base_off, bin_cursor, coarse);
-                hipLaunchKernelGGL(pre_fine_kernel, dim3(n_bins), dim3(1024), 0, sst, bin_start, coarse, M, pb, hist, offs, sorted);
+                hipLaunchKernelGGL(pre_coarse_scatter_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, sst, dig32, n, dstride, n_dig, (int)n_bins, pb, bstride,
+                                   pre.c ? pre.tab_stride : 0ull, pre.c ? items[p].base_off : 0ull, bin_cursor, coarse);
+                hipLaunchKernelGGL(pre_fine_kernel, dim3(n_bins), dim3(1024), 0, sst, bin_start, coarse, (uint32_t)wm, pb, hist, offs, sorted);
             }
             {
                 // buckets ranked by load within each bucket set
                 ProfScope ps("msm_sort", sst);
                 uint32_t* keycnt = g_ws.pre_cnt.as<uint32_t>() + b * cnt_words + 2048;       // [n_win][1024]
                 const unsigned slices = (M + MSM_ORDER_SLICE - 1) / MSM_ORDER_SLICE;
-                if (!pre.c) HIP_TRY(hipMemsetAsync(keycnt, 0, (size_t)n_win * 1024 * 4, sst));   // (table path: zeroed with the bin totals above)
+                if (!pre.c && !sort2) HIP_TRY(hipMemsetAsync(keycnt, 0, (size_t)n_win * 1024 * 4, sst));   // (two-level sort: zeroed with the bin totals above)
                 hipLaunchKernelGGL(msm_order_hist_kernel, dim3(slices, n_win), dim3(1024), 0, sst, hist, M, keycnt);
                 hipLaunchKernelGGL(msm_order_scan_kernel, dim3(n_win), dim3(1024), 0, sst, keycnt);
                 hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(slices, n_win), dim3(1024), 0, sst, hist, M, keycnt, order);
@@ -250,7 +259,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 if (log_split == 0) {
                     ProfScope ps("msm_accumulate", st);
                     hipLaunchKernelGGL((msm_accumulate_kernel<EC>), dim3((unsigned)((wm + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
-                                       d_bases, n_sorted, offs, hist, sorted, order, M, n_win, cap, desc_count, buckets);
+                                       d_bases, list_stride, offs, hist, sorted, order, M, n_win, cap, desc_count, buckets, occ);
                 } else {
                     const size_t threads = wm << log_split;
                     MZK_TRY(g_ws.split.reserve(threads * EC::PT_WORDS * 4));
@@ -258,11 +267,11 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                     {
                         ProfScope ps("msm_accumulate", st);               // the dominant launch alone: what rocprofv3 --stats averages
                         hipLaunchKernelGGL((msm_accumulate_split_kernel<EC>), dim3((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)),
-                                           dim3(MSM_ACC_THREADS), 0, st, d_bases, n_sorted, offs, hist, sorted, order, M, n_win, cap, log_split, desc_count, sub);
+                                           dim3(MSM_ACC_THREADS), 0, st, d_bases, list_stride, offs, hist, sorted, order, M, n_win, cap, log_split, desc_count, sub);
                     }
                     ProfScope pc("msm_split_combine", st);
                     hipLaunchKernelGGL((msm_split_combine_kernel<EC>), dim3((unsigned)((threads + 2 * MSM_ACC_THREADS - 1) / (2 * MSM_ACC_THREADS))), dim3(MSM_ACC_THREADS),
-                                       0, st, sub, (unsigned long long)wm, log_split, buckets);
+                                       0, st, sub, (unsigned long long)wm, log_split, buckets, occ);
                 }
             }
             {
@@ -270,14 +279,15 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 ProfScope ps("msm_long", st);
                 hipLaunchKernelGGL(msm_long_find_kernel, dim3((unsigned)((wm + 255) / 256)), dim3(256), 0, st, hist, offs, M, n_win, cap, desc_cap, desc, desc_count);
                 hipLaunchKernelGGL((msm_long_chunk_kernel<EC>), dim3((desc_cap + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, n_win), dim3(MSM_ACC_THREADS), 0, st,
-                                   d_bases, n_sorted, sorted, desc, desc_count, desc_cap, parts);
-                hipLaunchKernelGGL((msm_long_combine_kernel<EC>), dim3(n_win), dim3(1024), 0, st, desc, desc_count, desc_cap, M, parts, buckets);
+                                   d_bases, list_stride, sorted, desc, desc_count, desc_cap, parts);
+                hipLaunchKernelGGL((msm_long_combine_kernel<EC>), dim3(n_win), dim3(1024), 0, st, desc, desc_count, desc_cap, M, parts, buckets, occ);
             }
             if (overlap) HIP_TRY(hipEventRecord(ss.ev_acc[b], st));
         }
         {
             ProfScope ps("msm_reduce", st);
             uint32_t* buckets = g_ws.buckets.as<uint32_t>();
+            uint8_t* occ = g_ws.occ.as<uint8_t>();
             const int nw_all = n_win * count;                   // every bucket set folds independently
             // wide levels: one launch each over all bucket sets; narrow levels (<= 256 adds per set): one launch in all
             int first_tail = 1;
@@ -286,11 +296,11 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 const uint32_t h = M >> lvl;
                 const size_t threads = (size_t)nw_all * lvl * h;
                 hipLaunchKernelGGL((msm_fold_kernel<EC>), dim3((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
-                                   buckets, M, h, lvl, nw_all);
+                                   buckets, occ, M, h, lvl, nw_all);
             }
             if (first_tail <= log_m)
-                hipLaunchKernelGGL((msm_fold_tail_kernel<EC>), dim3(nw_all), dim3(256), 0, st, buckets, M, log_m, first_tail);
-            hipLaunchKernelGGL((msm_collect_kernel<EC>), dim3((n_out + 63) / 64), dim3(64), 0, st, buckets, M, log_m, nw_all, collect);
+                hipLaunchKernelGGL((msm_fold_tail_kernel<EC>), dim3(nw_all), dim3(256), 0, st, buckets, occ, M, log_m, first_tail);
+            hipLaunchKernelGGL((msm_collect_kernel<EC>), dim3((n_out + 63) / 64), dim3(64), 0, st, buckets, occ, M, log_m, nw_all, collect);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(g_ws.h_collect, collect, out_bytes, hipMemcpyDeviceToHost, st));
@@ -443,19 +453,21 @@ int32_t srs_build_internal(Srs& s, hipStream_t st) {
 
 namespace {
 template <class FR, class FQ>
-int32_t srs_generate(const uint32_t* beta_canon, uint64_t n, uint32_t* d_out) {
+int32_t srs_generate(const uint32_t* beta_canon, const uint32_t* g_xy_mont, uint64_t n, uint32_t* d_out) {
     hipStream_t st = nullptr;
     MZK_TRY(ws_acquire(st));
     MZK_TRY(g_ws.scalars.reserve((n ? n : 1) * 32));
-    MZK_TRY(g_ws.misc.reserve(32 + 256 * 4 * FQ::N * 4 + 256 * 2 * FQ::N * 4));
+    MZK_TRY(g_ws.misc.reserve(32 + 256 * 4 * FQ::N * 4 + 256 * 2 * FQ::N * 4 + 2 * FQ::N * 4));
     uint32_t* d_beta = g_ws.misc.as<uint32_t>();
     uint32_t* d_tab_xyzz = d_beta + 8;
     uint32_t* d_tab = d_tab_xyzz + 256 * 4 * FQ::N;
+    uint32_t* d_g = d_tab + 256 * 2 * FQ::N;
     HIP_TRY(hipMemcpyAsync(d_beta, beta_canon, 32, hipMemcpyHostToDevice, st));
+    if (g_xy_mont) HIP_TRY(hipMemcpyAsync(d_g, g_xy_mont, 2 * FQ::N * 4, hipMemcpyHostToDevice, st));
     const unsigned long long chunks = (n + 63) / 64;
     hipLaunchKernelGGL((fr_powers_kernel<FR>), dim3((unsigned)((chunks + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0, st,
                        d_beta, n, g_ws.scalars.as<uint32_t>());
-    hipLaunchKernelGGL((g1_pow2_table_kernel<FQ>), dim3(1), dim3(64), 0, st, d_tab_xyzz);
+    hipLaunchKernelGGL((g1_pow2_table_kernel<FQ>), dim3(1), dim3(64), 0, st, d_tab_xyzz, g_xy_mont ? d_g : nullptr);
     hipLaunchKernelGGL((g1_table_to_affine_kernel<FQ>), dim3(4), dim3(64), 0, st, d_tab_xyzz, d_tab, 256);
     hipLaunchKernelGGL((g1_fixed_base_kernel<FQ>), dim3((unsigned)((n + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
                        d_tab, g_ws.scalars.as<uint32_t>(), n, d_out);
@@ -526,8 +538,8 @@ void jac_sum_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uint64_t*
     else jac_sum_host<BnFq>(xyz, n, out);
 }
 
-int32_t srs_generate_dispatch(int curve, const uint32_t* beta_canon, uint64_t n, uint32_t* d_out) {
-    return curve == 0 ? srs_generate<BlsFr, BlsFq>(beta_canon, n, d_out) : srs_generate<BnFr, BnFq>(beta_canon, n, d_out);
+int32_t srs_generate_dispatch(int curve, const uint32_t* beta_canon, const uint32_t* g_xy_mont, uint64_t n, uint32_t* d_out) {
+    return curve == 0 ? srs_generate<BlsFr, BlsFq>(beta_canon, g_xy_mont, n, d_out) : srs_generate<BnFr, BnFq>(beta_canon, g_xy_mont, n, d_out);
 }
 void jac_to_affine_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uint64_t* xy) {
     if (curve == 0) jac_to_affine_host<BlsFq>(xyz, n, xy);

@@ -52,8 +52,10 @@ __global__ __launch_bounds__(MSM_THREADS) void pre_digits_kernel(const uint32_t*
 //   pre_coarse_scatter: counts its chunk again in LDS, reserves a range per bin with ONE global atomic
 //                       per bin, then writes (entry, low bucket bits) into it.
 // entry = w*tab_stride + base_off + i (row of the precomputed table), sign in bit 31.
+// bucket_stride: 0 on the table path (all windows share one bucket set); M on the plain path, whose window w owns the buckets
+// [w M, (w + 1) M) of one combined bucket range -- the same two-level sort then serves both paths.
 __global__ __launch_bounds__(PRE_CTHREADS) void pre_coarse_count_kernel(const uint32_t* __restrict__ digits, unsigned long long n, unsigned long long stride,
-                                                                int n_win, int n_bins, PreBins pb, uint32_t* __restrict__ bin_total) {
+                                                                int n_win, int n_bins, PreBins pb, uint32_t bucket_stride, uint32_t* __restrict__ bin_total) {
     __shared__ uint32_t bins[1024];
     const uint32_t tid = threadIdx.x;
     for (int j = tid; j < n_bins; j += PRE_CTHREADS) bins[j] = 0u;
@@ -66,7 +68,7 @@ __global__ __launch_bounds__(PRE_CTHREADS) void pre_coarse_count_kernel(const ui
             const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                if (i + k < hi && d4[k] != PRE_EMPTY) atomicAdd(&bins[pb.bin_of(d4[k] & 0x7FFFFFFFu)], 1u);
+                if (i + k < hi && d4[k] != PRE_EMPTY) atomicAdd(&bins[pb.bin_of((d4[k] & 0x7FFFFFFFu) + (uint32_t)w * bucket_stride)], 1u);
         }
     }
     __syncthreads();
@@ -92,8 +94,8 @@ __global__ __launch_bounds__(1024) void pre_bin_scan_kernel(const uint32_t* __re
 }
 
 __global__ __launch_bounds__(PRE_CTHREADS) void pre_coarse_scatter_kernel(const uint32_t* __restrict__ digits, unsigned long long n, unsigned long long stride,
-                                                                  int n_win, int n_bins, PreBins pb, unsigned long long tab_stride, unsigned long long base_off,
-                                                                  uint32_t* __restrict__ bin_cursor, unsigned long long* __restrict__ coarse) {
+                                                                  int n_win, int n_bins, PreBins pb, uint32_t bucket_stride, unsigned long long tab_stride,
+                                                                  unsigned long long base_off, uint32_t* __restrict__ bin_cursor, unsigned long long* __restrict__ coarse) {
     __shared__ uint32_t bins[1024];
     const uint32_t tid = threadIdx.x;
     for (int j = tid; j < n_bins; j += PRE_CTHREADS) bins[j] = 0u;
@@ -106,7 +108,7 @@ __global__ __launch_bounds__(PRE_CTHREADS) void pre_coarse_scatter_kernel(const 
             const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
             for (int k = 0; k < 4; k++)
-                if (i + k < hi && d4[k] != PRE_EMPTY) atomicAdd(&bins[pb.bin_of(d4[k] & 0x7FFFFFFFu)], 1u);
+                if (i + k < hi && d4[k] != PRE_EMPTY) atomicAdd(&bins[pb.bin_of((d4[k] & 0x7FFFFFFFu) + (uint32_t)w * bucket_stride)], 1u);
         }
     }
     __syncthreads();
@@ -124,7 +126,7 @@ __global__ __launch_bounds__(PRE_CTHREADS) void pre_coarse_scatter_kernel(const 
             for (int k = 0; k < 4; k++) {
                 const uint32_t d = d4[k];
                 if (i + k >= hi || d == PRE_EMPTY) continue;
-                const uint32_t b = d & 0x7FFFFFFFu;
+                const uint32_t b = (d & 0x7FFFFFFFu) + (uint32_t)w * bucket_stride;
                 const uint32_t bin = pb.bin_of(b);
                 const uint32_t pos = atomicAdd(&bins[bin], 1u);
                 const uint32_t e = (uint32_t)((unsigned long long)w * tab_stride + base_off + i + k) | (d & 0x80000000u);

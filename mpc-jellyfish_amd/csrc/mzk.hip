@@ -35,7 +35,7 @@ void DevBuf::release() {
     cap = 0;
 }
 void Workspace::release() {
-    for (DevBuf* b : {&ntt_scratch, &scalars, &hist, &offs, &cursor, &sorted, &buckets, &collect, &io, &misc, &digits, &long_desc, &long_parts, &plonk_polys, &plonk_out, &pre_cnt, &pre_off, &pre_ce, &pre_cb, &poly_tmp, &split, &link_tmp}) b->release();
+    for (DevBuf* b : {&ntt_scratch, &scalars, &hist, &offs, &cursor, &sorted, &buckets, &collect, &io, &misc, &digits, &long_desc, &long_parts, &plonk_polys, &plonk_out, &pre_cnt, &pre_off, &pre_ce, &pre_cb, &poly_tmp, &split, &link_tmp, &occ}) b->release();
     if (h_collect) (void)hipHostFree(h_collect);
     h_collect = nullptr;
     h_collect_cap = 0;
@@ -333,7 +333,7 @@ int32_t mzk_srs_release(uint64_t handle) {
     cx_->srs.erase(it);
     return MZK_OK;
 }
-int32_t mzk_srs_generate_for_testing(int32_t curve_id, const uint64_t* beta_canonical, uint64_t n_points, uint64_t* out_handle) {
+int32_t mzk_srs_generate_for_testing_g(int32_t curve_id, const uint64_t* beta_canonical, const uint64_t* g_xy_mont, uint64_t n_points, uint64_t* out_handle) {
     ENTER_CUR();
     if ((curve_id != 0 && curve_id != 1) || !out_handle || !beta_canonical) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
     Srs s{curve_id, n_points, nullptr, nullptr, nullptr, 0};
@@ -342,13 +342,16 @@ int32_t mzk_srs_generate_for_testing(int32_t curve_id, const uint64_t* beta_cano
     int32_t rc = MZK_OK;
     if (n_points) {
         const uint32_t* beta = reinterpret_cast<const uint32_t*>(beta_canonical);
-        rc = srs_generate_dispatch(curve_id, beta, n_points, s.d_xy);
+        rc = srs_generate_dispatch(curve_id, beta, reinterpret_cast<const uint32_t*>(g_xy_mont), n_points, s.d_xy);
     }
     if (rc == MZK_OK) rc = srs_build_internal(s, nullptr);
     if (rc != MZK_OK) { (void)hipFree(s.d_xy); return rc; }
     *out_handle = handle_make(cx_->logical, cx_->next_handle++);
     cx_->srs[*out_handle] = s;
     return MZK_OK;
+}
+int32_t mzk_srs_generate_for_testing(int32_t curve_id, const uint64_t* beta_canonical, uint64_t n_points, uint64_t* out_handle) {
+    return mzk_srs_generate_for_testing_g(curve_id, beta_canonical, nullptr, n_points, out_handle);
 }
 int32_t mzk_srs_download(uint64_t handle, uint64_t first, uint64_t n_points, uint64_t* out_xy_mont) {
     ENTER_HANDLE(handle);

@@ -17,7 +17,7 @@ import ctypes as C
 import numpy as np
 
 from . import lib as _lib
-from .params import CurveParams, curve as _curve, int_to_limbs
+from .params import CurveParams, curve as _curve, fq_to_mont, int_to_limbs
 
 
 class PCSError(Exception):
@@ -57,14 +57,17 @@ class UnivariateProverParam:
         return cls(c, h.value, a.shape[0])
 
     @classmethod
-    def gen_srs_for_testing(cls, curve, beta: int, max_degree: int) -> "UnivariateProverParam":
-        """powers_of_g = [beta^i * G] for i <= max_degree (srs.rs:118-153), built on the GPU."""
+    def gen_srs_for_testing(cls, curve, beta: int, max_degree: int, g=None) -> "UnivariateProverParam":
+        """powers_of_g = [beta^i * g] for i <= max_degree (srs.rs:118-153), built on the GPU.  g: affine base point as canonical
+        integers (x, y) -- `universal_setup_for_testing` draws it with G1::rand after beta (snark.rs:495-497); None: the curve's
+        standard generator."""
         c = _curve(curve)
         L = _lib.ensure_init()
         h = C.c_uint64()
         b = int_to_limbs(beta % c.r, 4)
-        _lib.check(L.mzk_srs_generate_for_testing(c.curve_id, C.c_void_p(b.ctypes.data), max_degree + 1, C.byref(h)),
-                   "mzk_srs_generate_for_testing")
+        gm = None if g is None else np.ascontiguousarray(np.concatenate([fq_to_mont(c, [g[0]])[0], fq_to_mont(c, [g[1]])[0]]))
+        _lib.check(L.mzk_srs_generate_for_testing_g(c.curve_id, C.c_void_p(b.ctypes.data), None if gm is None else C.c_void_p(gm.ctypes.data),
+                                                    max_degree + 1, C.byref(h)), "mzk_srs_generate_for_testing_g")
         return cls(c, h.value, max_degree + 1)
 
     def trim(self, supported_degree: int) -> "UnivariateProverParam":

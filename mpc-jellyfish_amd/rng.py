@@ -131,3 +131,74 @@ def compute_coset_representatives(curve, num_wire_types: int, coset_size: int | 
         ks.append(k)
         pows.append(p)
     return ks
+
+
+# ---- `universal_setup_for_testing` (plonk/src/proof_system/snark.rs:485-526; primitives/src/pcs/univariate_kzg/srs.rs:118-153) ----------
+# The reference's tests and its bench build their SRS with beta = Fr::rand, g = G1::rand, h = G2::rand drawn from the SAME rng that
+# `prove` then takes its blinders from.  A host that wants the reference's proof bytes for such a setup mirrors those draws:
+# [upstream ark-ec 0.4] `impl Distribution<Projective<P>> for Standard`: loop { x = BaseField::rand; greatest = rng.gen::<bool>()
+# (rand 0.8: the top bit of one u32); get_point_from_x_unchecked(x, greatest) -- the two roots of x^3 + b ordered as integers --
+# or draw again }, then the point times P::COFACTOR.
+G1_COFACTOR = {0: 0x396c8c005555e1568c00aaab0000aaab, 1: 1}
+
+
+def fq_rand(curve, rng: ChaChaRng) -> int:
+    c = _curve(curve)
+    nl = c.fq_limbs
+    shave = 64 * nl - c.q.bit_length()
+    while True:
+        limbs = [rng.next_u64() for _ in range(nl)]
+        limbs[-1] &= (1 << (64 - shave)) - 1
+        v = sum(l << (64 * i) for i, l in enumerate(limbs))
+        if v < c.q:
+            return v * pow(1 << (64 * nl), -1, c.q) % c.q
+
+
+def g1_rand(curve, rng: ChaChaRng):
+    """`E::G1::rand(rng)`: affine (x, y) as canonical integers.  The cofactor multiple is one single-pair MSM on the device."""
+    import numpy as np
+    from . import kzg
+    from .params import fq_from_mont, fq_to_mont, fr_bigints
+    c = _curve(curve)
+    b = 4 if c.curve_id == 0 else 3
+    while True:
+        x = fq_rand(c, rng)
+        greatest = rng.next_u32() >> 31 == 1
+        rhs = (x * x % c.q * x + b) % c.q
+        y = pow(rhs, (c.q + 1) // 4, c.q)                     # q = 3 mod 4 on both curves
+        if y * y % c.q != rhs:
+            continue
+        y = max(y, c.q - y) if greatest else min(y, c.q - y)
+        if G1_COFACTOR[c.curve_id] == 1:
+            return (x, y)
+        pt = np.concatenate([fq_to_mont(c, [x])[0], fq_to_mont(c, [y])[0]]).reshape(1, -1)
+        pp = kzg.UnivariateProverParam.from_affine(c, pt)
+        aff = kzg.jacobian_to_affine(c, kzg.msm_bigint(pp, fr_bigints([G1_COFACTOR[c.curve_id]]))[None])[0]
+        pp.release()
+        return tuple(fq_from_mont(c, aff))
+
+
+def g2_rand_skip(curve, rng: ChaChaRng) -> None:
+    """`E::G2::rand(rng)` as far as a prover is concerned: the draws it takes (h sits in the verifying key's open key only).
+    Fq2 = Fq[u] / (u^2 + 1); x^3 + b' (4 (1 + u) on BLS12-381, 3 / (9 + u) on BN254) is a square iff its norm is one in Fq."""
+    c = _curve(curve)
+    q = c.q
+    mul = lambda a, b: ((a[0] * b[0] - a[1] * b[1]) % q, (a[0] * b[1] + a[1] * b[0]) % q)
+    b2 = (4, 4) if c.curve_id == 0 else (27 * pow(82, -1, q) % q, (-3) * pow(82, -1, q) % q)
+    while True:
+        x = (fq_rand(c, rng), fq_rand(c, rng))
+        rng.next_u32()
+        x3 = mul(mul(x, x), x)
+        rhs = ((x3[0] + b2[0]) % q, (x3[1] + b2[1]) % q)
+        norm = (rhs[0] * rhs[0] + rhs[1] * rhs[1]) % q
+        if norm == 0 or pow(norm, (q - 1) // 2, q) == 1:
+            return
+
+
+def universal_setup_for_testing(curve, rng: ChaChaRng):
+    """(beta, g): powers_of_g[i] = beta^i g (kzg.UnivariateProverParam.gen_srs_for_testing(c, beta, degree, g=g)); the rng is left
+    where `prove` finds it after the reference's setup."""
+    beta = fr_rand(curve, rng)
+    g = g1_rand(curve, rng)
+    g2_rand_skip(curve, rng)
+    return beta, g

@@ -9,6 +9,10 @@ product package (mpc-jellyfish_amd/rng.py is a separate text by design):
   DensePolynomial::rand             ark-poly 0.4: degree + 1 draws of F::rand, low order first
   draw order of one proof           /root/reference/plonk/src/proof_system/prover.rs:79-83, 113-114, 133-138, 169-180, 947-955
   draw order of a batch             /root/reference/plonk/src/proof_system/snark.rs:277-399 (round by round, instance by instance)
+  universal_setup_for_testing       /root/reference/plonk/src/proof_system/snark.rs:485-526: beta = Fr::rand, g = G1::rand, h = G2::rand
+  G1::rand / G2::rand               ark-ec 0.4 `impl Distribution<Projective<P>> for Standard` [upstream, restated from the published
+                                    source; pinned only when integration/rust/gen_fixtures has run]: loop { x = BaseField::rand;
+                                    greatest = rng.gen::<bool>(); if x^3 + b is a square: the root chosen by `greatest`, times COFACTOR }
 
 ChaCha (Bernstein 2008; RFC 7539 section 2.1-2.3 for the quarter round and the state layout): constants "expand 32-byte k",
 key = the 32-byte seed, words 12-13 = 64-bit block counter, words 14-15 = stream id 0 (rand_chacha's layout, the original
@@ -150,3 +154,79 @@ def draw_batch_blinders(c, rng: BlockRng, num_wire_types: int, ultra_flags) -> t
             b["prod_lookup"] = dense_poly_rand(c, 2, rng)
     quot = [fr_rand(c, rng) for _ in range(num_wire_types - 1)]
     return per, quot
+
+
+# ---- universal_setup_for_testing (snark.rs:485-526; primitives/src/pcs/univariate_kzg/srs.rs:118-153) ----------------------------
+G1_COFACTOR = {0: 0x396c8c005555e1568c00aaab0000aaab, 1: 1}                 # ark-bls12-381 / ark-bn254 `G1Config::COFACTOR`
+
+
+def fq_rand(c, rng: BlockRng) -> int:
+    """`Fq::rand`, as fr_rand: fq_limbs u64 draws, top bits shaved, accepted below q; the limbs are the Montgomery image."""
+    n = c.fq_limbs
+    shave = 64 * n - c.q.bit_length()
+    while True:
+        limbs = [rng.next_u64() for _ in range(n)]
+        limbs[n - 1] &= ((1 << 64) - 1) >> shave
+        cand = sum(l << (64 * i) for i, l in enumerate(limbs))
+        if cand < c.q:
+            return cand * pow(1 << (64 * n), -1, c.q) % c.q
+
+
+def gen_bool(rng: BlockRng) -> bool:
+    """rand 0.8 `Standard` for bool: the most significant bit of ONE u32."""
+    return rng.next_u32() >> 31 == 1
+
+
+def _fq_sqrt(c, a: int):
+    """q = 3 mod 4 for both base fields (ark-ff `SqrtPrecomputation::Case3Mod4`): a^((q + 1) / 4), None when a is not a square."""
+    assert c.q % 4 == 3
+    y = pow(a, (c.q + 1) // 4, c.q)
+    return y if y * y % c.q == a % c.q else None
+
+
+def g1_rand(c, rng: BlockRng):
+    """`E::G1::rand(rng)` (snark.rs:496): affine point or None; get_point_from_x_unchecked orders the two roots as integers
+    (`y < -y` on canonical values) and `greatest` picks the larger."""
+    import pyref as P
+    while True:
+        x = fq_rand(c, rng)
+        greatest = gen_bool(rng)
+        y = _fq_sqrt(c, (x * x % c.q * x + c.b) % c.q)
+        if y is None:
+            continue
+        small, large = sorted((y, (-y) % c.q))
+        return P.g1_mul(c, G1_COFACTOR[c.curve_id], (x, large if greatest else small))
+
+
+def g2_rand_consume(c, rng: BlockRng) -> int:
+    """`E::G2::rand(rng)` (snark.rs:497) as far as the PROVER can tell: the draws it takes from the stream.  h enters the verifying
+    key's open key only (not the transcript, not the proof), so the point itself is not rebuilt here.  Fq2 = Fq[u] / (u^2 + 1) on
+    both curves; x^3 + b' (b' = 4 (1 + u) on BLS12-381, 3 / (9 + u) on BN254) has a square root iff its norm is a square in Fq
+    (ark-ff QuadExtField::sqrt, complex method; c1 = 0 has probability 2^-254).  Returns the number of attempts."""
+    q = c.q
+    mul = lambda a, b: ((a[0] * b[0] - a[1] * b[1]) % q, (a[0] * b[1] + a[1] * b[0]) % q)
+    if c.curve_id == 0:
+        b2 = (4, 4)
+    else:
+        inv82 = pow(82, -1, q)
+        b2 = (27 * inv82 % q, (-3) * inv82 % q)                                # 3 / (9 + u) = 3 (9 - u) / 82
+    attempts = 0
+    while True:
+        attempts += 1
+        x = (fq_rand(c, rng), fq_rand(c, rng))                                  # QuadExtField::rand: c0, then c1
+        gen_bool(rng)
+        x3 = mul(mul(x, x), x)
+        rhs = ((x3[0] + b2[0]) % q, (x3[1] + b2[1]) % q)
+        norm = (rhs[0] * rhs[0] + rhs[1] * rhs[1]) % q
+        if rhs[1] == 0:
+            raise NotImplementedError("c1 = 0: probability 2^-254")
+        if norm == 0 or pow(norm, (q - 1) // 2, q) == 1:
+            return attempts
+
+
+def universal_setup_for_testing(c, rng: BlockRng):
+    """(beta, g) of `universal_setup_for_testing` and the stream advanced past h: powers_of_g[i] = beta^i g (snark.rs:495-517)."""
+    beta = fr_rand(c, rng)
+    g = g1_rand(c, rng)
+    g2_rand_consume(c, rng)
+    return beta, g

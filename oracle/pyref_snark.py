@@ -24,11 +24,13 @@ PLOOKUP_EVAL_FIELDS = ("range_table_eval", "key_table_eval", "table_dom_sep_eval
 
 
 def prove(c, log_n, selector_vals, sigma_vals, k, wire_vals, pi_vals, pub_input, blind, srs_beta, transcript, g1_bytes, fr_bytes,
-          plookup=None, extra_msg=None):
-    """Returns {"proof": compressed Proof bytes, "vk": verifying-key commitments (affine points), "challenges", "core": prove_core output}."""
+          plookup=None, extra_msg=None, srs_g=None):
+    """Returns {"proof": compressed Proof bytes, "vk": verifying-key commitments (affine points), "challenges", "core": prove_core output}.
+    srs_g: the SRS is powers_of_g[i] = srs_beta^i * srs_g (default: the curve's standard generator; universal_setup_for_testing
+    draws a random one, snark.rs:496)."""
     r = c.r
     n = 1 << log_n
-    G = P.g1_gen(c)
+    G = P.g1_gen(c) if srs_g is None else srs_g
     ultra = plookup is not None
     pt = lambda dlog: P.g1_mul(c, dlog % r, G) if dlog % r else None
     # placeholders for the rounds not reached yet (generic values: no accidental zero denominators)

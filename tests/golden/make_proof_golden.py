@@ -28,7 +28,10 @@ import pyref_rng as RNG  # noqa: E402
 CASES = [(0, "TurboPlonk", 20, 8), (1, "TurboPlonk", 20, 8), (1, "UltraPlonk", 20, 3), (0, "UltraPlonk", 24, 4)]
 
 
-def build(curve_id, plonk_type, num_gates, range_bits, rng=None, want_core=False):
+def build(curve_id, plonk_type, num_gates, range_bits, rng=None, want_core=False, reference_setup=False):
+    """reference_setup: the SRS of `universal_setup_for_testing` (plonk/src/proof_system/snark.rs:495-517) -- beta = Fr::rand, then
+    g = G1::rand and h = G2::rand from the same `test_rng`, powers_of_g[i] = beta^i g -- instead of the curve's standard generator:
+    what plonk/benches/bench.rs and the reference's own tests prove over.  oracle/pyref_rng.py restates the two samplers."""
     pc = P.CURVES[curve_id]
     ultra = plonk_type == "UltraPlonk"
     W = 6 if ultra else 5
@@ -36,7 +39,12 @@ def build(curve_id, plonk_type, num_gates, range_bits, rng=None, want_core=False
     n = PC.bench_circuit(pc, num_gates, ultra, range_bits, list(range(1, W + 1)))[0]
     k = RNG.compute_coset_representatives(pc, W, n)
     n, wires, witness, sel, sigma, tables = PC.bench_circuit(pc, num_gates, ultra, range_bits, k)
-    if rng is None:
+    srs_g = None
+    if reference_setup:
+        assert rng is None
+        rng = RNG.test_rng()
+        srs_beta, srs_g = RNG.universal_setup_for_testing(pc, rng)
+    elif rng is None:
         rng = RNG.test_rng()
         srs_beta = RNG.fr_rand(pc, rng)
     else:                                                                 # a later proof on the same stream: the trapdoor was its first draw
@@ -47,7 +55,7 @@ def build(curve_id, plonk_type, num_gates, range_bits, rng=None, want_core=False
     g1 = lambda p: FS.g1_bytes(pc, p)
     fr = lambda x: FS.fr_bytes(pc, x)
     out = PS.prove(pc, n.bit_length() - 1, sel, sigma, k, w_vals, [0] * n, [], blind, srs_beta, FS.StandardTranscript(pc, b"PlonkProof"),
-                   g1, fr, plookup=tables)
+                   g1, fr, plookup=tables, srs_g=srs_g)
     vk = out["vk"]
     rec = {"curve": curve_id, "plonk_type": plonk_type, "num_gates": num_gates, "range_bit_len": range_bits, "domain_size": n,
            "srs_beta": "%x" % srs_beta, "k": ["%x" % x for x in k],
@@ -55,6 +63,9 @@ def build(curve_id, plonk_type, num_gates, range_bits, rng=None, want_core=False
            "plookup_comms": None, "challenges": {name: "%x" % v for name, v in out["challenges"].items()}, "proof": out["proof"].hex()}
     if ultra:
         rec["plookup_comms"] = {name: g1(p).hex() for name, p in vk["plookup"].items()}
+    if reference_setup:
+        rec["setup"] = "universal_setup_for_testing"
+        rec["srs_g"] = ["%x" % srs_g[0], "%x" % srs_g[1]]
     return (rec, out) if want_core else rec
 
 
@@ -112,6 +123,10 @@ if __name__ == "__main__":
     with open(os.path.join(HERE, "proof_vectors.json"), "w") as f:
         json.dump(vectors, f, indent=1)
     print("wrote", len(vectors), "proof vectors:", [len(v["proof"]) // 2 for v in vectors], "bytes")
+    refsetup = [build(*case, reference_setup=True) for case in CASES]
+    with open(os.path.join(HERE, "proof_vectors_refsetup.json"), "w") as f:
+        json.dump(refsetup, f, indent=1)
+    print("wrote", len(refsetup), "proof vectors over universal_setup_for_testing's SRS (g = G1::rand)")
     links = [build_link(*case) for case in LINK_CASES]
     with open(os.path.join(HERE, "link_vectors.json"), "w") as f:
         json.dump(links, f, indent=1)

@@ -50,6 +50,29 @@ def test_golden_proof_vectors(pyref, mj, index):
     assert not V.verify(pc, fresh(), vk, [], bytes(bad), pyref.g1_gen(pc), srs_beta)
 
 
+@pytest.mark.parametrize("index", [0, 1, 2, 3])
+def test_golden_proof_vectors_over_the_reference_testing_setup(pyref, mj, index):
+    """tests/golden/proof_vectors_refsetup.json (SRS of universal_setup_for_testing: g = G1::rand, snark.rs:495-517): regenerated
+    identically; g lies on the curve and in the subgroup; the restated verifier accepts with open key (g, h, beta h) -- h is any
+    G2 generator multiple for the pairing check, the prover never sees it."""
+    import pyref_verifier as V
+    vec = load_golden("proof_vectors_refsetup")[index]
+    gen = _generator()
+    assert gen.build(*gen.CASES[index], reference_setup=True) == vec, "tests/golden/proof_vectors_refsetup.json is stale: run tests/golden/make_proof_golden.py"
+    pc = pyref.CURVES[vec["curve"]]
+    g = (int(vec["srs_g"][0], 16), int(vec["srs_g"][1], 16))
+    assert pyref.g1_on_curve(pc, g) and pyref.g1_mul(pc, pc.r, g) is None and g != pyref.g1_gen(pc)
+    rng = RNG.test_rng()
+    assert RNG.universal_setup_for_testing(pc, rng) == (int(vec["srs_beta"], 16), g)
+    vk = golden_vk(V, pc, vec)
+    proof = bytes.fromhex(vec["proof"])
+    fresh = lambda: FS.StandardTranscript(pc, b"PlonkProof")
+    assert V.verify(pc, fresh(), vk, [], proof, g, int(vec["srs_beta"], 16))
+    bad = bytearray(proof)
+    bad[-40 if vec["plookup_comms"] is None else -2] ^= 1
+    assert not V.verify(pc, fresh(), vk, [], bytes(bad), g, int(vec["srs_beta"], 16))
+
+
 @pytest.mark.parametrize("index", [0, 1])
 def test_golden_link_vectors(pyref, mj, index):
     """tests/golden/link_vectors.json: two proofs on one `test_rng` stream and their LinkingProof, all by the restatements --
@@ -111,19 +134,21 @@ def test_golden_batch_vectors(pyref, mj, index):
     assert not V.verify_batch_proof(pc, fresh(), vks[::-1], pubs, blob, G, srs_beta)
 
 
-def test_reference_proof_fixtures_when_present():
+@pytest.mark.parametrize("name", ["proof_vectors", "proof_vectors_refsetup"])
+def test_reference_proof_fixtures_when_present(name):
     """tests/golden/ref_proof_vectors.json = `PlonkKzgSnark::{preprocess, prove}` of the reference itself on the four golden cases
-    (integration/rust/src/bin/gen_fixtures.rs).  When present: coset representatives, verifying-key commitments and the compressed
-    proof BYTES of the restatements must equal the reference's."""
+    (integration/rust/src/bin/gen_fixtures.rs); ref_proof_vectors_refsetup.json = the same over the reference's OWN
+    `universal_setup_for_testing` (g = G1::rand: also pins the restated sampler).  When present: coset representatives, verifying-key
+    commitments and the compressed proof BYTES of the restatements must equal the reference's."""
     import json
-    path = os.path.join(HERE, "golden", "ref_proof_vectors.json")
+    path = os.path.join(HERE, "golden", "ref_%s.json" % name)
     if not os.path.exists(path):
         pytest.skip("reference fixtures absent (integration/rust has not been run): parity unpinned")
     ref = json.load(open(path))
-    ours = load_golden("proof_vectors")
+    ours = load_golden(name)
     assert len(ref) == len(ours)
     for a, b in zip(ours, ref):
-        for f in ("curve", "plonk_type", "num_gates", "domain_size", "srs_beta"):
+        for f in ("curve", "plonk_type", "num_gates", "domain_size", "srs_beta") + (("srs_g",) if "srs_g" in a else ()):
             assert a[f] == b[f]
         assert [int(x, 16) for x in a["k"]] == [int(x, 16) for x in b["k"]]
         assert a["selector_comms"] == b["selector_comms"] and a["sigma_comms"] == b["sigma_comms"]

@@ -93,3 +93,27 @@ def test_device_and_cpp_batch_prove_reproduce_the_golden_batch_proof(gpu, mj, in
     for pk in pks:
         pk.release()
     ck.release()
+
+
+@pytest.mark.parametrize("index", [0, 1, 2, 3])
+def test_device_prover_over_the_reference_testing_setup(gpu, mj, index):
+    """tests/golden/proof_vectors_refsetup.json: the same four proofs over the SRS of `universal_setup_for_testing`
+    (plonk/src/proof_system/snark.rs:495-517: beta = Fr::rand, g = G1::rand, h = G2::rand from the rng `prove` continues on) --
+    what plonk/benches/bench.rs and the reference's own tests prove over.  The product mirrors the three draws (rng.py), builds
+    [beta^i g] on the device (mzk_srs_generate_for_testing_g) and must emit the oracle's bytes; integration/rust/gen_fixtures
+    writes the reference's bytes for the same case (tests/golden/ref_proof_vectors_refsetup.json) the day it runs."""
+    vec = load_golden("proof_vectors_refsetup")[index]
+    assert vec["setup"] == "universal_setup_for_testing"
+    c = mj.params.CURVES[vec["curve"]]
+    cs = mj.snark.gen_circuit_for_bench(c, vec["num_gates"], vec["plonk_type"], range_bit_len=vec["range_bit_len"])
+    rng = mj.rng.test_rng()
+    srs_beta, g = mj.rng.universal_setup_for_testing(c, rng)
+    assert "%x" % srs_beta == vec["srs_beta"] and ["%x" % g[0], "%x" % g[1]] == vec["srs_g"]
+    ck = mj.UnivariateProverParam.gen_srs_for_testing(c, srs_beta, cs.n + 2, g=g)
+    pk = mj.snark.preprocess(ck, cs)
+    sel, sig = pk.vk_commitments()
+    assert [mj.snark._g1(c, x).hex() for x in sel] == vec["selector_comms"] and [mj.snark._g1(c, x).hex() for x in sig] == vec["sigma_comms"]
+    _, proof_bytes = mj.snark.prove(rng, cs, pk)
+    assert proof_bytes.hex() == vec["proof"]
+    pk.release()
+    ck.release()
