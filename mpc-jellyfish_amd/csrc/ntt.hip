@@ -1,5 +1,6 @@
 // ntt.hip -- host side of the NTT: plan cache and pass launches.  The passes run on the reduced-radix
 // kernel of ntt_fx.cuh; ntt.cuh keeps the 32-bit-limb kernel it was derived from (same decomposition).
+#include <cstdlib>
 #include <map>
 #include <memory>
 
@@ -83,18 +84,53 @@ int32_t get_plan(int curve, int log_n, bool inverse, const uint32_t* coset, int 
     return MZK_OK;
 }
 
+// how many workgroups of the persistent pass one launch keeps resident (per device context; the occupancy query costs ~50 us)
+template <class X, bool TW_LDS>
+int32_t persistent_grid(size_t lds, unsigned* out) {
+    static unsigned cached[MAX_CTX][4] = {};                             // by LDS size class
+    const int cls = lds >= 48 * 1024 ? 0 : (lds >= 36 * 1024 ? 1 : (lds >= 18 * 1024 ? 2 : 3));
+    unsigned& slot = cached[cur().logical][cls];
+    if (!slot) {
+        int per_cu = 0, dev = 0, cus = 0;
+        HIP_TRY(hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (const void*)nttx_pass_persistent_kernel<X, TW_LDS>, NTTX_THREADS, lds));
+        HIP_TRY(hipGetDevice(&dev));
+        HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev));
+        if (per_cu < 1) per_cu = 1;
+        slot = (unsigned)(per_cu * cus);
+    }
+    *out = slot;
+    return MZK_OK;
+}
+
 template <class X>
 int32_t launch_pass(const NttxPassArgs& a, unsigned long long n_tiles, uint32_t batch, hipStream_t st) {
-    const size_t tile = (size_t)1 << (a.log_r + a.log_c), r = (size_t)1 << a.log_r;
+    const size_t tile = (size_t)1 << (a.log_r + a.log_c);
     const size_t lds = 2 * tile * 16 + tile * 4;
-    (void)r;
     static bool attr_set[MAX_CTX] = {};                                  // per device (function attributes live in the device's code object)
     if (!attr_set[cur().logical]) {
         HIP_TRY(hipFuncSetAttribute((const void*)nttx_pass_kernel<X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        HIP_TRY(hipFuncSetAttribute((const void*)nttx_pass_persistent_kernel<X, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        HIP_TRY(hipFuncSetAttribute((const void*)nttx_pass_persistent_kernel<X, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         attr_set[cur().logical] = true;
     }
     ProfScope ps("ntt_pass", st);
-    hipLaunchKernelGGL((nttx_pass_kernel<X>), dim3((unsigned)n_tiles, batch), dim3(NTTX_THREADS), lds, st, a);
+    // MZK_NTT_PERSISTENT = 1 / 2: the persistent pass with / without LDS-staged twiddles (ntt_fx.cuh) -- built and MEASURED in round 3
+    // (profiles/r03_ntt_experiments.txt): 0.647 / 0.679 ms per 2^22 transform against 0.603 ms for one tile per workgroup, which
+    // therefore stays the default.  Its 113 VGPRs (prefetched elements live across the stages) leave 2 workgroups per CU instead of 4.
+    static const int mode = std::getenv("MZK_NTT_PERSISTENT") ? std::atoi(std::getenv("MZK_NTT_PERSISTENT")) : 0;
+    const unsigned long long total = n_tiles * batch;
+    unsigned resident = 0;
+    const bool tw_lds = !a.is_final && mode != 2;                         // (mode 2: persistent without LDS-staged twiddles)
+    const size_t lds_p = lds + (tw_lds ? (((size_t)1 << a.log_r) - 1) * FS_TW_WORDS * 4 : 0);
+    if (mode) MZK_TRY((tw_lds ? persistent_grid<X, true>(lds_p, &resident) : persistent_grid<X, false>(lds_p, &resident)));
+    if (mode && total >= 3ull * resident && tile <= 2 * NTTX_THREADS) {
+        int log_tiles = 0;
+        while ((1ull << log_tiles) < n_tiles) log_tiles++;
+        if (tw_lds) hipLaunchKernelGGL((nttx_pass_persistent_kernel<X, true>), dim3(resident), dim3(NTTX_THREADS), lds_p, st, a, log_tiles, total);
+        else hipLaunchKernelGGL((nttx_pass_persistent_kernel<X, false>), dim3(resident), dim3(NTTX_THREADS), lds_p, st, a, log_tiles, total);
+    } else {
+        hipLaunchKernelGGL((nttx_pass_kernel<X>), dim3((unsigned)n_tiles, batch), dim3(NTTX_THREADS), lds, st, a);
+    }
     HIP_TRY(hipGetLastError());
     return MZK_OK;
 }

@@ -168,9 +168,13 @@ __global__ __launch_bounds__(NTTX_THREADS) void nttx_pass_kernel(NttxPassArgs a)
             g = (((i1_0 + c) * p1 + rest) << a.log_r) + r;
         }
         Fs<X> v;
+#ifdef MZK_NTT_DIAG_NOIO
+        v = Fs<X>::zero(); v.l[0] = (int32_t)g;
+#else
         if (a.in_planes) v = planes_get<X>(in, a.n, g);                                  // lazy: |limbs| <= 2^30
         else if (a.is_first && g >= a.in_len) v = Fs<X>::zero();
         else v = fs_load_packed<X>(in + g * 8);                                        // fresh: limbs in [0, 2^29)
+#endif
         ldss_store<X>(da, db, dc, (int)bitrev((unsigned)r, a.log_r) * C + c, v);
     }
     __syncthreads();
@@ -180,7 +184,11 @@ __global__ __launch_bounds__(NTTX_THREADS) void nttx_pass_kernel(NttxPassArgs a)
     // t = hi W is class C, so both outputs stay within 2^30.
     const int nbf = TILE >> 1;
     const int tw_rows = R - 1;
+#ifdef MZK_NTT_DIAG_NOSTAGES                         // (diagnostic builds only, tools/ntt_diag.sh: what a pass costs without its butterflies / without its HBM traffic)
+    for (int s = a.log_r; s < a.log_r; s++) {
+#else
     for (int s = a.skip; s < a.log_r; s++) {
+#endif
         const int half = 1 << s;
         const bool fresh = !a.in_planes && s == a.skip;
         for (int bt = tid; bt < nbf; bt += NTTX_THREADS) {
@@ -207,7 +215,11 @@ __global__ __launch_bounds__(NTTX_THREADS) void nttx_pass_kernel(NttxPassArgs a)
         if (!a.is_final) {
             const unsigned long long g = base + ((unsigned long long)r << a.log_s) + c;
             if (!a.is_first) v = fs_mulc<X>(v, tws_load(a.t_full, ((unsigned long long)r << a.log_s) + c0 + c));   // boundaries after pass 2
+#ifdef MZK_NTT_DIAG_NOIO
+            if (v.l[0] == 0x7fffffff && v.l[8] == 12345) planes_put<X>(out, a.n, g, v);
+#else
             planes_put<X>(out, a.n, g, v);                                           // pass 1: stored as it is (folded boundary)
+#endif
         } else {
             const unsigned long long rev = (i1_0 + c) + (rev_rest << log_r1);
             const unsigned long long g = rev + ((unsigned long long)r << a.log_p);
@@ -217,8 +229,229 @@ __global__ __launch_bounds__(NTTX_THREADS) void nttx_pass_kernel(NttxPassArgs a)
             } else if (a.f_one) {
                 v = fs_mulc<X>(v, tws_load(a.f_one, 0));
             }
+#ifdef MZK_NTT_DIAG_NOIO
+            const Fx<X> cv = fs_canonical<X>(v);
+            if (cv.l[0] == 0x7fffffff && cv.l[8] == 12345) fx_store_packed<X>(out + g * 8, cv);
+#else
             fx_store_packed<X>(out + g * 8, fs_canonical<X>(v));
+#endif
         }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
+// Persistent form of the same pass (round 3).  Measured on MI355X (tools/ntt_diag.sh): a 2^22 pass is 0.155 ms of butterflies when
+// it touches no HBM and 0.067 ms of HBM traffic (4.3 TB/s) when it runs no butterflies, but 0.194 ms as launched above -- one
+// workgroup per tile loads, transforms and stores in sequence, and only the OTHER workgroups of its CU fill its memory phases.
+// Here a workgroup walks over tiles t = blockIdx.x, += gridDim.x (tile index fastest, then the polynomial of the batch) and, right
+// after a tile has been staged into LDS, issues the global loads of its NEXT tile into registers (2 elements of 8 / 9 words per
+// thread): they complete under the stages of the current tile and are written to LDS once its results have left.
+// ------------------------------------------------------------------------------------------------
+struct NttxTile {
+    unsigned long long base, c0, p1, i1_0, rest, rev_rest, k1_blk;
+    const uint32_t* in;
+    uint32_t* out;
+};
+template <class X>
+__device__ __forceinline__ NttxTile nttx_tile(const NttxPassArgs& a, unsigned long long t, int log_tiles, int log_r1) {
+    NttxTile g;
+    const unsigned long long tile = t & ((1ull << log_tiles) - 1), poly = t >> log_tiles;          // (tiles per polynomial: a power of two)
+    g.in = a.in + poly * a.in_stride * (a.in_planes ? 9 : 8);
+    g.out = a.out + poly * a.out_stride * (a.out_planes ? 9 : 8);
+    g.base = g.c0 = g.i1_0 = g.rest = g.rev_rest = g.k1_blk = 0;
+    g.p1 = 1;
+    if (!a.is_final) {
+        const unsigned long long tiles_per_blk = 1ull << (a.log_s - a.log_c);
+        const unsigned long long blk = tile >> (a.log_s - a.log_c);
+        g.c0 = (tile & (tiles_per_blk - 1)) << a.log_c;
+        g.base = (blk << (a.log_r + a.log_s)) + g.c0;
+        g.k1_blk = a.is_first ? 0 : (blk >> (a.log_p - log_r1));
+    } else {
+        const int log_p1 = a.log_p - log_r1;
+        g.p1 = 1ull << log_p1;
+        g.rest = tile & (g.p1 - 1);
+        g.i1_0 = (tile >> log_p1) << a.log_c;
+        unsigned long long x = g.rest;
+        for (int k = a.n_pass - 2; k >= 1; k--) {
+            const unsigned long long d = x & ((1ull << a.log_radix[k]) - 1);
+            x >>= a.log_radix[k];
+            g.rev_rest = (g.rev_rest << a.log_radix[k]) | d;
+        }
+    }
+    return g;
+}
+// element e of a tile: where it comes from (global index, -1: a zero of the padding) and its row / column in the tile
+__device__ __forceinline__ void nttx_src(const NttxPassArgs& a, const NttxTile& g, int e, long long& gidx, int& r, int& c) {
+    const int C = 1 << a.log_c, R = 1 << a.log_r;
+    if (!a.is_final) {
+        c = e & (C - 1);
+        r = e >> a.log_c;
+        gidx = (long long)(g.base + ((unsigned long long)r << a.log_s) + c);
+    } else {
+        r = e & (R - 1);
+        c = e >> a.log_r;
+        gidx = (long long)((((g.i1_0 + c) * g.p1 + g.rest) << a.log_r) + r);
+    }
+    if (!a.in_planes && a.is_first && (unsigned long long)gidx >= a.in_len) gidx = -1;
+}
+template <class X>
+__device__ __forceinline__ void nttx_fetch(const NttxPassArgs& a, const NttxTile& g, long long gidx, uint32_t (&raw)[9]) {
+    if (gidx < 0) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) raw[i] = 0;
+        return;
+    }
+    if (a.in_planes) {
+        const int4 p = reinterpret_cast<const int4*>(g.in)[gidx], q = reinterpret_cast<const int4*>(g.in + 4 * a.n)[gidx];
+        raw[0] = p.x; raw[1] = p.y; raw[2] = p.z; raw[3] = p.w; raw[4] = q.x; raw[5] = q.y; raw[6] = q.z; raw[7] = q.w;
+        raw[8] = (uint32_t)reinterpret_cast<const int32_t*>(g.in + 8 * a.n)[gidx];
+    } else {
+        const uint4 p = reinterpret_cast<const uint4*>(g.in + gidx * 8)[0], q = reinterpret_cast<const uint4*>(g.in + gidx * 8)[1];
+        raw[0] = p.x; raw[1] = p.y; raw[2] = p.z; raw[3] = p.w; raw[4] = q.x; raw[5] = q.y; raw[6] = q.z; raw[7] = q.w;
+        raw[8] = 0;
+    }
+}
+template <class X>
+__device__ __forceinline__ Fs<X> nttx_decode(const NttxPassArgs& a, const uint32_t (&raw)[9]) {
+    Fs<X> v;
+    if (a.in_planes) {
+#pragma unroll
+        for (int i = 0; i < 9; i++) v.l[i] = (int32_t)raw[i];
+        return v;
+    }
+    return fs_unpack<X>(raw);
+}
+
+// workgroup barrier that orders LDS traffic only.  __syncthreads() is fence + barrier, and on gfx9-family hardware one counter
+// (vmcnt) tracks global loads AND stores: its fence waits for every outstanding global access -- the prefetch of the next tile
+// included, which would then overlap a single stage.  The stages exchange data through LDS alone, so lgkmcnt(0) is what they need.
+__device__ __forceinline__ void nttx_lds_barrier() {
+#if defined(__HIP_DEVICE_COMPILE__)
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+#endif
+}
+__device__ __forceinline__ FsTw tws_load_lds(const int4* tw, int idx) {
+    const int4* src = tw + idx * 5;
+    const int4 a = src[0], b = src[1], c = src[2], d = src[3], e = src[4];
+    FsTw t;
+    t.w[0] = a.x; t.w[1] = a.y; t.w[2] = a.z; t.w[3] = a.w;
+    t.w[4] = b.x; t.w[5] = b.y; t.w[6] = b.z; t.w[7] = b.w;
+    t.w[8] = c.x; t.q[0] = c.y; t.q[1] = c.z; t.q[2] = c.w;
+    t.q[3] = d.x; t.q[4] = d.y; t.q[5] = d.z; t.q[6] = d.w;
+    t.q[7] = e.x; t.q[8] = e.y;
+    return t;
+}
+
+// grid = (min(tiles * batch, what the chip holds at once)), block = NTTX_THREADS.  TW_LDS (every pass but the final one, whose
+// twiddles depend on the tile column): the R - 1 stage-twiddle records of the tile's block are staged in LDS behind the tile --
+// the stages then issue no global load at all, so the next tile's prefetch is not waited for by an in-order twiddle load.
+template <class X, bool TW_LDS>
+__global__ __launch_bounds__(NTTX_THREADS) void nttx_pass_persistent_kernel(NttxPassArgs a, int log_tiles, unsigned long long total) {
+    static_assert(X::XN == 9 && X::N == 8, "256-bit scalar fields: 8 boundary words, 9 limbs of 29 bits");
+    extern __shared__ int4 ldsx[];
+    const int R = 1 << a.log_r, C = 1 << a.log_c, TILE = R * C;
+    int4* da = ldsx;
+    int4* db = da + TILE;
+    int32_t* dc = reinterpret_cast<int32_t*>(db + TILE);
+    const int tid = threadIdx.x;
+    const int log_r1 = a.n_pass > 1 ? a.log_radix[0] : 0;
+    // elements per thread: e0 = tid, e1 = tid + NTTX_THREADS (a tile has at most 2 * NTTX_THREADS of them); with a zero-padded first
+    // pass only the rows r < R >> skip exist (the others are zeros that the first `skip` stages would merely copy)
+    const int n_src = a.skip > 0 ? (R >> a.skip) * C : TILE;
+    const int e0 = tid, e1 = tid + NTTX_THREADS;
+    unsigned long long t = blockIdx.x;
+    if (t >= total) return;
+    NttxTile g = nttx_tile<X>(a, t, log_tiles, log_r1);
+    int4* tw = reinterpret_cast<int4*>(dc + TILE);                                   // [R - 1][5] when TW_LDS
+    unsigned long long tw_k1 = ~0ull;
+    uint32_t raw0[9], raw1[9];
+    long long g0 = -1, g1 = -1;
+    int r0 = 0, c0 = 0, r1 = 0, c1 = 0;
+    if (e0 < n_src) { nttx_src(a, g, e0, g0, r0, c0); nttx_fetch<X>(a, g, g0, raw0); }
+    if (e1 < n_src) { nttx_src(a, g, e1, g1, r1, c1); nttx_fetch<X>(a, g, g1, raw1); }
+    for (;;) {
+        // ---- stage the fetched elements: bit-reversed rows (decimation in time) -------------------------------------
+        if (a.skip > 0) {
+            const int reps = 1 << a.skip;
+            if (e0 < n_src) {
+                const Fs<X> v = nttx_decode<X>(a, raw0);
+                const int pos = (int)bitrev((unsigned)r0, a.log_r) * C + c0;
+                for (int q = 0; q < reps; q++) ldss_store<X>(da, db, dc, pos + q * C, v);
+            }
+            if (e1 < n_src) {
+                const Fs<X> v = nttx_decode<X>(a, raw1);
+                const int pos = (int)bitrev((unsigned)r1, a.log_r) * C + c1;
+                for (int q = 0; q < reps; q++) ldss_store<X>(da, db, dc, pos + q * C, v);
+            }
+        } else {
+            if (e0 < n_src) ldss_store<X>(da, db, dc, (int)bitrev((unsigned)r0, a.log_r) * C + c0, nttx_decode<X>(a, raw0));
+            if (e1 < n_src) ldss_store<X>(da, db, dc, (int)bitrev((unsigned)r1, a.log_r) * C + c1, nttx_decode<X>(a, raw1));
+        }
+        if (TW_LDS && tw_k1 != g.k1_blk) {                         // pass 1: once per workgroup; later passes: when the block's k1 changes
+            const int4* src = reinterpret_cast<const int4*>(a.stage_tw + g.k1_blk * (unsigned long long)(R - 1) * FS_TW_WORDS);
+            for (int i = tid; i < (R - 1) * 5; i += NTTX_THREADS) tw[i] = src[i];
+            tw_k1 = g.k1_blk;
+        }
+        nttx_lds_barrier();                                        // the tile (and its twiddles) are in LDS; the previous tile's stores may still be draining
+        // ---- the next tile's loads go out now and land under the stages below ----------------------------------------
+        const unsigned long long tn = t + gridDim.x;
+        const bool more = tn < total;
+        NttxTile gn = g;
+        if (more) {
+            gn = nttx_tile<X>(a, tn, log_tiles, log_r1);
+            if (e0 < n_src) { nttx_src(a, gn, e0, g0, r0, c0); nttx_fetch<X>(a, gn, g0, raw0); }
+            if (e1 < n_src) { nttx_src(a, gn, e1, g1, r1, c1); nttx_fetch<X>(a, gn, g1, raw1); }
+        }
+        // ---- R-point transforms: one butterfly per thread per stage (as nttx_pass_kernel) ------------------------------
+        const int nbf = TILE >> 1;
+        const int tw_rows = R - 1;
+        for (int s = a.skip; s < a.log_r; s++) {
+            const int half = 1 << s;
+            const bool fresh = !a.in_planes && s == a.skip;
+            for (int bt = tid; bt < nbf; bt += NTTX_THREADS) {
+                const int c = bt & (C - 1);
+                const int jj = bt >> a.log_c;
+                const int j = jj & (half - 1);
+                const int lo_i = (((jj >> s) << (s + 1)) + j) * C + c, hi_i = lo_i + half * C;
+                Fs<X> lo = ldss_load<X>(da, db, dc, lo_i);
+                const Fs<X> hi = ldss_load<X>(da, db, dc, hi_i);
+                if (!fresh) lo = fs_norm(lo);
+                Fs<X> tt;
+                if (TW_LDS) tt = fs_mulc<X>(hi, tws_load_lds(tw, half - 1 + j));
+                else {
+                    const unsigned long long k1 = a.is_first ? 0ull : (a.is_final ? g.i1_0 + c : g.k1_blk);
+                    tt = fs_mulc<X>(hi, tws_load(a.stage_tw, k1 * tw_rows + (half - 1 + j)));
+                }
+                ldss_store<X>(da, db, dc, lo_i, fs_add(lo, tt));
+                ldss_store<X>(da, db, dc, hi_i, fs_sub(lo, tt));
+            }
+            nttx_lds_barrier();                                    // LDS only: the next tile's loads stay in flight
+        }
+        // ---- store --------------------------------------------------------------------------------------------------
+        for (int e = tid; e < TILE; e += NTTX_THREADS) {
+            const int c = e & (C - 1);
+            const int r = e >> a.log_c;
+            Fs<X> v = ldss_load<X>(da, db, dc, r * C + c);
+            if (!a.is_final) {
+                const unsigned long long gi = g.base + ((unsigned long long)r << a.log_s) + c;
+                if (!a.is_first) v = fs_mulc<X>(v, tws_load(a.t_full, ((unsigned long long)r << a.log_s) + g.c0 + c));   // boundaries after pass 2
+                planes_put<X>(g.out, a.n, gi, v);
+            } else {
+                const unsigned long long rev = (g.i1_0 + c) + (g.rev_rest << log_r1);
+                const unsigned long long gi = rev + ((unsigned long long)r << a.log_p);
+                if (a.f_lo) {
+                    v = fs_mulc<X>(v, tws_load(a.f_lo, gi & ((1ull << a.log_lb) - 1)));
+                    v = fs_mulc<X>(v, tws_load(a.f_hi, gi >> a.log_lb));
+                } else if (a.f_one) {
+                    v = fs_mulc<X>(v, tws_load(a.f_one, 0));
+                }
+                fx_store_packed<X>(g.out + gi * 8, fs_canonical<X>(v));
+            }
+        }
+        if (!more) break;
+        nttx_lds_barrier();                                        // every value of this tile has left LDS (its global stores may still be in flight)
+        t = tn;
+        g = gn;
     }
 }
 
