@@ -241,6 +241,14 @@ MZK_API int32_t mzk_plonk_perm_product_dev(uint64_t pk_handle, const void* d_wir
 MZK_API int32_t mzk_plonk_perm_product(uint64_t pk_handle, const uint64_t* wire_values, const uint64_t* beta_mont,
                                        const uint64_t* gamma_mont, uint64_t* out);
 
+/* The gather of `Arithmetization::compute_wire_polynomials` (relation/src/constraint_system.rs:1225-1247: `self.witness[var]` for
+ * every cell of `self.wire_variables[i]`) on the device: d_out[t] = d_witness[d_wire_variables[t]], t < count = W x n, 32-byte field
+ * elements of either curve, d_wire_variables = u32 variable indices (wire-major).  The index table is circuit structure -- resident
+ * once per circuit -- so a host-resident witness crosses PCIe as n_vars x 32 B instead of W x n x 32 B (the bench circuit: 1 / 5).
+ * An index >= n_vars yields zero.  Asynchronous; the wire iNTTs (mzk_ntt_dev) follow on the same stream. */
+MZK_API int32_t mzk_plonk_gather_witness_dev(const void* d_witness, uint64_t n_vars, const void* d_wire_variables, uint64_t count, void* d_out,
+                                             void* stream);
+
 /* ---- dense-polynomial primitives of prover rounds 4 and 5 on device-resident coefficient vectors ----
  * evaluate: `DensePolynomial::evaluate` (plonk/src/proof_system/prover.rs:216-235): `batch` polynomials of
  * `len` coefficients, `batch_stride` elements apart, all at the point x; out_mont: batch x 4 limbs on the

@@ -770,6 +770,13 @@ int32_t mzk_poly_mask_dev(int32_t curve_id, uint32_t n_polys, void* const* d_pol
     return poly_mask_dispatch(curve_id, n_polys, reinterpret_cast<uint32_t* const*>(d_polys), n, n_blinders, reinterpret_cast<const uint32_t*>(blinders_mont),
                               (hipStream_t)stream);
 }
+int32_t mzk_plonk_gather_witness_dev(const void* d_witness, uint64_t n_vars, const void* d_wire_variables, uint64_t count, void* d_out, void* stream) {
+    ENTER_CUR();
+    if (count && (!d_witness || !d_wire_variables || !d_out)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    if (n_vars >= (1ull << 32) || count >= (1ull << 40)) { set_error("witness too large"); return MZK_ERR_INVALID_ARG; }
+    return wire_gather_dispatch(reinterpret_cast<const uint32_t*>(d_witness), n_vars, reinterpret_cast<const uint32_t*>(d_wire_variables), count,
+                                reinterpret_cast<uint32_t*>(d_out), (hipStream_t)stream);
+}
 int32_t mzk_poly_div_linear_dev(int32_t curve_id, const void* d_poly, uint64_t len, const uint64_t* z_mont, void* d_out, void* stream) {
     ENTER_CUR();
     if ((!d_poly || !d_out) && len > 1) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }

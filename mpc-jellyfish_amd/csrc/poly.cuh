@@ -248,6 +248,19 @@ __global__ void poly_mask_kernel(MaskArgs a) {
     store_fp<P>(p + (a.n + j) * 8, b);
 }
 
+// ---- a1: the gather of Arithmetization::compute_wire_polynomials (relation/src/constraint_system.rs:1225-1247) -----------------------
+// out[t] = witness[wire_variables[t]] for the W * n cells of the wire table: 32-byte elements, two lanes per element (16 B each),
+// so a wave reads and writes whole 128-byte lines where the indices run (the bench circuit's mostly do).  Field-independent.
+static __global__ __launch_bounds__(256) void wire_gather_kernel(const uint4* __restrict__ witness, unsigned long long n_vars, const uint32_t* __restrict__ vars,
+                                                          unsigned long long count, uint4* __restrict__ out, unsigned int* __restrict__ bad) {
+    const unsigned long long t = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= 2 * count) return;
+    const unsigned long long cell = t >> 1;
+    const uint32_t v = vars[cell];
+    if (v >= n_vars) { if (bad) atomicOr(bad, 1u); out[t] = make_uint4(0, 0, 0, 0); return; }
+    out[t] = witness[2ull * v + (t & 1)];
+}
+
 // ---- division by the vanishing polynomial of a proof-linking domain (proof_linking.rs:119-158) -------------------------
 // Z_D(X) = prod_{i < count} (X - rho g^i).  When Z_D divides p, the quotient is p(x) / Z_D(x) pointwise on a coset that
 // avoids the roots; the kernel below multiplies the coset evaluations by 1 / Z_D(x): thread t owns the K points

@@ -217,6 +217,14 @@ int32_t poly_degree_dispatch(const uint32_t* d_poly, uint64_t len, unsigned long
     return MZK_OK;
 }
 
+int32_t wire_gather_dispatch(const uint32_t* d_witness, uint64_t n_vars, const uint32_t* d_vars, uint64_t count, uint32_t* d_out, hipStream_t st) {
+    if (count == 0) return MZK_OK;
+    hipLaunchKernelGGL(wire_gather_kernel, dim3((unsigned)((2 * count + 255) / 256)), dim3(256), 0, st, reinterpret_cast<const uint4*>(d_witness),
+                       (unsigned long long)n_vars, d_vars, (unsigned long long)count, reinterpret_cast<uint4*>(d_out), (unsigned int*)nullptr);
+    HIP_TRY(hipGetLastError());
+    return MZK_OK;
+}
+
 int32_t poly_mask_dispatch(int curve, uint32_t n_rows, uint32_t* const* d_rows, uint64_t n, uint32_t n_blind, const uint32_t* blind_mont, hipStream_t st) {
     if (n_rows == 0) return MZK_OK;
     if (n_rows > MASK_MAX_ROWS || n_blind == 0 || n_blind > MASK_MAX_BLIND || n_blind > n) { set_error("mask: at most 8 polynomials, 1..4 blinders each"); return MZK_ERR_INVALID_ARG; }

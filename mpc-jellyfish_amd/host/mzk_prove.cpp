@@ -1,6 +1,6 @@
 // mzk_prove -- PlonkKzgSnark::prove on the reference's bench circuit from a compiled host: C++ above the C ABI of
 // include/mzk.h, no Python, no HIP in this translation unit (g++ builds it).
-//   mzk_prove <curve: 0 BLS12-381 | 1 BN254> <turbo|ultra> <num_gates> [reps] [range_bit_len] [--gpus G] [--host-witness] [--check-agree]
+//   mzk_prove <curve: 0 BLS12-381 | 1 BN254> <turbo|ultra> <num_gates> [reps] [range_bit_len] [--gpus G] [--host-witness | --host-witness-vars] [--check-agree]
 // Prints one JSON line: proof bytes (hex), wall time per proof, per-round times of one profiled proof.
 // --gpus G: G devices driven from this ONE process, one host thread per device (ShardedProver, mzk_prover.hpp): commitments sharded by
 // point range, the quotient by residue class with one device-to-device exchange, rounds 4-5 by coefficient range; same proof bytes.
@@ -20,7 +20,8 @@ using namespace mzk_host;
 
 struct Options {
     int gpus = 1;                 // --gpus G: G devices from this one process, one host thread each (MZK_VIRTUAL_DEVICES=G: all on one card)
-    bool host_witness = false;    // --host-witness: every proof uploads its wire values from page-locked host memory
+    int host_witness = 0;         // --host-witness: every proof uploads its W x n wire values from page-locked host memory;
+                                  // --host-witness-vars: only the witness vector, gathered per wire on the device
     bool check_agree = false;     // --check-agree: every rank's proof bytes are compared (tests)
 };
 
@@ -31,7 +32,10 @@ int run(bool ultra, uint64_t num_gates, int reps, int range_bits, const Options&
     auto t0 = std::chrono::steady_clock::now();
     BenchCircuitHost<C> host = BenchCircuitHost<C>::generate(num_gates, ultra, range_bits);
     if (std::getenv("MZK_PROVE_CORRUPT_WITNESS"))                       // test hook: wire 0 of row 5 takes the value of row 6 -> gate 5 no longer holds
+    {
         host.wires[5] = host.wires[6];
+        host.witness[host.wire_variables[5]] = host.witness[host.wire_variables[6]];
+    }
     ChaChaRng rng = test_rng();
     const Fr beta = fr_rand<typename C::Fr>(rng);                       // the SRS trapdoor: first draw of the bench's rng (bench.rs:50-54)
     const auto beta_c = canonical(beta);
@@ -58,7 +62,7 @@ int run(bool ultra, uint64_t num_gates, int reps, int range_bits, const Options&
     for (uint8_t b : bytes) { hex.push_back(d[b >> 4]); hex.push_back(d[b & 15]); }
     std::printf("{\"curve\": %d, \"plonk_type\": \"%s\", \"num_gates\": %llu, \"log_n\": %d, \"gpus\": %d, \"host_witness\": %s, \"proof_bytes\": %zu, "
                 "\"prove_ms\": %.3f, \"circuit_build_s\": %.3f, \"preprocess_s\": %.3f, \"rounds_ms\": {",
-                C::ID, ultra ? "UltraPlonk" : "TurboPlonk", (unsigned long long)num_gates, host.log_n, opt.gpus, opt.host_witness ? "true" : "false",
+                C::ID, ultra ? "UltraPlonk" : "TurboPlonk", (unsigned long long)num_gates, host.log_n, opt.gpus, opt.host_witness == 0 ? "false" : (opt.host_witness == 1 ? "\"wire table\"" : "\"witness vector\""),
                 bytes.size(), ms, circuit_s, preprocess_s);
     bool first = true;
     for (auto& kv : prover.timings_ms) { std::printf("%s\"%s\": %.3f", first ? "" : ", ", kv.first.c_str(), kv.second); first = false; }
@@ -144,14 +148,15 @@ int main(int argc_in, char** argv_in) {
     for (int i = 0; i < argc_in; i++) {
         const std::string a = argv_in[i];
         if (a == "--gpus" && i + 1 < argc_in) opt.gpus = std::atoi(argv_in[++i]);
-        else if (a == "--host-witness") opt.host_witness = true;
+        else if (a == "--host-witness") opt.host_witness = 1;
+        else if (a == "--host-witness-vars") opt.host_witness = 2;
         else if (a == "--check-agree") opt.check_agree = true;
         else args.push_back(argv_in[i]);
     }
     const int argc = (int)args.size();
     char** argv = args.data();
     if (opt.gpus < 1 || opt.gpus > 16) { std::fprintf(stderr, "mzk_prove: --gpus 1..16\n"); return 2; }
-    if (argc < 4) { std::fprintf(stderr, "usage: %s <curve 0|1> <turbo|ultra> <num_gates> [reps] [range_bit_len] [--gpus G] [--host-witness] [--check-agree]\n", argv[0]); return 2; }
+    if (argc < 4) { std::fprintf(stderr, "usage: %s <curve 0|1> <turbo|ultra> <num_gates> [reps] [range_bit_len] [--gpus G] [--host-witness | --host-witness-vars] [--check-agree]\n", argv[0]); return 2; }
     const int curve = std::atoi(argv[1]);
     if (std::string(argv[2]) == "link") {
         if (argc < 8) { std::fprintf(stderr, "usage: %s <curve 0|1> link <num_gates_1> <num_gates_2> <alignment> <offset> <size> [reps]\n", argv[0]); return 2; }

@@ -103,6 +103,8 @@ struct BenchCircuitHost {                                              // the fi
     int log_n = 0, W = 5, nsel = 13;
     uint64_t n = 0;
     std::vector<Fr> k, wires, selectors, sigmas, tables;              // W x n, nsel x n, W x n, 4 x n (UltraPlonk)
+    std::vector<Fr> witness;                                           // the witness vector ...
+    std::vector<uint32_t> wire_variables;                              // ... and the variable on every (wire, row): wires[i] = witness[wire_variables[i]]
 
     // plonk/benches/bench.rs:29-46 through PlonkCircuit::new, Circuit::add and finalize_for_arithmetization
     static BenchCircuitHost generate(uint64_t num_gates, bool ultra, int range_bit_len = 8) {
@@ -134,6 +136,8 @@ struct BenchCircuitHost {                                              // the fi
         for (size_t v = 3; v < n_vars; v++) witness[v] = witness[v - 1] + one;
         cs.wires.resize((size_t)W * n);
         for (size_t i = 0; i < cs.wires.size(); i++) cs.wires[i] = witness[var[i]];
+        cs.witness = witness;
+        cs.wire_variables = var;
         // selectors: AdditionGate q_lc = [1,1,0,0], q_o = 1; ConstantGate q_c = value, q_o = 1; PaddingGate all zero
         std::vector<Fr>& sel = cs.selectors;
         sel.assign((size_t)cs.nsel * n, Fr::zero());
@@ -176,12 +180,15 @@ struct BenchCircuit {                                                  // ... an
     uint64_t n = 0;
     std::vector<Fr> k;
     DevBuf wire_values, selector_values, sigma_values, table_values;   // W x n, nsel x n, W x n, 4 x n (UltraPlonk)
-    // host_witness: the wire values of every proof start in page-locked HOST memory, as the reference holds its witness
-    // (constraint_system.rs:1225-1247); round 1 uploads them, column k + 1 under the iNTT of column k
-    PinnedBuf host_wires;
-    bool host_witness = false;
+    // host_witness: every proof starts from HOST memory (page-locked), as the reference holds its witness (constraint_system.rs:1225-1247).
+    //   1: the gathered wire table W x n (what a host that gathers itself hands over): round 1 uploads column k + 1 under the iNTT of column k
+    //   2: the witness VECTOR (n_vars x 32 B); the variable-index table is resident circuit structure and the gather runs on the device
+    PinnedBuf host_wires, host_vars;
+    DevBuf wire_variables;                                             // W x n u32
+    uint64_t n_vars = 0;
+    int host_witness = 0;
 
-    static BenchCircuit upload(const BenchCircuitHost<C>& h, bool host_witness = false) {
+    static BenchCircuit upload(const BenchCircuitHost<C>& h, int host_witness = 0) {
         BenchCircuit cs;
         cs.ultra = h.ultra; cs.log_n = h.log_n; cs.W = h.W; cs.nsel = h.nsel; cs.n = h.n; cs.k = h.k;
         auto up = [](DevBuf& d, const std::vector<Fr>& v, const char* what) {
@@ -192,10 +199,16 @@ struct BenchCircuit {                                                  // ... an
         up(cs.selector_values, h.selectors, "upload selectors");
         up(cs.sigma_values, h.sigmas, "upload sigma");
         if (h.ultra) up(cs.table_values, h.tables, "upload tables");
-        if (host_witness) {
-            cs.host_witness = true;
+        cs.host_witness = host_witness;
+        if (host_witness == 1) {
             cs.host_wires.alloc(h.wires.size() * EL);
             std::memcpy(cs.host_wires.p, h.wires.data(), h.wires.size() * EL);
+        } else if (host_witness == 2) {
+            cs.n_vars = h.witness.size();
+            cs.host_vars.alloc(h.witness.size() * EL);
+            std::memcpy(cs.host_vars.p, h.witness.data(), h.witness.size() * EL);
+            cs.wire_variables.alloc((h.wire_variables.size() * 4 + EL - 1) / EL);
+            check(mzk_dev_upload(cs.wire_variables.p, h.wire_variables.data(), h.wire_variables.size() * 4), "upload wire variables");
         }
         return cs;
     }
@@ -261,7 +274,7 @@ struct Prover {                                                        // Provin
     LocalComm* comm = nullptr;
     uint64_t lo = 0, hi = 0;
     DevBuf fixed;                                                      // (nsel + W [+ 4]) x n coefficient forms
-    DevBuf slab, quot, coeff, split, lin, batch, opening, shifted, hh, table, lookup, sorted, tmp, deg, rem, wv;
+    DevBuf slab, quot, coeff, split, lin, batch, opening, shifted, hh, table, lookup, sorted, tmp, deg, rem, wv, wit;
     std::vector<uint32_t> classes, own;                                // the classes that determine the quotient; this rank's share of them
     std::vector<void*> peer_rem;                                       // `rem` of every rank (device pointers), for the one exchange
     void* copy_stream = nullptr;
@@ -468,6 +481,16 @@ struct Prover {                                                        // Provin
         if (!cs.host_witness) {
             st.wire_values = cs.wire_values.p;
             check(mzk_dev_copy(coeff.p, cs.wire_values.p, (size_t)W * n * EL, nullptr), "copy");
+            check(mzk_ntt_dev(C::ID, coeff.p, n, log_n, 1, nullptr, W + 1, n, nullptr), "mzk_ntt_dev");
+        } else if (cs.host_witness == 2) {
+            // the witness vector crosses PCIe; `witness[wire_variable(i, j)]` (constraint_system.rs:1239) is gathered on the device
+            if (!wv.p) { wv.alloc((size_t)W * n); wit.alloc(cs.n_vars); check(mzk_stream_create(&copy_stream), "mzk_stream_create"); }
+            st.wire_values = wv.p;
+            check(mzk_stream_wait_stream(copy_stream, nullptr), "wait");                                     // the previous proof is done with `wit`
+            check(mzk_dev_upload_async(wit.p, cs.host_vars.p, cs.n_vars * EL, copy_stream), "upload");
+            check(mzk_stream_wait_stream(nullptr, copy_stream), "wait");
+            check(mzk_plonk_gather_witness_dev(wit.p, cs.n_vars, cs.wire_variables.p, (uint64_t)W * n, wv.p, nullptr), "mzk_plonk_gather_witness_dev");
+            check(mzk_dev_copy(coeff.p, wv.p, (size_t)W * n * EL, nullptr), "copy");
             check(mzk_ntt_dev(C::ID, coeff.p, n, log_n, 1, nullptr, W + 1, n, nullptr), "mzk_ntt_dev");
         } else {
             // host-resident witness (constraint_system.rs:1225-1247 gathers it on the host): column i + 1 crosses PCIe on a copy
@@ -956,7 +979,7 @@ struct ShardedProver {
         if (other) std::rethrow_exception(other);
     }
     // the testing SRS [beta^i] G on every device, the circuit uploaded to every device, PlonkKzgSnark::preprocess per device
-    void setup(const BenchCircuitHost<C>& host, const std::array<uint64_t, 4>& beta_canonical, bool host_witness = false) {
+    void setup(const BenchCircuitHost<C>& host, const std::array<uint64_t, 4>& beta_canonical, int host_witness = 0) {
         each([&](int r) {
             check(mzk_srs_generate_for_testing(C::ID, beta_canonical.data(), host.n + 3, &srs[r]), "mzk_srs_generate_for_testing");
             circuit[r] = std::make_unique<BenchCircuit<C>>(BenchCircuit<C>::upload(host, host_witness));

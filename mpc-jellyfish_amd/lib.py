@@ -60,6 +60,7 @@ _SIGS = {
     "mzk_plookup_product_dev": [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "mzk_plonk_perm_product_dev": [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "mzk_plonk_perm_product": [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "mzk_plonk_gather_witness_dev": [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p],
     "mzk_poly_eval_dev": [C.c_int32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p],
     "mzk_poly_lincomb_dev": [C.c_int32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p],
     "mzk_poly_mask_dev": [C.c_int32, C.c_uint32, C.POINTER(C.c_void_p), C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p],

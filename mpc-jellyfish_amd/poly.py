@@ -109,3 +109,16 @@ def mask(curve, rows, n: int, blinders, stream=None):
     bm = fr_to_mont(c, [x for b in blinders for x in b])
     ptrs = (C.c_void_p * k)(*[r.data_ptr() for r in rows])
     _lib.check(_lib.ensure_init().mzk_poly_mask_dev(c.curve_id, k, ptrs, n, h, C.c_void_p(bm.ctypes.data), _stream(rows[0], stream)), "mzk_poly_mask_dev")
+
+
+def gather_witness(witness_dev, wire_variables_dev, out=None, stream=None):
+    """out[i, j] = witness[wire_variables[i, j]]: the gather of Arithmetization::compute_wire_polynomials
+    (relation/src/constraint_system.rs:1225-1247).  witness (n_vars, 4) int64, wire_variables (W, n) int32, both CUDA."""
+    import torch
+    W, n = wire_variables_dev.shape
+    assert wire_variables_dev.dtype == torch.int32 and wire_variables_dev.is_contiguous() and witness_dev.is_contiguous()
+    if out is None:
+        out = torch.empty((W, n, 4), dtype=torch.int64, device=witness_dev.device)
+    _lib.check(_lib.ensure_init().mzk_plonk_gather_witness_dev(witness_dev.data_ptr(), witness_dev.shape[0], wire_variables_dev.data_ptr(), W * n,
+                                                               out.data_ptr(), _stream(out, stream)), "mzk_plonk_gather_witness_dev")
+    return out

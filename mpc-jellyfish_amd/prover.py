@@ -320,7 +320,21 @@ class TurboPlonkProver:
         slab = self._slab                                               # only the first n + 3 columns are read (in_len of the coset NTT)
         slab[:, n:n + 3] = 0
         coeff = self._coeff
-        if on_dev(wire_values):
+        if hasattr(wire_values, "wire_variables"):
+            # snark.HostWitness: the witness VECTOR crosses PCIe (n_vars x 32 B), the per-wire gather of compute_wire_polynomials
+            # (constraint_system.rs:1225-1247) runs on the device over the resident variable-index table
+            hw = wire_values
+            n_vars = int(hw.witness.shape[0])
+            if getattr(self, "_wit", None) is None or self._wit.shape[0] < n_vars:
+                self._wit = torch.empty((n_vars, 4), dtype=torch.int64, device=dev)
+                self._wv = torch.empty((W, n, 4), dtype=torch.int64, device=dev)
+            self._wit[:n_vars].copy_(hw.witness, non_blocking=True)
+            st.wv = self._wv
+            poly.gather_witness(self._wit[:n_vars], hw.wire_variables, out=st.wv)
+            coeff[:W] = st.wv
+            coeff[W] = pv
+            self.domain.ifft_in_place(coeff)
+        elif on_dev(wire_values):
             st.wv = wire_values
             coeff[:W] = st.wv
             coeff[W] = pv

@@ -38,6 +38,8 @@ class BenchCircuit:
     pub_input_values: object     # (n, 4) -- the bench circuit has no public input
     public_input: list
     table_values: object | None  # (4, n, 4): range, key, table_dom_sep, q_dom_sep (UltraPlonk)
+    witness: object = None       # (n_vars, 4): the witness vector `wire_values` was gathered from ...
+    wire_variables: object = None  # ... (W, n) int32: by these variable indices (constraint_system.rs:1225-1247)
 
     @property
     def num_wire_types(self):
@@ -133,7 +135,18 @@ def gen_circuit_for_bench(curve, num_gates: int, plonk_type: str = TURBO, range_
         rt = torch.zeros((1 << range_bit_len, 4), dtype=torch.int64, device=dev)
         rt[:, 0] = torch.arange(1 << range_bit_len, device=dev)
         tables[0, :1 << range_bit_len] = _to_mont_dev(c, rt)                               # compute_range_table (:1423-1438)
-    return BenchCircuit(c, plonk_type, n, k, wire_values, sel, sigma, torch.zeros((n, 4), dtype=torch.int64, device=dev), [], tables)
+    return BenchCircuit(c, plonk_type, n, k, wire_values, sel, sigma, torch.zeros((n, 4), dtype=torch.int64, device=dev), [], tables,
+                        witness=wit, wire_variables=var.to(torch.int32).contiguous())
+
+
+@dataclass
+class HostWitness:
+    """A witness that starts every proof in HOST memory, the way the reference holds it (`self.witness`, gathered per wire by
+    compute_wire_polynomials, relation/src/constraint_system.rs:1225-1247): `witness` = (n_vars, 4) int64 CPU tensor (page-locked for
+    asynchronous DMA), `wire_variables` = (W, n) int32 CUDA tensor, resident circuit structure.  Passed to `prove` in place of
+    `wire_values`: n_vars x 32 B cross PCIe and the gather runs on the device (mzk_plonk_gather_witness_dev)."""
+    witness: object
+    wire_variables: object
 
 
 def preprocess(commit_key: kzg.UnivariateProverParam, circuit: BenchCircuit, quotient_classes=None, quotient_gather=None,

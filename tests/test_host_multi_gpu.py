@@ -40,6 +40,12 @@ def test_host_resident_witness_same_bytes(gpu):
     base = _prove(0, "turbo", 4096, 1)
     assert _prove(0, "turbo", 4096, 1, ["--host-witness"], reps="2")["proof_hex"] == base["proof_hex"]
     assert _prove(0, "turbo", 4096, 4, ["--host-witness"], reps="2")["proof_hex"] == base["proof_hex"]
+    # --host-witness-vars: only the witness VECTOR crosses PCIe; `witness[wire_variable(i, j)]` is gathered on the device
+    # (mzk_plonk_gather_witness_dev over the resident variable-index table)
+    assert _prove(0, "turbo", 4096, 1, ["--host-witness-vars"], reps="2")["proof_hex"] == base["proof_hex"]
+    assert _prove(0, "turbo", 4096, 3, ["--host-witness-vars"], reps="2")["proof_hex"] == base["proof_hex"]
+    ultra = _prove(1, "ultra", 600, 1)
+    assert _prove(1, "ultra", 600, 2, ["--host-witness-vars"])["proof_hex"] == ultra["proof_hex"]
 
 
 def test_unsatisfied_witness_rejected_on_every_device(gpu):

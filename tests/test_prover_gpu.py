@@ -108,3 +108,26 @@ def test_prover_with_merlin_transcript(gpu, mj, pyref):
     assert t.get_and_append_challenge(b"zeta") == ch["zeta"]
     prover.release()
     ck.release()
+
+
+def test_prove_from_host_resident_witness(gpu, mj):
+    """A witness that starts in host memory (the reference gathers `witness[wire_variable(i, j)]` on the host,
+    relation/src/constraint_system.rs:1225-1247): (i) the gathered W x n wire table as a page-locked CPU tensor, uploaded column by
+    column under the wire iNTTs; (ii) snark.HostWitness -- the witness VECTOR alone, gathered on the device over the resident
+    variable-index table (mzk_plonk_gather_witness_dev).  Same proof bytes as the device-resident witness, both proof systems."""
+    import dataclasses
+    import torch
+    for curve_id, kind in ((0, "TurboPlonk"), (1, "UltraPlonk")):
+        c = mj.params.CURVES[curve_id]
+        cs = mj.snark.gen_circuit_for_bench(c, 300, kind)
+        assert torch.equal(cs.witness[cs.wire_variables.long().reshape(-1)].reshape(cs.wire_values.shape), cs.wire_values)
+        ck = mj.UnivariateProverParam.gen_srs_for_testing(c, 0xabcdef, cs.n + 2)
+        pk = mj.snark.preprocess(ck, cs)
+        want = mj.snark.prove(mj.rng.test_rng(), cs, pk)[1]
+        table = dataclasses.replace(cs, wire_values=cs.wire_values.cpu().pin_memory())
+        vector = dataclasses.replace(cs, wire_values=mj.snark.HostWitness(cs.witness.cpu().pin_memory(), cs.wire_variables))
+        for _ in range(2):                                             # twice: the staging buffers are reused across proofs
+            assert mj.snark.prove(mj.rng.test_rng(), table, pk)[1] == want
+            assert mj.snark.prove(mj.rng.test_rng(), vector, pk)[1] == want
+        pk.release()
+        ck.release()
