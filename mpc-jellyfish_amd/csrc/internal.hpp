@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <atomic>
 #include <condition_variable>
 #include <cstdint>
 #include <cstring>
@@ -49,7 +50,7 @@ struct Workspace {
 };
 
 // HIP-event timing of named regions (mzk_profile_*): one switch for the library, records per device context
-extern bool g_prof;
+extern std::atomic<bool> g_prof;                  // (switches shared by the device threads of one process: atomics)
 struct ProfRec { std::string name; hipEvent_t a, b; };
 struct ProfScope {
     hipEvent_t a = nullptr, b = nullptr;
@@ -58,8 +59,7 @@ struct ProfScope {
     ProfScope(const char* n, hipStream_t s);
     ~ProfScope();
 };
-extern uint32_t g_last_c, g_last_w, g_last_m;
-extern bool g_msm_precompute;
+extern std::atomic<bool> g_msm_precompute;
 
 struct Srs {
     int curve;
@@ -95,6 +95,7 @@ struct Ctx {
     std::mutex lock;
     Workspace ws;
     std::vector<ProfRec> prof_recs;
+    uint32_t last_c = 0, last_w = 0, last_m = 0;   // shape of the context's last MSM (mzk_msm_last_shape)
     std::map<uint64_t, Srs> srs;
     uint64_t next_handle = 1;
     IoSlot io[IO_SLOTS];

@@ -13,7 +13,7 @@
 #include "msm_pre.cuh"
 
 namespace mzk {
-bool g_msm_precompute = true;
+std::atomic<bool> g_msm_precompute{true};
 namespace {
 
 // ---- MSM ------------------------------------------------------------------------------------------
@@ -95,7 +95,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     const int log_m = c - 1;
     const int n_dig = msm_num_windows(is_mont ? FR::BITS : 256, c);      // digits per scalar
     const int n_win = pre.c ? 1 : n_dig;                                 // bucket sets per MSM
-    g_last_c = c; g_last_w = n_dig; g_last_m = M;
+    cur().last_c = c; cur().last_w = n_dig; cur().last_m = M;
     const size_t wm = (size_t)n_win * M;
     uint64_t n_max = 0, n_min = ~0ull;
     for (int p = 0; p < count; p++) { n_max = std::max<uint64_t>(n_max, items[p].n); n_min = std::min<uint64_t>(n_min, items[p].n); }

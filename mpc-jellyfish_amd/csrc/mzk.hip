@@ -53,7 +53,7 @@ int32_t ws_release(hipStream_t st) {
     return MZK_OK;
 }
 
-bool g_prof = false;
+std::atomic<bool> g_prof{false};
 ProfScope::ProfScope(const char* n, hipStream_t s) : st(s), name(n) {
     if (!g_prof) return;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
@@ -64,7 +64,6 @@ ProfScope::~ProfScope() {
     (void)hipEventRecord(b, st);
     cur().prof_recs.push_back({name, a, b});
 }
-uint32_t g_last_c = 0, g_last_w = 0, g_last_m = 0;
 
 // ---- contexts ------------------------------------------------------------------------------------------
 Ctx g_ctx[MAX_CTX];
@@ -976,9 +975,10 @@ int32_t mzk_srs_precompute(uint64_t srs_handle, uint32_t* out_window_bits, uint3
     return MZK_OK;
 }
 int32_t mzk_msm_last_shape(uint32_t* out_window_bits, uint32_t* out_windows, uint32_t* out_buckets) {
-    if (out_window_bits) *out_window_bits = g_last_c;
-    if (out_windows) *out_windows = g_last_w;
-    if (out_buckets) *out_buckets = g_last_m;
+    ENTER_CUR();
+    if (out_window_bits) *out_window_bits = cx_->last_c;
+    if (out_windows) *out_windows = cx_->last_w;
+    if (out_buckets) *out_buckets = cx_->last_m;
     return MZK_OK;
 }
 
