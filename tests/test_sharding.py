@@ -134,7 +134,9 @@ def test_class_range_covers_the_needed_classes_for_every_world():
     sh = import_module("mpc-jellyfish_amd.sharding")
     pl = import_module("mpc-jellyfish_amd.plonk")
     assert pl.quotient_classes_needed(5, 1 << 20) == list(range(6)) and pl.quotient_classes_needed(6, 1 << 22) == list(range(7))
-    assert pl.quotient_classes_needed(5, 8) == list(range(6)) and pl.quotient_classes_needed(5, 4) == list(range(8))      # n <= W + 2: all 8
+    # n <= W + 3: all 8 (at n = W + 3 the expected degree is (W + 1) n - 1: no spare coefficient, the degree check could not fail)
+    assert pl.quotient_classes_needed(5, 8) == list(range(8)) and pl.quotient_classes_needed(5, 4) == list(range(8))
+    assert pl.quotient_classes_needed(5, 16) == list(range(6)) and pl.quotient_classes_needed(6, 16) == list(range(7))
     for ncl in (6, 7, 8):
         for world in range(1, 9):
             owned = [sh.class_range(r, world, ncl) for r in range(world)]
