@@ -278,6 +278,7 @@ struct Prover {                                                        // Provin
     std::vector<uint32_t> classes, own;                                // the classes that determine the quotient; this rank's share of them
     std::vector<void*> peer_rem;                                       // `rem` of every rank (device pointers), for the one exchange
     void* copy_stream = nullptr;
+    bool one_ready = false;
     std::vector<Affine> selector_comms, sigma_comms;
     std::map<std::string, double> timings_ms;
     Fr w_n, gen;
@@ -591,12 +592,10 @@ struct Prover {                                                        // Provin
             const uint64_t lo = (uint64_t)i * (n + 2), hi = i < W - 1 ? lo + n + 2 : expected + 1;
             void* p = split.at((size_t)i * (n + 3));
             check(mzk_dev_copy(p, static_cast<const uint8_t*>(q) + lo * EL, (hi - lo) * EL, nullptr), "copy");
-            if (i < W - 1) check(mzk_dev_upload(static_cast<uint8_t*>(p) + (n + 2) * EL, b_quot[i].l, EL), "upload");
-            if (i > 0) {                                                                                      // t_i[0] -= b_{i-1}
-                const Fr negl = mzk::neg(last);
-                check(mzk_dev_upload(tmp.p, negl.l, EL), "upload");
-                lincomb({{Fr::one(), p, 1}, {Fr::one(), tmp.p, 1}}, p, 1);
-            }
+            // the masking scalars travel as kernel arguments of mzk_poly_lincomb_dev (times the resident constant one): no host-to-device
+            // copy, hence no stream synchronisation between the quotient kernels and the commitments
+            if (i < W - 1) lincomb({{b_quot[i], one_dev(), 1}}, static_cast<uint8_t*>(p) + (n + 2) * EL, 1);
+            if (i > 0) lincomb({{Fr::one(), p, 1}, {mzk::neg(last), one_dev(), 1}}, p, 1);                       // t_i[0] -= b_{i-1}
             if (i < W - 1) last = b_quot[i];
             split_len[i] = i < W - 1 ? n + 3 : hi - lo;
         }
@@ -612,6 +611,14 @@ struct Prover {                                                        // Provin
             throw std::runtime_error("WrongQuotientPolyDegree: quotient polynomial of degree " +
                                      (tail ? std::to_string(expected + tail - 1) : "below " + std::to_string(expected)) + ", expected " +
                                      std::to_string(expected) + " (the witness does not satisfy the circuit)");
+    }
+    const void* one_dev() {                                               // the field's one (Montgomery), resident: tmp[1]
+        if (!one_ready) {
+            const Fr one = Fr::one();
+            check(mzk_dev_upload(tmp.at(1), one.l, EL), "upload");
+            one_ready = true;
+        }
+        return tmp.at(1);
     }
     std::vector<Affine> commit_split(const std::vector<uint64_t>& split_len) {
         std::vector<const void*> p;
@@ -808,7 +815,7 @@ struct Prover {                                                        // Provin
         }
         void* outs[2] = {opening.p, shifted.p};
         for (int j = 0; j < 2 && width; j++) {
-            check(mzk_dev_upload(static_cast<uint8_t*>(bufs[j]) + width * EL, carry[j].l, EL), "upload");
+            lincomb({{carry[j], one_dev(), 1}}, static_cast<uint8_t*>(bufs[j]) + width * EL, 1);                 // the carried coefficient, without a copy
             check(mzk_poly_div_linear_dev(C::ID, bufs[j], width + 1, points[j].l, outs[j], nullptr), "mzk_poly_div_linear_dev");   // width coefficients: w on [lo, hi)
         }
         tick.mark("r5_polys");

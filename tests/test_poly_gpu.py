@@ -95,3 +95,37 @@ def test_degree_len(gpu, mj):
     z[999, 3] = 1                                                       # any non-zero limb counts
     assert int(mj.poly.degree_len_async(z).item()) == 1000
     assert int(mj.poly.degree_len_async(z[:0]).item()) == 0
+
+
+def test_gather_witness_and_stream_helpers(gpu, mj):
+    """mzk_plonk_gather_witness_dev (the gather of compute_wire_polynomials, relation/src/constraint_system.rs:1225-1247): ragged counts,
+    repeated and out-of-range variable indices (an index >= n_vars yields zero); and the stream helpers a host-resident witness is
+    uploaded with (mzk_stream_create / wait_stream / dev_upload_async / stream_sync)."""
+    import ctypes as C
+    import torch
+    c = mj.params.BLS12_381
+    L = mj.load()
+    for n_vars, count in ((1, 1), (7, 130), (1000, 4099)):
+        wit = mj.params.random_fr_mont(c, n_vars, seed=n_vars)
+        rs = np.random.default_rng(count)
+        idx = rs.integers(0, n_vars, size=count).astype(np.uint32)
+        idx[::17] = n_vars + rs.integers(0, 5, size=len(idx[::17])).astype(np.uint32)          # out of range -> zero
+        d_idx = torch.from_numpy(idx.view(np.int32)).cuda()
+        host = torch.from_numpy(wit.view(np.int64)).pin_memory()
+        d_wit = torch.empty_like(host, device="cuda")
+        st = C.c_void_p()
+        mj.lib.check(L.mzk_stream_create(C.byref(st)), "mzk_stream_create")
+        main = torch.cuda.current_stream().cuda_stream
+        mj.lib.check(L.mzk_dev_upload_async(d_wit.data_ptr(), host.data_ptr(), host.numel() * 8, st), "upload")
+        mj.lib.check(L.mzk_stream_wait_stream(main, st), "wait")
+        out = torch.empty((count, 4), dtype=torch.int64, device="cuda")
+        mj.lib.check(L.mzk_plonk_gather_witness_dev(d_wit.data_ptr(), n_vars, d_idx.data_ptr(), count, out.data_ptr(), main), "gather")
+        torch.cuda.synchronize()
+        mj.lib.check(L.mzk_stream_sync(st), "sync")
+        mj.lib.check(L.mzk_stream_destroy(st), "destroy")
+        want = np.zeros((count, 4), dtype=np.uint64)
+        ok = idx < n_vars
+        want[ok] = wit[idx[ok]]
+        assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
+    dev = C.c_int32(-7)
+    assert L.mzk_get_device(C.byref(dev)) == 0 and dev.value == 0
