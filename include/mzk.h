@@ -231,6 +231,21 @@ MZK_API int32_t mzk_plonk_quotient_combine_dev(int32_t curve_id, uint32_t log_n,
  * zero: the polynomial `coset.ifft` returns at prover.rs:672, provided its degree is below n_classes * n. */
 MZK_API int32_t mzk_plonk_quotient_combine_classes_dev(int32_t curve_id, uint32_t log_n, const uint32_t* classes, uint32_t n_classes,
                                                        const void* d_class_remainders, void* d_out, void* stream);
+/* ONE class fewer: W classes (5 of the 8 for TurboPlonk, 6 for UltraPlonk).  The W + 3 coefficients of the quotient t from X^(Wn) on
+ * are the top coefficients of its numerator (t (X^n - 1) = numerator and deg t = W (n + 1) + 2, so numerator[i] = t[i - n] above
+ * that degree; needs n > W + 2), and those are products of the TOP coefficients of the numerator's factors: the two permutation
+ * products of prover.rs:741-752 and, for TurboPlonk, the q_ecc / q_hash terms of :696-708 -- everything else lies lower.
+ * mzk_plonk_quotient_top_dev computes them on the device (one small kernel; d_polys as for mzk_plonk_quotient_chunked_dev: rows of
+ * in_stride elements, the W wire polynomials, then the permutation product, in_len >= n + 3 coefficient slots; key registered by
+ * mzk_plonk_pk_register_chunked) into d_top[0 .. W + 3), *out_n_top = W + 3 (nullable).  mzk_plonk_quotient_combine_top_dev subtracts
+ * their share h_k^(n n_classes) d_top[j] from the class remainders, solves the n_classes x n_classes system and places d_top in slab
+ * n_classes of d_out.  NOTE: the polynomial so recovered has degree W (n + 1) + 2 whatever the witness -- the reference's guard
+ * (`WrongQuotientPolyDegree`, prover.rs:915-918) can no longer fire; a host using this path must check the quotient identity itself
+ * (both hosts here do, at the evaluation challenge: r(zeta) against the verifier's linearisation constant).  Asynchronous. */
+MZK_API int32_t mzk_plonk_quotient_top_dev(uint64_t pk_handle, const void* d_polys, uint64_t in_stride, uint64_t in_len, const uint64_t* alpha_mont,
+                                           const uint64_t* beta_mont, const uint64_t* gamma_mont, void* d_top, uint32_t* out_n_top, void* stream);
+MZK_API int32_t mzk_plonk_quotient_combine_top_dev(int32_t curve_id, uint32_t log_n, const uint32_t* classes, uint32_t n_classes,
+                                                   const void* d_class_remainders, const void* d_top, uint32_t n_top, void* d_out, void* stream);
 
 /* Round 2: replaces Arithmetization::compute_prod_permutation_polynomial
  * (relation/src/constraint_system.rs:1197-1223), whose loop performs one field division per gate.
@@ -268,6 +283,11 @@ MZK_API int32_t mzk_poly_mask_dev(int32_t curve_id, uint32_t n_polys, void* cons
 /* quotient of p(X) / (X - z), len - 1 coefficients into d_out (remainder dropped, as ark-poly's `/` does at
  * prover.rs:504-506).  d_out must not alias d_poly.  Asynchronous. */
 MZK_API int32_t mzk_poly_div_linear_dev(int32_t curve_id, const void* d_poly, uint64_t len, const uint64_t* z_mont, void* d_out, void* stream);
+/* The same division, and the remainder p(z) -- which its suffix sums hold anyway -- into *d_rem (one element, device).  The opening
+ * proof's batch polynomial divided at zeta leaves (linearisation polynomial)(zeta) + sum_i v^i eval_i there: what a prover needs to
+ * check the quotient identity at zeta itself (mzk_plonk_quotient_top_dev). */
+MZK_API int32_t mzk_poly_div_linear_rem_dev(int32_t curve_id, const void* d_poly, uint64_t len, const uint64_t* z_mont, void* d_out, void* d_rem,
+                                            void* stream);
 /* *d_out_len (a u64 in DEVICE memory) = number of coefficients up to and including the highest non-zero one, 0 for the zero
  * polynomial: `DensePolynomial::degree` + 1 after `from_coefficients_vec` has stripped the trailing zeros.  The prover's only
  * guard against an unsatisfied witness is `quot_poly.degree() != expected_degree => WrongQuotientPolyDegree`

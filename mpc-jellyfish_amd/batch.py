@@ -15,6 +15,8 @@ fixes both the transcript and the order of the `prng` draws.  What the instances
 from __future__ import annotations
 
 import struct
+
+import numpy as np
 from dataclasses import dataclass, field
 
 from . import kzg, poly
@@ -151,9 +153,16 @@ def batch_prove(provers: list[TurboPlonkProver], wire_values: list, pub_input_va
         o, s = p._open_lists(st)
         open_polys += o
         shifted_polys += s
-    opening = p0._batched_witness(open_polys, v, zeta)
+    import torch
+    rem = torch.zeros((1, 4), dtype=torch.int64, device=lin.device)
+    opening = p0._batched_witness(open_polys, v, zeta, rem_out=rem)
     shifted = p0._batched_witness(shifted_polys, v, zeta * p0.w_n % r)
     open_comms = p0._commit([opening, shifted])
+    # the quotient identity at zeta over all instances (prover.check_quotient_identity): the guard against an unsatisfied witness
+    from .params import fr_from_mont
+    lin_constant = sum(p._lin_poly_constant(st, b) for p, st, b in zip(provers, states, bases)) % r
+    opened = [e for p, st in zip(provers, states) for e in p._opened_evals(st)]
+    p0.check_quotient_identity(fr_from_mont(c, rem.cpu().numpy().view(np.uint64))[0], lin_constant, opened, v)
     plookup_vec = [None if st.pe is None else (h, pl, st.pe) for st, h, pl in zip(states, h_vec, pl_vec)]
     return BatchProofCore(wires_vec, z_vec, evals_vec, plookup_vec, split_comms, open_comms[0], open_comms[1],
                           {"tau": tau, "beta": beta, "gamma": gamma, "alpha": alpha, "zeta": zeta, "v": v})

@@ -130,7 +130,7 @@ void jac_sum_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uint64_t*
 // poly.hip
 int32_t poly_eval_dispatch(int curve, const uint32_t* d_coeffs, uint64_t stride, uint64_t len, uint32_t batch, const uint32_t* x_mont, uint32_t* out_host,
                            hipStream_t st);
-int32_t poly_div_dispatch(int curve, const uint32_t* d_poly, uint64_t len, const uint32_t* z_mont, uint32_t* d_out, hipStream_t st);
+int32_t poly_div_dispatch(int curve, const uint32_t* d_poly, uint64_t len, const uint32_t* z_mont, uint32_t* d_out, uint32_t* d_rem /* nullable: p(z) */, hipStream_t st);
 int32_t poly_div_roots_dispatch(int curve, const uint32_t* d_poly, uint64_t len, uint32_t log_order, uint64_t first, uint64_t count, uint32_t* d_out,
                                 hipStream_t st);
 int32_t poly_lincomb_dispatch(int curve, uint32_t n_terms, const uint32_t* const* d_polys, const uint64_t* lens, const uint32_t* scalars, uint32_t* d_out,
@@ -144,8 +144,10 @@ int32_t plonk_pk_register(int curve, int log_n, int W, const uint32_t* sel, cons
                           uint64_t* out_handle);
 int32_t plonk_quotient_chunked_dev(uint64_t handle, const uint32_t* d_polys, uint64_t in_stride, uint64_t in_len, const uint32_t* tau, const uint32_t* alpha,
                                    const uint32_t* beta, const uint32_t* gamma, uint32_t* d_out, hipStream_t st);
-int32_t plonk_quotient_combine_dev(int curve, int log_n, const uint32_t* classes /* NULL: all 8 */, uint32_t n_classes, const uint32_t* d_r, uint32_t* d_out,
-                                   hipStream_t st);
+int32_t plonk_quotient_top_dev(uint64_t handle, const uint32_t* d_polys, uint64_t in_stride, uint64_t in_len, const uint32_t* alpha, const uint32_t* beta,
+                               const uint32_t* gamma, uint32_t* d_top, uint32_t* out_n_top, hipStream_t st);
+int32_t plonk_quotient_combine_dev(int curve, int log_n, const uint32_t* classes /* NULL: all 8 */, uint32_t n_classes, const uint32_t* d_r,
+                                   const uint32_t* d_top /* nullable */, uint32_t n_top, uint32_t* d_out, hipStream_t st);
 int32_t plonk_pk_release(uint64_t handle);
 void plonk_release_all();
 int32_t plonk_quotient_dev(uint64_t handle, uint32_t* d_polys, uint64_t in_len, const uint32_t* tau /* NULL: TurboPlonk */, const uint32_t* alpha,

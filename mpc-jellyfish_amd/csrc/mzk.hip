@@ -646,8 +646,22 @@ int32_t mzk_plonk_quotient_combine_classes_dev(int32_t curve_id, uint32_t log_n,
                                                void* d_out, void* stream) {
     ENTER_CUR();
     if (!d_class_remainders || !d_out || log_n > 27) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
-    return plonk_quotient_combine_dev(curve_id, (int)log_n, classes, n_classes, reinterpret_cast<const uint32_t*>(d_class_remainders),
+    return plonk_quotient_combine_dev(curve_id, (int)log_n, classes, n_classes, reinterpret_cast<const uint32_t*>(d_class_remainders), nullptr, 0,
                                       reinterpret_cast<uint32_t*>(d_out), (hipStream_t)stream);
+}
+int32_t mzk_plonk_quotient_top_dev(uint64_t pk_handle, const void* d_polys, uint64_t in_stride, uint64_t in_len, const uint64_t* alpha_mont,
+                                   const uint64_t* beta_mont, const uint64_t* gamma_mont, void* d_top, uint32_t* out_n_top, void* stream) {
+    ENTER_HANDLE(pk_handle);
+    return plonk_quotient_top_dev(pk_handle, reinterpret_cast<const uint32_t*>(d_polys), in_stride, in_len, reinterpret_cast<const uint32_t*>(alpha_mont),
+                                  reinterpret_cast<const uint32_t*>(beta_mont), reinterpret_cast<const uint32_t*>(gamma_mont),
+                                  reinterpret_cast<uint32_t*>(d_top), out_n_top, (hipStream_t)stream);
+}
+int32_t mzk_plonk_quotient_combine_top_dev(int32_t curve_id, uint32_t log_n, const uint32_t* classes, uint32_t n_classes, const void* d_class_remainders,
+                                           const void* d_top, uint32_t n_top, void* d_out, void* stream) {
+    ENTER_CUR();
+    if (!d_class_remainders || !d_out || !d_top || !classes || log_n > 27) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
+    return plonk_quotient_combine_dev(curve_id, (int)log_n, classes, n_classes, reinterpret_cast<const uint32_t*>(d_class_remainders),
+                                      reinterpret_cast<const uint32_t*>(d_top), n_top, reinterpret_cast<uint32_t*>(d_out), (hipStream_t)stream);
 }
 int32_t mzk_plonk_pk_release(uint64_t pk_handle) {
     ENTER_HANDLE(pk_handle);
@@ -709,7 +723,7 @@ int32_t mzk_plonk_quotient(uint64_t pk_handle, const uint64_t* polys, uint64_t i
         MZK_TRY(plonk_quotient_chunked_dev(pk_handle, g_ws.io.as<uint32_t>(), in_len, in_len, nullptr, reinterpret_cast<const uint32_t*>(alpha_mont),
                                            reinterpret_cast<const uint32_t*>(beta_mont), reinterpret_cast<const uint32_t*>(gamma_mont),
                                            g_ws.link_tmp.as<uint32_t>(), st));
-        MZK_TRY(plonk_quotient_combine_dev(plonk_pk_curve(pk_handle), log_n, classes, (uint32_t)ncl, g_ws.link_tmp.as<uint32_t>(),
+        MZK_TRY(plonk_quotient_combine_dev(plonk_pk_curve(pk_handle), log_n, classes, (uint32_t)ncl, g_ws.link_tmp.as<uint32_t>(), nullptr, 0,
                                            g_ws.plonk_out.as<uint32_t>(), st));
     } else {
         MZK_TRY(g_ws.plonk_polys.reserve((size_t)(W + 2) * m * 32));
@@ -781,7 +795,14 @@ int32_t mzk_poly_div_linear_dev(int32_t curve_id, const void* d_poly, uint64_t l
     if ((!d_poly || !d_out) && len > 1) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     if (!z_mont) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
     return poly_div_dispatch(curve_id, reinterpret_cast<const uint32_t*>(d_poly), len, reinterpret_cast<const uint32_t*>(z_mont),
-                             reinterpret_cast<uint32_t*>(d_out), (hipStream_t)stream);
+                             reinterpret_cast<uint32_t*>(d_out), nullptr, (hipStream_t)stream);
+}
+int32_t mzk_poly_div_linear_rem_dev(int32_t curve_id, const void* d_poly, uint64_t len, const uint64_t* z_mont, void* d_out, void* d_rem, void* stream) {
+    ENTER_CUR();
+    if ((!d_poly || !d_out) && len > 1) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    if (!z_mont || !d_rem || (!d_poly && len)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    return poly_div_dispatch(curve_id, reinterpret_cast<const uint32_t*>(d_poly), len, reinterpret_cast<const uint32_t*>(z_mont),
+                             reinterpret_cast<uint32_t*>(d_out), reinterpret_cast<uint32_t*>(d_rem), (hipStream_t)stream);
 }
 int32_t mzk_poly_degree_dev(const void* d_poly, uint64_t len, uint64_t* d_out_len, void* stream) {
     ENTER_CUR();

@@ -225,12 +225,19 @@ __global__ __launch_bounds__(PLK_THREADS) void plonk_fold_kernel(const uint32_t*
 //   r_k[j] = sum_q c_k^q T_q[j]   =>   T_q[j] = sum_k (V^-1)[q][k] r_k[j],  V[k][q] = c_k^q  (an s x s Vandermonde system per j).
 // deg t = W (n + 1) + 2 (prover.rs:916-919, 1126-1128) is below (W + 1) n, so s = W + 1 classes determine it: 6 of 8 for TurboPlonk,
 // 7 of 8 for UltraPlonk; with all 8 classes V^-1 is the 8-point inverse DFT scaled by g^(-nq) / 8.
+//
+// One class fewer (round 3): t = sum_{q<s} X^(qn) T_q + X^(sn) T_top with s = W classes, where T_top -- the W + 3 coefficients of t at
+// and above X^(Wn) -- is known without any evaluation (plonk_quotient_top_kernel below).  Then r_k[j] - c_k^s T_top[j] (j < W + 3)
+// are the remainders of the degree-< sn part and the same s x s system recovers it.
 struct CombineArgs {
     const uint32_t* r;         // [ncl][n] class-major
     uint32_t* out;             // [ncl * n]  (the caller zeroes the slabs above)
     unsigned long long n;
     int ncl;
     uint32_t mat[8][8][8];     // mat[q][k] = (V^-1)[q][k], Montgomery
+    const uint32_t* top;       // null, or the n_top coefficients of t from X^(ncl n) on (boundary form)
+    int n_top;
+    uint32_t ctop[8][8];       // c_k^ncl
 };
 template <class P>
 __global__ __launch_bounds__(PLK_THREADS) void plonk_combine_kernel(CombineArgs a) {
@@ -240,6 +247,13 @@ __global__ __launch_bounds__(PLK_THREADS) void plonk_combine_kernel(CombineArgs 
     F r[8];
 #pragma unroll
     for (int k = 0; k < 8; k++) r[k] = k < a.ncl ? load_fp<P>(a.r + ((size_t)k * a.n + j) * 8) : F::zero();
+    if (a.top && j < (unsigned long long)a.n_top) {
+        const F tj = load_fp<P>(a.top + j * 8);
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+            if (k < a.ncl) r[k] = r[k] - arg_fp<P>(a.ctop[k]) * tj;
+        store_fp<P>(a.out + ((size_t)a.ncl * a.n + j) * 8, tj);
+    }
 #pragma unroll 1
     for (int q = 0; q < a.ncl; q++) {
         F acc = arg_fp<P>(a.mat[q][0]) * r[0];
@@ -409,6 +423,125 @@ __global__ __launch_bounds__(PLK_THREADS) void fr_scan_mul_apply_kernel(const ui
     if (j >= n) return;
     if (j == 0) store_fp<P>(out, F::one());
     if (j + 1 < n) store_fp<P>(out + (j + 1) * 8, load_fp<P>(totals + (j / SCAN_BLOCK) * 8) * load_fp<P>(incl + j * 8));
+}
+
+// ---- the top W + 3 coefficients of the quotient without evaluating anything -------------------------------------------
+// t Z_H = num, Z_H = X^n - 1, deg t = W (n + 1) + 2 =: D_t, deg num <= D_t + n =: D.  For an index i > D_t:  num[i] = t[i - n] - t[i] =
+// t[i - n], so the K = W + 3 coefficients of t from X^(Wn) on are num[(W + 1) n + i'], i' < K (needs n > W + 2) -- the top K
+// coefficients of the numerator, and the top coefficients of a product of polynomials are the product, truncated to K terms, of the
+// factors' top coefficients ("reversed" power series: s_f[rho] = f[deg_bound(f) - rho]).  Which terms of the closure
+// (prover.rs:605-659, 677-759) reach that window:
+//   alpha z(X) prod_j (w_j + beta k_j X + gamma)  and  - alpha z(wX) prod_j (w_j + beta sigma_j + gamma):   bound (n + 2) + W (n + 1) = D
+//   q_ecc w_0 w_1 w_2 w_3 w_4  and  q_hash_j w_j^5:   bound (n - 1) + 5 (n + 1) = 6n + 4 = D - 3 for TurboPlonk (W = 5); below the
+//       window for UltraPlonk (D - (n + 4))
+//   everything else (q_lc w, q_mul w w, q_o w, pi, alpha^2 (z - 1) L_1, the Plookup terms: <= 5n + 3) lies below (W + 1) n.
+// z has n + 3, the wires n + 2 coefficients (mask_polynomial, prover.rs:463-486), sigma_j and the selectors n.
+struct TopArgs {
+    const uint32_t* polys;     // rows: W wires, then z (coefficients, boundary form)
+    unsigned long long stride, in_len, n;
+    const uint32_t* top_fixed; // [W + 5][8] coefficients n-8 .. n-1 of sigma_0..W-1, q_hash_0..3, q_ecc
+    int W, K, gate_shift;      // gate_shift: D - (6n + 4) if that is < K, else K (no gate term)
+    uint32_t alpha[8], beta[8], gamma[8];
+    uint32_t bk[PLK_MAX_WIRES][8];     // beta k_j
+    uint32_t wpow[12][8];      // w_n^(2 - rho), rho < K
+    uint32_t* out;             // K elements: out[i'] = t[W n + i']
+};
+constexpr int PLK_TOP_MAX = 9;         // K = W + 3 <= 9
+constexpr int PLK_TOP_THREADS = 512;   // 8 waves: two permutation products, the q_ecc product, four q_hash products (one idle)
+template <class P>
+__global__ __launch_bounds__(PLK_TOP_THREADS) void plonk_quotient_top_kernel(TopArgs a) {
+    using F = Fp<P>;
+    constexpr int KP = PLK_TOP_MAX;
+    // series: 0 P1, 1 P2, 2 E, 3..6 H_j, 7..12 F1_j, 13..18 F2_j, 19..23 W_j, 24 Q_ecc, 25..28 Q_hash_j, 29..32 hash powers
+    __shared__ uint32_t ser[33][KP][8];
+    __shared__ uint32_t part[8][KP][KP][8];
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+    const int K = a.K, W = a.W;
+    const unsigned long long n = a.n;
+    const F beta = arg_fp<P>(a.beta), gamma = arg_fp<P>(a.gamma);
+    auto coef = [&](int row, long long idx) {
+        return (idx >= 0 && (unsigned long long)idx < a.in_len) ? load_fp<P>(a.polys + ((size_t)row * a.stride + (size_t)idx) * 8) : F::zero();
+    };
+    auto fixed = [&](int row, long long idx) {                  // coefficient idx of a fixed polynomial (zero outside n-8 .. n-1)
+        const long long t = idx - ((long long)n - 8);
+        return (t >= 0 && t < 8) ? load_fp<P>(a.top_fixed + ((size_t)row * 8 + (size_t)t) * 8) : F::zero();
+    };
+    auto put = [&](int s, int rho, const F& v) {
+        for (int q = 0; q < 8; q++) ser[s][rho][q] = v.l[q];
+    };
+    auto get = [&](int s, int rho) {
+        F v;
+        for (int q = 0; q < 8; q++) v.l[q] = ser[s][rho][q];
+        return v;
+    };
+    for (int e = tid; e < 33 * KP; e += PLK_TOP_THREADS) {
+        const int s = e / KP, rho = e % KP;
+        F v = F::zero();
+        if (rho < K) {
+            const long long iw = (long long)n + 1 - rho;        // index in a wire polynomial (bound n + 1)
+            const long long iq = (long long)n - 1 - rho;        // index in a fixed polynomial (bound n - 1)
+            if (s == 0) v = coef(W, (long long)n + 2 - rho);
+            else if (s == 1) v = coef(W, (long long)n + 2 - rho) * arg_fp<P>(a.wpow[rho]);
+            else if (s >= 7 && s < 7 + W) {
+                const int j = s - 7;
+                v = coef(j, iw);
+                if (iw == 1) v = v + arg_fp<P>(a.bk[j]);
+                if (iw == 0) v = v + gamma;
+            } else if (s >= 13 && s < 13 + W) {
+                const int j = s - 13;
+                v = coef(j, iw) + beta * fixed(j, iw);
+                if (iw == 0) v = v + gamma;
+            } else if (s >= 19 && s < 24) v = coef(s - 19, iw);
+            else if (s == 24) v = fixed(W + 4, iq);
+            else if (s >= 25 && s < 29) v = fixed(W + (s - 25), iq);
+        }
+        put(s, rho, v);
+    }
+    __syncthreads();
+    const bool gate = a.gate_shift < K;
+    const int n_steps = W > 5 ? W : 5;
+    for (int step = 0; step < n_steps; step++) {
+        int dst = -1, sa = 0, sb = 0;
+        if (wave == 0 && step < W) { dst = 0; sa = 0; sb = 7 + step; }
+        else if (wave == 1 && step < W) { dst = 1; sa = 1; sb = 13 + step; }
+        else if (gate && wave == 2 && step < 5) { dst = 2; sa = step == 0 ? 24 : 2; sb = 19 + step; }
+        else if (gate && wave >= 3 && wave < 7 && step < 4) {
+            const int j = wave - 3;
+            if (step == 0) { dst = 29 + j; sa = 19 + j; sb = 19 + j; }           // w^2
+            else if (step == 1) { dst = 29 + j; sa = 29 + j; sb = 29 + j; }       // w^4
+            else if (step == 2) { dst = 29 + j; sa = 29 + j; sb = 19 + j; }       // w^5
+            else { dst = 3 + j; sa = 29 + j; sb = 25 + j; }                       // q_hash_j w^5
+        }
+        if (dst >= 0)
+            for (int p = lane; p < K * K; p += 64) {
+                const int rho = p / K, i = p % K;
+                if (i <= rho) {
+                    const F v = get(sa, i) * get(sb, rho - i);
+                    for (int q = 0; q < 8; q++) part[wave][rho][i][q] = v.l[q];
+                }
+            }
+        __syncthreads();
+        F acc = F::zero();
+        if (dst >= 0 && lane < K)
+            for (int i = 0; i <= lane; i++) {
+                F v;
+                for (int q = 0; q < 8; q++) v.l[q] = part[wave][lane][i][q];
+                acc = acc + v;
+            }
+        __syncthreads();
+        if (dst >= 0 && lane < K) put(dst, lane, acc);
+        __syncthreads();
+    }
+    if (tid < K) {
+        const int rho = tid;
+        F v = arg_fp<P>(a.alpha) * (get(0, rho) - get(1, rho));
+        if (gate && rho >= a.gate_shift) {
+            const int g = rho - a.gate_shift;
+            v = v + get(2, g);
+            for (int j = 0; j < 4; j++) v = v + get(3 + j, g);
+        }
+        store_fp<P>(a.out + (size_t)(K - 1 - rho) * 8, v);       // rho = D - ((W + 1) n + i')  =>  i' = W + 2 - rho = K - 1 - rho
+    }
 }
 
 }  // namespace mzk

@@ -22,6 +22,7 @@ struct PlonkPk {
     uint32_t* d_sigma_n = nullptr;      // [W][n] sigma_i on the gate domain H (extended permutation values)
     uint32_t* d_omega_n = nullptr;      // [n] w_n^j
     uint32_t* d_tab_n = nullptr;        // [5][n] range, key, table_dom_sep, q_dom_sep, q_lookup on H (UltraPlonk)
+    uint32_t* d_top_fixed = nullptr;    // [W + 5][8] coefficients n-8 .. n-1 of sigma_0..W-1, q_hash_0..3, q_ecc (chunked keys: plonk_quotient_top_kernel)
     uint32_t k[PLK_MAX_WIRES][8];
     uint32_t zh_inv[PLK_RATIO][8];
     uint32_t gen[8];
@@ -31,7 +32,7 @@ struct PlonkPk {
     std::vector<int> cls;
     uint32_t h_cls[PLK_RATIO][8];       // h_k = g * w_8n^k
     uint32_t c_cls[PLK_RATIO][8];       // h_k^n
-    std::array<uint32_t*, 7> bufs() const { return {d_fixed, d_xs, d_inv_den, d_inv_den_n, d_sigma_n, d_omega_n, d_tab_n}; }
+    std::array<uint32_t*, 8> bufs() const { return {d_fixed, d_xs, d_inv_den, d_inv_den_n, d_sigma_n, d_omega_n, d_tab_n, d_top_fixed}; }
 };
 std::map<uint64_t, std::unique_ptr<PlonkPk>> g_pks_of[MAX_CTX];              // proving keys per device context; the handle names its context
 #define g_pks (g_pks_of[cur().logical])
@@ -442,7 +443,54 @@ int32_t pk_build_chunked(PlonkPk& pk, const uint32_t* sel_coeffs, const uint32_t
         HIP_TRY(hipMemcpyAsync(pk.d_tab_n + (size_t)4 * n * 8, sel_coeffs + (size_t)13 * poly_len * 8, sl * 32, hipMemcpyHostToDevice, st));
         MZK_TRY(ntt_dispatch(pk.curve, pk.d_tab_n, sl, pk.log_n, false, nullptr, 5, n, st));
     }
+    {   // top coefficients of the fixed polynomials that reach the top of the quotient's numerator (plonk_quotient_top_kernel)
+        std::vector<uint32_t> top((size_t)(pk.W + 5) * 8 * 8, 0u);
+        auto fill = [&](int row, const uint32_t* coeffs) {
+            for (int t = 0; t < 8; t++) {
+                const long long idx = (long long)n - 8 + t;
+                if (idx >= 0 && (uint64_t)idx < sl) std::memcpy(&top[((size_t)row * 8 + t) * 8], coeffs + (size_t)idx * 8, 32);
+            }
+        };
+        for (int j = 0; j < pk.W; j++) fill(j, sig_coeffs + (size_t)j * poly_len * 8);
+        for (int j = 0; j < 4; j++) fill(pk.W + j, sel_coeffs + (size_t)(6 + j) * poly_len * 8);
+        fill(pk.W + 4, sel_coeffs + (size_t)12 * poly_len * 8);
+        HIP_TRY(hipMalloc((void**)&pk.d_top_fixed, top.size() * 4));
+        HIP_TRY(hipMemcpyAsync(pk.d_top_fixed, top.data(), top.size() * 4, hipMemcpyHostToDevice, st));
+        HIP_TRY(hipStreamSynchronize(st));                                // `top` leaves scope
+    }
     HIP_TRY(hipStreamSynchronize(st));
+    return MZK_OK;
+}
+
+// the W + 3 coefficients of the quotient from X^(Wn) on (plonk.cuh, plonk_quotient_top_kernel)
+template <class P>
+int32_t quotient_top_run(const PlonkPk& pk, const uint32_t* d_polys, uint64_t in_stride, uint64_t in_len, const uint32_t* alpha, const uint32_t* beta,
+                         const uint32_t* gamma, uint32_t* d_top, hipStream_t st) {
+    using F = Fp<P>;
+    const uint64_t n = 1ull << pk.log_n;
+    TopArgs a;
+    std::memset(&a, 0, sizeof a);
+    a.polys = d_polys; a.stride = in_stride; a.in_len = in_len; a.n = n; a.top_fixed = pk.d_top_fixed; a.W = pk.W; a.K = pk.W + 3;
+    const long long shift = ((long long)(pk.W + 1) * (long long)n + pk.W + 2) - (6ll * (long long)n + 4);      // D - (6n + 4)
+    a.gate_shift = shift < a.K ? (int)shift : a.K;
+    std::memcpy(a.alpha, alpha, 32); std::memcpy(a.beta, beta, 32); std::memcpy(a.gamma, gamma, 32);
+    F b;
+    std::memcpy(b.l, beta, 32);
+    for (int j = 0; j < pk.W; j++) {
+        F kj;
+        std::memcpy(kj.l, pk.k[j], 32);
+        const F v = b * kj;
+        std::memcpy(a.bk[j], v.l, 32);
+    }
+    F wn = F::from_const(P::ROOT);
+    for (int i = pk.log_n; i < P::TWO_ADICITY; i++) wn = sqr(wn);
+    F wi;
+    std::memcpy(wi.l, pk.w_inv, 32);
+    F cur = wn * wn;                                                       // w^2, then times w^-1 per step
+    for (int rho = 0; rho < a.K; rho++) { std::memcpy(a.wpow[rho], cur.l, 32); cur = cur * wi; }
+    a.out = d_top;
+    hipLaunchKernelGGL((plonk_quotient_top_kernel<P>), dim3(1), dim3(PLK_TOP_THREADS), 0, st, a);
+    HIP_TRY(hipGetLastError());
     return MZK_OK;
 }
 
@@ -504,7 +552,7 @@ int32_t quotient_chunked_run(const PlonkPk& pk, const uint32_t* d_polys, uint64_
 // the class remainders (class-major in the order of `classes`, all resident here after the exchange) -> the 8n quotient
 // coefficients (slabs above the number of classes are zero: the classes given must determine t, i.e. deg t < ncl * n)
 template <class P>
-int32_t quotient_combine_run(int log_n, const uint32_t* classes, int ncl, const uint32_t* d_r, uint32_t* d_out, hipStream_t st) {
+int32_t quotient_combine_run(int log_n, const uint32_t* classes, int ncl, const uint32_t* d_r, const uint32_t* d_top, int n_top, uint32_t* d_out, hipStream_t st) {
     using F = Fp<P>;
     const uint64_t n = 1ull << log_n;
     F w8 = F::from_const(P::ROOT);
@@ -515,6 +563,11 @@ int32_t quotient_combine_run(int log_n, const uint32_t* classes, int ncl, const 
     CombineArgs a;
     std::memset(&a, 0, sizeof a);
     a.r = d_r; a.out = d_out; a.n = n; a.ncl = ncl;
+    a.top = d_top; a.n_top = d_top ? n_top : 0;
+    for (int k = 0; k < ncl; k++) {
+        const F e = pow_u64(c[k], (uint64_t)ncl);
+        std::memcpy(a.ctop[k], e.l, 32);
+    }
     // inverse Vandermonde by Lagrange: column k of V^-1 holds the coefficients of L_k(X) = prod_{m != k} (X - c_m) / (c_k - c_m)
     for (int k = 0; k < ncl; k++) {
         F poly[9];
@@ -645,15 +698,35 @@ int32_t plonk_quotient_chunked_dev(uint64_t handle, const uint32_t* d_polys, uin
     return pk->curve == 0 ? quotient_chunked_run<BlsFr>(*pk, d_polys, in_stride, in_len, tau, alpha, beta, gamma, d_out, st)
                           : quotient_chunked_run<BnFr>(*pk, d_polys, in_stride, in_len, tau, alpha, beta, gamma, d_out, st);
 }
-int32_t plonk_quotient_combine_dev(int curve, int log_n, const uint32_t* classes, uint32_t n_classes, const uint32_t* d_r, uint32_t* d_out, hipStream_t st) {
+int32_t plonk_quotient_top_dev(uint64_t handle, const uint32_t* d_polys, uint64_t in_stride, uint64_t in_len, const uint32_t* alpha, const uint32_t* beta,
+                               const uint32_t* gamma, uint32_t* d_top, uint32_t* out_n_top, hipStream_t st) {
+    const PlonkPk* pk = find_pk(handle);
+    if (!pk) return MZK_ERR_BAD_HANDLE;
+    const uint64_t n = 1ull << pk->log_n;
+    if (!pk->d_top_fixed) { set_error("not a chunked proving key"); return MZK_ERR_INVALID_ARG; }
+    if (!d_polys || !d_top || !alpha || !beta || !gamma || in_len > in_stride || in_len < n + 3) {
+        set_error("bad argument (rows of n + 3 coefficient slots: W wire polynomials, then the permutation product)");
+        return MZK_ERR_INVALID_ARG;
+    }
+    if (n <= (uint64_t)pk->W + 2 || n < 8) { set_error("domain too small: the top W + 3 coefficients of the quotient are those of its numerator only for n > W + 2"); return MZK_ERR_UNSUPPORTED; }
+    if (out_n_top) *out_n_top = (uint32_t)pk->W + 3;
+    return pk->curve == 0 ? quotient_top_run<BlsFr>(*pk, d_polys, in_stride, in_len, alpha, beta, gamma, d_top, st)
+                          : quotient_top_run<BnFr>(*pk, d_polys, in_stride, in_len, alpha, beta, gamma, d_top, st);
+}
+int32_t plonk_quotient_combine_dev(int curve, int log_n, const uint32_t* classes, uint32_t n_classes, const uint32_t* d_r, const uint32_t* d_top, uint32_t n_top,
+                                   uint32_t* d_out, hipStream_t st) {
     if (curve != 0 && curve != 1) { set_error("unknown curve_id"); return MZK_ERR_INVALID_ARG; }
+    if (d_top && (n_top == 0 || n_top > PLK_TOP_MAX || n_top > (1ull << log_n) || (classes ? n_classes : 8u) >= PLK_RATIO)) {
+        set_error("combine: 1..9 top coefficients above at most 7 classes");
+        return MZK_ERR_INVALID_ARG;
+    }
     static const uint32_t all8[8] = {0, 1, 2, 3, 4, 5, 6, 7};
     if (!classes) { classes = all8; n_classes = 8; }
     bool ok = n_classes >= 1 && n_classes <= PLK_RATIO;
     for (uint32_t i = 0; ok && i < n_classes; i++) ok = classes[i] < PLK_RATIO && (i == 0 || classes[i] > classes[i - 1]);
     if (!ok) { set_error("combine: 1..8 strictly increasing residue classes < 8"); return MZK_ERR_INVALID_ARG; }
-    return curve == 0 ? quotient_combine_run<BlsFr>(log_n, classes, (int)n_classes, d_r, d_out, st)
-                      : quotient_combine_run<BnFr>(log_n, classes, (int)n_classes, d_r, d_out, st);
+    return curve == 0 ? quotient_combine_run<BlsFr>(log_n, classes, (int)n_classes, d_r, d_top, (int)n_top, d_out, st)
+                      : quotient_combine_run<BnFr>(log_n, classes, (int)n_classes, d_r, d_top, (int)n_top, d_out, st);
 }
 // number of resident residue classes of a chunked key (0: whole-domain key, -1: unknown handle); `out` receives them
 int plonk_pk_classes(uint64_t handle, uint32_t* out /* 8 slots, nullable */) {

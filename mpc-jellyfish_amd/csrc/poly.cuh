@@ -201,8 +201,10 @@ __global__ __launch_bounds__(1024) void fr_suffix_add_totals_kernel(uint32_t* __
 // q[k] = (S_incl[k+1] + above(block(k+1))) * zinv^(k+1), k < len - 1
 template <class P>
 __global__ __launch_bounds__(POLY_THREADS) void poly_div_finish_kernel(const uint32_t* __restrict__ sfx, const uint32_t* __restrict__ totals,
-                                                                        const uint32_t* __restrict__ zinvpow, unsigned long long len, uint32_t* __restrict__ q) {
+                                                                        const uint32_t* __restrict__ zinvpow, unsigned long long len, uint32_t* __restrict__ q,
+                                                                        uint32_t* __restrict__ rem) {
     const unsigned long long k = (unsigned long long)blockIdx.x * POLY_THREADS + threadIdx.x;
+    if (k == 0 && rem) store_fp<P>(rem, load_fp<P>(sfx) + load_fp<P>(totals));       // sum_i c_i z^i = p(z): the remainder
     if (k + 1 >= len) return;
     const Fp<P> s = load_fp<P>(sfx + (k + 1) * 8) + load_fp<P>(totals + ((k + 1) / DIV_BLOCK) * 8);
     store_fp<P>(q + k * 8, s * load_fp<P>(zinvpow + (k + 1) * 8));

@@ -36,13 +36,16 @@ int32_t eval_run(const uint32_t* d_coeffs, uint64_t stride, uint64_t len, uint32
 }
 
 template <class P>
-int32_t div_run(const uint32_t* d_poly, uint64_t len, const uint32_t* z_mont, uint32_t* d_out, hipStream_t st) {
+int32_t div_run(const uint32_t* d_poly, uint64_t len, const uint32_t* z_mont, uint32_t* d_out, uint32_t* d_rem, hipStream_t st) {
     using F = Fp<P>;
+    if (len == 0 && d_rem) HIP_TRY(hipMemsetAsync(d_rem, 0, 32, st));
+    if (len == 1 && d_rem) HIP_TRY(hipMemcpyAsync(d_rem, d_poly, 32, hipMemcpyDeviceToDevice, st));
     if (len <= 1) return MZK_OK;                                   // degree-0 (or empty) dividend: zero quotient, nothing to write
     F z;
     std::memcpy(z.l, z_mont, 32);
     if (z.is_zero()) {                                             // division by X: shift down
         HIP_TRY(hipMemcpyAsync(d_out, d_poly + 8, (len - 1) * 32, hipMemcpyDeviceToDevice, st));
+        if (d_rem) HIP_TRY(hipMemcpyAsync(d_rem, d_poly, 32, hipMemcpyDeviceToDevice, st));
         return MZK_OK;
     }
     const F zi = inv(z);
@@ -60,7 +63,7 @@ int32_t div_run(const uint32_t* d_poly, uint64_t len, const uint32_t* z_mont, ui
     hipLaunchKernelGGL((poly_div_scale_kernel<P>), dim3(eg), dim3(POLY_THREADS), 0, st, d_poly, zpow, len, t);
     hipLaunchKernelGGL((fr_suffix_add_block_kernel<P>), dim3(n_blocks), dim3(POLY_THREADS), 0, st, t, len, totals);
     hipLaunchKernelGGL((fr_suffix_add_totals_kernel<P>), dim3(1), dim3(1024), 0, st, totals, n_blocks);
-    hipLaunchKernelGGL((poly_div_finish_kernel<P>), dim3(eg), dim3(POLY_THREADS), 0, st, t, totals, zinvpow, len, d_out);
+    hipLaunchKernelGGL((poly_div_finish_kernel<P>), dim3(eg), dim3(POLY_THREADS), 0, st, t, totals, zinvpow, len, d_out, d_rem);
     HIP_TRY(hipGetLastError());
     MZK_TRY(ws_release(st));
     return MZK_OK;
@@ -151,7 +154,7 @@ int32_t div_roots_run(int curve, const uint32_t* d_poly, uint64_t len, uint32_t 
         F root = root0;
         for (uint64_t i = 0; i < count; i++) {
             uint32_t* dst = (i + 1 == count) ? d_out : buf[i & 1];
-            MZK_TRY((div_run<P>(cur, cur_len, root.l, dst, st)));
+            MZK_TRY((div_run<P>(cur, cur_len, root.l, dst, nullptr, st)));
             cur = dst;
             cur_len--;
             root = root * g;
@@ -189,9 +192,9 @@ int32_t poly_eval_dispatch(int curve, const uint32_t* d_coeffs, uint64_t stride,
     set_error("unknown curve_id");
     return MZK_ERR_INVALID_ARG;
 }
-int32_t poly_div_dispatch(int curve, const uint32_t* d_poly, uint64_t len, const uint32_t* z_mont, uint32_t* d_out, hipStream_t st) {
-    if (curve == 0) return div_run<BlsFr>(d_poly, len, z_mont, d_out, st);
-    if (curve == 1) return div_run<BnFr>(d_poly, len, z_mont, d_out, st);
+int32_t poly_div_dispatch(int curve, const uint32_t* d_poly, uint64_t len, const uint32_t* z_mont, uint32_t* d_out, uint32_t* d_rem, hipStream_t st) {
+    if (curve == 0) return div_run<BlsFr>(d_poly, len, z_mont, d_out, d_rem, st);
+    if (curve == 1) return div_run<BnFr>(d_poly, len, z_mont, d_out, d_rem, st);
     set_error("unknown curve_id");
     return MZK_ERR_INVALID_ARG;
 }

@@ -274,7 +274,9 @@ struct Prover {                                                        // Provin
     LocalComm* comm = nullptr;
     uint64_t lo = 0, hi = 0;
     DevBuf fixed;                                                      // (nsel + W [+ 4]) x n coefficient forms
-    DevBuf slab, quot, coeff, split, lin, batch, opening, shifted, hh, table, lookup, sorted, tmp, deg, rem, wv, wit;
+    DevBuf slab, quot, coeff, split, lin, batch, opening, shifted, hh, table, lookup, sorted, tmp, deg, rem, wv, wit, top;
+    bool use_top = false;                                              // W classes + mzk_plonk_quotient_top_dev (setup)
+    Fr batch_at_zeta;                                                  // value of the opening batch polynomial at zeta (check_quotient_identity)
     std::vector<uint32_t> classes, own;                                // the classes that determine the quotient; this rank's share of them
     std::vector<void*> peer_rem;                                       // `rem` of every rank (device pointers), for the one exchange
     void* copy_stream = nullptr;
@@ -303,11 +305,14 @@ struct Prover {                                                        // Provin
         for (int i = 0; i < W; i++) std::memcpy(&kk[4 * i], k[i].l, 32);
         const uint64_t* sel = host.data();
         const uint64_t* sig = sel + (size_t)nsel * n * 4;
-        // The quotient has degree W (n + 1) + 2 < (W + 1) n (prover.rs:916-919): W + 1 of the 8 residue classes of the quotient domain
-        // determine it -- 6 for TurboPlonk, 7 for UltraPlonk -- so only those are resident and evaluated (tiny domains keep all 8; one
-        // spare coefficient above the expected degree is required, or an unsatisfied witness could not trip WrongQuotientPolyDegree)
+        // The quotient has degree W (n + 1) + 2 (prover.rs:916-919).  Its W + 3 coefficients from X^(Wn) on are the top coefficients of
+        // its numerator (mzk_plonk_quotient_top_dev, n > W + 2), so W of the 8 residue classes of the quotient domain determine the
+        // rest -- 5 for TurboPlonk, 6 for UltraPlonk -- and only those are resident and evaluated; the polynomial so recovered has the
+        // expected degree whatever the witness, which is why check_quotient_identity exists.  Tiny domains: W + 1 classes with one spare
+        // coefficient above the expected degree (or an unsatisfied witness could not trip WrongQuotientPolyDegree), else all 8.
         classes.clear();
-        const uint32_t needed = ((uint64_t)W * (n + 1) + 2 < (uint64_t)(W + 1) * n - 1 && W + 1 <= 8) ? (uint32_t)W + 1 : 8u;
+        use_top = n > (uint64_t)W + 2 && n >= 8;
+        const uint32_t needed = use_top ? (uint32_t)W : (((uint64_t)W * (n + 1) + 2 < (uint64_t)(W + 1) * n - 1 && W + 1 <= 8) ? (uint32_t)W + 1 : 8u);
         for (uint32_t kcl = 0; kcl < needed; kcl++) classes.push_back(kcl);
         own = class_range(rank, world, needed);                          // contiguous blocks of ceil(needed / world); the last ranks may own none
         // a rank that owns no class still registers one (a key cannot be empty); it is never evaluated
@@ -315,6 +320,7 @@ struct Prover {                                                        // Provin
         check(mzk_plonk_pk_register_chunked(C::ID, log_n, W, sel, sig, ultra ? sig + (size_t)W * n * 4 : nullptr, n, kk.data(), resident.data(),
                                             (uint32_t)resident.size(), &pk), "mzk_plonk_pk_register_chunked");
         rem.alloc(classes.size() * n);                                   // the remainders of ALL needed classes: own ones computed here, the others received
+        top.alloc(16);                                                   // the quotient's top W + 3 coefficients (use_top)
         // the class-wise quotient reads the coefficient rows without overwriting them: n + 3 columns per row, no second copy
         slab.alloc((size_t)rows * (n + 3)); quot.alloc(m); coeff.alloc((size_t)(W + 1) * n);
         split.alloc((size_t)W * (n + 3)); lin.alloc(n + 3); batch.alloc(n + 4); opening.alloc(n + 3); shifted.alloc(n + 3); tmp.alloc(64);
@@ -453,7 +459,7 @@ struct Prover {                                                        // Provin
         const void* wire_values = nullptr;                               // W x n wire evaluations on this device
         Fr tau, beta, gamma, alpha, zeta;
         std::vector<Fr> wires_evals, wire_sigma_evals, plookup_evals;
-        Fr perm_next_eval;
+        Fr perm_next_eval, pi_eval;
     } st;
     int rowZ() const { return W; }
     int rowPI() const { return W + 1; }
@@ -575,8 +581,14 @@ struct Prover {                                                        // Provin
             comm->barrier();
         }
         // the inverse Vandermonde per coefficient index (replicated: every rank needs the quotient's coefficients for the split)
-        check(mzk_plonk_quotient_combine_classes_dev(C::ID, log_n, classes.data(), (uint32_t)classes.size(), rem.p, quot.p, nullptr),
-              "mzk_plonk_quotient_combine_classes_dev");
+        if (use_top) {
+            check(mzk_plonk_quotient_top_dev(pk, slab.p, n + 3, n + 3, alpha.l, st.beta.l, st.gamma.l, top.p, nullptr, nullptr), "mzk_plonk_quotient_top_dev");
+            check(mzk_plonk_quotient_combine_top_dev(C::ID, log_n, classes.data(), (uint32_t)classes.size(), rem.p, top.p, (uint32_t)W + 3, quot.p, nullptr),
+                  "mzk_plonk_quotient_combine_top_dev");
+        } else {
+            check(mzk_plonk_quotient_combine_classes_dev(C::ID, log_n, classes.data(), (uint32_t)classes.size(), rem.p, quot.p, nullptr),
+                  "mzk_plonk_quotient_combine_classes_dev");
+        }
         tick.mark("r3_quotient");
     }
     // split_quotient_polynomial (prover.rs:902-960) of the 8n coefficients at `q` into this->split; returns the W lengths
@@ -631,7 +643,9 @@ struct Prover {                                                        // Provin
         const Fr zeta_w = zeta * w_n;
         const int sigma0 = nsel, tab0 = nsel + W, H1 = rowH1(), PL = rowPL();
         EvalBatch ev(*this);
-        const size_t h_w = ev.add(krow(0), n + 2, W, n + 3, zeta);
+        // the wires and, in the same launch, z and the public-input polynomial (rows W, W + 1; every row is zero above its own length):
+        // pi(zeta) is not part of the proof, check_quotient_identity needs it
+        const size_t h_w = ev.add(krow(0), n + 3, W + 2, n + 3, zeta);
         const size_t h_s = ev.add(fix(sigma0), n, W - 1, n, zeta);
         const size_t h_z = ev.add(krow(rowZ()), n + 3, 1, n + 3, zeta_w);
         size_t h_tz = 0, h_tn = 0, h_h1 = 0, h_ql = 0, h_qln = 0, h_pl = 0, h_hn = 0, h_wn = 0;
@@ -648,6 +662,7 @@ struct Prover {                                                        // Provin
         ev.finish();
         const std::vector<Fr>& v = ev.vals;
         st.wires_evals.assign(v.begin() + h_w, v.begin() + h_w + W);
+        st.pi_eval = v[h_w + W + 1];
         st.wire_sigma_evals.assign(v.begin() + h_s, v.begin() + h_s + W - 1);
         st.perm_next_eval = v[h_z];
         std::vector<Fr>& pe = st.plookup_evals;
@@ -718,6 +733,50 @@ struct Prover {                                                        // Provin
         if (!(alpha_base == one)) for (auto& t : terms) t.s = t.s * alpha_base;
         return terms;
     }
+    // What the verifier takes for -(linearisation polynomial)(zeta): Verifier::compute_lin_poly_constant_term (verifier.rs:340-414) for this
+    // instance, times alpha_base.  The prover knows every input: its own evaluations and pi(zeta).
+    Fr lin_poly_constant(const Fr& alpha_base) const {
+        const std::vector<Fr>& we = st.wires_evals;
+        const std::vector<Fr>& pe = st.plookup_evals;
+        const Fr &alpha = st.alpha, &beta = st.beta, &gamma = st.gamma, &zeta = st.zeta;
+        const Fr one = Fr::one(), nf = from_u64<FrP>(n), a2 = alpha * alpha;
+        const Fr vanish = pow_u64(zeta, n) - one;
+        const Fr lagrange_1 = vanish * inv(nf * (zeta - one));
+        Fr tmp = st.pi_eval - a2 * lagrange_1;
+        Fr acc = alpha * st.perm_next_eval * (gamma + we[W - 1]);
+        for (int j = 0; j < W - 1; j++) acc = acc * (gamma + we[j] + beta * st.wire_sigma_evals[j]);
+        tmp = tmp - acc;
+        if (ultra) {
+            const Fr a3 = a2 * alpha, w_inv = inv(w_n);
+            const Fr lagrange_n = vanish * w_inv * inv(nf * (zeta - w_inv));
+            const Fr g1 = gamma * (one + beta);
+            const Fr pc = lagrange_n * (pe[H_1] - pe[H_2_NEXT] - a2) - alpha * lagrange_1
+                          - a3 * (zeta - w_inv) * pe[PROD_NEXT] * (g1 + pe[H_1] + beta * pe[H_1_NEXT]) * (g1 + beta * pe[H_2_NEXT]);
+            tmp = tmp + a3 * pc;
+        }
+        return tmp * alpha_base;
+    }
+    // the evaluations at zeta in the order of open_lists' first list (after the linearisation polynomial)
+    void opened_evals(std::vector<Fr>& out) const {
+        out.insert(out.end(), st.wires_evals.begin(), st.wires_evals.end());
+        out.insert(out.end(), st.wire_sigma_evals.begin(), st.wire_sigma_evals.end());
+        if (ultra) {
+            const std::vector<Fr>& pe = st.plookup_evals;
+            for (int i : {RANGE_TABLE, KEY_TABLE, H_1, Q_LOOKUP, TABLE_DOM_SEP, Q_DOM_SEP}) out.push_back(pe[i]);
+        }
+    }
+    // t(X) Z_H(X) = numerator(X), checked at the evaluation challenge the way the verifier will check it (verifier.rs:186-231, 340-414): the
+    // opening proof's batch polynomial lin + sum_i v^i p_i must take the value -r_0 + sum_i v^i p_i(zeta) at zeta, and its value there is
+    // the remainder its division by (X - zeta) leaves (mzk_poly_div_linear_rem_dev): one 32-byte read.  The guard against an unsatisfied
+    // witness where the top coefficients of the quotient come from its numerator (use_top): `WrongQuotientPolyDegree` (prover.rs:915-918)
+    // cannot fire there, the recovered polynomial having the expected degree by construction -- reported under the same name.
+    static void check_quotient_identity(const Fr& batch_at_zeta, const Fr& lin_constant, const std::vector<Fr>& opened, const Fr& v) {
+        Fr want = mzk::neg(lin_constant), c = Fr::one();
+        for (auto& e : opened) { c = c * v; want = want + c * e; }
+        if (!(batch_at_zeta == want))
+            throw std::runtime_error("WrongQuotientPolyDegree: the quotient identity t(X) Z_H(X) = numerator(X) does not hold at the evaluation "
+                                     "challenge (the witness does not satisfy the circuit)");
+    }
     // compute_quotient_component_for_lin_poly (prover.rs:343-358) over this->split
     std::vector<Term> quotient_lin_terms(const Fr& zeta, const std::vector<uint64_t>& split_len) const {
         const Fr one = Fr::one(), vanish = pow_u64(zeta, n) - one, zeta_n2 = (vanish + one) * zeta * zeta;
@@ -765,12 +824,19 @@ struct Prover {                                                        // Provin
         }
     }
     // compute_batched_witness_polynomial_commitment (prover.rs:490-509) up to the commitment
-    void batched_witness(const std::vector<Term>& polys, const Fr& v, const Fr& point, DevBuf& out) {
+    void batched_witness(const std::vector<Term>& polys, const Fr& v, const Fr& point, DevBuf& out, void* d_rem = nullptr) {
         std::vector<Term> t;
         Fr c = Fr::one();
         for (auto& p : polys) { t.push_back({c, p.p, p.len}); c = c * v; }
         lincomb_many(t, batch.p, n + 3);
-        check(mzk_poly_div_linear_dev(C::ID, batch.p, n + 3, point.l, out.p, nullptr), "mzk_poly_div_linear_dev");
+        if (d_rem) check(mzk_poly_div_linear_rem_dev(C::ID, batch.p, n + 3, point.l, out.p, d_rem, nullptr), "mzk_poly_div_linear_rem_dev");   // remainder = batch(point)
+        else check(mzk_poly_div_linear_dev(C::ID, batch.p, n + 3, point.l, out.p, nullptr), "mzk_poly_div_linear_dev");
+    }
+    void* rem_dev() const { return tmp.at(2); }                          // where the opening division leaves the batch polynomial's value at zeta
+    Fr download_fr(const void* d) const {
+        Fr v;
+        check(mzk_dev_download(v.l, d, EL), "download");
+        return v;
     }
     // Round 5 over several ranks.  The opening witness of a batch polynomial b at a point z is
     // w_j = sum_{i > j} b_i z^(i-j-1).  A rank needs w on its own coefficient range [lo, hi) only -- that is its MSM shard -- and
@@ -808,6 +874,9 @@ struct Prover {                                                        // Provin
         }
         const std::vector<uint8_t> all = comm->all_gather(rank, e, sizeof e);
         const Fr* every = reinterpret_cast<const Fr*>(all.data());
+        batch_at_zeta = Fr::zero();                                      // the open batch polynomial's value at zeta: every rank's range value times zeta^lo
+        for (int q = 0; q < world; q++)
+            batch_at_zeta = batch_at_zeta + pow_u64(zeta, std::min<uint64_t>(shard_range(n + 3, q, world).first, n + 3)) * every[2 * q];
         Fr carry[2] = {Fr::zero(), Fr::zero()};
         for (int q = rank + 1; q < world; q++) {                         // S_hi: the ranges above, shifted down to start at hi
             const uint64_t lo_q = std::min<uint64_t>(shard_range(n + 3, q, world).first, n + 3);
@@ -888,11 +957,17 @@ struct Prover {                                                        // Provin
             lincomb_many(terms, lin.p, n + 3);
             open_polys.push_back({Fr::one(), lin.p, n + 3});
             open_lists(open_polys, shifted_polys);
-            batched_witness(open_polys, v, zeta, opening);
+            batched_witness(open_polys, v, zeta, opening, rem_dev());
             batched_witness(shifted_polys, v, zeta * w_n, shifted);
             tick.mark("r5_polys");
             oc = commit({opening.p, shifted.p}, {n + 2, n + 2});
             tick.mark("r5_commit");
+            batch_at_zeta = download_fr(rem_dev());                         // (the commitments have synchronised the stream)
+        }
+        {
+            std::vector<Fr> opened;
+            opened_evals(opened);
+            check_quotient_identity(batch_at_zeta, lin_poly_constant(Fr::one()), opened, v);
         }
         proof.opening_proof = oc[0];
         proof.shifted_opening_proof = oc[1];
@@ -1154,9 +1229,15 @@ BatchProof<C> batch_prove(ChaChaRng& rng, const std::vector<Prover<C>*>& provers
     const Fr v = tr.get_and_append_challenge("v");
     std::vector<Term> open_polys{{Fr::one(), p0.lin.p, n + 3}}, shifted_polys;
     for (auto* p : provers) p->open_lists(open_polys, shifted_polys);
-    p0.batched_witness(open_polys, v, zeta, p0.opening);
+    p0.batched_witness(open_polys, v, zeta, p0.opening, p0.rem_dev());
     p0.batched_witness(shifted_polys, v, zeta * p0.w_n, p0.shifted);
     const auto oc = p0.commit({p0.opening.p, p0.shifted.p}, {n + 2, n + 2});
+    {   // the quotient identity at zeta over all instances (Prover::check_quotient_identity): the guard against an unsatisfied witness
+        Fr lin_constant = Fr::zero();
+        std::vector<Fr> opened;
+        for (size_t i = 0; i < K; i++) { lin_constant = lin_constant + provers[i]->lin_poly_constant(bases[i]); provers[i]->opened_evals(opened); }
+        P::check_quotient_identity(p0.download_fr(p0.rem_dev()), lin_constant, opened, v);
+    }
     proof.opening_proof = oc[0];
     proof.shifted_opening_proof = oc[1];
     return proof;

@@ -56,6 +56,8 @@ _SIGS = {
     "mzk_plonk_quotient_chunked_dev": [C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "mzk_plonk_quotient_combine_dev": [C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p],
     "mzk_plonk_quotient_combine_classes_dev": [C.c_int32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p],
+    "mzk_plonk_quotient_top_dev": [C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p],
+    "mzk_plonk_quotient_combine_top_dev": [C.c_int32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p],
     "mzk_plookup_sorted_vec_dev": [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "mzk_plookup_product_dev": [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "mzk_plonk_perm_product_dev": [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
@@ -65,6 +67,7 @@ _SIGS = {
     "mzk_poly_lincomb_dev": [C.c_int32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p],
     "mzk_poly_mask_dev": [C.c_int32, C.c_uint32, C.POINTER(C.c_void_p), C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p],
     "mzk_poly_div_linear_dev": [C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p],
+    "mzk_poly_div_linear_rem_dev": [C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
     "mzk_poly_degree_dev": [C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p],
     "mzk_poly_div_roots_dev": [C.c_int32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p],
     "mzk_dev_alloc": [C.c_uint64, C.POINTER(C.c_void_p)],

@@ -161,21 +161,48 @@ def compute_quotient_chunked_dev(pk: ProvingKeyDevice, challenges: Challenges, p
     return out
 
 
-def quotient_classes_needed(num_wire_types: int, domain_size: int) -> list[int]:
-    """The residue classes of the quotient domain that have to be evaluated: deg t = W (n + 1) + 2 (prover.rs:916-919) is below
-    (W + 1) n as soon as n > W + 2, so W + 1 of the 8 classes determine the quotient -- 6 for TurboPlonk, 7 for UltraPlonk;
-    tiny domains keep all 8.  One SPARE coefficient is required above the expected degree (n >= W + 4): the interpolant through
-    (W + 1) n points has degree < (W + 1) n whatever the witness, so at n = W + 3, where that bound IS the expected degree, an
-    unsatisfied witness would pass the reference's only guard (`WrongQuotientPolyDegree`, prover.rs:915-918) that the whole-domain
-    path trips."""
+def quotient_top_supported(num_wire_types: int, domain_size: int) -> bool:
+    """n > W + 2 (and n >= 8): the coefficients of the quotient from X^(Wn) on are then the top W + 3 coefficients of its numerator
+    (include/mzk.h, mzk_plonk_quotient_top_dev)."""
+    return domain_size > num_wire_types + 2 and domain_size >= 8 and num_wire_types <= 7
+
+
+def quotient_classes_needed(num_wire_types: int, domain_size: int, top: bool = True) -> list[int]:
+    """The residue classes of the quotient domain that have to be evaluated.  deg t = W (n + 1) + 2 (prover.rs:916-919).
+    top=True (the device provers): the W + 3 coefficients from X^(Wn) on come from compute_quotient_top_dev, so W classes determine
+    the rest -- 5 of the 8 for TurboPlonk, 6 for UltraPlonk (n > W + 2; smaller domains fall back to the rule below).  The recovered
+    polynomial then has the expected degree for ANY witness: the caller checks the quotient identity at zeta instead
+    (prover.py, check_quotient_identity).
+    top=False (host-pointer mzk_plonk_quotient, whose caller keeps the reference's degree guard): deg t is below (W + 1) n as soon as
+    n > W + 2, so W + 1 classes determine it; tiny domains keep all 8.  One SPARE coefficient is required above the expected degree
+    (n >= W + 4): the interpolant through (W + 1) n points has degree < (W + 1) n whatever the witness, so at n = W + 3, where that
+    bound IS the expected degree, an unsatisfied witness would pass `WrongQuotientPolyDegree` (prover.rs:915-918)."""
     W, n = num_wire_types, domain_size
+    if top and quotient_top_supported(W, n):
+        return list(range(W))
     return list(range(W + 1)) if W * (n + 1) + 2 < (W + 1) * n - 1 and W + 1 <= 8 else list(range(8))
 
 
-def combine_quotient_classes(curve, domain_size: int, class_remainders, classes=None, out_dev=None, stream=None):
+def compute_quotient_top_dev(pk: ProvingKeyDevice, challenges: Challenges, polys_dev, in_len: int, out_dev=None, stream=None):
+    """The W + 3 coefficients of the quotient from X^(Wn) on, from the top coefficients of the numerator's factors (no evaluation):
+    polys_dev as for compute_quotient_chunked_dev (rows: W wire polynomials, then z).  Returns a (16, 4) CUDA tensor, the first W + 3
+    rows filled.  Asynchronous."""
+    import torch
+    assert pk.classes is not None and polys_dev.dim() == 3 and polys_dev.shape[2] == 4 and polys_dev.is_cuda and polys_dev.is_contiguous()
+    out = torch.zeros((16, 4), dtype=torch.int64, device=polys_dev.device) if out_dev is None else out_dev
+    st = torch.cuda.current_stream(polys_dev.device).cuda_stream if stream is None else stream
+    ch = fr_to_mont(pk.curve, [challenges.alpha, challenges.beta, challenges.gamma])
+    p = lambda i: C.c_void_p(ch[i].ctypes.data)
+    _lib.check(_lib.ensure_init().mzk_plonk_quotient_top_dev(pk.handle, polys_dev.data_ptr(), polys_dev.shape[1], in_len, p(0), p(1), p(2), out.data_ptr(), None, st),
+               "mzk_plonk_quotient_top_dev")
+    return out
+
+
+def combine_quotient_classes(curve, domain_size: int, class_remainders, classes=None, out_dev=None, stream=None, top=None, n_top: int = 0):
     """SURVEY.md 8(e).3, after the exchange: (len(classes), n, 4) class remainders (class-major, in the order of `classes`;
     default all 8) -> (8n, 4) quotient coefficients, what `coset.ifft` returns at prover.rs:672 (slabs above len(classes) zero).
-    Asynchronous."""
+    top / n_top: the result of compute_quotient_top_dev and W + 3 -- the classes then only have to determine the n len(classes)
+    coefficients below.  Asynchronous."""
     import torch
     c = _curve(curve)
     n = domain_size
@@ -185,8 +212,13 @@ def combine_quotient_classes(curve, domain_size: int, class_remainders, classes=
     out = torch.empty((8 * n, 4), dtype=torch.int64, device=r.device) if out_dev is None else out_dev
     st = torch.cuda.current_stream(r.device).cuda_stream if stream is None else stream
     ca = np.ascontiguousarray(cl, dtype=np.uint32)
-    _lib.check(_lib.ensure_init().mzk_plonk_quotient_combine_classes_dev(c.curve_id, n.bit_length() - 1, C.c_void_p(ca.ctypes.data), len(cl),
-                                                                         r.data_ptr(), out.data_ptr(), st), "mzk_plonk_quotient_combine_classes_dev")
+    L = _lib.ensure_init()
+    if top is None:
+        _lib.check(L.mzk_plonk_quotient_combine_classes_dev(c.curve_id, n.bit_length() - 1, C.c_void_p(ca.ctypes.data), len(cl), r.data_ptr(), out.data_ptr(), st),
+                   "mzk_plonk_quotient_combine_classes_dev")
+    else:
+        _lib.check(L.mzk_plonk_quotient_combine_top_dev(c.curve_id, n.bit_length() - 1, C.c_void_p(ca.ctypes.data), len(cl), r.data_ptr(), top.data_ptr(), n_top,
+                                                        out.data_ptr(), st), "mzk_plonk_quotient_combine_top_dev")
     return out
 
 

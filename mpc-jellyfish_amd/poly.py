@@ -63,15 +63,21 @@ def lincomb(curve, terms, out_len: int | None = None, out=None, stream=None):
     return out
 
 
-def div_by_linear(curve, poly_dev, z: int, stream=None):
-    """Quotient of p(X) / (X - z) as a (len-1, 4) CUDA tensor (remainder dropped, as ark-poly does)."""
+def div_by_linear(curve, poly_dev, z: int, stream=None, rem_out=None):
+    """Quotient of p(X) / (X - z) as a (len-1, 4) CUDA tensor (remainder dropped, as ark-poly does).  rem_out: a (1, 4) CUDA tensor that
+    receives the remainder p(z) (asynchronously)."""
     import torch
     c = _curve(curve)
     n = poly_dev.shape[0]
     out = torch.zeros((max(n - 1, 0), 4), dtype=torch.int64, device=poly_dev.device)
     zm = fr_to_mont(c, [z])[0]
-    _lib.check(_lib.ensure_init().mzk_poly_div_linear_dev(c.curve_id, poly_dev.data_ptr(), n, C.c_void_p(zm.ctypes.data), out.data_ptr(),
-                                                          _stream(poly_dev, stream)), "mzk_poly_div_linear_dev")
+    L = _lib.ensure_init()
+    if rem_out is None:
+        _lib.check(L.mzk_poly_div_linear_dev(c.curve_id, poly_dev.data_ptr(), n, C.c_void_p(zm.ctypes.data), out.data_ptr(), _stream(poly_dev, stream)),
+                   "mzk_poly_div_linear_dev")
+    else:
+        _lib.check(L.mzk_poly_div_linear_rem_dev(c.curve_id, poly_dev.data_ptr(), n, C.c_void_p(zm.ctypes.data), out.data_ptr(), rem_out.data_ptr(),
+                                                 _stream(poly_dev, stream)), "mzk_poly_div_linear_rem_dev")
     return out
 
 

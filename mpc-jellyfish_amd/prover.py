@@ -25,7 +25,7 @@ import numpy as np
 from . import kzg, plonk, poly
 from . import transcript as _transcript
 from .domain import Radix2EvaluationDomain
-from .params import CurveParams, curve as _curve, fr_to_mont
+from .params import CurveParams, curve as _curve, fr_from_mont, fr_to_mont
 
 
 PlonkError = plonk.PlonkError
@@ -443,7 +443,12 @@ class TurboPlonkProver:
                 local = torch.empty((0, n, 4), dtype=torch.int64, device=slab.device)
             every = self.quotient_gather(local, len(self.classes_needed)) if self.quotient_gather is not None else local
             resident = self.classes_needed if self.quotient_gather is not None else self.own_classes
-            plonk.combine_quotient_classes(c, n, every.contiguous(), classes=resident, out_dev=quot)
+            if len(resident) == self.W and plonk.quotient_top_supported(self.W, n):
+                # W classes + the W + 3 top coefficients of the numerator (every rank computes its own copy of those)
+                top = plonk.compute_quotient_top_dev(self.pk, ch, slab, n + 3)
+                plonk.combine_quotient_classes(c, n, every.contiguous(), classes=resident, out_dev=quot, top=top, n_top=self.W + 3)
+            else:
+                plonk.combine_quotient_classes(c, n, every.contiguous(), classes=resident, out_dev=quot)
         # quot_poly.degree() != expected_degree => WrongQuotientPolyDegree (prover.rs:915-918): the reference's only guard against an
         # unsatisfied witness (batch_prove_internal never runs check_circuit_satisfiability).  The length is computed on the
         # device now and read in check_quotient_degree, after the round's commitments have synchronised the stream anyway.
@@ -500,7 +505,9 @@ class TurboPlonkProver:
         t0 = time.perf_counter()
         zeta_w = zeta * self.w_n % r
         ev = _RangeEvals(self) if self._ranged() else _Evals(self)
-        h_w = ev.add(keep[:W], zeta, length=n + 2)
+        # wires, and in the same launch z and the public-input polynomial (rows W, W + 1; every row is zero above its own length): pi(zeta)
+        # is not part of the proof, check_quotient_identity needs it
+        h_w = ev.add(keep[:W + 2], zeta, length=n + 3)
         h_s = ev.add(self.fixed[self.sigma0:self.sigma0 + W - 1], zeta)
         h_z = ev.add(st.z_poly, zeta_w)
         if self.ultra:
@@ -510,7 +517,8 @@ class TurboPlonkProver:
             h_h1, h_ql, h_qln = ev.add(st.h1, zeta), ev.add(q_lookup, zeta), ev.add(q_lookup, zeta_w)
             h_nx = ev.add(keep[[st.PL, st.H1, st.H1 + 1, 3, 4]], zeta_w)
         ev.finish()
-        st.wires_evals, st.wire_sigma_evals, st.perm_next_eval = ev.get(h_w), ev.get(h_s), ev.get(h_z)[0]
+        st.wires_evals, st.wire_sigma_evals, st.perm_next_eval = ev.get(h_w)[:W], ev.get(h_s), ev.get(h_z)[0]
+        st.pi_eval = ev.get(h_w)[W + 1]
         st.pe = None
         if self.ultra:
             at_zeta, at_next, nx = ev.get(h_tz), ev.get(h_tn), ev.get(h_nx)
@@ -562,6 +570,55 @@ class TurboPlonkProver:
             terms = [(s * alpha_base % r, p) for s, p in terms]
         return terms
 
+    def _lin_poly_constant(self, st, alpha_base: int = 1) -> int:
+        """What the verifier takes for -(linearisation polynomial)(zeta): Verifier::compute_lin_poly_constant_term (verifier.rs:340-414) for
+        this instance, times alpha_base.  The prover knows every input: its own evaluations and pi(zeta)."""
+        r, n, W = self.curve.r, self.n, self.W
+        alpha, beta, gamma, zeta = st.alpha, st.beta, st.gamma, st.zeta
+        we, se, zn, pe = st.wires_evals, st.wire_sigma_evals, st.perm_next_eval, st.pe
+        a2 = alpha * alpha % r
+        vanish = (pow(zeta, n, r) - 1) % r
+        lagrange_1 = vanish * pow(n * (zeta - 1) % r, -1, r) % r
+        tmp = (st.pi_eval - a2 * lagrange_1) % r
+        acc = alpha * zn % r * ((gamma + we[W - 1]) % r) % r
+        for j in range(W - 1):
+            acc = acc * ((gamma + we[j] + beta * se[j]) % r) % r
+        tmp = (tmp - acc) % r
+        if self.ultra:
+            a3 = a2 * alpha % r
+            w_inv = pow(self.w_n, -1, r)
+            lagrange_n = vanish * w_inv % r * pow(n * (zeta - w_inv) % r, -1, r) % r
+            g1 = gamma * ((1 + beta) % r) % r
+            pc = (lagrange_n * ((pe["h_1_eval"] - pe["h_2_next_eval"] - a2) % r) - alpha * lagrange_1
+                  - a3 * ((zeta - w_inv) % r) % r * pe["prod_next_eval"] % r * ((g1 + pe["h_1_eval"] + beta * pe["h_1_next_eval"]) % r) % r
+                  * ((g1 + beta * pe["h_2_next_eval"]) % r)) % r
+            tmp = (tmp + a3 * pc) % r
+        return tmp * alpha_base % r
+
+    def _opened_evals(self, st):
+        """the evaluations at zeta in the order of _open_lists' first list (after the linearisation polynomial)"""
+        out = list(st.wires_evals) + list(st.wire_sigma_evals)
+        if self.ultra:
+            pe = st.pe
+            out += [pe["range_table_eval"], pe["key_table_eval"], pe["h_1_eval"], pe["q_lookup_eval"], pe["table_dom_sep_eval"], pe["q_dom_sep_eval"]]
+        return out
+
+    def check_quotient_identity(self, batch_at_zeta: int, lin_constant: int, opened_evals, v_ch: int):
+        """t(X) Z_H(X) = numerator(X), checked at the evaluation challenge the way the verifier will check it (verifier.rs:186-231, 340-414):
+        the opening proof's batch polynomial lin + sum_i v^i p_i must take the value -r_0 + sum_i v^i p_i(zeta) at zeta -- and its value
+        there is the remainder its division by (X - zeta) leaves (mzk_poly_div_linear_rem_dev), so the check costs one 32-byte read.
+        This is the guard against an unsatisfied witness on the path that takes the top coefficients of the quotient from its
+        numerator (plonk.compute_quotient_top_dev): the reference's `WrongQuotientPolyDegree` (prover.rs:915-918) cannot fire there,
+        the recovered polynomial having the expected degree by construction."""
+        r = self.curve.r
+        want, cf = (-lin_constant) % r, 1
+        for e in opened_evals:
+            cf = cf * v_ch % r
+            want = (want + cf * e) % r
+        if batch_at_zeta % r != want:
+            raise PlonkError("the quotient identity t(X) Z_H(X) = numerator(X) does not hold at the evaluation challenge "
+                             "(the witness does not satisfy the circuit)", kind="WrongQuotientPolyDegree")
+
     def _quotient_lin_terms(self, zeta, split):
         """compute_quotient_component_for_lin_poly (prover.rs:343-358)"""
         r, n = self.curve.r, self.n
@@ -587,21 +644,22 @@ class TurboPlonkProver:
             shifted_polys += [st.pl_poly, tabs[0], tabs[1], st.h1, st.h2, q_lookup, st.wire_polys[3], st.wire_polys[4], tabs[2]]
         return open_polys, shifted_polys
 
-    def _batched_witness(self, polys, v_ch, point):
-        """compute_batched_witness_polynomial_commitment (prover.rs:490-509) up to the commitment: sum_i v^i p_i, divided by (X - point)"""
+    def _batched_witness(self, polys, v_ch, point, rem_out=None):
+        """compute_batched_witness_polynomial_commitment (prover.rs:490-509) up to the commitment: sum_i v^i p_i, divided by (X - point);
+        rem_out (a (1, 4) device tensor) receives the remainder = the batch polynomial's value at the point"""
         c, r, n = self.curve, self.curve.r, self.n
         if len(polys) == 1:
-            return poly.div_by_linear(c, polys[0].contiguous(), point)
+            return poly.div_by_linear(c, polys[0].contiguous(), point, rem_out=rem_out)
         bterms, cf = [], 1
         for p in polys:
             bterms.append((cf, p))
             cf = cf * v_ch % r
         if len(bterms) <= poly.MAX_TERMS:
-            return poly.div_by_linear(c, poly.lincomb(c, bterms, out_len=n + 3), point)
+            return poly.div_by_linear(c, poly.lincomb(c, bterms, out_len=n + 3), point, rem_out=rem_out)
         acc = poly.lincomb(c, bterms[:poly.MAX_TERMS], out_len=n + 3)      # more terms than one launch takes: accumulate
         for i in range(poly.MAX_TERMS, len(bterms), poly.MAX_TERMS - 1):
             acc = poly.lincomb(c, [(1, acc)] + bterms[i:i + poly.MAX_TERMS - 1], out_len=n + 3)
-        return poly.div_by_linear(c, acc, point)
+        return poly.div_by_linear(c, acc, point, rem_out=rem_out)
 
     def _lincomb_many(self, terms, out_len):
         """sum of (scalar, polynomial) terms, more than one launch's worth if need be"""
@@ -656,6 +714,8 @@ class TurboPlonkProver:
             lo_q = min(shard_range(com.ck.length, q, world)[0], n + 3)
             carry[0] = (carry[0] + pow(zeta, lo_q - hi, r) * every[q][0]) % r
             carry[1] = (carry[1] + pow(zw, lo_q - hi, r) * every[q][1]) % r
+        # the batch polynomial's value at zeta (check_quotient_identity): every rank's range value times zeta^lo
+        self._batch_at_zeta = sum(pow(zeta, min(shard_range(com.ck.length, q, world)[0], n + 3), r) * every[q][0] for q in range(world)) % r
         wit = []
         for b_, cy, z_ in ((b_open, carry[0], zeta), (b_shift, carry[1], zw)):
             if not width:
@@ -715,12 +775,15 @@ class TurboPlonkProver:
                                                                       open_polys, shifted_polys, v_ch, zeta, tick, t0)
         else:
             lin = poly.lincomb(c, self._lin_poly_terms(st) + self._quotient_lin_terms(zeta, split), out_len=n + 3)
-            opening = self._batched_witness([lin] + open_polys, v_ch, zeta)
+            rem = torch.zeros((1, 4), dtype=torch.int64, device=lin.device)
+            opening = self._batched_witness([lin] + open_polys, v_ch, zeta, rem_out=rem)
             shifted = self._batched_witness(shifted_polys, v_ch, zeta * self.w_n % r)
             tick("r5_polys", t0)
             t0 = time.perf_counter()
             open_comms = self._commit([opening, shifted])
             tick("r5_commit", t0)
+            self._batch_at_zeta = fr_from_mont(c, rem.cpu().numpy().view(np.uint64))[0]      # (the commitments have synchronised the stream)
+        self.check_quotient_identity(self._batch_at_zeta, self._lin_poly_constant(st), self._opened_evals(st), v_ch)
         self.last_challenges = {"tau": tau, "beta": beta, "gamma": gamma, "alpha": alpha, "zeta": zeta, "v": v_ch}
         self.last = {"wire_polys": st.wire_polys, "z_poly": st.z_poly, "quot": quot, "split": split, "lin": lin, "opening": opening, "shifted": shifted}
         if ultra:

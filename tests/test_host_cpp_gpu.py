@@ -147,12 +147,14 @@ def test_unsatisfied_witness_is_rejected_by_both_hosts(gpu, mj):
 
 def test_unsatisfied_witness_at_the_smallest_domain(gpu, mj):
     """n = 8 = W + 3 (TurboPlonk): the expected quotient degree 5 (n + 1) + 2 = 47 is exactly 6 n - 1, so a polynomial recovered from
-    6 residue classes has degree <= 47 whatever the witness and `WrongQuotientPolyDegree` could never fire.  The class
-    rule therefore keeps all 8 classes there (one spare coefficient is required), and a corrupted witness is rejected by both hosts."""
+    6 residue classes has degree <= 47 whatever the witness and `WrongQuotientPolyDegree` could never fire: without the
+    top coefficients the class rule keeps all 8 classes there.  The device provers take 5 classes and the top 8 coefficients from the
+    numerator (n > W + 2) and check the quotient identity at zeta instead: a corrupted witness is rejected by both hosts."""
     import torch
     c = mj.params.BLS12_381
-    assert mj.plonk.quotient_classes_needed(5, 8) == list(range(8)) and mj.plonk.quotient_classes_needed(5, 16) == list(range(6))
-    assert mj.plonk.quotient_classes_needed(6, 8) == list(range(8)) and mj.plonk.quotient_classes_needed(6, 16) == list(range(7))
+    assert mj.plonk.quotient_classes_needed(5, 8, top=False) == list(range(8)) and mj.plonk.quotient_classes_needed(5, 16, top=False) == list(range(6))
+    assert mj.plonk.quotient_classes_needed(6, 8, top=False) == list(range(8)) and mj.plonk.quotient_classes_needed(6, 16, top=False) == list(range(7))
+    assert mj.plonk.quotient_classes_needed(5, 8) == list(range(5)) and mj.plonk.quotient_classes_needed(6, 8) == list(range(8))
     cs = mj.snark.gen_circuit_for_bench(c, 16, "TurboPlonk")
     assert cs.n == 8
     rng = mj.rng.test_rng()

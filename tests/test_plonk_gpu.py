@@ -92,7 +92,7 @@ def test_quotient_of_a_satisfied_circuit_is_a_low_degree_polynomial(gpu, mj, cre
     assert ev(t) * (pow(x, n, r) - 1) % r == gate
     # the host-pointer entry point over a key that holds only the 6 needed residue classes (the hosts' default) returns the same
     # 8n coefficients as over the whole-domain key; over 5 classes -- which cannot determine a degree-(5n + 7) quotient -- it refuses
-    pk6 = mj.plonk.ProvingKeyDevice.register(c, n, sel_polys, sigma_polys, k, classes=mj.plonk.quotient_classes_needed(5, n))
+    pk6 = mj.plonk.ProvingKeyDevice.register(c, n, sel_polys, sigma_polys, k, classes=mj.plonk.quotient_classes_needed(5, n, top=False))
     assert np.array_equal(mj.plonk.compute_quotient_polynomial(pk6, ch, wire_polys, z_poly, pi_poly), t)
     pk5 = mj.plonk.ProvingKeyDevice.register(c, n, sel_polys, sigma_polys, k, classes=[0, 1, 2, 3, 4])
     with pytest.raises(Exception):
@@ -107,6 +107,71 @@ def test_quotient_of_a_satisfied_circuit_is_a_low_degree_polynomial(gpu, mj, cre
     assert bad6[5 * n + 8:6 * n].any() and not bad6[6 * n:].any(), "from 6 classes the interpolant has degree < 6n, and not 5n + 7"
     pk.release()
     pk6.release()
+
+
+@pytest.mark.parametrize("curve_id", [0, 1])
+@pytest.mark.parametrize("log_n", [3, 4, 6, 9])
+def test_quotient_from_one_class_fewer_and_the_top_coefficients(gpu, mj, pyref, curve_id, log_n):
+    """mzk_plonk_quotient_top_dev + mzk_plonk_quotient_combine_top_dev: W classes and the W + 3 top coefficients of the numerator give the
+    same 8n coefficients as the whole-domain key.  The circuit of the test above (add / mul / x^5 / ecc gates, identity permutation
+    sigma_j = k_j X) with BLINDED polynomials: w_j + (b0 + b1 X) Z_H and z = 1 + (c0 + c1 X + c2 X^2) Z_H keep the numerator divisible
+    by Z_H and bring the quotient to its full degree 5 (n + 1) + 2 with the q_hash / q_ecc terms inside the top window."""
+    import torch
+    c = mj.params.CURVES[curve_id]
+    pc = pyref.CURVES[curve_id]
+    n = 1 << log_n
+    rng = random.Random(1234 + 7 * curve_id + log_n)
+    r = c.r
+    w = [[rng.randrange(r) for _ in range(n)] for _ in range(5)]
+    sel = [[0] * n for _ in range(13)]
+    for i in range(n):
+        kind = i % 4
+        if kind == 0:
+            sel[0][i] = sel[1][i] = 1; sel[10][i] = 1
+            w[4][i] = (w[0][i] + w[1][i]) % r
+        elif kind == 1:
+            sel[4][i] = 3; sel[5][i] = 1; sel[10][i] = 1
+            w[4][i] = (3 * w[0][i] * w[1][i] + w[2][i] * w[3][i]) % r
+        elif kind == 2:
+            sel[6][i] = 1; sel[7][i] = 5; sel[8][i] = rng.randrange(r); sel[9][i] = 2; sel[10][i] = 1
+            w[4][i] = (pow(w[0][i], 5, r) + 5 * pow(w[1][i], 5, r) + sel[8][i] * pow(w[2][i], 5, r) + 2 * pow(w[3][i], 5, r)) % r
+        else:
+            sel[12][i] = rng.randrange(1, r)
+            w[4][i] = rng.randrange(r)
+            prod = w[0][i] * w[1][i] % r * w[2][i] % r * w[3][i] % r * w[4][i] % r
+            sel[11][i] = (-sel[12][i] * prod) % r
+    k = [1, 7, 13, 17, 23]
+    sel_polys = [_interpolate(mj, c, log_n, s_) for s_ in sel]
+    sigma_polys = [fr_mont_limbs(c, [0, kj] + [0] * (n - 2)) for kj in k]
+
+    def blinded(coeffs, blind):                                   # p + blind(X) (X^n - 1)
+        out = list(coeffs) + [0] * (n + len(blind) - len(coeffs))
+        for i, b in enumerate(blind):
+            out[n + i] = (out[n + i] + b) % r
+            out[i] = (out[i] - b) % r
+        return out
+    wire_int = [blinded(fr_from_mont_limbs(c, _interpolate(mj, c, log_n, col)), [rng.randrange(1, r), rng.randrange(1, r)]) for col in w]
+    z_int = blinded([1] + [0] * (n - 1), [rng.randrange(1, r) for _ in range(3)])
+    rows = np.zeros((7, n + 3, 4), dtype=np.uint64)
+    for j in range(5):
+        rows[j, :n + 2] = fr_mont_limbs(c, wire_int[j])
+    rows[5] = fr_mont_limbs(c, z_int)
+    ch = mj.plonk.Challenges(rng.randrange(r), rng.randrange(r), rng.randrange(r))
+    pk = mj.plonk.ProvingKeyDevice.register(c, n, sel_polys, sigma_polys, k)
+    want = mj.plonk.compute_quotient_polynomial(pk, ch, [rows[j] for j in range(5)], rows[5], rows[6])
+    assert want[5 * n + 7].any() and not want[5 * n + 8:].any(), "the blinded quotient has degree exactly 5 (n + 1) + 2"
+    classes = mj.plonk.quotient_classes_needed(5, n)
+    assert classes == [0, 1, 2, 3, 4] and mj.plonk.quotient_classes_needed(5, n, top=False) == ([0, 1, 2, 3, 4, 5] if n > 8 else list(range(8)))
+    for cl in (classes, [1, 3, 4, 6, 7]):
+        pk5 = mj.plonk.ProvingKeyDevice.register(c, n, sel_polys, sigma_polys, k, classes=cl)
+        slab = torch.from_numpy(rows.view(np.int64)).cuda()
+        rem = mj.plonk.compute_quotient_chunked_dev(pk5, ch, slab, n + 3)
+        top = mj.plonk.compute_quotient_top_dev(pk5, ch, slab, n + 3)
+        got = mj.plonk.combine_quotient_classes(c, n, rem, classes=cl, top=top, n_top=8).cpu().numpy().view(np.uint64)
+        assert np.array_equal(top.cpu().numpy().view(np.uint64)[:8], want[5 * n:5 * n + 8]), "top coefficients"
+        assert np.array_equal(got, want)
+        pk5.release()
+    pk.release()
 
 
 def test_quotient_device_resident_and_errors(gpu, mj, cref):

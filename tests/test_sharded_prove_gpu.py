@@ -55,12 +55,14 @@ def test_sharded_prove_matches_single_process(gpu, tmp_path, curve_id, plonk_typ
 @pytest.mark.parametrize("curve_id,plonk_type,num_gates,classes", [(0, "TurboPlonk", 1 << 10, list(range(8))), (1, "UltraPlonk", 1 << 9, list(range(8))),
                                                                   (0, "TurboPlonk", 1 << 10, None), (1, "UltraPlonk", 1 << 9, None),
                                                                   (1, "TurboPlonk", 1 << 7, [0, 2, 3, 5, 6, 7]), (0, "UltraPlonk", 1 << 8, [1, 2, 3, 4, 5, 6, 7]),
+                                                                  (1, "TurboPlonk", 1 << 7, [0, 2, 3, 5, 7]), (0, "UltraPlonk", 1 << 8, [1, 2, 4, 5, 6, 7]),
                                                                   (0, "TurboPlonk", 64, [1, 4, 6])])
 def test_chunked_quotient_single_process(gpu, mj, curve_id, plonk_type, num_gates, classes):
     """Residue classes on one GPU: class-wise size-n coset NTTs + fused kernel + local inverse + the inverse Vandermonde per
     coefficient must give the very coefficients of the whole-domain quotient (coset FFT(8n) path, `quotient_classes="whole"`) --
-    from all 8 classes (an 8-point iDFT), from the default reduced set (6 of 8 for TurboPlonk, 7 for UltraPlonk: deg t =
-    W (n + 1) + 2 needs no more, prover.rs:916-919) and from other class sets of that size.  A key holding 3 classes must produce
+    from all 8 classes (an 8-point iDFT), from W + 1 of them (6 of 8 for TurboPlonk, 7 for UltraPlonk: deg t = W (n + 1) + 2 needs no
+    more, prover.rs:916-919), and from the default W classes together with the W + 3 top coefficients that mzk_plonk_quotient_top_dev
+    takes from the numerator (contiguous and scattered class sets).  A key holding 3 classes must produce
     those classes' remainders t mod (X^n - h_k^n) of the same quotient."""
     import torch
     c = mj.params.CURVES[curve_id]
@@ -72,9 +74,10 @@ def test_chunked_quotient_single_process(gpu, mj, curve_id, plonk_type, num_gate
     core0, bytes0 = mj.snark.prove(mj.rng.test_rng(), cs, pk0)
     quot0 = pk0.last["quot"].clone()
     pk1 = mj.snark.preprocess(ck, cs, quotient_classes=classes)
+    W = 6 if plonk_type == "UltraPlonk" else 5
     if classes is None:
-        assert pk1.own_classes == list(range(7 if plonk_type == "UltraPlonk" else 6))
-    if classes is None or len(classes) >= 6:
+        assert pk1.own_classes == list(range(W))                     # W classes + the top W + 3 coefficients from the numerator (round 3)
+    if classes is None or len(classes) >= W:
         core1, bytes1 = mj.snark.prove(mj.rng.test_rng(), cs, pk1)
         assert torch.equal(pk1.last["quot"], quot0)
         assert bytes1 == bytes0

@@ -128,16 +128,21 @@ def test_host_batch_normalisation(mj, cref, curve_id):
 
 
 def test_class_range_covers_the_needed_classes_for_every_world():
-    """sharding.class_range: the 6 (TurboPlonk) / 7 (UltraPlonk) / 8 needed residue classes over 1..8 ranks -- contiguous, disjoint,
+    """sharding.class_range: the 5 (TurboPlonk) / 6 (UltraPlonk) / 8 needed residue classes (6 / 7 without the top coefficients) over 1..8 ranks -- contiguous, disjoint,
     in rank order, every class owned exactly once; ranks beyond the classes own none (8 GPUs, 6 classes)."""
     from importlib import import_module
     sh = import_module("mpc-jellyfish_amd.sharding")
     pl = import_module("mpc-jellyfish_amd.plonk")
-    assert pl.quotient_classes_needed(5, 1 << 20) == list(range(6)) and pl.quotient_classes_needed(6, 1 << 22) == list(range(7))
-    # n <= W + 3: all 8 (at n = W + 3 the expected degree is (W + 1) n - 1: no spare coefficient, the degree check could not fail)
-    assert pl.quotient_classes_needed(5, 8) == list(range(8)) and pl.quotient_classes_needed(5, 4) == list(range(8))
-    assert pl.quotient_classes_needed(5, 16) == list(range(6)) and pl.quotient_classes_needed(6, 16) == list(range(7))
-    for ncl in (6, 7, 8):
+    # the device provers' rule: W classes, the W + 3 top coefficients come from the numerator (n > W + 2)
+    assert pl.quotient_classes_needed(5, 1 << 20) == list(range(5)) and pl.quotient_classes_needed(6, 1 << 22) == list(range(6))
+    assert pl.quotient_classes_needed(5, 8) == list(range(5)) and pl.quotient_classes_needed(5, 4) == list(range(8))
+    assert pl.quotient_classes_needed(6, 8) == list(range(8)) and pl.quotient_classes_needed(6, 16) == list(range(6))
+    # without them (host-pointer mzk_plonk_quotient, whose caller keeps the degree guard): W + 1 classes; n <= W + 3: all 8 (at n = W + 3
+    # the expected degree is (W + 1) n - 1: no spare coefficient, the degree check could not fail)
+    assert pl.quotient_classes_needed(5, 1 << 20, top=False) == list(range(6)) and pl.quotient_classes_needed(6, 1 << 22, top=False) == list(range(7))
+    assert pl.quotient_classes_needed(5, 8, top=False) == list(range(8)) and pl.quotient_classes_needed(5, 4, top=False) == list(range(8))
+    assert pl.quotient_classes_needed(5, 16, top=False) == list(range(6)) and pl.quotient_classes_needed(6, 16, top=False) == list(range(7))
+    for ncl in (5, 6, 7, 8):
         for world in range(1, 9):
             owned = [sh.class_range(r, world, ncl) for r in range(world)]
             assert sum(owned, []) == list(range(ncl)), (ncl, world)

@@ -86,7 +86,7 @@ def measure(mj, L, curve, log_n, mode, reps=2, srs=None, pk=None):
         if pk is None:
             own_pk = True
             fixed = mj.params.random_fr_mont(c, 18 * n, seed=31).reshape(18, n, 4)
-            pk = mj.plonk.ProvingKeyDevice.register(c, n, list(fixed[:13]), list(fixed[13:]), [1, 2, 3, 4, 5], classes=mj.plonk.quotient_classes_needed(5, n))
+            pk = mj.plonk.ProvingKeyDevice.register(c, n, list(fixed[:13]), list(fixed[13:]), [1, 2, 3, 4, 5], classes=mj.plonk.quotient_classes_needed(5, n, top=False))
             del fixed
         wires = HostBuf(L, 5 * n, pinned)
         wires.a[:] = np.tile(rnd[:n], (5, 1))
