@@ -114,13 +114,16 @@ def test_cpp_host_batch_prove_matches_python_mirror(gpu, mj, curve_id, plonk_typ
     ck.release()
 
 
-def test_unsatisfied_witness_is_rejected_by_both_hosts(gpu, mj):
+@pytest.mark.parametrize("curve_id,plonk_type", [(0, "TurboPlonk"), (1, "UltraPlonk")])
+def test_unsatisfied_witness_is_rejected_by_both_hosts(gpu, mj, curve_id, plonk_type):
     """`quot_poly.degree() != expected_degree => WrongQuotientPolyDegree` (prover.rs:915-918) is the reference's only guard against a
     witness that does not satisfy the circuit (batch_prove_internal never calls check_circuit_satisfiability): with one wire value
-    changed, the Python mirror raises PlonkError, `batch_prove` too, and the compiled host exits non-zero -- no proof bytes."""
+    changed, the Python mirror raises PlonkError, `batch_prove` too, and the compiled host exits non-zero -- no proof bytes.  (Here the
+    quotient's top coefficients come from the numerator, so its degree is right by construction: what fires is the hosts' check of the
+    quotient identity at zeta, reported under the same name.)"""
     import torch
-    c = mj.params.BLS12_381
-    cs = mj.snark.gen_circuit_for_bench(c, 64, "TurboPlonk")
+    c = mj.params.CURVES[curve_id]
+    cs = mj.snark.gen_circuit_for_bench(c, 64, plonk_type)
     rng = mj.rng.test_rng()
     ck = mj.UnivariateProverParam.gen_srs_for_testing(c, mj.rng.fr_rand(c, rng), cs.n + 2)
     pk = mj.snark.preprocess(ck, cs)
@@ -141,7 +144,7 @@ def test_unsatisfied_witness_is_rejected_by_both_hosts(gpu, mj):
         p.release()
     ck.release()
     env = dict(os.environ, MZK_PROVE_CORRUPT_WITNESS="1")
-    out = subprocess.run([BIN, "0", "turbo", "64", "0"], capture_output=True, text=True, timeout=600, env=env)
+    out = subprocess.run([BIN, str(curve_id), "turbo" if plonk_type == "TurboPlonk" else "ultra", "64", "0"], capture_output=True, text=True, timeout=600, env=env)
     assert out.returncode == 1 and "WrongQuotientPolyDegree" in out.stderr and "proof_hex" not in out.stdout
 
 
