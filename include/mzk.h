@@ -221,6 +221,12 @@ MZK_API int32_t mzk_plonk_pk_register_chunked(int32_t curve_id, uint32_t log_n, 
 MZK_API int32_t mzk_plonk_quotient_chunked_dev(uint64_t pk_handle, const void* d_polys, uint64_t in_stride, uint64_t in_len,
                                                const uint64_t* tau_mont, const uint64_t* alpha_mont, const uint64_t* beta_mont,
                                                const uint64_t* gamma_mont, void* d_out, void* stream);
+/* The same with flags.  MZK_QUOTIENT_PI_ZERO: the caller's public-input polynomial (row W + 1 of d_polys) is the zero polynomial -- a circuit
+ * without public inputs, or all of them zero: its row is then neither transformed nor read (one coset NTT in W + 2 less per class). */
+#define MZK_QUOTIENT_PI_ZERO 1u
+MZK_API int32_t mzk_plonk_quotient_chunked_flags_dev(uint64_t pk_handle, const void* d_polys, uint64_t in_stride, uint64_t in_len, uint32_t flags,
+                                                     const uint64_t* tau_mont, const uint64_t* alpha_mont, const uint64_t* beta_mont,
+                                                     const uint64_t* gamma_mont, void* d_out, void* stream);
 MZK_API int32_t mzk_plonk_quotient_combine_dev(int32_t curve_id, uint32_t log_n, const void* d_class_remainders, void* d_out, void* stream);
 /* The same recovery from FEWER classes.  The quotient has degree W (n + 1) + 2 (`quotient_polynomial_degree`,
  * plonk/src/proof_system/prover.rs:916-919, 1126-1128), below (W + 1) n once n > W + 2: the remainders modulo X^n - h_k^n on any

@@ -82,7 +82,7 @@ def batch_prove(provers: list[TurboPlonkProver], wire_values: list, pub_input_va
     # round 1
     states, wires_vec = [], []
     for k, p in enumerate(provers):
-        st, wires_comms = p._stage_round1(wire_values[k], pub_input_values[k], blinds[k], tick)
+        st, wires_comms = p._stage_round1(wire_values[k], pub_input_values[k], blinds[k], tick, pi_zero=not any(pub_inputs[k]))
         t.append_commitments(b"witness_poly_comms", [_pt(c, x) for x in wires_comms])
         states.append(st)
         wires_vec.append(wires_comms)

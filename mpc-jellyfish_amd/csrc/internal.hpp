@@ -113,8 +113,11 @@ inline int handle_ctx(uint64_t h) { return (int)(h >> 48) - 1; }
 // ntt.hip
 // scale: 0 = boundary form in and out; 1 = output left in the internal form x * R' (R' = 2^261 = 32 R) of the quotient kernels;
 // 2 = input in that form, output back in the boundary form (the factor rides in the final pass's multiplication)
+// d_src (nullable): out of place -- the first pass reads the batch there (src_stride elements apart) and d_data only receives the result;
+// d_patch (with d_src): 4 elements per batch entry that replace the input indices 0..3 (ntt_fx.cuh)
 int32_t ntt_dispatch(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool inverse, const uint32_t* coset,
-                     uint32_t batch, uint64_t stride, hipStream_t st, int scale = 0);
+                     uint32_t batch, uint64_t stride, hipStream_t st, int scale = 0, const uint32_t* d_src = nullptr, uint64_t src_stride = 0,
+                     const uint32_t* d_patch = nullptr);
 void ntt_release_plans();
 void msm_release_streams();
 // msm.hip
@@ -142,8 +145,8 @@ int32_t poly_mask_dispatch(int curve, uint32_t n_rows, uint32_t* const* d_rows, 
 int32_t plonk_pk_register(int curve, int log_n, int W, const uint32_t* sel, const uint32_t* sig, const uint32_t* tab /* NULL: TurboPlonk */,
                           uint64_t poly_len, const uint32_t* k_mont, const uint32_t* classes /* NULL: whole domain */, uint32_t n_classes,
                           uint64_t* out_handle);
-int32_t plonk_quotient_chunked_dev(uint64_t handle, const uint32_t* d_polys, uint64_t in_stride, uint64_t in_len, const uint32_t* tau, const uint32_t* alpha,
-                                   const uint32_t* beta, const uint32_t* gamma, uint32_t* d_out, hipStream_t st);
+int32_t plonk_quotient_chunked_dev(uint64_t handle, const uint32_t* d_polys, uint64_t in_stride, uint64_t in_len, uint32_t flags, const uint32_t* tau,
+                                   const uint32_t* alpha, const uint32_t* beta, const uint32_t* gamma, uint32_t* d_out, hipStream_t st);
 int32_t plonk_quotient_top_dev(uint64_t handle, const uint32_t* d_polys, uint64_t in_stride, uint64_t in_len, const uint32_t* alpha, const uint32_t* beta,
                                const uint32_t* gamma, uint32_t* d_top, uint32_t* out_n_top, hipStream_t st);
 int32_t plonk_quotient_combine_dev(int curve, int log_n, const uint32_t* classes /* NULL: all 8 */, uint32_t n_classes, const uint32_t* d_r,

@@ -634,8 +634,13 @@ int32_t mzk_plonk_pk_register_chunked(int32_t curve_id, uint32_t log_n, uint32_t
 }
 int32_t mzk_plonk_quotient_chunked_dev(uint64_t pk_handle, const void* d_polys, uint64_t in_stride, uint64_t in_len, const uint64_t* tau_mont,
                                        const uint64_t* alpha_mont, const uint64_t* beta_mont, const uint64_t* gamma_mont, void* d_out, void* stream) {
+    return mzk_plonk_quotient_chunked_flags_dev(pk_handle, d_polys, in_stride, in_len, 0, tau_mont, alpha_mont, beta_mont, gamma_mont, d_out, stream);
+}
+int32_t mzk_plonk_quotient_chunked_flags_dev(uint64_t pk_handle, const void* d_polys, uint64_t in_stride, uint64_t in_len, uint32_t flags, const uint64_t* tau_mont,
+                                             const uint64_t* alpha_mont, const uint64_t* beta_mont, const uint64_t* gamma_mont, void* d_out, void* stream) {
     ENTER_HANDLE(pk_handle);
-    return plonk_quotient_chunked_dev(pk_handle, reinterpret_cast<const uint32_t*>(d_polys), in_stride, in_len, reinterpret_cast<const uint32_t*>(tau_mont),
+    if (flags & ~(uint32_t)MZK_QUOTIENT_PI_ZERO) { set_error("unknown flag"); return MZK_ERR_INVALID_ARG; }
+    return plonk_quotient_chunked_dev(pk_handle, reinterpret_cast<const uint32_t*>(d_polys), in_stride, in_len, flags, reinterpret_cast<const uint32_t*>(tau_mont),
                                       reinterpret_cast<const uint32_t*>(alpha_mont), reinterpret_cast<const uint32_t*>(beta_mont),
                                       reinterpret_cast<const uint32_t*>(gamma_mont), reinterpret_cast<uint32_t*>(d_out), (hipStream_t)stream);
 }
@@ -720,7 +725,7 @@ int32_t mzk_plonk_quotient(uint64_t pk_handle, const uint64_t* polys, uint64_t i
         MZK_TRY(g_ws.io.reserve((size_t)(W + 2) * in_len * 32));
         MZK_TRY(g_ws.link_tmp.reserve((size_t)ncl * n * 32));
         HIP_TRY(hipMemcpyAsync(g_ws.io.p, polys, (size_t)(W + 2) * in_len * 32, hipMemcpyHostToDevice, st));
-        MZK_TRY(plonk_quotient_chunked_dev(pk_handle, g_ws.io.as<uint32_t>(), in_len, in_len, nullptr, reinterpret_cast<const uint32_t*>(alpha_mont),
+        MZK_TRY(plonk_quotient_chunked_dev(pk_handle, g_ws.io.as<uint32_t>(), in_len, in_len, 0, nullptr, reinterpret_cast<const uint32_t*>(alpha_mont),
                                            reinterpret_cast<const uint32_t*>(beta_mont), reinterpret_cast<const uint32_t*>(gamma_mont),
                                            g_ws.link_tmp.as<uint32_t>(), st));
         MZK_TRY(plonk_quotient_combine_dev(plonk_pk_curve(pk_handle), log_n, classes, (uint32_t)ncl, g_ws.link_tmp.as<uint32_t>(), nullptr, 0,

@@ -123,7 +123,7 @@ int32_t launch_pass(const NttxPassArgs& a, unsigned long long n_tiles, uint32_t 
     const bool tw_lds = !a.is_final && mode != 2;                         // (mode 2: persistent without LDS-staged twiddles)
     const size_t lds_p = lds + (tw_lds ? (((size_t)1 << a.log_r) - 1) * FS_TW_WORDS * 4 : 0);
     if (mode) MZK_TRY((tw_lds ? persistent_grid<X, true>(lds_p, &resident) : persistent_grid<X, false>(lds_p, &resident)));
-    if (mode && total >= 3ull * resident && tile <= 2 * NTTX_THREADS) {
+    if (mode && total >= 3ull * resident && tile <= 2 * NTTX_THREADS && !a.patch) {
         int log_tiles = 0;
         while ((1ull << log_tiles) < n_tiles) log_tiles++;
         if (tw_lds) hipLaunchKernelGGL((nttx_pass_persistent_kernel<X, true>), dim3(resident), dim3(NTTX_THREADS), lds_p, st, a, log_tiles, total);
@@ -136,13 +136,15 @@ int32_t launch_pass(const NttxPassArgs& a, unsigned long long n_tiles, uint32_t 
 }
 
 // d_data: batch polynomials, `stride` elements apart, transformed in place (async on st)
+// d_src (nullable): the first pass reads the batch from there (src_stride elements apart, not overwritten) instead of d_data, which
+// then only receives the result; d_patch (nullable, needs d_src): 4 replacement elements per batch entry for the input indices 0..3
 template <class X>
 int32_t ntt_dev(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool inverse, const uint32_t* coset,
-                uint32_t batch, uint64_t stride, hipStream_t st, int scale) {
+                uint32_t batch, uint64_t stride, hipStream_t st, int scale, const uint32_t* d_src, uint64_t src_stride, const uint32_t* d_patch) {
     if (log_n < 0 || log_n > X::TWO_ADICITY || log_n > 30) { set_error("log_n out of range"); return MZK_ERR_INVALID_ARG; }
     const uint64_t N = 1ull << log_n;
     if (batch == 0) return MZK_OK;
-    if (stride < N || batch > 65535) { set_error("bad batch/stride"); return MZK_ERR_INVALID_ARG; }
+    if (stride < N || batch > 65535 || (d_src && src_stride < in_len) || (d_patch && (!d_src || N < 4))) { set_error("bad batch/stride"); return MZK_ERR_INVALID_ARG; }
     if (in_len > N) in_len = N;
     if (log_n == 0 && scale == 0) return MZK_OK;   // size-1 transform is the identity (offset^0 = 1, N^-1 = 1)
     if (log_n == 0) { set_error("scaled size-1 transform"); return MZK_ERR_UNSUPPORTED; }
@@ -169,7 +171,7 @@ int32_t ntt_dev(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool in
         a.f_one = pl->h.final_factor ? pl->d_fone : nullptr;
         a.in_len = in_len;
         a.n = N;
-        if (a.is_first && !a.is_final)                                  // zero-padded input: leading stages of pass 1 are copies
+        if (a.is_first && !a.is_final && !d_patch)                      // zero-padded input: leading stages of pass 1 are copies
             while (a.skip < lr && in_len <= (N >> (a.skip + 1))) a.skip++;
         int lc = NTT_TILE_LOG - lr;
         if (lc < 0) lc = 0;
@@ -179,8 +181,9 @@ int32_t ntt_dev(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool in
         // pass 1 reads the caller's buffer, middle passes run in place on scratch, the last pass
         // writes back to the caller's buffer (K = 1: data -> scratch, copied back below)
         const bool from_data = k == 0, to_data = (k == K - 1) && K > 1;
-        a.in = from_data ? d_data : scratch;
-        a.in_stride = from_data ? stride : N;
+        a.in = from_data ? (d_src ? const_cast<uint32_t*>(d_src) : d_data) : scratch;
+        a.in_stride = from_data ? (d_src ? src_stride : stride) : N;
+        a.patch = from_data ? d_patch : nullptr;
         a.in_planes = from_data ? 0 : 1;
         a.out = to_data ? d_data : scratch;
         a.out_stride = to_data ? stride : N;
@@ -198,9 +201,9 @@ int32_t ntt_dev(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool in
 }  // namespace
 
 int32_t ntt_dispatch(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool inverse, const uint32_t* coset,
-                     uint32_t batch, uint64_t stride, hipStream_t st, int scale) {
-    if (curve == MZK_CURVE_BLS12_381) return ntt_dev<BlsFrX>(curve, d_data, in_len, log_n, inverse, coset, batch, stride, st, scale);
-    if (curve == MZK_CURVE_BN254) return ntt_dev<BnFrX>(curve, d_data, in_len, log_n, inverse, coset, batch, stride, st, scale);
+                     uint32_t batch, uint64_t stride, hipStream_t st, int scale, const uint32_t* d_src, uint64_t src_stride, const uint32_t* d_patch) {
+    if (curve == MZK_CURVE_BLS12_381) return ntt_dev<BlsFrX>(curve, d_data, in_len, log_n, inverse, coset, batch, stride, st, scale, d_src, src_stride, d_patch);
+    if (curve == MZK_CURVE_BN254) return ntt_dev<BnFrX>(curve, d_data, in_len, log_n, inverse, coset, batch, stride, st, scale, d_src, src_stride, d_patch);
     set_error("unknown curve_id");
     return MZK_ERR_INVALID_ARG;
 }

@@ -53,6 +53,8 @@ struct NttxPassArgs {
     int is_first, is_final, n_pass;
     int skip;                  // first pass of a zero-padded input (in_len <= N >> skip): the first `skip` stages are copies
     int in_planes, out_planes; // 1: the 9-limb plane layout of the scratch buffer; 0: the boundary's packed 8 words
+    const uint32_t* patch;     // first pass, nullable: elements g < 4 of batch entry y are read from patch[y * 4 + g] (packed) instead of `in` --
+                               // the class-wise quotient transforms p mod (X^n - c), which differs from p's first n coefficients in 2-3 places
     int log_radix[NTT_MAX_PASSES];
 };
 
@@ -172,6 +174,7 @@ __global__ __launch_bounds__(NTTX_THREADS) void nttx_pass_kernel(NttxPassArgs a)
         v = Fs<X>::zero(); v.l[0] = (int32_t)g;
 #else
         if (a.in_planes) v = planes_get<X>(in, a.n, g);                                  // lazy: |limbs| <= 2^30
+        else if (a.patch && g < 4) v = fs_load_packed<X>(a.patch + ((unsigned long long)blockIdx.y * 4 + g) * 8);
         else if (a.is_first && g >= a.in_len) v = Fs<X>::zero();
         else v = fs_load_packed<X>(in + g * 8);                                        // fresh: limbs in [0, 2^29)
 #endif

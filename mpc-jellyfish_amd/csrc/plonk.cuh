@@ -88,7 +88,8 @@ __global__ __launch_bounds__(PLK_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
     for (int j = 0; j < W; j++) w[j] = ldx<X>(a.wire + ((size_t)j * os + i) * 8);
     auto sel = [&](int j) { return ldx<X>(a.sel + ((size_t)j * fs + i) * 8); };
     // ---- gate identity (prover.rs:696-708); value bounds in units of p on the right
-    F t = fx_add(sel(11), ldx<X>(a.pi + i * 8));                                       // q_c + pi                     2
+    F t = sel(11);                                                                     // q_c + pi                     2
+    if (a.pi) t = fx_add(t, ldx<X>(a.pi + i * 8));                                     // (null: the public-input polynomial is zero)
 #pragma unroll
     for (int j = 0; j < 4; j++) t = fx_add(t, fx_mul(sel(j), w[j]));                  // q_lc                         6.1, limbs < 6 * 2^29
     t = fx_norm(t);
@@ -219,6 +220,22 @@ __global__ __launch_bounds__(PLK_THREADS) void plonk_fold_kernel(const uint32_t*
     F v = j < in_len ? load_fp<P>(p + j * 8) : F::zero();
     if (n + j < in_len) v = v + fr_arg<P>(c_mont) * load_fp<P>(p + (n + j) * 8);
     store_fp<P>(dst + t * 8, v);
+}
+
+// The same fold for polynomials of at most n + 4 coefficients, where only the first in_len - n <= 4 coefficients change: the size-n coset
+// NTT then reads p's first n coefficients in place and takes elements 0..3 from here (ntt_fx.cuh, NttxPassArgs::patch).
+//   patch[row][j] = p[j] + h_k^n * p[n + j],  j < 4
+template <class P>
+__global__ void plonk_fold_patch_kernel(const uint32_t* __restrict__ src, unsigned long long src_stride, unsigned long long in_len, unsigned long long n, int rows,
+                                        FrArg c_mont, uint32_t* __restrict__ patch) {
+    using F = Fp<P>;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * 4) return;
+    const unsigned long long row = t / 4, j = t % 4;
+    const uint32_t* p = src + row * src_stride * 8;
+    F v = (j < in_len && j < n) ? load_fp<P>(p + j * 8) : F::zero();
+    if (n + j < in_len) v = v + fr_arg<P>(c_mont) * load_fp<P>(p + (n + j) * 8);
+    store_fp<P>(patch + (size_t)t * 8, v);
 }
 
 // r_k = t mod (X^n - c_k), c_k = g^n w_8^k, for s of the 8 classes k  ->  the s coefficient slabs T_q of t = sum_{q<s} X^(qn) T_q:

@@ -497,16 +497,20 @@ int32_t quotient_top_run(const PlonkPk& pk, const uint32_t* d_polys, uint64_t in
 // per resident class: fold the online polynomials mod (X^n - h_k^n), size-n coset NTTs, the fused kernel on n points,
 // size-n inverse coset NTT.  d_out[lc] = t mod (X^n - h_k^n), n coefficients per class.
 template <class P>
-int32_t quotient_chunked_run(const PlonkPk& pk, const uint32_t* d_polys, uint64_t in_stride, uint64_t in_len, const uint32_t* tau, const uint32_t* alpha,
-                             const uint32_t* beta, const uint32_t* gamma, uint32_t* d_out, hipStream_t st) {
+int32_t quotient_chunked_run(const PlonkPk& pk, const uint32_t* d_polys, uint64_t in_stride, uint64_t in_len, uint32_t flags, const uint32_t* tau,
+                             const uint32_t* alpha, const uint32_t* beta, const uint32_t* gamma, uint32_t* d_out, hipStream_t st) {
     using F = Fp<P>;
     const uint64_t n = 1ull << pk.log_n;
     const int rows = pk.W + 2 + (pk.ultra ? 3 : 0);
     const size_t ncl = pk.cls.size();
     ProfScope total("plonk_quotient_chunked_total", st);
     MZK_TRY(ws_acquire(st));
-    MZK_TRY(g_ws.plonk_polys.reserve((size_t)rows * n * 32 + 64));
+    MZK_TRY(g_ws.plonk_polys.reserve((size_t)rows * n * 32 + 64 + (size_t)rows * 4 * 32));
     uint32_t* work = g_ws.plonk_polys.as<uint32_t>();
+    uint32_t* patch = work + ((size_t)rows * n + 2) * 8;
+    const bool pi_zero = (flags & MZK_QUOTIENT_PI_ZERO) != 0;              // the caller knows its public-input polynomial is zero: row W + 1 is neither
+                                                                           // transformed nor read
+    const bool patched = in_len <= n + 4 && n >= 4;                        // p mod (X^n - c) differs from p's first n coefficients in <= 4 places
     QuotientArgs a;
     a.m = n; a.fstride = ncl * n; a.ostride = n; a.next_off = 1;
     fill_quotient_constants<P>(a, pk, tau, alpha, beta, gamma);
@@ -515,16 +519,28 @@ int32_t quotient_chunked_run(const PlonkPk& pk, const uint32_t* d_polys, uint64_
         const int k = pk.cls[lc];
         FrArg c_k;
         std::memcpy(c_k.l, pk.c_cls[k], 32);
-        hipLaunchKernelGGL((plonk_fold_kernel<P>), dim3((unsigned)((fold_threads + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st,
-                           d_polys, in_stride, in_len, n, rows, c_k, work);
+        // evaluations on the class, in the internal form: size-n coset NTTs of p mod (X^n - c_k)
+        auto transform = [&](int first, int count) -> int32_t {             // rows first .. first + count - 1
+            if (patched)                                                    // read in place (not overwritten), elements 0..3 from the patch
+                return ntt_dispatch(pk.curve, work + (size_t)first * n * 8, n, pk.log_n, false, pk.h_cls[k], (uint32_t)count, n, st, 1,
+                                    d_polys + (size_t)first * in_stride * 8, in_stride, patch + (size_t)first * 4 * 8);
+            return ntt_dispatch(pk.curve, work + (size_t)first * n * 8, n, pk.log_n, false, pk.h_cls[k], (uint32_t)count, n, st, 1);
+        };
+        if (patched) hipLaunchKernelGGL((plonk_fold_patch_kernel<P>), dim3((rows * 4 + 63) / 64), dim3(64), 0, st, d_polys, in_stride, in_len, n, rows, c_k, patch);
+        else hipLaunchKernelGGL((plonk_fold_kernel<P>), dim3((unsigned)((fold_threads + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st,
+                                d_polys, in_stride, in_len, n, rows, c_k, work);
         HIP_TRY(hipGetLastError());
-        MZK_TRY(ntt_dispatch(pk.curve, work, n, pk.log_n, false, pk.h_cls[k], rows, n, st, 1));          // evaluations in the internal form
+        if (!pi_zero) MZK_TRY(transform(0, rows));
+        else {
+            MZK_TRY(transform(0, pk.W + 1));
+            if (pk.ultra) MZK_TRY(transform(pk.W + 2, 3));
+        }
         a.sel = pk.d_fixed + lc * n * 8;
         a.sig = pk.d_fixed + ((size_t)pk.nsel * ncl + lc) * n * 8;
         a.tab = pk.ultra ? pk.d_fixed + ((size_t)(pk.nsel + pk.W) * ncl + lc) * n * 8 : nullptr;
         a.wire = work;
         a.z = work + (size_t)pk.W * n * 8;
-        a.pi = work + (size_t)(pk.W + 1) * n * 8;
+        a.pi = pi_zero ? nullptr : work + (size_t)(pk.W + 1) * n * 8;
         a.h = pk.ultra ? work + (size_t)(pk.W + 2) * n * 8 : nullptr;
         a.pl = pk.ultra ? work + (size_t)(pk.W + 4) * n * 8 : nullptr;
         a.xs = pk.d_xs + lc * n * 8;
@@ -686,8 +702,8 @@ int32_t plookup_product_dev(uint64_t handle, const uint32_t* d_table, const uint
     return pk->curve == 0 ? lookup_product_run<BlsFr>(*pk, d_table, d_lookup, d_sorted, beta, gamma, d_out, st)
                           : lookup_product_run<BnFr>(*pk, d_table, d_lookup, d_sorted, beta, gamma, d_out, st);
 }
-int32_t plonk_quotient_chunked_dev(uint64_t handle, const uint32_t* d_polys, uint64_t in_stride, uint64_t in_len, const uint32_t* tau, const uint32_t* alpha,
-                                   const uint32_t* beta, const uint32_t* gamma, uint32_t* d_out, hipStream_t st) {
+int32_t plonk_quotient_chunked_dev(uint64_t handle, const uint32_t* d_polys, uint64_t in_stride, uint64_t in_len, uint32_t flags, const uint32_t* tau,
+                                   const uint32_t* alpha, const uint32_t* beta, const uint32_t* gamma, uint32_t* d_out, hipStream_t st) {
     const PlonkPk* pk = find_pk(handle);
     if (!pk) return MZK_ERR_BAD_HANDLE;
     if (pk->cls.empty()) { set_error("not a chunked proving key"); return MZK_ERR_INVALID_ARG; }
@@ -695,8 +711,8 @@ int32_t plonk_quotient_chunked_dev(uint64_t handle, const uint32_t* d_polys, uin
         set_error("bad argument (online polynomials have degree < 2n)");
         return MZK_ERR_INVALID_ARG;
     }
-    return pk->curve == 0 ? quotient_chunked_run<BlsFr>(*pk, d_polys, in_stride, in_len, tau, alpha, beta, gamma, d_out, st)
-                          : quotient_chunked_run<BnFr>(*pk, d_polys, in_stride, in_len, tau, alpha, beta, gamma, d_out, st);
+    return pk->curve == 0 ? quotient_chunked_run<BlsFr>(*pk, d_polys, in_stride, in_len, flags, tau, alpha, beta, gamma, d_out, st)
+                          : quotient_chunked_run<BnFr>(*pk, d_polys, in_stride, in_len, flags, tau, alpha, beta, gamma, d_out, st);
 }
 int32_t plonk_quotient_top_dev(uint64_t handle, const uint32_t* d_polys, uint64_t in_stride, uint64_t in_len, const uint32_t* alpha, const uint32_t* beta,
                                const uint32_t* gamma, uint32_t* d_top, uint32_t* out_n_top, hipStream_t st) {

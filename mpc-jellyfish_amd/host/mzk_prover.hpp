@@ -567,8 +567,9 @@ struct Prover {                                                        // Provin
         // per OWN class: fold mod X^n - h_k^n, size-n coset NTTs, the fused kernel, size-n inverse coset NTT -> t mod (X^n - h_k^n), straight
         // into this class's slot of `rem` (the rows of the slab are read, not overwritten)
         if (!own.empty())
-            check(mzk_plonk_quotient_chunked_dev(pk, slab.p, n + 3, n + 3, ultra ? st.tau.l : nullptr, alpha.l, st.beta.l, st.gamma.l,
-                                                 rem.at((size_t)own[0] * n), nullptr), "mzk_plonk_quotient_chunked_dev");
+            check(mzk_plonk_quotient_chunked_flags_dev(pk, slab.p, n + 3, n + 3, MZK_QUOTIENT_PI_ZERO /* the bench circuit has no public input: round1 */,
+                                                       ultra ? st.tau.l : nullptr, alpha.l, st.beta.l, st.gamma.l, rem.at((size_t)own[0] * n), nullptr),
+                  "mzk_plonk_quotient_chunked_flags_dev");
         if (world > 1) {
             // THE one exchange: every rank pushes its class remainders into the same slots of every other rank's
             // `rem`, device to device (xGMI peer copies; n x 32 B per class and peer), then all ranks meet

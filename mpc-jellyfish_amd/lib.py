@@ -54,6 +54,8 @@ _SIGS = {
     "mzk_plonk_pk_register_chunked": [C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint32,
                                       C.POINTER(C.c_uint64)],
     "mzk_plonk_quotient_chunked_dev": [C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "mzk_plonk_quotient_chunked_flags_dev": [C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                                             C.c_void_p],
     "mzk_plonk_quotient_combine_dev": [C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p],
     "mzk_plonk_quotient_combine_classes_dev": [C.c_int32, C.c_uint32, C.c_void_p, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p],
     "mzk_plonk_quotient_top_dev": [C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(C.c_uint32), C.c_void_p],

@@ -143,10 +143,11 @@ def compute_quotient_polynomial_dev(pk: ProvingKeyDevice, challenges: Challenges
     return out_dev
 
 
-def compute_quotient_chunked_dev(pk: ProvingKeyDevice, challenges: Challenges, polys_dev, in_len: int, out_dev=None, stream=None):
+def compute_quotient_chunked_dev(pk: ProvingKeyDevice, challenges: Challenges, polys_dev, in_len: int, out_dev=None, stream=None, pi_zero: bool = False):
     """SURVEY.md 8(e).3, local part: polys_dev is a (W + 2 [+ 3], stride, 4) CUDA tensor of coefficient rows (first in_len
     <= 2n slots used, not overwritten); returns (len(pk.classes), n, 4): per resident class k the coefficients of
-    t mod (X^n - h_k^n).  Asynchronous."""
+    t mod (X^n - h_k^n).  pi_zero: the public-input polynomial (row W + 1) is known to be zero -- it is then neither transformed nor
+    read (MZK_QUOTIENT_PI_ZERO).  Asynchronous."""
     import torch
     n = pk.domain_size
     rows = pk.num_wire_types + 2 + (3 if pk.ultra else 0)
@@ -156,8 +157,9 @@ def compute_quotient_chunked_dev(pk: ProvingKeyDevice, challenges: Challenges, p
     st = torch.cuda.current_stream(polys_dev.device).cuda_stream if stream is None else stream
     ch = fr_to_mont(pk.curve, [challenges.alpha, challenges.beta, challenges.gamma, challenges.tau])
     p = lambda i: C.c_void_p(ch[i].ctypes.data)
-    _lib.check(_lib.ensure_init().mzk_plonk_quotient_chunked_dev(pk.handle, polys_dev.data_ptr(), polys_dev.shape[1], in_len, p(3) if pk.ultra else None,
-                                                                 p(0), p(1), p(2), out.data_ptr(), st), "mzk_plonk_quotient_chunked_dev")
+    _lib.check(_lib.ensure_init().mzk_plonk_quotient_chunked_flags_dev(pk.handle, polys_dev.data_ptr(), polys_dev.shape[1], in_len, 1 if pi_zero else 0,
+                                                                       p(3) if pk.ultra else None, p(0), p(1), p(2), out.data_ptr(), st),
+               "mzk_plonk_quotient_chunked_flags_dev")
     return out
 
 

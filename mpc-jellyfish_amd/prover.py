@@ -303,13 +303,14 @@ class TurboPlonkProver:
 
     # ---- the rounds of one instance, as separate stages so that batch_prove (batch.py) can interleave several instances the way
     # ---- batch_prove_internal does (snark.rs:263-431); `st` carries what Oracles (structs.rs:875-887) carries, on the device
-    def _stage_round1(self, wire_values, pub_input_values, blind: Blinders, tick):
-        """prover.rs:72-87: wire and public-input iNTTs, masking, W commitments."""
+    def _stage_round1(self, wire_values, pub_input_values, blind: Blinders, tick, pi_zero: bool = False):
+        """prover.rs:72-87: wire and public-input iNTTs, masking, W commitments.  pi_zero: the caller knows that pub_input_values is all
+        zero (no public input): round 3 then skips the public-input polynomial."""
         import time
         import types
         import torch
         n, W, ultra = self.n, self.W, self.ultra
-        st = types.SimpleNamespace(blind=blind)
+        st = types.SimpleNamespace(blind=blind, pi_zero=bool(pi_zero))
         dev = self.fixed.device
         on_dev = lambda x: torch.is_tensor(x) and x.is_cuda
         as_host = lambda x: x if torch.is_tensor(x) else torch.from_numpy(np.ascontiguousarray(x).view(np.int64))
@@ -437,7 +438,7 @@ class TurboPlonkProver:
         if self.pk.classes is None:
             plonk.compute_quotient_polynomial_dev(self.pk, ch, slab, n + 3, quot)
         else:                                                            # local classes, one exchange, 8-point iDFT per coefficient
-            local = plonk.compute_quotient_chunked_dev(self.pk, ch, slab, n + 3) if self.own_classes else None
+            local = plonk.compute_quotient_chunked_dev(self.pk, ch, slab, n + 3, pi_zero=st.pi_zero) if self.own_classes else None
             if local is None:                                            # this rank owns no class: it only takes part in the exchange
                 import torch
                 local = torch.empty((0, n, 4), dtype=torch.int64, device=slab.device)
@@ -732,8 +733,9 @@ class TurboPlonkProver:
         tick("r5_commit", t0)
         return lin, wit[0], wit[1], open_comms
 
-    def prove(self, wire_values, pub_input_values, ch, blind: Blinders, profile: bool = False) -> ProofCore:
-        """ch: ProverChallenges (fixed) or a challenge source (FixedChallenges / TranscriptChallenges)."""
+    def prove(self, wire_values, pub_input_values, ch, blind: Blinders, profile: bool = False, pi_zero: bool = False) -> ProofCore:
+        """ch: ProverChallenges (fixed) or a challenge source (FixedChallenges / TranscriptChallenges).  pi_zero: pub_input_values is all
+        zero (a circuit without public inputs)."""
         src = FixedChallenges(ch) if isinstance(ch, ProverChallenges) else ch
         import time
         import torch
@@ -745,7 +747,7 @@ class TurboPlonkProver:
                 torch.cuda.synchronize()
                 tm[name] = round((time.perf_counter() - t0) * 1e3, 3)
 
-        st, wires_comms = self._stage_round1(wire_values, pub_input_values, blind, tick)
+        st, wires_comms = self._stage_round1(wire_values, pub_input_values, blind, tick, pi_zero=pi_zero)
         tau = src.after_round1(wires_comms)
         h_comms = self._stage_round1_5(st, tau, tick)
         beta, gamma = src.after_round1_5(h_comms)

@@ -220,7 +220,7 @@ def prove(rng: _rng.ChaChaRng, circuit: BenchCircuit, pk: _prover.TurboPlonkProv
         raise ValueError("proving key domain size %d != expected domain size %d" % (pk.n, circuit.n))           # snark.rs:233-240
     blind = draw_blinders(circuit.curve, rng, circuit.num_wire_types, pk.ultra)
     src = _prover.TranscriptChallenges(pk, circuit.public_input, extra_transcript_init_msg)
-    core = pk.prove(circuit.wire_values, circuit.pub_input_values, src, blind, profile=profile)
+    core = pk.prove(circuit.wire_values, circuit.pub_input_values, src, blind, profile=profile, pi_zero=not any(circuit.public_input))
     return core, serialize_proof(circuit.curve, core)
 
 
