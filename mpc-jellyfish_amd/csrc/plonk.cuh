@@ -46,6 +46,10 @@ struct QuotientArgs {
     const uint32_t* pl;       // [m] Plookup product polynomial
     const uint32_t* inv_den_n;// [m]  w^(n-1) / (n * (x_i - w^(n-1)))
     uint32_t tau[8], alpha3[8], w_inv[8];
+    // bit j: selector j is the zero polynomial (found at registration): its gate term is neither read nor computed.  A circuit without
+    // Rescue / elliptic-curve / multiplication gates -- the reference's bench circuit is additions only -- skips 16 + 3 + 4 of the
+    // 56 products per point and 7 of the 28 operand streams.
+    uint32_t sel_zero;
 };
 
 template <class P>
@@ -88,21 +92,31 @@ __global__ __launch_bounds__(PLK_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
     for (int j = 0; j < W; j++) w[j] = ldx<X>(a.wire + ((size_t)j * os + i) * 8);
     auto sel = [&](int j) { return ldx<X>(a.sel + ((size_t)j * fs + i) * 8); };
     // ---- gate identity (prover.rs:696-708); value bounds in units of p on the right
-    F t = sel(11);                                                                     // q_c + pi                     2
+    // Every term below is optional (sel_zero, uniform over the launch); the bounds on the right are those with all of them present.
+    const uint32_t sz = a.sel_zero;
+    auto has = [&](int j) { return !((sz >> j) & 1u); };
+    F t = F::zero();                                                                   // q_c + pi                     2
+    if (has(11)) t = sel(11);
     if (a.pi) t = fx_add(t, ldx<X>(a.pi + i * 8));                                     // (null: the public-input polynomial is zero)
 #pragma unroll
-    for (int j = 0; j < 4; j++) t = fx_add(t, fx_mul(sel(j), w[j]));                  // q_lc                         6.1, limbs < 6 * 2^29
+    for (int j = 0; j < 4; j++)
+        if (has(j)) t = fx_add(t, fx_mul(sel(j), w[j]));                              // q_lc                         6.1, limbs < 6 * 2^29
     t = fx_norm(t);
-    const F w01 = fx_mul(w[0], w[1]), w23 = fx_mul(w[2], w[3]);                       // class M
-    t = fx_add(t, fx_add(fx_mul(sel(4), w01), fx_mul(sel(5), w23)));                  // q_mul                        8.2
-    t = fx_add(t, fx_mul(sel(12), fx_mul(fx_mul(w01, w23), w[4])));                   // q_ecc                        9.3, limbs < 4 * 2^29 + 8
-    t = fx_norm(t);
+    if (has(4) || has(5) || has(12)) {
+        const F w01 = fx_mul(w[0], w[1]), w23 = fx_mul(w[2], w[3]);                   // class M
+        if (has(4)) t = fx_add(t, fx_mul(sel(4), w01));                               // q_mul                        8.2
+        if (has(5)) t = fx_add(t, fx_mul(sel(5), w23));
+        if (has(12)) t = fx_add(t, fx_mul(sel(12), fx_mul(fx_mul(w01, w23), w[4])));  // q_ecc                        9.3, limbs < 4 * 2^29 + 8
+        t = fx_norm(t);
+    }
 #pragma unroll
     for (int j = 0; j < 4; j++) {                                                     // q_hash * w^5                 13.5, limbs < 5 * 2^29 + 8
+        if (!has(6 + j)) continue;
         const F w2 = fx_sqr(w[j]);
         t = fx_add(t, fx_mul(sel(6 + j), fx_mul(fx_sqr(w2), w[j])));
     }
-    t = fx_norm(fx_sub2(t, fx_mul(sel(10), w[4])));                                   // - q_o w4 (+ 2p)               15.5
+    if (has(10)) t = fx_sub2(t, fx_mul(sel(10), w[4]));                               // - q_o w4 (+ 2p)               15.5
+    t = fx_norm(t);
     // ---- copy constraints (prover.rs:741-758)
     const F alpha = arg_fx<X>(a.alpha), beta = arg_fx<X>(a.beta), gamma = arg_fx<X>(a.gamma);
     const F z_x = ldx<X>(a.z + i * 8);

@@ -22,6 +22,7 @@ struct PlonkPk {
     uint32_t* d_sigma_n = nullptr;      // [W][n] sigma_i on the gate domain H (extended permutation values)
     uint32_t* d_omega_n = nullptr;      // [n] w_n^j
     uint32_t* d_tab_n = nullptr;        // [5][n] range, key, table_dom_sep, q_dom_sep, q_lookup on H (UltraPlonk)
+    uint32_t sel_zero = 0;              // bit j: selector polynomial j is identically zero (QuotientArgs::sel_zero)
     uint32_t* d_top_fixed = nullptr;    // [W + 5][8] coefficients n-8 .. n-1 of sigma_0..W-1, q_hash_0..3, q_ecc (chunked keys: plonk_quotient_top_kernel)
     uint32_t k[PLK_MAX_WIRES][8];
     uint32_t zh_inv[PLK_RATIO][8];
@@ -292,6 +293,7 @@ void fill_quotient_constants(QuotientArgs& a, const PlonkPk& pk, const uint32_t*
     to_internal<P>(a.alpha2, a2.l);
     to_internal<P>(a.beta, beta);
     to_internal<P>(a.gamma, gamma);
+    a.sel_zero = pk.sel_zero;
     if (pk.ultra) {
         const F a3 = a2 * al;
         to_internal<P>(a.tau, tau);
@@ -635,6 +637,15 @@ int32_t plonk_pk_register(int curve, int log_n, int W, const uint32_t* sel, cons
     pk->curve = curve; pk->log_n = log_n; pk->W = W; pk->ultra = ultra; pk->nsel = PLK_SELECTORS + (ultra ? 1 : 0);
     std::memset(pk->k, 0, sizeof pk->k);
     std::memcpy(pk->k, k_mont, (size_t)W * 32);
+    {   // selectors that are the zero polynomial: their gate terms are skipped (plonk.cuh)
+        const uint64_t words = poly_len * 8;
+        for (int j = 0; j < PLK_SELECTORS; j++) {
+            const uint32_t* c = sel + (size_t)j * words;
+            bool zero = true;
+            for (uint64_t i = 0; i < words && zero; i++) zero = c[i] == 0;
+            if (zero) pk->sel_zero |= 1u << j;
+        }
+    }
     int32_t rc;
     if (classes) {
         pk->cls.assign(classes, classes + n_classes);
