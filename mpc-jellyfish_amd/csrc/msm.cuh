@@ -25,6 +25,12 @@ namespace mzk {
 
 constexpr int MSM_THREADS = 256;
 constexpr int MSM_ACC_THREADS = 128;
+// heavy buckets (msm_heavy_* below): entries one thread of a level-1 run sums / entries per level-1 run / items a run of a later
+// level may take (32 per thread before the tree) / counters per window (runs of levels 0, B, C; parts of levels 2, 3)
+constexpr uint32_t MSM_HEAVY_PER_THREAD = 16;
+constexpr uint32_t MSM_HEAVY_RUN = MSM_ACC_THREADS * MSM_HEAVY_PER_THREAD;
+constexpr uint32_t MSM_HEAVY_FANIN = MSM_ACC_THREADS * 32;
+constexpr int MSM_HEAVY_COUNTERS = 5;
 
 // window size of the plain path: ~log2(n) - 2 (mean bucket load ~8: short dependent chains, enough buckets to
 // fill the chip even for small n), clamped to [4, 16]
@@ -336,13 +342,17 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(const u
                                                                           const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ order,
                                                                           uint32_t M, int n_win, uint32_t cap, uint32_t* __restrict__ long_count,
                                                                           uint32_t* __restrict__ buckets, uint8_t* __restrict__ occ) {
-    if (blockIdx.x == 0 && threadIdx.x < (unsigned)n_win) long_count[threadIdx.x] = 0u;     // what msm_long_find_kernel counts into (saves a fill)
+    if (blockIdx.x == 0)                                       // what msm_long_find_kernel counts into: saves a fill (per window: 1 + MSM_HEAVY_COUNTERS words)
+        for (unsigned i = threadIdx.x; i < (unsigned)n_win * (1 + MSM_HEAVY_COUNTERS); i += MSM_ACC_THREADS) long_count[i] = 0u;
     const unsigned long long t0 = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
     if (t0 >= (unsigned long long)n_win * M) return;
     const unsigned long long w = t0 / M;
     const unsigned long long t = w * M + order[t0];            // lanes of a wave take buckets of equal load
     const uint32_t start = offs[t];
-    const uint32_t cnt = min(hist[t], cap);                    // the rest of an over-long bucket: msm_long_* kernels
+    // the rest of an over-long bucket: msm_long_* kernels; ALL of a heavy one: msm_heavy_* (a lone chain of `cap` additions would
+    // outlast the whole launch)
+    const uint32_t h = hist[t];
+    const uint32_t cnt = h > cap + MSM_HEAVY_RUN ? 0u : min(h, cap);
     const uint32_t* list = sorted + w * n + start;
     typename EC::Pt acc = EC::inf();
     for (uint32_t k = 0; k < cnt; k++) {
@@ -365,7 +375,8 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_split_kernel(c
                                                                                 const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ order,
                                                                                 uint32_t M, int n_win, uint32_t cap, int log_split, uint32_t* __restrict__ long_count,
                                                                                 uint32_t* __restrict__ sub) {
-    if (blockIdx.x == 0 && threadIdx.x < (unsigned)n_win) long_count[threadIdx.x] = 0u;
+    if (blockIdx.x == 0)
+        for (unsigned i = threadIdx.x; i < (unsigned)n_win * (1 + MSM_HEAVY_COUNTERS); i += MSM_ACC_THREADS) long_count[i] = 0u;
     const unsigned long long t1 = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
     const unsigned long long t0 = t1 >> log_split;
     if (t0 >= (unsigned long long)n_win * M) return;
@@ -373,7 +384,8 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_split_kernel(c
     const unsigned long long w = t0 / M;
     const unsigned long long t = w * M + order[t0];
     const uint32_t start = offs[t];
-    const uint32_t cnt = min(hist[t], cap);
+    const uint32_t h = hist[t];
+    const uint32_t cnt = h > cap + MSM_HEAVY_RUN ? 0u : min(h, cap);
     const uint32_t* list = sorted + w * n + start;
     typename EC::Pt acc = EC::inf();
     for (uint32_t k = part; k < cnt; k += S) {
@@ -451,14 +463,48 @@ struct LongDesc { uint32_t bucket, start, len, idx_in_run, run_len; };
 
 // one thread per (window, bucket): a long bucket reserves its run of descriptors with one atomic
 // (desc_count must be zeroed first); runs of different buckets land in arrival order, each contiguous
+//
+// HEAVY buckets (round 3): more than MSM_HEAVY_RUN entries beyond the cap -- all-equal scalars, the short top digit of small scalars
+// (witness VALUES are often 8 / 32 / 64-bit numbers), a handful of buckets holding most of the points.  One thread per chunk of `cap`
+// and ONE workgroup per window for the tree (below) leaves the chip idle there.  A heavy bucket's remainder is cut into level-1 runs of
+// MSM_HEAVY_RUN entries (ALL of them: the regular accumulation skips a heavy bucket -- a lone chain of `cap` dependent additions
+// would outlast the launch): a workgroup per run, MSM_HEAVY_PER_THREAD mixed adds per thread (msm_heavy_chunk_kernel), then workgroup
+// trees over the 128 partial sums of a run and over the runs of a bucket (msm_heavy_reduce_kernel, levels A, B, C: up to
+// MSM_HEAVY_FANIN items each), the last of which adds into the bucket.  dest: bit 31 set = slot of the next level's parts.
+struct HeavyRun { uint32_t src, n, dest; };
+constexpr uint32_t MSM_HEAVY_DEST_PART = 0x80000000u;
+// counters of window w at heavy_count + w * MSM_HEAVY_COUNTERS: [0] level-1 runs, [1] level-B runs, [2] level-C runs, [3] parts of level 2, [4] of level 3
+__device__ __forceinline__ void msm_heavy_push(uint32_t b, uint32_t start, uint32_t rem, uint32_t run_cap, uint32_t* __restrict__ cnt,
+                                               HeavyRun* __restrict__ runs0, HeavyRun* __restrict__ runsB, HeavyRun* __restrict__ runsC) {
+    const uint32_t n1 = (rem + MSM_HEAVY_RUN - 1) / MSM_HEAVY_RUN;
+    const uint32_t r0 = atomicAdd(&cnt[0], n1);
+    if (r0 + n1 > run_cap) return;                                     // cannot happen: run_cap >= 2 * entries / MSM_HEAVY_RUN + 2
+    if (n1 == 1) { runs0[r0] = HeavyRun{start, rem, b}; return; }
+    const uint32_t p2 = atomicAdd(&cnt[3], n1);
+    for (uint32_t i = 0; i < n1; i++)
+        runs0[r0 + i] = HeavyRun{start + i * MSM_HEAVY_RUN, min(MSM_HEAVY_RUN, rem - i * MSM_HEAVY_RUN), MSM_HEAVY_DEST_PART | (p2 + i)};
+    const uint32_t n2 = (n1 + MSM_HEAVY_FANIN - 1) / MSM_HEAVY_FANIN;
+    const uint32_t rb = atomicAdd(&cnt[1], n2);
+    if (n2 == 1) { runsB[rb] = HeavyRun{p2, n1, b}; return; }
+    const uint32_t p3 = atomicAdd(&cnt[4], n2);
+    for (uint32_t j = 0; j < n2; j++)
+        runsB[rb + j] = HeavyRun{p2 + j * MSM_HEAVY_FANIN, min(MSM_HEAVY_FANIN, n1 - j * MSM_HEAVY_FANIN), MSM_HEAVY_DEST_PART | (p3 + j)};
+    runsC[atomicAdd(&cnt[2], 1u)] = HeavyRun{p3, n2, b};
+}
+
 __global__ __launch_bounds__(256) void msm_long_find_kernel(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs, uint32_t M, int n_win,
                                                             uint32_t cap, uint32_t desc_cap, LongDesc* __restrict__ desc,
-                                                            uint32_t* __restrict__ desc_count) {
+                                                            uint32_t* __restrict__ desc_count, uint32_t run_cap, HeavyRun* __restrict__ heavy_runs) {
     const unsigned long long t = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (unsigned long long)n_win * M) return;
     const uint32_t c = hist[t];
     if (c <= cap) return;
     const uint32_t w = (uint32_t)(t / M), b = (uint32_t)(t % M);
+    if (c - cap > MSM_HEAVY_RUN) {                                     // heavy: its own kernels take ALL its entries
+        HeavyRun* base = heavy_runs + (size_t)w * 3 * run_cap;
+        msm_heavy_push(b, offs[t], c, run_cap, desc_count + n_win + (size_t)w * MSM_HEAVY_COUNTERS, base, base + run_cap, base + 2 * (size_t)run_cap);
+        return;
+    }
     const uint32_t nch = (c - cap + cap - 1) / cap;
     const uint32_t pos = atomicAdd(&desc_count[w], nch);
     for (uint32_t j = 0; j < nch; j++) {
@@ -492,45 +538,98 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_long_chunk_kernel(const u
     EC::store_pt(parts, (size_t)w * desc_cap + i, acc);
 }
 
-// one 1024-thread workgroup per window: pairwise tree over each bucket's run of chunk sums, then
-// bucket += run total.  Chunk sums live in global memory; a workgroup barrier plus a workgroup-scope
-// fence orders the passes (all traffic stays on one CU).
+// one thread per long bucket: its run of chunk sums (at most MSM_HEAVY_RUN / cap + 1 of them: longer buckets are heavy, see above) is added
+// to the bucket one after the other -- chains of a few additions, in parallel over the runs.  (Until round 3 ONE workgroup per window
+// walked a pairwise tree over all runs: 3 - 30 ms once tens of thousands of buckets were over-long.)  ONE call site of EC::add.
 template <class EC>
-__global__ __launch_bounds__(1024) void msm_long_combine_kernel(const LongDesc* __restrict__ desc, const uint32_t* __restrict__ desc_count,
-                                                                uint32_t desc_cap, uint32_t M, uint32_t* __restrict__ parts,
-                                                                uint32_t* __restrict__ buckets, uint8_t* __restrict__ occ) {
-    const uint32_t w = blockIdx.x, t = threadIdx.x;
+__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_long_combine_kernel(const LongDesc* __restrict__ desc, const uint32_t* __restrict__ desc_count,
+                                                                            uint32_t desc_cap, uint32_t M, const uint32_t* __restrict__ parts,
+                                                                            uint32_t* __restrict__ buckets, uint8_t* __restrict__ occ) {
+    const uint32_t w = blockIdx.y;
     const uint32_t cnt = min(desc_count[w], desc_cap);
-    if (cnt == 0) return;
     const LongDesc* dw = desc + (size_t)w * desc_cap;
     const size_t pbase = (size_t)w * desc_cap;
-    // the tree is as deep as the longest run
-    __shared__ uint32_t max_run;
-    if (t == 0) max_run = 0;
-    __syncthreads();
-    uint32_t mine = 0;
-    for (uint32_t i = t; i < cnt; i += 1024) mine = max(mine, dw[i].run_len);
-    if (mine) atomicMax(&max_run, mine);
-    __syncthreads();
-    const uint32_t longest = max_run;
-    for (uint32_t s = 1; s < longest; s <<= 1) {
-        for (uint32_t i = t; i < cnt; i += 1024) {
-            const LongDesc d = dw[i];
-            if ((d.idx_in_run & (2 * s - 1)) == 0 && d.idx_in_run + s < d.run_len) {
-                typename EC::Pt a = EC::load_pt(parts, pbase + i), b = EC::load_pt(parts, pbase + i + s);
-                EC::store_pt(parts, pbase + i, EC::add(a, b));
-            }
-        }
-        __threadfence_block();
-        __syncthreads();
-    }
-    for (uint32_t i = t; i < cnt; i += 1024) {
+    for (uint32_t i = blockIdx.x * MSM_ACC_THREADS + threadIdx.x; i < cnt; i += gridDim.x * MSM_ACC_THREADS) {
         const LongDesc d = dw[i];
-        if (d.idx_in_run == 0) {
-            const size_t bi = (size_t)w * M + d.bucket;
-            typename EC::Pt a = occ[bi] ? EC::load_pt(buckets, bi) : EC::inf(), b = EC::load_pt(parts, pbase + i);      // (the first `cap` points may sum to infinity)
-            EC::store_pt(buckets, bi, EC::add(a, b));
-            occ[bi] = 1;
+        if (d.idx_in_run != 0) continue;
+        const size_t bi = (size_t)w * M + d.bucket;
+        typename EC::Pt acc = occ[bi] ? EC::load_pt(buckets, bi) : EC::inf();       // (the first `cap` points may sum to infinity)
+        for (uint32_t j = 0; j < d.run_len; j++) acc = EC::add(acc, EC::load_pt(parts, pbase + i + j));
+        const bool empty = acc.is_inf();
+        occ[bi] = empty ? 0 : 1;
+        if (!empty) EC::store_pt(buckets, bi, acc);
+    }
+}
+
+// level 1 of a heavy bucket: one workgroup per run of <= MSM_HEAVY_RUN entries, thread t sums entries [32 t, 32 t + 32) -> h1[run * 128 + t]
+template <class EC>
+__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_heavy_chunk_kernel(const uint32_t* __restrict__ bases, unsigned long long n, const uint32_t* __restrict__ sorted,
+                                                                           const HeavyRun* __restrict__ heavy_runs, const uint32_t* __restrict__ heavy_count,
+                                                                           uint32_t run_cap, uint32_t* __restrict__ h1) {
+    const uint32_t w = blockIdx.y, t = threadIdx.x;
+    const uint32_t cnt = min(heavy_count[(size_t)w * MSM_HEAVY_COUNTERS], run_cap);
+    const HeavyRun* runs = heavy_runs + (size_t)w * 3 * run_cap;
+    for (uint32_t r = blockIdx.x; r < cnt; r += gridDim.x) {
+        const HeavyRun run = runs[r];
+        const uint32_t lo = t * MSM_HEAVY_PER_THREAD;
+        if (lo >= run.n) continue;
+        const uint32_t hi = min(run.n, lo + MSM_HEAVY_PER_THREAD);
+        const uint32_t* list = sorted + (size_t)w * n + run.src;
+        typename EC::Pt acc = EC::inf();
+        for (uint32_t k = lo; k < hi; k++) {
+            const uint32_t e = list[k];
+            acc = EC::madd(acc, EC::load_aff(bases, e & 0x7fffffffu), (e >> 31) != 0);
+        }
+        EC::store_pt(h1, ((size_t)w * run_cap + r) * MSM_ACC_THREADS + t, acc);
+    }
+}
+// levels A (the 128 partial sums of a level-1 run), B and C (the runs of a bucket): a workgroup per run; a thread first sums the items
+// t, t + 128, .. of the run, then the 128 sums go through an LDS tree; the last level of a bucket stores into it (the regular
+// accumulation leaves a heavy bucket empty).  ONE call site of EC::add (see msm_split_combine_kernel).
+template <class EC>
+__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_heavy_reduce_kernel(const HeavyRun* __restrict__ heavy_runs, const uint32_t* __restrict__ heavy_count,
+                                                                            uint32_t run_cap, int level /* 0 = A, 1 = B, 2 = C */,
+                                                                            const uint32_t* __restrict__ parts_in, uint32_t* __restrict__ parts_out, uint32_t M,
+                                                                            uint32_t* __restrict__ buckets, uint8_t* __restrict__ occ) {
+    __shared__ uint32_t lds[MSM_ACC_THREADS * EC::PT_WORDS];
+    const uint32_t w = blockIdx.y;
+    const int tid = threadIdx.x;
+    const uint32_t cnt = min(heavy_count[(size_t)w * MSM_HEAVY_COUNTERS + level], run_cap);
+    const HeavyRun* runs = heavy_runs + ((size_t)w * 3 + level) * run_cap;
+    const size_t in_base = (size_t)w * run_cap * (level == 0 ? MSM_ACC_THREADS : 1), out_base = (size_t)w * run_cap;
+    for (uint32_t r = blockIdx.x; r < cnt; r += gridDim.x) {
+        const HeavyRun run = runs[r];
+        const uint32_t n_items = level == 0 ? (run.n + MSM_HEAVY_PER_THREAD - 1) / MSM_HEAVY_PER_THREAD : run.n;
+        const size_t src = in_base + (level == 0 ? (size_t)r * MSM_ACC_THREADS : (size_t)run.src);
+        const int per = (int)((n_items + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS);          // items per thread (uniform bound)
+        typename EC::Pt acc = (uint32_t)tid < n_items ? EC::load_pt(parts_in, src + tid) : EC::inf();
+        const bool to_bucket = !(run.dest & MSM_HEAVY_DEST_PART);
+        const size_t bi = (size_t)w * M + run.dest;
+        const int n_steps = (per - 1) + 7;
+#pragma unroll 1
+        for (int s = 0; s < n_steps; s++) {
+            typename EC::Pt a = EC::inf(), b = EC::inf();
+            bool act = false;
+            if (s < per - 1) {                                         // the thread's own items, one after the other
+                const uint32_t q = (uint32_t)tid + (uint32_t)(s + 1) * MSM_ACC_THREADS;
+                if (q < n_items) { a = acc; b = EC::load_pt(parts_in, src + q); act = true; }
+            } else {                                                   // tree level l: thread t < 64 >> l adds the sums of threads 2t and 2t + 1
+                const int l = s - (per - 1);
+                __syncthreads();
+                if (tid < (MSM_ACC_THREADS >> l)) pt_lds_put<EC>(lds, tid, acc);
+                __syncthreads();
+                if (tid < (MSM_ACC_THREADS >> (l + 1))) { a = pt_lds_get<EC>(lds, 2 * tid); b = pt_lds_get<EC>(lds, 2 * tid + 1); act = true; }
+            }
+            if (act) acc = EC::add(a, b);
+        }
+        if (tid == 0) {
+            if (to_bucket) {
+                const bool empty = acc.is_inf();
+                occ[bi] = empty ? 0 : 1;
+                if (!empty) EC::store_pt(buckets, bi, acc);
+            } else {
+                EC::store_pt(parts_out, out_base + (run.dest & ~MSM_HEAVY_DEST_PART), acc);
+            }
         }
     }
 }

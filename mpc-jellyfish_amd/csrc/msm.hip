@@ -112,8 +112,12 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     MZK_TRY(g_ws.offs.reserve(nb * wm * 4));
     MZK_TRY(g_ws.cursor.reserve(nb * wm * 4));                           // bucket order by load
     const uint32_t desc_cap_max = (uint32_t)(sorted_max / MSM_MIN_CAP + 1);          // cap >= MSM_MIN_CAP below
-    MZK_TRY(g_ws.long_desc.reserve((size_t)n_win * desc_cap_max * sizeof(LongDesc) + (size_t)n_win * 4));
-    MZK_TRY(g_ws.long_parts.reserve((size_t)n_win * desc_cap_max * EC::PT_WORDS * 4));
+    // heavy buckets (msm.cuh): per window <= entries / MSM_HEAVY_RUN full level-1 runs plus one partial run per heavy bucket
+    const uint32_t run_cap_max = (uint32_t)(2 * (sorted_max / MSM_HEAVY_RUN) + 2);
+    const size_t heavy_runs_bytes = (size_t)n_win * 3 * run_cap_max * sizeof(HeavyRun);
+    MZK_TRY(g_ws.long_desc.reserve((size_t)n_win * desc_cap_max * sizeof(LongDesc) + (size_t)n_win * 4 * (1 + MSM_HEAVY_COUNTERS) + 16 + heavy_runs_bytes));
+    MZK_TRY(g_ws.long_parts.reserve((size_t)n_win * desc_cap_max * EC::PT_WORDS * 4 +
+                                    (size_t)n_win * run_cap_max * (MSM_ACC_THREADS + 2) * EC::PT_WORDS * 4));
     const unsigned long long dstride_max = (n_max + 7) & ~7ull;
     const size_t digits_bytes = (size_t)n_dig * dstride_max * ((pre.c || sort2) ? 4 : 2), sorted_words = ((size_t)n_dig * n_max + 3) & ~(size_t)3;
     MZK_TRY(g_ws.digits.reserve(nb * digits_bytes));
@@ -198,7 +202,13 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
             }
             const uint32_t cap = (uint32_t)std::max<unsigned long long>(MSM_MIN_CAP, peak + 6 * (unsigned long long)std::sqrt((double)peak) + 8);
             const uint32_t desc_cap = (uint32_t)(n_sorted / cap + 1);
-            uint32_t* desc_count = reinterpret_cast<uint32_t*>(desc + (size_t)n_win * desc_cap);
+            uint32_t* desc_count = reinterpret_cast<uint32_t*>(desc + (size_t)n_win * desc_cap);       // n_win words, then the heavy counters
+            const uint32_t* heavy_count = desc_count + n_win;
+            const uint32_t run_cap = (uint32_t)(2 * (n_sorted / MSM_HEAVY_RUN) + 2);
+            HeavyRun* heavy_runs = reinterpret_cast<HeavyRun*>(desc_count + (((size_t)n_win * (1 + MSM_HEAVY_COUNTERS) + 3) & ~(size_t)3));
+            uint32_t* h1 = parts + (size_t)n_win * desc_cap * EC::PT_WORDS;                          // level-1 sums: 128 per run
+            uint32_t* h2 = h1 + (size_t)n_win * run_cap * MSM_ACC_THREADS * EC::PT_WORDS;             // one per level-1 run
+            uint32_t* h3 = h2 + (size_t)n_win * run_cap * EC::PT_WORDS;                               // one per level-B run
             const unsigned long long dstride = (n + 7) & ~7ull;
             const unsigned gs = (unsigned)((n + MSM_THREADS - 1) / MSM_THREADS);
             if (overlap && (size_t)p >= nb) HIP_TRY(hipStreamWaitEvent(sst, ss.ev_acc[b], 0));     // MSM p - nb has read this set
@@ -277,10 +287,20 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
             {
                 // over-long buckets (skewed scalars); no-ops for uniformly random scalars
                 ProfScope ps("msm_long", st);
-                hipLaunchKernelGGL(msm_long_find_kernel, dim3((unsigned)((wm + 255) / 256)), dim3(256), 0, st, hist, offs, M, n_win, cap, desc_cap, desc, desc_count);
+                hipLaunchKernelGGL(msm_long_find_kernel, dim3((unsigned)((wm + 255) / 256)), dim3(256), 0, st, hist, offs, M, n_win, cap, desc_cap, desc, desc_count,
+                                   run_cap, heavy_runs);
                 hipLaunchKernelGGL((msm_long_chunk_kernel<EC>), dim3((desc_cap + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, n_win), dim3(MSM_ACC_THREADS), 0, st,
                                    d_bases, list_stride, sorted, desc, desc_count, desc_cap, parts);
-                hipLaunchKernelGGL((msm_long_combine_kernel<EC>), dim3(n_win), dim3(1024), 0, st, desc, desc_count, desc_cap, M, parts, buckets, occ);
+                hipLaunchKernelGGL((msm_long_combine_kernel<EC>), dim3(std::min<uint32_t>((desc_cap + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, 1024u), n_win),
+                                   dim3(MSM_ACC_THREADS), 0, st, desc, desc_count, desc_cap, M, parts, buckets, occ);
+                // heavy buckets: a workgroup per run of MSM_HEAVY_RUN entries, then workgroup trees (levels A, B; C only when a bucket can hold
+                // more than MSM_HEAVY_RUN * MSM_HEAVY_FANIN entries).  Every workgroup exits at once when there is no heavy bucket.
+                const dim3 hg(std::min<uint32_t>(run_cap, 2048u), n_win);
+                hipLaunchKernelGGL((msm_heavy_chunk_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, d_bases, list_stride, sorted, heavy_runs, heavy_count, run_cap, h1);
+                hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, heavy_runs, heavy_count, run_cap, 0, h1, h2, M, buckets, occ);
+                hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, heavy_runs, heavy_count, run_cap, 1, h2, h3, M, buckets, occ);
+                if (n_sorted > (uint64_t)MSM_HEAVY_RUN * MSM_HEAVY_FANIN)
+                    hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), dim3(64, n_win), dim3(MSM_ACC_THREADS), 0, st, heavy_runs, heavy_count, run_cap, 2, h3, h3, M, buckets, occ);
             }
             if (overlap) HIP_TRY(hipEventRecord(ss.ev_acc[b], st));
         }

@@ -174,6 +174,42 @@ def test_msm_full_size_trapdoor(gpu, mj, cref, curve_id, log_n):
     pp.release()
 
 
+@pytest.mark.parametrize("mode", ["one_bucket", "u8", "booleans", "iota", "repeats"])
+def test_msm_heavy_buckets_full_size_trapdoor(gpu, mj, cref, mode):
+    """Scalar distributions that put most of 2^20 x 13 digits into a handful of buckets -- what witness VALUES look like (small
+    numbers, flags, counters) -- against the trapdoor identity commit(p) = [p(beta)]G.  They take the msm_heavy_* kernels (workgroup
+    per run of a heavy bucket, workgroup trees over the runs; `one_bucket` -- every scalar equal to d (1 + 2^20 + 2^40 + ..), all 13
+    digits of all scalars in ONE bucket -- needs all three tree levels) and the per-run msm_long_combine_kernel (`repeats`)."""
+    import time
+    import torch
+    curve_id, n = 0, 1 << 20
+    c = mj.params.CURVES[curve_id]
+    beta = 0x2b3c4d5e6f708192a3b4c5d6e7f8091a2b3c4d5e6f708192a3b4c5d6e7f80912 % c.r
+    pp = mj.UnivariateProverParam.gen_srs_for_testing(curve_id, beta, n - 1)
+    rng = np.random.default_rng(99)
+    if mode == "one_bucket":
+        d = 0x2f0f1
+        vals = np.repeat(_bigints([sum(d << (20 * i) for i in range(12)) + (5 << 240)]), n, axis=0)
+    elif mode == "repeats":
+        few = [int.from_bytes(rng.bytes(32), "little") % c.r for _ in range(4096)]
+        vals = np.tile(_bigints(few), (n // 4096, 1))
+    else:
+        vals = np.zeros((n, 4), dtype=np.uint64)
+        vals[:, 0] = {"u8": rng.integers(0, 256, n), "booleans": rng.integers(0, 2, n), "iota": np.arange(n)}[mode].astype(np.uint64)
+    mont = cref.fr_convert(curve_id, vals, True)                          # canonical -> Montgomery
+    t = torch.from_numpy(vals.view(np.int64)).cuda()
+    mj.msm_bigint(pp, t)                                                  # (builds the table)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    jac = mj.msm_bigint(pp, t)
+    ms = (time.perf_counter() - t0) * 1e3
+    p_beta = cref.poly_eval(curve_id, mont, mj.params.fr_to_mont(c, [beta])[0])
+    k = mj.params.limbs_to_int(cref.fr_convert(curve_id, p_beta.reshape(1, 4), False)[0])
+    assert np.array_equal(cref.jac_to_affine(curve_id, jac)[0], cref.g1_mul_gen(curve_id, k))
+    assert ms < 40.0, "heavy-bucket MSM fell off a performance cliff: %.1f ms" % ms
+    pp.release()
+
+
 def test_msm_batch_fused(gpu, mj, cref):
     """mzk_msm_batch / mzk_msm_batch_dev: MSMs of different lengths (two window sizes, an empty one)
     in one call equal the single calls and the oracle."""
