@@ -138,7 +138,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     const size_t cnt_words = 2048 + (size_t)n_win * 1024;                // bin totals, bin cursors, order keys
     MZK_TRY(g_ws.pre_cnt.reserve(nb * cnt_words * 4));
     if (pre.c || sort2) {
-        MZK_TRY(g_ws.pre_off.reserve(nb * 2048 * 4));
+        MZK_TRY(g_ws.pre_off.reserve(nb * 8192 * 4));                      // bin_start [n_bins + 1 <= 1025], then the huge-bin words (msm_pre.cuh)
         MZK_TRY(g_ws.pre_ce.reserve(nb * sorted_words * 8));
     }
     MZK_TRY(g_ws.buckets.reserve((size_t)count * wm * EC::PT_WORDS * 4));
@@ -224,7 +224,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 ProfScope ps("msm_sort", sst);
                 uint32_t* dig32 = reinterpret_cast<uint32_t*>(g_ws.digits.as<char>() + b * digits_bytes);
                 uint32_t* cnt = g_ws.pre_cnt.as<uint32_t>() + b * cnt_words;
-                uint32_t* coff = g_ws.pre_off.as<uint32_t>() + b * 2048;
+                uint32_t* coff = g_ws.pre_off.as<uint32_t>() + b * 8192;
                 unsigned long long* coarse = g_ws.pre_ce.as<unsigned long long>() + b * sorted_words;
                 const uint32_t n_chunks = (uint32_t)((n + PRE_CHUNK - 1) / PRE_CHUNK);
                 uint32_t* bin_total = cnt;                       // [n_bins]
@@ -234,10 +234,20 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 hipLaunchKernelGGL((pre_digits_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, sst, d_scalars, n, is_mont, c, n_dig, dig32, dstride);
                 HIP_TRY(hipMemsetAsync(cnt, 0, cnt_words * 4, sst));              // bin totals and, further down, the order keys: one fill
                 hipLaunchKernelGGL(pre_coarse_count_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, sst, dig32, n, dstride, n_dig, (int)n_bins, pb, bstride, bin_total);
-                hipLaunchKernelGGL(pre_bin_scan_kernel, dim3(1), dim3(1024), 0, sst, bin_total, (int)n_bins, bin_start, bin_cursor);
+                // a bin with more than PRE_HUGE entries (skewed scalars) is sorted by the pre_huge_* kernels in slices of `slice` records
+                uint32_t* huge = coff + 1088;
+                const uint64_t records = n * (uint64_t)n_dig;             // what the coarse level holds (both paths)
+                const uint32_t slice = (uint32_t)std::max<uint64_t>(16384, (records + 2047) / 2048);
+                const uint32_t slice_grid = (uint32_t)std::min<uint64_t>(PRE_SLICE_CAP, records / slice + PRE_HUGE_MAX + 1);
+                const uint32_t huge_grid = (uint32_t)std::min<uint64_t>(PRE_HUGE_MAX, records / PRE_HUGE + 1);
+                hipLaunchKernelGGL(pre_bin_scan_kernel, dim3(1), dim3(1024), 0, sst, bin_total, (int)n_bins, bin_start, bin_cursor, slice, huge);
                 hipLaunchKernelGGL(pre_coarse_scatter_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, sst, dig32, n, dstride, n_dig, (int)n_bins, pb, bstride,
                                    pre.c ? pre.tab_stride : 0ull, pre.c ? items[p].base_off : 0ull, bin_cursor, coarse);
-                hipLaunchKernelGGL(pre_fine_kernel, dim3(n_bins), dim3(1024), 0, sst, bin_start, coarse, (uint32_t)wm, pb, hist, offs, sorted);
+                hipLaunchKernelGGL(pre_fine_kernel, dim3(n_bins), dim3(1024), 0, sst, bin_start, coarse, (uint32_t)wm, pb, hist, offs, sorted, huge);
+                hipLaunchKernelGGL(pre_huge_zero_kernel, dim3(huge_grid), dim3(1024), 0, sst, huge, (uint32_t)wm, pb, hist);
+                hipLaunchKernelGGL(pre_huge_count_kernel, dim3(slice_grid), dim3(1024), 0, sst, huge, bin_start, coarse, (uint32_t)wm, pb, slice, hist);
+                hipLaunchKernelGGL(pre_huge_scan_kernel, dim3(huge_grid), dim3(1024), 0, sst, huge, bin_start, (uint32_t)wm, pb, hist, offs, order);
+                hipLaunchKernelGGL(pre_huge_scatter_kernel, dim3(slice_grid), dim3(1024), 0, sst, huge, bin_start, coarse, (uint32_t)wm, pb, slice, order, sorted);
             }
             {
                 // buckets ranked by load within each bucket set

@@ -76,12 +76,22 @@ __global__ __launch_bounds__(PRE_CTHREADS) void pre_coarse_count_kernel(const ui
         if (bins[j]) atomicAdd(&bin_total[j], bins[j]);
 }
 
+// Bins of the fine level are sized for the expected load (PreBins).  Skewed scalars can put most entries into one bin -- small witness
+// values leave every digit of a level below 2^12, flags put them into ONE bucket -- and pre_fine_kernel, one workgroup per bin that
+// re-reads the bin once per staged run, then takes milliseconds (8 ms for 2^20 8-bit scalars).  A bin with more than PRE_HUGE entries is
+// HUGE: pre_fine skips it and pre_huge_{count,scan,scatter} sort it with as many workgroups as it has slices of `slice` records
+// (LDS histogram per slice, one global atomic per slice and non-empty bucket).  No huge bin (uniform scalars): three empty launches.
+constexpr uint32_t PRE_HUGE = 131072;
+constexpr int PRE_HUGE_MAX = 128;             // huge bins per sort (more: the rest stays with pre_fine_kernel -- slow, still correct)
+constexpr int PRE_SLICE_CAP = 2816;           // slice descriptors per sort
+// layout of the per-sort words at `huge` (after bin_start in the pre_off block): [0] huge bins, [1] slices, [2 ..] bins, [256 ..] slices (bin << 16 | j)
 __global__ __launch_bounds__(1024) void pre_bin_scan_kernel(const uint32_t* __restrict__ bin_total, int n_bins, uint32_t* __restrict__ bin_start,
-                                                            uint32_t* __restrict__ bin_cursor) {
+                                                            uint32_t* __restrict__ bin_cursor, uint32_t slice, uint32_t* __restrict__ huge) {
     __shared__ uint32_t part[1024];
     const int t = threadIdx.x;
     const uint32_t mine = t < n_bins ? bin_total[t] : 0u;
     part[t] = mine;
+    if (t < 2) huge[t] = 0u;
     __syncthreads();
     for (int d = 1; d < 1024; d <<= 1) {
         uint32_t v = t >= d ? part[t - d] : 0;
@@ -91,6 +101,94 @@ __global__ __launch_bounds__(1024) void pre_bin_scan_kernel(const uint32_t* __re
     }
     if (t < n_bins) { bin_start[t] = part[t] - mine; bin_cursor[t] = part[t] - mine; }
     if (t == n_bins - 1) bin_start[n_bins] = part[t];                 // total
+    if (mine > PRE_HUGE) {
+        const uint32_t h = atomicAdd(&huge[0], 1u);
+        if (h < (uint32_t)PRE_HUGE_MAX) {
+            const uint32_t ns = (mine + slice - 1) / slice;
+            const uint32_t sb = atomicAdd(&huge[1], ns);
+            huge[2 + h] = (uint32_t)t;
+            for (uint32_t j = 0; j < ns && sb + j < (uint32_t)PRE_SLICE_CAP; j++) huge[256 + sb + j] = ((uint32_t)t << 16) | j;
+        }
+    }
+}
+// is `bin` one of the (at most PRE_HUGE_MAX) registered huge bins?  (a bin beyond the cap stays with pre_fine_kernel)
+__device__ __forceinline__ bool pre_is_huge(const uint32_t* __restrict__ huge, uint32_t bin) {
+    const uint32_t nh = min(huge[0], (uint32_t)PRE_HUGE_MAX);
+    for (uint32_t h = 0; h < nh; h++)
+        if (huge[2 + h] == bin) return true;
+    return false;
+}
+// one workgroup per slice of a huge bin: bucket histogram of the slice -> hist (zeroed by pre_huge_zero_kernel)
+__global__ __launch_bounds__(1024) void pre_huge_zero_kernel(const uint32_t* __restrict__ huge, uint32_t M, PreBins pb, uint32_t* __restrict__ hist) {
+    const uint32_t h = blockIdx.x;
+    if (h >= min(huge[0], (uint32_t)PRE_HUGE_MAX)) return;
+    const uint32_t bin = huge[2 + h], rsize = pb.size_of(bin, M), bucket0 = pb.first_bucket(bin);
+    for (uint32_t j = threadIdx.x; j < rsize; j += 1024) hist[bucket0 + j] = 0u;
+}
+__global__ __launch_bounds__(1024) void pre_huge_count_kernel(const uint32_t* __restrict__ huge, const uint32_t* __restrict__ bin_start,
+                                                              const unsigned long long* __restrict__ coarse, uint32_t M, PreBins pb, uint32_t slice,
+                                                              uint32_t* __restrict__ hist) {
+    __shared__ uint32_t bins[1 << PRE_FINE_LOG];
+    const uint32_t s = blockIdx.x, tid = threadIdx.x;
+    if (s >= min(huge[1], (uint32_t)PRE_SLICE_CAP)) return;
+    const uint32_t desc = huge[256 + s], bin = desc >> 16, j = desc & 0xFFFFu;
+    const uint32_t rsize = pb.size_of(bin, M), bucket0 = pb.first_bucket(bin);
+    const uint32_t start = bin_start[bin] + j * slice, end = min(bin_start[bin + 1], start + slice);
+    for (uint32_t q = tid; q < rsize; q += 1024) bins[q] = 0u;
+    __syncthreads();
+    for (uint32_t k = start + tid; k < end; k += 1024) atomicAdd(&bins[(uint32_t)(coarse[k] >> 32)], 1u);
+    __syncthreads();
+    for (uint32_t q = tid; q < rsize; q += 1024)
+        if (bins[q]) atomicAdd(&hist[bucket0 + q], bins[q]);
+}
+// one workgroup per huge bin: offs = bin start + exclusive scan of hist; cursor = offs (what pre_huge_scatter reserves from)
+__global__ __launch_bounds__(1024) void pre_huge_scan_kernel(const uint32_t* __restrict__ huge, const uint32_t* __restrict__ bin_start, uint32_t M, PreBins pb,
+                                                             const uint32_t* __restrict__ hist, uint32_t* __restrict__ offs, uint32_t* __restrict__ cursor) {
+    __shared__ uint32_t part[1024];
+    const uint32_t h = blockIdx.x, tid = threadIdx.x;
+    if (h >= min(huge[0], (uint32_t)PRE_HUGE_MAX)) return;
+    const uint32_t bin = huge[2 + h], rsize = pb.size_of(bin, M), bucket0 = pb.first_bucket(bin), start = bin_start[bin];
+    const uint32_t per = (rsize + 1023) / 1024;
+    uint32_t sum = 0;
+    for (uint32_t j = tid * per; j < min(rsize, (tid + 1) * per); j++) sum += hist[bucket0 + j];
+    part[tid] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        uint32_t v = tid >= (uint32_t)d ? part[tid - d] : 0;
+        __syncthreads();
+        part[tid] += v;
+        __syncthreads();
+    }
+    uint32_t run = start + part[tid] - sum;
+    for (uint32_t j = tid * per; j < min(rsize, (tid + 1) * per); j++) {
+        offs[bucket0 + j] = run;
+        cursor[bucket0 + j] = run;
+        run += hist[bucket0 + j];
+    }
+}
+// one workgroup per slice: counts again, reserves its range of every bucket with one global atomic, writes the entries
+__global__ __launch_bounds__(1024) void pre_huge_scatter_kernel(const uint32_t* __restrict__ huge, const uint32_t* __restrict__ bin_start,
+                                                                const unsigned long long* __restrict__ coarse, uint32_t M, PreBins pb, uint32_t slice,
+                                                                uint32_t* __restrict__ cursor, uint32_t* __restrict__ sorted) {
+    __shared__ uint32_t bins[1 << PRE_FINE_LOG];
+    const uint32_t s = blockIdx.x, tid = threadIdx.x;
+    if (s >= min(huge[1], (uint32_t)PRE_SLICE_CAP)) return;
+    const uint32_t desc = huge[256 + s], bin = desc >> 16, j = desc & 0xFFFFu;
+    const uint32_t rsize = pb.size_of(bin, M), bucket0 = pb.first_bucket(bin);
+    const uint32_t start = bin_start[bin] + j * slice, end = min(bin_start[bin + 1], start + slice);
+    for (uint32_t q = tid; q < rsize; q += 1024) bins[q] = 0u;
+    __syncthreads();
+    for (uint32_t k = start + tid; k < end; k += 1024) atomicAdd(&bins[(uint32_t)(coarse[k] >> 32)], 1u);
+    __syncthreads();
+    for (uint32_t q = tid; q < rsize; q += 1024) {
+        const uint32_t c = bins[q];
+        bins[q] = c ? atomicAdd(&cursor[bucket0 + q], c) : 0u;          // this slice's range of bucket q starts here (absolute index)
+    }
+    __syncthreads();
+    for (uint32_t k = start + tid; k < end; k += 1024) {
+        const unsigned long long r = coarse[k];
+        sorted[atomicAdd(&bins[(uint32_t)(r >> 32)], 1u)] = (uint32_t)r;
+    }
 }
 
 __global__ __launch_bounds__(PRE_CTHREADS) void pre_coarse_scatter_kernel(const uint32_t* __restrict__ digits, unsigned long long n, unsigned long long stride,
@@ -145,7 +243,7 @@ constexpr uint32_t PRE_STAGE = 24576;        // entries staged per run (96 KiB)
 
 __global__ __launch_bounds__(1024) void pre_fine_kernel(const uint32_t* __restrict__ bin_start, const unsigned long long* __restrict__ coarse,
                                                         uint32_t M, PreBins pb, uint32_t* __restrict__ hist, uint32_t* __restrict__ offs,
-                                                        uint32_t* __restrict__ sorted) {
+                                                        uint32_t* __restrict__ sorted, const uint32_t* __restrict__ huge) {
     __shared__ uint32_t bins[1 << PRE_FINE_LOG];          // counts, then scatter cursors (relative to the bin)
     __shared__ uint32_t loc[(1 << PRE_FINE_LOG) + 1];     // exclusive offsets of the buckets inside the bin
     __shared__ uint32_t part[1024];
@@ -154,6 +252,7 @@ __global__ __launch_bounds__(1024) void pre_fine_kernel(const uint32_t* __restri
     const uint32_t bin = blockIdx.x, tid = threadIdx.x;
     const uint32_t rsize = pb.size_of(bin, M), bucket0 = pb.first_bucket(bin);
     const uint32_t start = bin_start[bin], end = bin_start[bin + 1];
+    if (end - start > PRE_HUGE && pre_is_huge(huge, bin)) return;       // (uniform over the workgroup) sorted by pre_huge_* kernels
     for (uint32_t j = tid; j < rsize; j += 1024) bins[j] = 0;
     __syncthreads();
     for (uint32_t k = start + tid; k < end; k += 4096) {
