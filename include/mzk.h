@@ -91,6 +91,16 @@ MZK_API int32_t mzk_srs_generate_for_testing(int32_t curve_id, const uint64_t* b
  * h = G2::rand from the same rng: a host that mirrors those draws passes its g here.  g_xy_mont = NULL: the standard generator. */
 MZK_API int32_t mzk_srs_generate_for_testing_g(int32_t curve_id, const uint64_t* beta_canonical, const uint64_t* g_xy_mont, uint64_t n_points,
                                                uint64_t* out_handle);
+/* The testing SRS over the LAGRANGE basis of the gate domain H (|H| = 2^log_n, generated by the primitive root w): point i = L_i(beta) g
+ * for i < 2^log_n, then n_extra points beta^j (beta^n - 1) g = the commitments of X^j Z_H(X).  For a polynomial p with values v_i = p(w^i)
+ * and its masked form p + (b_0 + b_1 X + ..) Z_H (mask_polynomial, prover.rs:463-486), an MSM of (v_0 .. v_(n-1), b_0, b_1, ..) over this
+ * SRS is the SAME group element as the commitment of the masked coefficients over beta^i g (univariate_kzg/mod.rs:90-116) -- but the
+ * scalars are the witness VALUES, which are mostly small numbers (flags, counters, 64-bit amounts): their high digits are zero and the MSM
+ * touches a fraction of the table rows (mzk_msm_*: zero digits cost nothing, heavy buckets have their own kernels).  Round 1 of both
+ * hosts commits the wires this way when given such a key.  (From an SRS without trapdoor the same points are the inverse group-NTT of
+ * its first 2^log_n points: mzk_srs_lagrange_from_srs.) */
+MZK_API int32_t mzk_srs_generate_lagrange_for_testing(int32_t curve_id, const uint64_t* beta_canonical, const uint64_t* g_xy_mont, uint32_t log_n,
+                                                      uint32_t n_extra, uint64_t* out_handle);
 MZK_API int32_t mzk_srs_download(uint64_t handle, uint64_t first, uint64_t n_points, uint64_t* out_xy_mont);
 MZK_API int32_t mzk_srs_len(uint64_t handle, uint64_t* out_n_points);
 

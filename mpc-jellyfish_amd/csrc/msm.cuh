@@ -762,4 +762,58 @@ __global__ __launch_bounds__(MSM_THREADS) void fr_powers_kernel(const uint32_t* 
     }
 }
 
+// Lagrange-basis scalars of the testing SRS: out[i] = L_i(beta) = w^i (beta^n - 1) / (n (beta - w^i)), i < n = 2^log_n (w the primitive
+// n-th root of unity, so that sum_i v_i L_i(X) interpolates v on H), then out[n + j] = beta^j (beta^n - 1), j < n_extra -- the
+// commitments of X^j Z_H(X), what a masked polynomial p + (b_0 + b_1 X + ..) Z_H adds to the commitment of p.  Canonical form.
+// 64 consecutive i per thread with one shared inversion.
+template <class FR>
+__global__ __launch_bounds__(MSM_THREADS) void fr_lagrange_kernel(const uint32_t* __restrict__ beta_canon, int log_n, unsigned int n_extra,
+                                                                  uint32_t* __restrict__ out_canon) {
+    using F = Fp<FR>;
+    constexpr int CH = 64;
+    const unsigned long long n = 1ull << log_n;
+    const unsigned long long t = (unsigned long long)blockIdx.x * MSM_THREADS + threadIdx.x;
+    const unsigned long long start = t * CH;
+    if (start >= n + n_extra) return;
+    F b;
+#pragma unroll
+    for (int q = 0; q < 8; q++) b.l[q] = beta_canon[q];
+    b = to_mont(b);
+    const F vanish = pow_u64(b, n) - F::one();
+    if (start >= n) return;                                    // (thread 0 writes the n_extra entries)
+    F w = F::from_const(FR::ROOT);
+    for (int i = log_n; i < FR::TWO_ADICITY; i++) w = sqr(w);
+    const unsigned long long end = start + CH < n ? start + CH : n;
+    const int cnt = (int)(end - start);
+    F x = pow_u64(w, start);
+    F pref[CH], xs[CH];
+    F run = F::one();
+    for (int j = 0; j < cnt; j++) {
+        F d = b - x;
+        if (d.is_zero()) d = F::one();
+        xs[j] = x;
+        pref[j] = run;
+        run = run * d;
+        x = x * w;
+    }
+    const F c = vanish * inv(from_u64<FR>(n));
+    F inv_run = inv(run);
+    for (int j = cnt - 1; j >= 0; j--) {
+        F d = b - xs[j];
+        const bool hit = d.is_zero();
+        if (hit) d = F::one();
+        F li = xs[j] * c * (inv_run * pref[j]);
+        if (vanish.is_zero()) li = hit ? F::one() : F::zero();  // beta on the domain: L_i(beta) is 1 at beta = w^i, 0 elsewhere
+        store_fp<FR>(out_canon + (start + j) * 8, from_mont(li));
+        inv_run = inv_run * d;
+    }
+    if (t == 0) {
+        F p = vanish;
+        for (unsigned int j = 0; j < n_extra; j++) {
+            store_fp<FR>(out_canon + (n + j) * 8, from_mont(p));
+            p = p * b;
+        }
+    }
+}
+
 }  // namespace mzk

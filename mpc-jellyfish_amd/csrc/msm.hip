@@ -507,6 +507,33 @@ int32_t srs_generate(const uint32_t* beta_canon, const uint32_t* g_xy_mont, uint
     return MZK_OK;
 }
 
+// the same over the Lagrange basis of H = <w>, |H| = 2^log_n: point i = L_i(beta) g, then n_extra points beta^j (beta^n - 1) g
+template <class FR, class FQ>
+int32_t srs_lagrange_generate(const uint32_t* beta_canon, const uint32_t* g_xy_mont, int log_n, uint32_t n_extra, uint32_t* d_out) {
+    hipStream_t st = nullptr;
+    const uint64_t n = 1ull << log_n, total = n + n_extra;
+    MZK_TRY(ws_acquire(st));
+    MZK_TRY(g_ws.scalars.reserve(total * 32));
+    MZK_TRY(g_ws.misc.reserve(32 + 256 * 4 * FQ::N * 4 + 256 * 2 * FQ::N * 4 + 2 * FQ::N * 4));
+    uint32_t* d_beta = g_ws.misc.as<uint32_t>();
+    uint32_t* d_tab_xyzz = d_beta + 8;
+    uint32_t* d_tab = d_tab_xyzz + 256 * 4 * FQ::N;
+    uint32_t* d_g = d_tab + 256 * 2 * FQ::N;
+    HIP_TRY(hipMemcpyAsync(d_beta, beta_canon, 32, hipMemcpyHostToDevice, st));
+    if (g_xy_mont) HIP_TRY(hipMemcpyAsync(d_g, g_xy_mont, 2 * FQ::N * 4, hipMemcpyHostToDevice, st));
+    const unsigned long long chunks = (n + 63) / 64;
+    hipLaunchKernelGGL((fr_lagrange_kernel<FR>), dim3((unsigned)((chunks + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0, st,
+                       d_beta, log_n, n_extra, g_ws.scalars.as<uint32_t>());
+    hipLaunchKernelGGL((g1_pow2_table_kernel<FQ>), dim3(1), dim3(64), 0, st, d_tab_xyzz, g_xy_mont ? d_g : nullptr);
+    hipLaunchKernelGGL((g1_table_to_affine_kernel<FQ>), dim3(4), dim3(64), 0, st, d_tab_xyzz, d_tab, 256);
+    hipLaunchKernelGGL((g1_fixed_base_kernel<FQ>), dim3((unsigned)((total + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
+                       d_tab, g_ws.scalars.as<uint32_t>(), total, d_out);
+    HIP_TRY(hipGetLastError());
+    MZK_TRY(ws_release(st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return MZK_OK;
+}
+
 // n Jacobian points -> affine on the host (`normalize_batch`): ONE Fermat inversion for all of them (Montgomery's trick)
 template <class FQ>
 void jac_to_affine_host(const uint64_t* xyz, uint64_t n, uint64_t* xy) {
@@ -570,6 +597,10 @@ void jac_sum_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uint64_t*
 
 int32_t srs_generate_dispatch(int curve, const uint32_t* beta_canon, const uint32_t* g_xy_mont, uint64_t n, uint32_t* d_out) {
     return curve == 0 ? srs_generate<BlsFr, BlsFq>(beta_canon, g_xy_mont, n, d_out) : srs_generate<BnFr, BnFq>(beta_canon, g_xy_mont, n, d_out);
+}
+int32_t srs_lagrange_generate_dispatch(int curve, const uint32_t* beta_canon, const uint32_t* g_xy_mont, int log_n, uint32_t n_extra, uint32_t* d_out) {
+    return curve == 0 ? srs_lagrange_generate<BlsFr, BlsFq>(beta_canon, g_xy_mont, log_n, n_extra, d_out)
+                      : srs_lagrange_generate<BnFr, BnFq>(beta_canon, g_xy_mont, log_n, n_extra, d_out);
 }
 void jac_to_affine_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uint64_t* xy) {
     if (curve == 0) jac_to_affine_host<BlsFq>(xyz, n, xy);

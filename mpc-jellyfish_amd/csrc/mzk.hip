@@ -349,6 +349,21 @@ int32_t mzk_srs_generate_for_testing_g(int32_t curve_id, const uint64_t* beta_ca
     cx_->srs[*out_handle] = s;
     return MZK_OK;
 }
+int32_t mzk_srs_generate_lagrange_for_testing(int32_t curve_id, const uint64_t* beta_canonical, const uint64_t* g_xy_mont, uint32_t log_n, uint32_t n_extra,
+                                              uint64_t* out_handle) {
+    ENTER_CUR();
+    if ((curve_id != 0 && curve_id != 1) || !out_handle || !beta_canonical || log_n > 27 || n_extra > 16) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
+    const uint64_t n_points = (1ull << log_n) + n_extra;
+    Srs s{curve_id, n_points, nullptr, nullptr, nullptr, 0};
+    HIP_TRY(hipMalloc((void**)&s.d_xy, (size_t)n_points * 2 * fq_words(curve_id) * 4));
+    int32_t rc = srs_lagrange_generate_dispatch(curve_id, reinterpret_cast<const uint32_t*>(beta_canonical), reinterpret_cast<const uint32_t*>(g_xy_mont), (int)log_n,
+                                                n_extra, s.d_xy);
+    if (rc == MZK_OK) rc = srs_build_internal(s, nullptr);
+    if (rc != MZK_OK) { (void)hipFree(s.d_xy); return rc; }
+    *out_handle = handle_make(cx_->logical, cx_->next_handle++);
+    cx_->srs[*out_handle] = s;
+    return MZK_OK;
+}
 int32_t mzk_srs_generate_for_testing(int32_t curve_id, const uint64_t* beta_canonical, uint64_t n_points, uint64_t* out_handle) {
     return mzk_srs_generate_for_testing_g(curve_id, beta_canonical, nullptr, n_points, out_handle);
 }

@@ -23,6 +23,7 @@ struct Options {
     int host_witness = 0;         // --host-witness: every proof uploads its W x n wire values from page-locked host memory;
                                   // --host-witness-vars: only the witness vector, gathered per wire on the device
     bool check_agree = false;     // --check-agree: every rank's proof bytes are compared (tests)
+    bool lagrange = false;        // --lagrange: round 1 commits the wires from their VALUES over a Lagrange-basis key (same proof bytes)
 };
 
 template <class C>
@@ -42,7 +43,7 @@ int run(bool ultra, uint64_t num_gates, int reps, int range_bits, const Options&
     ShardedProver<C> sp(opt.gpus);
     double circuit_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     t0 = std::chrono::steady_clock::now();
-    sp.setup(host, beta_c, opt.host_witness);                           // SRS, circuit upload and PlonkKzgSnark::preprocess on every device
+    sp.setup(host, beta_c, opt.host_witness, opt.lagrange);                           // SRS, circuit upload and PlonkKzgSnark::preprocess on every device
     const double preprocess_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     Proof<C> proof = sp.prove(rng, false, opt.check_agree);             // the proof whose bytes are printed (and warm-up)
     const std::vector<uint8_t> bytes = proof.serialize_compressed();
@@ -60,9 +61,9 @@ int run(bool ultra, uint64_t num_gates, int reps, int range_bits, const Options&
     std::string hex;
     static const char* d = "0123456789abcdef";
     for (uint8_t b : bytes) { hex.push_back(d[b >> 4]); hex.push_back(d[b & 15]); }
-    std::printf("{\"curve\": %d, \"plonk_type\": \"%s\", \"num_gates\": %llu, \"log_n\": %d, \"gpus\": %d, \"host_witness\": %s, \"proof_bytes\": %zu, "
+    std::printf("{\"curve\": %d, \"plonk_type\": \"%s\", \"num_gates\": %llu, \"log_n\": %d, \"gpus\": %d, \"host_witness\": %s, \"lagrange_round1\": %s, \"proof_bytes\": %zu, "
                 "\"prove_ms\": %.3f, \"circuit_build_s\": %.3f, \"preprocess_s\": %.3f, \"rounds_ms\": {",
-                C::ID, ultra ? "UltraPlonk" : "TurboPlonk", (unsigned long long)num_gates, host.log_n, opt.gpus, opt.host_witness == 0 ? "false" : (opt.host_witness == 1 ? "\"wire table\"" : "\"witness vector\""),
+                C::ID, ultra ? "UltraPlonk" : "TurboPlonk", (unsigned long long)num_gates, host.log_n, opt.gpus, opt.host_witness == 0 ? "false" : (opt.host_witness == 1 ? "\"wire table\"" : "\"witness vector\""), opt.lagrange ? "true" : "false",
                 bytes.size(), ms, circuit_s, preprocess_s);
     bool first = true;
     for (auto& kv : prover.timings_ms) { std::printf("%s\"%s\": %.3f", first ? "" : ", ", kv.first.c_str(), kv.second); first = false; }
@@ -151,6 +152,7 @@ int main(int argc_in, char** argv_in) {
         else if (a == "--host-witness") opt.host_witness = 1;
         else if (a == "--host-witness-vars") opt.host_witness = 2;
         else if (a == "--check-agree") opt.check_agree = true;
+        else if (a == "--lagrange") opt.lagrange = true;
         else args.push_back(argv_in[i]);
     }
     const int argc = (int)args.size();

@@ -267,6 +267,11 @@ struct Prover {                                                        // Provin
     uint64_t n, m;
     std::vector<Fr> k;
     uint64_t srs = 0, pk = 0;
+    // optional: a commit key over the Lagrange basis of the gate domain, n + 3 points (mzk_srs_generate_lagrange_for_testing /
+    // mzk_srs_lagrange_from_srs): round 1 then commits the wires from their VALUES (plus the two blinders), the same group elements
+    // as the commitments of the masked coefficient forms, with scalars that are mostly small numbers
+    uint64_t srs_lagrange = 0;
+    DevBuf vals_ext;
     // several devices: this prover is rank `rank` of `world`; it commits over the SRS points [lo, hi) of every
     // polynomial (one fixed partition of the n + 3 powers), owns the residue classes `own` of the quotient domain, and runs rounds
     // 4-5 on its coefficient range.  world == 1: lo = 0, hi = n + 3, every class.
@@ -341,7 +346,7 @@ struct Prover {                                                        // Provin
     }
 
     // Jacobian sums of the coefficients [a, b) of every polynomial over the SRS points of the same indices
-    std::vector<uint64_t> msm_partials(const std::vector<const void*>& polys, const std::vector<uint64_t>& lens, uint64_t a, uint64_t b) {
+    std::vector<uint64_t> msm_partials(const std::vector<const void*>& polys, const std::vector<uint64_t>& lens, uint64_t a, uint64_t b, uint64_t key = 0) {
         const uint32_t kpolys = (uint32_t)polys.size();
         std::vector<const void*> p(kpolys);
         std::vector<uint64_t> l(kpolys), off(kpolys), xyz((size_t)kpolys * 3 * QL);
@@ -351,7 +356,7 @@ struct Prover {                                                        // Provin
             l[i] = s1 - s0;
             off[i] = s1 > s0 ? s0 : a;
         }
-        check(mzk_msm_batch_dev(srs, kpolys, p.data(), l.data(), off.data(), 1, xyz.data(), nullptr), "mzk_msm_batch_dev");
+        check(mzk_msm_batch_dev(key ? key : srs, kpolys, p.data(), l.data(), off.data(), 1, xyz.data(), nullptr), "mzk_msm_batch_dev");
         return xyz;
     }
     std::vector<Affine> to_affine(const std::vector<uint64_t>& xyz) const {
@@ -378,8 +383,8 @@ struct Prover {                                                        // Provin
     }
     // UnivariateKzgPCS::batch_commit (mod.rs:119-131) on device-resident coefficient vectors; over several ranks every MSM is
     // sharded by point range (this rank: [lo, hi))
-    std::vector<Affine> commit(const std::vector<const void*>& polys, const std::vector<uint64_t>& lens) {
-        return combine_partials(msm_partials(polys, lens, lo, hi));
+    std::vector<Affine> commit(const std::vector<const void*>& polys, const std::vector<uint64_t>& lens, uint64_t key = 0) {
+        return combine_partials(msm_partials(polys, lens, lo, hi, key));
     }
     // ... of polynomials of which this rank holds ONLY the coefficients [lo, lo + lens[i])
     std::vector<Affine> commit_slices(const std::vector<const void*>& slices, const std::vector<uint64_t>& lens) {
@@ -519,8 +524,17 @@ struct Prover {                                                        // Provin
         { std::vector<int> rs; for (int i = 0; i < W; i++) rs.push_back(i); mask(rs, st.b.wires); }
         tick.mark("r1_ntt_mask");
         std::vector<const void*> p; std::vector<uint64_t> l;
-        for (int i = 0; i < W; i++) { p.push_back(row(i)); l.push_back(n + 2); }
-        auto comms = commit(p, l);
+        if (srs_lagrange) {
+            // sum_i v_i [L_i(beta)]g + b_0 [Z_H(beta)]g + b_1 [beta Z_H(beta)]g: rows of n + 3 slots, the values, then the blinders
+            if (!vals_ext.p) vals_ext.alloc((size_t)W * (n + 3));
+            check(mzk_dev_copy2d(vals_ext.p, (n + 3) * EL, st.wire_values, n * EL, n * EL, W, nullptr), "copy2d");
+            for (int i = 0; i < W; i++)
+                for (int j = 0; j < 2; j++) lincomb({{st.b.wires[i][j], one_dev(), 1}}, vals_ext.at((size_t)i * (n + 3) + n + j), 1);
+            for (int i = 0; i < W; i++) { p.push_back(vals_ext.at((size_t)i * (n + 3))); l.push_back(n + 2); }
+        } else {
+            for (int i = 0; i < W; i++) { p.push_back(row(i)); l.push_back(n + 2); }
+        }
+        auto comms = commit(p, l, srs_lagrange);
         tick.mark("r1_commit");
         return comms;
     }
@@ -987,7 +1001,7 @@ struct ShardedProver {
     LocalComm comm;
     std::vector<std::unique_ptr<BenchCircuit<C>>> circuit;             // per device
     std::vector<std::unique_ptr<P>> prover;
-    std::vector<uint64_t> srs;
+    std::vector<uint64_t> srs, srs_lagrange;
     // worker threads
     std::vector<std::thread> threads;
     std::mutex mu;
@@ -998,12 +1012,13 @@ struct ShardedProver {
     bool stop = false;
     std::vector<std::exception_ptr> errors;
 
-    explicit ShardedProver(int g) : G(g), comm(g), circuit(g), prover(g), srs(g, 0), errors(g) {
+    explicit ShardedProver(int g) : G(g), comm(g), circuit(g), prover(g), srs(g, 0), srs_lagrange(g, 0), errors(g) {
         if (G > 1)
             for (int r = 0; r < G; r++) threads.emplace_back([this, r] { worker(r); });
     }
     ~ShardedProver() {
-        try { each([&](int r) { prover[r].reset(); circuit[r].reset(); if (srs[r]) (void)mzk_srs_release(srs[r]); srs[r] = 0; }); } catch (...) {}
+        try { each([&](int r) { prover[r].reset(); circuit[r].reset(); if (srs[r]) (void)mzk_srs_release(srs[r]); srs[r] = 0;
+                                    if (srs_lagrange[r]) (void)mzk_srs_release(srs_lagrange[r]); srs_lagrange[r] = 0; }); } catch (...) {}
         {
             std::lock_guard<std::mutex> lk(mu);
             stop = true;
@@ -1062,11 +1077,16 @@ struct ShardedProver {
         if (other) std::rethrow_exception(other);
     }
     // the testing SRS [beta^i] G on every device, the circuit uploaded to every device, PlonkKzgSnark::preprocess per device
-    void setup(const BenchCircuitHost<C>& host, const std::array<uint64_t, 4>& beta_canonical, int host_witness = 0) {
+    // lagrange: also the key over the Lagrange basis of the gate domain -- round 1 then commits from the wire values
+    void setup(const BenchCircuitHost<C>& host, const std::array<uint64_t, 4>& beta_canonical, int host_witness = 0, bool lagrange = false) {
         each([&](int r) {
             check(mzk_srs_generate_for_testing(C::ID, beta_canonical.data(), host.n + 3, &srs[r]), "mzk_srs_generate_for_testing");
+            if (lagrange)
+                check(mzk_srs_generate_lagrange_for_testing(C::ID, beta_canonical.data(), nullptr, (uint32_t)host.log_n, 3, &srs_lagrange[r]),
+                      "mzk_srs_generate_lagrange_for_testing");
             circuit[r] = std::make_unique<BenchCircuit<C>>(BenchCircuit<C>::upload(host, host_witness));
             prover[r] = std::make_unique<P>(srs[r], *circuit[r], r, G, &comm);
+            prover[r]->srs_lagrange = srs_lagrange[r];
         });
         for (int r = 0; r < G; r++) {                                     // where every rank receives the class remainders of the others
             prover[r]->peer_rem.resize(G);

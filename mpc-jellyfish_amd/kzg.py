@@ -70,6 +70,22 @@ class UnivariateProverParam:
                                                     max_degree + 1, C.byref(h)), "mzk_srs_generate_for_testing_g")
         return cls(c, h.value, max_degree + 1)
 
+    @classmethod
+    def gen_lagrange_srs_for_testing(cls, curve, beta: int, domain_size: int, n_extra: int = 3, g=None) -> "UnivariateProverParam":
+        """The testing SRS over the Lagrange basis of the gate domain H (|H| = domain_size): point i = L_i(beta) g, then n_extra points
+        beta^j (beta^n - 1) g (include/mzk.h, mzk_srs_generate_lagrange_for_testing).  An MSM of (values on H, blinders) over it equals
+        the commitment of the masked coefficient form over gen_srs_for_testing(beta, ..., g) -- round 1 commits the wires this way
+        (TurboPlonkProver.lagrange_ck): witness values are mostly small numbers, whose high digits cost the MSM nothing."""
+        c = _curve(curve)
+        assert domain_size & (domain_size - 1) == 0
+        L = _lib.ensure_init()
+        h = C.c_uint64()
+        b = int_to_limbs(beta % c.r, 4)
+        gm = None if g is None else np.ascontiguousarray(np.concatenate([fq_to_mont(c, [g[0]])[0], fq_to_mont(c, [g[1]])[0]]))
+        _lib.check(L.mzk_srs_generate_lagrange_for_testing(c.curve_id, C.c_void_p(b.ctypes.data), None if gm is None else C.c_void_p(gm.ctypes.data),
+                                                           domain_size.bit_length() - 1, n_extra, C.byref(h)), "mzk_srs_generate_lagrange_for_testing")
+        return cls(c, h.value, domain_size + n_extra)
+
     def trim(self, supported_degree: int) -> "UnivariateProverParam":
         """srs.rs:77-93: keep powers_of_g[..=supported_degree]."""
         if supported_degree + 1 > self.length:

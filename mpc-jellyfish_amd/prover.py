@@ -227,6 +227,7 @@ class TurboPlonkProver:
         self.ck = commit_key
         self.ultra = plookup is not None
         self.committer = None                        # set to a sharding.ShardedCommitter for multi-GPU commits
+        self.lagrange_ck = None                      # kzg.UnivariateProverParam.gen_lagrange_srs_for_testing(...): round 1 commits from the wire VALUES
         self.range_mode = True                       # several ranks: rounds 4 and 5 work on this rank's coefficient range only
         self.W = len(sigma_polys)
         self.nsel = len(selector_polys)
@@ -367,7 +368,20 @@ class TurboPlonkProver:
         self._mask(slab, list(range(W)), blind.wires)
         tick("r1_ntt_mask", t0)
         t0 = time.perf_counter()
-        wires_comms = self._commit([slab[i, :n + 2] for i in range(W)])
+        if self.lagrange_ck is not None and self.committer is None:
+            # commit from the VALUES over the Lagrange-basis key: sum_i v_i [L_i(beta)]g + b_0 [Z_H(beta)]g + b_1 [beta Z_H(beta)]g is the
+            # same group element as the commitment of the masked coefficients (include/mzk.h, mzk_srs_generate_lagrange_for_testing) --
+            # with scalars that are mostly small numbers
+            if getattr(self, "_vals_ext", None) is None:
+                self._vals_ext = torch.zeros((W, n + 3, 4), dtype=torch.int64, device=dev)
+            ext = self._vals_ext
+            ext[:, :n] = st.wv
+            bl = fr_to_mont(self.curve, [b for row in blind.wires for b in row]).view(np.int64).reshape(W, 2, 4)
+            ext[:, n:n + 2] = torch.from_numpy(bl).to(dev)
+            jac = kzg.msm_bigint_batch(self.lagrange_ck, [ext[i, :n + 2] for i in range(W)], scalars_are_mont=True)
+            wires_comms = [kzg.Commitment(self.curve, xy) for xy in kzg.jacobian_to_affine(self.curve, jac)]
+        else:
+            wires_comms = self._commit([slab[i, :n + 2] for i in range(W)])
         tick("r1_commit", t0)
         return st, wires_comms
 

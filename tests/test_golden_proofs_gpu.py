@@ -30,6 +30,30 @@ def test_device_prover_reproduces_the_golden_proof(gpu, mj, index):
     ck.release()
 
 
+@pytest.mark.parametrize("name,index", [("proof_vectors", 0), ("proof_vectors", 1), ("proof_vectors", 2), ("proof_vectors", 3), ("proof_vectors_refsetup", 0),
+                                        ("proof_vectors_refsetup", 3)])
+def test_golden_proofs_with_round_1_committed_over_the_lagrange_basis(gpu, mj, name, index):
+    """TurboPlonkProver.lagrange_ck: the wire commitments of round 1 are MSMs of the wire VALUES (and the two blinders) over
+    [L_i(beta)]g, [X^j Z_H(beta)]g -- the same group elements, hence the same proof bytes, as the golden vectors made from coefficient
+    forms (both testing set-ups: g the generator, g = G1::rand)."""
+    vec = load_golden(name)[index]
+    c = mj.params.CURVES[vec["curve"]]
+    cs = mj.snark.gen_circuit_for_bench(c, vec["num_gates"], vec["plonk_type"], range_bit_len=vec["range_bit_len"])
+    rng = mj.rng.test_rng()
+    if "srs_g" in vec:
+        srs_beta, g = mj.rng.universal_setup_for_testing(c, rng)
+    else:
+        srs_beta, g = mj.rng.fr_rand(c, rng), None
+    ck = mj.UnivariateProverParam.gen_srs_for_testing(c, srs_beta, cs.n + 2, g=g)
+    pk = mj.snark.preprocess(ck, cs)
+    pk.lagrange_ck = mj.UnivariateProverParam.gen_lagrange_srs_for_testing(c, srs_beta, cs.n, g=g)
+    _, proof_bytes = mj.snark.prove(rng, cs, pk)
+    assert proof_bytes.hex() == vec["proof"]
+    pk.lagrange_ck.release()
+    pk.release()
+    ck.release()
+
+
 @pytest.mark.parametrize("index", [0, 1])
 def test_device_link_proofs_reproduce_the_golden_link(gpu, mj, index):
     """prove_with_link_hint twice + link_proofs on the device: both proofs and the LinkingProof of tests/golden/link_vectors.json."""

@@ -210,6 +210,34 @@ def test_msm_heavy_buckets_full_size_trapdoor(gpu, mj, cref, mode):
     pp.release()
 
 
+@pytest.mark.parametrize("curve_id", [0, 1])
+@pytest.mark.parametrize("log_n", [0, 3, 6, 10])
+def test_lagrange_srs_for_testing_against_the_definition(gpu, mj, pyref, curve_id, log_n):
+    """mzk_srs_generate_lagrange_for_testing: point i = [L_i(beta)]G with L_i(beta) = w^i (beta^n - 1) / (n (beta - w^i)) (big ints, one oracle
+    scalar multiplication per sampled point), the extra points [beta^j (beta^n - 1)]G; sum_i points = G (the L_i sum to one); beta ON the
+    domain gives the unit vector."""
+    c = mj.params.CURVES[curve_id]
+    pc = pyref.CURVES[curve_id]
+    r, n = c.r, 1 << log_n
+    w = pow(c.fr_generator, (r - 1) >> log_n, r) if log_n else 1
+    G = pyref.g1_gen(pc)
+    for beta in (0x1234567890abcdef1122334455667788 % r, pow(w, 5 % n, r)):
+        pp = mj.UnivariateProverParam.gen_lagrange_srs_for_testing(c, beta, n, n_extra=3)
+        pts = pp.powers_of_g()
+        vanish = (pow(beta, n, r) - 1) % r
+        for i in sorted({0, 1 % n, 5 % n, n // 2, n - 1}):
+            wi = pow(w, i, r)
+            li = (1 if beta == wi else 0) if vanish == 0 else wi * vanish % r * pow(n * (beta - wi) % r, -1, r) % r
+            want = pyref.g1_mul(pc, li, G)
+            assert affine_from_limbs(c, pts[i]) == want, (log_n, i)
+        for j in range(3):
+            want = pyref.g1_mul(pc, pow(beta, j, r) * vanish % r, G)
+            assert affine_from_limbs(c, pts[n + j]) == want, ("extra", j)
+        ones = np.repeat(_bigints([1]), n, axis=0)
+        assert jacobian_to_affine_ints(pc, mj.msm_bigint(pp, ones)) == G
+        pp.release()
+
+
 def test_msm_batch_fused(gpu, mj, cref):
     """mzk_msm_batch / mzk_msm_batch_dev: MSMs of different lengths (two window sizes, an empty one)
     in one call equal the single calls and the oracle."""
