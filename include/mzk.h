@@ -101,6 +101,11 @@ MZK_API int32_t mzk_srs_generate_for_testing_g(int32_t curve_id, const uint64_t*
  * its first 2^log_n points: mzk_srs_lagrange_from_srs.) */
 MZK_API int32_t mzk_srs_generate_lagrange_for_testing(int32_t curve_id, const uint64_t* beta_canonical, const uint64_t* g_xy_mont, uint32_t log_n,
                                                       uint32_t n_extra, uint64_t* out_handle);
+/* The same key from the points of a registered SRS alone (no trapdoor): [L_i(beta)]g = (1/n) sum_j w^(-ij) [beta^j]g, the inverse NTT over the
+ * group of its first 2^log_n points, then [beta^(n+j)]g - [beta^j]g for the n_extra tail (the SRS must hold 2^log_n + n_extra points).
+ * (n / 2) log2 n scalar multiplications: 0.14 s at 2^16, 1.2 s at 2^20 (BLS12-381; BN254 half that) -- once per SRS and domain size.
+ * Synchronises. */
+MZK_API int32_t mzk_srs_lagrange_from_srs(uint64_t srs_handle, uint32_t log_n, uint32_t n_extra, uint64_t* out_handle);
 MZK_API int32_t mzk_srs_download(uint64_t handle, uint64_t first, uint64_t n_points, uint64_t* out_xy_mont);
 MZK_API int32_t mzk_srs_len(uint64_t handle, uint64_t* out_n_points);
 

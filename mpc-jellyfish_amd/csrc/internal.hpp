@@ -127,6 +127,7 @@ int32_t msm_batch_dispatch(const Srs& s, uint32_t n_polys, const uint32_t* const
 int32_t srs_build_internal(Srs& s, hipStream_t st);
 int32_t srs_build_pre(Srs& s, hipStream_t st);
 int32_t srs_generate_dispatch(int curve, const uint32_t* beta_canon, const uint32_t* g_xy_mont /* NULL: the standard generator */, uint64_t n, uint32_t* d_out);
+int32_t srs_lagrange_from_points_dispatch(int curve, const uint32_t* d_xy, int log_n, uint32_t n_extra, uint32_t* d_out);
 int32_t srs_lagrange_generate_dispatch(int curve, const uint32_t* beta_canon, const uint32_t* g_xy_mont /* nullable */, int log_n, uint32_t n_extra, uint32_t* d_out);
 void jac_to_affine_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uint64_t* xy);
 void jac_sum_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uint64_t* out);

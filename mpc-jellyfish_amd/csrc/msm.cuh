@@ -762,6 +762,90 @@ __global__ __launch_bounds__(MSM_THREADS) void fr_powers_kernel(const uint32_t* 
     }
 }
 
+// ---- Lagrange-basis SRS from an SRS WITHOUT trapdoor: the inverse NTT over the group ---------------------------------------------
+// S_j = [beta^j]g = sum_i (w^i)^j [L_i(beta)]g (X^j interpolated on H), i.e. S is the forward transform of the Lagrange-basis points:
+//     [L_i(beta)]g = (1/n) sum_j w^(-ij) S_j.
+// Decimation in frequency (natural order in, bit-reversed out) on an XYZZ array: a stage with half-size h maps (a, b) = (A[i], A[i + h])
+// to (a + b, w_(2h)^(-k) (a - b)), k = i mod h -- a point addition, a subtraction and ONE 255-bit scalar multiplication (double and
+// add) per butterfly: (n / 2) log2 n of them, 1.2 s at n = 2^20 on BLS12-381 (tools/lagrange_key_time.py).  A one-off per SRS and
+// domain size.  ec_ntt_finish scales by 1/n, undoes the bit reversal and normalises.
+template <class FQ>
+__device__ __forceinline__ XYZZ<Fp<FQ>> ec_scalar_mul(const XYZZ<Fp<FQ>>& p, const uint32_t (&k)[8]) {
+    XYZZ<Fp<FQ>> acc = XYZZ<Fp<FQ>>::inf();
+    bool started = false;
+#pragma unroll 1
+    for (int bit = 255; bit >= 0; bit--) {
+        if (started) acc = xyzz_dbl(acc);
+        if ((k[bit >> 5] >> (bit & 31)) & 1u) {
+            acc = started ? xyzz_add(acc, p) : p;
+            started = true;
+        }
+    }
+    return acc;
+}
+template <class FQ>
+__global__ __launch_bounds__(MSM_ACC_THREADS) void ec_ntt_load_kernel(const uint32_t* __restrict__ xy, unsigned long long n, uint32_t* __restrict__ a) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
+    if (i >= n) return;
+    store_xyzz<FQ>(a, i, XYZZ<Fp<FQ>>::from_affine(load_affine<FQ>(xy, i)));
+}
+// winv_canon: w_n^-1 (canonical); h: half-size of this stage
+template <class FR, class FQ>
+__global__ __launch_bounds__(MSM_ACC_THREADS) void ec_ntt_stage_kernel(uint32_t* __restrict__ a, unsigned long long n, unsigned long long h,
+                                                                       const uint32_t* __restrict__ winv_canon) {
+    const unsigned long long t = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
+    if (t >= n / 2) return;
+    const unsigned long long k = t % h, i = (t / h) * 2 * h + k, j = i + h;
+    const XYZZ<Fp<FQ>> p = load_xyzz<FQ>(a, i), q = load_xyzz<FQ>(a, j);
+    XYZZ<Fp<FQ>> qn = q;
+    qn.y = neg(q.y);
+    store_xyzz<FQ>(a, i, xyzz_add(p, q));
+    XYZZ<Fp<FQ>> d = xyzz_add(p, qn);
+    if (k) {                                                   // times w_(2h)^(-k) = (w_n^-1)^(k n / (2h))
+        Fp<FR> w;
+#pragma unroll
+        for (int q8 = 0; q8 < 8; q8++) w.l[q8] = winv_canon[q8];
+        const Fp<FR> tw = from_mont(pow_u64(to_mont(w), k * (n / (2 * h))));
+        uint32_t kk[8];
+#pragma unroll
+        for (int q8 = 0; q8 < 8; q8++) kk[q8] = tw.l[q8];
+        d = ec_scalar_mul<FQ>(d, kk);
+    }
+    store_xyzz<FQ>(a, j, d);
+}
+// out[bitrev(i)] = affine(ninv * A[i])
+template <class FQ>
+__global__ __launch_bounds__(MSM_ACC_THREADS) void ec_ntt_finish_kernel(const uint32_t* __restrict__ a, unsigned long long n, int log_n,
+                                                                        const uint32_t* __restrict__ ninv_canon, uint32_t* __restrict__ out_xy) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
+    if (i >= n) return;
+    uint32_t kk[8];
+#pragma unroll
+    for (int q = 0; q < 8; q++) kk[q] = ninv_canon[q];
+    const XYZZ<Fp<FQ>> p = ec_scalar_mul<FQ>(load_xyzz<FQ>(a, i), kk);
+    unsigned long long r = 0;
+    for (int b = 0; b < log_n; b++) r |= ((i >> b) & 1ull) << (log_n - 1 - b);
+    Affine<Fp<FQ>> q;
+    if (p.is_inf()) { q.x = Fp<FQ>::zero(); q.y = Fp<FQ>::zero(); }
+    else q = xyzz_to_affine(p);
+    store_fp<FQ>(out_xy + r * 2 * FQ::N, q.x);
+    store_fp<FQ>(out_xy + r * 2 * FQ::N + FQ::N, q.y);
+}
+// out[j] = S_(n + j) - S_j = [beta^j (beta^n - 1)]g, j < n_extra
+template <class FQ>
+__global__ void ec_ntt_extra_kernel(const uint32_t* __restrict__ xy, unsigned long long n, unsigned int n_extra, uint32_t* __restrict__ out_xy) {
+    const unsigned int j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n_extra) return;
+    Affine<Fp<FQ>> lo = load_affine<FQ>(xy, j);
+    lo.y = neg(lo.y);
+    const XYZZ<Fp<FQ>> d = xyzz_madd(XYZZ<Fp<FQ>>::from_affine(load_affine<FQ>(xy, n + j)), lo);
+    Affine<Fp<FQ>> q;
+    if (d.is_inf()) { q.x = Fp<FQ>::zero(); q.y = Fp<FQ>::zero(); }
+    else q = xyzz_to_affine(d);
+    store_fp<FQ>(out_xy + (size_t)j * 2 * FQ::N, q.x);
+    store_fp<FQ>(out_xy + (size_t)j * 2 * FQ::N + FQ::N, q.y);
+}
+
 // Lagrange-basis scalars of the testing SRS: out[i] = L_i(beta) = w^i (beta^n - 1) / (n (beta - w^i)), i < n = 2^log_n (w the primitive
 // n-th root of unity, so that sum_i v_i L_i(X) interpolates v on H), then out[n + j] = beta^j (beta^n - 1), j < n_extra -- the
 // commitments of X^j Z_H(X), what a masked polynomial p + (b_0 + b_1 X + ..) Z_H adds to the commitment of p.  Canonical form.

@@ -364,6 +364,25 @@ int32_t mzk_srs_generate_lagrange_for_testing(int32_t curve_id, const uint64_t* 
     cx_->srs[*out_handle] = s;
     return MZK_OK;
 }
+int32_t mzk_srs_lagrange_from_srs(uint64_t srs_handle, uint32_t log_n, uint32_t n_extra, uint64_t* out_handle) {
+    ENTER_HANDLE(srs_handle);
+    auto it = cx_->srs.find(srs_handle);
+    if (it == cx_->srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+    const Srs src = it->second;
+    if (!out_handle || log_n > 27 || n_extra > 16 || (1ull << log_n) + n_extra > src.n) {
+        set_error("bad argument (the SRS must hold 2^log_n + n_extra points)");
+        return MZK_ERR_INVALID_ARG;
+    }
+    const uint64_t n_points = (1ull << log_n) + n_extra;
+    Srs s{src.curve, n_points, nullptr, nullptr, nullptr, 0};
+    HIP_TRY(hipMalloc((void**)&s.d_xy, (size_t)n_points * 2 * fq_words(src.curve) * 4));
+    int32_t rc = srs_lagrange_from_points_dispatch(src.curve, src.d_xy, (int)log_n, n_extra, s.d_xy);
+    if (rc == MZK_OK) rc = srs_build_internal(s, nullptr);
+    if (rc != MZK_OK) { (void)hipFree(s.d_xy); return rc; }
+    *out_handle = handle_make(cx_->logical, cx_->next_handle++);
+    cx_->srs[*out_handle] = s;
+    return MZK_OK;
+}
 int32_t mzk_srs_generate_for_testing(int32_t curve_id, const uint64_t* beta_canonical, uint64_t n_points, uint64_t* out_handle) {
     return mzk_srs_generate_for_testing_g(curve_id, beta_canonical, nullptr, n_points, out_handle);
 }

@@ -23,7 +23,8 @@ struct Options {
     int host_witness = 0;         // --host-witness: every proof uploads its W x n wire values from page-locked host memory;
                                   // --host-witness-vars: only the witness vector, gathered per wire on the device
     bool check_agree = false;     // --check-agree: every rank's proof bytes are compared (tests)
-    bool lagrange = false;        // --lagrange: round 1 commits the wires from their VALUES over a Lagrange-basis key (same proof bytes)
+    bool lagrange = true;         // round 1 commits the wires from their VALUES over the Lagrange-basis key derived from the SRS (same proof
+                                  // bytes); --no-lagrange: from the masked coefficient forms, as the reference does
 };
 
 template <class C>
@@ -62,9 +63,9 @@ int run(bool ultra, uint64_t num_gates, int reps, int range_bits, const Options&
     static const char* d = "0123456789abcdef";
     for (uint8_t b : bytes) { hex.push_back(d[b >> 4]); hex.push_back(d[b & 15]); }
     std::printf("{\"curve\": %d, \"plonk_type\": \"%s\", \"num_gates\": %llu, \"log_n\": %d, \"gpus\": %d, \"host_witness\": %s, \"lagrange_round1\": %s, \"proof_bytes\": %zu, "
-                "\"prove_ms\": %.3f, \"circuit_build_s\": %.3f, \"preprocess_s\": %.3f, \"rounds_ms\": {",
+                "\"prove_ms\": %.3f, \"circuit_build_s\": %.3f, \"preprocess_s\": %.3f, \"lagrange_key_s\": %.3f, \"rounds_ms\": {",
                 C::ID, ultra ? "UltraPlonk" : "TurboPlonk", (unsigned long long)num_gates, host.log_n, opt.gpus, opt.host_witness == 0 ? "false" : (opt.host_witness == 1 ? "\"wire table\"" : "\"witness vector\""), opt.lagrange ? "true" : "false",
-                bytes.size(), ms, circuit_s, preprocess_s);
+                bytes.size(), ms, circuit_s, preprocess_s, sp.lagrange_key_s);
     bool first = true;
     for (auto& kv : prover.timings_ms) { std::printf("%s\"%s\": %.3f", first ? "" : ", ", kv.first.c_str(), kv.second); first = false; }
     std::vector<uint8_t> vk_bytes;                                      // VerifyingKey commitments (selectors, then sigmas), compressed
@@ -153,12 +154,13 @@ int main(int argc_in, char** argv_in) {
         else if (a == "--host-witness-vars") opt.host_witness = 2;
         else if (a == "--check-agree") opt.check_agree = true;
         else if (a == "--lagrange") opt.lagrange = true;
+        else if (a == "--no-lagrange") opt.lagrange = false;
         else args.push_back(argv_in[i]);
     }
     const int argc = (int)args.size();
     char** argv = args.data();
     if (opt.gpus < 1 || opt.gpus > 16) { std::fprintf(stderr, "mzk_prove: --gpus 1..16\n"); return 2; }
-    if (argc < 4) { std::fprintf(stderr, "usage: %s <curve 0|1> <turbo|ultra> <num_gates> [reps] [range_bit_len] [--gpus G] [--host-witness | --host-witness-vars] [--check-agree]\n", argv[0]); return 2; }
+    if (argc < 4) { std::fprintf(stderr, "usage: %s <curve 0|1> <turbo|ultra> <num_gates> [reps] [range_bit_len] [--gpus G] [--host-witness | --host-witness-vars] [--check-agree] [--no-lagrange]\n", argv[0]); return 2; }
     const int curve = std::atoi(argv[1]);
     if (std::string(argv[2]) == "link") {
         if (argc < 8) { std::fprintf(stderr, "usage: %s <curve 0|1> link <num_gates_1> <num_gates_2> <alignment> <offset> <size> [reps]\n", argv[0]); return 2; }

@@ -1002,6 +1002,7 @@ struct ShardedProver {
     std::vector<std::unique_ptr<BenchCircuit<C>>> circuit;             // per device
     std::vector<std::unique_ptr<P>> prover;
     std::vector<uint64_t> srs, srs_lagrange;
+    double lagrange_key_s = 0;                                         // wall time of mzk_srs_lagrange_from_srs on rank 0 (set-up, once per SRS and domain)
     // worker threads
     std::vector<std::thread> threads;
     std::mutex mu;
@@ -1078,12 +1079,14 @@ struct ShardedProver {
     }
     // the testing SRS [beta^i] G on every device, the circuit uploaded to every device, PlonkKzgSnark::preprocess per device
     // lagrange: also the key over the Lagrange basis of the gate domain -- round 1 then commits from the wire values
-    void setup(const BenchCircuitHost<C>& host, const std::array<uint64_t, 4>& beta_canonical, int host_witness = 0, bool lagrange = false) {
+    void setup(const BenchCircuitHost<C>& host, const std::array<uint64_t, 4>& beta_canonical, int host_witness = 0, bool lagrange = true) {
         each([&](int r) {
             check(mzk_srs_generate_for_testing(C::ID, beta_canonical.data(), host.n + 3, &srs[r]), "mzk_srs_generate_for_testing");
-            if (lagrange)
-                check(mzk_srs_generate_lagrange_for_testing(C::ID, beta_canonical.data(), nullptr, (uint32_t)host.log_n, 3, &srs_lagrange[r]),
-                      "mzk_srs_generate_lagrange_for_testing");
+            if (lagrange) {                                               // from the SRS's points alone (no trapdoor): an inverse NTT over the group
+                const auto t0 = std::chrono::steady_clock::now();
+                check(mzk_srs_lagrange_from_srs(srs[r], (uint32_t)host.log_n, 3, &srs_lagrange[r]), "mzk_srs_lagrange_from_srs");
+                if (r == 0) lagrange_key_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            }
             circuit[r] = std::make_unique<BenchCircuit<C>>(BenchCircuit<C>::upload(host, host_witness));
             prover[r] = std::make_unique<P>(srs[r], *circuit[r], r, G, &comm);
             prover[r]->srs_lagrange = srs_lagrange[r];

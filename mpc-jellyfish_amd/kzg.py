@@ -86,6 +86,14 @@ class UnivariateProverParam:
                                                            domain_size.bit_length() - 1, n_extra, C.byref(h)), "mzk_srs_generate_lagrange_for_testing")
         return cls(c, h.value, domain_size + n_extra)
 
+    def lagrange_key(self, domain_size: int, n_extra: int = 3) -> "UnivariateProverParam":
+        """The Lagrange-basis key of THIS SRS for the gate domain of `domain_size` points, without the trapdoor: the inverse group-NTT of
+        its first domain_size points (mzk_srs_lagrange_from_srs; 0.14 s at 2^16, 1.2 s at 2^20 on BLS12-381: a one-off per SRS and domain)."""
+        assert domain_size & (domain_size - 1) == 0 and self.offset == 0 and self.length >= domain_size + n_extra
+        h = C.c_uint64()
+        _lib.check(_lib.ensure_init().mzk_srs_lagrange_from_srs(self.handle, domain_size.bit_length() - 1, n_extra, C.byref(h)), "mzk_srs_lagrange_from_srs")
+        return UnivariateProverParam(self.curve, h.value, domain_size + n_extra)
+
     def trim(self, supported_degree: int) -> "UnivariateProverParam":
         """srs.rs:77-93: keep powers_of_g[..=supported_degree]."""
         if supported_degree + 1 > self.length:

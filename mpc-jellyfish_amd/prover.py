@@ -285,6 +285,9 @@ class TurboPlonkProver:
 
     def release(self):
         self.pk.release()
+        if self.lagrange_ck is not None:
+            self.lagrange_ck.release()
+            self.lagrange_ck = None
 
     def _mask(self, t, rows, blinders):
         """poly + (b_0 + b_1 X + ..)(X^n - 1) on the device rows (prover.rs:463-486), one launch for all of them."""

@@ -150,9 +150,11 @@ class HostWitness:
 
 
 def preprocess(commit_key: kzg.UnivariateProverParam, circuit: BenchCircuit, quotient_classes=None, quotient_gather=None,
-               quotient_shard=None) -> _prover.TurboPlonkProver:
+               quotient_shard=None, lagrange: bool = True) -> _prover.TurboPlonkProver:
     """snark.rs:529-617: interpolate selectors, sigmas (and Plookup tables), keep them with the commit key.  The
-    verifying-key commitments are produced on demand by `TurboPlonkProver.vk_commitments()`."""
+    verifying-key commitments are produced on demand by `TurboPlonkProver.vk_commitments()`.  lagrange: also derive the commit key over
+    the Lagrange basis of the gate domain from the SRS's points (kzg.UnivariateProverParam.lagrange_key) -- round 1 then commits the
+    wires from their values (same commitments; single-process proving)."""
     c, n = circuit.curve, circuit.n
     if commit_key.length < n + 3:
         raise ValueError("SRS too small: need domain size + 3 powers (srs.rs:88)")          # snark.rs:535-541
@@ -170,8 +172,11 @@ def preprocess(commit_key: kzg.UnivariateProverParam, circuit: BenchCircuit, quo
         dom.ifft_in_place(tab)
         tab_h = host(tab)
         plookup = {name: tab_h[i] for i, name in enumerate(("range_table_poly", "key_table_poly", "table_dom_sep_poly", "q_dom_sep_poly"))}
-    return _prover.TurboPlonkProver(c, n, list(host(sel)), list(host(sig)), circuit.k, commit_key, plookup=plookup,
-                                    quotient_classes=quotient_classes, quotient_gather=quotient_gather, quotient_shard=quotient_shard)
+    pk = _prover.TurboPlonkProver(c, n, list(host(sel)), list(host(sig)), circuit.k, commit_key, plookup=plookup,
+                                  quotient_classes=quotient_classes, quotient_gather=quotient_gather, quotient_shard=quotient_shard)
+    if lagrange and quotient_shard is None and quotient_gather is None and commit_key.offset == 0:
+        pk.lagrange_ck = commit_key.lagrange_key(n)
+    return pk
 
 
 def draw_blinders(curve, rng: _rng.ChaChaRng, num_wire_types: int, ultra: bool) -> _prover.Blinders:

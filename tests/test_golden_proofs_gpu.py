@@ -30,6 +30,16 @@ def test_device_prover_reproduces_the_golden_proof(gpu, mj, index):
     ck.release()
 
 
+def _rng_after_setup(mj, c, reference_setup):
+    """test_rng advanced past the SRS draws (beta, or universal_setup_for_testing's beta, g, h)"""
+    rng = mj.rng.test_rng()
+    if reference_setup:
+        mj.rng.universal_setup_for_testing(c, rng)
+    else:
+        mj.rng.fr_rand(c, rng)
+    return rng
+
+
 @pytest.mark.parametrize("name,index", [("proof_vectors", 0), ("proof_vectors", 1), ("proof_vectors", 2), ("proof_vectors", 3), ("proof_vectors_refsetup", 0),
                                         ("proof_vectors_refsetup", 3)])
 def test_golden_proofs_with_round_1_committed_over_the_lagrange_basis(gpu, mj, name, index):
@@ -45,12 +55,14 @@ def test_golden_proofs_with_round_1_committed_over_the_lagrange_basis(gpu, mj, n
     else:
         srs_beta, g = mj.rng.fr_rand(c, rng), None
     ck = mj.UnivariateProverParam.gen_srs_for_testing(c, srs_beta, cs.n + 2, g=g)
-    pk = mj.snark.preprocess(ck, cs)
-    pk.lagrange_ck = mj.UnivariateProverParam.gen_lagrange_srs_for_testing(c, srs_beta, cs.n, g=g)
-    _, proof_bytes = mj.snark.prove(rng, cs, pk)
-    assert proof_bytes.hex() == vec["proof"]
-    pk.lagrange_ck.release()
-    pk.release()
+    for mode in ("from the SRS", "from beta", "off"):
+        pk = mj.snark.preprocess(ck, cs, lagrange=mode == "from the SRS")
+        assert (pk.lagrange_ck is not None) == (mode == "from the SRS")
+        if mode == "from beta":
+            pk.lagrange_ck = mj.UnivariateProverParam.gen_lagrange_srs_for_testing(c, srs_beta, cs.n, g=g)
+        _, proof_bytes = mj.snark.prove(_rng_after_setup(mj, c, "srs_g" in vec), cs, pk)
+        assert proof_bytes.hex() == vec["proof"], mode
+        pk.release()
     ck.release()
 
 

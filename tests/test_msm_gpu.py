@@ -238,6 +238,25 @@ def test_lagrange_srs_for_testing_against_the_definition(gpu, mj, pyref, curve_i
         pp.release()
 
 
+@pytest.mark.parametrize("curve_id", [0, 1])
+@pytest.mark.parametrize("log_n", [0, 1, 3, 7, 10])
+def test_lagrange_key_from_the_points_of_an_srs(gpu, mj, curve_id, log_n):
+    """mzk_srs_lagrange_from_srs (no trapdoor: the inverse NTT over the group of the SRS's first n points, then S_(n+j) - S_j) gives the
+    very points mzk_srs_generate_lagrange_for_testing computes from beta -- standard generator and a base point of the caller's."""
+    c = mj.params.CURVES[curve_id]
+    n = 1 << log_n
+    beta = 0x5eed0123456789abcdef00112233445566778899 % c.r
+    for g in (None, "rand"):
+        if g == "rand":
+            g = mj.rng.g1_rand(c, mj.rng.test_rng())
+        ck = mj.UnivariateProverParam.gen_srs_for_testing(c, beta, n + 2, g=g)
+        want = mj.UnivariateProverParam.gen_lagrange_srs_for_testing(c, beta, n, n_extra=3, g=g)
+        got = ck.lagrange_key(n, n_extra=3)
+        assert np.array_equal(got.powers_of_g(), want.powers_of_g()), (log_n, g is None)
+        for p in (ck, want, got):
+            p.release()
+
+
 def test_msm_batch_fused(gpu, mj, cref):
     """mzk_msm_batch / mzk_msm_batch_dev: MSMs of different lengths (two window sizes, an empty one)
     in one call equal the single calls and the oracle."""
