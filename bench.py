@@ -376,7 +376,8 @@ def main():
         round3()
         whole_ms = median_ms(round3)
         pk.release()
-        # the default path of both hosts: the W + 1 = 6 needed residue classes, class by class, then the inverse Vandermonde
+        # the default path of both hosts: W = 5 residue classes, class by class, the W + 3 top coefficients from the numerator's factors, then
+        # the inverse Vandermonde (random polynomials here: what is timed is the work, the result is not a quotient)
         needed = mj.plonk.quotient_classes_needed(5, pn)
         t1 = time.perf_counter()
         pk = mj.plonk.ProvingKeyDevice.register(curve, pn, list(fixed[:13]), list(fixed[13:]), [1, 2, 3, 4, 5], classes=needed)
@@ -386,7 +387,8 @@ def main():
 
         def round3_classes():
             mj.plonk.compute_quotient_chunked_dev(pk, ch, d_rows, pn + 3, out_dev=d_rem)
-            mj.plonk.combine_quotient_classes(curve, pn, d_rem, classes=needed, out_dev=d_out)
+            top = mj.plonk.compute_quotient_top_dev(pk, ch, d_rows, pn + 3)
+            mj.plonk.combine_quotient_classes(curve, pn, d_rem, classes=needed, out_dev=d_out, top=top, n_top=8)
         round3_classes()
         r3_wall = median_ms(round3_classes) * 1e-3
         L.mzk_profile_reset()                          # one more pass with the library's event timers on (they cost time: not in round3_ms)
@@ -396,9 +398,12 @@ def main():
         L.mzk_profile_enable(0)
         qk_ms, qk_cnt = mlib.profile_get("plonk_quotient_kernel")
         L.mzk_profile_reset()
-        plonk = {"what": "TurboPlonk round 3 without commitments, the default path: per needed residue class (6 of 8) fold + 7 coset NTT(n) + fused "
-                         "quotient kernel + inverse coset NTT(n), then the inverse Vandermonde per coefficient; `whole_domain_ms` = 7 coset NTT(8n) + "
-                         "kernel on 8n points + coset iNTT(8n), the round-1 path; selector/sigma evaluations resident per proving key",
+        plonk = {"what": "TurboPlonk round 3 without commitments on RANDOM polynomials (every selector non-zero, a public-input polynomial), the default "
+                         "path: per residue class (5 of 8) 7 coset NTT(n) read in place + fused quotient kernel + inverse coset NTT(n), the top 8 "
+                         "coefficients from the numerator's factors, then the inverse Vandermonde per coefficient; `whole_domain_ms` = 7 coset NTT(8n) + "
+                         "kernel on 8n points + coset iNTT(8n), the round-1 path; selector/sigma evaluations resident per proving key.  (In a proof of "
+                         "the bench circuit -- additions only, no public input -- the kernel skips the zero selectors and the round takes `prove."
+                         "rounds_ms.r3_quotient`.)",
                  "log_n": pl, "classes": len(needed), "round3_ms": round(r3_wall * 1e3, 3), "whole_domain_ms": round(whole_ms, 3),
                  "quotient_kernel_ms_per_class": round(qk_ms / max(qk_cnt, 1), 3), "pk_register_s": round(t_pk, 3)}
         pk.release()
@@ -444,6 +449,17 @@ def main():
                 mj.snark.prove(rng, circuit, prover)
             torch.cuda.synchronize()
             return (time.perf_counter() - ta) / k * 1e3
+        # round 1 from the masked COEFFICIENT forms, as the reference commits (univariate_kzg/mod.rs:90-116): the same prover without its
+        # Lagrange-basis key
+        lag_key, prover.lagrange_ck = prover.lagrange_ck, None
+        coeff_ms = timed_proofs(cs, reps)
+        coeff_core, coeff_bytes = mj.snark.prove(mj.rng.test_rng(), cs, prover, profile=True)
+        prover.lagrange_ck = lag_key
+        coeff_same = bool(coeff_bytes == mj.snark.prove(mj.rng.test_rng(), cs, prover)[1])
+        tl = time.perf_counter()
+        tmp_key = ck.lagrange_key(pn)
+        lagrange_key_s = time.perf_counter() - tl
+        tmp_key.release()
         # (i) the witness starts in page-locked HOST memory, as the reference holds it (constraint_system.rs:1225-1247 gathers it on the
         # host): every proof uploads its 5 x n x 32 B, wire k + 1 under the iNTT of wire k (prover.py _stage_round1)
         import dataclasses
@@ -473,6 +489,14 @@ def main():
                  "log_n": pl, "prove_ms": round(prove_ms, 2), "reps": reps, "min_ms": round(min(each), 2), "median_ms": round(sorted(each)[len(each) // 2], 2),
                  "max_ms": round(max(each), 2),
                  "ns_per_gate": round(prove_ms * 1e6 / pn, 1), "rounds_ms": core.timings_ms, "proof_bytes": len(proof_bytes),
+                 "round1_commit": "Lagrange basis: the wire commitments are MSMs of the wire VALUES (plus two blinders) over [L_i(beta)]g, the key "
+                                  "derived from the SRS's own points by an inverse NTT over the group at preprocess (`lagrange_key_s`, once per SRS "
+                                  "and domain; its fixed-base table is a second %.1f GB).  Same group elements, same proof bytes.  The bench circuit's "
+                                  "values are 0, 1, 2, .. / all ones / zeros: small scalars whose high digits cost nothing -- a DENSE witness gains "
+                                  "nothing (`dense_witness_ms`).  `coefficient_commit_ms` is the same proof with round 1 committed from the masked "
+                                  "coefficient forms, as the reference does" % (13 * (pn + 3) * 112 / 1e9),
+                 "lagrange_key_s": round(lagrange_key_s, 3),
+                 "coefficient_commit_ms": round(coeff_ms, 2), "coefficient_commit_rounds_ms": coeff_core.timings_ms, "coefficient_commit_same_proof_bytes": coeff_same,
                  "from_host_witness_ms": round(host_ms, 2), "from_host_witness_same_proof_bytes": host_bytes_same,
                  "from_host_witness_vector_ms": round(vec_ms, 2),
                  "from_host_witness_note": "`prove_ms` has the 5 x n wire values already in HBM.  from_host_witness_ms: they start in page-locked host "
@@ -481,8 +505,9 @@ def main():
                                            "(constraint_system.rs:1225-1247) is gathered on the device over the resident index table"
                                            % (5 * pn * 32 / 1e6, n_vars * 32 / 1e6),
                  "dense_witness_ms": round(dense_ms, 2), "dense_witness_rounds_ms": dense_core.timings_ms,
-                 "dense_witness_note": "same gates (selectors), random satisfying witness: all five wire polynomials dense (the bench circuit "
-                                       "commits two zero and two sparse wire polynomials in round 1)",
+                 "dense_witness_note": "same gates (selectors), random satisfying witness: all five wire polynomials dense and all wire values "
+                                       "random field elements (the bench circuit's values are small numbers; in coefficient form two of its wire "
+                                       "polynomials are zero and two sparse)",
                  "circuit_build_s": round(t_circ, 3), "preprocess_s": round(t_pre, 3),
                  "reference_published": "29591 ns/gate at 2^15 gates, 24 threads of a 5900X (bench.md:16); not comparable hardware"}
         prover.release()
@@ -668,6 +693,7 @@ def main():
         # ... and at the reference's own bench size (NUM_GATES_LARGE = 32768, plonk/benches/bench.rs:26), whose published CPU figures
         # are 29 591 (TurboPlonk, BLS12-381) and 33 701 (UltraPlonk, BN254) ns per constraint on 24 threads of a 5900X (bench.md)
         for name, argv in (("turbo_bls12_381", ["0", "turbo", str(1 << args.plonk_log_n), "10"]),
+                           ("turbo_bls12_381_coefficient_commit", ["0", "turbo", str(1 << args.plonk_log_n), "10", "--no-lagrange"]),
                            ("turbo_bls12_381_host_witness", ["0", "turbo", str(1 << args.plonk_log_n), "10", "--host-witness"]),
                            ("turbo_bls12_381_host_witness_vector", ["0", "turbo", str(1 << args.plonk_log_n), "10", "--host-witness-vars"]),
                            ("ultra_bn254", ["1", "ultra", str(1 << (args.ultra_log_n or args.plonk_log_n)), "10"]),

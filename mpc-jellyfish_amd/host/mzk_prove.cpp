@@ -23,8 +23,9 @@ struct Options {
     int host_witness = 0;         // --host-witness: every proof uploads its W x n wire values from page-locked host memory;
                                   // --host-witness-vars: only the witness vector, gathered per wire on the device
     bool check_agree = false;     // --check-agree: every rank's proof bytes are compared (tests)
-    bool lagrange = true;         // round 1 commits the wires from their VALUES over the Lagrange-basis key derived from the SRS (same proof
-                                  // bytes); --no-lagrange: from the masked coefficient forms, as the reference does
+    int lagrange = -1;            // round 1 commits the wires from their VALUES over the Lagrange-basis key derived from the SRS (same proof
+                                  // bytes): -1 = from 2^13 gates on (below, small scalars only add latency), --lagrange = always,
+                                  // --no-lagrange = never (from the masked coefficient forms, as the reference does)
 };
 
 template <class C>
@@ -44,7 +45,8 @@ int run(bool ultra, uint64_t num_gates, int reps, int range_bits, const Options&
     ShardedProver<C> sp(opt.gpus);
     double circuit_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     t0 = std::chrono::steady_clock::now();
-    sp.setup(host, beta_c, opt.host_witness, opt.lagrange);                           // SRS, circuit upload and PlonkKzgSnark::preprocess on every device
+    const bool lagrange = opt.lagrange < 0 ? host.log_n >= 13 : opt.lagrange != 0;
+    sp.setup(host, beta_c, opt.host_witness, lagrange);                           // SRS, circuit upload and PlonkKzgSnark::preprocess on every device
     const double preprocess_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     Proof<C> proof = sp.prove(rng, false, opt.check_agree);             // the proof whose bytes are printed (and warm-up)
     const std::vector<uint8_t> bytes = proof.serialize_compressed();
@@ -64,7 +66,7 @@ int run(bool ultra, uint64_t num_gates, int reps, int range_bits, const Options&
     for (uint8_t b : bytes) { hex.push_back(d[b >> 4]); hex.push_back(d[b & 15]); }
     std::printf("{\"curve\": %d, \"plonk_type\": \"%s\", \"num_gates\": %llu, \"log_n\": %d, \"gpus\": %d, \"host_witness\": %s, \"lagrange_round1\": %s, \"proof_bytes\": %zu, "
                 "\"prove_ms\": %.3f, \"circuit_build_s\": %.3f, \"preprocess_s\": %.3f, \"lagrange_key_s\": %.3f, \"rounds_ms\": {",
-                C::ID, ultra ? "UltraPlonk" : "TurboPlonk", (unsigned long long)num_gates, host.log_n, opt.gpus, opt.host_witness == 0 ? "false" : (opt.host_witness == 1 ? "\"wire table\"" : "\"witness vector\""), opt.lagrange ? "true" : "false",
+                C::ID, ultra ? "UltraPlonk" : "TurboPlonk", (unsigned long long)num_gates, host.log_n, opt.gpus, opt.host_witness == 0 ? "false" : (opt.host_witness == 1 ? "\"wire table\"" : "\"witness vector\""), lagrange ? "true" : "false",
                 bytes.size(), ms, circuit_s, preprocess_s, sp.lagrange_key_s);
     bool first = true;
     for (auto& kv : prover.timings_ms) { std::printf("%s\"%s\": %.3f", first ? "" : ", ", kv.first.c_str(), kv.second); first = false; }
@@ -153,8 +155,8 @@ int main(int argc_in, char** argv_in) {
         else if (a == "--host-witness") opt.host_witness = 1;
         else if (a == "--host-witness-vars") opt.host_witness = 2;
         else if (a == "--check-agree") opt.check_agree = true;
-        else if (a == "--lagrange") opt.lagrange = true;
-        else if (a == "--no-lagrange") opt.lagrange = false;
+        else if (a == "--lagrange") opt.lagrange = 1;
+        else if (a == "--no-lagrange") opt.lagrange = 0;
         else args.push_back(argv_in[i]);
     }
     const int argc = (int)args.size();

@@ -149,12 +149,16 @@ class HostWitness:
     wire_variables: object
 
 
+LAGRANGE_MIN_DOMAIN = 1 << 13          # preprocess(lagrange=None): round 1 over the Lagrange basis from this domain size on
+
+
 def preprocess(commit_key: kzg.UnivariateProverParam, circuit: BenchCircuit, quotient_classes=None, quotient_gather=None,
-               quotient_shard=None, lagrange: bool = True) -> _prover.TurboPlonkProver:
+               quotient_shard=None, lagrange: bool | None = None) -> _prover.TurboPlonkProver:
     """snark.rs:529-617: interpolate selectors, sigmas (and Plookup tables), keep them with the commit key.  The
     verifying-key commitments are produced on demand by `TurboPlonkProver.vk_commitments()`.  lagrange: also derive the commit key over
     the Lagrange basis of the gate domain from the SRS's points (kzg.UnivariateProverParam.lagrange_key) -- round 1 then commits the
-    wires from their values (same commitments; single-process proving)."""
+    wires from their values (same commitments; single-process proving).  None: from 2^13 gates on (below, an MSM is a chain of
+    latencies and small scalars only add over-long buckets to it: 2.0 against 0.9 ms for round 1 at 2^10 gates)."""
     c, n = circuit.curve, circuit.n
     if commit_key.length < n + 3:
         raise ValueError("SRS too small: need domain size + 3 powers (srs.rs:88)")          # snark.rs:535-541
@@ -174,6 +178,8 @@ def preprocess(commit_key: kzg.UnivariateProverParam, circuit: BenchCircuit, quo
         plookup = {name: tab_h[i] for i, name in enumerate(("range_table_poly", "key_table_poly", "table_dom_sep_poly", "q_dom_sep_poly"))}
     pk = _prover.TurboPlonkProver(c, n, list(host(sel)), list(host(sig)), circuit.k, commit_key, plookup=plookup,
                                   quotient_classes=quotient_classes, quotient_gather=quotient_gather, quotient_shard=quotient_shard)
+    if lagrange is None:
+        lagrange = n >= LAGRANGE_MIN_DOMAIN
     if lagrange and quotient_shard is None and quotient_gather is None and commit_key.offset == 0:
         pk.lagrange_ck = commit_key.lagrange_key(n)
     return pk

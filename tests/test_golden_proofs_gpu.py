@@ -56,7 +56,7 @@ def test_golden_proofs_with_round_1_committed_over_the_lagrange_basis(gpu, mj, n
         srs_beta, g = mj.rng.fr_rand(c, rng), None
     ck = mj.UnivariateProverParam.gen_srs_for_testing(c, srs_beta, cs.n + 2, g=g)
     for mode in ("from the SRS", "from beta", "off"):
-        pk = mj.snark.preprocess(ck, cs, lagrange=mode == "from the SRS")
+        pk = mj.snark.preprocess(ck, cs, lagrange=mode == "from the SRS")           # (None, the default: from 2^13 gates on)
         assert (pk.lagrange_ck is not None) == (mode == "from the SRS")
         if mode == "from beta":
             pk.lagrange_ck = mj.UnivariateProverParam.gen_lagrange_srs_for_testing(c, srs_beta, cs.n, g=g)

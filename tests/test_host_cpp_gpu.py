@@ -18,7 +18,7 @@ def test_cpp_host_prove_matches_python_mirror(gpu, mj, curve_id, plonk_type, num
     if not os.path.exists(BIN):                                        # normally built by __graft_entry__.build(); g++ is in the image
         subprocess.check_call(["make", "-C", os.path.join(ROOT, "mpc-jellyfish_amd", "host"), "-s"])
     assert os.path.exists(BIN)
-    out = subprocess.run([BIN, str(curve_id), "ultra" if plonk_type == "UltraPlonk" else "turbo", str(num_gates), "0", str(range_bits)],
+    out = subprocess.run([BIN, str(curve_id), "ultra" if plonk_type == "UltraPlonk" else "turbo", str(num_gates), "0", str(range_bits), "--lagrange"],
                          capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stderr[-2000:]
     got = json.loads(out.stdout.strip().splitlines()[-1])
@@ -30,8 +30,8 @@ def test_cpp_host_prove_matches_python_mirror(gpu, mj, curve_id, plonk_type, num
     _, proof_bytes = mj.snark.prove(rng, cs, pk)
     assert got["log_n"] == cs.n.bit_length() - 1
     assert got["proof_hex"] == proof_bytes.hex()
-    # the default commits round 1 from the wire VALUES over the Lagrange-basis key derived from the SRS; --no-lagrange from the masked
-    # coefficient forms, as the reference does: same proof
+    # --lagrange (the default from 2^13 gates on) commits round 1 from the wire VALUES over the Lagrange-basis key derived from the SRS;
+    # --no-lagrange from the masked coefficient forms, as the reference does: same proof
     assert got["lagrange_round1"] is True
     out = subprocess.run([BIN, str(curve_id), "ultra" if plonk_type == "UltraPlonk" else "turbo", str(num_gates), "0", str(range_bits), "--no-lagrange"],
                          capture_output=True, text=True, timeout=600)
