@@ -228,6 +228,8 @@ class TurboPlonkProver:
         self.ultra = plookup is not None
         self.committer = None                        # set to a sharding.ShardedCommitter for multi-GPU commits
         self.lagrange_ck = None                      # kzg.UnivariateProverParam.gen_lagrange_srs_for_testing(...): round 1 commits from the wire VALUES
+        self.identity_check = True                   # check_quotient_identity at the end of a proof (tools/scale_model.py times rank 0's share of a
+                                                     # multi-rank proof with stand-in exchanges and turns it off)
         self.range_mode = True                       # several ranks: rounds 4 and 5 work on this rank's coefficient range only
         self.W = len(sigma_polys)
         self.nsel = len(selector_polys)
@@ -802,7 +804,8 @@ class TurboPlonkProver:
             open_comms = self._commit([opening, shifted])
             tick("r5_commit", t0)
             self._batch_at_zeta = fr_from_mont(c, rem.cpu().numpy().view(np.uint64))[0]      # (the commitments have synchronised the stream)
-        self.check_quotient_identity(self._batch_at_zeta, self._lin_poly_constant(st), self._opened_evals(st), v_ch)
+        if self.identity_check:
+            self.check_quotient_identity(self._batch_at_zeta, self._lin_poly_constant(st), self._opened_evals(st), v_ch)
         self.last_challenges = {"tau": tau, "beta": beta, "gamma": gamma, "alpha": alpha, "zeta": zeta, "v": v_ch}
         self.last = {"wire_polys": st.wire_polys, "z_poly": st.z_poly, "quot": quot, "split": split, "lin": lin, "opening": opening, "shifted": shifted}
         if ultra:

@@ -8,7 +8,7 @@ and per G it measures, on this one GPU, exactly what rank 0 of a G-rank run exec
   commits      every batch_commit of the proof (round 1: W wires; 1.5: h_1, h_2; 2: z; 2.5: Plookup product; 3: W split-quotient
                parts; 5: two openings) as ONE mzk_msm_batch_dev over the rank's point range [0, len / G) of every polynomial
                (sharding.ShardedCommitter), on the SRS's fixed-base table;
-  quotient     the rank's ceil(needed / G) residue classes (needed = W + 1 of the 8) through mzk_plonk_quotient_chunked_dev, and
+  quotient     the rank's ceil(needed / G) residue classes (needed = W of the 8) through mzk_plonk_quotient_chunked_dev, the top coefficients and
                the inverse-Vandermonde combine every rank runs after the exchange;
   ranged       rounds 4 and 5 (evaluations; linearisation + batch polynomials, their division by (X - z)) on the rank's
                coefficient range only (prover.py _RangeEvals / _openings_ranged): timed in a real proof whose committer reports
@@ -20,7 +20,7 @@ and it ADDS, from stated constants (not measurable on one GPU):
   collectives  one small all-gather per commit group (k x 144 / 96 bytes per rank) at SMALL_COLLECTIVE_US each, and the one
                exchange of class remainders: (G - 1) x classes_per_rank x n x 32 bytes received per rank at XGMI_GBPS.
 
-    python tools/scale_model.py [--c5-log-n 22] > profiles/r02_scale_model.json
+    python tools/scale_model.py [--c5-log-n 22] > profiles/r03_scale_model.json
 """
 import argparse
 import json
@@ -91,6 +91,9 @@ def model(mj, curve, plonk_type, log_n):
     for _ in range(3):
         mj.snark.prove(rng, cs, pk)
     torch.cuda.synchronize()
+    import gc
+    gc.collect()                                                     # (the interpreter's first full collection would land in a timed proof: bench.py)
+    gc.freeze()
     t0 = time.perf_counter()
     for _ in range(5):
         mj.snark.prove(rng, cs, pk)
@@ -101,6 +104,7 @@ def model(mj, curve, plonk_type, log_n):
     needed = list(pk.classes_needed)
     ranged_keys = ["r4_evals", "r5_polys"]
     ranged_ms = {1: sum(rounds[k] for k in ranged_keys)}
+    pk.identity_check = False                                        # (RankZero's exchanged values are stand-ins)
     for G in (2, 4, 8):
         pk.committer = RankZero(mj, ck, G)
         samples = []
@@ -123,6 +127,12 @@ def model(mj, curve, plonk_type, log_n):
         groups.append(("r2_5_prod_lookup", 1, n + 3))
     groups += [("r3_split_quotient", W, n + 3), ("r5_openings", 2, n + 2)]
     scal = torch.from_numpy(mj.params.random_fr_mont(c, n + 3, seed=5).view(np.int64)).cuda()
+    # round 1 is committed from the wire VALUES over the Lagrange-basis key (both hosts from 2^13 gates on; the compiled host shards it by
+    # point range like every other commitment): rows of n values + 2 blinders
+    lag = ck.lagrange_key(n)
+    ext = torch.zeros((W, n + 3, 4), dtype=torch.int64, device="cuda")
+    ext[:, :n] = cs.wire_values
+    ext[:, n:n + 2] = scal[:2]
     out = {"config": {"plonk_type": plonk_type, "curve": c.name, "log_n": log_n, "classes_needed": len(needed)},
            "measured_one_gpu": {"prove_ms": round(prove1_ms, 2), "rounds_ms": rounds, "replicated_ms": round(replicated_ms, 2),
                                 "replicated_stages": replicated_keys},
@@ -137,19 +147,26 @@ def model(mj, curve, plonk_type, log_n):
             slab = torch.from_numpy(mj.params.random_fr_mont(c, rows * (n + 3), seed=6).view(np.int64).reshape(rows, n + 3, 4)).cuda()
         ch = mj.plonk.Challenges(0x1234567, 0x89abcde, 0xf012345, 0x1357911)
         res = torch.empty((per, n, 4), dtype=torch.int64, device="cuda")
-        class_ms[per] = median_ms(lambda: mj.plonk.compute_quotient_chunked_dev(key.pk, ch, slab, n + 3, out_dev=res))
+        class_ms[per] = median_ms(lambda: mj.plonk.compute_quotient_chunked_dev(key.pk, ch, slab, n + 3, out_dev=res, pi_zero=True))
+        if per == len(needed):
+            top_ms = median_ms(lambda: mj.plonk.compute_quotient_top_dev(key.pk, ch, slab, n + 3))
         key.release()
         del key, res
         torch.cuda.empty_cache()
     rem = torch.from_numpy(mj.params.random_fr_mont(c, len(needed) * n, seed=7).view(np.int64).reshape(len(needed), n, 4)).cuda()
     quot = torch.empty((8 * n, 4), dtype=torch.int64, device="cuda")
-    combine_ms = median_ms(lambda: mj.plonk.combine_quotient_classes(c, n, rem, classes=needed, out_dev=quot))
+    top = torch.from_numpy(mj.params.random_fr_mont(c, 16, seed=8).view(np.int64)).cuda()
+    combine_ms = top_ms + median_ms(lambda: mj.plonk.combine_quotient_classes(c, n, rem, classes=needed, out_dev=quot, top=top, n_top=W + 3))
     del rem, quot
     point_bytes = 3 * c.fq_limbs * 8
     for G in (1, 2, 4, 8):
         commits = {}
         for name, k, length in groups:
             hi = length // G if G > 1 else length                       # rank 0's point range [0, len / G)
+            if name == "r1_wires":
+                sets = [ext[i, :hi] for i in range(W)]
+                commits[name] = round(median_ms(lambda: mj.msm_bigint_batch(lag, sets, scalars_are_mont=True)), 3)
+                continue
             sets = [scal[:hi]] * k
             commits[name] = round(median_ms(lambda: mj.msm_bigint_batch(ck, sets, scalars_are_mont=True)), 3)
         per = -(-len(needed) // G)
@@ -166,6 +183,7 @@ def model(mj, curve, plonk_type, log_n):
     for G in ("1", "2", "4", "8"):
         out["per_G"][G]["speedup_vs_1"] = round(base / out["per_G"][G]["predicted_prove_ms"], 2)
     out["model_vs_measured_at_G1"] = round(base / prove1_ms, 3)
+    lag.release()
     ck.release()
     return out
 
