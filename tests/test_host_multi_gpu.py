@@ -29,7 +29,7 @@ def _prove(curve_id, kind, gates, gpus, extra=(), reps="0"):
 @pytest.mark.parametrize("curve_id,kind,gates", [(0, "turbo", 1024), (1, "ultra", 600), (0, "turbo", 64), (1, "turbo", 8192)])
 def test_virtual_devices_emit_the_single_device_proof(gpu, curve_id, kind, gates):
     one = _prove(curve_id, kind, gates, 1)
-    for g in (2, 3, 4, 8):                                   # 3: an uneven class split (2 + 2 + 2 of 6, 3 + 3 + 1 of 7); 8: ranks that own no class
+    for g in (2, 3, 4, 8):                                   # 3: an uneven class split (2 + 2 + 1 of 5, 2 + 2 + 2 of 6); 8: ranks that own no class; 8192 gates: round 1 over the Lagrange-basis key, sharded
         many = _prove(curve_id, kind, gates, g)
         assert many["gpus"] == g and many["proof_hex"] == one["proof_hex"] and many["vk_hex"] == one["vk_hex"], (curve_id, kind, gates, g)
 
@@ -46,6 +46,10 @@ def test_host_resident_witness_same_bytes(gpu):
     assert _prove(0, "turbo", 4096, 3, ["--host-witness-vars"], reps="2")["proof_hex"] == base["proof_hex"]
     ultra = _prove(1, "ultra", 600, 1)
     assert _prove(1, "ultra", 600, 2, ["--host-witness-vars"])["proof_hex"] == ultra["proof_hex"]
+    # ... and with round 1 committed from those uploaded / gathered VALUES over the Lagrange-basis key (forced on below 2^13 gates)
+    assert _prove(0, "turbo", 4096, 1, ["--host-witness", "--lagrange"], reps="2")["proof_hex"] == base["proof_hex"]
+    assert _prove(0, "turbo", 4096, 3, ["--host-witness-vars", "--lagrange"], reps="2")["proof_hex"] == base["proof_hex"]
+    assert _prove(1, "ultra", 600, 2, ["--lagrange"])["proof_hex"] == ultra["proof_hex"]
 
 
 def test_unsatisfied_witness_rejected_on_every_device(gpu):
