@@ -546,11 +546,19 @@ struct Prover {                                                        // Provin
         check(mzk_plookup_sorted_vec_dev(pk, st.wire_values, tau.l, table.p, lookup.p, sorted.p, nullptr), "mzk_plookup_sorted_vec_dev");
         check(mzk_dev_copy(hh.p, sorted.p, n * EL, nullptr), "copy");
         check(mzk_dev_copy(hh.at(n), sorted.at(n - 1), n * EL, nullptr), "copy");
+        if (srs_lagrange) {
+            // h_1, h_2 are committed from the sorted vector's VALUES (table entries and looked-up values: small numbers unless the circuit
+            // looks up keyed tables) plus their three blinders, over the Lagrange-basis key -- as the wires in round 1
+            if (!vals_ext.p) vals_ext.alloc((size_t)W * (n + 3));
+            check(mzk_dev_copy2d(vals_ext.p, (n + 3) * EL, hh.p, n * EL, n * EL, 2, nullptr), "copy2d");
+            for (int i = 0; i < 2; i++)
+                for (int j = 0; j < 3; j++) lincomb({{st.b.h[i][j], one_dev(), 1}}, vals_ext.at((size_t)i * (n + 3) + n + j), 1);
+        }
         check(mzk_ntt_dev(C::ID, hh.p, n, log_n, 1, nullptr, 2, n, nullptr), "mzk_ntt_dev");
         check(mzk_dev_copy2d(row(H1), (n + 3) * EL, hh.p, n * EL, n * EL, 2, nullptr), "copy2d");
         mask({H1, H1 + 1}, st.b.h);
         tick.mark("r1_5_sorted_vec");
-        auto comms = commit({row(H1), row(H1 + 1)}, {n + 3, n + 3});
+        auto comms = srs_lagrange ? commit({vals_ext.p, vals_ext.at(n + 3)}, {n + 3, n + 3}, srs_lagrange) : commit({row(H1), row(H1 + 1)}, {n + 3, n + 3});
         tick.mark("r1_5_commit");
         return comms;
     }

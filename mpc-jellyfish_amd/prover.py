@@ -403,12 +403,22 @@ class TurboPlonkProver:
         hh = torch.empty((2, n, 4), dtype=torch.int64, device=self.fixed.device)
         hh[0] = st.sorted_vec[:n]
         hh[1] = st.sorted_vec[n - 1:]
+        lagrange = self.lagrange_ck is not None and self.committer is None
+        if lagrange:                                                     # h_1, h_2 from the sorted vector's VALUES + three blinders each, as the wires in round 1
+            ext = self._vals_ext
+            ext[:2, :n] = hh
+            bl = fr_to_mont(self.curve, [b for row in st.blind.h for b in row]).view(np.int64).reshape(2, 3, 4)
+            ext[:2, n:n + 3] = torch.from_numpy(bl).to(hh.device)
         self.domain.ifft_in_place(hh)
         slab[st.H1:st.H1 + 2, :n] = hh
         self._mask(slab, [st.H1, st.H1 + 1], st.blind.h)
         tick("r1_5_sorted_vec", t0)
         t0 = time.perf_counter()
-        h_comms = self._commit([slab[st.H1, :n + 3], slab[st.H1 + 1, :n + 3]])
+        if lagrange:
+            jac = kzg.msm_bigint_batch(self.lagrange_ck, [ext[0, :n + 3], ext[1, :n + 3]], scalars_are_mont=True)
+            h_comms = [kzg.Commitment(self.curve, xy) for xy in kzg.jacobian_to_affine(self.curve, jac)]
+        else:
+            h_comms = self._commit([slab[st.H1, :n + 3], slab[st.H1 + 1, :n + 3]])
         tick("r1_5_commit", t0)
         return h_comms
 
