@@ -117,7 +117,7 @@ inline int handle_ctx(uint64_t h) { return (int)(h >> 48) - 1; }
 // d_patch (with d_src): 4 elements per batch entry that replace the input indices 0..3 (ntt_fx.cuh)
 int32_t ntt_dispatch(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool inverse, const uint32_t* coset,
                      uint32_t batch, uint64_t stride, hipStream_t st, int scale = 0, const uint32_t* d_src = nullptr, uint64_t src_stride = 0,
-                     const uint32_t* d_patch = nullptr);
+                     const uint32_t* d_patch = nullptr, int skip_batch = -1 /* a batch entry that is not transformed */);
 void ntt_release_plans();
 void msm_release_streams();
 // msm.hip

@@ -123,7 +123,7 @@ int32_t launch_pass(const NttxPassArgs& a, unsigned long long n_tiles, uint32_t 
     const bool tw_lds = !a.is_final && mode != 2;                         // (mode 2: persistent without LDS-staged twiddles)
     const size_t lds_p = lds + (tw_lds ? (((size_t)1 << a.log_r) - 1) * FS_TW_WORDS * 4 : 0);
     if (mode) MZK_TRY((tw_lds ? persistent_grid<X, true>(lds_p, &resident) : persistent_grid<X, false>(lds_p, &resident)));
-    if (mode && total >= 3ull * resident && tile <= 2 * NTTX_THREADS && !a.patch) {
+    if (mode && total >= 3ull * resident && tile <= 2 * NTTX_THREADS && !a.patch && a.skip_batch < 0) {
         int log_tiles = 0;
         while ((1ull << log_tiles) < n_tiles) log_tiles++;
         if (tw_lds) hipLaunchKernelGGL((nttx_pass_persistent_kernel<X, true>), dim3(resident), dim3(NTTX_THREADS), lds_p, st, a, log_tiles, total);
@@ -140,7 +140,8 @@ int32_t launch_pass(const NttxPassArgs& a, unsigned long long n_tiles, uint32_t 
 // then only receives the result; d_patch (nullable, needs d_src): 4 replacement elements per batch entry for the input indices 0..3
 template <class X>
 int32_t ntt_dev(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool inverse, const uint32_t* coset,
-                uint32_t batch, uint64_t stride, hipStream_t st, int scale, const uint32_t* d_src, uint64_t src_stride, const uint32_t* d_patch) {
+                uint32_t batch, uint64_t stride, hipStream_t st, int scale, const uint32_t* d_src, uint64_t src_stride, const uint32_t* d_patch,
+                int skip_batch) {
     if (log_n < 0 || log_n > X::TWO_ADICITY || log_n > 30) { set_error("log_n out of range"); return MZK_ERR_INVALID_ARG; }
     const uint64_t N = 1ull << log_n;
     if (batch == 0) return MZK_OK;
@@ -184,6 +185,7 @@ int32_t ntt_dev(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool in
         a.in = from_data ? (d_src ? const_cast<uint32_t*>(d_src) : d_data) : scratch;
         a.in_stride = from_data ? (d_src ? src_stride : stride) : N;
         a.patch = from_data ? d_patch : nullptr;
+        a.skip_batch = skip_batch;
         a.in_planes = from_data ? 0 : 1;
         a.out = to_data ? d_data : scratch;
         a.out_stride = to_data ? stride : N;
@@ -201,9 +203,10 @@ int32_t ntt_dev(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool in
 }  // namespace
 
 int32_t ntt_dispatch(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool inverse, const uint32_t* coset,
-                     uint32_t batch, uint64_t stride, hipStream_t st, int scale, const uint32_t* d_src, uint64_t src_stride, const uint32_t* d_patch) {
-    if (curve == MZK_CURVE_BLS12_381) return ntt_dev<BlsFrX>(curve, d_data, in_len, log_n, inverse, coset, batch, stride, st, scale, d_src, src_stride, d_patch);
-    if (curve == MZK_CURVE_BN254) return ntt_dev<BnFrX>(curve, d_data, in_len, log_n, inverse, coset, batch, stride, st, scale, d_src, src_stride, d_patch);
+                     uint32_t batch, uint64_t stride, hipStream_t st, int scale, const uint32_t* d_src, uint64_t src_stride, const uint32_t* d_patch,
+                     int skip_batch) {
+    if (curve == MZK_CURVE_BLS12_381) return ntt_dev<BlsFrX>(curve, d_data, in_len, log_n, inverse, coset, batch, stride, st, scale, d_src, src_stride, d_patch, skip_batch);
+    if (curve == MZK_CURVE_BN254) return ntt_dev<BnFrX>(curve, d_data, in_len, log_n, inverse, coset, batch, stride, st, scale, d_src, src_stride, d_patch, skip_batch);
     set_error("unknown curve_id");
     return MZK_ERR_INVALID_ARG;
 }

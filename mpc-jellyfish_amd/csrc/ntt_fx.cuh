@@ -53,6 +53,8 @@ struct NttxPassArgs {
     int is_first, is_final, n_pass;
     int skip;                  // first pass of a zero-padded input (in_len <= N >> skip): the first `skip` stages are copies
     int in_planes, out_planes; // 1: the 9-limb plane layout of the scratch buffer; 0: the boundary's packed 8 words
+    int skip_batch;            // -1, or a batch entry whose workgroups exit at once (the class-wise quotient transforms rows 0 .. W + 4 of a slab but
+                               // has no use for an all-zero public-input row in the middle of them)
     const uint32_t* patch;     // first pass, nullable: elements g < 4 of batch entry y are read from patch[y * 4 + g] (packed) instead of `in` --
                                // the class-wise quotient transforms p mod (X^n - c), which differs from p's first n coefficients in 2-3 places
     int log_radix[NTT_MAX_PASSES];
@@ -111,6 +113,7 @@ template <class X>
 __global__ __launch_bounds__(NTTX_THREADS) void nttx_pass_kernel(NttxPassArgs a) {
     static_assert(X::XN == 9 && X::N == 8, "256-bit scalar fields: 8 boundary words, 9 limbs of 29 bits");
     extern __shared__ int4 ldsx[];
+    if ((int)blockIdx.y == a.skip_batch) return;
     const int R = 1 << a.log_r, C = 1 << a.log_c, TILE = R * C;
     int4* da = ldsx;
     int4* db = da + TILE;

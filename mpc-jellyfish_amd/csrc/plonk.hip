@@ -522,21 +522,19 @@ int32_t quotient_chunked_run(const PlonkPk& pk, const uint32_t* d_polys, uint64_
         FrArg c_k;
         std::memcpy(c_k.l, pk.c_cls[k], 32);
         // evaluations on the class, in the internal form: size-n coset NTTs of p mod (X^n - c_k)
-        auto transform = [&](int first, int count) -> int32_t {             // rows first .. first + count - 1
+        auto transform = [&](int first, int count, int skip) -> int32_t {   // rows first .. first + count - 1, row `skip` left out
             if (patched)                                                    // read in place (not overwritten), elements 0..3 from the patch
                 return ntt_dispatch(pk.curve, work + (size_t)first * n * 8, n, pk.log_n, false, pk.h_cls[k], (uint32_t)count, n, st, 1,
-                                    d_polys + (size_t)first * in_stride * 8, in_stride, patch + (size_t)first * 4 * 8);
-            return ntt_dispatch(pk.curve, work + (size_t)first * n * 8, n, pk.log_n, false, pk.h_cls[k], (uint32_t)count, n, st, 1);
+                                    d_polys + (size_t)first * in_stride * 8, in_stride, patch + (size_t)first * 4 * 8, skip);
+            return ntt_dispatch(pk.curve, work + (size_t)first * n * 8, n, pk.log_n, false, pk.h_cls[k], (uint32_t)count, n, st, 1, nullptr, 0, nullptr, skip);
         };
         if (patched) hipLaunchKernelGGL((plonk_fold_patch_kernel<P>), dim3((rows * 4 + 63) / 64), dim3(64), 0, st, d_polys, in_stride, in_len, n, rows, c_k, patch);
         else hipLaunchKernelGGL((plonk_fold_kernel<P>), dim3((unsigned)((fold_threads + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st,
                                 d_polys, in_stride, in_len, n, rows, c_k, work);
         HIP_TRY(hipGetLastError());
-        if (!pi_zero) MZK_TRY(transform(0, rows));
-        else {
-            MZK_TRY(transform(0, pk.W + 1));
-            if (pk.ultra) MZK_TRY(transform(pk.W + 2, 3));
-        }
+        if (!pi_zero) MZK_TRY(transform(0, rows, -1));
+        else if (pk.ultra) MZK_TRY(transform(0, rows, pk.W + 1));          // one batch; the workgroups of the public-input row exit at once
+        else MZK_TRY(transform(0, pk.W + 1, -1));
         a.sel = pk.d_fixed + lc * n * 8;
         a.sig = pk.d_fixed + ((size_t)pk.nsel * ncl + lc) * n * 8;
         a.tab = pk.ultra ? pk.d_fixed + ((size_t)(pk.nsel + pk.W) * ncl + lc) * n * 8 : nullptr;

@@ -403,6 +403,17 @@ def test_error_paths(gpu, mj):
     assert L.mzk_ntt(1, sc.ctypes.data_as(C.c_void_p), 4, 29, 0, None) == -1                                         # beyond BN254's two-adicity
     assert L.mzk_plonk_pk_release(12345) == -4
     assert L.mzk_strerror(-8).startswith(b"Plookup")
+    # round-3 entry points: the Lagrange-basis key needs 2^log_n + n_extra points in the SRS; the quotient's top coefficients need a chunked
+    # proving key; the division with remainder needs somewhere to put it
+    h = C.c_uint64()
+    assert L.mzk_srs_lagrange_from_srs(pp.handle, 3, 3, C.byref(h)) == -1                                            # 8 + 3 > 8 points
+    assert L.mzk_srs_lagrange_from_srs(0xdead, 2, 1, C.byref(h)) == -4
+    assert L.mzk_srs_lagrange_from_srs(pp.handle, 2, 3, C.byref(h)) == 0 and L.mzk_srs_release(h.value) == 0
+    beta = np.array([5, 0, 0, 0], dtype=np.uint64)
+    assert L.mzk_srs_generate_lagrange_for_testing(0, beta.ctypes.data_as(C.c_void_p), None, 40, 3, C.byref(h)) == -1
+    assert L.mzk_srs_generate_lagrange_for_testing(0, beta.ctypes.data_as(C.c_void_p), None, 4, 99, C.byref(h)) == -1
+    assert L.mzk_plonk_quotient_top_dev(12345, None, 0, 0, None, None, None, None, None, None) == -4
+    assert L.mzk_poly_div_linear_rem_dev(0, None, 4, beta.ctypes.data_as(C.c_void_p), None, None, None) == -1
     released = pp.handle
     pp.release()
     assert L.mzk_srs_release(released) == -4, "releasing a handle twice is an error, not a crash"              # MZK_ERR_BAD_HANDLE
