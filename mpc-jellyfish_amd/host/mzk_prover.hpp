@@ -493,7 +493,7 @@ struct Prover {                                                        // Provin
         if (!cs.host_witness) {
             st.wire_values = cs.wire_values.p;
             check(mzk_dev_copy(coeff.p, cs.wire_values.p, (size_t)W * n * EL, nullptr), "copy");
-            check(mzk_ntt_dev(C::ID, coeff.p, n, log_n, 1, nullptr, W + 1, n, nullptr), "mzk_ntt_dev");
+            check(mzk_ntt_dev(C::ID, coeff.p, n, log_n, 1, nullptr, W, n, nullptr), "mzk_ntt_dev");   // (the zero public-input row needs no transform)
         } else if (cs.host_witness == 2) {
             // the witness vector crosses PCIe; `witness[wire_variable(i, j)]` (constraint_system.rs:1239) is gathered on the device
             if (!wv.p) { wv.alloc((size_t)W * n); wit.alloc(cs.n_vars); check(mzk_stream_create(&copy_stream), "mzk_stream_create"); }
@@ -503,14 +503,13 @@ struct Prover {                                                        // Provin
             check(mzk_stream_wait_stream(nullptr, copy_stream), "wait");
             check(mzk_plonk_gather_witness_dev(wit.p, cs.n_vars, cs.wire_variables.p, (uint64_t)W * n, wv.p, nullptr), "mzk_plonk_gather_witness_dev");
             check(mzk_dev_copy(coeff.p, wv.p, (size_t)W * n * EL, nullptr), "copy");
-            check(mzk_ntt_dev(C::ID, coeff.p, n, log_n, 1, nullptr, W + 1, n, nullptr), "mzk_ntt_dev");
+            check(mzk_ntt_dev(C::ID, coeff.p, n, log_n, 1, nullptr, W, n, nullptr), "mzk_ntt_dev");   // (the zero public-input row needs no transform)
         } else {
             // host-resident witness (constraint_system.rs:1225-1247 gathers it on the host): column i + 1 crosses PCIe on a copy
             // stream while column i is transformed on the null stream
             if (!wv.p) { wv.alloc((size_t)W * n); check(mzk_stream_create(&copy_stream), "mzk_stream_create"); }
             st.wire_values = wv.p;
             check(mzk_stream_wait_stream(copy_stream, nullptr), "wait");                                     // the previous proof is done with `wv`
-            check(mzk_ntt_dev(C::ID, coeff.at((size_t)W * n), n, log_n, 1, nullptr, 1, n, nullptr), "mzk_ntt_dev");
             for (int i = 0; i < W; i++) {
                 check(mzk_dev_upload_async(wv.at((size_t)i * n), static_cast<const uint8_t*>(cs.host_wires.p) + (size_t)i * n * EL, n * EL, copy_stream), "upload");
                 check(mzk_stream_wait_stream(nullptr, copy_stream), "wait");                                 // columns 0..i have arrived

@@ -340,12 +340,12 @@ class TurboPlonkProver:
             poly.gather_witness(self._wit[:n_vars], hw.wire_variables, out=st.wv)
             coeff[:W] = st.wv
             coeff[W] = pv
-            self.domain.ifft_in_place(coeff)
+            self.domain.ifft_in_place(coeff[:W] if st.pi_zero else coeff)          # (iNTT of the zero vector is the zero vector)
         elif on_dev(wire_values):
             st.wv = wire_values
             coeff[:W] = st.wv
             coeff[W] = pv
-            self.domain.ifft_in_place(coeff)
+            self.domain.ifft_in_place(coeff[:W] if st.pi_zero else coeff)          # (iNTT of the zero vector is the zero vector)
         else:
             # HOST-resident witness: the reference gathers witness[wire_variable(i, j)] on the host and starts from there
             # (constraint_system.rs:1225-1247).  Wire k + 1 crosses PCIe on a copy stream while wire k is transformed; from
@@ -363,7 +363,8 @@ class TurboPlonkProver:
                     st.wv[i].copy_(hv[i], non_blocking=True)
                     self._wv_ev[i].record(self._copy_stream)
             coeff[W] = pv
-            self.domain.ifft_in_place(coeff[W:W + 1])
+            if not st.pi_zero:
+                self.domain.ifft_in_place(coeff[W:W + 1])
             for i in range(W):
                 main.wait_event(self._wv_ev[i])
                 coeff[i] = st.wv[i]
