@@ -473,6 +473,20 @@ struct LongDesc { uint32_t bucket, start, len, idx_in_run, run_len; };
 // MSM_HEAVY_FANIN items each), the last of which adds into the bucket.  dest: bit 31 set = slot of the next level's parts.
 struct HeavyRun { uint32_t src, n, dest; };
 constexpr uint32_t MSM_HEAVY_DEST_PART = 0x80000000u;
+// the heavy kernels of the MSMs of ONE batch run as one launch per level (blockIdx.z = MSM): their chains of a few dozen dependent
+// additions are latency, and five of them in sequence were 1.6 of the 3.6 ms of a round 1 committed from small witness values
+constexpr int MSM_HEAVY_JOBS = 8;
+struct HeavyJob {
+    const uint32_t* bases;
+    const uint32_t* sorted;
+    unsigned long long n;              // stride between the windows' lists (0: one combined list)
+    const HeavyRun* runs;
+    const uint32_t* count;
+    uint32_t *h1, *h2, *h3, *buckets;
+    uint8_t* occ;
+    uint32_t run_cap, M;
+};
+struct HeavyJobs { HeavyJob j[MSM_HEAVY_JOBS]; };
 // counters of window w at heavy_count + w * MSM_HEAVY_COUNTERS: [0] level-1 runs, [1] level-B runs, [2] level-C runs, [3] parts of level 2, [4] of level 3
 __device__ __forceinline__ void msm_heavy_push(uint32_t b, uint32_t start, uint32_t rem, uint32_t run_cap, uint32_t* __restrict__ cnt,
                                                HeavyRun* __restrict__ runs0, HeavyRun* __restrict__ runsB, HeavyRun* __restrict__ runsC) {
@@ -563,39 +577,40 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_long_combine_kernel(const
 
 // level 1 of a heavy bucket: one workgroup per run of <= MSM_HEAVY_RUN entries, thread t sums entries [32 t, 32 t + 32) -> h1[run * 128 + t]
 template <class EC>
-__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_heavy_chunk_kernel(const uint32_t* __restrict__ bases, unsigned long long n, const uint32_t* __restrict__ sorted,
-                                                                           const HeavyRun* __restrict__ heavy_runs, const uint32_t* __restrict__ heavy_count,
-                                                                           uint32_t run_cap, uint32_t* __restrict__ h1) {
-    const uint32_t w = blockIdx.y, t = threadIdx.x;
-    const uint32_t cnt = min(heavy_count[(size_t)w * MSM_HEAVY_COUNTERS], run_cap);
-    const HeavyRun* runs = heavy_runs + (size_t)w * 3 * run_cap;
+__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_heavy_chunk_kernel(HeavyJobs jobs) {
+    const HeavyJob& jb = jobs.j[blockIdx.z];
+    const uint32_t w = blockIdx.y, t = threadIdx.x, run_cap = jb.run_cap;
+    const uint32_t cnt = min(jb.count[(size_t)w * MSM_HEAVY_COUNTERS], run_cap);
+    const HeavyRun* runs = jb.runs + (size_t)w * 3 * run_cap;
     for (uint32_t r = blockIdx.x; r < cnt; r += gridDim.x) {
         const HeavyRun run = runs[r];
         const uint32_t lo = t * MSM_HEAVY_PER_THREAD;
         if (lo >= run.n) continue;
         const uint32_t hi = min(run.n, lo + MSM_HEAVY_PER_THREAD);
-        const uint32_t* list = sorted + (size_t)w * n + run.src;
+        const uint32_t* list = jb.sorted + (size_t)w * jb.n + run.src;
         typename EC::Pt acc = EC::inf();
         for (uint32_t k = lo; k < hi; k++) {
             const uint32_t e = list[k];
-            acc = EC::madd(acc, EC::load_aff(bases, e & 0x7fffffffu), (e >> 31) != 0);
+            acc = EC::madd(acc, EC::load_aff(jb.bases, e & 0x7fffffffu), (e >> 31) != 0);
         }
-        EC::store_pt(h1, ((size_t)w * run_cap + r) * MSM_ACC_THREADS + t, acc);
+        EC::store_pt(jb.h1, ((size_t)w * run_cap + r) * MSM_ACC_THREADS + t, acc);
     }
 }
 // levels A (the 128 partial sums of a level-1 run), B and C (the runs of a bucket): a workgroup per run; a thread first sums the items
 // t, t + 128, .. of the run, then the 128 sums go through an LDS tree; the last level of a bucket stores into it (the regular
 // accumulation leaves a heavy bucket empty).  ONE call site of EC::add (see msm_split_combine_kernel).
 template <class EC>
-__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_heavy_reduce_kernel(const HeavyRun* __restrict__ heavy_runs, const uint32_t* __restrict__ heavy_count,
-                                                                            uint32_t run_cap, int level /* 0 = A, 1 = B, 2 = C */,
-                                                                            const uint32_t* __restrict__ parts_in, uint32_t* __restrict__ parts_out, uint32_t M,
-                                                                            uint32_t* __restrict__ buckets, uint8_t* __restrict__ occ) {
+__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_heavy_reduce_kernel(HeavyJobs jobs, int level /* 0 = A, 1 = B, 2 = C */) {
     __shared__ uint32_t lds[MSM_ACC_THREADS * EC::PT_WORDS];
-    const uint32_t w = blockIdx.y;
+    const HeavyJob& jb = jobs.j[blockIdx.z];
+    const uint32_t w = blockIdx.y, run_cap = jb.run_cap, M = jb.M;
     const int tid = threadIdx.x;
-    const uint32_t cnt = min(heavy_count[(size_t)w * MSM_HEAVY_COUNTERS + level], run_cap);
-    const HeavyRun* runs = heavy_runs + ((size_t)w * 3 + level) * run_cap;
+    const uint32_t* parts_in = level == 0 ? jb.h1 : (level == 1 ? jb.h2 : jb.h3);
+    uint32_t* parts_out = level == 0 ? jb.h2 : jb.h3;
+    uint32_t* buckets = jb.buckets;
+    uint8_t* occ = jb.occ;
+    const uint32_t cnt = min(jb.count[(size_t)w * MSM_HEAVY_COUNTERS + level], run_cap);
+    const HeavyRun* runs = jb.runs + ((size_t)w * 3 + level) * run_cap;
     const size_t in_base = (size_t)w * run_cap * (level == 0 ? MSM_ACC_THREADS : 1), out_base = (size_t)w * run_cap;
     for (uint32_t r = blockIdx.x; r < cnt; r += gridDim.x) {
         const HeavyRun run = runs[r];

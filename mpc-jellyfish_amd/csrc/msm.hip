@@ -115,9 +115,15 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     // heavy buckets (msm.cuh): per window <= entries / MSM_HEAVY_RUN full level-1 runs plus one partial run per heavy bucket
     const uint32_t run_cap_max = (uint32_t)(2 * (sorted_max / MSM_HEAVY_RUN) + 2);
     const size_t heavy_runs_bytes = (size_t)n_win * 3 * run_cap_max * sizeof(HeavyRun);
-    MZK_TRY(g_ws.long_desc.reserve((size_t)n_win * desc_cap_max * sizeof(LongDesc) + (size_t)n_win * 4 * (1 + MSM_HEAVY_COUNTERS) + 16 + heavy_runs_bytes));
-    MZK_TRY(g_ws.long_parts.reserve((size_t)n_win * desc_cap_max * EC::PT_WORDS * 4 +
-                                    (size_t)n_win * run_cap_max * (MSM_ACC_THREADS + 2) * EC::PT_WORDS * 4));
+    // In a batch of at most SORT_SETS (and MSM_HEAVY_JOBS) MSMs every MSM keeps its own sorted list until the end, so their heavy
+    // kernels are deferred and run as ONE launch per level over all of them (msm.cuh, HeavyJobs): each MSM then needs its own
+    // descriptors, counters and partial sums ("slot").
+    const bool defer_heavy = count > 1 && (size_t)count <= nb && count <= MSM_HEAVY_JOBS;
+    const size_t slots = defer_heavy ? (size_t)count : 1;
+    const size_t desc_slot_bytes = (((size_t)n_win * desc_cap_max * sizeof(LongDesc) + (size_t)n_win * 4 * (1 + MSM_HEAVY_COUNTERS) + 16 + heavy_runs_bytes) + 255) & ~(size_t)255;
+    const size_t parts_slot_words = (size_t)n_win * desc_cap_max * EC::PT_WORDS + (size_t)n_win * run_cap_max * (MSM_ACC_THREADS + 2) * EC::PT_WORDS;
+    MZK_TRY(g_ws.long_desc.reserve(slots * desc_slot_bytes));
+    MZK_TRY(g_ws.long_parts.reserve(slots * parts_slot_words * 4));
     const unsigned long long dstride_max = (n_max + 7) & ~7ull;
     const size_t digits_bytes = (size_t)n_dig * dstride_max * ((pre.c || sort2) ? 4 : 2), sorted_words = ((size_t)n_dig * n_max + 3) & ~(size_t)3;
     MZK_TRY(g_ws.digits.reserve(nb * digits_bytes));
@@ -154,8 +160,10 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
         g_ws.h_collect_cap = out_bytes;
     }
     uint32_t* collect = g_ws.collect.as<uint32_t>();
-    LongDesc* desc = g_ws.long_desc.as<LongDesc>();
-    uint32_t* parts = g_ws.long_parts.as<uint32_t>();
+    HeavyJobs jobs;
+    std::memset(&jobs, 0, sizeof jobs);
+    uint32_t heavy_run_cap_max = 0;
+    bool heavy_level_c = false;
     hipStream_t sst = st;                                                // the stream the sorts run on
     SortStreams& ss = g_sort[cur().logical];
     if (overlap) {
@@ -202,6 +210,9 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
             }
             const uint32_t cap = (uint32_t)std::max<unsigned long long>(MSM_MIN_CAP, peak + 6 * (unsigned long long)std::sqrt((double)peak) + 8);
             const uint32_t desc_cap = (uint32_t)(n_sorted / cap + 1);
+            const size_t slot = defer_heavy ? (size_t)p : 0;
+            LongDesc* desc = reinterpret_cast<LongDesc*>(g_ws.long_desc.as<char>() + slot * desc_slot_bytes);
+            uint32_t* parts = g_ws.long_parts.as<uint32_t>() + slot * parts_slot_words;
             uint32_t* desc_count = reinterpret_cast<uint32_t*>(desc + (size_t)n_win * desc_cap);       // n_win words, then the heavy counters
             const uint32_t* heavy_count = desc_count + n_win;
             const uint32_t run_cap = (uint32_t)(2 * (n_sorted / MSM_HEAVY_RUN) + 2);
@@ -305,14 +316,29 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                                    dim3(MSM_ACC_THREADS), 0, st, desc, desc_count, desc_cap, M, parts, buckets, occ);
                 // heavy buckets: a workgroup per run of MSM_HEAVY_RUN entries, then workgroup trees (levels A, B; C only when a bucket can hold
                 // more than MSM_HEAVY_RUN * MSM_HEAVY_FANIN entries).  Every workgroup exits at once when there is no heavy bucket.
-                const dim3 hg(std::min<uint32_t>(run_cap, 2048u), n_win);
-                hipLaunchKernelGGL((msm_heavy_chunk_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, d_bases, list_stride, sorted, heavy_runs, heavy_count, run_cap, h1);
-                hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, heavy_runs, heavy_count, run_cap, 0, h1, h2, M, buckets, occ);
-                hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, heavy_runs, heavy_count, run_cap, 1, h2, h3, M, buckets, occ);
-                if (n_sorted > (uint64_t)MSM_HEAVY_RUN * MSM_HEAVY_FANIN)
-                    hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), dim3(64, n_win), dim3(MSM_ACC_THREADS), 0, st, heavy_runs, heavy_count, run_cap, 2, h3, h3, M, buckets, occ);
+                HeavyJob& jb = jobs.j[defer_heavy ? p : 0];
+                jb.bases = d_bases; jb.sorted = sorted; jb.n = list_stride; jb.runs = heavy_runs; jb.count = heavy_count;
+                jb.h1 = h1; jb.h2 = h2; jb.h3 = h3; jb.buckets = buckets; jb.occ = occ; jb.run_cap = run_cap; jb.M = M;
+                heavy_run_cap_max = std::max(heavy_run_cap_max, run_cap);
+                heavy_level_c = heavy_level_c || n_sorted > (uint64_t)MSM_HEAVY_RUN * MSM_HEAVY_FANIN;
+                if (!defer_heavy) {
+                    const dim3 hg(std::min<uint32_t>(run_cap, 2048u), n_win, 1);
+                    hipLaunchKernelGGL((msm_heavy_chunk_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, jobs);
+                    hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, jobs, 0);
+                    hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, jobs, 1);
+                    if (n_sorted > (uint64_t)MSM_HEAVY_RUN * MSM_HEAVY_FANIN)
+                        hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), dim3(64, n_win, 1), dim3(MSM_ACC_THREADS), 0, st, jobs, 2);
+                }
             }
             if (overlap) HIP_TRY(hipEventRecord(ss.ev_acc[b], st));
+        }
+        if (defer_heavy) {                                          // the heavy buckets of all MSMs of the batch, one launch per level
+            ProfScope ps("msm_long", st);
+            const dim3 hg(std::min<uint32_t>(heavy_run_cap_max, 2048u), n_win, (unsigned)count);
+            hipLaunchKernelGGL((msm_heavy_chunk_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, jobs);
+            hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, jobs, 0);
+            hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, jobs, 1);
+            if (heavy_level_c) hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), dim3(64, n_win, (unsigned)count), dim3(MSM_ACC_THREADS), 0, st, jobs, 2);
         }
         {
             ProfScope ps("msm_reduce", st);
