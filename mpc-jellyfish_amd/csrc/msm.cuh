@@ -30,7 +30,12 @@ constexpr int MSM_ACC_THREADS = 128;
 constexpr uint32_t MSM_HEAVY_PER_THREAD = 16;
 constexpr uint32_t MSM_HEAVY_RUN = MSM_ACC_THREADS * MSM_HEAVY_PER_THREAD;
 constexpr uint32_t MSM_HEAVY_FANIN = MSM_ACC_THREADS * 32;
-constexpr int MSM_HEAVY_COUNTERS = 5;
+constexpr int MSM_HEAVY_COUNTERS = 6;
+// a bucket is HEAVY when it holds more than MSM_HEAVY_RUN entries beyond the cap: its entries all go to the msm_heavy_* kernels (a workgroup
+// per run of MSM_HEAVY_RUN entries: worth it only for runs that fill it -- with the threshold at 2 or 4 caps, 2^20 32-bit scalars (4096
+// buckets of 256) went from 3.0 to 4.6 ms and 4096 repeated values from 5.8 to 21 ms); between the cap and that it is over-long: its first
+// `cap` entries stay with the regular accumulation, the rest with the msm_long_* kernels
+__host__ __device__ inline bool msm_is_heavy(uint32_t count, uint32_t cap) { return count > cap + MSM_HEAVY_RUN; }
 
 // window size of the plain path: ~log2(n) - 2 (mean bucket load ~8: short dependent chains, enough buckets to
 // fill the chip even for small n), clamped to [4, 16]
@@ -352,7 +357,7 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(const u
     // the rest of an over-long bucket: msm_long_* kernels; ALL of a heavy one: msm_heavy_* (a lone chain of `cap` additions would
     // outlast the whole launch)
     const uint32_t h = hist[t];
-    const uint32_t cnt = h > cap + MSM_HEAVY_RUN ? 0u : min(h, cap);
+    const uint32_t cnt = msm_is_heavy(h, cap) ? 0u : min(h, cap);
     const uint32_t* list = sorted + w * n + start;
     typename EC::Pt acc = EC::inf();
     for (uint32_t k = 0; k < cnt; k++) {
@@ -385,7 +390,7 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_split_kernel(c
     const unsigned long long t = w * M + order[t0];
     const uint32_t start = offs[t];
     const uint32_t h = hist[t];
-    const uint32_t cnt = h > cap + MSM_HEAVY_RUN ? 0u : min(h, cap);
+    const uint32_t cnt = msm_is_heavy(h, cap) ? 0u : min(h, cap);
     const uint32_t* list = sorted + w * n + start;
     typename EC::Pt acc = EC::inf();
     for (uint32_t k = part; k < cnt; k += S) {
@@ -471,7 +476,7 @@ struct LongDesc { uint32_t bucket, start, len, idx_in_run, run_len; };
 // would outlast the launch): a workgroup per run, MSM_HEAVY_PER_THREAD mixed adds per thread (msm_heavy_chunk_kernel), then workgroup
 // trees over the 128 partial sums of a run and over the runs of a bucket (msm_heavy_reduce_kernel, levels A, B, C: up to
 // MSM_HEAVY_FANIN items each), the last of which adds into the bucket.  dest: bit 31 set = slot of the next level's parts.
-struct HeavyRun { uint32_t src, n, dest; };
+struct HeavyRun { uint32_t src, n, dest, p1; };           // p1 (level-1 runs): where the run's partial sums start in h1
 constexpr uint32_t MSM_HEAVY_DEST_PART = 0x80000000u;
 // the heavy kernels of the MSMs of ONE batch run as one launch per level (blockIdx.z = MSM): their chains of a few dozen dependent
 // additions are latency, and five of them in sequence were 1.6 of the 3.6 ms of a round 1 committed from small witness values
@@ -484,26 +489,29 @@ struct HeavyJob {
     const uint32_t* count;
     uint32_t *h1, *h2, *h3, *buckets;
     uint8_t* occ;
-    uint32_t run_cap, M;
+    uint32_t run_cap, h1_cap, M;       // runs / level-1 partial sums per window
 };
 struct HeavyJobs { HeavyJob j[MSM_HEAVY_JOBS]; };
-// counters of window w at heavy_count + w * MSM_HEAVY_COUNTERS: [0] level-1 runs, [1] level-B runs, [2] level-C runs, [3] parts of level 2, [4] of level 3
+// counters of window w at heavy_count + w * MSM_HEAVY_COUNTERS: [0] level-1 runs, [1] level-B runs, [2] level-C runs, [3] parts of level 2, [4] of level 3,
+// [5] level-1 partial sums (one per MSM_HEAVY_PER_THREAD entries of a run)
 __device__ __forceinline__ void msm_heavy_push(uint32_t b, uint32_t start, uint32_t rem, uint32_t run_cap, uint32_t* __restrict__ cnt,
                                                HeavyRun* __restrict__ runs0, HeavyRun* __restrict__ runsB, HeavyRun* __restrict__ runsC) {
     const uint32_t n1 = (rem + MSM_HEAVY_RUN - 1) / MSM_HEAVY_RUN;
     const uint32_t r0 = atomicAdd(&cnt[0], n1);
-    if (r0 + n1 > run_cap) return;                                     // cannot happen: run_cap >= 2 * entries / MSM_HEAVY_RUN + 2
-    if (n1 == 1) { runs0[r0] = HeavyRun{start, rem, b}; return; }
+    if (r0 + n1 > run_cap) return;                                     // cannot happen: run_cap >= 2 * entries / MSM_HEAVY_RUN + 2 (a heavy bucket holds more than MSM_HEAVY_RUN entries)
+    const uint32_t p1 = atomicAdd(&cnt[5], (rem + MSM_HEAVY_PER_THREAD - 1) / MSM_HEAVY_PER_THREAD + n1);     // (rounding slack: one per run)
+    constexpr uint32_t PER_RUN = MSM_HEAVY_RUN / MSM_HEAVY_PER_THREAD;
+    if (n1 == 1) { runs0[r0] = HeavyRun{start, rem, b, p1}; return; }
     const uint32_t p2 = atomicAdd(&cnt[3], n1);
     for (uint32_t i = 0; i < n1; i++)
-        runs0[r0 + i] = HeavyRun{start + i * MSM_HEAVY_RUN, min(MSM_HEAVY_RUN, rem - i * MSM_HEAVY_RUN), MSM_HEAVY_DEST_PART | (p2 + i)};
+        runs0[r0 + i] = HeavyRun{start + i * MSM_HEAVY_RUN, min(MSM_HEAVY_RUN, rem - i * MSM_HEAVY_RUN), MSM_HEAVY_DEST_PART | (p2 + i), p1 + i * PER_RUN};
     const uint32_t n2 = (n1 + MSM_HEAVY_FANIN - 1) / MSM_HEAVY_FANIN;
     const uint32_t rb = atomicAdd(&cnt[1], n2);
-    if (n2 == 1) { runsB[rb] = HeavyRun{p2, n1, b}; return; }
+    if (n2 == 1) { runsB[rb] = HeavyRun{p2, n1, b, 0}; return; }
     const uint32_t p3 = atomicAdd(&cnt[4], n2);
     for (uint32_t j = 0; j < n2; j++)
-        runsB[rb + j] = HeavyRun{p2 + j * MSM_HEAVY_FANIN, min(MSM_HEAVY_FANIN, n1 - j * MSM_HEAVY_FANIN), MSM_HEAVY_DEST_PART | (p3 + j)};
-    runsC[atomicAdd(&cnt[2], 1u)] = HeavyRun{p3, n2, b};
+        runsB[rb + j] = HeavyRun{p2 + j * MSM_HEAVY_FANIN, min(MSM_HEAVY_FANIN, n1 - j * MSM_HEAVY_FANIN), MSM_HEAVY_DEST_PART | (p3 + j), 0};
+    runsC[atomicAdd(&cnt[2], 1u)] = HeavyRun{p3, n2, b, 0};
 }
 
 __global__ __launch_bounds__(256) void msm_long_find_kernel(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs, uint32_t M, int n_win,
@@ -514,7 +522,7 @@ __global__ __launch_bounds__(256) void msm_long_find_kernel(const uint32_t* __re
     const uint32_t c = hist[t];
     if (c <= cap) return;
     const uint32_t w = (uint32_t)(t / M), b = (uint32_t)(t % M);
-    if (c - cap > MSM_HEAVY_RUN) {                                     // heavy: its own kernels take ALL its entries
+    if (msm_is_heavy(c, cap)) {                                        // heavy: its own kernels take ALL its entries
         HeavyRun* base = heavy_runs + (size_t)w * 3 * run_cap;
         msm_heavy_push(b, offs[t], c, run_cap, desc_count + n_win + (size_t)w * MSM_HEAVY_COUNTERS, base, base + run_cap, base + 2 * (size_t)run_cap);
         return;
@@ -575,7 +583,7 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_long_combine_kernel(const
     }
 }
 
-// level 1 of a heavy bucket: one workgroup per run of <= MSM_HEAVY_RUN entries, thread t sums entries [32 t, 32 t + 32) -> h1[run * 128 + t]
+// level 1 of a heavy bucket: one workgroup per run of <= MSM_HEAVY_RUN entries, thread t sums its MSM_HEAVY_PER_THREAD entries -> h1[run.p1 + t]
 template <class EC>
 __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_heavy_chunk_kernel(HeavyJobs jobs) {
     const HeavyJob& jb = jobs.j[blockIdx.z];
@@ -593,7 +601,7 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_heavy_chunk_kernel(HeavyJ
             const uint32_t e = list[k];
             acc = EC::madd(acc, EC::load_aff(jb.bases, e & 0x7fffffffu), (e >> 31) != 0);
         }
-        EC::store_pt(jb.h1, ((size_t)w * run_cap + r) * MSM_ACC_THREADS + t, acc);
+        EC::store_pt(jb.h1, (size_t)w * jb.h1_cap + run.p1 + t, acc);
     }
 }
 // levels A (the 128 partial sums of a level-1 run), B and C (the runs of a bucket): a workgroup per run; a thread first sums the items
@@ -611,16 +619,18 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_heavy_reduce_kernel(Heavy
     uint8_t* occ = jb.occ;
     const uint32_t cnt = min(jb.count[(size_t)w * MSM_HEAVY_COUNTERS + level], run_cap);
     const HeavyRun* runs = jb.runs + ((size_t)w * 3 + level) * run_cap;
-    const size_t in_base = (size_t)w * run_cap * (level == 0 ? MSM_ACC_THREADS : 1), out_base = (size_t)w * run_cap;
+    const size_t in_base = (size_t)w * (level == 0 ? jb.h1_cap : run_cap), out_base = (size_t)w * run_cap;
     for (uint32_t r = blockIdx.x; r < cnt; r += gridDim.x) {
         const HeavyRun run = runs[r];
         const uint32_t n_items = level == 0 ? (run.n + MSM_HEAVY_PER_THREAD - 1) / MSM_HEAVY_PER_THREAD : run.n;
-        const size_t src = in_base + (level == 0 ? (size_t)r * MSM_ACC_THREADS : (size_t)run.src);
+        const size_t src = in_base + (level == 0 ? (size_t)run.p1 : (size_t)run.src);
         const int per = (int)((n_items + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS);          // items per thread (uniform bound)
+        int log_w = 0;                                                 // the tree is as wide as the run has sums: 2^log_w >= min(128, n_items)
+        while ((1u << log_w) < n_items && log_w < 7) log_w++;
         typename EC::Pt acc = (uint32_t)tid < n_items ? EC::load_pt(parts_in, src + tid) : EC::inf();
         const bool to_bucket = !(run.dest & MSM_HEAVY_DEST_PART);
         const size_t bi = (size_t)w * M + run.dest;
-        const int n_steps = (per - 1) + 7;
+        const int n_steps = (per - 1) + log_w;
 #pragma unroll 1
         for (int s = 0; s < n_steps; s++) {
             typename EC::Pt a = EC::inf(), b = EC::inf();
@@ -631,9 +641,9 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_heavy_reduce_kernel(Heavy
             } else {                                                   // tree level l: thread t < 64 >> l adds the sums of threads 2t and 2t + 1
                 const int l = s - (per - 1);
                 __syncthreads();
-                if (tid < (MSM_ACC_THREADS >> l)) pt_lds_put<EC>(lds, tid, acc);
+                if (tid < ((1 << log_w) >> l)) pt_lds_put<EC>(lds, tid, acc);
                 __syncthreads();
-                if (tid < (MSM_ACC_THREADS >> (l + 1))) { a = pt_lds_get<EC>(lds, 2 * tid); b = pt_lds_get<EC>(lds, 2 * tid + 1); act = true; }
+                if (tid < ((1 << log_w) >> (l + 1))) { a = pt_lds_get<EC>(lds, 2 * tid); b = pt_lds_get<EC>(lds, 2 * tid + 1); act = true; }
             }
             if (act) acc = EC::add(a, b);
         }

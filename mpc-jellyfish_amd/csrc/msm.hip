@@ -114,6 +114,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     const uint32_t desc_cap_max = (uint32_t)(sorted_max / MSM_MIN_CAP + 1);          // cap >= MSM_MIN_CAP below
     // heavy buckets (msm.cuh): per window <= entries / MSM_HEAVY_RUN full level-1 runs plus one partial run per heavy bucket
     const uint32_t run_cap_max = (uint32_t)(2 * (sorted_max / MSM_HEAVY_RUN) + 2);
+    const uint32_t h1_cap_max = (uint32_t)(sorted_max / MSM_HEAVY_PER_THREAD + 2 * (size_t)run_cap_max + 2);       // level-1 sums: one per 16 entries (+ slack per run)
     const size_t heavy_runs_bytes = (size_t)n_win * 3 * run_cap_max * sizeof(HeavyRun);
     // In a batch of at most SORT_SETS (and MSM_HEAVY_JOBS) MSMs every MSM keeps its own sorted list until the end, so their heavy
     // kernels are deferred and run as ONE launch per level over all of them (msm.cuh, HeavyJobs): each MSM then needs its own
@@ -121,7 +122,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     const bool defer_heavy = count > 1 && (size_t)count <= nb && count <= MSM_HEAVY_JOBS;
     const size_t slots = defer_heavy ? (size_t)count : 1;
     const size_t desc_slot_bytes = (((size_t)n_win * desc_cap_max * sizeof(LongDesc) + (size_t)n_win * 4 * (1 + MSM_HEAVY_COUNTERS) + 16 + heavy_runs_bytes) + 255) & ~(size_t)255;
-    const size_t parts_slot_words = (size_t)n_win * desc_cap_max * EC::PT_WORDS + (size_t)n_win * run_cap_max * (MSM_ACC_THREADS + 2) * EC::PT_WORDS;
+    const size_t parts_slot_words = (size_t)n_win * desc_cap_max * EC::PT_WORDS + (size_t)n_win * ((size_t)h1_cap_max + 2 * (size_t)run_cap_max) * EC::PT_WORDS;
     MZK_TRY(g_ws.long_desc.reserve(slots * desc_slot_bytes));
     MZK_TRY(g_ws.long_parts.reserve(slots * parts_slot_words * 4));
     const unsigned long long dstride_max = (n_max + 7) & ~7ull;
@@ -216,9 +217,10 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
             uint32_t* desc_count = reinterpret_cast<uint32_t*>(desc + (size_t)n_win * desc_cap);       // n_win words, then the heavy counters
             const uint32_t* heavy_count = desc_count + n_win;
             const uint32_t run_cap = (uint32_t)(2 * (n_sorted / MSM_HEAVY_RUN) + 2);
+            const uint32_t h1_cap = (uint32_t)(n_sorted / MSM_HEAVY_PER_THREAD + 2 * (size_t)run_cap + 2);
             HeavyRun* heavy_runs = reinterpret_cast<HeavyRun*>(desc_count + (((size_t)n_win * (1 + MSM_HEAVY_COUNTERS) + 3) & ~(size_t)3));
-            uint32_t* h1 = parts + (size_t)n_win * desc_cap * EC::PT_WORDS;                          // level-1 sums: 128 per run
-            uint32_t* h2 = h1 + (size_t)n_win * run_cap * MSM_ACC_THREADS * EC::PT_WORDS;             // one per level-1 run
+            uint32_t* h1 = parts + (size_t)n_win * desc_cap * EC::PT_WORDS;                          // level-1 sums: one per MSM_HEAVY_PER_THREAD entries of a run
+            uint32_t* h2 = h1 + (size_t)n_win * h1_cap * EC::PT_WORDS;                                // one per level-1 run
             uint32_t* h3 = h2 + (size_t)n_win * run_cap * EC::PT_WORDS;                               // one per level-B run
             const unsigned long long dstride = (n + 7) & ~7ull;
             const unsigned gs = (unsigned)((n + MSM_THREADS - 1) / MSM_THREADS);
@@ -318,7 +320,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 // more than MSM_HEAVY_RUN * MSM_HEAVY_FANIN entries).  Every workgroup exits at once when there is no heavy bucket.
                 HeavyJob& jb = jobs.j[defer_heavy ? p : 0];
                 jb.bases = d_bases; jb.sorted = sorted; jb.n = list_stride; jb.runs = heavy_runs; jb.count = heavy_count;
-                jb.h1 = h1; jb.h2 = h2; jb.h3 = h3; jb.buckets = buckets; jb.occ = occ; jb.run_cap = run_cap; jb.M = M;
+                jb.h1 = h1; jb.h2 = h2; jb.h3 = h3; jb.buckets = buckets; jb.occ = occ; jb.run_cap = run_cap; jb.h1_cap = h1_cap; jb.M = M;
                 heavy_run_cap_max = std::max(heavy_run_cap_max, run_cap);
                 heavy_level_c = heavy_level_c || n_sorted > (uint64_t)MSM_HEAVY_RUN * MSM_HEAVY_FANIN;
                 if (!defer_heavy) {
