@@ -325,6 +325,113 @@ MZK_API int32_t mzk_poly_degree_dev(const void* d_poly, uint64_t len, uint64_t* 
 MZK_API int32_t mzk_poly_div_roots_dev(int32_t curve_id, const void* d_poly, uint64_t len, uint32_t log_order, uint64_t first, uint64_t count,
                                        void* d_out, void* stream);
 
+/* ---- the prover's rounds on device-resident state: replaces the BODIES of Prover::run_1st_round .. compute_opening_proofs
+ *      (plonk/src/proof_system/prover.rs:72-419) as PlonkKzgSnark::batch_prove_internal calls them (snark.rs:263-431).
+ * One mzk_prover per (proving key, instance slot): it owns, in HBM, the coefficient forms of the key's fixed polynomials, their
+ * evaluations on the residue classes of the quotient domain that the quotient needs (mzk_plonk_pk_register_chunked), and the
+ * workspace of one proof in flight (`Oracles`, structs.rs:875-887).  The CALLER keeps what the reference's snark.rs keeps: the
+ * transcript (challenges in, commitments / evaluations out), the rng (blinders in, in the reference's draw order: SURVEY.md
+ * Appendix C) and the `Proof` struct.  Nothing but challenges, blinders, public inputs, commitments (affine x||y, mont; (0,0) =
+ * infinity: `Commitment(G1Affine)`) and evaluations crosses the boundary per round; the witness crosses once (or not at all:
+ * MZK_WITNESS_DEV_*).  All field elements Montgomery, 4 limbs.
+ *
+ *   reference                                          here
+ *   Prover::new + ProvingKey (structs.rs:575-590)       mzk_prover_create
+ *   run_1st_round          prover.rs:72-87             mzk_prover_round1        -> W wire commitments
+ *   run_plookup_1st_round  prover.rs:89-118            mzk_prover_round1_5      -> h_1, h_2 commitments          (UltraPlonk)
+ *   run_2nd_round          prover.rs:125-141           mzk_prover_round2        -> permutation-product commitment
+ *   run_plookup_2nd_round  prover.rs:143-183           mzk_prover_round2_5      -> Plookup-product commitment    (UltraPlonk)
+ *   run_3rd_round          prover.rs:192-209           mzk_prover_round3        -> W split-quotient commitments  (all instances)
+ *   compute_evaluations (+ plookup)  prover.rs:216-299 mzk_prover_round4        -> ProofEvaluations (+ PlookupEvaluations)
+ *   compute_(non_)quotient_component_for_lin_poly + compute_opening_proofs  prover.rs:302-460
+ *                                                      mzk_prover_round5        -> opening proof, shifted opening proof (all instances)
+ *
+ * Rounds must be called in this order (MZK_ERR_STATE otherwise); a new mzk_prover_round1 starts the next proof on the same handle.
+ * `batch_prove` over K instances: K handles (one per instance, same domain size and curve), rounds 1 - 2.5 and 4 per handle,
+ * rounds 3 and 5 once with all handles (alpha_base_k = alpha^(3k), alpha^(7k) with Plookup: prover.rs:661-669, snark.rs:408-428).
+ *
+ * Unsatisfied witness: the reference's only guard is `WrongQuotientPolyDegree` (prover.rs:915-918), raised in round 3.  Here the
+ * quotient is recovered from W residue classes and the top coefficients of its numerator (mzk_plonk_quotient_top_dev), which has
+ * the expected degree whatever the witness; the guard is the quotient identity at zeta, checked at the end of round 5 on a value
+ * the opening's division leaves anyway: mzk_prover_round5 returns MZK_ERR_WRONG_QUOTIENT_DEGREE (the proof must be discarded).
+ * Tiny domains (n <= W + 2) keep the reference's guard and round 3 returns that code. */
+#define MZK_ERR_WRONG_QUOTIENT_DEGREE (-9) /* PlonkError::WrongQuotientPolyDegree: the witness does not satisfy the circuit */
+#define MZK_ERR_STATE (-10)                /* prover rounds called out of order */
+
+/* Several devices / processes: this prover is rank `rank` of `world` -- it commits over the SRS points
+ * [rank (n+3) / world ..) of every polynomial, evaluates ceil(W / world) residue classes of the quotient, runs rounds 4-5 on its
+ * coefficient range.  The callbacks move a few hundred bytes through host memory (Jacobian partial sums of 144 / 96 B, field elements
+ * of 32 B); every rank ends each round with the SAME commitments and evaluations.  all_gather: every rank's `bytes` bytes,
+ * concatenated in rank order, into recv (world x bytes).  exchange_classes (nullable): make the class remainders of all ranks
+ * resident in d_rem (n_classes x class_bytes, device; this rank has filled [first_own, first_own + n_own)); NULL = the prover pushes
+ * its own classes into the peers' buffers itself (mzk_prover_set_peer_buffers, hipMemcpyPeerAsync over xGMI) and calls barrier.
+ * Callbacks return 0 on success. */
+typedef struct mzk_comm {
+    void* ctx;
+    int32_t rank, world;
+    int32_t (*all_gather)(void* ctx, const void* send, uint64_t bytes, void* recv);
+    int32_t (*barrier)(void* ctx);
+    int32_t (*exchange_classes)(void* ctx, void* d_rem, uint64_t class_bytes, uint32_t first_own, uint32_t n_own, uint32_t n_classes);
+} mzk_comm;
+
+/* selector_coeffs: nsel x poly_len (nsel = 13, or 14 with q_lookup last: num_wire_types 6), sigma_coeffs: W x poly_len, table_coeffs:
+ * 4 x poly_len (range, key, table_dom_sep, q_dom_sep; NULL for TurboPlonk): `ProvingKey{selectors, sigmas, plookup_pk}` as
+ * DensePolynomial coefficient vectors, low order first, poly_len <= n = 2^log_n (host).  k_mont: the W coset representatives `vk.k`.
+ * commit_key: SRS handle with >= n + 3 points (`pk.commit_key`, trim(n + 2): snark.rs:535, 561).  lagrange_key: 0, or a handle from
+ * mzk_srs_lagrange_from_srs(commit_key, log_n, 3): round 1 (and 1.5) then commit the wire VALUES over the Lagrange basis -- same
+ * group elements, mostly small scalars.  comm: NULL = one device.  The prover lives on the calling thread's device. */
+MZK_API int32_t mzk_prover_create(int32_t curve_id, uint32_t log_n, uint32_t num_wire_types, const uint64_t* selector_coeffs,
+                                  const uint64_t* sigma_coeffs, const uint64_t* table_coeffs, uint64_t poly_len, const uint64_t* k_mont,
+                                  uint64_t commit_key, uint64_t lagrange_key, const mzk_comm* comm, uint64_t* out_prover);
+MZK_API int32_t mzk_prover_destroy(uint64_t prover);
+/* `VerifyingKey{selector_comms, sigma_comms}` (preprocess, snark.rs:562-594) from the resident coefficient forms: nsel + W affine points,
+ * then -- UltraPlonk, out_plookup_xy non-NULL -- range_table_comm, key_table_comm, table_dom_sep_comm, q_dom_sep_comm (:575-590). */
+MZK_API int32_t mzk_prover_vk_commitments(uint64_t prover, uint64_t* out_xy_mont, uint64_t* out_plookup_xy_mont);
+/* `wire_variables` of the finalised circuit (relation/src/constraint_system.rs:1225-1247), W x n u32 (host), every entry < n_vars (checked:
+ * MZK_ERR_INVALID_ARG -- the reference panics on such an index): resident circuit structure for MZK_WITNESS_*_VECTOR. */
+MZK_API int32_t mzk_prover_set_wire_variables(uint64_t prover, const uint32_t* wire_variables, uint64_t n_vars);
+#define MZK_WITNESS_DEV_WIRES 0   /* device, W x n: witness[wire_variable(i, j)] already gathered */
+#define MZK_WITNESS_HOST_WIRES 1  /* host, W x n (page-locked memory: column k + 1 crosses PCIe under the iNTT of column k) */
+#define MZK_WITNESS_HOST_VECTOR 2 /* host, n_vars witness values; gathered on the device (mzk_prover_set_wire_variables) */
+#define MZK_WITNESS_DEV_VECTOR 3  /* device, n_vars witness values */
+/* Round 1: compute_wire_polynomials (gather + W iNTTs), compute_pub_input_polynomial, mask_polynomial, batch_commit.
+ * witness_len: W x n or n_vars elements.  Public input: n_pub values; pub_input_rows = NULL places them on rows 0 .. n_pub - 1 (where
+ * finalize_for_arithmetization puts the IO gates), else row pub_input_rows[i] < n.  blinders_mont: W x 2 (`DensePolynomial::rand(1)` per
+ * wire, in wire order).  out_comms_xy: W affine points. */
+MZK_API int32_t mzk_prover_round1(uint64_t prover, int32_t witness_kind, const void* witness, uint64_t witness_len, const uint64_t* pub_input_rows,
+                                  const uint64_t* pub_input_mont, uint64_t n_pub, const uint64_t* blinders_mont, uint64_t* out_comms_xy);
+/* UltraPlonk only.  blinders: 2 x 3 (h_1 then h_2); out: 2 points.  MZK_ERR_LOOKUP when a looked-up value is not in the table. */
+MZK_API int32_t mzk_prover_round1_5(uint64_t prover, const uint64_t* tau_mont, const uint64_t* blinders_mont, uint64_t* out_comms_xy);
+/* blinders: 3; out: 1 point. */
+MZK_API int32_t mzk_prover_round2(uint64_t prover, const uint64_t* beta_mont, const uint64_t* gamma_mont, const uint64_t* blinders_mont,
+                                  uint64_t* out_comm_xy);
+/* UltraPlonk only.  blinders: 3; out: 1 point. */
+MZK_API int32_t mzk_prover_round2_5(uint64_t prover, const uint64_t* blinders_mont, uint64_t* out_comm_xy);
+/* provers: the n_instances handles in instance order (all past round 2 / 2.5).  blinders: W - 1 (split_quotient_polynomial's draws,
+ * prover.rs:947-955).  out: W points. */
+MZK_API int32_t mzk_prover_round3(const uint64_t* provers, uint32_t n_instances, const uint64_t* alpha_mont, const uint64_t* blinders_mont,
+                                  uint64_t* out_comms_xy);
+/* out_evals_mont: wires_evals (W), wire_sigma_evals (W - 1), perm_next_eval (1), then for UltraPlonk the 15 PlookupEvaluations in
+ * their declaration order (structs.rs:496-541): range_table, key_table, table_dom_sep, q_dom_sep, h_1, q_lookup, prod_next,
+ * range_table_next, key_table_next, table_dom_sep_next, h_1_next, h_2_next, q_lookup_next, w_3_next, w_4_next. */
+MZK_API int32_t mzk_prover_round4(uint64_t prover, const uint64_t* zeta_mont, uint64_t* out_evals_mont);
+/* out: opening_proof, shifted_opening_proof (2 points).  MZK_ERR_WRONG_QUOTIENT_DEGREE: see above. */
+MZK_API int32_t mzk_prover_round5(const uint64_t* provers, uint32_t n_instances, const uint64_t* v_mont, uint64_t* out_comms_xy);
+/* Multi-device hosts in one process: this rank's class-remainder buffer (device pointer, bytes), and the same buffers of all `world`
+ * ranks with their logical devices, for the one device-to-device exchange of round 3 (mzk_comm.exchange_classes == NULL). */
+MZK_API int32_t mzk_prover_exchange_buffer(uint64_t prover, void** out_dptr, uint64_t* out_bytes);
+MZK_API int32_t mzk_prover_set_peer_buffers(uint64_t prover, void* const* peer_dptrs, const int32_t* peer_devices);
+/* A device-resident polynomial of the proof in flight (valid until the next mzk_prover_round1 on this handle): which = 0 .. W - 1 the
+ * masked wire polynomials (n + 2 coefficients; wire 0 is the `linking_wire_poly` of prove_with_link_hint, snark.rs:81-119), W the
+ * permutation product (n + 3). */
+MZK_API int32_t mzk_prover_poly_dev(uint64_t prover, uint32_t which, const void** out_dptr, uint64_t* out_len);
+/* on != 0: every round synchronises the device at its internal stage boundaries and records wall milliseconds; mzk_prover_timings writes
+ * them as one JSON object ("r1_ntt_mask", "r1_commit", .. "r5_commit") into buf (NUL-terminated, truncated to cap). */
+MZK_API int32_t mzk_prover_profile(uint64_t prover, int32_t on);
+MZK_API int32_t mzk_prover_timings(uint64_t prover, char* buf, uint64_t cap);
+/* Bytes of HBM this prover holds: coefficient forms, resident class evaluations (proving key), per-proof workspace. */
+MZK_API int32_t mzk_prover_hbm_bytes(uint64_t prover, uint64_t* out_fixed, uint64_t* out_proving_key, uint64_t* out_workspace);
+
 /* ---- page-locked host memory for the host-pointer entry points (mzk_ntt, mzk_ntt_batch, mzk_msm, mzk_msm_batch) ----
  * A shim that swaps only the two third-party call sites moves every operand over PCIe.  From memory
  * obtained here (hipHostMalloc), or registered in place (hipHostRegister: worth it for long-lived buffers only), the transfers
@@ -380,6 +487,13 @@ MZK_API int32_t mzk_msm_set_precompute(int32_t on);
  * VariableBaseMSM does not pay: bench.py prints it beside the headline.  All zeros when the table is disabled or did not fit. */
 MZK_API int32_t mzk_srs_precompute(uint64_t srs_handle, uint32_t* out_window_bits, uint32_t* out_levels, uint64_t* out_table_bytes,
                                    double* out_build_ms);
+/* HBM accounting (bench.py reports it per leg).  An SRS: its points (boundary form + the MSM's internal form: 96 + 112 B per point on
+ * BLS12-381, 64 + 80 B on BN254) and its fixed-base table (0 until built; the reference keeps the points only: srs.rs:36-40).  A proving
+ * key: the resident evaluations of the fixed polynomials and the per-point tables.  The device context: the shared scratch of the NTT /
+ * MSM / quotient kernels (grow-only) and the buffers of the host-pointer I/O slots. */
+MZK_API int32_t mzk_srs_hbm_bytes(uint64_t srs_handle, uint64_t* out_points_bytes, uint64_t* out_table_bytes);
+MZK_API int32_t mzk_plonk_pk_hbm_bytes(uint64_t pk_handle, uint64_t* out_bytes);
+MZK_API int32_t mzk_workspace_hbm_bytes(uint64_t* out_bytes);
 /* Last MSM's shape: window bits, windows, buckets per window (for DESIGN.md's op counts). */
 MZK_API int32_t mzk_msm_last_shape(uint32_t* out_window_bits, uint32_t* out_windows, uint32_t* out_buckets);
 

@@ -1,9 +1,10 @@
 // hostfp.hpp -- host-side Montgomery field on 64-bit limbs (same memory image as the device's
-// 32-bit-limb Fp<P>).  Used only for the serial tail of an MSM (the 255-doubling Horner over the
-// per-window partial sums, ~0.3 ms) which no GPU thread can do faster than one CPU core.
+// 32-bit-limb Fp<P>).  Used for scalars only: the challenges, evaluations and linearisation coefficients of the prover rounds
+// (csrc/prover.hip), the EC sum of <= 8 partial commitments, Jacobian -> affine.
 // Product code: not shared with oracle/.
 #pragma once
 #include <cstdint>
+#include <array>
 #include <cstring>
 
 #include "constants.cuh"
@@ -78,5 +79,54 @@ struct Fp64 {
 template <class P> inline Fp64<P> sqr(const Fp64<P>& a) { return a * a; }
 template <class P> inline Fp64<P> dbl(const Fp64<P>& a) { return a + a; }
 template <class P> inline Fp64<P> neg(const Fp64<P>& a) { return Fp64<P>::zero() - a; }
+
+// ---- helpers of the host-side prover logic (csrc/prover.hip, host/mzk_host.hpp) ----------------------------
+// (their own namespace: fp.cuh has device-side functions of the same names on Fp<P>)
+namespace h64 {
+template <class P>
+Fp64<P> from_u64(uint64_t v) {
+    Fp64<P> a = Fp64<P>::zero(), r2;
+    a.l[0] = v;
+    for (int i = 0; i < Fp64<P>::N; i++) r2.l[i] = Fp64<P>::c64(P::R2, i);
+    return a * r2;
+}
+template <class P>
+Fp64<P> pow_u64(Fp64<P> b, uint64_t e) {
+    Fp64<P> acc = Fp64<P>::one();
+    for (; e; e >>= 1) {
+        if (e & 1) acc = acc * b;
+        b = b * b;
+    }
+    return acc;
+}
+template <class P>
+Fp64<P> inv(const Fp64<P>& a) {                              // a^(p-2)
+    uint64_t e[Fp64<P>::N];
+    for (int i = 0; i < Fp64<P>::N; i++) e[i] = Fp64<P>::mod(i);
+    e[0] -= 2;                                               // every modulus here is odd and > 2: no borrow beyond limb 0
+    Fp64<P> acc = Fp64<P>::one(), b = a;
+    for (int i = 0; i < Fp64<P>::N; i++)
+        for (int k = 0; k < 64; k++) {
+            if ((e[i] >> k) & 1) acc = acc * b;
+            b = b * b;
+        }
+    return acc;
+}
+template <class P>
+std::array<uint64_t, Fp64<P>::N> canonical(const Fp64<P>& a) {   // Montgomery -> integer
+    Fp64<P> one = Fp64<P>::zero();
+    one.l[0] = 1;
+    Fp64<P> c = a * one;
+    std::array<uint64_t, Fp64<P>::N> r;
+    std::memcpy(r.data(), c.l, sizeof c.l);
+    return r;
+}
+template <class P>
+Fp64<P> root_of_unity(int log_n) {
+    Fp64<P> w = Fp64<P>::from_words(P::ROOT);
+    for (int i = log_n; i < P::TWO_ADICITY; i++) w = w * w;
+    return w;
+}
+}  // namespace h64
 
 }  // namespace mzk

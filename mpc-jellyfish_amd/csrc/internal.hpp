@@ -47,6 +47,7 @@ struct Workspace {
     size_t h_collect_cap = 0;
     hipEvent_t last_use = nullptr;
     void release();
+    size_t bytes();
 };
 
 // HIP-event timing of named regions (mzk_profile_*): one switch for the library, records per device context
@@ -167,5 +168,6 @@ int plonk_pk_log_n(uint64_t handle);
 int plonk_pk_curve(uint64_t handle);
 int plonk_pk_classes(uint64_t handle, uint32_t* out);
 int plonk_pk_wires(uint64_t handle);
+uint64_t plonk_pk_bytes(uint64_t handle);
 
 }  // namespace mzk

@@ -43,6 +43,12 @@ void Workspace::release() {
     last_use = nullptr;
 }
 
+size_t Workspace::bytes() {
+    size_t b = 0;
+    for (DevBuf* d : {&ntt_scratch, &scalars, &hist, &offs, &cursor, &sorted, &buckets, &collect, &io, &misc, &digits, &long_desc, &long_parts, &plonk_polys, &plonk_out, &pre_cnt, &pre_off, &pre_ce, &pre_cb, &poly_tmp, &split, &link_tmp, &occ}) b += d->cap;
+    return b;
+}
+
 int32_t ws_acquire(hipStream_t st) {
     if (!g_ws.last_use) HIP_TRY(hipEventCreateWithFlags(&g_ws.last_use, hipEventDisableTiming));
     else HIP_TRY(hipStreamWaitEvent(st, g_ws.last_use, 0));
@@ -281,6 +287,8 @@ const char* mzk_strerror(int32_t code) {
         case MZK_ERR_OOM: return "out of device memory";
         case MZK_ERR_NOT_INIT: return "mzk_init not called";
         case MZK_ERR_LOOKUP: return "Plookup: lookup value outside the table";
+        case MZK_ERR_WRONG_QUOTIENT_DEGREE: return "WrongQuotientPolyDegree";
+        case MZK_ERR_STATE: return "prover rounds called out of order";
         default: return "unknown error";
     }
 }
@@ -402,6 +410,27 @@ int32_t mzk_srs_len(uint64_t handle, uint64_t* out_n_points) {
     auto it = cx_->srs.find(handle);
     if (it == cx_->srs.end() || !out_n_points) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
     *out_n_points = it->second.n;
+    return MZK_OK;
+}
+// HBM a registered SRS holds: its points (boundary form + the MSM's internal reduced-radix form) and its fixed-base table
+int32_t mzk_srs_hbm_bytes(uint64_t handle, uint64_t* out_points_bytes, uint64_t* out_table_bytes) {
+    ENTER_HANDLE(handle);
+    auto it = cx_->srs.find(handle);
+    if (it == cx_->srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+    const Srs& s = it->second;
+    const uint64_t aff_int = s.curve == MZK_CURVE_BLS12_381 ? 2 * 14 * 4 : 2 * 10 * 4;      // 29-bit limbs: ecx.cuh
+    if (out_points_bytes) *out_points_bytes = s.n * (uint64_t)(2 * fq_words(s.curve) * 4) + (s.d_int ? s.n * aff_int : 0);
+    if (out_table_bytes) *out_table_bytes = s.d_pre ? (uint64_t)s.pre_levels * s.n * aff_int : 0;
+    return MZK_OK;
+}
+// scratch memory of the calling thread's device context: the shared workspace of the NTT / MSM / quotient kernels (grow-only) and the
+// device buffers of the host-pointer I/O slots
+int32_t mzk_workspace_hbm_bytes(uint64_t* out_bytes) {
+    ENTER_CUR();
+    if (!out_bytes) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    uint64_t b = cx_->ws.bytes();
+    for (auto& slot : cx_->io) b += slot.buf.cap;
+    *out_bytes = b;
     return MZK_OK;
 }
 
@@ -665,6 +694,12 @@ int32_t mzk_plonk_pk_register_chunked(int32_t curve_id, uint32_t log_n, uint32_t
     return plonk_pk_register(curve_id, (int)log_n, (int)num_wire_types, reinterpret_cast<const uint32_t*>(selector_coeffs),
                              reinterpret_cast<const uint32_t*>(sigma_coeffs), reinterpret_cast<const uint32_t*>(table_coeffs), poly_len,
                              reinterpret_cast<const uint32_t*>(k_mont), classes, n_classes, out_handle);
+}
+int32_t mzk_plonk_pk_hbm_bytes(uint64_t pk_handle, uint64_t* out_bytes) {
+    ENTER_HANDLE(pk_handle);
+    if (!out_bytes) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    *out_bytes = plonk_pk_bytes(pk_handle);
+    return *out_bytes ? MZK_OK : MZK_ERR_BAD_HANDLE;
 }
 int32_t mzk_plonk_quotient_chunked_dev(uint64_t pk_handle, const void* d_polys, uint64_t in_stride, uint64_t in_len, const uint64_t* tau_mont,
                                        const uint64_t* alpha_mont, const uint64_t* beta_mont, const uint64_t* gamma_mont, void* d_out, void* stream) {

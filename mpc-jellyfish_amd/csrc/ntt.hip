@@ -33,7 +33,7 @@ struct PlanKey {
 };
 std::map<PlanKey, std::unique_ptr<NttPlanDev>> g_plans_of[MAX_CTX];      // one plan cache per device context
 #define g_plans (g_plans_of[cur().logical])
-uint64_t g_plan_clock = 0;
+std::atomic<uint64_t> g_plan_clock{0};           // LRU clock shared by the device threads of one process
 // A plan holds device tables (up to tens of MB for the largest domains) and is keyed by the coset offset: a caller sweeping
 // offsets (per-proof random cosets, the multiprover's public-polynomial FFTs) must not grow the cache without bound.
 constexpr size_t NTT_MAX_PLANS = 48;

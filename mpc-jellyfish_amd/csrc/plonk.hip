@@ -37,7 +37,7 @@ struct PlonkPk {
 };
 std::map<uint64_t, std::unique_ptr<PlonkPk>> g_pks_of[MAX_CTX];              // proving keys per device context; the handle names its context
 #define g_pks (g_pks_of[cur().logical])
-uint64_t g_next_pk = 1;
+std::atomic<uint64_t> g_next_pk{1};              // shared by the device threads of one process
 
 // data[i] *= c (boundary form -> internal form x * R' with c = 32: plonk.cuh)
 template <class P>
@@ -667,6 +667,17 @@ int32_t plonk_pk_release(uint64_t handle) {
     for (auto* d : it->second->bufs()) if (d) (void)hipFree(d);
     g_pks.erase(it);
     return MZK_OK;
+}
+// HBM held by a proving key: the resident evaluations of the fixed polynomials and the per-point tables
+uint64_t plonk_pk_bytes(uint64_t handle) {
+    const PlonkPk* pk = find_pk(handle);
+    if (!pk) return 0;
+    const uint64_t n = 1ull << pk->log_n, pts = pk->cls.empty() ? (uint64_t)PLK_RATIO * n : (uint64_t)pk->cls.size() * n;
+    const uint64_t nfix = (uint64_t)pk->nsel + pk->W + (pk->ultra ? 4 : 0);
+    uint64_t b = (nfix + 2 + (pk->ultra ? 1 : 0)) * pts * 32;              // d_fixed, d_xs, d_inv_den (, d_inv_den_n)
+    b += ((uint64_t)pk->W + 1 + (pk->ultra ? 5 : 0)) * n * 32;             // d_sigma_n, d_omega_n (, d_tab_n)
+    if (pk->d_top_fixed) b += ((uint64_t)pk->W + 5) * 8 * 32;
+    return b;
 }
 void plonk_release_all() {
     for (auto& kv : g_pks)

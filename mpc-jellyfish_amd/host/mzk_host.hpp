@@ -33,51 +33,13 @@ inline void check(int32_t rc, const char* where) {
     if (rc != MZK_OK) throw std::runtime_error(std::string(where) + ": " + mzk_strerror(rc) + ": " + mzk_last_error());
 }
 
-// ---- host field helpers on top of Fp64 ------------------------------------------------------------------
-template <class P>
-Fp64<P> from_u64(uint64_t v) {
-    Fp64<P> a = Fp64<P>::zero(), r2;
-    a.l[0] = v;
-    for (int i = 0; i < Fp64<P>::N; i++) r2.l[i] = Fp64<P>::c64(P::R2, i);
-    return a * r2;
-}
-template <class P>
-Fp64<P> pow_u64(Fp64<P> b, uint64_t e) {
-    Fp64<P> acc = Fp64<P>::one();
-    for (; e; e >>= 1) {
-        if (e & 1) acc = acc * b;
-        b = b * b;
-    }
-    return acc;
-}
-template <class P>
-Fp64<P> inv(const Fp64<P>& a) {                              // a^(p-2)
-    uint64_t e[Fp64<P>::N];
-    for (int i = 0; i < Fp64<P>::N; i++) e[i] = Fp64<P>::mod(i);
-    e[0] -= 2;                                               // every modulus here is odd and > 2: no borrow beyond limb 0
-    Fp64<P> acc = Fp64<P>::one(), b = a;
-    for (int i = 0; i < Fp64<P>::N; i++)
-        for (int k = 0; k < 64; k++) {
-            if ((e[i] >> k) & 1) acc = acc * b;
-            b = b * b;
-        }
-    return acc;
-}
-template <class P>
-std::array<uint64_t, Fp64<P>::N> canonical(const Fp64<P>& a) {   // Montgomery -> integer
-    Fp64<P> one = Fp64<P>::zero();
-    one.l[0] = 1;
-    Fp64<P> c = a * one;
-    std::array<uint64_t, Fp64<P>::N> r;
-    std::memcpy(r.data(), c.l, sizeof c.l);
-    return r;
-}
-template <class P>
-Fp64<P> root_of_unity(int log_n) {
-    Fp64<P> w = Fp64<P>::from_words(P::ROOT);
-    for (int i = log_n; i < P::TWO_ADICITY; i++) w = w * w;
-    return w;
-}
+// host field helpers on top of Fp64 (from_u64, pow_u64, inv, canonical, root_of_unity): csrc/hostfp.hpp -- the library's own prover rounds
+// (csrc/prover.hip) use the same ones
+using mzk::h64::canonical;
+using mzk::h64::from_u64;
+using mzk::h64::inv;
+using mzk::h64::pow_u64;
+using mzk::h64::root_of_unity;
 
 // ---- rand_chacha ChaCha{8,12,20}Rng and ark-ff's Fp::rand ------------------------------------------------
 struct ChaChaRng {

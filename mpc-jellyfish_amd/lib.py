@@ -98,6 +98,28 @@ _SIGS = {
     "mzk_msm_set_precompute": [C.c_int32],
     "mzk_srs_precompute": [C.c_uint64, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64), C.POINTER(C.c_double)],
     "mzk_msm_last_shape": [C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)],
+    "mzk_srs_hbm_bytes": [C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
+    "mzk_plonk_pk_hbm_bytes": [C.c_uint64, C.POINTER(C.c_uint64)],
+    "mzk_workspace_hbm_bytes": [C.POINTER(C.c_uint64)],
+    # the prover's rounds (csrc/prover.hip); mzk_comm* travels as a void pointer (native.Comm)
+    "mzk_prover_create": [C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
+                          C.POINTER(C.c_uint64)],
+    "mzk_prover_destroy": [C.c_uint64],
+    "mzk_prover_vk_commitments": [C.c_uint64, C.c_void_p, C.c_void_p],
+    "mzk_prover_set_wire_variables": [C.c_uint64, C.c_void_p, C.c_uint64],
+    "mzk_prover_round1": [C.c_uint64, C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p],
+    "mzk_prover_round1_5": [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p],
+    "mzk_prover_round2": [C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
+    "mzk_prover_round2_5": [C.c_uint64, C.c_void_p, C.c_void_p],
+    "mzk_prover_round3": [C.POINTER(C.c_uint64), C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p],
+    "mzk_prover_round4": [C.c_uint64, C.c_void_p, C.c_void_p],
+    "mzk_prover_round5": [C.POINTER(C.c_uint64), C.c_uint32, C.c_void_p, C.c_void_p],
+    "mzk_prover_exchange_buffer": [C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)],
+    "mzk_prover_set_peer_buffers": [C.c_uint64, C.POINTER(C.c_void_p), C.POINTER(C.c_int32)],
+    "mzk_prover_poly_dev": [C.c_uint64, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64)],
+    "mzk_prover_profile": [C.c_uint64, C.c_int32],
+    "mzk_prover_timings": [C.c_uint64, C.c_char_p, C.c_uint64],
+    "mzk_prover_hbm_bytes": [C.c_uint64, C.POINTER(C.c_uint64), C.POINTER(C.c_uint64), C.POINTER(C.c_uint64)],
 }
 _STR_FUNCS = ("mzk_strerror", "mzk_last_error", "mzk_version")
 EXPORTS = tuple(_SIGS) + _STR_FUNCS
