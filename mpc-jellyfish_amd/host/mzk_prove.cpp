@@ -1,6 +1,9 @@
 // mzk_prove -- PlonkKzgSnark::prove on the reference's bench circuit from a compiled host: C++ above the C ABI of
 // include/mzk.h, no Python, no HIP in this translation unit (g++ builds it).
 //   mzk_prove <curve: 0 BLS12-381 | 1 BN254> <turbo|ultra> <num_gates> [reps] [range_bit_len] [--gpus G] [--host-witness | --host-witness-vars] [--check-agree]
+//   mzk_prove <curve> file <circuit file> [reps] [--gpus G] [--host-witness] ...
+// `file`: ANY finalised circuit -- public inputs, every gate type, copy constraints, lookups -- as the arrays `Arithmetization` exposes
+// (format: BenchCircuitHost::read in mzk_prover.hpp; mpc-jellyfish_amd/circuit_io.py writes it).
 // Prints one JSON line: proof bytes (hex), wall time per proof, per-round times of one profiled proof.
 // --gpus G: G devices driven from this ONE process, one host thread per device (ShardedProver, mzk_prover.hpp): commitments sharded by
 // point range, the quotient by residue class with one device-to-device exchange, rounds 4-5 by coefficient range; same proof bytes.
@@ -29,15 +32,16 @@ struct Options {
 };
 
 template <class C>
-int run(bool ultra, uint64_t num_gates, int reps, int range_bits, const Options& opt) {
+int run(bool ultra, uint64_t num_gates, int reps, int range_bits, const Options& opt, const char* circuit_file = nullptr) {
     using Fr = Fp64<typename C::Fr>;
     if (opt.gpus == 1) check(mzk_init(-1), "mzk_init");                  // (with several devices each worker thread binds its own)
     auto t0 = std::chrono::steady_clock::now();
-    BenchCircuitHost<C> host = BenchCircuitHost<C>::generate(num_gates, ultra, range_bits);
+    BenchCircuitHost<C> host = circuit_file ? BenchCircuitHost<C>::read(circuit_file) : BenchCircuitHost<C>::generate(num_gates, ultra, range_bits);
+    ultra = host.ultra;
     if (std::getenv("MZK_PROVE_CORRUPT_WITNESS"))                       // test hook: wire 0 of row 5 takes the value of row 6 -> gate 5 no longer holds
     {
         host.wires[5] = host.wires[6];
-        host.witness[host.wire_variables[5]] = host.witness[host.wire_variables[6]];
+        if (!host.witness.empty()) host.witness[host.wire_variables[5]] = host.witness[host.wire_variables[6]];
     }
     ChaChaRng rng = test_rng();
     const Fr beta = fr_rand<typename C::Fr>(rng);                       // the SRS trapdoor: first draw of the bench's rng (bench.rs:50-54)
@@ -183,6 +187,15 @@ int main(int argc_in, char** argv_in) {
         try {
             const bool u = std::string(argv[3]) == "ultra";
             return curve == 0 ? run_batch<Bls12_381>(u, std::atoi(argv[4]), gates) : run_batch<Bn254>(u, std::atoi(argv[4]), gates);
+        } catch (const std::exception& e) {
+            std::fprintf(stderr, "mzk_prove: %s\n", e.what());
+            return 1;
+        }
+    }
+    if (std::string(argv[2]) == "file") {
+        try {
+            const int reps = argc > 4 ? std::atoi(argv[4]) : 0;
+            return curve == 0 ? run<Bls12_381>(false, 0, reps, 8, opt, argv[3]) : run<Bn254>(false, 0, reps, 8, opt, argv[3]);
         } catch (const std::exception& e) {
             std::fprintf(stderr, "mzk_prove: %s\n", e.what());
             return 1;

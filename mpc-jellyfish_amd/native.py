@@ -153,27 +153,26 @@ class NativeProver:
         return self._comms(out)
 
     def round1_5(self, tau, blind_h):
-        bl = self._mont([b for row in blind_h for b in row])
+        bl, t = self._mont([b for row in blind_h for b in row]), self._mont([tau])      # (named: the arrays must outlive the call)
         out = self._points(2)
-        _check(_lib.load().mzk_prover_round1_5(self.handle, _ptr(self._mont([tau])), _ptr(bl), _ptr(out)), "mzk_prover_round1_5")
+        _check(_lib.load().mzk_prover_round1_5(self.handle, _ptr(t), _ptr(bl), _ptr(out)), "mzk_prover_round1_5")
         return self._comms(out)
 
     def round2(self, beta, gamma, blind_z):
-        out = self._points(1)
-        _check(_lib.load().mzk_prover_round2(self.handle, _ptr(self._mont([beta])), _ptr(self._mont([gamma])), _ptr(self._mont(blind_z)), _ptr(out)),
-               "mzk_prover_round2")
+        out, b, g, bl = self._points(1), self._mont([beta]), self._mont([gamma]), self._mont(blind_z)
+        _check(_lib.load().mzk_prover_round2(self.handle, _ptr(b), _ptr(g), _ptr(bl), _ptr(out)), "mzk_prover_round2")
         return self._comms(out)[0]
 
     def round2_5(self, blind_pl):
-        out = self._points(1)
-        _check(_lib.load().mzk_prover_round2_5(self.handle, _ptr(self._mont(blind_pl)), _ptr(out)), "mzk_prover_round2_5")
+        out, bl = self._points(1), self._mont(blind_pl)
+        _check(_lib.load().mzk_prover_round2_5(self.handle, _ptr(bl), _ptr(out)), "mzk_prover_round2_5")
         return self._comms(out)[0]
 
     def round4(self, zeta):
         c, W = self.curve, self.W
         cnt = 2 * W + (15 if self.ultra else 0)
-        out = np.zeros((cnt, 4), dtype=np.uint64)
-        _check(_lib.load().mzk_prover_round4(self.handle, _ptr(self._mont([zeta])), _ptr(out)), "mzk_prover_round4")
+        out, z = np.zeros((cnt, 4), dtype=np.uint64), self._mont([zeta])
+        _check(_lib.load().mzk_prover_round4(self.handle, _ptr(z), _ptr(out)), "mzk_prover_round4")
         ev = fr_from_mont(c, out)
         pe = dict(zip(_prover.PLOOKUP_EVALS, ev[2 * W:])) if self.ultra else None
         return ev[:W], ev[W:2 * W - 1], ev[2 * W - 1], pe
@@ -211,8 +210,8 @@ def round3(provers, alpha, blind_quot):
     """run_3rd_round over all instances (prover.rs:192-209): one quotient, split, W commitments"""
     p0 = provers[0]
     hs = (C.c_uint64 * len(provers))(*[p.handle for p in provers])
-    out = p0._points(p0.W)
-    _check(_lib.load().mzk_prover_round3(hs, len(provers), _ptr(p0._mont([alpha])), _ptr(p0._mont(blind_quot)), _ptr(out)), "mzk_prover_round3")
+    out, a, bl = p0._points(p0.W), p0._mont([alpha]), p0._mont(blind_quot)
+    _check(_lib.load().mzk_prover_round3(hs, len(provers), _ptr(a), _ptr(bl), _ptr(out)), "mzk_prover_round3")
     return p0._comms(out)
 
 
@@ -220,8 +219,8 @@ def round5(provers, v_ch):
     """linearisation polynomial + compute_opening_proofs over all instances (prover.rs:302-460): two commitments"""
     p0 = provers[0]
     hs = (C.c_uint64 * len(provers))(*[p.handle for p in provers])
-    out = p0._points(2)
-    _check(_lib.load().mzk_prover_round5(hs, len(provers), _ptr(p0._mont([v_ch])), _ptr(out)), "mzk_prover_round5")
+    out, v = p0._points(2), p0._mont([v_ch])
+    _check(_lib.load().mzk_prover_round5(hs, len(provers), _ptr(v), _ptr(out)), "mzk_prover_round5")
     return p0._comms(out)
 
 
