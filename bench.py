@@ -460,6 +460,44 @@ def main():
         tmp_key = ck.lagrange_key(pn)
         lagrange_key_s = time.perf_counter() - tl
         tmp_key.release()
+        # the SAME proof through the round-level C ABI (mzk_prover_create / round1 .. round5, include/mzk.h): the rounds run inside the
+        # library, this process keeps transcript, rng and Proof -- what a Rust caller of the drop-in gets
+        from importlib import import_module
+        native = import_module("mpc-jellyfish_amd.native")
+        npk = native.preprocess(prover.ck, cs, lagrange_ck=prover.lagrange_ck)
+        for _ in range(2):
+            native.prove(rng, cs, npk)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for _ in range(reps):
+            native.prove(rng, cs, npk)
+        torch.cuda.synchronize()
+        abi_ms = (time.perf_counter() - ta) / reps * 1e3
+        abi_core, abi_bytes = native.prove(mj.rng.test_rng(), cs, npk, profile=True)
+        abi_same = bool(abi_bytes == mj.snark.prove(mj.rng.test_rng(), cs, prover)[1])
+        npk.set_wire_variables(cs.wire_variables.cpu().numpy(), int(cs.witness.shape[0]))
+        abi_vec = mj.snark.HostWitness(cs.witness.cpu().pin_memory(), cs.wire_variables)
+        for _ in range(2):
+            native.prove(rng, cs, npk, witness=abi_vec)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for _ in range(reps):
+            native.prove(rng, cs, npk, witness=abi_vec)
+        torch.cuda.synchronize()
+        abi_vec_ms = (time.perf_counter() - ta) / reps * 1e3
+        # HBM held for this proof system instance (the reference keeps one commit key: srs.rs:36-40)
+        hbm = dict(npk.hbm_bytes())
+        for name, key in (("commit_key", prover.ck), ("lagrange_key", prover.lagrange_ck)):
+            if key is not None:
+                a_, b_ = C.c_uint64(), C.c_uint64()
+                mlib.check(L.mzk_srs_hbm_bytes(key.handle, C.byref(a_), C.byref(b_)), "mzk_srs_hbm_bytes")
+                hbm[name + "_points"], hbm[name + "_fixed_base_table"] = a_.value, b_.value
+        a_ = C.c_uint64()
+        mlib.check(L.mzk_workspace_hbm_bytes(C.byref(a_)), "mzk_workspace_hbm_bytes")
+        hbm["library_scratch"] = a_.value
+        hbm["total"] = sum(hbm.values())
+        npk.release()
+        del abi_vec
         # (i) the witness starts in page-locked HOST memory, as the reference holds it (constraint_system.rs:1225-1247 gathers it on the
         # host): every proof uploads its 5 x n x 32 B, wire k + 1 under the iNTT of wire k (prover.py _stage_round1)
         import dataclasses
@@ -485,7 +523,8 @@ def main():
         prove = {"what": "PlonkKzgSnark::prove of one TurboPlonk proof on the reference's bench circuit (bench.rs:29-46: a = a + 1, "
                          "gates - 10 times): 7 iNTT(n), grand product, coset NTTs, quotient, 13 MSM, evaluations, linearisation, "
                          "openings, ChaCha test_rng blinders, Merlin transcript, compressed proof bytes; proving key resident; "
-                         "the quotient's degree is checked as the reference checks it (a wrong witness raises)",
+                         "an unsatisfied witness raises WrongQuotientPolyDegree -- from the quotient identity at zeta at the end of round 5 "
+                         "(the quotient comes from W residue classes + the numerator's top coefficients, so its degree cannot be wrong: DESIGN.md 4.3)",
                  "log_n": pl, "prove_ms": round(prove_ms, 2), "reps": reps, "min_ms": round(min(each), 2), "median_ms": round(sorted(each)[len(each) // 2], 2),
                  "max_ms": round(max(each), 2),
                  "ns_per_gate": round(prove_ms * 1e6 / pn, 1), "rounds_ms": core.timings_ms, "proof_bytes": len(proof_bytes),
@@ -496,6 +535,11 @@ def main():
                                   "nothing (`dense_witness_ms`).  `coefficient_commit_ms` is the same proof with round 1 committed from the masked "
                                   "coefficient forms, as the reference does" % (13 * (pn + 3) * 112 / 1e9),
                  "lagrange_key_s": round(lagrange_key_s, 3),
+                 "round_level_abi_ms": round(abi_ms, 2), "round_level_abi_rounds_ms": abi_core.timings_ms, "round_level_abi_same_proof_bytes": abi_same,
+                 "round_level_abi_from_host_witness_vector_ms": round(abi_vec_ms, 2),
+                 "round_level_abi_note": "the same proofs through mzk_prover_create / round1 .. round5 (include/mzk.h): the rounds of prover.rs:72-419 "
+                                         "run inside the library, the caller (here ctypes + the Python transcript) keeps transcript, rng and Proof",
+                 "hbm_bytes": hbm,
                  "coefficient_commit_ms": round(coeff_ms, 2), "coefficient_commit_rounds_ms": coeff_core.timings_ms, "coefficient_commit_same_proof_bytes": coeff_same,
                  "from_host_witness_ms": round(host_ms, 2), "from_host_witness_same_proof_bytes": host_bytes_same,
                  "from_host_witness_vector_ms": round(vec_ms, 2),
@@ -533,6 +577,9 @@ def main():
                               "proving key, host pointers): the 25 coset FFTs never reach the host and the CPU loops are gone",
                       "log_n": args.plonk_log_n, "pcie_gb_per_proof": {k: v["pcie_gb"] for k, v in modes.items()},
                       "ms": {k: v["ms"] for k, v in modes.items()}, "pcie_gb_per_s": {k: v["pcie_gb_per_s"] for k, v in modes.items()},
+                      "round_level": prove["round_level_abi_ms"] if prove else None,
+                      "round_level_note": "ms per proof when the caller swaps the BODIES of Prover::run_1st_round .. compute_opening_proofs for "
+                                          "mzk_prover_round1 .. round5 (INTEGRATION.md section 2b): witness vector in, commitments and evaluations out",
                       "device_resident_prove_ms": prove["prove_ms"] if prove else None}
         except Exception as e:                              # noqa: BLE001  (secondary: the headline must still be printed)
             dropin = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
@@ -578,7 +625,7 @@ def main():
         prove_sharded = {"what": "PlonkKzgSnark::prove on the bench circuit, strong scaling: commitments sharded by point range over the ranks "
                                  "(all-gather of Jacobian partials + local EC sum, 8(e).1), quotient domain split into residue classes with one "
                                  "all-gather (8(e).3) when the world size divides 8.  Python-orchestrated (compare with `prove` of the 1-GPU line); "
-                                 "profiles/r02_scale_model.json holds the model this is to be checked against",
+                                 "profiles/r04_scale_model.json (tools/scale_model.py) holds the model this is to be checked against",
                          }
         try:
             prove_sharded["turbo_bls12_381"] = sharded_prove(curve, args.plonk_log_n, "TurboPlonk")
