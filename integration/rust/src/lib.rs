@@ -58,6 +58,38 @@ pub struct SrsHandle {
     pub len: usize,
 }
 
+impl SrsHandle {
+    /// the library's handle (for the round-level entry points: rounds.rs)
+    pub fn raw(&self) -> u64 {
+        self.handle
+    }
+}
+
+/// text of the calling thread's last library error
+pub fn last_error() -> String {
+    unsafe { CStr::from_ptr(mzk_last_error()) }.to_string_lossy().into_owned()
+}
+
+/// x||y Montgomery limbs -> affine point; (0, 0) encodes infinity (`Commitment(G1Affine)`, pcs/structs.rs:16-19)
+pub fn affine_from_limbs<P: SWCurveConfig>(xy: &[u64]) -> Affine<P>
+where
+    P::BaseField: PrimeField,
+{
+    let limbs = xy.len() / 2;
+    if xy.iter().all(|w| *w == 0) {
+        return Affine::<P>::identity();
+    }
+    let f = |w: &[u64]| {
+        let mut v = P::BaseField::zero();
+        unsafe { core::ptr::copy_nonoverlapping(w.as_ptr(), &mut v as *mut P::BaseField as *mut u64, limbs) };
+        v
+    };
+    Affine::<P>::new_unchecked(f(&xy[..limbs]), f(&xy[limbs..]))
+}
+
+/// The round-level swap: the bodies of Prover::run_1st_round .. compute_opening_proofs behind mzk_prover_* (INTEGRATION.md section 2b).
+pub mod rounds;
+
 impl Drop for SrsHandle {
     fn drop(&mut self) {
         unsafe { mzk_srs_release(self.handle) };

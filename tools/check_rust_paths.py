@@ -10,7 +10,7 @@ import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = sys.argv[1] if len(sys.argv) > 1 else "/root/reference"
-RUST = [os.path.join(ROOT, "integration", "rust", p) for p in ("src/lib.rs", "src/bin/gen_fixtures.rs", "Cargo.toml")]
+RUST = [os.path.join(ROOT, "integration", "rust", p) for p in ("src/lib.rs", "src/rounds.rs", "src/bin/gen_fixtures.rs", "Cargo.toml")]
 
 # (reference file, regex that must match there, token that must appear in integration/rust)
 CHECKS = [
@@ -71,6 +71,25 @@ CHECKS = [
     ("plonk/benches/bench.rs", r"a = cs\.add\(a, cs\.one\(\)\)\?;", "cs.add(a, cs.one())"),
     # jf_utils::test_rng
     ("utilities/src/lib.rs", r"pub fn test_rng\(\) -> StdRng", "jf_utils::test_rng()"),
+    # rounds.rs: the transcript calls, struct literals and error variant of batch_prove_internal that the round-level swap keeps
+    ("plonk/src/transcript/mod.rs", r"fn append_commitments<E, P>\(\s*&mut self,\s*label: &'static \[u8\],\s*comms: &\[Commitment<E>\],", 'transcript.append_commitments(b"witness_poly_comms", &comms)'),
+    ("plonk/src/transcript/mod.rs", r"fn append_commitment<E, P>\(", 'transcript.append_commitment(b"perm_poly_comms", &comm)'),
+    ("plonk/src/transcript/mod.rs", r"fn get_and_append_challenge<E>\(\s*&mut self,\s*label: &'static \[u8\],?\s*\) -> Result<E::ScalarField, PlonkError>", 'transcript.get_and_append_challenge::<E>(b"tau")'),
+    ("plonk/src/transcript/mod.rs", r"fn append_proof_evaluations<E: Pairing>\(", "transcript.append_proof_evaluations::<E>(&poly_evals)"),
+    ("plonk/src/transcript/mod.rs", r"fn append_plookup_evaluations<E: Pairing>\(", "transcript.append_plookup_evaluations::<E>(evals)"),
+    ("plonk/src/proof_system/snark.rs", r'transcript\.append_commitments\(b"quot_poly_comms", &split_quot_poly_comms\)', 'b"quot_poly_comms"'),
+    ("plonk/src/proof_system/snark.rs", r'transcript\.append_commitments\(b"h_poly_comms", &h_poly_comms\)', 'b"h_poly_comms"'),
+    ("plonk/src/proof_system/snark.rs", r'transcript\.append_commitment\(b"plookup_poly_comms", &prod_lookup_poly_comm\)', 'b"plookup_poly_comms"'),
+    ("plonk/src/proof_system/snark.rs", r'get_and_append_challenge::<E>\(b"zeta"\).{0,3000}get_and_append_challenge::<E>\(b"v"\)', 'get_and_append_challenge::<E>(b"v")'),
+    ("plonk/src/errors.rs", r"WrongQuotientPolyDegree\(usize, usize\)", "SnarkError::WrongQuotientPolyDegree(0, 0)"),
+    ("plonk/src/proof_system/structs.rs", r"pub struct ProofEvaluations<F: Field> \{[^}]*pub wires_evals: Vec<F>,[^}]*pub wire_sigma_evals: Vec<F>,[^}]*pub perm_next_eval: F,", "ProofEvaluations { wires_evals"),
+    ("plonk/src/proof_system/structs.rs", r"pub struct PlookupProof<E: Pairing> \{[^}]*h_poly_comms: Vec<Commitment<E>>,[^}]*prod_lookup_poly_comm: Commitment<E>,[^}]*poly_evals: PlookupEvaluations<E::ScalarField>,", "PlookupProof { h_poly_comms"),
+    ("plonk/src/proof_system/structs.rs", r"pub struct BatchProof<E: Pairing> \{[^}]*wires_poly_comms_vec: Vec<Vec<Commitment<E>>>,[^}]*prod_perm_poly_comms_vec[^}]*poly_evals_vec[^}]*plookup_proofs_vec[^}]*split_quot_poly_comms[^}]*opening_proof[^}]*shifted_opening_proof",
+     "BatchProof { wires_poly_comms_vec, prod_perm_poly_comms_vec, poly_evals_vec, plookup_proofs_vec, split_quot_poly_comms"),
+    ("relation/src/traits.rs", r"fn public_input\(&self\) -> Result<Vec<Self::Wire>, CircuitError>;", "cs.public_input()?"),
+    ("relation/src/constraint_system.rs", r"pub\(crate\) wire_variables: \[Vec<Variable>; GATE_WIDTH \+ 2\],", "witness_and_wire_variables"),
+    ("relation/src/constraint_system.rs", r"pub\(crate\) witness: Vec<F>,", "witness_and_wire_variables"),
+    ("plonk/src/proof_system/prover.rs", r"DensePolynomial::rand\(hiding_bound, prng\)\.mul_by_vanishing_poly\(self\.domain\)", "DensePolynomial::rand(hiding_bound, prng)"),
     # the call sites lib.rs documents
     ("primitives/src/pcs/univariate_kzg/mod.rs", r"msm_bigint\(", "msm_bigint"),
     ("plonk/src/proof_system/prover.rs", r"fft_in_place|\.coset_fft|\.fft\(", "fft_in_place"),
