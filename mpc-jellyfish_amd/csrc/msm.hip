@@ -61,6 +61,10 @@ constexpr int SORT_SETS = 6;                                       // sorts run 
 struct SortStreams {                                               // one set per device context
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_sorted[SORT_SETS] = {}, ev_acc[SORT_SETS] = {};
+    // lanes: SMALL MSMs of a batch (every kernel of them a latency-bound launch on a fraction of the chip) run their whole per-MSM
+    // pipeline -- sort, accumulation, over-long buckets -- side by side, MSM p on lane p % SORT_SETS with that lane's buffers
+    hipStream_t lane[SORT_SETS] = {};
+    hipEvent_t ev_lane[SORT_SETS] = {};
 };
 SortStreams g_sort[MAX_CTX];
 int32_t sort_stream_init(SortStreams& ss) {
@@ -72,6 +76,8 @@ int32_t sort_stream_init(SortStreams& ss) {
     for (int i = 0; i < SORT_SETS; i++) {
         HIP_TRY(hipEventCreateWithFlags(&ss.ev_sorted[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ss.ev_acc[i], hipEventDisableTiming));
+        HIP_TRY(hipStreamCreateWithFlags(&ss.lane[i], hipStreamNonBlocking));
+        HIP_TRY(hipEventCreateWithFlags(&ss.ev_lane[i], hipEventDisableTiming));
     }
     return MZK_OK;
 }
@@ -106,8 +112,13 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     const bool sort2 = !pre.c && !no_sort2 && n_min >= (1ull << 16) && wm >= (1u << 14) && (wm >> PRE_FINE_LOG) <= 1024;
     const uint64_t sorted_max = pre.c ? n_max * n_dig : n_max;           // entries per bucket set
     MZK_TRY(ws_acquire(st));
-    const bool overlap = count > 1 && std::getenv("MZK_MSM_NO_OVERLAP") == nullptr;
-    const size_t nb = overlap ? (size_t)std::min(count, SORT_SETS) : 1;   // sets of sort buffers
+    // Batches of SMALL MSMs (<= 2^17 pairs: shards of a multi-GPU proof, the reference's own bench size 2^15) run in lanes -- one stream
+    // per MSM, all of its kernels on it -- instead of the two-stream pipeline that hides the sort of MSM p + 1 under the accumulation of
+    // MSM p: at these sizes every launch is a chain of latencies on a corner of the chip, and five chains side by side cost about one.
+    static const bool no_lanes = std::getenv("MZK_MSM_NO_LANES") != nullptr;                     // (A/B switch)
+    const bool lanes = count > 1 && count <= SORT_SETS && count <= MSM_HEAVY_JOBS && n_max <= (1ull << 17) && !no_lanes;
+    const bool overlap = count > 1 && !lanes && std::getenv("MZK_MSM_NO_OVERLAP") == nullptr;
+    const size_t nb = (overlap || lanes) ? (size_t)std::min(count, SORT_SETS) : 1;   // sets of sort buffers
     MZK_TRY(g_ws.hist.reserve(nb * wm * 4));
     MZK_TRY(g_ws.offs.reserve(nb * wm * 4));
     MZK_TRY(g_ws.cursor.reserve(nb * wm * 4));                           // bucket order by load
@@ -141,6 +152,14 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
             if (shrink > 0) { pb.low = 1u << top_bits; pb.low_log = PRE_FINE_LOG - shrink; pb.low_bins = pb.low >> pb.low_log; }
         }
     }
+    // Small bucket ranges: the fine level is one workgroup per bin of 2^PRE_FINE_LOG buckets -- 16 workgroups for the 2^15 buckets of a
+    // 2^15-pair MSM (29 us of latency per sort).  With uniform bins narrowed to 2^L buckets about 256 workgroups share the same entries.
+    if ((pre.c || sort2) && pb.low == 0 && (wm >> PRE_FINE_LOG) < 128) {
+        int lg = 0;
+        while ((2ull << lg) <= wm) lg++;
+        const int L = std::max(5, lg - 8);
+        if (L < PRE_FINE_LOG && (wm >> L) >= 2 && (wm >> L) <= 1024 && wm % (1ull << L) == 0) { pb.low = (uint32_t)wm; pb.low_log = (uint32_t)L; pb.low_bins = (uint32_t)(wm >> L); }
+    }
     const uint32_t n_bins = pre.c ? std::max<uint32_t>(1u, pb.count(M)) : (sort2 ? pb.count((uint32_t)wm) : 0u);
     const size_t cnt_words = 2048 + (size_t)n_win * 1024;                // bin totals, bin cursors, order keys
     MZK_TRY(g_ws.pre_cnt.reserve(nb * cnt_words * 4));
@@ -173,11 +192,21 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
         HIP_TRY(hipEventRecord(ss.ev_start, st));                        // scalars and workspace are ready on st
         HIP_TRY(hipStreamWaitEvent(sst, ss.ev_start, 0));
     }
+    size_t split_words_per_set = 0;                                      // lanes: every MSM needs its own partial sums of the split accumulation
+    if (lanes) {
+        MZK_TRY(sort_stream_init(ss));
+        HIP_TRY(hipEventRecord(ss.ev_start, st));
+        for (int q = 0; q < count; q++) HIP_TRY(hipStreamWaitEvent(ss.lane[q], ss.ev_start, 0));
+        split_words_per_set = (wm << 3) * EC::PT_WORDS;                  // up to 2^3 threads per bucket (max_split)
+        MZK_TRY(g_ws.split.reserve((size_t)count * split_words_per_set * 4));
+    }
+    hipStream_t const caller_st = st;
     {
         ProfScope total("msm_total", st);
         const unsigned n_ranges = M >> MSM_RANGE_LOG ? M >> MSM_RANGE_LOG : 1u;
         for (int p = 0; p < count; p++) {
-            const size_t b = overlap ? (size_t)p % nb : 0;               // this MSM's set of sort buffers
+            const size_t b = (overlap || lanes) ? (size_t)p % nb : 0;    // this MSM's set of sort buffers
+            if (lanes) { sst = ss.lane[b]; st = ss.lane[b]; }            // everything of this MSM on its lane (st is the caller's stream again below)
             uint32_t* hist = g_ws.hist.as<uint32_t>() + b * wm;
             uint32_t* offs = g_ws.offs.as<uint32_t>() + b * wm;
             uint32_t* order = g_ws.cursor.as<uint32_t>() + b * wm;
@@ -239,14 +268,15 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 uint32_t* cnt = g_ws.pre_cnt.as<uint32_t>() + b * cnt_words;
                 uint32_t* coff = g_ws.pre_off.as<uint32_t>() + b * 8192;
                 unsigned long long* coarse = g_ws.pre_ce.as<unsigned long long>() + b * sorted_words;
-                const uint32_t n_chunks = (uint32_t)((n + PRE_CHUNK - 1) / PRE_CHUNK);
+                const uint32_t chunk = pre_chunk_of(n);
+                const uint32_t n_chunks = (uint32_t)((n + chunk - 1) / chunk);
                 uint32_t* bin_total = cnt;                       // [n_bins]
                 uint32_t* bin_cursor = cnt + 1024;               // [n_bins]
                 uint32_t* bin_start = coff;                      // [n_bins + 1]
                 const uint32_t bstride = pre.c ? 0u : M;                 // plain path: window w sorts into buckets [w M, (w + 1) M)
                 hipLaunchKernelGGL((pre_digits_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, sst, d_scalars, n, is_mont, c, n_dig, dig32, dstride);
                 HIP_TRY(hipMemsetAsync(cnt, 0, cnt_words * 4, sst));              // bin totals and, further down, the order keys: one fill
-                hipLaunchKernelGGL(pre_coarse_count_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, sst, dig32, n, dstride, n_dig, (int)n_bins, pb, bstride, bin_total);
+                hipLaunchKernelGGL(pre_coarse_count_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, sst, dig32, n, dstride, n_dig, (int)n_bins, pb, bstride, chunk, bin_total);
                 // a bin with more than PRE_HUGE entries (skewed scalars) is sorted by the pre_huge_* kernels in slices of `slice` records
                 uint32_t* huge = coff + 1088;
                 const uint64_t records = n * (uint64_t)n_dig;             // what the coarse level holds (both paths)
@@ -254,7 +284,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 const uint32_t slice_grid = (uint32_t)std::min<uint64_t>(PRE_SLICE_CAP, records / slice + PRE_HUGE_MAX + 1);
                 const uint32_t huge_grid = (uint32_t)std::min<uint64_t>(PRE_HUGE_MAX, records / PRE_HUGE + 1);
                 hipLaunchKernelGGL(pre_bin_scan_kernel, dim3(1), dim3(1024), 0, sst, bin_total, (int)n_bins, bin_start, bin_cursor, slice, huge);
-                hipLaunchKernelGGL(pre_coarse_scatter_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, sst, dig32, n, dstride, n_dig, (int)n_bins, pb, bstride,
+                hipLaunchKernelGGL(pre_coarse_scatter_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, sst, dig32, n, dstride, n_dig, (int)n_bins, pb, bstride, chunk,
                                    pre.c ? pre.tab_stride : 0ull, pre.c ? items[p].base_off : 0ull, bin_cursor, coarse);
                 hipLaunchKernelGGL(pre_fine_kernel, dim3(n_bins), dim3(1024), 0, sst, bin_start, coarse, (uint32_t)wm, pb, hist, offs, sorted, huge);
                 hipLaunchKernelGGL(pre_huge_zero_kernel, dim3(huge_grid), dim3(1024), 0, sst, huge, (uint32_t)wm, pb, hist);
@@ -283,7 +313,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 int log_split = 0;
                 const unsigned long long mean = n_sorted / M;
                 static const int max_split = std::getenv("MZK_MSM_MAX_SPLIT") ? std::atoi(std::getenv("MZK_MSM_MAX_SPLIT")) : 3;   // (tuning switch)
-                while (log_split < max_split) {
+                while (log_split < max_split && !(lanes && log_split >= 3)) {      // (lanes: the per-MSM partial-sum buffers hold 2^3 per bucket)
                     const int nx = log_split + 1;
                     const bool small_grid = (wm << nx) <= (1ull << 18);
                     if (small_grid ? (mean >> (nx + 1)) == 0 : ((1ull << nx) - 1) * 32 > mean) break;
@@ -295,8 +325,8 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                                        d_bases, list_stride, offs, hist, sorted, order, M, n_win, cap, desc_count, buckets, occ);
                 } else {
                     const size_t threads = wm << log_split;
-                    MZK_TRY(g_ws.split.reserve(threads * EC::PT_WORDS * 4));
-                    uint32_t* sub = g_ws.split.as<uint32_t>();
+                    if (!lanes) MZK_TRY(g_ws.split.reserve(threads * EC::PT_WORDS * 4));
+                    uint32_t* sub = g_ws.split.as<uint32_t>() + (lanes ? b * split_words_per_set : 0);
                     {
                         ProfScope ps("msm_accumulate", st);               // the dominant launch alone: what rocprofv3 --stats averages
                         hipLaunchKernelGGL((msm_accumulate_split_kernel<EC>), dim3((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)),
@@ -333,6 +363,11 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 }
             }
             if (overlap) HIP_TRY(hipEventRecord(ss.ev_acc[b], st));
+            if (lanes) {
+                HIP_TRY(hipEventRecord(ss.ev_lane[b], st));
+                st = caller_st;
+                HIP_TRY(hipStreamWaitEvent(st, ss.ev_lane[b], 0));       // the heavy-bucket levels and the reduction follow on the caller's stream
+            }
         }
         if (defer_heavy) {                                          // the heavy buckets of all MSMs of the batch, one launch per level
             ProfScope ps("msm_long", st);
@@ -671,7 +706,12 @@ void msm_release_streams() {
     if (!ss.stream) return;
     (void)hipStreamDestroy(ss.stream);
     (void)hipEventDestroy(ss.ev_start);
-    for (int i = 0; i < SORT_SETS; i++) { (void)hipEventDestroy(ss.ev_sorted[i]); (void)hipEventDestroy(ss.ev_acc[i]); }
+    for (int i = 0; i < SORT_SETS; i++) {
+        (void)hipEventDestroy(ss.ev_sorted[i]);
+        (void)hipEventDestroy(ss.ev_acc[i]);
+        if (ss.lane[i]) (void)hipStreamDestroy(ss.lane[i]);
+        if (ss.ev_lane[i]) (void)hipEventDestroy(ss.ev_lane[i]);
+    }
     ss = SortStreams();
 }
 

@@ -11,7 +11,15 @@
 
 namespace mzk {
 
-constexpr int PRE_CHUNK = 4096;              // scalars per coarse-partition workgroup (multiple of 4 * PRE_CTHREADS)
+constexpr int PRE_CHUNK = 4096;              // scalars per coarse-partition workgroup at large sizes; small MSMs take smaller chunks (pre_chunk_of)
+// A workgroup of the coarse level owns `chunk` scalars (a multiple of 4: rows of digits are read 16 bytes at a time).  4096 of them give
+// 256 workgroups at 2^20 scalars; a 2^15-scalar MSM would run on 8 (measured: 27 + 38 us for the two coarse kernels of a 2^15-pair MSM,
+// all latency), so small sizes halve the chunk until about 128 workgroups exist.
+inline uint32_t pre_chunk_of(unsigned long long n) {
+    uint32_t chunk = PRE_CHUNK;
+    while (chunk > 256 && n / chunk < 128) chunk >>= 1;
+    return chunk;
+}
 constexpr int PRE_CTHREADS = 1024;
 constexpr int PRE_FINE_LOG = 11;             // buckets per fine workgroup (2^19 buckets -> 256 workgroups)
 constexpr uint32_t PRE_EMPTY = 0xFFFFFFFFu;
@@ -55,21 +63,23 @@ __global__ __launch_bounds__(MSM_THREADS) void pre_digits_kernel(const uint32_t*
 // bucket_stride: 0 on the table path (all windows share one bucket set); M on the plain path, whose window w owns the buckets
 // [w M, (w + 1) M) of one combined bucket range -- the same two-level sort then serves both paths.
 __global__ __launch_bounds__(PRE_CTHREADS) void pre_coarse_count_kernel(const uint32_t* __restrict__ digits, unsigned long long n, unsigned long long stride,
-                                                                int n_win, int n_bins, PreBins pb, uint32_t bucket_stride, uint32_t* __restrict__ bin_total) {
+                                                                int n_win, int n_bins, PreBins pb, uint32_t bucket_stride, uint32_t chunk,
+                                                                uint32_t* __restrict__ bin_total) {
     __shared__ uint32_t bins[1024];
     const uint32_t tid = threadIdx.x;
     for (int j = tid; j < n_bins; j += PRE_CTHREADS) bins[j] = 0u;
     __syncthreads();
-    const unsigned long long lo = (unsigned long long)blockIdx.x * PRE_CHUNK, hi = min(n, lo + PRE_CHUNK);
-    for (int w = 0; w < n_win; w++) {
-        const uint32_t* dw = digits + (size_t)w * stride;
-        for (unsigned long long i = lo + 4ull * tid; i < hi; i += 4 * PRE_CTHREADS) {           // stride rows are 16-B aligned, lo is too
-            const uint4 v = *reinterpret_cast<const uint4*>(dw + i);
-            const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
+    const unsigned long long lo = (unsigned long long)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    // the chunk's (window, four scalars) items spread over the threads: a small chunk still keeps the whole workgroup busy
+    const uint32_t quads = (uint32_t)((hi - lo + 3) / 4), items = quads * (uint32_t)n_win;
+    for (uint32_t t = tid; t < items; t += PRE_CTHREADS) {
+        const uint32_t w = t / quads;
+        const unsigned long long i = lo + 4ull * (t - w * quads);                                 // stride rows are 16-B aligned, lo is too
+        const uint4 v = *reinterpret_cast<const uint4*>(digits + (size_t)w * stride + i);
+        const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (i + k < hi && d4[k] != PRE_EMPTY) atomicAdd(&bins[pb.bin_of((d4[k] & 0x7FFFFFFFu) + (uint32_t)w * bucket_stride)], 1u);
-        }
+        for (int k = 0; k < 4; k++)
+            if (i + k < hi && d4[k] != PRE_EMPTY) atomicAdd(&bins[pb.bin_of((d4[k] & 0x7FFFFFFFu) + w * bucket_stride)], 1u);
     }
     __syncthreads();
     for (int j = tid; j < n_bins; j += PRE_CTHREADS)
@@ -192,22 +202,22 @@ __global__ __launch_bounds__(1024) void pre_huge_scatter_kernel(const uint32_t* 
 }
 
 __global__ __launch_bounds__(PRE_CTHREADS) void pre_coarse_scatter_kernel(const uint32_t* __restrict__ digits, unsigned long long n, unsigned long long stride,
-                                                                  int n_win, int n_bins, PreBins pb, uint32_t bucket_stride, unsigned long long tab_stride,
+                                                                  int n_win, int n_bins, PreBins pb, uint32_t bucket_stride, uint32_t chunk, unsigned long long tab_stride,
                                                                   unsigned long long base_off, uint32_t* __restrict__ bin_cursor, unsigned long long* __restrict__ coarse) {
     __shared__ uint32_t bins[1024];
     const uint32_t tid = threadIdx.x;
     for (int j = tid; j < n_bins; j += PRE_CTHREADS) bins[j] = 0u;
     __syncthreads();
-    const unsigned long long lo = (unsigned long long)blockIdx.x * PRE_CHUNK, hi = min(n, lo + PRE_CHUNK);
-    for (int w = 0; w < n_win; w++) {
-        const uint32_t* dw = digits + (size_t)w * stride;
-        for (unsigned long long i = lo + 4ull * tid; i < hi; i += 4 * PRE_CTHREADS) {
-            const uint4 v = *reinterpret_cast<const uint4*>(dw + i);
-            const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
+    const unsigned long long lo = (unsigned long long)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    const uint32_t quads = (uint32_t)((hi - lo + 3) / 4), items = quads * (uint32_t)n_win;       // as in pre_coarse_count_kernel
+    for (uint32_t t = tid; t < items; t += PRE_CTHREADS) {
+        const uint32_t w = t / quads;
+        const unsigned long long i = lo + 4ull * (t - w * quads);
+        const uint4 v = *reinterpret_cast<const uint4*>(digits + (size_t)w * stride + i);
+        const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int k = 0; k < 4; k++)
-                if (i + k < hi && d4[k] != PRE_EMPTY) atomicAdd(&bins[pb.bin_of((d4[k] & 0x7FFFFFFFu) + (uint32_t)w * bucket_stride)], 1u);
-        }
+        for (int k = 0; k < 4; k++)
+            if (i + k < hi && d4[k] != PRE_EMPTY) atomicAdd(&bins[pb.bin_of((d4[k] & 0x7FFFFFFFu) + w * bucket_stride)], 1u);
     }
     __syncthreads();
     for (int j = tid; j < n_bins; j += PRE_CTHREADS) {
@@ -215,21 +225,20 @@ __global__ __launch_bounds__(PRE_CTHREADS) void pre_coarse_scatter_kernel(const 
         bins[j] = c ? atomicAdd(&bin_cursor[j], c) : 0u;              // this chunk's range in bin j starts here
     }
     __syncthreads();
-    for (int w = 0; w < n_win; w++) {
-        const uint32_t* dw = digits + (size_t)w * stride;
-        for (unsigned long long i = lo + 4ull * tid; i < hi; i += 4 * PRE_CTHREADS) {
-            const uint4 v = *reinterpret_cast<const uint4*>(dw + i);
-            const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
+    for (uint32_t t = tid; t < items; t += PRE_CTHREADS) {
+        const uint32_t w = t / quads;
+        const unsigned long long i = lo + 4ull * (t - w * quads);
+        const uint4 v = *reinterpret_cast<const uint4*>(digits + (size_t)w * stride + i);
+        const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
-            for (int k = 0; k < 4; k++) {
-                const uint32_t d = d4[k];
-                if (i + k >= hi || d == PRE_EMPTY) continue;
-                const uint32_t b = (d & 0x7FFFFFFFu) + (uint32_t)w * bucket_stride;
-                const uint32_t bin = pb.bin_of(b);
-                const uint32_t pos = atomicAdd(&bins[bin], 1u);
-                const uint32_t e = (uint32_t)((unsigned long long)w * tab_stride + base_off + i + k) | (d & 0x80000000u);
-                coarse[pos] = ((unsigned long long)(b - pb.first_bucket(bin)) << 32) | e;               // one 8-byte record: bucket inside the bin, entry
-            }
+        for (int k = 0; k < 4; k++) {
+            const uint32_t d = d4[k];
+            if (i + k >= hi || d == PRE_EMPTY) continue;
+            const uint32_t b = (d & 0x7FFFFFFFu) + w * bucket_stride;
+            const uint32_t bin = pb.bin_of(b);
+            const uint32_t pos = atomicAdd(&bins[bin], 1u);
+            const uint32_t e = (uint32_t)((unsigned long long)w * tab_stride + base_off + i + k) | (d & 0x80000000u);
+            coarse[pos] = ((unsigned long long)(b - pb.first_bucket(bin)) << 32) | e;                   // one 8-byte record: bucket inside the bin, entry
         }
     }
 }
