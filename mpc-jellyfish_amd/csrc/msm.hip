@@ -61,10 +61,6 @@ constexpr int SORT_SETS = 6;                                       // sorts run 
 struct SortStreams {                                               // one set per device context
     hipStream_t stream = nullptr;
     hipEvent_t ev_start = nullptr, ev_sorted[SORT_SETS] = {}, ev_acc[SORT_SETS] = {};
-    // lanes: SMALL MSMs of a batch (every kernel of them a latency-bound launch on a fraction of the chip) run their whole per-MSM
-    // pipeline -- sort, accumulation, over-long buckets -- side by side, MSM p on lane p % SORT_SETS with that lane's buffers
-    hipStream_t lane[SORT_SETS] = {};
-    hipEvent_t ev_lane[SORT_SETS] = {};
 };
 SortStreams g_sort[MAX_CTX];
 int32_t sort_stream_init(SortStreams& ss) {
@@ -76,8 +72,6 @@ int32_t sort_stream_init(SortStreams& ss) {
     for (int i = 0; i < SORT_SETS; i++) {
         HIP_TRY(hipEventCreateWithFlags(&ss.ev_sorted[i], hipEventDisableTiming));
         HIP_TRY(hipEventCreateWithFlags(&ss.ev_acc[i], hipEventDisableTiming));
-        HIP_TRY(hipStreamCreateWithFlags(&ss.lane[i], hipStreamNonBlocking));
-        HIP_TRY(hipEventCreateWithFlags(&ss.ev_lane[i], hipEventDisableTiming));
     }
     return MZK_OK;
 }
@@ -112,13 +106,10 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     const bool sort2 = !pre.c && !no_sort2 && n_min >= (1ull << 16) && wm >= (1u << 14) && (wm >> PRE_FINE_LOG) <= 1024;
     const uint64_t sorted_max = pre.c ? n_max * n_dig : n_max;           // entries per bucket set
     MZK_TRY(ws_acquire(st));
-    // Batches of SMALL MSMs (<= 2^17 pairs: shards of a multi-GPU proof, the reference's own bench size 2^15) run in lanes -- one stream
-    // per MSM, all of its kernels on it -- instead of the two-stream pipeline that hides the sort of MSM p + 1 under the accumulation of
-    // MSM p: at these sizes every launch is a chain of latencies on a corner of the chip, and five chains side by side cost about one.
-    static const bool no_lanes = std::getenv("MZK_MSM_NO_LANES") != nullptr;                     // (A/B switch)
-    const bool lanes = count > 1 && count <= SORT_SETS && count <= MSM_HEAVY_JOBS && n_max <= (1ull << 17) && !no_lanes;
-    const bool overlap = count > 1 && !lanes && std::getenv("MZK_MSM_NO_OVERLAP") == nullptr;
-    const size_t nb = (overlap || lanes) ? (size_t)std::min(count, SORT_SETS) : 1;   // sets of sort buffers
+    // (Tried in round 4 and dropped: batches of SMALL MSMs in "lanes", one stream per MSM with all of its kernels on it -- cross-stream
+    // event waits and queue switches cost more than the latency chains they overlap: profiles/r04_small_msm_lanes_experiment.txt.)
+    const bool overlap = count > 1 && std::getenv("MZK_MSM_NO_OVERLAP") == nullptr;
+    const size_t nb = overlap ? (size_t)std::min(count, SORT_SETS) : 1;   // sets of sort buffers
     MZK_TRY(g_ws.hist.reserve(nb * wm * 4));
     MZK_TRY(g_ws.offs.reserve(nb * wm * 4));
     MZK_TRY(g_ws.cursor.reserve(nb * wm * 4));                           // bucket order by load
@@ -192,21 +183,12 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
         HIP_TRY(hipEventRecord(ss.ev_start, st));                        // scalars and workspace are ready on st
         HIP_TRY(hipStreamWaitEvent(sst, ss.ev_start, 0));
     }
-    size_t split_words_per_set = 0;                                      // lanes: every MSM needs its own partial sums of the split accumulation
-    if (lanes) {
-        MZK_TRY(sort_stream_init(ss));
-        HIP_TRY(hipEventRecord(ss.ev_start, st));
-        for (int q = 0; q < count; q++) HIP_TRY(hipStreamWaitEvent(ss.lane[q], ss.ev_start, 0));
-        split_words_per_set = (wm << 3) * EC::PT_WORDS;                  // up to 2^3 threads per bucket (max_split)
-        MZK_TRY(g_ws.split.reserve((size_t)count * split_words_per_set * 4));
-    }
-    hipStream_t const caller_st = st;
+
     {
         ProfScope total("msm_total", st);
         const unsigned n_ranges = M >> MSM_RANGE_LOG ? M >> MSM_RANGE_LOG : 1u;
         for (int p = 0; p < count; p++) {
-            const size_t b = (overlap || lanes) ? (size_t)p % nb : 0;    // this MSM's set of sort buffers
-            if (lanes) { sst = ss.lane[b]; st = ss.lane[b]; }            // everything of this MSM on its lane (st is the caller's stream again below)
+            const size_t b = overlap ? (size_t)p % nb : 0;               // this MSM's set of sort buffers
             uint32_t* hist = g_ws.hist.as<uint32_t>() + b * wm;
             uint32_t* offs = g_ws.offs.as<uint32_t>() + b * wm;
             uint32_t* order = g_ws.cursor.as<uint32_t>() + b * wm;
@@ -313,7 +295,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 int log_split = 0;
                 const unsigned long long mean = n_sorted / M;
                 static const int max_split = std::getenv("MZK_MSM_MAX_SPLIT") ? std::atoi(std::getenv("MZK_MSM_MAX_SPLIT")) : 3;   // (tuning switch)
-                while (log_split < max_split && !(lanes && log_split >= 3)) {      // (lanes: the per-MSM partial-sum buffers hold 2^3 per bucket)
+                while (log_split < max_split) {
                     const int nx = log_split + 1;
                     const bool small_grid = (wm << nx) <= (1ull << 18);
                     if (small_grid ? (mean >> (nx + 1)) == 0 : ((1ull << nx) - 1) * 32 > mean) break;
@@ -325,8 +307,8 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                                        d_bases, list_stride, offs, hist, sorted, order, M, n_win, cap, desc_count, buckets, occ);
                 } else {
                     const size_t threads = wm << log_split;
-                    if (!lanes) MZK_TRY(g_ws.split.reserve(threads * EC::PT_WORDS * 4));
-                    uint32_t* sub = g_ws.split.as<uint32_t>() + (lanes ? b * split_words_per_set : 0);
+                    MZK_TRY(g_ws.split.reserve(threads * EC::PT_WORDS * 4));
+                    uint32_t* sub = g_ws.split.as<uint32_t>();
                     {
                         ProfScope ps("msm_accumulate", st);               // the dominant launch alone: what rocprofv3 --stats averages
                         hipLaunchKernelGGL((msm_accumulate_split_kernel<EC>), dim3((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)),
@@ -363,11 +345,6 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 }
             }
             if (overlap) HIP_TRY(hipEventRecord(ss.ev_acc[b], st));
-            if (lanes) {
-                HIP_TRY(hipEventRecord(ss.ev_lane[b], st));
-                st = caller_st;
-                HIP_TRY(hipStreamWaitEvent(st, ss.ev_lane[b], 0));       // the heavy-bucket levels and the reduction follow on the caller's stream
-            }
         }
         if (defer_heavy) {                                          // the heavy buckets of all MSMs of the batch, one launch per level
             ProfScope ps("msm_long", st);
@@ -706,12 +683,7 @@ void msm_release_streams() {
     if (!ss.stream) return;
     (void)hipStreamDestroy(ss.stream);
     (void)hipEventDestroy(ss.ev_start);
-    for (int i = 0; i < SORT_SETS; i++) {
-        (void)hipEventDestroy(ss.ev_sorted[i]);
-        (void)hipEventDestroy(ss.ev_acc[i]);
-        if (ss.lane[i]) (void)hipStreamDestroy(ss.lane[i]);
-        if (ss.ev_lane[i]) (void)hipEventDestroy(ss.ev_lane[i]);
-    }
+    for (int i = 0; i < SORT_SETS; i++) { (void)hipEventDestroy(ss.ev_sorted[i]); (void)hipEventDestroy(ss.ev_acc[i]); }
     ss = SortStreams();
 }
 
