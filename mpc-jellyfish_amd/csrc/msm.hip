@@ -96,9 +96,19 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     const int n_dig = msm_num_windows(is_mont ? FR::BITS : 256, c);      // digits per scalar
     const int n_win = pre.c ? 1 : n_dig;                                 // bucket sets per MSM
     cur().last_c = c; cur().last_w = n_dig; cur().last_m = M;
-    const size_t wm = (size_t)n_win * M;
     uint64_t n_max = 0, n_min = ~0ull;
     for (int p = 0; p < count; p++) { n_max = std::max<uint64_t>(n_max, items[p].n); n_min = std::min<uint64_t>(n_min, items[p].n); }
+    // A batch of SMALL table-path MSMs is FUSED (msm_pre.cuh, PreMulti): one sort, one accumulation, one pass over the over-long buckets
+    // for all of them, over the concatenation of their bucket sets -- at these sizes every launch is a chain of latencies on a corner of
+    // the chip (a 2^15-pair MSM: ~25 launches, 0.26 ms of them before the reduction), and k chains side by side in ONE launch cost about
+    // one.  Downstream of the coarse sort level the fused batch IS a plain-path problem with `count` bucket sets.  Needs uniform coarse
+    // bins (no short top digit: top_bits >= c - 1).
+    static const bool no_fuse = std::getenv("MZK_MSM_NO_FUSE") != nullptr;                       // (A/B switch)
+    const int top_bits_all = (is_mont ? FR::BITS : 256) - c * (n_dig - 1);
+    const bool fuse = pre.c && count > 1 && count <= PRE_FUSE_MAX && n_max <= (1ull << 17) && top_bits_all >= c - 1 && !no_fuse;
+    const int sets = fuse ? count : n_win;                               // bucket sets of one pass of the pipeline below
+    const int passes = fuse ? 1 : count;
+    const size_t wm = (size_t)sets * M;
     // Large plain-path MSMs (no fixed-base table: what bench.py's headline runs) sort with the table path's two-level LDS sort over
     // the COMBINED bucket range of their windows (window w owns buckets [w M, (w + 1) M)): one coalesced pass over the digits per
     // level instead of msm_sort_kernel's one scan of a window's digits per 2048-bucket range.
@@ -108,8 +118,8 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     MZK_TRY(ws_acquire(st));
     // (Tried in round 4 and dropped: batches of SMALL MSMs in "lanes", one stream per MSM with all of its kernels on it -- cross-stream
     // event waits and queue switches cost more than the latency chains they overlap: profiles/r04_small_msm_lanes_experiment.txt.)
-    const bool overlap = count > 1 && std::getenv("MZK_MSM_NO_OVERLAP") == nullptr;
-    const size_t nb = overlap ? (size_t)std::min(count, SORT_SETS) : 1;   // sets of sort buffers
+    const bool overlap = passes > 1 && std::getenv("MZK_MSM_NO_OVERLAP") == nullptr;
+    const size_t nb = overlap ? (size_t)std::min(passes, SORT_SETS) : 1;  // sets of sort buffers
     MZK_TRY(g_ws.hist.reserve(nb * wm * 4));
     MZK_TRY(g_ws.offs.reserve(nb * wm * 4));
     MZK_TRY(g_ws.cursor.reserve(nb * wm * 4));                           // bucket order by load
@@ -117,18 +127,19 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     // heavy buckets (msm.cuh): per window <= entries / MSM_HEAVY_RUN full level-1 runs plus one partial run per heavy bucket
     const uint32_t run_cap_max = (uint32_t)(2 * (sorted_max / MSM_HEAVY_RUN) + 2);
     const uint32_t h1_cap_max = (uint32_t)(sorted_max / MSM_HEAVY_PER_THREAD + 2 * (size_t)run_cap_max + 2);       // level-1 sums: one per 16 entries (+ slack per run)
-    const size_t heavy_runs_bytes = (size_t)n_win * 3 * run_cap_max * sizeof(HeavyRun);
+    const size_t heavy_runs_bytes = (size_t)sets * 3 * run_cap_max * sizeof(HeavyRun);
     // In a batch of at most SORT_SETS (and MSM_HEAVY_JOBS) MSMs every MSM keeps its own sorted list until the end, so their heavy
     // kernels are deferred and run as ONE launch per level over all of them (msm.cuh, HeavyJobs): each MSM then needs its own
     // descriptors, counters and partial sums ("slot").
-    const bool defer_heavy = count > 1 && (size_t)count <= nb && count <= MSM_HEAVY_JOBS;
-    const size_t slots = defer_heavy ? (size_t)count : 1;
-    const size_t desc_slot_bytes = (((size_t)n_win * desc_cap_max * sizeof(LongDesc) + (size_t)n_win * 4 * (1 + MSM_HEAVY_COUNTERS) + 16 + heavy_runs_bytes) + 255) & ~(size_t)255;
-    const size_t parts_slot_words = (size_t)n_win * desc_cap_max * EC::PT_WORDS + (size_t)n_win * ((size_t)h1_cap_max + 2 * (size_t)run_cap_max) * EC::PT_WORDS;
+    const bool defer_heavy = passes > 1 && (size_t)passes <= nb && passes <= MSM_HEAVY_JOBS;
+    const size_t slots = defer_heavy ? (size_t)passes : 1;
+    const size_t desc_slot_bytes = (((size_t)sets * desc_cap_max * sizeof(LongDesc) + (size_t)sets * 4 * (1 + MSM_HEAVY_COUNTERS) + 16 + heavy_runs_bytes) + 255) & ~(size_t)255;
+    const size_t parts_slot_words = (size_t)sets * desc_cap_max * EC::PT_WORDS + (size_t)sets * ((size_t)h1_cap_max + 2 * (size_t)run_cap_max) * EC::PT_WORDS;
     MZK_TRY(g_ws.long_desc.reserve(slots * desc_slot_bytes));
     MZK_TRY(g_ws.long_parts.reserve(slots * parts_slot_words * 4));
     const unsigned long long dstride_max = (n_max + 7) & ~7ull;
-    const size_t digits_bytes = (size_t)n_dig * dstride_max * ((pre.c || sort2) ? 4 : 2), sorted_words = ((size_t)n_dig * n_max + 3) & ~(size_t)3;
+    const size_t fused_k = fuse ? (size_t)count : 1;                      // MSMs per pass
+    const size_t digits_bytes = fused_k * n_dig * dstride_max * ((pre.c || sort2) ? 4 : 2), sorted_words = (fused_k * n_dig * n_max + 3) & ~(size_t)3;
     MZK_TRY(g_ws.digits.reserve(nb * digits_bytes));
     MZK_TRY(g_ws.sorted.reserve(nb * sorted_words * 4));
     // coarse bins of the table path: the low 2^top_bits buckets also receive the short top digit of every scalar, so they
@@ -151,15 +162,15 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
         const int L = std::max(5, lg - 8);
         if (L < PRE_FINE_LOG && (wm >> L) >= 2 && (wm >> L) <= 1024 && wm % (1ull << L) == 0) { pb.low = (uint32_t)wm; pb.low_log = (uint32_t)L; pb.low_bins = (uint32_t)(wm >> L); }
     }
-    const uint32_t n_bins = pre.c ? std::max<uint32_t>(1u, pb.count(M)) : (sort2 ? pb.count((uint32_t)wm) : 0u);
-    const size_t cnt_words = 2048 + (size_t)n_win * 1024;                // bin totals, bin cursors, order keys
+    const uint32_t n_bins = (pre.c || sort2) ? std::max<uint32_t>(1u, pb.count((uint32_t)wm)) : 0u;      // (table path, one MSM: wm == M)
+    const size_t cnt_words = 2048 + (size_t)sets * 1024;                 // bin totals, bin cursors, order keys
     MZK_TRY(g_ws.pre_cnt.reserve(nb * cnt_words * 4));
     if (pre.c || sort2) {
         MZK_TRY(g_ws.pre_off.reserve(nb * 8192 * 4));                      // bin_start [n_bins + 1 <= 1025], then the huge-bin words (msm_pre.cuh)
         MZK_TRY(g_ws.pre_ce.reserve(nb * sorted_words * 8));
     }
-    MZK_TRY(g_ws.buckets.reserve((size_t)count * wm * EC::PT_WORDS * 4));
-    MZK_TRY(g_ws.occ.reserve((size_t)count * wm));                        // one byte per bucket slot: does it hold a point?
+    MZK_TRY(g_ws.buckets.reserve((size_t)passes * wm * EC::PT_WORDS * 4));
+    MZK_TRY(g_ws.occ.reserve((size_t)passes * wm));                       // one byte per bucket slot: does it hold a point?
     const int n_out_one = n_win * (log_m + 1);
     const int n_out = n_out_one * count;
     const size_t out_bytes = (size_t)n_out * 4 * FQ::N * 4;
@@ -187,13 +198,13 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     {
         ProfScope total("msm_total", st);
         const unsigned n_ranges = M >> MSM_RANGE_LOG ? M >> MSM_RANGE_LOG : 1u;
-        for (int p = 0; p < count; p++) {
+        for (int p = 0; p < passes; p++) {
             const size_t b = overlap ? (size_t)p % nb : 0;               // this MSM's set of sort buffers
             uint32_t* hist = g_ws.hist.as<uint32_t>() + b * wm;
             uint32_t* offs = g_ws.offs.as<uint32_t>() + b * wm;
             uint32_t* order = g_ws.cursor.as<uint32_t>() + b * wm;
             uint32_t* sorted = g_ws.sorted.as<uint32_t>() + b * sorted_words;
-            const uint64_t n = items[p].n;
+            const uint64_t n = fuse ? n_max : items[p].n;                // fused: the longest MSM of the batch sizes grids and caps
             const uint32_t* d_scalars = items[p].d_scalars;
             const uint32_t* d_bases = items[p].d_bases;
             uint32_t* buckets = g_ws.buckets.as<uint32_t>() + (size_t)p * wm * EC::PT_WORDS;
@@ -225,14 +236,14 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
             const size_t slot = defer_heavy ? (size_t)p : 0;
             LongDesc* desc = reinterpret_cast<LongDesc*>(g_ws.long_desc.as<char>() + slot * desc_slot_bytes);
             uint32_t* parts = g_ws.long_parts.as<uint32_t>() + slot * parts_slot_words;
-            uint32_t* desc_count = reinterpret_cast<uint32_t*>(desc + (size_t)n_win * desc_cap);       // n_win words, then the heavy counters
-            const uint32_t* heavy_count = desc_count + n_win;
+            uint32_t* desc_count = reinterpret_cast<uint32_t*>(desc + (size_t)sets * desc_cap);        // `sets` words, then the heavy counters
+            const uint32_t* heavy_count = desc_count + sets;
             const uint32_t run_cap = (uint32_t)(2 * (n_sorted / MSM_HEAVY_RUN) + 2);
             const uint32_t h1_cap = (uint32_t)(n_sorted / MSM_HEAVY_PER_THREAD + 2 * (size_t)run_cap + 2);
-            HeavyRun* heavy_runs = reinterpret_cast<HeavyRun*>(desc_count + (((size_t)n_win * (1 + MSM_HEAVY_COUNTERS) + 3) & ~(size_t)3));
-            uint32_t* h1 = parts + (size_t)n_win * desc_cap * EC::PT_WORDS;                          // level-1 sums: one per MSM_HEAVY_PER_THREAD entries of a run
-            uint32_t* h2 = h1 + (size_t)n_win * h1_cap * EC::PT_WORDS;                                // one per level-1 run
-            uint32_t* h3 = h2 + (size_t)n_win * run_cap * EC::PT_WORDS;                               // one per level-B run
+            HeavyRun* heavy_runs = reinterpret_cast<HeavyRun*>(desc_count + (((size_t)sets * (1 + MSM_HEAVY_COUNTERS) + 3) & ~(size_t)3));
+            uint32_t* h1 = parts + (size_t)sets * desc_cap * EC::PT_WORDS;                           // level-1 sums: one per MSM_HEAVY_PER_THREAD entries of a run
+            uint32_t* h2 = h1 + (size_t)sets * h1_cap * EC::PT_WORDS;                                 // one per level-1 run
+            uint32_t* h3 = h2 + (size_t)sets * run_cap * EC::PT_WORDS;                                // one per level-B run
             const unsigned long long dstride = (n + 7) & ~7ull;
             const unsigned gs = (unsigned)((n + MSM_THREADS - 1) / MSM_THREADS);
             if (overlap && (size_t)p >= nb) HIP_TRY(hipStreamWaitEvent(sst, ss.ev_acc[b], 0));     // MSM p - nb has read this set
@@ -240,10 +251,10 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
             if (!pre.c && !sort2) {
                 ProfScope ps("msm_sort", sst);
                 uint16_t* digits = reinterpret_cast<uint16_t*>(g_ws.digits.as<char>() + b * digits_bytes);
-                hipLaunchKernelGGL((msm_digits_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, sst, d_scalars, n, is_mont, c, n_win, digits, dstride);
-                hipLaunchKernelGGL((msm_sort_kernel<false>), dim3(n_ranges, n_win), dim3(MSM_SORT_THREADS), 0, sst, digits, n, dstride, M, hist, offs, sorted);
-                hipLaunchKernelGGL(msm_scan_kernel, dim3(n_win), dim3(1024), 0, sst, hist, offs, M);
-                hipLaunchKernelGGL((msm_sort_kernel<true>), dim3(n_ranges, n_win), dim3(MSM_SORT_THREADS), 0, sst, digits, n, dstride, M, hist, offs, sorted);
+                hipLaunchKernelGGL((msm_digits_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, sst, d_scalars, n, is_mont, c, sets, digits, dstride);
+                hipLaunchKernelGGL((msm_sort_kernel<false>), dim3(n_ranges, sets), dim3(MSM_SORT_THREADS), 0, sst, digits, n, dstride, M, hist, offs, sorted);
+                hipLaunchKernelGGL(msm_scan_kernel, dim3(sets), dim3(1024), 0, sst, hist, offs, M);
+                hipLaunchKernelGGL((msm_sort_kernel<true>), dim3(n_ranges, sets), dim3(MSM_SORT_THREADS), 0, sst, digits, n, dstride, M, hist, offs, sorted);
             } else {
                 ProfScope ps("msm_sort", sst);
                 uint32_t* dig32 = reinterpret_cast<uint32_t*>(g_ws.digits.as<char>() + b * digits_bytes);
@@ -256,18 +267,30 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 uint32_t* bin_cursor = cnt + 1024;               // [n_bins]
                 uint32_t* bin_start = coff;                      // [n_bins + 1]
                 const uint32_t bstride = pre.c ? 0u : M;                 // plain path: window w sorts into buckets [w M, (w + 1) M)
-                hipLaunchKernelGGL((pre_digits_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, sst, d_scalars, n, is_mont, c, n_dig, dig32, dstride);
+                PreMulti multi;
+                std::memset(&multi, 0, sizeof multi);
+                if (fuse) {                                              // the digits of MSM q: n_dig rows of dstride words from dig32 + q * n_dig * dstride
+                    multi.count = (uint32_t)count; multi.set_stride = M;
+                    for (int q = 0; q < count; q++) {
+                        multi.n[q] = items[q].n; multi.base_off[q] = items[q].base_off;
+                        hipLaunchKernelGGL((pre_digits_kernel<FR>), dim3((unsigned)((items[q].n + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0, sst,
+                                           items[q].d_scalars, items[q].n, is_mont, c, n_dig, dig32 + (size_t)q * n_dig * dstride, dstride);
+                    }
+                } else {
+                    hipLaunchKernelGGL((pre_digits_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, sst, d_scalars, n, is_mont, c, n_dig, dig32, dstride);
+                }
+                const dim3 coarse_grid(n_chunks, (unsigned)fused_k);
                 HIP_TRY(hipMemsetAsync(cnt, 0, cnt_words * 4, sst));              // bin totals and, further down, the order keys: one fill
-                hipLaunchKernelGGL(pre_coarse_count_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, sst, dig32, n, dstride, n_dig, (int)n_bins, pb, bstride, chunk, bin_total);
+                hipLaunchKernelGGL(pre_coarse_count_kernel, coarse_grid, dim3(PRE_CTHREADS), 0, sst, dig32, n, dstride, n_dig, (int)n_bins, pb, bstride, chunk, multi, bin_total);
                 // a bin with more than PRE_HUGE entries (skewed scalars) is sorted by the pre_huge_* kernels in slices of `slice` records
                 uint32_t* huge = coff + 1088;
-                const uint64_t records = n * (uint64_t)n_dig;             // what the coarse level holds (both paths)
+                const uint64_t records = n * (uint64_t)n_dig * fused_k;   // what the coarse level holds (both paths)
                 const uint32_t slice = (uint32_t)std::max<uint64_t>(16384, (records + 2047) / 2048);
                 const uint32_t slice_grid = (uint32_t)std::min<uint64_t>(PRE_SLICE_CAP, records / slice + PRE_HUGE_MAX + 1);
                 const uint32_t huge_grid = (uint32_t)std::min<uint64_t>(PRE_HUGE_MAX, records / PRE_HUGE + 1);
                 hipLaunchKernelGGL(pre_bin_scan_kernel, dim3(1), dim3(1024), 0, sst, bin_total, (int)n_bins, bin_start, bin_cursor, slice, huge);
-                hipLaunchKernelGGL(pre_coarse_scatter_kernel, dim3(n_chunks), dim3(PRE_CTHREADS), 0, sst, dig32, n, dstride, n_dig, (int)n_bins, pb, bstride, chunk,
-                                   pre.c ? pre.tab_stride : 0ull, pre.c ? items[p].base_off : 0ull, bin_cursor, coarse);
+                hipLaunchKernelGGL(pre_coarse_scatter_kernel, coarse_grid, dim3(PRE_CTHREADS), 0, sst, dig32, n, dstride, n_dig, (int)n_bins, pb, bstride, chunk,
+                                   pre.c ? pre.tab_stride : 0ull, pre.c ? items[p].base_off : 0ull, multi, bin_cursor, coarse);
                 hipLaunchKernelGGL(pre_fine_kernel, dim3(n_bins), dim3(1024), 0, sst, bin_start, coarse, (uint32_t)wm, pb, hist, offs, sorted, huge);
                 hipLaunchKernelGGL(pre_huge_zero_kernel, dim3(huge_grid), dim3(1024), 0, sst, huge, (uint32_t)wm, pb, hist);
                 hipLaunchKernelGGL(pre_huge_count_kernel, dim3(slice_grid), dim3(1024), 0, sst, huge, bin_start, coarse, (uint32_t)wm, pb, slice, hist);
@@ -277,12 +300,12 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
             {
                 // buckets ranked by load within each bucket set
                 ProfScope ps("msm_sort", sst);
-                uint32_t* keycnt = g_ws.pre_cnt.as<uint32_t>() + b * cnt_words + 2048;       // [n_win][1024]
+                uint32_t* keycnt = g_ws.pre_cnt.as<uint32_t>() + b * cnt_words + 2048;       // [sets][1024]
                 const unsigned slices = (M + MSM_ORDER_SLICE - 1) / MSM_ORDER_SLICE;
-                if (!pre.c && !sort2) HIP_TRY(hipMemsetAsync(keycnt, 0, (size_t)n_win * 1024 * 4, sst));   // (two-level sort: zeroed with the bin totals above)
-                hipLaunchKernelGGL(msm_order_hist_kernel, dim3(slices, n_win), dim3(1024), 0, sst, hist, M, keycnt);
-                hipLaunchKernelGGL(msm_order_scan_kernel, dim3(n_win), dim3(1024), 0, sst, keycnt);
-                hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(slices, n_win), dim3(1024), 0, sst, hist, M, keycnt, order);
+                if (!pre.c && !sort2) HIP_TRY(hipMemsetAsync(keycnt, 0, (size_t)sets * 1024 * 4, sst));    // (two-level sort: zeroed with the bin totals above)
+                hipLaunchKernelGGL(msm_order_hist_kernel, dim3(slices, sets), dim3(1024), 0, sst, hist, M, keycnt);
+                hipLaunchKernelGGL(msm_order_scan_kernel, dim3(sets), dim3(1024), 0, sst, keycnt);
+                hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(slices, sets), dim3(1024), 0, sst, hist, M, keycnt, order);
             }
             if (overlap) {
                 HIP_TRY(hipEventRecord(ss.ev_sorted[b], sst));
@@ -304,7 +327,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 if (log_split == 0) {
                     ProfScope ps("msm_accumulate", st);
                     hipLaunchKernelGGL((msm_accumulate_kernel<EC>), dim3((unsigned)((wm + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
-                                       d_bases, list_stride, offs, hist, sorted, order, M, n_win, cap, desc_count, buckets, occ);
+                                       d_bases, list_stride, offs, hist, sorted, order, M, sets, cap, desc_count, buckets, occ);
                 } else {
                     const size_t threads = wm << log_split;
                     MZK_TRY(g_ws.split.reserve(threads * EC::PT_WORDS * 4));
@@ -312,7 +335,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                     {
                         ProfScope ps("msm_accumulate", st);               // the dominant launch alone: what rocprofv3 --stats averages
                         hipLaunchKernelGGL((msm_accumulate_split_kernel<EC>), dim3((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)),
-                                           dim3(MSM_ACC_THREADS), 0, st, d_bases, list_stride, offs, hist, sorted, order, M, n_win, cap, log_split, desc_count, sub);
+                                           dim3(MSM_ACC_THREADS), 0, st, d_bases, list_stride, offs, hist, sorted, order, M, sets, cap, log_split, desc_count, sub);
                     }
                     ProfScope pc("msm_split_combine", st);
                     hipLaunchKernelGGL((msm_split_combine_kernel<EC>), dim3((unsigned)((threads + 2 * MSM_ACC_THREADS - 1) / (2 * MSM_ACC_THREADS))), dim3(MSM_ACC_THREADS),
@@ -322,11 +345,11 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
             {
                 // over-long buckets (skewed scalars); no-ops for uniformly random scalars
                 ProfScope ps("msm_long", st);
-                hipLaunchKernelGGL(msm_long_find_kernel, dim3((unsigned)((wm + 255) / 256)), dim3(256), 0, st, hist, offs, M, n_win, cap, desc_cap, desc, desc_count,
+                hipLaunchKernelGGL(msm_long_find_kernel, dim3((unsigned)((wm + 255) / 256)), dim3(256), 0, st, hist, offs, M, sets, cap, desc_cap, desc, desc_count,
                                    run_cap, heavy_runs);
-                hipLaunchKernelGGL((msm_long_chunk_kernel<EC>), dim3((desc_cap + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, n_win), dim3(MSM_ACC_THREADS), 0, st,
+                hipLaunchKernelGGL((msm_long_chunk_kernel<EC>), dim3((desc_cap + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, sets), dim3(MSM_ACC_THREADS), 0, st,
                                    d_bases, list_stride, sorted, desc, desc_count, desc_cap, parts);
-                hipLaunchKernelGGL((msm_long_combine_kernel<EC>), dim3(std::min<uint32_t>((desc_cap + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, 1024u), n_win),
+                hipLaunchKernelGGL((msm_long_combine_kernel<EC>), dim3(std::min<uint32_t>((desc_cap + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, 1024u), sets),
                                    dim3(MSM_ACC_THREADS), 0, st, desc, desc_count, desc_cap, M, parts, buckets, occ);
                 // heavy buckets: a workgroup per run of MSM_HEAVY_RUN entries, then workgroup trees (levels A, B; C only when a bucket can hold
                 // more than MSM_HEAVY_RUN * MSM_HEAVY_FANIN entries).  Every workgroup exits at once when there is no heavy bucket.
@@ -336,29 +359,29 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 heavy_run_cap_max = std::max(heavy_run_cap_max, run_cap);
                 heavy_level_c = heavy_level_c || n_sorted > (uint64_t)MSM_HEAVY_RUN * MSM_HEAVY_FANIN;
                 if (!defer_heavy) {
-                    const dim3 hg(std::min<uint32_t>(run_cap, 2048u), n_win, 1);
+                    const dim3 hg(std::min<uint32_t>(run_cap, 2048u), sets, 1);
                     hipLaunchKernelGGL((msm_heavy_chunk_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, jobs);
                     hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, jobs, 0);
                     hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, jobs, 1);
                     if (n_sorted > (uint64_t)MSM_HEAVY_RUN * MSM_HEAVY_FANIN)
-                        hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), dim3(64, n_win, 1), dim3(MSM_ACC_THREADS), 0, st, jobs, 2);
+                        hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), dim3(64, sets, 1), dim3(MSM_ACC_THREADS), 0, st, jobs, 2);
                 }
             }
             if (overlap) HIP_TRY(hipEventRecord(ss.ev_acc[b], st));
         }
         if (defer_heavy) {                                          // the heavy buckets of all MSMs of the batch, one launch per level
             ProfScope ps("msm_long", st);
-            const dim3 hg(std::min<uint32_t>(heavy_run_cap_max, 2048u), n_win, (unsigned)count);
+            const dim3 hg(std::min<uint32_t>(heavy_run_cap_max, 2048u), sets, (unsigned)passes);
             hipLaunchKernelGGL((msm_heavy_chunk_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, jobs);
             hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, jobs, 0);
             hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, jobs, 1);
-            if (heavy_level_c) hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), dim3(64, n_win, (unsigned)count), dim3(MSM_ACC_THREADS), 0, st, jobs, 2);
+            if (heavy_level_c) hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), dim3(64, sets, (unsigned)passes), dim3(MSM_ACC_THREADS), 0, st, jobs, 2);
         }
         {
             ProfScope ps("msm_reduce", st);
             uint32_t* buckets = g_ws.buckets.as<uint32_t>();
             uint8_t* occ = g_ws.occ.as<uint8_t>();
-            const int nw_all = n_win * count;                   // every bucket set folds independently
+            const int nw_all = sets * passes;                   // every bucket set folds independently (= n_win * count)
             // wide levels: one launch each over all bucket sets; narrow levels (<= 256 adds per set): one launch in all
             int first_tail = 1;
             while (first_tail <= log_m && (size_t)first_tail * (M >> first_tail) > 256) first_tail++;

@@ -39,6 +39,16 @@ struct PreBins {
     __host__ __device__ uint32_t count(uint32_t M) const { return low_bins + ((M - low + (1u << PRE_FINE_LOG) - 1) >> PRE_FINE_LOG); }
 };
 
+// A FUSED batch of small table-path MSMs (msm.hip, msm_group_dev): the `count` MSMs are sorted, accumulated and reduced as ONE problem whose
+// bucket range is the concatenation of their bucket sets -- MSM q owns the buckets [q * set_stride, (q + 1) * set_stride) -- the way the
+// plain path concatenates the bucket sets of its windows.  Only the digit -> (bucket, table row) mapping of the coarse level knows about
+// it: blockIdx.y = q, the digits of MSM q start at digits + q * n_win * stride, its scalars number n[q], its first SRS point is base_off[q].
+constexpr int PRE_FUSE_MAX = 8;
+struct PreMulti {
+    uint32_t count, set_stride;                 // count == 0: one MSM (n, base_off from the kernel arguments)
+    unsigned long long n[PRE_FUSE_MAX], base_off[PRE_FUSE_MAX];
+};
+
 // digits[w*stride + i] = sign<<31 | (magnitude-1), PRE_EMPTY for a zero digit
 template <class FR>
 __global__ __launch_bounds__(MSM_THREADS) void pre_digits_kernel(const uint32_t* __restrict__ scalars, unsigned long long n, int is_mont,
@@ -64,12 +74,14 @@ __global__ __launch_bounds__(MSM_THREADS) void pre_digits_kernel(const uint32_t*
 // [w M, (w + 1) M) of one combined bucket range -- the same two-level sort then serves both paths.
 __global__ __launch_bounds__(PRE_CTHREADS) void pre_coarse_count_kernel(const uint32_t* __restrict__ digits, unsigned long long n, unsigned long long stride,
                                                                 int n_win, int n_bins, PreBins pb, uint32_t bucket_stride, uint32_t chunk,
-                                                                uint32_t* __restrict__ bin_total) {
+                                                                PreMulti multi, uint32_t* __restrict__ bin_total) {
     __shared__ uint32_t bins[1024];
     const uint32_t tid = threadIdx.x;
     for (int j = tid; j < n_bins; j += PRE_CTHREADS) bins[j] = 0u;
     __syncthreads();
-    const unsigned long long lo = (unsigned long long)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    const uint32_t q = blockIdx.y, set_base = q * multi.set_stride;
+    if (multi.count) { n = multi.n[q]; digits += (size_t)q * n_win * stride; }
+    const unsigned long long lo = (unsigned long long)blockIdx.x * chunk, hi = max(lo, min(n, lo + chunk));
     // the chunk's (window, four scalars) items spread over the threads: a small chunk still keeps the whole workgroup busy
     const uint32_t quads = (uint32_t)((hi - lo + 3) / 4), items = quads * (uint32_t)n_win;
     for (uint32_t t = tid; t < items; t += PRE_CTHREADS) {
@@ -79,7 +91,7 @@ __global__ __launch_bounds__(PRE_CTHREADS) void pre_coarse_count_kernel(const ui
         const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if (i + k < hi && d4[k] != PRE_EMPTY) atomicAdd(&bins[pb.bin_of((d4[k] & 0x7FFFFFFFu) + w * bucket_stride)], 1u);
+            if (i + k < hi && d4[k] != PRE_EMPTY) atomicAdd(&bins[pb.bin_of((d4[k] & 0x7FFFFFFFu) + w * bucket_stride + set_base)], 1u);
     }
     __syncthreads();
     for (int j = tid; j < n_bins; j += PRE_CTHREADS)
@@ -203,12 +215,15 @@ __global__ __launch_bounds__(1024) void pre_huge_scatter_kernel(const uint32_t* 
 
 __global__ __launch_bounds__(PRE_CTHREADS) void pre_coarse_scatter_kernel(const uint32_t* __restrict__ digits, unsigned long long n, unsigned long long stride,
                                                                   int n_win, int n_bins, PreBins pb, uint32_t bucket_stride, uint32_t chunk, unsigned long long tab_stride,
-                                                                  unsigned long long base_off, uint32_t* __restrict__ bin_cursor, unsigned long long* __restrict__ coarse) {
+                                                                  unsigned long long base_off, PreMulti multi, uint32_t* __restrict__ bin_cursor,
+                                                                  unsigned long long* __restrict__ coarse) {
     __shared__ uint32_t bins[1024];
     const uint32_t tid = threadIdx.x;
     for (int j = tid; j < n_bins; j += PRE_CTHREADS) bins[j] = 0u;
     __syncthreads();
-    const unsigned long long lo = (unsigned long long)blockIdx.x * chunk, hi = min(n, lo + chunk);
+    const uint32_t q = blockIdx.y, set_base = q * multi.set_stride;
+    if (multi.count) { n = multi.n[q]; base_off = multi.base_off[q]; digits += (size_t)q * n_win * stride; }
+    const unsigned long long lo = (unsigned long long)blockIdx.x * chunk, hi = max(lo, min(n, lo + chunk));
     const uint32_t quads = (uint32_t)((hi - lo + 3) / 4), items = quads * (uint32_t)n_win;       // as in pre_coarse_count_kernel
     for (uint32_t t = tid; t < items; t += PRE_CTHREADS) {
         const uint32_t w = t / quads;
@@ -217,7 +232,7 @@ __global__ __launch_bounds__(PRE_CTHREADS) void pre_coarse_scatter_kernel(const 
         const uint32_t d4[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
         for (int k = 0; k < 4; k++)
-            if (i + k < hi && d4[k] != PRE_EMPTY) atomicAdd(&bins[pb.bin_of((d4[k] & 0x7FFFFFFFu) + w * bucket_stride)], 1u);
+            if (i + k < hi && d4[k] != PRE_EMPTY) atomicAdd(&bins[pb.bin_of((d4[k] & 0x7FFFFFFFu) + w * bucket_stride + set_base)], 1u);
     }
     __syncthreads();
     for (int j = tid; j < n_bins; j += PRE_CTHREADS) {
@@ -234,7 +249,7 @@ __global__ __launch_bounds__(PRE_CTHREADS) void pre_coarse_scatter_kernel(const 
         for (int k = 0; k < 4; k++) {
             const uint32_t d = d4[k];
             if (i + k >= hi || d == PRE_EMPTY) continue;
-            const uint32_t b = (d & 0x7FFFFFFFu) + w * bucket_stride;
+            const uint32_t b = (d & 0x7FFFFFFFu) + w * bucket_stride + set_base;
             const uint32_t bin = pb.bin_of(b);
             const uint32_t pos = atomicAdd(&bins[bin], 1u);
             const uint32_t e = (uint32_t)((unsigned long long)w * tab_stride + base_off + i + k) | (d & 0x80000000u);
