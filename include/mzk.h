@@ -281,7 +281,9 @@ MZK_API int32_t mzk_plonk_perm_product(uint64_t pk_handle, const uint64_t* wire_
  * every cell of `self.wire_variables[i]`) on the device: d_out[t] = d_witness[d_wire_variables[t]], t < count = W x n, 32-byte field
  * elements of either curve, d_wire_variables = u32 variable indices (wire-major).  The index table is circuit structure -- resident
  * once per circuit -- so a host-resident witness crosses PCIe as n_vars x 32 B instead of W x n x 32 B (the bench circuit: 1 / 5).
- * An index >= n_vars yields zero.  Asynchronous; the wire iNTTs (mzk_ntt_dev) follow on the same stream. */
+ * An index >= n_vars yields zero and is NOT reported here (the call is asynchronous): the reference panics on such an index, so validate
+ * the table once where it is registered -- mzk_prover_set_wire_variables does (MZK_ERR_INVALID_ARG), the Python mirror checks its index
+ * tensor on first use.  Asynchronous; the wire iNTTs (mzk_ntt_dev) follow on the same stream. */
 MZK_API int32_t mzk_plonk_gather_witness_dev(const void* d_witness, uint64_t n_vars, const void* d_wire_variables, uint64_t count, void* d_out,
                                              void* stream);
 
@@ -484,7 +486,9 @@ MZK_API int32_t mzk_msm_set_precompute(int32_t on);
  * window bits c, levels W = ceil(256 / c), bytes of HBM it occupies (W x n x 112 B for BLS12-381, x 80 B for BN254) and the wall
  * time the build took (W - 1 launches of c doublings per point, synchronised).  A fixed-base table is legitimate for KZG -- the
  * commit key never changes (primitives/src/pcs/univariate_kzg/srs.rs:77-93) -- but it is a set-up cost ark-ec's
- * VariableBaseMSM does not pay: bench.py prints it beside the headline.  All zeros when the table is disabled or did not fit. */
+ * VariableBaseMSM does not pay: bench.py prints it beside the headline.  All zeros when the table is disabled or did not fit:
+ * a table is only built while it takes at most half of the free HBM, and never beyond MZK_MSM_TABLE_BUDGET bytes (environment; unset = no
+ * budget) -- such an SRS commits on the plain (variable-base) path, same points. */
 MZK_API int32_t mzk_srs_precompute(uint64_t srs_handle, uint32_t* out_window_bits, uint32_t* out_levels, uint64_t* out_table_bytes,
                                    double* out_build_ms);
 /* HBM accounting (bench.py reports it per leg).  An SRS: its points (boundary form + the MSM's internal form: 96 + 112 B per point on
@@ -494,6 +498,8 @@ MZK_API int32_t mzk_srs_precompute(uint64_t srs_handle, uint32_t* out_window_bit
 MZK_API int32_t mzk_srs_hbm_bytes(uint64_t srs_handle, uint64_t* out_points_bytes, uint64_t* out_table_bytes);
 MZK_API int32_t mzk_plonk_pk_hbm_bytes(uint64_t pk_handle, uint64_t* out_bytes);
 MZK_API int32_t mzk_workspace_hbm_bytes(uint64_t* out_bytes);
+/* Frees that scratch (synchronises the device; it grows again on demand). */
+MZK_API int32_t mzk_workspace_release(void);
 /* Last MSM's shape: window bits, windows, buckets per window (for DESIGN.md's op counts). */
 MZK_API int32_t mzk_msm_last_shape(uint32_t* out_window_bits, uint32_t* out_windows, uint32_t* out_buckets);
 

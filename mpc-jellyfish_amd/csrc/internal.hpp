@@ -92,7 +92,7 @@ struct IoSlot {
 };
 struct Ctx {
     int logical = -1, device = -1;
-    bool init = false;
+    std::atomic<bool> init{false};                  // read without g_ctx_lock by the threads of other devices (handle look-ups)
     std::mutex lock;
     Workspace ws;
     std::vector<ProfRec> prof_recs;

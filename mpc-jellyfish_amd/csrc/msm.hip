@@ -466,7 +466,9 @@ int32_t srs_build_pre_t(Srs& s, hipStream_t st) {
     const size_t level = (size_t)s.n * EC::AFF_WORDS;
     size_t free_b = 0, total_b = 0;
     HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-    if ((size_t)W * level * 4 > free_b / 2) { s.pre_c = -1; return MZK_OK; }      // not worth half the free HBM
+    size_t budget = free_b / 2;                                                    // not worth half the free HBM
+    if (const char* b = std::getenv("MZK_MSM_TABLE_BUDGET")) budget = std::min<size_t>(budget, (size_t)std::strtoull(b, nullptr, 10));
+    if ((size_t)W * level * 4 > budget) { s.pre_c = -1; return MZK_OK; }           // this SRS commits on the plain path
     HIP_TRY(hipMalloc((void**)&s.d_pre, (size_t)W * level * 4));
     HIP_TRY(hipStreamSynchronize(st));
     const auto t_build = std::chrono::steady_clock::now();

@@ -74,7 +74,7 @@ ProfScope::~ProfScope() {
 // ---- contexts ------------------------------------------------------------------------------------------
 Ctx g_ctx[MAX_CTX];
 std::mutex g_ctx_lock;                        // guards `init` / `device` of the table and g_default
-int g_default = -1;                           // first context initialised: what threads without a binding of their own use
+std::atomic<int> g_default{-1};               // first context initialised: what threads without a binding of their own use
 thread_local int t_dev = -1;                  // logical device this thread is bound to (mzk_init / mzk_set_device)
 thread_local Ctx* t_ctx = nullptr;            // context of the entry point now running on this thread
 Ctx& cur() { return *t_ctx; }
@@ -86,7 +86,7 @@ using namespace mzk;
 namespace {
 
 Ctx* ctx_for_thread() {
-    const int d = t_dev >= 0 ? t_dev : g_default;
+    const int d = t_dev >= 0 ? t_dev : g_default.load();
     if (d < 0 || !g_ctx[d].init) { set_error("mzk_init has not been called"); return nullptr; }
     return &g_ctx[d];
 }
@@ -239,7 +239,7 @@ int32_t mzk_set_device(int32_t device) {
 
 int32_t mzk_get_device(int32_t* out_device) {
     if (!out_device) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
-    *out_device = t_dev >= 0 ? t_dev : g_default;
+    *out_device = t_dev >= 0 ? t_dev : g_default.load();
     return *out_device >= 0 ? MZK_OK : MZK_ERR_NOT_INIT;
 }
 
@@ -421,6 +421,15 @@ int32_t mzk_srs_hbm_bytes(uint64_t handle, uint64_t* out_points_bytes, uint64_t*
     const uint64_t aff_int = s.curve == MZK_CURVE_BLS12_381 ? 2 * 14 * 4 : 2 * 10 * 4;      // 29-bit limbs: ecx.cuh
     if (out_points_bytes) *out_points_bytes = s.n * (uint64_t)(2 * fq_words(s.curve) * 4) + (s.d_int ? s.n * aff_int : 0);
     if (out_table_bytes) *out_table_bytes = s.d_pre ? (uint64_t)s.pre_levels * s.n * aff_int : 0;
+    return MZK_OK;
+}
+// releases the grow-only scratch of the calling thread's device context (it is re-acquired on demand): a process that has run its
+// largest problem and goes on with smaller ones, or bench.py before it reports what ONE kind of proof holds
+int32_t mzk_workspace_release(void) {
+    ENTER_CUR();
+    HIP_TRY(hipDeviceSynchronize());
+    cx_->ws.release();
+    for (auto& slot : cx_->io) slot.buf.release();
     return MZK_OK;
 }
 // scratch memory of the calling thread's device context: the shared workspace of the NTT / MSM / quotient kernels (grow-only) and the

@@ -166,7 +166,7 @@ def compute_quotient_chunked_dev(pk: ProvingKeyDevice, challenges: Challenges, p
 def quotient_top_supported(num_wire_types: int, domain_size: int) -> bool:
     """n > W + 2 (and n >= 8): the coefficients of the quotient from X^(Wn) on are then the top W + 3 coefficients of its numerator
     (include/mzk.h, mzk_plonk_quotient_top_dev)."""
-    return domain_size > num_wire_types + 2 and domain_size >= 8 and num_wire_types <= 7
+    return domain_size > num_wire_types + 2 and domain_size >= 8 and num_wire_types <= 6       # (plonk_quotient_top_kernel: series slots for W <= 6)
 
 
 def quotient_classes_needed(num_wire_types: int, domain_size: int, top: bool = True) -> list[int]:

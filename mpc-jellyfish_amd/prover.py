@@ -332,6 +332,13 @@ class TurboPlonkProver:
             # (constraint_system.rs:1225-1247) runs on the device over the resident variable-index table
             hw = wire_values
             n_vars = int(hw.witness.shape[0])
+            # the reference panics on a variable index outside the witness (`self.witness[var]`, constraint_system.rs:1239); the device gather
+            # would read zero instead: checked once per index table (one reduction + one 8-byte read)
+            if getattr(self, "_vars_checked", None) != (hw.wire_variables.data_ptr(), n_vars):
+                top = int(hw.wire_variables.max().item()) if hw.wire_variables.numel() else -1
+                if top >= n_vars or int(hw.wire_variables.min().item()) < 0:
+                    raise PlonkError("wire_variables: variable index %d outside the witness vector of %d variables" % (top, n_vars))
+                self._vars_checked = (hw.wire_variables.data_ptr(), n_vars)
             if getattr(self, "_wit", None) is None or self._wit.shape[0] < n_vars:
                 self._wit = torch.empty((n_vars, 4), dtype=torch.int64, device=dev)
                 self._wv = torch.empty((W, n, 4), dtype=torch.int64, device=dev)
@@ -353,6 +360,7 @@ class TurboPlonkProver:
             hv = as_host(wire_values)
             if getattr(self, "_wv", None) is None:
                 self._wv = torch.empty((W, n, 4), dtype=torch.int64, device=dev)
+            if getattr(self, "_copy_stream", None) is None:             # (the witness-vector path allocates _wv too, without the stream)
                 self._copy_stream = torch.cuda.Stream(device=dev)
                 self._wv_ev = [torch.cuda.Event() for _ in range(W)]
             st.wv = self._wv
@@ -815,6 +823,11 @@ class TurboPlonkProver:
             open_comms = self._commit([opening, shifted])
             tick("r5_commit", t0)
             self._batch_at_zeta = fr_from_mont(c, rem.cpu().numpy().view(np.uint64))[0]      # (the commitments have synchronised the stream)
+        if not self.identity_check and self.pk.classes is not None and len(self.classes_needed) == self.W:
+            # the W-class path recovers a polynomial of the expected degree whatever the witness: the identity at zeta is its ONLY guard
+            if not getattr(self, "_allow_unchecked", False):
+                raise PlonkError("identity_check = False on the W-class quotient path leaves an unsatisfied witness undetected; measurement "
+                                 "harnesses set _allow_unchecked as well")
         if self.identity_check:
             self.check_quotient_identity(self._batch_at_zeta, self._lin_poly_constant(st), self._opened_evals(st), v_ch)
         self.last_challenges = {"tau": tau, "beta": beta, "gamma": gamma, "alpha": alpha, "zeta": zeta, "v": v_ch}

@@ -257,6 +257,20 @@ def test_lagrange_key_from_the_points_of_an_srs(gpu, mj, curve_id, log_n):
             p.release()
 
 
+@pytest.mark.parametrize("curve_id", [0, 1])
+def test_lagrange_key_from_the_points_of_an_srs_at_2p16(gpu, mj, curve_id):
+    """The same at 2^16 points (three passes of the group NTT's stage loop; 0.14 s): every point against the key computed from beta."""
+    c = mj.params.CURVES[curve_id]
+    n = 1 << 16
+    beta = 0x0f1e2d3c4b5a69788796a5b4c3d2e1f00112233445566778 % c.r
+    ck = mj.UnivariateProverParam.gen_srs_for_testing(c, beta, n + 2)
+    want = mj.UnivariateProverParam.gen_lagrange_srs_for_testing(c, beta, n, n_extra=3)
+    got = ck.lagrange_key(n, n_extra=3)
+    assert np.array_equal(got.powers_of_g(), want.powers_of_g())
+    for p in (ck, want, got):
+        p.release()
+
+
 def test_msm_batch_fused(gpu, mj, cref):
     """mzk_msm_batch / mzk_msm_batch_dev: MSMs of different lengths (two window sizes, an empty one)
     in one call equal the single calls and the oracle."""

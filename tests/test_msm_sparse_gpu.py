@@ -53,7 +53,7 @@ def test_sparse_and_skewed_scalars_both_paths(gpu, mj, cref, curve_id):
     pp.release()
 
 
-def test_plain_path_two_level_sort_at_full_size(gpu, mj):
+def test_plain_path_two_level_sort_at_full_size(gpu, mj, cref):
     """2^20 pairs with the table off (bench.py's headline shape: 16 windows of 2^15 buckets) against the table path and the trapdoor:
     commit(p) over [beta^i]G is [p(beta)]G."""
     import torch
@@ -80,4 +80,76 @@ def test_plain_path_two_level_sort_at_full_size(gpu, mj):
     from conftest import fr_mont_limbs
     one = mj.jacobian_to_affine(c, mj.msm_bigint(pp, fr_mont_limbs(c, [acc]), scalars_are_mont=True)[None])[0]
     assert np.array_equal(plain, one)
+    # ... and against the ORACLE's scalar multiplication [p(beta)]G (oracle/cpu_ref.c), not only the library's own 1-pair MSM
+    assert np.array_equal(plain, cref.g1_mul_gen(0, acc))
+    pp.release()
+
+
+def test_srs_whose_table_does_not_fit_commits_on_the_plain_path(gpu, mj, cref):
+    """MZK_MSM_TABLE_BUDGET (bytes): an SRS whose fixed-base table would exceed it gets none -- mzk_srs_precompute reports zeros -- and its
+    commitments come from the variable-base path: the oracle's point all the same (include/mzk.h, mzk_srs_precompute)."""
+    import ctypes as C
+    import os
+    import torch
+    c = mj.params.BLS12_381
+    n = 1 << 14
+    beta = 0xabcdef0123456789
+    x = mj.params.random_fr_mont(c, n, seed=41)
+    acc = 0
+    for v in reversed(mj.params.fr_from_mont(c, x)):
+        acc = (acc * beta + int(v)) % c.r
+    want = cref.g1_mul_gen(0, acc)
+    L = mj.load()
+    os.environ["MZK_MSM_TABLE_BUDGET"] = str(1 << 20)                  # 1 MB: the 16 x 2^14 x 112 B table (29 MB) does not fit
+    try:
+        pp = mj.UnivariateProverParam.gen_srs_for_testing(c, beta, n - 1)
+        bits, levels, nbytes, ms = C.c_uint32(7), C.c_uint32(7), C.c_uint64(7), C.c_double(7)
+        mj.lib.check(L.mzk_srs_precompute(pp.handle, C.byref(bits), C.byref(levels), C.byref(nbytes), C.byref(ms)), "mzk_srs_precompute")
+        assert (bits.value, levels.value, nbytes.value) == (0, 0, 0)
+        pts, tab = C.c_uint64(), C.c_uint64()
+        mj.lib.check(L.mzk_srs_hbm_bytes(pp.handle, C.byref(pts), C.byref(tab)), "mzk_srs_hbm_bytes")
+        assert tab.value == 0 and pts.value == n * (96 + 112)
+        d = torch.from_numpy(x.view(np.int64)).cuda()
+        got = mj.jacobian_to_affine(c, mj.msm_bigint(pp, d, scalars_are_mont=True)[None])[0]
+        assert mj.lib.msm_last_shape()[1] > 1                          # several windows with their own buckets: the plain path
+        assert np.array_equal(got, want)
+        batch = mj.jacobian_to_affine(c, mj.msm_bigint_batch(pp, [d, d[: n // 2]], scalars_are_mont=True))
+        assert np.array_equal(batch[0], want)
+        pp.release()
+    finally:
+        del os.environ["MZK_MSM_TABLE_BUDGET"]
+    # ... and with the budget lifted the same SRS length gets its table and the same point
+    pp = mj.UnivariateProverParam.gen_srs_for_testing(c, beta, n - 1)
+    got = mj.jacobian_to_affine(c, mj.msm_bigint(pp, torch.from_numpy(x.view(np.int64)).cuda(), scalars_are_mont=True)[None])[0]
+    mj.lib.check(L.mzk_srs_hbm_bytes(pp.handle, C.byref(pts), C.byref(tab)), "mzk_srs_hbm_bytes")
+    assert tab.value == 16 * n * 112 and np.array_equal(got, want)
+    pp.release()
+
+
+@pytest.mark.parametrize("curve_id,log_n,count", [(0, 12, 5), (0, 15, 6), (1, 14, 8), (1, 16, 3), (0, 10, 2)])
+def test_fused_batches_of_small_msms_against_the_oracle(gpu, mj, cref, curve_id, log_n, count):
+    """Batches of small table-path MSMs are sorted and accumulated as ONE problem over the concatenation of their bucket sets (msm_pre.cuh,
+    PreMulti): different lengths, different point ranges (base offsets), an empty and an all-zero member; every sum against the C oracle's
+    Pippenger and against MZK_MSM_NO_FUSE-style single calls."""
+    import torch
+    c = mj.params.CURVES[curve_id]
+    n = 1 << log_n
+    pp = mj.UnivariateProverParam.gen_srs_for_testing(c, 0x1234567 + log_n, n + 2)
+    srs = pp.powers_of_g()
+    polys, offs = [], []
+    for k in range(count):
+        ln = [n + 3, n, n // 2 + 1, 1024, n + 2, 7 * n // 8, 1500, n][k % 8]
+        ln = min(ln, n + 3)
+        off = [0, 3, 1, 0, 1, n // 8, 0, 2][k % 8]
+        off = min(off, n + 3 - ln)
+        x = mj.params.random_fr_mont(c, ln, seed=100 + k)
+        if k == 2:
+            x[:] = 0                                                   # the zero polynomial: infinity
+        polys.append(x)
+        offs.append(off)
+    d = [torch.from_numpy(p.view(np.int64)).cuda() for p in polys]
+    jac = mj.kzg.msm_bigint_batch(pp, d, scalars_are_mont=True, base_offsets=offs)
+    for k in range(count):
+        want = cref.jac_to_affine(curve_id, cref.msm(curve_id, srs[offs[k]:offs[k] + len(polys[k])], polys[k], scalars_are_mont=True, threads=4))[0]
+        assert np.array_equal(cref.jac_to_affine(curve_id, jac[k])[0], want), (k, len(polys[k]), offs[k])
     pp.release()

@@ -265,3 +265,27 @@ def test_batch_prove_over_native_handles_matches_the_mirror(gpu, mj, pyref, curv
     for p in mirrors + natives:
         p.release()
     ck.release()
+
+
+def test_a_wrongly_asserted_pi_zero_trips_the_identity_at_zeta(gpu, mj, pyref):
+    """MZK_QUOTIENT_PI_ZERO / `pi_zero=True` lets round 3 skip the public-input polynomial; asserted for a circuit that HAS a non-zero
+    public input, the quotient no longer matches the numerator and the check at zeta (the only guard on the W-class path) must fire --
+    in the Python mirror, where the caller asserts it, as in the library's rounds, which decide it from the data."""
+    c, pc = mj.params.CURVES[0], pyref.CURVES[0]
+    log_n, n, W = 6, 64, 5
+    rng = random.Random(4242)
+    sel_p, sig_p, k, wires, pi, kw = _general_instance(mj, pc, c, log_n, False, rng)
+    ck = mj.UnivariateProverParam.gen_srs_for_testing(c, rng.randrange(1, c.r), n + 2)
+    mirror = mj.prover.TurboPlonkProver(c, n, sel_p, sig_p, k, ck)
+    blind = mj.snark.draw_blinders(c, mj.rng.test_rng(), W, False)
+    pub = pi[:4]
+    mirror.prove(wires, fr_mont_limbs(c, pi), mj.prover.TranscriptChallenges(mirror, pub), blind)                     # fine
+    with pytest.raises(mj.plonk.PlonkError) as e:
+        mirror.prove(wires, fr_mont_limbs(c, pi), mj.prover.TranscriptChallenges(mirror, pub), blind, pi_zero=True)
+    assert e.value.kind == "WrongQuotientPolyDegree"
+    # switching the guard off on this path is refused (ADVICE r3): it would leave nothing
+    mirror.identity_check = False
+    with pytest.raises(mj.plonk.PlonkError):
+        mirror.prove(wires, fr_mont_limbs(c, pi), mj.prover.TranscriptChallenges(mirror, pub), blind)
+    mirror.release()
+    ck.release()
