@@ -464,7 +464,9 @@ def main():
         # library, this process keeps transcript, rng and Proof -- what a Rust caller of the drop-in gets
         from importlib import import_module
         native = import_module("mpc-jellyfish_amd.native")
-        npk = native.preprocess(prover.ck, cs, lagrange_ck=prover.lagrange_ck)
+        torch.cuda.synchronize()
+        mlib.check(L.mzk_workspace_release(), "mzk_workspace_release")    # the library's grow-only scratch starts again: `hbm_bytes.library_scratch`
+        npk = native.preprocess(prover.ck, cs, lagrange_ck=prover.lagrange_ck)     # below is what PROOFS of this size need, not the earlier legs' maxima
         for _ in range(2):
             native.prove(rng, cs, npk)
         torch.cuda.synchronize()

@@ -122,7 +122,8 @@ def test_srs_whose_table_does_not_fit_commits_on_the_plain_path(gpu, mj, cref):
     pp = mj.UnivariateProverParam.gen_srs_for_testing(c, beta, n - 1)
     got = mj.jacobian_to_affine(c, mj.msm_bigint(pp, torch.from_numpy(x.view(np.int64)).cuda(), scalars_are_mont=True)[None])[0]
     mj.lib.check(L.mzk_srs_hbm_bytes(pp.handle, C.byref(pts), C.byref(tab)), "mzk_srs_hbm_bytes")
-    assert tab.value == 16 * n * 112 and np.array_equal(got, want)
+    mj.lib.check(L.mzk_srs_precompute(pp.handle, C.byref(bits), C.byref(levels), C.byref(nbytes), C.byref(ms)), "mzk_srs_precompute")
+    assert bits.value == 16 and levels.value >= 16 and tab.value == levels.value * n * 112 and np.array_equal(got, want)
     pp.release()
 
 
