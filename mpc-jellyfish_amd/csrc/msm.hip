@@ -456,8 +456,10 @@ int32_t srs_build_pre_t(Srs& s, hipStream_t st) {
     //   BLS12-381: c = 16 -> 16 digits, top 15 bits;  c = 20 -> 13 digits, top 15 bits
     //   BN254:     c = 15 -> 17 digits, top 14 bits;  c = 17 -> 15 digits, top 16 bits;  c = 20 -> 13 digits, top 14 bits
     int c;
-    if (s.curve == MZK_CURVE_BLS12_381) c = lg <= 16 ? 16 : 20;
-    else c = lg <= 15 ? 15 : (lg <= 18 ? 17 : 20);
+    // (re-swept in round 4 with the fused small batches, profiles/r04_msm_window_sweep.txt: BLS12-381 at 2^17 points c = 16 0.80 / 2.34 ms
+    // (one MSM / batch of five) against 0.92 / 2.99 at c = 20, equal at 2^18; BN254 at 2^19 c = 17 1.04 / 4.24 against 1.10 / 4.70 at c = 20)
+    if (s.curve == MZK_CURVE_BLS12_381) c = lg <= 17 ? 16 : 20;
+    else c = lg <= 15 ? 15 : (lg <= 19 ? 17 : 20);
     if (const char* force = std::getenv("MZK_PRE_C")) {            // tuning only (tools/msm_window_sweep.py): force the table's window
         const int f = std::atoi(force);
         if (f >= 8 && f <= 22) c = f;
