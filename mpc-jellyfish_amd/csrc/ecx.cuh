@@ -4,13 +4,15 @@
 // limb capacity has to be tracked).  Same formulas as ec.cuh (EFD madd-2008-s / add-2008-s /
 // dbl-2008-s-1 / mdbl-2008-s-1), same exceptional cases.
 //
-// BN254 Fq runs on 10 limbs (290 bits for a 254-bit p): the subtraction pads are then XPAD_MULT = 128 times larger
-// (constants.cuh), every "< Kp" below reads "< 128 Kp" (< 2^13 p at most, products still come out below 1.01 p), and
-// a pad exceeds the value it is subtracted from by more than 3 * 2^261 ~ 507 p, which the top-limb borrow needs.
+// BN254 Fq runs on 9 limbs (261 bits for a 254-bit p: R' / p = 169, 7 bits of head-room; 81 instead of the 100 limb products of the
+// 10-limb form of rounds 1-3).  There the value bounds DO bind: a product of A p and B p comes out below (A B / 169 + 1) p, so the
+// pads are the smallest that cover their subtrahends -- X::XSUB_XY = 8 p (an accumulator coordinate), XSUB_PQ = 4 p (PPP + 2Q),
+// XSUB_2S = 4 p (2S) instead of 64 / 32 / 8 p -- and the accumulator invariant is X, Y < X::XKXY p = 8 p.  The comments below give the
+// generous field's bounds; tools/ecx_bounds.py propagates both sets through every line (and refuses 9 limbs with the wide pads).
 //
 // Limb classes:  M = every limb < 2^29 (an fx_mul result, or a canonical value)
 //                N = every limb < 2^29 + 8 (after fx_norm)
-// Invariant of an accumulator: X, Y in N with value < 64p; ZZ, ZZZ in M; infinity <=> ZZ == 0 (all limbs).
+// Invariant of an accumulator: X, Y in N with value < XKXY p (64p; BN254: 8p); ZZ, ZZZ in M; infinity <=> ZZ == 0 (all limbs).
 #pragma once
 #include "ec.cuh"
 #include "fx.cuh"
@@ -70,8 +72,8 @@ MZK_HD XYZZX<X> xyzzx_dbl_affine(const AffineX<X>& p) {
     const Fx<X> x2 = fx_sqr(p.x);                                           // M
     const Fx<X> m = fx_norm(fx_add(fx_add(x2, x2), x2));                    // 3x^2, N, < 6p
     const Fx<X> mm = fx_sqr(m);                                             // M
-    r.x = fx_norm(fx_sub8(mm, fx_add(s, s)));                               // M + 8p - 2S: N, < 10p
-    const Fx<X> d = fx_norm(fx_sub_pad<X>(s, r.x, X::XSUB64));              // S - X3, N
+    r.x = fx_norm(fx_sub_pad<X>(mm, fx_add(s, s), X::XSUB_2S));                               // M + 8p - 2S: N, < 10p
+    const Fx<X> d = fx_norm(fx_sub_pad<X>(s, r.x, X::XSUB_XY));              // S - X3, N
     r.y = fx_norm(fx_sub2(fx_mul(m, d), fx_mul(w, p.y)));                   // N, < 4p
     r.zz = v;
     r.zzz = w;
@@ -90,8 +92,8 @@ MZK_HD XYZZX<X> xyzzx_dbl(const XYZZX<X>& p) {
     const Fx<X> x2 = fx_sqr(p.x);
     const Fx<X> m = fx_norm(fx_add(fx_add(x2, x2), x2));
     const Fx<X> mm = fx_sqr(m);
-    r.x = fx_norm(fx_sub8(mm, fx_add(s, s)));
-    const Fx<X> d = fx_norm(fx_sub_pad<X>(s, r.x, X::XSUB64));
+    r.x = fx_norm(fx_sub_pad<X>(mm, fx_add(s, s), X::XSUB_2S));
+    const Fx<X> d = fx_norm(fx_sub_pad<X>(s, r.x, X::XSUB_XY));
     r.y = fx_norm(fx_sub2(fx_mul(m, d), fx_mul(w, p.y)));
     r.zz = fx_mul(v, p.zz);
     r.zzz = fx_mul(w, p.zzz);
@@ -110,8 +112,8 @@ MZK_HD XYZZX<X> xyzzx_madd(const XYZZX<X>& p, const AffineX<X>& q, bool negate) 
     }
     const Fx<X> u2 = fx_mul(q.x, p.zz);                                     // M
     const Fx<X> s2 = fx_mul(qy, p.zzz);                                     // M
-    const Fx<X> pp_ = fx_norm(fx_sub_pad<X>(u2, p.x, X::XSUB64));           // U2 - X1, N
-    const Fx<X> rr_ = fx_norm(fx_sub_pad<X>(s2, p.y, X::XSUB64));           // S2 - Y1, N
+    const Fx<X> pp_ = fx_norm(fx_sub_pad<X>(u2, p.x, X::XSUB_XY));           // U2 - X1, N
+    const Fx<X> rr_ = fx_norm(fx_sub_pad<X>(s2, p.y, X::XSUB_XY));           // S2 - Y1, N
     const Fx<X> pp = fx_sqr(pp_);                                           // M
     const Fx<X> rr2 = fx_sqr(rr_);                                          // M
     if (fx_is_zero_m(pp)) {                                                 // U2 == X1 (mod p)
@@ -126,8 +128,8 @@ MZK_HD XYZZX<X> xyzzx_madd(const XYZZX<X>& p, const AffineX<X>& q, bool negate) 
     XYZZX<X> r;
     const Fx<X> ppp = fx_mul(pp_, pp);                                      // M
     const Fx<X> qv = fx_mul(p.x, pp);                                       // M
-    r.x = fx_norm(fx_sub32(rr2, fx_add(ppp, fx_add(qv, qv))));              // R^2 - PPP - 2Q: N, < 34p
-    const Fx<X> d = fx_norm(fx_sub_pad<X>(qv, r.x, X::XSUB64));             // Q - X3, N
+    r.x = fx_norm(fx_sub_pad<X>(rr2, fx_add(ppp, fx_add(qv, qv)), X::XSUB_PQ));              // R^2 - PPP - 2Q: N, < 34p
+    const Fx<X> d = fx_norm(fx_sub_pad<X>(qv, r.x, X::XSUB_XY));             // Q - X3, N
     r.y = fx_mul2(rr_, d, p.y, fx_neg_m(ppp));                              // R (Q - X3) - Y1 PPP in ONE reduction: M, < 2p
     r.zz = fx_mul(p.zz, pp);                                                // M
     r.zzz = fx_mul(p.zzz, ppp);                                             // M
@@ -152,8 +154,8 @@ MZK_HD XYZZX<X> xyzzx_add(const XYZZX<X>& p, const XYZZX<X>& q) {
     XYZZX<X> r;
     const Fx<X> ppp = fx_mul(pp_, pp);
     const Fx<X> qv = fx_mul(u1, pp);
-    r.x = fx_norm(fx_sub32(rr2, fx_add(ppp, fx_add(qv, qv))));
-    const Fx<X> d = fx_norm(fx_sub_pad<X>(qv, r.x, X::XSUB64));
+    r.x = fx_norm(fx_sub_pad<X>(rr2, fx_add(ppp, fx_add(qv, qv)), X::XSUB_PQ));
+    const Fx<X> d = fx_norm(fx_sub_pad<X>(qv, r.x, X::XSUB_XY));
     r.y = fx_mul2(rr_, d, s1, fx_neg_m(ppp));
     r.zz = fx_mul(fx_mul(p.zz, q.zz), pp);
     r.zzz = fx_mul(fx_mul(p.zzz, q.zzz), ppp);

@@ -282,15 +282,24 @@ struct EcFx {
     using Field = X;
     using Aff = AffineX<X>;
     using Pt = XYZZX<X>;
-    static constexpr int AFF_WORDS = 2 * X::XN, PT_WORDS = 4 * X::XN;      // 28 / 56 words: 16-byte multiples
-    static_assert((2 * X::XN) % 4 == 0, "affine point must be a whole number of 16-byte words");
+    static constexpr int AFF_WORDS = 2 * X::XN, PT_WORDS = 4 * X::XN;      // BLS12-381: 28 / 56 words; BN254: 18 / 36
+    static_assert((4 * X::XN) % 4 == 0 && (2 * X::XN) % 2 == 0, "points are whole 16-byte / 8-byte words");
     static __device__ __forceinline__ Aff load_aff(const uint32_t* __restrict__ bases, unsigned long long idx) {
         uint32_t w[AFF_WORDS];
-        const uint4* src = reinterpret_cast<const uint4*>(bases + idx * AFF_WORDS);
+        if constexpr (AFF_WORDS % 4 == 0) {
+            const uint4* src = reinterpret_cast<const uint4*>(bases + idx * AFF_WORDS);
 #pragma unroll
-        for (int i = 0; i < AFF_WORDS / 4; i++) {
-            const uint4 v = src[i];
-            w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+            for (int i = 0; i < AFF_WORDS / 4; i++) {
+                const uint4 v = src[i];
+                w[4 * i] = v.x; w[4 * i + 1] = v.y; w[4 * i + 2] = v.z; w[4 * i + 3] = v.w;
+            }
+        } else {                                                           // 18 words (BN254 on 9 limbs): 72-byte points, 8-byte aligned
+            const uint2* src = reinterpret_cast<const uint2*>(bases + idx * AFF_WORDS);
+#pragma unroll
+            for (int i = 0; i < AFF_WORDS / 2; i++) {
+                const uint2 v = src[i];
+                w[2 * i] = v.x; w[2 * i + 1] = v.y;
+            }
         }
         Aff p;
 #pragma unroll

@@ -418,7 +418,7 @@ int32_t mzk_srs_hbm_bytes(uint64_t handle, uint64_t* out_points_bytes, uint64_t*
     auto it = cx_->srs.find(handle);
     if (it == cx_->srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
     const Srs& s = it->second;
-    const uint64_t aff_int = s.curve == MZK_CURVE_BLS12_381 ? 2 * 14 * 4 : 2 * 10 * 4;      // 29-bit limbs: ecx.cuh
+    const uint64_t aff_int = s.curve == MZK_CURVE_BLS12_381 ? 2 * 14 * 4 : 2 * 9 * 4;       // 29-bit limbs: ecx.cuh
     if (out_points_bytes) *out_points_bytes = s.n * (uint64_t)(2 * fq_words(s.curve) * 4) + (s.d_int ? s.n * aff_int : 0);
     if (out_table_bytes) *out_table_bytes = s.d_pre ? (uint64_t)s.pre_levels * s.n * aff_int : 0;
     return MZK_OK;
@@ -1071,7 +1071,7 @@ int32_t mzk_srs_precompute(uint64_t srs_handle, uint32_t* out_window_bits, uint3
     Srs& s = it->second;
     MZK_TRY(srs_build_pre(s, nullptr));
     const bool have = s.d_pre != nullptr && s.pre_c > 0;
-    const uint64_t aff_bytes = (s.curve == MZK_CURVE_BLS12_381 ? 28u : 20u) * 4u;       // EcFx::AFF_WORDS: 2 x 14 / 2 x 10 limbs of 29 bits
+    const uint64_t aff_bytes = (s.curve == MZK_CURVE_BLS12_381 ? 28u : 18u) * 4u;       // EcFx::AFF_WORDS: 2 x 14 / 2 x 9 limbs of 29 bits
     if (out_window_bits) *out_window_bits = have ? (uint32_t)s.pre_c : 0u;
     if (out_levels) *out_levels = have ? (uint32_t)s.pre_levels : 0u;
     if (out_table_bytes) *out_table_bytes = have ? (uint64_t)s.pre_levels * s.n * aff_bytes : 0u;

@@ -1,0 +1,163 @@
+#!/usr/bin/env python3
+"""tools/ecx_bounds.py -- worst-case bound propagation through the reduced-radix EC formulas of csrc/ecx.cuh (xyzzx_madd, xyzzx_add,
+xyzzx_dbl, xyzzx_dbl_affine) for a field on XN limbs of 29 bits: every intermediate value is tracked as (value / p, largest limb) and
+every contract of fx.cuh is asserted --
+
+  * fx_mul / fx_sqr / fx_mul2: no 64-bit column overflow (XN * sum of limb products + XN * 2^58 < 2^64), result below 2^(29 XN) so that
+    its limbs are a fully carried class-M value;
+  * fx_sub_pad(a, b, K p spread by s): value(b) < K p and every limb of b within what the spread lends (2^(29+s) - 2^s), no 32-bit overflow;
+  * the accumulator invariant (X, Y below KXY p in class N; ZZ, ZZZ below 2 p in class M) is re-established by every formula;
+  * fx_is_zero_m only ever sees values below 2 p.
+
+Run without a GPU (the CPU suite does: tests/test_ecx_bounds.py).  Two parameter sets ship:
+    BLS12-381 Fq, 14 limbs, 25 bits of head-room: pads 64 p / 32 p / 8 p (generous: value bounds never bind)
+    BN254 Fq,      9 limbs,  7 bits of head-room: pads  8 p /  4 p / 4 p (tight: round 4; 81 instead of 100 limb products per multiplication)
+"""
+import sys
+
+L = 29
+M_LIMB = 2.0 ** L - 1          # class M: an fx_mul result, or a canonical value
+N_LIMB = 2.0 ** L + 7          # class N: after fx_norm
+
+
+class V:
+    """upper bounds: value < v * p, every limb but the top one <= limb (inclusive)"""
+
+    def __init__(self, v, limb, name=""):
+        self.v, self.limb, self.name = v, limb, name
+
+
+class Field:
+    def __init__(self, name, p_bits, p, xn, pad_xy, pad_pq, pad_2s, kxy):
+        self.name, self.p, self.xn = name, p, xn
+        self.H = 2.0 ** (L * xn) / p / 1.0                       # R' / p: the head-room factor of a Montgomery product
+        self.cap = 2.0 ** (L * xn) / p                           # values must stay below 2^(29 XN)
+        self.pad_xy, self.pad_pq, self.pad_2s, self.kxy = pad_xy, pad_pq, pad_2s, kxy
+        self.log = []
+
+    # ---- fx.cuh contracts
+    def _col(self, *pairs):
+        tot = self.xn * (sum(a * b for a, b in pairs) + 2.0 ** (2 * L))
+        assert tot < 2.0 ** 64, "%s: column overflow: %.1f * 2^58" % (self.name, tot / 2.0 ** 58)
+
+    def mul(self, a, b, name=""):
+        self._col((a.limb, b.limb))
+        v = a.v * b.v / self.H + 1.0
+        assert v < self.cap, "%s: %s = %.2f p does not fit %d limbs" % (self.name, name, v, self.xn)
+        self.log.append((name, v))
+        return V(v, M_LIMB, name)
+
+    def mul2(self, x, y, u, w, name=""):
+        self._col((x.limb, y.limb), (u.limb, w.limb))
+        v = (x.v * y.v + u.v * w.v) / self.H + 1.0
+        assert v < self.cap, name
+        self.log.append((name, v))
+        return V(v, M_LIMB, name)
+
+    def add(self, a, b):
+        assert a.limb + b.limb < 2.0 ** 32
+        return V(a.v + b.v, a.limb + b.limb)
+
+    def sub_pad(self, a, b, K, s, name=""):
+        assert b.v <= K, "%s: %s: subtrahend %.2f p exceeds the pad %d p" % (self.name, name, b.v, K)
+        assert b.limb <= 2.0 ** (L + s) - 2.0 ** s, "%s: %s: subtrahend limbs %.3f * 2^29 exceed what a spread by %d lends" % (self.name, name, b.limb / 2.0 ** L, s)
+        limb = a.limb + 2.0 ** (L + s) + M_LIMB                # pad limb = digit (< 2^29) + 2^(29+s) - 2^s
+        assert limb < 2.0 ** 32, name
+        assert a.v + K < self.cap, name
+        return V(a.v + K, limb, name)
+
+    def norm(self, a):
+        assert a.limb < 2.0 ** 32
+        return V(a.v, N_LIMB, a.name)
+
+    def neg_m(self, y):                                           # 2p - y for a class-M y: limbs < 2^30
+        assert y.v <= 2.0 and y.limb <= M_LIMB
+        return V(2.0, 2.0 ** (L + 1) - 1)
+
+    def zero_test(self, a, name):
+        assert a.v <= 2.0, "%s: fx_is_zero_m(%s) needs a value below 2p, got %.2f p" % (self.name, name, a.v)
+
+    def acc_ok(self, x, y, zz, zzz, where):
+        assert x.v <= self.kxy and y.v <= self.kxy, "%s: %s leaves X / Y at %.2f / %.2f p, invariant %d p" % (self.name, where, x.v, y.v, self.kxy)
+        assert x.limb <= N_LIMB and y.limb <= N_LIMB
+        assert zz.v <= 2.0 and zzz.v <= 2.0 and zz.limb <= M_LIMB and zzz.limb <= M_LIMB, where
+
+    # ---- the formulas, line by line as in ecx.cuh
+    def accumulator(self):
+        return V(self.kxy, N_LIMB, "X"), V(self.kxy, N_LIMB, "Y"), V(2.0, M_LIMB, "ZZ"), V(2.0, M_LIMB, "ZZZ")
+
+    def madd(self):
+        x1, y1, zz1, zzz1 = self.accumulator()
+        qx, qy = V(1.0, M_LIMB), V(2.0, 2.0 ** (L + 1) - 1)      # canonical x; y or 2p - y
+        u2, s2 = self.mul(qx, zz1, "U2"), self.mul(qy, zzz1, "S2")
+        pp_ = self.norm(self.sub_pad(u2, x1, self.pad_xy, 1, "U2 - X1"))
+        rr_ = self.norm(self.sub_pad(s2, y1, self.pad_xy, 1, "S2 - Y1"))
+        pp, rr2 = self.mul(pp_, pp_, "PP"), self.mul(rr_, rr_, "RR")
+        self.zero_test(pp, "PP"); self.zero_test(rr2, "RR")
+        ppp, qv = self.mul(pp_, pp, "PPP"), self.mul(x1, pp, "Q")
+        x3 = self.norm(self.sub_pad(rr2, self.add(ppp, self.add(qv, qv)), self.pad_pq, 2, "RR - PPP - 2Q"))
+        d = self.norm(self.sub_pad(qv, x3, self.pad_xy, 1, "Q - X3"))
+        y3 = self.mul2(rr_, d, y1, self.neg_m(ppp), "Y3")
+        self.acc_ok(x3, self.norm(y3), self.mul(zz1, pp, "ZZ3"), self.mul(zzz1, ppp, "ZZZ3"), "madd")
+        # first addition into an empty accumulator: (x, +-y, 1, 1)
+        self.acc_ok(V(1.0, M_LIMB), self.norm(qy), V(1.0, M_LIMB), V(1.0, M_LIMB), "madd into infinity")
+
+    def add_(self):
+        x1, y1, zz1, zzz1 = self.accumulator()
+        x2, y2, zz2, zzz2 = self.accumulator()
+        u1, u2 = self.mul(x1, zz2, "U1"), self.mul(x2, zz1, "U2")
+        s1, s2 = self.mul(y1, zzz2, "S1"), self.mul(y2, zzz1, "S2")
+        pp_ = self.norm(self.sub_pad(u2, u1, 2, 0, "U2 - U1"))
+        rr_ = self.norm(self.sub_pad(s2, s1, 2, 0, "S2 - S1"))
+        pp, rr2 = self.mul(pp_, pp_, "PP"), self.mul(rr_, rr_, "RR")
+        self.zero_test(pp, "PP"); self.zero_test(rr2, "RR")
+        ppp, qv = self.mul(pp_, pp, "PPP"), self.mul(u1, pp, "Q")
+        x3 = self.norm(self.sub_pad(rr2, self.add(ppp, self.add(qv, qv)), self.pad_pq, 2, "RR - PPP - 2Q"))
+        d = self.norm(self.sub_pad(qv, x3, self.pad_xy, 1, "Q - X3"))
+        y3 = self.mul2(rr_, d, s1, self.neg_m(ppp), "Y3")
+        self.acc_ok(x3, self.norm(y3), self.mul(self.mul(zz1, zz2, "ZZ1 ZZ2"), pp, "ZZ3"), self.mul(self.mul(zzz1, zzz2, "ZZZ1 ZZZ2"), ppp, "ZZZ3"), "add")
+
+    def dbl(self, affine):
+        if affine:
+            x, y, zz, zzz = V(1.0, M_LIMB), V(2.0, N_LIMB), None, None
+        else:
+            x, y, zz, zzz = self.accumulator()
+        u = self.norm(self.add(y, y))
+        v = self.mul(u, u, "V")
+        w, s, x2 = self.mul(u, v, "W"), self.mul(x, v, "S"), self.mul(x, x, "X^2")
+        m = self.norm(self.add(self.add(x2, x2), x2))
+        mm = self.mul(m, m, "M^2")
+        x3 = self.norm(self.sub_pad(mm, self.add(s, s), self.pad_2s, 1, "M^2 - 2S"))
+        d = self.norm(self.sub_pad(s, x3, self.pad_xy, 1, "S - X3"))
+        y3 = self.norm(self.sub_pad(self.mul(m, d, "M (S - X3)"), self.mul(w, y, "W Y"), 2, 0, "Y3"))
+        zz3 = v if affine else self.mul(v, zz, "ZZ3")
+        zzz3 = w if affine else self.mul(w, zzz, "ZZZ3")
+        self.acc_ok(x3, y3, zz3, zzz3, "dbl_affine" if affine else "dbl")
+
+    def check(self):
+        self.madd(); self.add_(); self.dbl(False); self.dbl(True)
+        worst = max(self.log, key=lambda t: t[1])
+        return "%-10s %2d limbs, head-room x%.0f, pads %d / %d / %d p, accumulator X, Y < %d p: ok (largest product value: %s = %.2f p of at most %.0f p)" % (
+            self.name, self.xn, self.H, self.pad_xy, self.pad_pq, self.pad_2s, self.kxy, worst[0], worst[1], self.cap)
+
+
+BLS_Q = 0x1a0111ea397fe69a4b1ba7b6434bacd764774b84f38512bf6730d2a0f6b0f6241eabfffeb153ffffb9feffffffffaaab
+BN_Q = 21888242871839275222246405745257275088696311157297823662689037894645226208583
+FIELDS = [Field("BLS12-381", 381, BLS_Q, 14, 64, 32, 8, 64), Field("BN254", 254, BN_Q, 9, 8, 4, 4, 8)]
+
+
+def main():
+    for f in FIELDS:
+        print(f.check())
+    # the head-room rule the generous set-up relied on must FAIL for BN254 on 9 limbs with the wide pads: the tool has teeth
+    try:
+        Field("BN254 wide pads", 254, BN_Q, 9, 64, 32, 8, 64).check()
+    except AssertionError as e:
+        print("BN254 on 9 limbs with the 64 / 32 / 8 p pads is refused, as it must be:", e)
+        return 0
+    print("the checker accepted a set-up that overflows")
+    return 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())
