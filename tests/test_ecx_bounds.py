@@ -22,7 +22,7 @@ def test_the_checked_pad_set_is_the_generated_one():
     for name, struct in (("BLS12-381", "BlsFqX"), ("BN254", "BnFqX")):
         f = next(x for x in E.FIELDS if x.name == name)
         body = text[text.index("struct %s " % struct):]
-        body = body[:body.index("};")]
+        body = body[:body.index("\n};")]
         assert int(re.search(r"XN = (\d+);", body).group(1)) == f.xn
         assert int(re.search(r"XKXY = (\d+);", body).group(1)) == f.kxy
         for arr, k in (("XSUB_XY", f.pad_xy), ("XSUB_PQ", f.pad_pq), ("XSUB_2S", f.pad_2s)):

@@ -297,9 +297,9 @@ def test_msm_batch_fused(gpu, mj, cref):
 
 @pytest.mark.parametrize("curve_id", [0, 1])
 def test_msm_precomputed_table_path(gpu, mj, cref, curve_id):
-    """n >= 2^15 runs on the precomputed-multiples table (one bucket set, c = log2 of the SRS size > 16, the plain
-    path's maximum): sub-ranges of the SRS (base_offset), a batch mixing table and plain paths, and the switch that
-    turns the table off must all give the oracle's point.  Both curves (BN254 Fq on 10 x 29-bit limbs)."""
+    """n >= 2^10 runs on the precomputed-multiples table (one bucket set for all windows): sub-ranges of the SRS (base_offset), a batch
+    mixing table and plain paths, and the switch that turns the table off must all give the oracle's point.  Both curves (BN254 Fq on
+    9 x 29-bit limbs with the tight subtraction pads: tools/ecx_bounds.py)."""
     c = mj.params.CURVES[curve_id]
     n_srs = (1 << 17) + 64
     bases = cref.g1_arith_bases(curve_id, 0xfeed, 0x1d, n_srs)
@@ -312,7 +312,10 @@ def test_msm_precomputed_table_path(gpu, mj, cref, curve_id):
         want = cref.jac_to_affine(curve_id, cref.msm(curve_id, bases[off:off + n], scalars[:n], threads=8))[0]
         got = cref.jac_to_affine(curve_id, mj.msm_bigint(pp, scalars[:n], base_offset=off))[0]
         assert np.array_equal(got, want), (off, n)
-    assert mj.lib.msm_last_shape()[0] > 16, "large MSMs must have taken the precomputed-table path"
+    import ctypes as C
+    pts, tab = C.c_uint64(), C.c_uint64()
+    mj.lib.check(mj.load().mzk_srs_hbm_bytes(pp.handle, C.byref(pts), C.byref(tab)), "mzk_srs_hbm_bytes")
+    assert tab.value > 0 and mj.lib.msm_last_shape()[2] == 1 << (mj.lib.msm_last_shape()[0] - 1), "large MSMs must have taken the precomputed-table path"
     # batch: large (table) and small (plain) members interleaved
     sets = [scalars[:1 << 17], scalars[:1000], scalars[:(1 << 17) + 3], scalars[:0]]
     offs = [1, 2, 0, 0]
@@ -478,7 +481,7 @@ def test_srs_precompute_report_and_same_points(gpu, mj, cref, curve_id):
     bits, levels, nbytes, ms = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_double()
     assert L.mzk_srs_precompute(pp.handle, C.byref(bits), C.byref(levels), C.byref(nbytes), C.byref(ms)) == 0
     assert bits.value in (15, 16, 17, 20) and levels.value == (256 + bits.value) // bits.value      # signed digits of a 256-bit integer
-    assert nbytes.value == levels.value * n * (112 if curve_id == 0 else 80) and ms.value > 0
+    assert nbytes.value == levels.value * n * (112 if curve_id == 0 else 72) and ms.value > 0            # 2 x 14 / 2 x 9 limbs of 29 bits
     first = ms.value
     assert L.mzk_srs_precompute(pp.handle, None, None, None, C.byref(ms)) == 0 and ms.value == first, "built once"
     assert L.mzk_srs_precompute(0xdead, None, None, None, None) == -4

@@ -36,13 +36,14 @@ def test_sparse_and_skewed_scalars_both_paths(gpu, mj, cref, curve_id):
     pats = _patterns(mj, c, n)
     want = {k: cref.jac_to_affine(curve_id, cref.msm(curve_id, bases, v, scalars_are_mont=True, threads=8))[0] for k, v in pats.items()}
     L = mj.load()
+    shapes = {}
     for table in (1, 0):
         L.mzk_msm_set_precompute(table)
         try:
             for k, v in pats.items():
                 got = cref.jac_to_affine(curve_id, mj.msm_bigint(pp, v, scalars_are_mont=True))[0]
                 assert np.array_equal(got, want[k]), (curve_id, table, k)
-            assert (mj.lib.msm_last_shape()[0] > 16) == bool(table)
+            shapes[table] = mj.lib.msm_last_shape()                      # (window bits, digits per scalar, buckets per set)
             # one fused batch: dense and (nearly) empty members share one bucket reduction
             names = ["dense", "few", "zero", "half", "zero", "all_equal", "plus_minus"]
             jac = mj.msm_bigint_batch(pp, [pats[k] for k in names], scalars_are_mont=True)
@@ -50,6 +51,7 @@ def test_sparse_and_skewed_scalars_both_paths(gpu, mj, cref, curve_id):
                 assert np.array_equal(cref.jac_to_affine(curve_id, jac[i])[0], want[k]), (curve_id, table, "batch", k)
         finally:
             L.mzk_msm_set_precompute(1)
+    assert shapes[1][0] > shapes[0][0], "the table path (window 16 / 17 at this SRS size) and the plain path (window log2 n - 2) must both have run"
     pp.release()
 
 
