@@ -103,12 +103,13 @@ int32_t persistent_grid(size_t lds, unsigned* out) {
 }
 
 template <class X>
-int32_t launch_pass(const NttxPassArgs& a, unsigned long long n_tiles, uint32_t batch, hipStream_t st) {
+int32_t launch_pass(const NttxPassArgs& a, unsigned long long n_tiles, uint32_t batch, hipStream_t st, bool r4) {
     const size_t tile = (size_t)1 << (a.log_r + a.log_c);
     const size_t lds = 2 * tile * 16 + tile * 4;
     static bool attr_set[MAX_CTX] = {};                                  // per device (function attributes live in the device's code object)
     if (!attr_set[cur().logical]) {
-        HIP_TRY(hipFuncSetAttribute((const void*)nttx_pass_kernel<X>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        HIP_TRY(hipFuncSetAttribute((const void*)nttx_pass_kernel<X, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
+        HIP_TRY(hipFuncSetAttribute((const void*)nttx_pass_kernel<X, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         HIP_TRY(hipFuncSetAttribute((const void*)nttx_pass_persistent_kernel<X, false>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         HIP_TRY(hipFuncSetAttribute((const void*)nttx_pass_persistent_kernel<X, true>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)(160 * 1024)));
         attr_set[cur().logical] = true;
@@ -128,8 +129,10 @@ int32_t launch_pass(const NttxPassArgs& a, unsigned long long n_tiles, uint32_t 
         while ((1ull << log_tiles) < n_tiles) log_tiles++;
         if (tw_lds) hipLaunchKernelGGL((nttx_pass_persistent_kernel<X, true>), dim3(resident), dim3(NTTX_THREADS), lds_p, st, a, log_tiles, total);
         else hipLaunchKernelGGL((nttx_pass_persistent_kernel<X, false>), dim3(resident), dim3(NTTX_THREADS), lds_p, st, a, log_tiles, total);
+    } else if (r4) {
+        hipLaunchKernelGGL((nttx_pass_kernel<X, true>), dim3((unsigned)n_tiles, batch), dim3(NTTX_THREADS), lds, st, a);
     } else {
-        hipLaunchKernelGGL((nttx_pass_kernel<X>), dim3((unsigned)n_tiles, batch), dim3(NTTX_THREADS), lds, st, a);
+        hipLaunchKernelGGL((nttx_pass_kernel<X, false>), dim3((unsigned)n_tiles, batch), dim3(NTTX_THREADS), lds, st, a);
     }
     HIP_TRY(hipGetLastError());
     return MZK_OK;
@@ -157,6 +160,12 @@ int32_t ntt_dev(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool in
     ProfScope total("ntt_total", st);
     const int K = pl->h.n_pass;
     int log_p = 0;
+    // launches of at least 2^21 elements (a 2^22 transform; the batch of seven 2^20-point class transforms of the quotient round) take
+    // 2048-element tiles and stage pairs in registers (ntt_fx.cuh, R4); smaller ones the 1024-element radix-2 form, which fills the chip
+    // with twice as many workgroups.  MZK_NTT_NO_RADIX4=1: the round-3 form everywhere (A/B).
+    static const bool no_r4 = std::getenv("MZK_NTT_NO_RADIX4") != nullptr;
+    const bool r4 = !no_r4 && (uint64_t)N * batch >= (1ull << 21);
+    const int tile_log = r4 ? 11 : NTT_TILE_LOG;
     for (int k = 0; k < K; k++) {
         NttxPassArgs a;
         std::memset(&a, 0, sizeof a);
@@ -174,7 +183,7 @@ int32_t ntt_dev(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool in
         a.n = N;
         if (a.is_first && !a.is_final && !d_patch)                      // zero-padded input: leading stages of pass 1 are copies
             while (a.skip < lr && in_len <= (N >> (a.skip + 1))) a.skip++;
-        int lc = NTT_TILE_LOG - lr;
+        int lc = tile_log - lr;
         if (lc < 0) lc = 0;
         if (a.is_final) lc = K == 1 ? 0 : (lc < pl->h.log_radix[0] ? lc : pl->h.log_radix[0]);
         else lc = lc < a.log_s ? lc : a.log_s;
@@ -191,7 +200,7 @@ int32_t ntt_dev(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool in
         a.out_stride = to_data ? stride : N;
         a.out_planes = (to_data || K == 1) ? 0 : 1;
         const unsigned long long n_tiles = N >> (lr + lc);
-        MZK_TRY((launch_pass<X>(a, n_tiles, batch, st)));
+        MZK_TRY((launch_pass<X>(a, n_tiles, batch, st, r4)));
         log_p += lr;
     }
     if (K == 1)

@@ -108,8 +108,8 @@ __device__ __forceinline__ FsTw tws_load(const uint32_t* __restrict__ table, uns
     return t;
 }
 
-// grid = (N / (R*C), batch), block = NTTX_THREADS
-template <class X>
+// grid = (N / (R*C), batch), block = NTTX_THREADS.  R4: stage PAIRS in registers (below), for 2048-element tiles.
+template <class X, bool R4>
 __global__ __launch_bounds__(NTTX_THREADS) void nttx_pass_kernel(NttxPassArgs a) {
     static_assert(X::XN == 9 && X::N == 8, "256-bit scalar fields: 8 boundary words, 9 limbs of 29 bits");
     extern __shared__ int4 ldsx[];
@@ -190,10 +190,44 @@ __global__ __launch_bounds__(NTTX_THREADS) void nttx_pass_kernel(NttxPassArgs a)
     // t = hi W is class C, so both outputs stay within 2^30.
     const int nbf = TILE >> 1;
     const int tw_rows = R - 1;
+    int s0 = a.skip;
+    // R4 (round 4): two stages per LDS round trip.  A thread takes the four rows b, b + h, b + 2h, b + 3h (h = 2^s) of one column through
+    // stages s and s + 1 in registers -- the same four constant-operand products and normalisations as two radix-2 stages, half the
+    // barriers and LDS traffic, 36 data registers instead of 18: 120 VGPRs, four waves per SIMD, which is what 2048-element tiles (72 KB of
+    // LDS, every thread one group of four rows) leave anyway.  Measured (profiles/r04_ntt_radix4.txt, bit-identical outputs): with
+    // 2048-element tiles 0.612 -> 0.592 ms at 2^22, 2.31 -> 2.16 ms at 2^24, 0.190 -> 0.184 at 2^20 -- but 0.070 -> 0.084 ms at 2^16 (too few
+    // workgroups), and on 1024-element tiles (half the threads idle in the paired steps) 0.654 ms at 2^22: the dispatcher takes this form
+    // for launches of at least 2^21 elements (ntt.hip).
+    if constexpr (R4)
+    for (; s0 + 1 < a.log_r; s0 += 2) {
+        const int s = s0, half = 1 << s;
+        const bool fresh = !a.in_planes && s == a.skip;
+        for (int g = tid; g < (TILE >> 2); g += NTTX_THREADS) {
+            const int c = g & (C - 1);
+            const int jj = g >> a.log_c;
+            const int j = jj & (half - 1);
+            const int i0 = ((((jj >> s) << (s + 2)) + j) * C) + c, st = half * C;
+            Fs<X> x0 = ldss_load<X>(da, db, dc, i0), x2 = ldss_load<X>(da, db, dc, i0 + 2 * st);
+            const Fs<X> x1 = ldss_load<X>(da, db, dc, i0 + st), x3 = ldss_load<X>(da, db, dc, i0 + 3 * st);
+            if (!fresh) { x0 = fs_norm(x0); x2 = fs_norm(x2); }
+            const unsigned long long k1 = a.is_first ? 0ull : (a.is_final ? i1_0 + c : k1_blk);
+            const uint32_t* tw = a.stage_tw + k1 * tw_rows * FS_TW_WORDS;
+            const FsTw w1 = tws_load(tw, (unsigned long long)(half - 1 + j));
+            const Fs<X> t1 = fs_mulc<X>(x1, w1), t3 = fs_mulc<X>(x3, w1);
+            const Fs<X> y0 = fs_norm(fs_add(x0, t1)), y1 = fs_norm(fs_sub(x0, t1));
+            const Fs<X> u2 = fs_mulc<X>(fs_add(x2, t3), tws_load(tw, (unsigned long long)(2 * half - 1 + j)));
+            const Fs<X> u3 = fs_mulc<X>(fs_sub(x2, t3), tws_load(tw, (unsigned long long)(3 * half - 1 + j)));
+            ldss_store<X>(da, db, dc, i0, fs_add(y0, u2));
+            ldss_store<X>(da, db, dc, i0 + 2 * st, fs_sub(y0, u2));
+            ldss_store<X>(da, db, dc, i0 + st, fs_add(y1, u3));
+            ldss_store<X>(da, db, dc, i0 + 3 * st, fs_sub(y1, u3));
+        }
+        __syncthreads();
+    }
 #ifdef MZK_NTT_DIAG_NOSTAGES                         // (diagnostic builds only, tools/ntt_diag.sh: what a pass costs without its butterflies / without its HBM traffic)
     for (int s = a.log_r; s < a.log_r; s++) {
 #else
-    for (int s = a.skip; s < a.log_r; s++) {
+    for (int s = s0; s < a.log_r; s++) {
 #endif
         const int half = 1 << s;
         const bool fresh = !a.in_planes && s == a.skip;
