@@ -106,6 +106,10 @@ MZK_API int32_t mzk_srs_generate_lagrange_for_testing(int32_t curve_id, const ui
  * (n / 2) log2 n scalar multiplications: 0.14 s at 2^16, 1.2 s at 2^20 (BLS12-381; BN254 half that) -- once per SRS and domain size.
  * Synchronises. */
 MZK_API int32_t mzk_srs_lagrange_from_srs(uint64_t srs_handle, uint32_t log_n, uint32_t n_extra, uint64_t* out_handle);
+/* A new SRS handle holding the points [first, first + n_points) of a registered one (a device copy; `trim` generalised, srs.rs:77-93): a rank
+ * of a multi-GPU prover keeps the range it commits over -- 1 / G of the points and of the fixed-base table, built with the window that suits
+ * the slice's size -- and hands it to mzk_prover_create as its commit key (see there).  The source stays registered. */
+MZK_API int32_t mzk_srs_slice(uint64_t handle, uint64_t first, uint64_t n_points, uint64_t* out_handle);
 MZK_API int32_t mzk_srs_download(uint64_t handle, uint64_t first, uint64_t n_points, uint64_t* out_xy_mont);
 MZK_API int32_t mzk_srs_len(uint64_t handle, uint64_t* out_n_points);
 
@@ -381,14 +385,16 @@ typedef struct mzk_comm {
  * DensePolynomial coefficient vectors, low order first, poly_len <= n = 2^log_n (host).  k_mont: the W coset representatives `vk.k`.
  * commit_key: SRS handle with >= n + 3 points (`pk.commit_key`, trim(n + 2): snark.rs:535, 561).  lagrange_key: 0, or a handle from
  * mzk_srs_lagrange_from_srs(commit_key, log_n, 3): round 1 (and 1.5) then commit the wire VALUES over the Lagrange basis -- same
- * group elements, mostly small scalars.  comm: NULL = one device.  The prover lives on the calling thread's device. */
+ * group elements, mostly small scalars.  comm: NULL = one device.  The prover lives on the calling thread's device.
+ * With a comm, commit_key (and lagrange_key) may instead hold ONLY this rank's point range [rank (n+3) / world ..) -- exactly that many points
+ * (mzk_srs_slice): the rank then keeps 1 / world of the SRS and of its fixed-base table. */
 MZK_API int32_t mzk_prover_create(int32_t curve_id, uint32_t log_n, uint32_t num_wire_types, const uint64_t* selector_coeffs,
                                   const uint64_t* sigma_coeffs, const uint64_t* table_coeffs, uint64_t poly_len, const uint64_t* k_mont,
                                   uint64_t commit_key, uint64_t lagrange_key, const mzk_comm* comm, uint64_t* out_prover);
 MZK_API int32_t mzk_prover_destroy(uint64_t prover);
 /* `VerifyingKey{selector_comms, sigma_comms}` (preprocess, snark.rs:562-594) from the resident coefficient forms: nsel + W affine points,
  * then -- UltraPlonk, out_plookup_xy non-NULL -- range_table_comm, key_table_comm, table_dom_sep_comm, q_dom_sep_comm (:575-590). */
-MZK_API int32_t mzk_prover_vk_commitments(uint64_t prover, uint64_t* out_xy_mont, uint64_t* out_plookup_xy_mont);
+MZK_API int32_t mzk_prover_vk_commitments(uint64_t prover, uint64_t* out_xy_mont, uint64_t* out_plookup_xy_mont);      /* (with a comm: a collective, every rank calls it) */
 /* `wire_variables` of the finalised circuit (relation/src/constraint_system.rs:1225-1247), W x n u32 (host), every entry < n_vars (checked:
  * MZK_ERR_INVALID_ARG -- the reference panics on such an index): resident circuit structure for MZK_WITNESS_*_VECTOR. */
 MZK_API int32_t mzk_prover_set_wire_variables(uint64_t prover, const uint32_t* wire_variables, uint64_t n_vars);

@@ -329,6 +329,23 @@ int32_t mzk_srs_register_dev(int32_t curve_id, const void* d_xy_mont, uint64_t n
     cx_->srs[*out_handle] = s;
     return MZK_OK;
 }
+// a new SRS holding the points [first, first + n_points) of a registered one (on its device): a rank of a multi-GPU prover keeps only
+// the range it commits over -- 1 / G of the points and of the fixed-base table, whose window then follows the slice's size
+int32_t mzk_srs_slice(uint64_t handle, uint64_t first, uint64_t n_points, uint64_t* out_handle) {
+    ENTER_HANDLE(handle);
+    auto it = cx_->srs.find(handle);
+    if (it == cx_->srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
+    if (!out_handle || first + n_points > it->second.n) { set_error("slice outside the SRS"); return MZK_ERR_INVALID_ARG; }
+    const Srs& src = it->second;
+    Srs s{src.curve, n_points, nullptr, nullptr, nullptr, 0};
+    const size_t pt = (size_t)2 * fq_words(src.curve) * 4, bytes = (size_t)n_points * pt;
+    HIP_TRY(hipMalloc((void**)&s.d_xy, bytes ? bytes : 4));
+    if (bytes) HIP_TRY(hipMemcpy(s.d_xy, reinterpret_cast<const uint8_t*>(src.d_xy) + first * pt, bytes, hipMemcpyDeviceToDevice));
+    MZK_TRY(srs_build_internal(s, nullptr));
+    *out_handle = handle_make(cx_->logical, cx_->next_handle++);
+    cx_->srs[*out_handle] = s;
+    return MZK_OK;
+}
 int32_t mzk_srs_release(uint64_t handle) {
     ENTER_HANDLE(handle);
     auto it = cx_->srs.find(handle);

@@ -117,6 +117,7 @@ struct ProverT final : ProverBase {
     int rank = 0, world = 1;
     mzk_comm comm{};
     uint64_t lo = 0, hi = 0;
+    uint64_t key_first = 0;                                            // SRS index of the commit key's first point: lo when the key is this rank's slice
     Buf fixed;                                                         // (nsel + W [+ 4]) x n coefficient forms
     Buf slab, quot, coeff, split, lin, batch, opening, shifted, hh, table, lookup, sorted, tmp, deg, rem, wv, wit, top, vals_ext, qsum, vars;
     Pinned stage_pi;
@@ -174,14 +175,16 @@ struct ProverT final : ProverBase {
         if (world < 1 || rank < 0 || rank >= world || (world > 1 && (!comm.all_gather || !comm.barrier)))
             fail(MZK_ERR_INVALID_ARG, "mzk_comm: 0 <= rank < world, all_gather and barrier callbacks required");
         for (int i = 0; i < W; i++) k.push_back(load(k_mont + 4 * i));
+        std::tie(lo, hi) = shard_range(n + 3, rank, world);            // the proving key keeps trim(n + 2) = n + 3 powers (snark.rs:535, 561)
         uint64_t srs_len = 0;
         ck(mzk_srs_len(srs, &srs_len));
-        if (srs_len < n + 3) fail(MZK_ERR_INVALID_ARG, "commit key too small: need domain size + 3 powers (srs.rs:88)");
+        if (world > 1 && srs_len == hi - lo) key_first = lo;           // the key IS this rank's range of the SRS (mzk_srs_slice)
+        else if (srs_len < n + 3) fail(MZK_ERR_INVALID_ARG, "commit key too small: need domain size + 3 powers (srs.rs:88), or exactly this rank's point range");
         if (srs_lagrange) {
             ck(mzk_srs_len(srs_lagrange, &srs_len));
-            if (srs_len < n + 3) fail(MZK_ERR_INVALID_ARG, "Lagrange-basis key too small: 2^log_n + 3 points (mzk_srs_lagrange_from_srs(.., log_n, 3))");
+            if (key_first ? srs_len != hi - lo : srs_len < n + 3)
+                fail(MZK_ERR_INVALID_ARG, "Lagrange-basis key: 2^log_n + 3 points (mzk_srs_lagrange_from_srs(.., log_n, 3)), sliced like the commit key");
         }
-        std::tie(lo, hi) = shard_range(n + 3, rank, world);            // the proving key keeps trim(n + 2) = n + 3 powers (snark.rs:535, 561)
         const int nfix = nsel + W + (ultra ? 4 : 0);
         fixed.alloc((size_t)nfix * n);
         ck(mzk_dev_memset(fixed.p, 0, (size_t)nfix * n * EL, nullptr));
@@ -238,7 +241,7 @@ struct ProverT final : ProverBase {
             const uint64_t s0 = std::min(a, lens[i]), s1 = std::min(b, lens[i]);
             p[i] = static_cast<const uint8_t*>(polys[i]) + s0 * EL;
             l[i] = s1 - s0;
-            off[i] = s1 > s0 ? s0 : a;
+            off[i] = (s1 > s0 ? s0 : a) - key_first;                     // (a sliced key starts at this rank's lo: a >= lo there)
         }
         ck(mzk_msm_batch_dev(key ? key : srs, kp, p.data(), l.data(), off.data(), 1, xyz.data(), nullptr));
         return xyz;
@@ -265,17 +268,20 @@ struct ProverT final : ProverBase {
     // ... of polynomials of which this rank holds ONLY the coefficients [lo, lo + lens[i])
     void commit_slices(const std::vector<const void*>& slices, const std::vector<uint64_t>& lens, uint64_t* out_xy) {
         const uint32_t kp = (uint32_t)slices.size();
-        std::vector<uint64_t> off(kp, lo), xyz((size_t)kp * 3 * QL);
+        std::vector<uint64_t> off(kp, lo - key_first), xyz((size_t)kp * 3 * QL);
         ck(mzk_msm_batch_dev(srs, kp, slices.data(), lens.data(), off.data(), 1, xyz.data(), nullptr));
         combine_partials(xyz, out_xy);
     }
-    void vk_commitments(uint64_t* out_xy, uint64_t* out_plookup_xy) override {   // whole MSMs on this device (set-up work, replicated on every rank)
+    void vk_commitments(uint64_t* out_xy, uint64_t* out_plookup_xy) override {   // set-up work: over several ranks sharded by point range like every commitment
         std::vector<const void*> ptrs;
         std::vector<uint64_t> lens;
         const int cnt = nsel + W + (ultra && out_plookup_xy ? 4 : 0);
         for (int i = 0; i < cnt; i++) { ptrs.push_back(fix(i)); lens.push_back(n); }
         std::vector<uint64_t> xy((size_t)cnt * PT);
-        ck(mzk_g1_jacobian_to_affine(CURVE, msm_partials(ptrs, lens, 0, n + 3).data(), cnt, xy.data()));
+        for (int i = 0; i < cnt; i += 16) {                                      // (mzk_msm_batch_dev groups at most 16 MSMs)
+            const int k = std::min(16, cnt - i);
+            commit(std::vector<const void*>(ptrs.begin() + i, ptrs.begin() + i + k), std::vector<uint64_t>(lens.begin() + i, lens.begin() + i + k), &xy[(size_t)i * PT]);
+        }
         std::memcpy(out_xy, xy.data(), (size_t)(nsel + W) * PT * 8);
         if (ultra && out_plookup_xy) std::memcpy(out_plookup_xy, &xy[(size_t)(nsel + W) * PT], 4 * PT * 8);
     }

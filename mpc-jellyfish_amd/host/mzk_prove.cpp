@@ -26,6 +26,7 @@ struct Options {
     int host_witness = 0;         // --host-witness: every proof uploads its W x n wire values from page-locked host memory;
                                   // --host-witness-vars: only the witness vector, gathered per wire on the device
     bool check_agree = false;     // --check-agree: every rank's proof bytes are compared (tests)
+    bool slice_srs = true;        // --no-slice: with --gpus G every rank keeps the whole commit key (and its table) instead of its point range
     int lagrange = -1;            // round 1 commits the wires from their VALUES over the Lagrange-basis key derived from the SRS (same proof
                                   // bytes): -1 = from 2^13 gates on (below, small scalars only add latency), --lagrange = always,
                                   // --no-lagrange = never (from the masked coefficient forms, as the reference does)
@@ -50,7 +51,7 @@ int run(bool ultra, uint64_t num_gates, int reps, int range_bits, const Options&
     double circuit_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     t0 = std::chrono::steady_clock::now();
     const bool lagrange = opt.lagrange < 0 ? host.log_n >= 13 : opt.lagrange != 0;
-    sp.setup(host, beta_c, opt.host_witness, lagrange);                           // SRS, circuit upload and PlonkKzgSnark::preprocess on every device
+    sp.setup(host, beta_c, opt.host_witness, lagrange, opt.slice_srs);                           // SRS, circuit upload and PlonkKzgSnark::preprocess on every device
     const double preprocess_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     Proof<C> proof = sp.prove(rng, false, opt.check_agree);             // the proof whose bytes are printed (and warm-up)
     const std::vector<uint8_t> bytes = proof.serialize_compressed();
@@ -161,6 +162,7 @@ int main(int argc_in, char** argv_in) {
         else if (a == "--check-agree") opt.check_agree = true;
         else if (a == "--lagrange") opt.lagrange = 1;
         else if (a == "--no-lagrange") opt.lagrange = 0;
+        else if (a == "--no-slice") opt.slice_srs = false;
         else args.push_back(argv_in[i]);
     }
     const int argc = (int)args.size();

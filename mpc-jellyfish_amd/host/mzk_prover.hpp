@@ -619,13 +619,25 @@ struct ShardedProver {
     }
     // the testing SRS [beta^i] G on every device, the circuit uploaded to every device, PlonkKzgSnark::preprocess per device
     // lagrange: also the key over the Lagrange basis of the gate domain -- round 1 then commits from the wire values
-    void setup(const BenchCircuitHost<C>& host, const std::array<uint64_t, 4>& beta_canonical, int host_witness = 0, bool lagrange = true) {
+    // slice_srs (several devices): every rank keeps ONLY its point range of the commit key(s) -- mzk_srs_slice -- i.e. 1 / G of the SRS and of
+    // its fixed-base table, built with the window that suits the slice (2^17-point shards at G = 8: window 16 and fused small batches)
+    void setup(const BenchCircuitHost<C>& host, const std::array<uint64_t, 4>& beta_canonical, int host_witness = 0, bool lagrange = true, bool slice_srs = true) {
         each([&](int r) {
             check(mzk_srs_generate_for_testing(C::ID, beta_canonical.data(), host.n + 3, &srs[r]), "mzk_srs_generate_for_testing");
             if (lagrange) {                                               // from the SRS's points alone (no trapdoor): an inverse NTT over the group
                 const auto t0 = std::chrono::steady_clock::now();
                 check(mzk_srs_lagrange_from_srs(srs[r], (uint32_t)host.log_n, 3, &srs_lagrange[r]), "mzk_srs_lagrange_from_srs");
                 if (r == 0) lagrange_key_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+            }
+            if (G > 1 && slice_srs) {
+                const auto range = shard_range(host.n + 3, r, G);
+                for (uint64_t* key : {&srs[r], &srs_lagrange[r]}) {
+                    if (!*key) continue;
+                    uint64_t part = 0;
+                    check(mzk_srs_slice(*key, range.first, range.second - range.first, &part), "mzk_srs_slice");
+                    check(mzk_srs_release(*key), "mzk_srs_release");
+                    *key = part;
+                }
             }
             circuit[r] = std::make_unique<BenchCircuit<C>>(BenchCircuit<C>::upload(host, host_witness));
             mzk_comm cm{&rank_ctx[r], r, G, &cb_all_gather, &cb_barrier, nullptr};

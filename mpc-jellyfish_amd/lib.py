@@ -33,6 +33,7 @@ _SIGS = {
     "mzk_srs_generate_for_testing_g": [C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.POINTER(C.c_uint64)],
     "mzk_srs_lagrange_from_srs": [C.c_uint64, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)],
     "mzk_srs_generate_lagrange_for_testing": [C.c_int32, C.c_void_p, C.c_void_p, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint64)],
+    "mzk_srs_slice": [C.c_uint64, C.c_uint64, C.c_uint64, C.POINTER(C.c_uint64)],
     "mzk_srs_download": [C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p],
     "mzk_srs_len": [C.c_uint64, C.POINTER(C.c_uint64)],
     "mzk_msm": [C.c_uint64, C.c_uint64, C.c_void_p, C.c_uint64, C.c_int32, C.c_void_p],
