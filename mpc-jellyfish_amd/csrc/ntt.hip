@@ -160,11 +160,12 @@ int32_t ntt_dev(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool in
     ProfScope total("ntt_total", st);
     const int K = pl->h.n_pass;
     int log_p = 0;
-    // launches of at least 2^21 elements (a 2^22 transform; the batch of seven 2^20-point class transforms of the quotient round) take
-    // 2048-element tiles and stage pairs in registers (ntt_fx.cuh, R4); smaller ones the 1024-element radix-2 form, which fills the chip
-    // with twice as many workgroups.  MZK_NTT_NO_RADIX4=1: the round-3 form everywhere (A/B).
+    // transforms of at least 2^21 points take 2048-element tiles and stage pairs in registers (ntt_fx.cuh, R4): -4 % at 2^22, -7 % at 2^24;
+    // smaller ones the 1024-element radix-2 form, which fills the chip with twice as many workgroups -- also in batches (the seven
+    // 2^20-point class transforms of the quotient round measured 5.56-5.72 ms without and 5.75-5.78 ms with R4: profiles/r04_ntt_radix4.txt).
+    // MZK_NTT_NO_RADIX4=1: the round-3 form everywhere (A/B).
     static const bool no_r4 = std::getenv("MZK_NTT_NO_RADIX4") != nullptr;
-    const bool r4 = !no_r4 && (uint64_t)N * batch >= (1ull << 21);
+    const bool r4 = !no_r4 && N >= (1ull << 21);
     const int tile_log = r4 ? 11 : NTT_TILE_LOG;
     for (int k = 0; k < K; k++) {
         NttxPassArgs a;

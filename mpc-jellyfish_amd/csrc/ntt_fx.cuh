@@ -197,7 +197,7 @@ __global__ __launch_bounds__(NTTX_THREADS) void nttx_pass_kernel(NttxPassArgs a)
     // LDS, every thread one group of four rows) leave anyway.  Measured (profiles/r04_ntt_radix4.txt, bit-identical outputs): with
     // 2048-element tiles 0.612 -> 0.592 ms at 2^22, 2.31 -> 2.16 ms at 2^24, 0.190 -> 0.184 at 2^20 -- but 0.070 -> 0.084 ms at 2^16 (too few
     // workgroups), and on 1024-element tiles (half the threads idle in the paired steps) 0.654 ms at 2^22: the dispatcher takes this form
-    // for launches of at least 2^21 elements (ntt.hip).
+    // for transforms of at least 2^21 points (ntt.hip).
     if constexpr (R4)
     for (; s0 + 1 < a.log_r; s0 += 2) {
         const int s = s0, half = 1 << s;
