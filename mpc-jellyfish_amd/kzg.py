@@ -94,6 +94,14 @@ class UnivariateProverParam:
         _lib.check(_lib.ensure_init().mzk_srs_lagrange_from_srs(self.handle, domain_size.bit_length() - 1, n_extra, C.byref(h)), "mzk_srs_lagrange_from_srs")
         return UnivariateProverParam(self.curve, h.value, domain_size + n_extra)
 
+    def slice(self, first: int, count: int) -> "UnivariateProverParam":
+        """A NEW registration holding the points [first, first + count) of this one (mzk_srs_slice): what a rank of a multi-GPU prover keeps
+        of the commit key -- its own fixed-base table, 1 / G of the size, built with the window that suits the slice."""
+        assert 0 <= first and first + count <= self.length
+        h = C.c_uint64()
+        _lib.check(_lib.ensure_init().mzk_srs_slice(self.handle, self.offset + first, count, C.byref(h)), "mzk_srs_slice")
+        return UnivariateProverParam(self.curve, h.value, count)
+
     def trim(self, supported_degree: int) -> "UnivariateProverParam":
         """srs.rs:77-93: keep powers_of_g[..=supported_degree]."""
         if supported_degree + 1 > self.length:

@@ -7,7 +7,15 @@ and per G it measures, on this one GPU, exactly what rank 0 of a G-rank run exec
 
   commits      every batch_commit of the proof (round 1: W wires; 1.5: h_1, h_2; 2: z; 2.5: Plookup product; 3: W split-quotient
                parts; 5: two openings) as ONE mzk_msm_batch_dev over the rank's point range [0, len / G) of every polynomial
-               (sharding.ShardedCommitter), on the SRS's fixed-base table;
+               (sharding.ShardedCommitter), under THREE schedules (round 4):
+                 replicated   every rank holds the whole SRS and its table (window for 2^20+ points) and commits over its range of it
+                              (round 3's set-up);
+                 sliced       every rank holds only its range (mzk_srs_slice: 1 / G of the table, window chosen for the slice; small
+                              shards are fused into one sort / accumulation) -- what the compiled host does since round 4;
+                 by_polynomial  the reference's own parallelism (univariate_kzg/mod.rs:119-131, one polynomial per worker): groups of W
+                              polynomials as whole polynomials on W ranks, the spare ranks taking point-range halves of the largest;
+                              groups of one or two polynomials by point range as above.  Its cost on the busiest rank is measured
+                              as the batch that rank would run;
   quotient     the rank's ceil(needed / G) residue classes (needed = W of the 8) through mzk_plonk_quotient_chunked_dev, the top coefficients and
                the inverse-Vandermonde combine every rank runs after the exchange;
   ranged       rounds 4 and 5 (evaluations; linearisation + batch polynomials, their division by (X - z)) on the rank's
@@ -20,7 +28,7 @@ and it ADDS, from stated constants (not measurable on one GPU):
   collectives  one small all-gather per commit group (k x 144 / 96 bytes per rank) at SMALL_COLLECTIVE_US each, and the one
                exchange of class remainders: (G - 1) x classes_per_rank x n x 32 bytes received per rank at XGMI_GBPS.
 
-    python tools/scale_model.py [--c5-log-n 22] > profiles/r03_scale_model.json
+    python tools/scale_model.py [--c5-log-n 22] > profiles/r04_scale_model.json
 """
 import argparse
 import json
@@ -161,21 +169,45 @@ def model(mj, curve, plonk_type, log_n):
     del rem, quot
     point_bytes = 3 * c.fq_limbs * 8
     for G in (1, 2, 4, 8):
-        commits = {}
+        commits, sliced, by_poly = {}, {}, {}
+        ck_s = ck.slice(0, (n + 3) // G) if G > 1 else ck                # rank 0's range as an SRS of its own
+        lag_s = lag.slice(0, (n + 3) // G) if G > 1 else lag
         for name, k, length in groups:
             hi = length // G if G > 1 else length                       # rank 0's point range [0, len / G)
             if name == "r1_wires":
                 sets = [ext[i, :hi] for i in range(W)]
                 commits[name] = round(median_ms(lambda: mj.msm_bigint_batch(lag, sets, scalars_are_mont=True)), 3)
+                sliced[name] = round(median_ms(lambda: mj.msm_bigint_batch(lag_s, sets, scalars_are_mont=True)), 3)
+                # whole polynomials: rank 0 commits ceil(W / G) wires whole (from their values over the Lagrange key), G >= W: one
+                whole = [ext[i, :length] for i in range(-(-W // G))]
+                by_poly[name] = round(median_ms(lambda: mj.msm_bigint_batch(lag, whole, scalars_are_mont=True)), 3) if G > 1 else commits[name]
                 continue
             sets = [scal[:hi]] * k
             commits[name] = round(median_ms(lambda: mj.msm_bigint_batch(ck, sets, scalars_are_mont=True)), 3)
+            sliced[name] = round(median_ms(lambda: mj.msm_bigint_batch(ck_s, sets, scalars_are_mont=True)), 3)
+            if k >= W and G > 1:
+                # the busiest rank: floor(W / G) whole polynomials and, if G does not divide W, its share of the rest cut by point range
+                full, rest = W // G, W % G
+                part = [scal[:length]] * full + ([scal[:max(1, length * rest // G)]] if rest and G < W else [])
+                if not part:
+                    part = [scal[:length]]                               # G > W: W ranks take one whole polynomial each
+                by_poly[name] = round(median_ms(lambda: mj.msm_bigint_batch(ck, part, scalars_are_mont=True)), 3)
+            else:
+                by_poly[name] = sliced[name]                             # one or two polynomials: by point range (on the sliced key)
+        if G > 1:
+            ck_s.release()
+            lag_s.release()
         per = -(-len(needed) // G)
         gather_bytes = (G - 1) * per * n * 32
         exchange_ms = 0.0 if G == 1 else SMALL_COLLECTIVE_US / 1e3 + gather_bytes / (XGMI_GBPS * 1e9) * 1e3
         small_ms = 0.0 if G == 1 else (len(groups) + 2) * SMALL_COLLECTIVE_US / 1e3      # + the round-4 and round-5 exchanges of partial values
-        total = sum(commits.values()) + class_ms[per] + combine_ms + exchange_ms + small_ms + replicated_ms + ranged_ms[G]
+        rest_ms = class_ms[per] + combine_ms + exchange_ms + small_ms + replicated_ms + ranged_ms[G]
+        best = min((sum(sliced.values()), "sliced"), (sum(by_poly.values()), "by_polynomial"), (sum(commits.values()), "replicated"))
+        total = best[0] + rest_ms
         out["per_G"][str(G)] = {"commits_ms": commits, "commit_total_ms": round(sum(commits.values()), 2),
+                                "commits_sliced_srs_ms": sliced, "commit_total_sliced_srs_ms": round(sum(sliced.values()), 2),
+                                "commits_by_polynomial_ms": by_poly, "commit_total_by_polynomial_ms": round(sum(by_poly.values()), 2),
+                                "best_commit_schedule": best[1], "predicted_prove_replicated_srs_ms": round(sum(commits.values()) + rest_ms, 2),
                                 "quotient_classes_per_rank": per, "quotient_local_ms": round(class_ms[per], 3), "combine_ms": round(combine_ms, 3),
                                 "class_exchange_ms": round(exchange_ms, 3), "class_exchange_bytes_received": gather_bytes,
                                 "small_collectives_ms": round(small_ms, 3), "replicated_ms": round(replicated_ms, 2),
