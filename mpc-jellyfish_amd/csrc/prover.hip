@@ -178,11 +178,12 @@ struct ProverT final : ProverBase {
         std::tie(lo, hi) = shard_range(n + 3, rank, world);            // the proving key keeps trim(n + 2) = n + 3 powers (snark.rs:535, 561)
         uint64_t srs_len = 0;
         ck(mzk_srs_len(srs, &srs_len));
-        if (world > 1 && srs_len == hi - lo) key_first = lo;           // the key IS this rank's range of the SRS (mzk_srs_slice)
+        const bool sliced = world > 1 && srs_len == hi - lo;           // the key IS this rank's range of the SRS (mzk_srs_slice)
+        if (sliced) key_first = lo;
         else if (srs_len < n + 3) fail(MZK_ERR_INVALID_ARG, "commit key too small: need domain size + 3 powers (srs.rs:88), or exactly this rank's point range");
         if (srs_lagrange) {
             ck(mzk_srs_len(srs_lagrange, &srs_len));
-            if (key_first ? srs_len != hi - lo : srs_len < n + 3)
+            if (sliced ? srs_len != hi - lo : srs_len < n + 3)
                 fail(MZK_ERR_INVALID_ARG, "Lagrange-basis key: 2^log_n + 3 points (mzk_srs_lagrange_from_srs(.., log_n, 3)), sliced like the commit key");
         }
         const int nfix = nsel + W + (ultra ? 4 : 0);
