@@ -597,7 +597,7 @@ def main():
             gather = lambda local, n_classes: mj.sharding.gather_quotient_classes(local, via_host=(backend != "nccl"), n_classes=n_classes)
             prover = mj.snark.preprocess(ck, cs, quotient_shard=(rank, world), quotient_gather=gather)
             prover.vk_commitments()
-            prover.committer = mj.sharding.ShardedCommitter(crv, ck, device=coll_dev)
+            prover.committer = mj.sharding.ShardedCommitter(crv, ck, device=coll_dev, slice_srs=True)     # every rank keeps its point range of the SRS (1 / N of the table)
             rng = mj.rng.test_rng()
             for _ in range(3):
                 mj.snark.prove(rng, cs, prover)

@@ -99,8 +99,7 @@ class ShardedCommitter:
         total = self.ck.length if self.ck is not None else max([int(p.shape[0]) for p in polys] + [1])
         lo_r, hi_r = shard_range(total, rank, world)
         if self.slice_srs and self._slice is None and hi_r > lo_r:
-            from . import kzg
-            self._slice = kzg.UnivariateProverParam.from_affine(self.c, self.ck.powers_of_g(lo_r, hi_r - lo_r))
+            self._slice = self.ck.slice(lo_r, hi_r - lo_r)               # mzk_srs_slice: a device copy of this rank's range
             self._slice_lo = lo_r
         slices, offsets = [], []
         for p in polys:
@@ -158,8 +157,7 @@ class ShardedCommitter:
         k, L = len(slices), self.c.fq_limbs
         lo_r, hi_r = self.point_range()
         if self.slice_srs and self._slice is None and hi_r > lo_r:
-            from . import kzg
-            self._slice = kzg.UnivariateProverParam.from_affine(self.c, self.ck.powers_of_g(lo_r, hi_r - lo_r))
+            self._slice = self.ck.slice(lo_r, hi_r - lo_r)               # mzk_srs_slice: a device copy of this rank's range
             self._slice_lo = lo_r
         sl = [s.contiguous() if hasattr(s, "contiguous") else np.ascontiguousarray(s) for s in slices]
         assert all(int(s.shape[0]) <= hi_r - lo_r for s in sl)
