@@ -162,6 +162,73 @@ MZK_HD XYZZX<X> xyzzx_add(const XYZZX<X>& p, const XYZZX<X>& q) {
     return r;
 }
 
+#if defined(__HIPCC__)
+// ---- one addition on FOUR lanes ----------------------------------------------------------------------------------------------
+// A level of the bucket reduction is ONE addition deep: when it has fewer additions than the chip has lanes, its time is the latency
+// of the 14 dependent-ish products of xyzzx_add on a lone lane (~17 us with loads).  The products of an addition form four rounds of
+// at most four independent ones, so a QUAD of lanes (lane & 3 = role) takes one addition in four product-latencies: lane k holds
+// coordinate k (x, y, zz, zzz) of both operands and ends with coordinate k of the sum; operands move by DPP quad permutes (a VALU
+// move per limb, no LDS, no barrier).  All four lanes run the same instruction stream; a lane's product of a round may be unused.
+//   round 1   L0 U1 = x1 zz2     L1 S1 = y1 zzz2    L2 U2 = x2 zz1     L3 S2 = y2 zzz1      (own first operand x partner's second)
+//             d = partner's - own:  L0 P = U2 - U1,  L1 R = S2 - S1  (L2 -P, L3 -R)
+//   round 2   L0 PP = P^2        L1 RR = R^2        L2 zz1 zz2         L3 zzz1 zzz2
+//   round 3   L0 PPP = P PP      L1 Q = U1 PP       L2 ZZ3 = zz1 zz2 PP
+//             L1 X3 = RR - PPP - 2Q, Q - X3
+//   round 4   L0 S1 PPP          L1 R (Q - X3)      L3 ZZZ3 = zzz1 zzz2 PPP;   L1 Y3 = R (Q - X3) - S1 PPP
+// Same operations, pads and operand classes as xyzzx_add except Y3, which is a padded difference of two products (class N, < 4p,
+// as in xyzzx_dbl) instead of one fused product; tools/ecx_bounds.py (add_quad) walks it for both fields.  Exceptional operands
+// (an infinity, P = +-Q) are detected on the lanes that see them, OR-ed over the quad, and sent through xyzzx_add on all four lanes.
+template <int CTRL, class X>
+__device__ __forceinline__ Fx<X> fx_quad_perm(const Fx<X>& a) {
+    Fx<X> r;
+#pragma unroll
+    for (int i = 0; i < X::XN; i++) r.l[i] = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)a.l[i], CTRL, 0xF, 0xF, true);
+    return r;
+}
+template <class X>
+__device__ __forceinline__ Fx<X> fx_sel(bool c, const Fx<X>& a, const Fx<X>& b) {
+    Fx<X> r;
+#pragma unroll
+    for (int i = 0; i < X::XN; i++) r.l[i] = c ? a.l[i] : b.l[i];
+    return r;
+}
+constexpr int QP_SWAP2 = 0x4E, QP_SWAP1 = 0xB1, QP_L0 = 0x00, QP_L1 = 0x55, QP_L2 = 0xAA, QP_L3 = 0xFF;       // quad_perm controls
+
+// ca, cb: coordinate `role` of the accumulators a and b; returns coordinate `role` of a + b.  The four lanes of a quad must all be active.
+template <class X>
+__device__ __forceinline__ Fx<X> xyzzx_add_quad(const Fx<X>& ca, const Fx<X>& cb, int role) {
+    const bool r0 = role == 0, r1 = role == 1, hi = role >= 2;
+    uint32_t za = 0, zb = 0;
+#pragma unroll
+    for (int i = 0; i < X::XN; i++) { za |= ca.l[i]; zb |= cb.l[i]; }
+    int special = (role == 2 && (za == 0 || zb == 0)) ? 1 : 0;                 // an operand at infinity (zz == 0)
+    const Fx<X> p1 = fx_mul(ca, fx_quad_perm<QP_SWAP2>(cb));                    // U1 | S1 | U2 | S2
+    const Fx<X> d = fx_norm(fx_sub2(fx_quad_perm<QP_SWAP2>(p1), p1));           // P | R | -P | -R: N, < 4p
+    const Fx<X> p2 = fx_mul(fx_sel(hi, ca, d), fx_sel(hi, cb, d));              // PP | RR | zz1 zz2 | zzz1 zzz2
+    if (r0 && fx_is_zero_m(p2)) special = 1;                                    // U2 == U1: the same point or inverse points
+    special |= __builtin_amdgcn_update_dpp(0, special, QP_SWAP1, 0xF, 0xF, true);
+    special |= __builtin_amdgcn_update_dpp(0, special, QP_SWAP2, 0xF, 0xF, true);
+    if (special) {                                                              // (quad-uniform) every lane adds the whole points
+        XYZZX<X> a, b;
+        a.x = fx_quad_perm<QP_L0>(ca); a.y = fx_quad_perm<QP_L1>(ca); a.zz = fx_quad_perm<QP_L2>(ca); a.zzz = fx_quad_perm<QP_L3>(ca);
+        b.x = fx_quad_perm<QP_L0>(cb); b.y = fx_quad_perm<QP_L1>(cb); b.zz = fx_quad_perm<QP_L2>(cb); b.zzz = fx_quad_perm<QP_L3>(cb);
+        const XYZZX<X> r = xyzzx_add(a, b);
+        return fx_sel(hi, fx_sel(role == 2, r.zz, r.zzz), fx_sel(r0, r.x, r.y));
+    }
+    const Fx<X> pp = fx_quad_perm<QP_L0>(p2);
+    const Fx<X> u1 = fx_quad_perm<QP_L0>(p1);
+    const Fx<X> p3 = fx_mul(fx_sel(r0, d, fx_sel(r1, u1, p2)), pp);             // PPP | Q | ZZ3 | -
+    const Fx<X> ppp = fx_quad_perm<QP_L0>(p3);
+    const Fx<X> x3 = fx_norm(fx_sub_pad<X>(p2, fx_add(ppp, fx_add(p3, p3)), X::XSUB_PQ));        // L1: RR - PPP - 2Q
+    const Fx<X> qx = fx_norm(fx_sub_pad<X>(p3, x3, X::XSUB_XY));                // L1: Q - X3
+    const Fx<X> s1 = fx_quad_perm<QP_L1>(p1);
+    const Fx<X> p4 = fx_mul(fx_sel(r0, s1, fx_sel(r1, d, p2)), fx_sel(r1, qx, ppp));             // S1 PPP | R (Q - X3) | - | ZZZ3
+    const Fx<X> y3 = fx_norm(fx_sub2(p4, fx_quad_perm<QP_L0>(p4)));             // L1: N, < 4p
+    const Fx<X> x3_0 = fx_quad_perm<QP_L1>(x3);
+    return fx_sel(hi, fx_sel(role == 2, p3, p4), fx_sel(r0, x3_0, y3));
+}
+#endif
+
 template <class X>
 MZK_HD XYZZ<Fp<X>> xyzzx_to_boundary(const XYZZX<X>& p) {
     XYZZ<Fp<X>> r;

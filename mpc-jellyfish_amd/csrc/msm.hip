@@ -321,7 +321,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 while (log_split < max_split) {
                     const int nx = log_split + 1;
                     const bool small_grid = (wm << nx) <= (1ull << 18);
-                    if (small_grid ? (mean >> (nx + 1)) == 0 : ((1ull << nx) - 1) * 32 > mean) break;
+                    if (small_grid ? ((mean >> (nx + 1)) == 0 || (nx == 3 && (mean >> 5) == 0)) : ((1ull << nx) - 1) * 32 > mean) break;    // (8 threads per bucket only while their chains keep 4 adds: the 7 M extra additions outweigh shorter ones)
                     log_split = nx;
                 }
                 if (log_split == 0) {
@@ -385,14 +385,22 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
             // wide levels: one launch each over all bucket sets; narrow levels (<= 256 adds per set): one launch in all
             int first_tail = 1;
             while (first_tail <= log_m && (size_t)first_tail * (M >> first_tail) > 256) first_tail++;
+            // a level with few additions lasts as long as ONE of them: four lanes per addition there (msm.cuh, fold_one_quad)
+            static const size_t quad_max = std::getenv("MZK_MSM_QUAD_MAX") ? (size_t)std::atoll(std::getenv("MZK_MSM_QUAD_MAX")) : 65536;      // (A/B switch; 0 = off.  Measured: a level of 49 K additions 32 -> 23 us, of 82 K the same either way)
             for (int lvl = 1; lvl < first_tail; lvl++) {
                 const uint32_t h = M >> lvl;
                 const size_t threads = (size_t)nw_all * lvl * h;
-                hipLaunchKernelGGL((msm_fold_kernel<EC>), dim3((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
-                                   buckets, occ, M, h, lvl, nw_all);
+                if (threads <= quad_max)
+                    hipLaunchKernelGGL((msm_fold_quad_kernel<EC>), dim3((unsigned)((4 * threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
+                                       buckets, occ, M, h, lvl, nw_all);
+                else
+                    hipLaunchKernelGGL((msm_fold_kernel<EC>), dim3((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
+                                       buckets, occ, M, h, lvl, nw_all);
             }
-            if (first_tail <= log_m)
-                hipLaunchKernelGGL((msm_fold_tail_kernel<EC>), dim3(nw_all), dim3(256), 0, st, buckets, occ, M, log_m, first_tail);
+            if (first_tail <= log_m) {
+                if (quad_max) hipLaunchKernelGGL((msm_fold_tail_quad_kernel<EC>), dim3(nw_all), dim3(MSM_TAIL_QUAD_THREADS), 0, st, buckets, occ, M, log_m, first_tail);
+                else hipLaunchKernelGGL((msm_fold_tail_kernel<EC>), dim3(nw_all), dim3(256), 0, st, buckets, occ, M, log_m, first_tail);
+            }
             hipLaunchKernelGGL((msm_collect_kernel<EC>), dim3((n_out + 63) / 64), dim3(64), 0, st, buckets, occ, M, log_m, nw_all, collect);
         }
         HIP_TRY(hipGetLastError());

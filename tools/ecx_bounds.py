@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """tools/ecx_bounds.py -- worst-case bound propagation through the reduced-radix EC formulas of csrc/ecx.cuh (xyzzx_madd, xyzzx_add,
-xyzzx_dbl, xyzzx_dbl_affine) for a field on XN limbs of 29 bits: every intermediate value is tracked as (value / p, largest limb) and
+xyzzx_add_quad, xyzzx_dbl, xyzzx_dbl_affine) for a field on XN limbs of 29 bits: every intermediate value is tracked as (value / p, largest limb) and
 every contract of fx.cuh is asserted --
 
   * fx_mul / fx_sqr / fx_mul2: no 64-bit column overflow (XN * sum of limb products + XN * 2^58 < 2^64), result below 2^(29 XN) so that
@@ -117,6 +117,23 @@ class Field:
         y3 = self.mul2(rr_, d, s1, self.neg_m(ppp), "Y3")
         self.acc_ok(x3, self.norm(y3), self.mul(self.mul(zz1, zz2, "ZZ1 ZZ2"), pp, "ZZ3"), self.mul(self.mul(zzz1, zzz2, "ZZZ1 ZZZ2"), ppp, "ZZZ3"), "add")
 
+    def add_quad(self):                                           # xyzzx_add_quad: the same addition on four lanes; Y3 = T1 - T2 + 2p
+        x1, y1, zz1, zzz1 = self.accumulator()
+        x2, y2, zz2, zzz2 = self.accumulator()
+        u1, u2 = self.mul(x1, zz2, "U1"), self.mul(x2, zz1, "U2")
+        s1, s2 = self.mul(y1, zzz2, "S1"), self.mul(y2, zzz1, "S2")
+        pp_ = self.norm(self.sub_pad(u2, u1, 2, 0, "U2 - U1"))
+        rr_ = self.norm(self.sub_pad(s2, s1, 2, 0, "S2 - S1"))
+        pp, rr2 = self.mul(pp_, pp_, "PP"), self.mul(rr_, rr_, "RR")
+        self.zero_test(pp, "PP")
+        zz12, zzz12 = self.mul(zz1, zz2, "ZZ1 ZZ2"), self.mul(zzz1, zzz2, "ZZZ1 ZZZ2")
+        ppp, qv, zz3 = self.mul(pp_, pp, "PPP"), self.mul(u1, pp, "Q"), self.mul(zz12, pp, "ZZ3")
+        x3 = self.norm(self.sub_pad(rr2, self.add(ppp, self.add(qv, qv)), self.pad_pq, 2, "RR - PPP - 2Q"))
+        d = self.norm(self.sub_pad(qv, x3, self.pad_xy, 1, "Q - X3"))
+        t1, t2, zzz3 = self.mul(rr_, d, "R (Q - X3)"), self.mul(s1, ppp, "S1 PPP"), self.mul(zzz12, ppp, "ZZZ3")
+        y3 = self.norm(self.sub_pad(t1, t2, 2, 0, "Y3"))
+        self.acc_ok(x3, y3, zz3, zzz3, "add_quad")
+
     def dbl(self, affine):
         if affine:
             x, y, zz, zzz = V(1.0, M_LIMB), V(2.0, N_LIMB), None, None
@@ -135,7 +152,7 @@ class Field:
         self.acc_ok(x3, y3, zz3, zzz3, "dbl_affine" if affine else "dbl")
 
     def check(self):
-        self.madd(); self.add_(); self.dbl(False); self.dbl(True)
+        self.madd(); self.add_(); self.add_quad(); self.dbl(False); self.dbl(True)
         worst = max(self.log, key=lambda t: t[1])
         return "%-10s %2d limbs, head-room x%.0f, pads %d / %d / %d p, accumulator X, Y < %d p: ok (largest product value: %s = %.2f p of at most %.0f p)" % (
             self.name, self.xn, self.H, self.pad_xy, self.pad_pq, self.pad_2s, self.kxy, worst[0], worst[1], self.cap)
