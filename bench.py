@@ -171,6 +171,11 @@ def main():
             jac = mj.sharding.all_gather_sum(curve, jac, device=coll_dev)
         return jac
 
+    def launch_count():
+        v = C.c_uint64()
+        mlib.check(L.mzk_launch_count(C.byref(v)), "mzk_launch_count")
+        return int(v.value)
+
     def timed_steps():
         """W warm-ups, then exactly K steps between barrier + synchronize on both sides; max over ranks."""
         for _ in range(args.warmup):
@@ -180,6 +185,7 @@ def main():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize()
+        l0 = launch_count()
         t0 = time.perf_counter()
         for _ in range(args.steps):
             res = step()
@@ -188,6 +194,7 @@ def main():
             dist.barrier()
         el = time.perf_counter() - t0
         L.mzk_profile_enable(0)
+        launches = (launch_count() - l0) // max(args.steps, 1)
         if world > 1:
             tmax = torch.tensor([el], dtype=torch.float64, device=cdev)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
@@ -199,7 +206,8 @@ def main():
         comb_ms, _ = mlib.profile_get("msm_split_combine")
         phases = {"sort": round(sort_ms / max(tot_cnt, 1), 4), "accumulate": round(acc_ms / max(acc_cnt, 1), 4),
                   "split_combine": round(comb_ms / max(tot_cnt, 1), 4),
-                  "reduce": round(red_ms / max(tot_cnt, 1), 4), "device_total": round(tot_ms / max(tot_cnt, 1), 4)}
+                  "reduce": round(red_ms / max(tot_cnt, 1), 4), "device_total": round(tot_ms / max(tot_cnt, 1), 4),
+                  "kernel_launches": launches}
         return el, res, acc_ms / max(acc_cnt, 1), phases, mlib.msm_last_shape()
 
     elapsed, result, acc_avg_ms, phases, (c_bits, n_win, n_buckets) = timed_steps()
@@ -470,11 +478,13 @@ def main():
         for _ in range(2):
             native.prove(rng, cs, npk)
         torch.cuda.synchronize()
+        l0 = launch_count()
         ta = time.perf_counter()
         for _ in range(reps):
             native.prove(rng, cs, npk)
         torch.cuda.synchronize()
         abi_ms = (time.perf_counter() - ta) / reps * 1e3
+        abi_launches = (launch_count() - l0) // reps
         abi_core, abi_bytes = native.prove(mj.rng.test_rng(), cs, npk, profile=True)
         abi_same = bool(abi_bytes == mj.snark.prove(mj.rng.test_rng(), cs, prover)[1])
         npk.set_wire_variables(cs.wire_variables.cpu().numpy(), int(cs.witness.shape[0]))
@@ -539,6 +549,7 @@ def main():
                  "lagrange_key_s": round(lagrange_key_s, 3),
                  "round_level_abi_ms": round(abi_ms, 2), "round_level_abi_rounds_ms": abi_core.timings_ms, "round_level_abi_same_proof_bytes": abi_same,
                  "round_level_abi_from_host_witness_vector_ms": round(abi_vec_ms, 2),
+                 "kernel_launches_per_proof": abi_launches,
                  "round_level_abi_note": "the same proofs through mzk_prover_create / round1 .. round5 (include/mzk.h): the rounds of prover.rs:72-419 "
                                          "run inside the library, the caller (here ctypes + the Python transcript) keeps transcript, rng and Proof",
                  "hbm_bytes": hbm,

@@ -506,6 +506,9 @@ MZK_API int32_t mzk_plonk_pk_hbm_bytes(uint64_t pk_handle, uint64_t* out_bytes);
 MZK_API int32_t mzk_workspace_hbm_bytes(uint64_t* out_bytes);
 /* Frees that scratch (synchronises the device; it grows again on demand). */
 MZK_API int32_t mzk_workspace_release(void);
+/* Kernel launches the library has made in this process so far (all device contexts; copies and fills are not kernels): bench.py
+ * reports launches per proof and per MSM from differences of it.  out may not be null. */
+MZK_API int32_t mzk_launch_count(uint64_t* out_launches);
 /* Last MSM's shape: window bits, windows, buckets per window (for DESIGN.md's op counts). */
 MZK_API int32_t mzk_msm_last_shape(uint32_t* out_window_bits, uint32_t* out_windows, uint32_t* out_buckets);
 

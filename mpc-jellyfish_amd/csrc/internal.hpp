@@ -50,6 +50,15 @@ struct Workspace {
     size_t bytes();
 };
 
+// every kernel launch of the library is counted (mzk_launch_count)
+extern std::atomic<uint64_t> g_launches;
+#undef hipLaunchKernelGGL
+#define hipLaunchKernelGGL(kernelName, ...)                                  \
+    do {                                                                     \
+        ::mzk::g_launches.fetch_add(1, std::memory_order_relaxed);           \
+        hipLaunchKernelGGLInternal((kernelName), __VA_ARGS__);               \
+    } while (0)
+
 // HIP-event timing of named regions (mzk_profile_*): one switch for the library, records per device context
 extern std::atomic<bool> g_prof;                  // (switches shared by the device threads of one process: atomics)
 struct ProfRec { std::string name; hipEvent_t a, b; };

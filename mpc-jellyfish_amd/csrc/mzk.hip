@@ -60,6 +60,7 @@ int32_t ws_release(hipStream_t st) {
 }
 
 std::atomic<bool> g_prof{false};
+std::atomic<uint64_t> g_launches{0};
 ProfScope::ProfScope(const char* n, hipStream_t s) : st(s), name(n) {
     if (!g_prof) return;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) { a = b = nullptr; return; }
@@ -438,6 +439,11 @@ int32_t mzk_srs_hbm_bytes(uint64_t handle, uint64_t* out_points_bytes, uint64_t*
     const uint64_t aff_int = s.curve == MZK_CURVE_BLS12_381 ? 2 * 14 * 4 : 2 * 9 * 4;       // 29-bit limbs: ecx.cuh
     if (out_points_bytes) *out_points_bytes = s.n * (uint64_t)(2 * fq_words(s.curve) * 4) + (s.d_int ? s.n * aff_int : 0);
     if (out_table_bytes) *out_table_bytes = s.d_pre ? (uint64_t)s.pre_levels * s.n * aff_int : 0;
+    return MZK_OK;
+}
+int32_t mzk_launch_count(uint64_t* out_launches) {
+    if (!out_launches) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    *out_launches = g_launches.load(std::memory_order_relaxed);
     return MZK_OK;
 }
 // releases the grow-only scratch of the calling thread's device context (it is re-acquired on demand): a process that has run its
