@@ -131,10 +131,18 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     // In a batch of at most SORT_SETS (and MSM_HEAVY_JOBS) MSMs every MSM keeps its own sorted list until the end, so their heavy
     // kernels are deferred and run as ONE launch per level over all of them (msm.cuh, HeavyJobs): each MSM then needs its own
     // descriptors, counters and partial sums ("slot").
-    const bool defer_heavy = passes > 1 && (size_t)passes <= nb && passes <= MSM_HEAVY_JOBS;
-    const size_t slots = defer_heavy ? (size_t)passes : 1;
     const size_t desc_slot_bytes = (((size_t)sets * desc_cap_max * sizeof(LongDesc) + (size_t)sets * 4 * (1 + MSM_HEAVY_COUNTERS) + 16 + heavy_runs_bytes) + 255) & ~(size_t)255;
     const size_t parts_slot_words = (size_t)sets * desc_cap_max * EC::PT_WORDS + (size_t)sets * ((size_t)h1_cap_max + 2 * (size_t)run_cap_max) * EC::PT_WORDS;
+    bool defer_heavy = passes > 1 && (size_t)passes <= nb && passes <= MSM_HEAVY_JOBS;
+    // ... while the slots fit: the scratch is sized for the worst case (every entry in heavy buckets: ~3.5 x the sorted list per slot,
+    // 2.3 GB for five 2^20-pair MSMs) and scales with n.  A batch whose slots would need more than what is reserved already AND more than
+    // a quarter of the free HBM (batches of 2^24 pairs and up) runs its heavy kernels per MSM out of one slot instead.
+    if (defer_heavy && (size_t)passes * parts_slot_words * 4 > g_ws.long_parts.cap) {
+        size_t free_b = 0, total_b = 0;
+        HIP_TRY(hipMemGetInfo(&free_b, &total_b));
+        if ((size_t)passes * parts_slot_words * 4 > free_b / 4) defer_heavy = false;
+    }
+    const size_t slots = defer_heavy ? (size_t)passes : 1;
     MZK_TRY(g_ws.long_desc.reserve(slots * desc_slot_bytes));
     MZK_TRY(g_ws.long_parts.reserve(slots * parts_slot_words * 4));
     const unsigned long long dstride_max = (n_max + 7) & ~7ull;
@@ -292,10 +300,12 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 hipLaunchKernelGGL(pre_coarse_scatter_kernel, coarse_grid, dim3(PRE_CTHREADS), 0, sst, dig32, n, dstride, n_dig, (int)n_bins, pb, bstride, chunk,
                                    pre.c ? pre.tab_stride : 0ull, pre.c ? items[p].base_off : 0ull, multi, bin_cursor, coarse);
                 hipLaunchKernelGGL(pre_fine_kernel, dim3(n_bins), dim3(1024), 0, sst, bin_start, coarse, (uint32_t)wm, pb, hist, offs, sorted, huge);
-                hipLaunchKernelGGL(pre_huge_zero_kernel, dim3(huge_grid), dim3(1024), 0, sst, huge, (uint32_t)wm, pb, hist);
-                hipLaunchKernelGGL(pre_huge_count_kernel, dim3(slice_grid), dim3(1024), 0, sst, huge, bin_start, coarse, (uint32_t)wm, pb, slice, hist);
-                hipLaunchKernelGGL(pre_huge_scan_kernel, dim3(huge_grid), dim3(1024), 0, sst, huge, bin_start, (uint32_t)wm, pb, hist, offs, order);
-                hipLaunchKernelGGL(pre_huge_scatter_kernel, dim3(slice_grid), dim3(1024), 0, sst, huge, bin_start, coarse, (uint32_t)wm, pb, slice, order, sorted);
+                if (records > PRE_HUGE) {                                // (no bin of a sort with at most PRE_HUGE records can be huge: four launches less for small MSMs)
+                    hipLaunchKernelGGL(pre_huge_zero_kernel, dim3(huge_grid), dim3(1024), 0, sst, huge, (uint32_t)wm, pb, hist);
+                    hipLaunchKernelGGL(pre_huge_count_kernel, dim3(slice_grid), dim3(1024), 0, sst, huge, bin_start, coarse, (uint32_t)wm, pb, slice, hist);
+                    hipLaunchKernelGGL(pre_huge_scan_kernel, dim3(huge_grid), dim3(1024), 0, sst, huge, bin_start, (uint32_t)wm, pb, hist, offs, order);
+                    hipLaunchKernelGGL(pre_huge_scatter_kernel, dim3(slice_grid), dim3(1024), 0, sst, huge, bin_start, coarse, (uint32_t)wm, pb, slice, order, sorted);
+                }
             }
             {
                 // buckets ranked by load within each bucket set

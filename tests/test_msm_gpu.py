@@ -72,6 +72,56 @@ def test_msm_matches_c_oracle(gpu, mj, cref, curve_id, n):
     pp.release()
 
 
+@pytest.mark.parametrize("curve_id", [0, 1])
+@pytest.mark.parametrize("table", [1, 0])
+def test_bucket_reduction_exceptional_operands(gpu, mj, cref, curve_id, table):
+    """The levels of the bucket reduction add BUCKETS to each other (msm.cuh fold_one / fold_one_quad, four lanes per addition on the
+    narrow levels): with all bases equal and scalars 1 .. n every bucket holds the same point, so every addition of every level is a
+    doubling; with the upper half of the bases negated the first level cancels to infinity and the later ones add infinities.  Both must
+    take the exceptional path of xyzzx_add_quad and give the oracle's point."""
+    from mpc_jellyfish_amd import lib as mlib
+    c = mj.params.CURVES[curve_id]
+    n = 4096
+    g = cref.g1_arith_bases(curve_id, 5, 7, 1)[0]
+    neg = cref.g1_mul(curve_id, g, c.r - 1)
+    L = mlib.ensure_init()
+    L.mzk_msm_set_precompute(table)
+    try:
+        for kind in ("doublings", "cancel", "mixed"):
+            bases = np.repeat(g[None], n, axis=0)
+            scalars = _bigints(list(range(1, n + 1)))
+            if kind == "cancel":
+                bases[n // 2:] = neg
+            if kind == "mixed":                              # a few distinct multiples, signs by parity: equal, inverse and ordinary pairs side by side
+                rng = np.random.default_rng(11)
+                scalars = _bigints([int(v) for v in rng.integers(1, 64, size=n)])
+                bases[1::2] = neg
+            pp = mj.UnivariateProverParam.from_affine(curve_id, bases)
+            want = cref.jac_to_affine(curve_id, cref.msm(curve_id, bases, scalars, threads=8))[0]
+            got = cref.jac_to_affine(curve_id, mj.msm_bigint(pp, scalars))[0]
+            assert np.array_equal(got, want), kind
+            pp.release()
+    finally:
+        L.mzk_msm_set_precompute(1)
+
+
+def test_launch_count(gpu, mj, cref):
+    """mzk_launch_count: kernels launched so far; an MSM adds a few dozen, a null pointer is refused."""
+    import ctypes as C
+    from mpc_jellyfish_amd import lib as mlib
+    L = mlib.ensure_init()
+    pp = mj.UnivariateProverParam.gen_srs_for_testing(0, 77, 2047)
+    scalars = mj.params.random_fr_mont(mj.params.CURVES[0], 2048, seed=1)
+    mj.msm_bigint(pp, scalars, scalars_are_mont=True)                    # (builds the fixed-base table)
+    a, b = C.c_uint64(), C.c_uint64()
+    mlib.check(L.mzk_launch_count(C.byref(a)), "mzk_launch_count")
+    mj.msm_bigint(pp, scalars, scalars_are_mont=True)
+    mlib.check(L.mzk_launch_count(C.byref(b)), "mzk_launch_count")
+    assert 10 <= b.value - a.value <= 80
+    assert L.mzk_launch_count(None) == -1                                # MZK_ERR_INVALID_ARG
+    pp.release()
+
+
 def test_msm_skewed_and_degenerate_scalars(gpu, mj, cref):
     """All points in one bucket per window; all-zero scalars; a single non-zero scalar."""
     curve_id, n = 0, 5000
