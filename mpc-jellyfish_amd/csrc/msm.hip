@@ -59,7 +59,8 @@ struct PreInfo { int c = 0; uint64_t tab_stride = 0; };      // c == 0: plain pa
 // accumulation of MSM p (VALU-bound at two waves per SIMD, which leaves register file and LDS for it).  SORT_SETS sets of sort buffers (~220 MB each at 2^20).
 constexpr int SORT_SETS = 6;                                       // sorts run up to five MSMs ahead of the accumulation (3 sets left the sort of a dense MSM that follows two sparse ones exposed: round 1 of the bench circuit)
 struct SortStreams {                                               // one set per device context
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;                                  // (non-null once the set is initialised)
+    hipStream_t streams[4] = {};                                   // sorts go round these: the ~14 short launches of a sort are a latency chain, chains side by side cost one
     hipEvent_t ev_start = nullptr, ev_sorted[SORT_SETS] = {}, ev_acc[SORT_SETS] = {};
 };
 SortStreams g_sort[MAX_CTX];
@@ -67,7 +68,8 @@ int32_t sort_stream_init(SortStreams& ss) {
     if (ss.stream) return MZK_OK;
     int prio_least = 0, prio_greatest = 0;                               // the short sort kernels go first whenever a slot frees up
     HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    HIP_TRY(hipStreamCreateWithPriority(&ss.stream, hipStreamNonBlocking, std::getenv("MZK_MSM_SORT_PRIO_LOW") ? prio_least : prio_greatest));
+    for (auto& q : ss.streams) HIP_TRY(hipStreamCreateWithPriority(&q, hipStreamNonBlocking, std::getenv("MZK_MSM_SORT_PRIO_LOW") ? prio_least : prio_greatest));
+    ss.stream = ss.streams[0];
     HIP_TRY(hipEventCreateWithFlags(&ss.ev_start, hipEventDisableTiming));
     for (int i = 0; i < SORT_SETS; i++) {
         HIP_TRY(hipEventCreateWithFlags(&ss.ev_sorted[i], hipEventDisableTiming));
@@ -194,13 +196,12 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     std::memset(&jobs, 0, sizeof jobs);
     uint32_t heavy_run_cap_max = 0;
     bool heavy_level_c = false;
-    hipStream_t sst = st;                                                // the stream the sorts run on
+    static const int n_sort_streams = std::min(4, std::max(1, std::getenv("MZK_MSM_SORT_STREAMS") ? std::atoi(std::getenv("MZK_MSM_SORT_STREAMS")) : 2));       // (A/B switch)
     SortStreams& ss = g_sort[cur().logical];
     if (overlap) {
         MZK_TRY(sort_stream_init(ss));
-        sst = ss.stream;
         HIP_TRY(hipEventRecord(ss.ev_start, st));                        // scalars and workspace are ready on st
-        HIP_TRY(hipStreamWaitEvent(sst, ss.ev_start, 0));
+        for (int q = 0; q < n_sort_streams; q++) HIP_TRY(hipStreamWaitEvent(ss.streams[q], ss.ev_start, 0));
     }
 
     {
@@ -208,6 +209,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
         const unsigned n_ranges = M >> MSM_RANGE_LOG ? M >> MSM_RANGE_LOG : 1u;
         for (int p = 0; p < passes; p++) {
             const size_t b = overlap ? (size_t)p % nb : 0;               // this MSM's set of sort buffers
+            const hipStream_t sst = overlap ? ss.streams[p % n_sort_streams] : st;      // the stream this MSM's sort runs on
             uint32_t* hist = g_ws.hist.as<uint32_t>() + b * wm;
             uint32_t* offs = g_ws.offs.as<uint32_t>() + b * wm;
             uint32_t* order = g_ws.cursor.as<uint32_t>() + b * wm;
@@ -726,7 +728,7 @@ void jac_to_affine_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uin
 void msm_release_streams() {
     SortStreams& ss = g_sort[cur().logical];
     if (!ss.stream) return;
-    (void)hipStreamDestroy(ss.stream);
+    for (auto& q : ss.streams) (void)hipStreamDestroy(q);
     (void)hipEventDestroy(ss.ev_start);
     for (int i = 0; i < SORT_SETS; i++) { (void)hipEventDestroy(ss.ev_sorted[i]); (void)hipEventDestroy(ss.ev_acc[i]); }
     ss = SortStreams();
