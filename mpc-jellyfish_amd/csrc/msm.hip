@@ -154,7 +154,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     MZK_TRY(g_ws.sorted.reserve(nb * sorted_words * 4));
     // coarse bins of the table path: the low 2^top_bits buckets also receive the short top digit of every scalar, so they
     // are binned finer by the density ratio 1 + M / (2^top_bits (n_dig - 1)) (msm_pre.cuh PreBins)
-    PreBins pb{0, PRE_FINE_LOG, 0};
+    PreBins pb{0, PRE_FINE_LOG, 0, PRE_FINE_LOG};
     if (pre.c && n_dig > 1) {
         const int top_bits = (is_mont ? FR::BITS : 256) - c * (n_dig - 1);
         if (top_bits >= PRE_FINE_LOG && top_bits < c - 1) {
@@ -171,6 +171,25 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
         while ((2ull << lg) <= wm) lg++;
         const int L = std::max(5, lg - 8);
         if (L < PRE_FINE_LOG && (wm >> L) >= 2 && (wm >> L) <= 1024 && wm % (1ull << L) == 0) { pb.low = (uint32_t)wm; pb.low_log = (uint32_t)L; pb.low_bins = (uint32_t)(wm >> L); }
+    }
+    // Large MSMs: a fine workgroup re-reads its bin once per PRE_STAGE entries and a bin of more than PRE_HUGE entries goes to the
+    // pre_huge_* kernels (meant for skewed scalars) -- at 2^22 pairs EVERY bin of 2^11 buckets held 200 K entries and the sort took 1.5 ms
+    // where four times the 2^20 sort is 1.1.  Bins are halved while they would hold more than ~64 K entries and fit the 1024 the coarse level can count.
+    if (pre.c || sort2) {
+        const uint64_t rec_max = n_max * (uint64_t)n_dig * (fuse ? (uint64_t)count : 1);
+        while (rec_max / std::max<uint32_t>(1u, pb.count((uint32_t)wm)) > 65536) {
+            PreBins t = pb;
+            if (t.low) {
+                if (t.low_log <= 5) break;
+                t.low_log--; t.low_bins = t.low >> t.low_log;
+            }
+            if (t.low != (uint32_t)wm) {
+                if (t.hi_log <= 5) break;
+                t.hi_log--;
+            }
+            if (t.count((uint32_t)wm) > 1024) break;
+            pb = t;
+        }
     }
     const uint32_t n_bins = (pre.c || sort2) ? std::max<uint32_t>(1u, pb.count((uint32_t)wm)) : 0u;      // (table path, one MSM: wm == M)
     const size_t cnt_words = 2048 + (size_t)sets * 1024;                 // bin totals, bin cursors, order keys

@@ -29,14 +29,17 @@ constexpr uint32_t PRE_EMPTY = 0xFFFFFFFFu;
 // number of entries.  low == 0: uniform bins.
 struct PreBins {
     uint32_t low, low_log, low_bins;
-    __host__ __device__ uint32_t bin_of(uint32_t b) const { return b < low ? b >> low_log : low_bins + ((b - low) >> PRE_FINE_LOG); }
-    __host__ __device__ uint32_t first_bucket(uint32_t bin) const { return bin < low_bins ? bin << low_log : low + ((bin - low_bins) << PRE_FINE_LOG); }
+    uint32_t hi_log;                            // buckets per bin above `low`: 2^hi_log <= 2^PRE_FINE_LOG (what the kernels' LDS arrays hold); narrower for
+                                                // large MSMs (msm.hip: a fine workgroup re-reads its bin once per PRE_STAGE entries, and a bin of more than
+                                                // PRE_HUGE entries leaves the regular path altogether -- at 2^22 pairs every bin of 2^11 buckets did)
+    __host__ __device__ uint32_t bin_of(uint32_t b) const { return b < low ? b >> low_log : low_bins + ((b - low) >> hi_log); }
+    __host__ __device__ uint32_t first_bucket(uint32_t bin) const { return bin < low_bins ? bin << low_log : low + ((bin - low_bins) << hi_log); }
     __host__ __device__ uint32_t size_of(uint32_t bin, uint32_t M) const {
-        const uint32_t full = bin < low_bins ? 1u << low_log : 1u << PRE_FINE_LOG;
+        const uint32_t full = bin < low_bins ? 1u << low_log : 1u << hi_log;
         const uint32_t left = M - first_bucket(bin);
         return full < left ? full : left;
     }
-    __host__ __device__ uint32_t count(uint32_t M) const { return low_bins + ((M - low + (1u << PRE_FINE_LOG) - 1) >> PRE_FINE_LOG); }
+    __host__ __device__ uint32_t count(uint32_t M) const { return low_bins + ((M - low + (1u << hi_log) - 1) >> hi_log); }
 };
 
 // A FUSED batch of small table-path MSMs (msm.hip, msm_group_dev): the `count` MSMs are sorted, accumulated and reduced as ONE problem whose
