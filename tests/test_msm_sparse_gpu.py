@@ -87,6 +87,34 @@ def test_plain_path_two_level_sort_at_full_size(gpu, mj, cref):
     pp.release()
 
 
+def test_large_sorts_keep_to_the_regular_path_at_2p22(gpu, mj, cref):
+    """2^22 pairs: the fine bins of the two-level sort are halved until they hold about 64 K records (msm.hip; at 2^11 buckets per bin every
+    bin of a 2^22-pair sort was 'huge').  Table path and plain path (different bin layouts: two regions / uniform) against each other and
+    against the oracle's [p(beta)]G."""
+    import torch
+    c = mj.params.BLS12_381
+    n = 1 << 22
+    beta = 0x7e57ab1e5
+    pp = mj.UnivariateProverParam.gen_srs_for_testing(c, beta, n - 1)
+    x = mj.params.random_fr_mont(c, n, seed=22)
+    d = torch.from_numpy(x.view(np.int64)).cuda()
+    L = mj.load()
+    with_table = mj.jacobian_to_affine(c, mj.msm_bigint(pp, d, scalars_are_mont=True)[None])[0]
+    assert mj.lib.msm_last_shape()[0] == 20
+    L.mzk_msm_set_precompute(0)
+    try:
+        plain = mj.jacobian_to_affine(c, mj.msm_bigint(pp, d, scalars_are_mont=True)[None])[0]
+        assert mj.lib.msm_last_shape() == (16, 16, 1 << 15)
+    finally:
+        L.mzk_msm_set_precompute(1)
+    assert np.array_equal(plain, with_table)
+    acc = 0
+    for v in reversed(mj.params.fr_from_mont(c, x)):
+        acc = (acc * beta + int(v)) % c.r
+    assert np.array_equal(plain, cref.g1_mul_gen(0, acc))
+    pp.release()
+
+
 def test_srs_whose_table_does_not_fit_commits_on_the_plain_path(gpu, mj, cref):
     """MZK_MSM_TABLE_BUDGET (bytes): an SRS whose fixed-base table would exceed it gets none -- mzk_srs_precompute reports zeros -- and its
     commitments come from the variable-base path: the oracle's point all the same (include/mzk.h, mzk_srs_precompute)."""
