@@ -174,10 +174,11 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     }
     // Large MSMs: a fine workgroup re-reads its bin once per PRE_STAGE entries and a bin of more than PRE_HUGE entries goes to the
     // pre_huge_* kernels (meant for skewed scalars) -- at 2^22 pairs EVERY bin of 2^11 buckets held 200 K entries and the sort took 1.5 ms
-    // where four times the 2^20 sort is 1.1.  Bins are halved while they would hold more than ~64 K entries and fit the 1024 the coarse level can count.
+    // where four times the 2^20 sort is 1.1.  Bins are halved while they would hold more than ~32 K entries (about one staged run) and fit the 1024 the coarse level can count.
     if (pre.c || sort2) {
         const uint64_t rec_max = n_max * (uint64_t)n_dig * (fuse ? (uint64_t)count : 1);
-        while (rec_max / std::max<uint32_t>(1u, pb.count((uint32_t)wm)) > 65536) {
+        static const uint64_t per_bin = std::getenv("MZK_PRE_BIN_RECORDS") ? std::strtoull(std::getenv("MZK_PRE_BIN_RECORDS"), nullptr, 10) : 32768;     // (tuning switch; 65536: the 2^20 sort 0.27 instead of 0.245 ms)
+        while (rec_max / std::max<uint32_t>(1u, pb.count((uint32_t)wm)) > per_bin) {
             PreBins t = pb;
             if (t.low) {
                 if (t.low_log <= 5) break;
