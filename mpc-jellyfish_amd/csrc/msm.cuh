@@ -858,70 +858,128 @@ __global__ __launch_bounds__(MSM_THREADS) void fr_powers_kernel(const uint32_t* 
 // S_j = [beta^j]g = sum_i (w^i)^j [L_i(beta)]g (X^j interpolated on H), i.e. S is the forward transform of the Lagrange-basis points:
 //     [L_i(beta)]g = (1/n) sum_j w^(-ij) S_j.
 // Decimation in frequency (natural order in, bit-reversed out) on an XYZZ array: a stage with half-size h maps (a, b) = (A[i], A[i + h])
-// to (a + b, w_(2h)^(-k) (a - b)), k = i mod h -- a point addition, a subtraction and ONE 255-bit scalar multiplication (double and
-// add) per butterfly: (n / 2) log2 n of them, 1.2 s at n = 2^20 on BLS12-381 (tools/lagrange_key_time.py).  A one-off per SRS and
-// domain size.  ec_ntt_finish scales by 1/n, undoes the bit reversal and normalises.
-template <class FQ>
-__device__ __forceinline__ XYZZ<Fp<FQ>> ec_scalar_mul(const XYZZ<Fp<FQ>>& p, const uint32_t (&k)[8]) {
-    XYZZ<Fp<FQ>> acc = XYZZ<Fp<FQ>>::inf();
-    bool started = false;
+// to (a + b, w_(2h)^(-k) (a - b)), k = i mod h -- a point addition, a subtraction and ONE 255-bit scalar multiplication per butterfly:
+// (n / 2) log2 n of them.  A one-off per SRS and domain size.  The finishing pass scales by 1/n, undoes the bit reversal and normalises.
+// Rounds 1-3 ran it bitwise (255 doublings + ~128 additions) on the 32-bit-limb arithmetic: 1.18 s at n = 2^20 on BLS12-381; since round 4:
+// the reduced-radix arithmetic of the MSM (EcFx: 29-bit lazy limbs, ecx.cuh) with a signed 4-bit window per scalar multiplication --
+// 0.58 s (BN254: 0.23 s; tools/lagrange_key_time.py).  A butterfly's multiple of D = a - b is sum_w d_w 16^w D with digits d_w in [-7, 8]: 7 additions build
+// D .. 8D (in the thread's slice of a global scratch array: 8 x 224 bytes do not fit registers beside the accumulator), then 64 windows of
+// four doublings and at most one addition -- 252 doublings + ~60 additions + 7 against 255 + ~128 of the bitwise form, each on products
+// of 2 N'^2 single multiply-adds instead of 2 N^2 multiply-add / carry pairs.  The scaling by 1/n rides in the twiddles: an element is
+// multiplied the first time it lands in the upper half of a butterfly, which happens in the FIRST block of a stage (every later block
+// descends from an upper half already scaled), so that block's twiddles are w^(-k) / n (and its k = 0 element, which has none, gets
+// 1/n alone: log2 n scalar multiplications in all, plus element 0 at the end) instead of n more multiplications in a finishing pass.
+template <class X>
+__global__ __launch_bounds__(MSM_ACC_THREADS) void ecx_ntt_load_kernel(const uint32_t* __restrict__ xy, unsigned long long n, uint32_t* __restrict__ a) {
+    const unsigned long long i = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
+    if (i >= n) return;
+    using EC = EcFx<X>;
+    const Fp<X> x = load_fp<X>(xy + i * 2 * X::N), y = load_fp<X>(xy + i * 2 * X::N + X::N);
+    AffineX<X> p;
+    p.x = fx_from_boundary<X>(x);
+    p.y = fx_from_boundary<X>(y);
+    EC::store_pt(a, i, XYZZX<X>::from_affine(p));                // (0, 0) = infinity on both sides
+}
+template <class X>
+__device__ __forceinline__ XYZZX<X> xyzzx_neg(const XYZZX<X>& p) {            // -Y = K p - Y, K p the pad that covers an accumulator coordinate
+    XYZZX<X> r = p;
+    r.y = fx_norm(fx_sub_pad<X>(Fx<X>::zero(), p.y, X::XSUB_XY));
+    return r;
+}
+// k * d, k a canonical 256-bit integer; tab: this thread's 8 slots of the scratch table (slot s of thread t at tab + (s * stride + t) points)
+template <class X>
+__device__ __forceinline__ XYZZX<X> ecx_scalar_mul(const XYZZX<X>& d, const uint32_t (&k)[8], uint32_t* __restrict__ tab, unsigned long long t, unsigned long long stride) {
+    using EC = EcFx<X>;
+    if (d.is_inf()) return d;
+    XYZZX<X> m = d;
+    EC::store_pt(tab, t, m);                                                  // 1 D
 #pragma unroll 1
-    for (int bit = 255; bit >= 0; bit--) {
-        if (started) acc = xyzz_dbl(acc);
-        if ((k[bit >> 5] >> (bit & 31)) & 1u) {
-            acc = started ? xyzz_add(acc, p) : p;
-            started = true;
+    for (int s = 1; s < 8; s++) {
+        m = s == 1 ? xyzzx_dbl(m) : xyzzx_add(m, d);                          // 2 D, then + D each
+        EC::store_pt(tab, (unsigned long long)s * stride + t, m);
+    }
+    // signed base-16 digits d_w = nibble + carry, minus 16 when above 8: the carry runs upwards, so they are recoded low to high first --
+    // magnitudes 0..8 packed eight to a word, signs one bit each, a 65th digit for the last carry
+    uint32_t dig[9];
+    uint32_t sgn[2] = {0, 0};
+    uint32_t carry = 0;
+#pragma unroll
+    for (int w8 = 0; w8 < 8; w8++) {
+        uint32_t word = k[w8], out = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            uint32_t v = ((word >> (4 * q)) & 15u) + carry;
+            carry = v > 8u ? 1u : 0u;                                         // digits in [-7, 8]
+            const uint32_t mag = carry ? 16u - v : v;
+            out |= mag << (4 * q);
+            sgn[(w8 * 8 + q) >> 5] |= carry << ((w8 * 8 + q) & 31);
+        }
+        dig[w8] = out;
+    }
+    dig[8] = carry;
+    XYZZX<X> acc = XYZZX<X>::inf();
+#pragma unroll 1
+    for (int w = 64; w >= 0; w--) {
+        if (w < 64) {
+#pragma unroll 1
+            for (int q = 0; q < 4; q++) acc = xyzzx_dbl(acc);
+        }
+        const uint32_t mag = w == 64 ? dig[8] : (dig[w >> 3] >> (4 * (w & 7))) & 15u;
+        if (mag) {
+            XYZZX<X> e = EC::load_pt(tab, (unsigned long long)(mag - 1) * stride + t);
+            if (w < 64 && ((sgn[w >> 5] >> (w & 31)) & 1u)) e = xyzzx_neg(e);
+            acc = xyzzx_add(acc, e);
         }
     }
     return acc;
 }
-template <class FQ>
-__global__ __launch_bounds__(MSM_ACC_THREADS) void ec_ntt_load_kernel(const uint32_t* __restrict__ xy, unsigned long long n, uint32_t* __restrict__ a) {
-    const unsigned long long i = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
-    if (i >= n) return;
-    store_xyzz<FQ>(a, i, XYZZ<Fp<FQ>>::from_affine(load_affine<FQ>(xy, i)));
-}
-// winv_canon: w_n^-1 (canonical); h: half-size of this stage
-template <class FR, class FQ>
-__global__ __launch_bounds__(MSM_ACC_THREADS) void ec_ntt_stage_kernel(uint32_t* __restrict__ a, unsigned long long n, unsigned long long h,
-                                                                       const uint32_t* __restrict__ winv_canon) {
+template <class FR, class X>
+__global__ __launch_bounds__(MSM_ACC_THREADS) void ecx_ntt_stage_kernel(uint32_t* __restrict__ a, unsigned long long n, unsigned long long h,
+                                                                        const uint32_t* __restrict__ winv_canon, uint32_t* __restrict__ tab) {
+    using EC = EcFx<X>;
     const unsigned long long t = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
     if (t >= n / 2) return;
     const unsigned long long k = t % h, i = (t / h) * 2 * h + k, j = i + h;
-    const XYZZ<Fp<FQ>> p = load_xyzz<FQ>(a, i), q = load_xyzz<FQ>(a, j);
-    XYZZ<Fp<FQ>> qn = q;
-    qn.y = neg(q.y);
-    store_xyzz<FQ>(a, i, xyzz_add(p, q));
-    XYZZ<Fp<FQ>> d = xyzz_add(p, qn);
-    if (k) {                                                   // times w_(2h)^(-k) = (w_n^-1)^(k n / (2h))
-        Fp<FR> w;
+    const bool scale = t < h;                                  // first block: its upper half is scaled by 1/n here (winv_canon + 8)
+    const XYZZX<X> p = EC::load_pt(a, i), q = EC::load_pt(a, j);
+    EC::store_pt(a, i, xyzzx_add(p, q));
+    XYZZX<X> d = xyzzx_add(p, xyzzx_neg(q));
+    if (k || scale) {                                          // times w_(2h)^(-k) = (w_n^-1)^(k n / (2h)) [/ n]
+        Fp<FR> w, ni;
 #pragma unroll
-        for (int q8 = 0; q8 < 8; q8++) w.l[q8] = winv_canon[q8];
-        const Fp<FR> tw = from_mont(pow_u64(to_mont(w), k * (n / (2 * h))));
+        for (int q8 = 0; q8 < 8; q8++) { w.l[q8] = winv_canon[q8]; ni.l[q8] = winv_canon[8 + q8]; }
+        Fp<FR> twm = pow_u64(to_mont(w), k * (n / (2 * h)));
+        if (scale) twm = twm * to_mont(ni);
+        const Fp<FR> tw = from_mont(twm);
         uint32_t kk[8];
 #pragma unroll
         for (int q8 = 0; q8 < 8; q8++) kk[q8] = tw.l[q8];
-        d = ec_scalar_mul<FQ>(d, kk);
+        d = ecx_scalar_mul<X>(d, kk, tab, t, n / 2);
     }
-    store_xyzz<FQ>(a, j, d);
+    EC::store_pt(a, j, d);
 }
-// out[bitrev(i)] = affine(ninv * A[i])
-template <class FQ>
-__global__ __launch_bounds__(MSM_ACC_THREADS) void ec_ntt_finish_kernel(const uint32_t* __restrict__ a, unsigned long long n, int log_n,
-                                                                        const uint32_t* __restrict__ ninv_canon, uint32_t* __restrict__ out_xy) {
+// out[bitrev(i)] = affine(ninv * A[i]) in the boundary form
+template <class X>
+__global__ __launch_bounds__(MSM_ACC_THREADS) void ecx_ntt_finish_kernel(const uint32_t* __restrict__ a, unsigned long long n, int log_n,
+                                                                         const uint32_t* __restrict__ ninv_canon, uint32_t* __restrict__ tab,
+                                                                         uint32_t* __restrict__ out_xy) {
+    using EC = EcFx<X>;
     const unsigned long long i = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
     if (i >= n) return;
-    uint32_t kk[8];
+    XYZZX<X> p = EC::load_pt(a, i);
+    if (i == 0) {                                              // the one element that never was in an upper half
+        uint32_t kk[8];
 #pragma unroll
-    for (int q = 0; q < 8; q++) kk[q] = ninv_canon[q];
-    const XYZZ<Fp<FQ>> p = ec_scalar_mul<FQ>(load_xyzz<FQ>(a, i), kk);
+        for (int q = 0; q < 8; q++) kk[q] = ninv_canon[q];
+        p = ecx_scalar_mul<X>(p, kk, tab, 0, 1);
+    }
     unsigned long long r = 0;
     for (int b = 0; b < log_n; b++) r |= ((i >> b) & 1ull) << (log_n - 1 - b);
-    Affine<Fp<FQ>> q;
-    if (p.is_inf()) { q.x = Fp<FQ>::zero(); q.y = Fp<FQ>::zero(); }
-    else q = xyzz_to_affine(p);
-    store_fp<FQ>(out_xy + r * 2 * FQ::N, q.x);
-    store_fp<FQ>(out_xy + r * 2 * FQ::N + FQ::N, q.y);
+    Affine<Fp<X>> q;
+    if (p.is_inf()) { q.x = Fp<X>::zero(); q.y = Fp<X>::zero(); }
+    else q = xyzz_to_affine(xyzzx_to_boundary(p));
+    store_fp<X>(out_xy + r * 2 * X::N, q.x);
+    store_fp<X>(out_xy + r * 2 * X::N + X::N, q.y);
 }
 // out[j] = S_(n + j) - S_j = [beta^j (beta^n - 1)]g, j < n_extra
 template <class FQ>

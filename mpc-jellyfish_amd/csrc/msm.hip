@@ -642,15 +642,18 @@ int32_t srs_lagrange_generate(const uint32_t* beta_canon, const uint32_t* g_xy_m
 }
 
 // ... and from the points of an SRS alone (no trapdoor): the inverse group-NTT of its first 2^log_n points (msm.cuh), then S_(n+j) - S_j
-template <class FR, class FQ>
+template <class FR, class FQ, class X>
 int32_t srs_lagrange_from_points(const uint32_t* d_xy, int log_n, uint32_t n_extra, uint32_t* d_out) {
     using F = Fp<FR>;
+    using EC = EcFx<X>;
     hipStream_t st = nullptr;
     const uint64_t n = 1ull << log_n;
     MZK_TRY(ws_acquire(st));
-    MZK_TRY(g_ws.long_parts.reserve(n * 4 * FQ::N * 4));
+    // the array (n points) and the window tables of the scalar multiplications (8 points for each of the n / 2 threads of a stage)
+    MZK_TRY(g_ws.long_parts.reserve((n * 5 + 8) * EC::PT_WORDS * 4));
     MZK_TRY(g_ws.misc.reserve(64));
     uint32_t* a = g_ws.long_parts.as<uint32_t>();
+    uint32_t* tab = a + n * EC::PT_WORDS;
     uint32_t* d_c = g_ws.misc.as<uint32_t>();
     F w = F::from_const(FR::ROOT);
     for (int i = log_n; i < FR::TWO_ADICITY; i++) w = sqr(w);
@@ -658,10 +661,10 @@ int32_t srs_lagrange_from_points(const uint32_t* d_xy, int log_n, uint32_t n_ext
     HIP_TRY(hipMemcpyAsync(d_c, winv.l, 32, hipMemcpyHostToDevice, st));
     HIP_TRY(hipMemcpyAsync(d_c + 8, ninv.l, 32, hipMemcpyHostToDevice, st));
     const unsigned gn = (unsigned)((n + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS), gh = (unsigned)((n / 2 + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS);
-    hipLaunchKernelGGL((ec_ntt_load_kernel<FQ>), dim3(gn), dim3(MSM_ACC_THREADS), 0, st, d_xy, n, a);
+    hipLaunchKernelGGL((ecx_ntt_load_kernel<X>), dim3(gn), dim3(MSM_ACC_THREADS), 0, st, d_xy, n, a);
     for (uint64_t h = n / 2; h >= 1; h >>= 1)
-        hipLaunchKernelGGL((ec_ntt_stage_kernel<FR, FQ>), dim3(gh ? gh : 1), dim3(MSM_ACC_THREADS), 0, st, a, n, h, d_c);
-    hipLaunchKernelGGL((ec_ntt_finish_kernel<FQ>), dim3(gn), dim3(MSM_ACC_THREADS), 0, st, a, n, log_n, d_c + 8, d_out);
+        hipLaunchKernelGGL((ecx_ntt_stage_kernel<FR, X>), dim3(gh ? gh : 1), dim3(MSM_ACC_THREADS), 0, st, a, n, h, d_c, tab);
+    hipLaunchKernelGGL((ecx_ntt_finish_kernel<X>), dim3(gn), dim3(MSM_ACC_THREADS), 0, st, a, n, log_n, d_c + 8, tab, d_out);
     if (n_extra) hipLaunchKernelGGL((ec_ntt_extra_kernel<FQ>), dim3(1), dim3(64), 0, st, d_xy, n, n_extra, d_out + n * 2 * FQ::N);
     HIP_TRY(hipGetLastError());
     MZK_TRY(ws_release(st));
@@ -738,7 +741,7 @@ int32_t srs_lagrange_generate_dispatch(int curve, const uint32_t* beta_canon, co
                       : srs_lagrange_generate<BnFr, BnFq>(beta_canon, g_xy_mont, log_n, n_extra, d_out);
 }
 int32_t srs_lagrange_from_points_dispatch(int curve, const uint32_t* d_xy, int log_n, uint32_t n_extra, uint32_t* d_out) {
-    return curve == 0 ? srs_lagrange_from_points<BlsFr, BlsFq>(d_xy, log_n, n_extra, d_out) : srs_lagrange_from_points<BnFr, BnFq>(d_xy, log_n, n_extra, d_out);
+    return curve == 0 ? srs_lagrange_from_points<BlsFr, BlsFq, BlsFqX>(d_xy, log_n, n_extra, d_out) : srs_lagrange_from_points<BnFr, BnFq, BnFqX>(d_xy, log_n, n_extra, d_out);
 }
 void jac_to_affine_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uint64_t* xy) {
     if (curve == 0) jac_to_affine_host<BlsFq>(xyz, n, xy);
