@@ -297,6 +297,12 @@ MZK_API int32_t mzk_plonk_gather_witness_dev(const void* d_witness, uint64_t n_v
  * HOST (the call synchronises). */
 MZK_API int32_t mzk_poly_eval_dev(int32_t curve_id, const void* d_coeffs, uint64_t len, uint32_t batch, uint64_t batch_stride,
                                   const uint64_t* x_mont, uint64_t* out_mont, void* stream);
+/* Evaluations of several (batches of) polynomials at up to two points in ONE call and one synchronisation: job j evaluates batches[j]
+ * polynomials of lens[j] coefficients, strides[j] elements apart from d_coeffs[j], at x_mont[which_x[j]] (which_x[j] is 0 or 1; x_mont
+ * holds two elements, the second may repeat the first); out_mont receives the values job after job (sum of batches[] elements).  What
+ * round 4 of the prover needs (prover.rs:216-299: everything at zeta and at zeta * omega).  At most 64 jobs. */
+MZK_API int32_t mzk_poly_eval_many_dev(int32_t curve_id, uint32_t n_jobs, const void* const* d_coeffs, const uint64_t* lens, const uint32_t* batches,
+                                       const uint64_t* strides, const uint32_t* which_x, const uint64_t* x_mont, uint64_t* out_mont, void* stream);
 /* out[j] = sum_k scalars[k] * polys[k][j], j < out_len (a polynomial shorter than out_len counts as zero beyond its
  * length): `mul_poly` and the polynomial additions of prover.rs:302-358, 497-501, 1115-1122.  At most 32 terms;
  * d_out may be one of the inputs.  scalars_mont: n_terms x 4 limbs, host.  Asynchronous. */

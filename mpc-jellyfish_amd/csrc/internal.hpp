@@ -145,6 +145,8 @@ void jac_sum_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uint64_t*
 // poly.hip
 int32_t poly_eval_dispatch(int curve, const uint32_t* d_coeffs, uint64_t stride, uint64_t len, uint32_t batch, const uint32_t* x_mont, uint32_t* out_host,
                            hipStream_t st);
+struct EvalJob { const uint32_t* d; uint64_t len, stride; uint32_t batch, which_x; };
+int32_t poly_eval_many_dispatch(int curve, const EvalJob* jobs, uint32_t n_jobs, const uint32_t* x_mont /* 2 x 8 words */, uint32_t* out_host, hipStream_t st);
 int32_t poly_div_dispatch(int curve, const uint32_t* d_poly, uint64_t len, const uint32_t* z_mont, uint32_t* d_out, uint32_t* d_rem /* nullable: p(z) */, hipStream_t st);
 int32_t poly_div_roots_dispatch(int curve, const uint32_t* d_poly, uint64_t len, uint32_t log_order, uint64_t first, uint64_t count, uint32_t* d_out,
                                 hipStream_t st);

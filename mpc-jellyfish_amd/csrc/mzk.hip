@@ -875,6 +875,21 @@ int32_t mzk_poly_eval_dev(int32_t curve_id, const void* d_coeffs, uint64_t len, 
     return poly_eval_dispatch(curve_id, reinterpret_cast<const uint32_t*>(d_coeffs), batch_stride, len, batch, reinterpret_cast<const uint32_t*>(x_mont),
                               reinterpret_cast<uint32_t*>(out_mont), (hipStream_t)stream);
 }
+int32_t mzk_poly_eval_many_dev(int32_t curve_id, uint32_t n_jobs, const void* const* d_coeffs, const uint64_t* lens, const uint32_t* batches,
+                               const uint64_t* strides, const uint32_t* which_x, const uint64_t* x_mont, uint64_t* out_mont, void* stream) {
+    ENTER_CUR();
+    if (n_jobs == 0) return MZK_OK;
+    if (!d_coeffs || !lens || !batches || !strides || !which_x || !x_mont || !out_mont || n_jobs > 64) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
+    EvalJob jobs[64];
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        if ((!d_coeffs[j] && lens[j] && batches[j]) || (batches[j] > 1 && strides[j] < lens[j]) || batches[j] > 65535 || which_x[j] > 1) {
+            set_error("bad argument");
+            return MZK_ERR_INVALID_ARG;
+        }
+        jobs[j] = {reinterpret_cast<const uint32_t*>(d_coeffs[j]), lens[j], strides[j], batches[j], which_x[j]};
+    }
+    return poly_eval_many_dispatch(curve_id, jobs, n_jobs, reinterpret_cast<const uint32_t*>(x_mont), reinterpret_cast<uint32_t*>(out_mont), (hipStream_t)stream);
+}
 int32_t mzk_poly_lincomb_dev(int32_t curve_id, uint32_t n_terms, const void* const* d_polys, const uint64_t* lens, const uint64_t* scalars_mont,
                              void* d_out, uint64_t out_len, void* stream) {
     ENTER_CUR();

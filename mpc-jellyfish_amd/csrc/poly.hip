@@ -35,6 +35,49 @@ int32_t eval_run(const uint32_t* d_coeffs, uint64_t stride, uint64_t len, uint32
     return MZK_OK;
 }
 
+// several evaluation jobs at up to two points: the two power tables once, a partial launch per job, ONE final launch, ONE copy and wait
+template <class P>
+int32_t eval_many_run(const EvalJob* jobs, uint32_t n_jobs, const uint32_t* x_mont, uint32_t* out_host, hipStream_t st) {
+    using F = Fp<P>;
+    uint64_t max_len = 0, total = 0;
+    bool used[2] = {false, false};
+    for (uint32_t j = 0; j < n_jobs; j++) { max_len = std::max(max_len, jobs[j].len); total += jobs[j].batch; used[jobs[j].which_x & 1] = true; }
+    if (total == 0) return MZK_OK;
+    if (max_len == 0) { std::memset(out_host, 0, (size_t)total * 32); return MZK_OK; }
+    uint64_t T = POLY_EVAL_T;
+    while (T * 32 < max_len && T < (uint64_t)POLY_EVAL_T_MAX) T <<= 1;
+    const int blocks = (int)(T / POLY_THREADS);
+    F x[2], y[2];
+    for (int q = 0; q < 2; q++) { std::memcpy(x[q].l, x_mont + 8 * q, 32); y[q] = pow_u64(x[q], T); }
+    MZK_TRY(ws_acquire(st));
+    MZK_TRY(g_ws.poly_tmp.reserve(2 * (size_t)T * 32 + (size_t)total * blocks * 32 + (size_t)total * 32));
+    uint32_t* xpow = g_ws.poly_tmp.as<uint32_t>();
+    uint32_t* partial = xpow + 2 * (size_t)T * 8;
+    uint32_t* d_out = partial + (size_t)total * blocks * 8;
+    const uint64_t tlen = max_len < T ? max_len : T;
+    for (int q = 0; q < 2; q++)
+        if (used[q])
+            hipLaunchKernelGGL((fr_powers_mont_kernel<P>), dim3((unsigned)(((tlen + 15) / 16 + POLY_THREADS - 1) / POLY_THREADS)), dim3(POLY_THREADS), 0, st,
+                               to_fr_arg<P>(x[q]), tlen, xpow + (size_t)q * T * 8);
+    uint64_t at = 0;
+    for (uint32_t j = 0; j < n_jobs; j++) {
+        const EvalJob& jb = jobs[j];
+        if (jb.batch == 0) continue;
+        const int q = (int)(jb.which_x & 1);
+        if (jb.len == 0) HIP_TRY(hipMemsetAsync(partial + at * blocks * 8, 0, (size_t)jb.batch * blocks * 32, st));
+        else
+            hipLaunchKernelGGL((poly_eval_partial_kernel<P>), dim3(blocks, jb.batch), dim3(POLY_THREADS), 0, st, jb.d, jb.stride, jb.len, xpow + (size_t)q * T * 8,
+                               to_fr_arg<P>(y[q]), (unsigned long long)T, partial + at * blocks * 8);
+        at += jb.batch;
+    }
+    hipLaunchKernelGGL((poly_eval_final_kernel<P>), dim3((unsigned)total), dim3(POLY_THREADS), 0, st, partial, blocks, d_out);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(out_host, d_out, (size_t)total * 32, hipMemcpyDeviceToHost, st));
+    MZK_TRY(ws_release(st));
+    HIP_TRY(hipStreamSynchronize(st));
+    return MZK_OK;
+}
+
 template <class P>
 int32_t div_run(const uint32_t* d_poly, uint64_t len, const uint32_t* z_mont, uint32_t* d_out, uint32_t* d_rem, hipStream_t st) {
     using F = Fp<P>;
@@ -189,6 +232,12 @@ int32_t poly_eval_dispatch(int curve, const uint32_t* d_coeffs, uint64_t stride,
                            hipStream_t st) {
     if (curve == 0) return eval_run<BlsFr>(d_coeffs, stride, len, batch, x_mont, out_host, st);
     if (curve == 1) return eval_run<BnFr>(d_coeffs, stride, len, batch, x_mont, out_host, st);
+    set_error("unknown curve_id");
+    return MZK_ERR_INVALID_ARG;
+}
+int32_t poly_eval_many_dispatch(int curve, const EvalJob* jobs, uint32_t n_jobs, const uint32_t* x_mont, uint32_t* out_host, hipStream_t st) {
+    if (curve == 0) return eval_many_run<BlsFr>(jobs, n_jobs, x_mont, out_host, st);
+    if (curve == 1) return eval_many_run<BnFr>(jobs, n_jobs, x_mont, out_host, st);
     set_error("unknown curve_id");
     return MZK_ERR_INVALID_ARG;
 }

@@ -296,28 +296,44 @@ struct ProverT final : ProverBase {
     // evaluations of one round, collected and finished together.  Over several ranks every rank evaluates its coefficient range
     // [lo, hi) of each polynomial -- sum_{j in range} c_j x^j = x^lo * (the range read as a polynomial of its own) -- and ONE
     // all-gather of the partial values (32 bytes each) at the end of the round gives every rank all the sums.
-    struct EvalBatch {
+    struct EvalBatch {                                                 // (at most two distinct points per batch: zeta and zeta * omega)
         ProverT& P;
         std::vector<Fr> vals;
+        std::vector<Fr> scale;                                         // per value: x^lo of a ranged job (ranks > 1), one otherwise
+        std::vector<const void*> ptrs;
+        std::vector<uint64_t> lens, strides;
+        std::vector<uint32_t> batches, which;
+        Fr xs[2];
+        int n_x = 0;
         explicit EvalBatch(ProverT& p) : P(p) {}
+        uint32_t point(const Fr& x) {
+            for (int q = 0; q < n_x; q++) if (xs[q] == x) return (uint32_t)q;
+            if (n_x == 2) fail(MZK_ERR_INVALID_ARG, "EvalBatch: more than two points");
+            xs[n_x] = x;
+            return (uint32_t)n_x++;
+        }
         size_t add(const void* d, uint64_t len, uint32_t batch_n, uint64_t stride, const Fr& x) {
-            const size_t at = vals.size();
-            if (P.world == 1) {
-                for (auto& v : P.evaluate(d, len, batch_n, stride, x)) vals.push_back(v);
-                return at;
-            }
-            const uint64_t a = std::min(P.lo, len), b = std::min(P.hi, len);
-            if (b > a) {
-                const Fr xa = pow_u64(x, a);
-                for (auto& v : P.evaluate(static_cast<const uint8_t*>(d) + a * EL, b - a, batch_n, stride, x)) vals.push_back(v * xa);
-            } else {
-                for (uint32_t i = 0; i < batch_n; i++) vals.push_back(Fr::zero());
-            }
+            const size_t at = scale.size();
+            uint64_t a = 0, b = len;
+            if (P.world > 1) { a = std::min(P.lo, len); b = std::min(P.hi, len); }
+            const Fr xa = a ? pow_u64(x, a) : Fr::one();
+            ptrs.push_back(static_cast<const uint8_t*>(d) + a * EL);
+            lens.push_back(b > a ? b - a : 0);
+            strides.push_back(stride);
+            batches.push_back(batch_n);
+            which.push_back(point(x));
+            for (uint32_t i = 0; i < batch_n; i++) scale.push_back(xa);
             return at;
         }
-        void finish() {
+        void finish() {                                                // ONE library call and one wait for the whole round
+            vals.assign(scale.size(), Fr::zero());
+            if (n_x == 1) xs[1] = xs[0];
+            if (!scale.empty())
+                ck(mzk_poly_eval_many_dev(CURVE, (uint32_t)ptrs.size(), ptrs.data(), lens.data(), batches.data(), strides.data(), which.data(), xs[0].l,
+                                          reinterpret_cast<uint64_t*>(vals.data()), nullptr));
             if (P.world == 1) return;
             const size_t cnt = vals.size();
+            for (size_t i = 0; i < cnt; i++) vals[i] = vals[i] * scale[i];
             std::vector<Fr> all((size_t)P.world * cnt);
             if (P.comm.all_gather(P.comm.ctx, vals.data(), cnt * sizeof(Fr), all.data())) fail(MZK_ERR_INVALID_ARG, "mzk_comm.all_gather failed");
             for (size_t i = 0; i < cnt; i++) {

@@ -45,6 +45,32 @@ def evaluate(curve, polys_dev, x: int, length: int | None = None, offset: int = 
     return fr_from_mont(c, out)
 
 
+def evaluate_many(curve, jobs, xs) -> list[list[int]]:
+    """Several evaluation jobs at up to two points in ONE library call and one wait (mzk_poly_eval_many_dev: what round 4 needs,
+    prover.rs:216-299).  jobs: list of (polys_dev, length or None, which) with polys_dev as in `evaluate` and which = index into xs
+    (one or two points).  Returns the values per job as canonical ints."""
+    c = _curve(curve)
+    assert 1 <= len(xs) <= 2 and len(jobs) <= 64
+    xm = np.ascontiguousarray(fr_to_mont(c, [xs[0], xs[-1]]))
+    ptrs, lens, batches, strides, which = [], [], [], [], []
+    for t, length, w in jobs:
+        batch, stride = (1, t.shape[0]) if t.dim() == 2 else (t.shape[0], t.shape[1])
+        assert t.is_cuda and t.is_contiguous() and t.shape[-1] == 4 and 0 <= w < len(xs)
+        ptrs.append(t.data_ptr()); lens.append(stride if length is None else length); batches.append(batch); strides.append(stride); which.append(w)
+    a_ptr = np.array(ptrs, dtype=np.uint64); a_len = np.array(lens, dtype=np.uint64); a_b = np.array(batches, dtype=np.uint32)
+    a_s = np.array(strides, dtype=np.uint64); a_w = np.array(which, dtype=np.uint32)
+    out = np.empty((int(a_b.sum()), 4), dtype=np.uint64)
+    _lib.check(_lib.ensure_init().mzk_poly_eval_many_dev(c.curve_id, len(jobs), C.c_void_p(a_ptr.ctypes.data), C.c_void_p(a_len.ctypes.data),
+                                                         C.c_void_p(a_b.ctypes.data), C.c_void_p(a_s.ctypes.data), C.c_void_p(a_w.ctypes.data),
+                                                         C.c_void_p(xm.ctypes.data), C.c_void_p(out.ctypes.data), _stream(jobs[0][0], None)),
+               "mzk_poly_eval_many_dev")
+    vals = fr_from_mont(c, out)
+    res, at = [], 0
+    for b in batches:
+        res.append(vals[at:at + b]); at += b
+    return res
+
+
 def lincomb(curve, terms, out_len: int | None = None, out=None, stream=None):
     """terms: list of (scalar:int, poly:(len,4) CUDA tensor).  Returns sum_k scalar_k * poly_k as a
     (out_len, 4) CUDA tensor (default: the longest input)."""

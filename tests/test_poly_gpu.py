@@ -37,6 +37,28 @@ def test_evaluate_matches_oracle(gpu, mj, cref, curve_id, n):
 
 
 @pytest.mark.parametrize("curve_id", [0, 1])
+def test_evaluate_many_matches_single_calls(gpu, mj, curve_id):
+    """mzk_poly_eval_many_dev (a round's evaluations at zeta and zeta * omega in one call) against mzk_poly_eval_dev job by job: batches,
+    shorter logical lengths, an empty job, one point only."""
+    import ctypes as C
+    from mpc_jellyfish_amd import lib as mlib
+    c = mj.params.CURVES[curve_id]
+    rng = random.Random(5)
+    a = _dev(mj.params.random_fr_mont(c, 3 * 5000, seed=1).reshape(3, 5000, 4))
+    b = _dev(mj.params.random_fr_mont(c, 70001, seed=2))
+    d = _dev(mj.params.random_fr_mont(c, 2 * 300, seed=3).reshape(2, 300, 4))
+    x0, x1 = rng.randrange(c.r), rng.randrange(c.r)
+    jobs = [(a, None, 0), (b, None, 1), (d, 257, 1), (b, 0, 0), (a, 4097, 1), (d, None, 0)]
+    got = mj.poly.evaluate_many(c, jobs, [x0, x1])
+    for (t, length, w), g in zip(jobs, got):
+        assert g == mj.poly.evaluate(c, t, [x0, x1][w], length=length)
+    assert mj.poly.evaluate_many(c, [(b, None, 0)], [x1])[0] == mj.poly.evaluate(c, b, x1)
+    L = mlib.ensure_init()
+    assert L.mzk_poly_eval_many_dev(c.curve_id, 65, None, None, None, None, None, None, None, None) == -1
+    assert L.mzk_poly_eval_many_dev(c.curve_id, 0, None, None, None, None, None, None, None, None) == 0
+
+
+@pytest.mark.parametrize("curve_id", [0, 1])
 @pytest.mark.parametrize("n", [1, 2, 3, 2047, 2048, 2049, 70001, (1 << 20) + 3])
 def test_div_by_linear_matches_oracle(gpu, mj, cref, curve_id, n):
     c = mj.params.CURVES[curve_id]
