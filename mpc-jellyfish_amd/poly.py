@@ -47,16 +47,19 @@ def evaluate(curve, polys_dev, x: int, length: int | None = None, offset: int = 
 
 def evaluate_many(curve, jobs, xs) -> list[list[int]]:
     """Several evaluation jobs at up to two points in ONE library call and one wait (mzk_poly_eval_many_dev: what round 4 needs,
-    prover.rs:216-299).  jobs: list of (polys_dev, length or None, which) with polys_dev as in `evaluate` and which = index into xs
-    (one or two points).  Returns the values per job as canonical ints."""
+    prover.rs:216-299).  jobs: list of (polys_dev, length or None, which[, offset]) with polys_dev, length and offset as in `evaluate`
+    and which = index into xs (one or two points).  Returns the values per job as canonical ints."""
     c = _curve(curve)
     assert 1 <= len(xs) <= 2 and len(jobs) <= 64
     xm = np.ascontiguousarray(fr_to_mont(c, [xs[0], xs[-1]]))
     ptrs, lens, batches, strides, which = [], [], [], [], []
-    for t, length, w in jobs:
+    for job in jobs:
+        t, length, w = job[:3]
+        offset = job[3] if len(job) > 3 else 0
         batch, stride = (1, t.shape[0]) if t.dim() == 2 else (t.shape[0], t.shape[1])
-        assert t.is_cuda and t.is_contiguous() and t.shape[-1] == 4 and 0 <= w < len(xs)
-        ptrs.append(t.data_ptr()); lens.append(stride if length is None else length); batches.append(batch); strides.append(stride); which.append(w)
+        n = stride - offset if length is None else length
+        assert t.is_cuda and t.is_contiguous() and t.shape[-1] == 4 and 0 <= w < len(xs) and 0 <= offset and n >= 0 and offset + n <= stride
+        ptrs.append(t.data_ptr() + 32 * offset); lens.append(n); batches.append(batch); strides.append(stride); which.append(w)
     a_ptr = np.array(ptrs, dtype=np.uint64); a_len = np.array(lens, dtype=np.uint64); a_b = np.array(batches, dtype=np.uint32)
     a_s = np.array(strides, dtype=np.uint64); a_w = np.array(which, dtype=np.uint32)
     out = np.empty((int(a_b.sum()), 4), dtype=np.uint64)

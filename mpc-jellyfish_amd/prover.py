@@ -163,18 +163,33 @@ class ProofCore:
 
 
 class _Evals:
-    """Evaluations of device polynomials, collected and finished together.  Single process: evaluated at once."""
+    """Evaluations of device polynomials at up to two points, collected and finished together: ONE library call and one wait per round
+    (mzk_poly_eval_many_dev)."""
 
     def __init__(self, prover):
-        self.p, self.vals = prover, []
+        self.p, self.vals, self.jobs, self.count, self.xs = prover, [], [], 0, []
+
+    def _which(self, x: int) -> int:
+        if x not in self.xs:
+            assert len(self.xs) < 2, "two evaluation points per round"
+            self.xs.append(x)
+        return self.xs.index(x)
+
+    def _push(self, polys, length, x, offset=0):
+        batch = 1 if polys.dim() == 2 else polys.shape[0]
+        self.jobs.append((polys, length, self._which(x), offset))       # (keeps gathered copies alive until finish)
+        h = (self.count, batch)
+        self.count += batch
+        return h
 
     def add(self, polys, x: int, length: int | None = None):
-        v = poly.evaluate(self.p.curve, polys, x, length=length)
-        self.vals += v
-        return (len(self.vals) - len(v), len(v))
+        return self._push(polys, length, x)
+
+    def _run(self):
+        return [v for job in poly.evaluate_many(self.p.curve, self.jobs, self.xs) for v in job] if self.jobs else []
 
     def finish(self):
-        pass
+        self.vals = self._run()
 
     def get(self, h):
         return self.vals[h[0]:h[0] + h[1]]
@@ -188,21 +203,21 @@ class _RangeEvals(_Evals):
     def __init__(self, prover):
         super().__init__(prover)
         self.lo, self.hi = prover.committer.point_range()
+        self.scale = []
 
     def add(self, polys, x: int, length: int | None = None):
         r = self.p.curve.r
         stride = polys.shape[0] if polys.dim() == 2 else polys.shape[1]
-        batch = 1 if polys.dim() == 2 else polys.shape[0]
         L = stride if length is None else length
         a, b = min(self.lo, L), min(self.hi, L)
-        v = poly.evaluate(self.p.curve, polys, x, length=b - a, offset=a) if b > a else [0] * batch
-        xlo = pow(x, a, r)
-        self.vals += [t * xlo % r for t in v]
-        return (len(self.vals) - len(v), len(v))
+        h = self._push(polys, max(b - a, 0), x, a if b > a else 0)
+        self.scale += [pow(x, a, r)] * h[1]
+        return h
 
     def finish(self):
         r = self.p.curve.r
-        every = self.p.committer.all_gather_fr(self.vals)
+        mine = [v * s % r for v, s in zip(self._run(), self.scale)]
+        every = self.p.committer.all_gather_fr(mine)
         self.vals = [sum(col) % r for col in zip(*every)]
 
 
