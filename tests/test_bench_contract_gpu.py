@@ -26,6 +26,15 @@ def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
     cb = d["cpu_baseline"]
     assert set(("value", "unit", "cores", "kind", "sample")) <= set(cb) and cb["kind"] in ("port", "reference") and cb["matches_gpu"] is True
     assert cb["prove_2p11"]["matches_gpu"] is True and cb["prove_c1"]["matches_gpu"] is True
+    # the evidence as FLAT scalars where the driver's record keeps them -- the host's CPU, every CPU figure at one and at
+    # all threads, the proof-level figures (general case = dense witness) -- under cpu_baseline / roofline and at the top level
+    for key in ("cpu_model", "cpu_threads_host", "cpu_threads_used", "value_1_thread", "cpu_msm_2p20_1_thread_ms", "cpu_ntt_2p22_ms", "cpu_ntt_2p22_1_thread_ms",
+                "cpu_prove_c1_ms", "cpu_prove_2p11_ms", "gpu_prove_ms", "gpu_prove_dense_witness_ms", "gpu_ntt_2p22_ms"):
+        assert cb.get(key) not in (None, ""), key
+    assert cb["cores"] == cb["cpu_threads_used"] >= 1 and cb["cpu_ntt_2p22_matches_gpu_whole_vector"] is True and cb["cpu_prove_2p11_matches_gpu"] is True
+    for key in ("prove_ms", "prove_dense_witness_ms", "prove_coefficient_commit_ms", "ntt_2p22_ms", "kernel_launches_per_proof", "hbm_total_bytes"):
+        assert d[key] == d["roofline"][key] and d[key] > 0, key
+    assert not any(isinstance(v, (dict, list)) for k, v in cb.items() if k.startswith(("cpu_", "gpu_", "value")))
     assert big_keys(d), "precompute cost, variable-base leg, shim-only leg"
     assert d["prove_cpp_host"]["turbo_bls12_381"]["proof_bytes"] == d["prove"]["proof_bytes"]
     assert d["prove_cpp_host"]["ultra_bn254"]["proof_bytes"] == d["prove_ultra_bn254"]["proof_bytes"]
@@ -72,6 +81,8 @@ def test_bench_two_ranks_rehearsal_and_watchdog(gpu):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     sh = d["prove_sharded"]
     assert "error" not in sh and sh["turbo_bls12_381"]["ranks_agree_on_proof"] and sh["ultra_bn254"]["ranks_agree_on_proof"]
+    rp = d["prove_replicas"]                              # N independent provers, one per rank: proofs/s, the same proof bytes everywhere
+    assert "error" not in rp and rp["ranks_agree_on_proof"] is True and rp["proofs_per_s"] > 0 and d["prove_replicas_proofs_per_s"] == rp["proofs_per_s"]
     cm = d["prove_cpp_host_multi_gpu"]                    # the compiled host driving both (virtual) devices from one process
     assert cm["same_proof_bytes"] is True and cm["gpus_2"]["prove_ms"] > 0, cm
     out, lines = _two_ranks(["--secondary-timeout", "1", "--plonk-log-n", "16", "--ultra-sharded-log-n", "16"], 29633)

@@ -150,3 +150,134 @@ def test_ntt_random_ragged_sweep(gpu, mj, cref, curve_id):
         inverse = bool(case & 1)
         got = d.ifft(a) if inverse else d.fft(a)
         assert np.array_equal(got, cref.ntt(curve_id, padded, log_n, inverse, off_limbs, threads=4)), (case, log_n, in_len, offset, inverse)
+
+
+# ---- the kernel configurations C3 / C4 / C5 actually run: transforms of >= 2^21 points (nttx_pass_kernel<., true>) --------------------
+def _large_cases(mj, c, log_n):
+    """(offset, offset limbs, input length): plain, Fr::GENERATOR coset (the quotient domain's), ragged zero-padded input."""
+    n = 1 << log_n
+    g = mj.params.fr_to_mont(c, [c.fr_generator])[0]
+    return [(1, None, n), (c.fr_generator, g, n), (c.fr_generator, g, n // 8 + 3), (1, None, n // 2 + 1)]
+
+
+@pytest.mark.parametrize("curve_id", [0, 1])
+@pytest.mark.parametrize("log_n", [21, 22])
+def test_ntt_large_matches_c_oracle_full_vector(gpu, mj, cref, curve_id, log_n):
+    """Full-vector equality with the C restatement of ark-poly's radix-2 transform (oracle/ntt_impl.inc) on the stage-pair kernel the
+    >= 2^21-point transforms take (csrc/ntt.hip: r4) -- forward and inverse, plain and coset, ragged input.  The reference's own check
+    pattern for this call site is relation/src/constraint_system.rs:2028-2034 (iFFT of the evaluations against the polynomial)."""
+    import os
+    c = mj.params.CURVES[curve_id]
+    n = 1 << log_n
+    th = min(16, os.cpu_count() or 1)
+    a = mj.params.random_fr_mont(c, n, seed=300 + log_n)
+    for offset, off_limbs, in_len in _large_cases(mj, c, log_n):
+        d = _dom(mj, c, log_n, offset)
+        padded = np.zeros((n, 4), dtype=np.uint64)
+        padded[:in_len] = a[:in_len]
+        assert np.array_equal(d.fft(a[:in_len]), cref.ntt(curve_id, padded, log_n, False, off_limbs, threads=th)), (log_n, offset, in_len, "fwd")
+        assert np.array_equal(d.ifft(a[:in_len]), cref.ntt(curve_id, padded, log_n, True, off_limbs, threads=th)), (log_n, offset, in_len, "inv")
+
+
+_NTT_DIGEST_SCRIPT = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+import mpc_jellyfish_amd as mj
+from importlib import import_module
+import_module("mpc-jellyfish_amd.lib").init(0)
+for curve_id in (0, 1):
+    c = mj.params.CURVES[curve_id]
+    for log_n in (21, 22):
+        n = 1 << log_n
+        a = mj.params.random_fr_mont(c, n, seed=300 + log_n)
+        for offset, in_len in ((1, n), (c.fr_generator, n), (c.fr_generator, n // 8 + 3), (1, n // 2 + 1)):
+            d = mj.Radix2EvaluationDomain(curve_id, log_n)
+            d = d if offset == 1 else d.get_coset(offset)
+            for inv in (False, True):
+                out = d.ifft(a[:in_len]) if inv else d.fft(a[:in_len])
+                print(curve_id, log_n, offset == 1, in_len, inv, hashlib.sha256(np.ascontiguousarray(out).tobytes()).hexdigest())
+"""
+
+
+def test_ntt_two_kernels_one_answer(gpu, mj):
+    """The stage-pair kernel (default from 2^21 points) and the radix-2 form (MZK_NTT_NO_RADIX4=1, a child process: the switch is read
+    once per process) give the same bytes on every case of the full-vector test above -- which pins both to the oracle."""
+    import hashlib
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MZK_NTT_NO_RADIX4="1")
+    r = subprocess.run([sys.executable, "-c", _NTT_DIGEST_SCRIPT, root], env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    want = {}
+    for line in r.stdout.split("\n"):
+        f = line.split()
+        if len(f) == 6:
+            want[(int(f[0]), int(f[1]), f[2] == "True", int(f[3]), f[4] == "True")] = f[5]
+    assert len(want) == 2 * 2 * 4 * 2
+    for curve_id in (0, 1):
+        c = mj.params.CURVES[curve_id]
+        for log_n in (21, 22):
+            n = 1 << log_n
+            a = mj.params.random_fr_mont(c, n, seed=300 + log_n)
+            for offset, _, in_len in _large_cases(mj, c, log_n):
+                d = _dom(mj, c, log_n, offset)
+                for inv in (False, True):
+                    out = d.ifft(a[:in_len]) if inv else d.fft(a[:in_len])
+                    assert hashlib.sha256(np.ascontiguousarray(out).tobytes()).hexdigest() == want[(curve_id, log_n, offset == 1, in_len, inv)], \
+                        (curve_id, log_n, offset, in_len, inv)
+
+
+def test_ntt_2p25_bn254_matches_c_oracle_full_vector(gpu, mj, cref):
+    """C5's quotient domain (UltraPlonk / BN254, 2^22 gates -> 2^25 points; three stage-pair passes): the whole 2^25-point coset
+    transform and its inverse against the C oracle (1 GiB per vector; the oracle takes 10-40 s on the box's host threads)."""
+    import os
+    import torch
+    c = mj.params.BN254
+    log_n, n = 25, 1 << 25
+    th = min(16, os.cpu_count() or 1)
+    x = mj.params.random_fr_mont(c, n, seed=2500)
+    g = mj.params.fr_to_mont(c, [c.fr_generator])[0]
+    d = mj.Radix2EvaluationDomain(1, log_n).get_coset(c.fr_generator)
+    t = torch.from_numpy(x.view(np.int64)).cuda()
+    d.fft_in_place(t)
+    want = cref.ntt(1, x, log_n, False, g, threads=th)
+    assert np.array_equal(t.cpu().numpy().view(np.uint64), want)
+    del want
+    t.copy_(torch.from_numpy(x.view(np.int64)))
+    d.ifft_in_place(t)
+    want = cref.ntt(1, x, log_n, True, g, threads=th)
+    assert np.array_equal(t.cpu().numpy().view(np.uint64), want)
+
+
+@pytest.mark.parametrize("curve_id,log_n", [(1, 25), (0, 27)])
+def test_ntt_largest_sizes_seeded_spot_evaluations(gpu, mj, cref, curve_id, log_n):
+    """>= 60 seeded output indices of the forward coset transform against Horner's rule on the oracle
+    (n field products per index, run on the host's threads), then inverse(forward(x)) == x on the whole vector."""
+    import os
+    import random
+    from concurrent.futures import ThreadPoolExecutor
+    import torch
+    c = mj.params.CURVES[curve_id]
+    n = 1 << log_n
+    x = mj.params.random_fr_mont(c, n, seed=9000 + log_n)
+    g = mj.params.fr_to_mont(c, [c.fr_generator])[0]
+    d = mj.Radix2EvaluationDomain(curve_id, log_n).get_coset(c.fr_generator)
+    t = torch.from_numpy(x.view(np.int64)).cuda()
+    d.fft_in_place(t)
+    ev = t.cpu().numpy().view(np.uint64)
+    rng = random.Random(4242 + log_n)
+    idx = sorted({0, 1, n // 2, n - 1} | {rng.randrange(n) for _ in range(60)})
+    assert len(idx) >= 60
+
+    def one(i):
+        pt = cref.domain_element(curve_id, log_n, i, g)
+        return i, np.array_equal(ev[i], cref.poly_eval(curve_id, x, pt))
+
+    with ThreadPoolExecutor(max_workers=min(16, os.cpu_count() or 1)) as ex:       # ctypes releases the GIL: the Horner loops run in parallel
+        bad = [i for i, ok in ex.map(one, idx) if not ok]
+    assert not bad, bad
+    d.ifft_in_place(t)
+    assert np.array_equal(t.cpu().numpy().view(np.uint64), x)
