@@ -47,3 +47,32 @@ def write_circuit(path: str, curve, log_n: int, selector_values, sigma_values, k
         f.write(_limbs(c, wire_values))
         f.write(np.asarray(rows, dtype="<u8").tobytes())
         f.write(_limbs(c, pub_input))
+
+
+def read_circuit(src) -> dict:
+    """The inverse of write_circuit: a path or the file's bytes -> {"curve_id", "num_wire_types", "log_n", "k" (W,4), "selectors" (nsel,n,4),
+    "sigmas" (W,n,4), "tables" {name: (n,4)} | None, "wires" (W,n,4), "pub_rows" [..], "pub_values" (n_pub,4)}, uint64 Montgomery limbs."""
+    data = src if isinstance(src, (bytes, bytearray)) else open(src, "rb").read()
+    if data[:8] != MAGIC:
+        raise ValueError("not a MZKCIRC1 circuit file")
+    curve_id, W, log_n, n_pub = struct.unpack_from("<IIII", data, 8)
+    if W not in (5, 6):
+        raise ValueError("num_wire_types must be 5 or 6")
+    n, nsel, pos = 1 << log_n, 14 if W == 6 else 13, 24
+
+    def take(rows, cols):
+        nonlocal pos
+        cnt = rows * cols * 4
+        a = np.frombuffer(data, dtype="<u8", count=cnt, offset=pos).astype(np.uint64).reshape(rows, cols, 4)
+        pos += cnt * 8
+        return a
+
+    out = {"curve_id": curve_id, "num_wire_types": W, "log_n": log_n, "k": take(1, W)[0], "selectors": take(nsel, n), "sigmas": take(W, n)}
+    out["tables"] = dict(zip(TABLES, take(4, n))) if W == 6 else None
+    out["wires"] = take(W, n)
+    out["pub_rows"] = [int(x) for x in np.frombuffer(data, dtype="<u8", count=n_pub, offset=pos)]
+    pos += 8 * n_pub
+    out["pub_values"] = take(1, n_pub)[0] if n_pub else np.zeros((0, 4), dtype=np.uint64)
+    if pos != len(data):
+        raise ValueError("trailing or missing bytes in the circuit file")
+    return out

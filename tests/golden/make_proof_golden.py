@@ -69,6 +69,51 @@ def build(curve_id, plonk_type, num_gates, range_bits, rng=None, want_core=False
     return (rec, out) if want_core else rec
 
 
+# general circuits (oracle/pyref_circuit.py general_circuit / general_ultra_circuit): (curve, plonk type, log2 domain size, builder seed)
+GENERAL_CASES = [(0, "TurboPlonk", 4, 11), (1, "TurboPlonk", 5, 12), (1, "UltraPlonk", 4, 13), (0, "UltraPlonk", 5, 14)]
+
+
+def general_instance(curve_id, plonk_type, log_n, seed):
+    """The circuit of one general case: (selector values, sigma values, k, wire values, public-input vector, public input, tables | None)."""
+    import random
+    pc = P.CURVES[curve_id]
+    rnd = random.Random(seed)
+    tables = None
+    if plonk_type == "UltraPlonk":
+        sel, sigma, k, w, pi, tables = PC.general_ultra_circuit(pc, log_n, rnd)
+    else:
+        sel, sigma, k, w, pi = PC.general_circuit(pc, log_n, rnd)
+    pub = pi[:4]                                                          # the public input sits on rows 0 .. 3 (row 3 is non-zero)
+    assert pub[3] != 0 and not any(pi[4:])
+    return sel, sigma, k, w, pi, pub, tables
+
+
+def build_general(curve_id, plonk_type, log_n, seed):
+    """A whole proof of a GENERAL circuit -- a non-zero public input, addition / multiplication / x^5 gates, copy constraints over all
+    wires, key and range lookups (UltraPlonk) -- by the schoolbook prover, `test_rng` drawing the SRS trapdoor and then the blinders as in
+    `build`.  The same instance is rebuilt from (log_n, seed) by the GPU tests, which must emit these bytes from the Python mirror, the
+    round-level C ABI and `mzk_prove file`."""
+    pc = P.CURVES[curve_id]
+    ultra = plonk_type == "UltraPlonk"
+    W = 6 if ultra else 5
+    sel, sigma, k, w, pi, pub, tables = general_instance(curve_id, plonk_type, log_n, seed)
+    rng = RNG.test_rng()
+    srs_beta = RNG.fr_rand(pc, rng)
+    blind = RNG.draw_blinders(pc, rng, W, ultra)
+    g1 = lambda p: FS.g1_bytes(pc, p)
+    out = PS.prove(pc, log_n, sel, sigma, k, w, pi, pub, blind, srs_beta, FS.StandardTranscript(pc, b"PlonkProof"), g1, lambda x: FS.fr_bytes(pc, x),
+                   plookup=tables)
+    vk = out["vk"]
+    rec = {"curve": curve_id, "plonk_type": plonk_type, "log_n": log_n, "seed": seed, "domain_size": 1 << log_n, "srs_beta": "%x" % srs_beta,
+           "k": ["%x" % x for x in k], "public_input": ["%x" % x for x in pub],
+           "gates": {"addition": sum(1 for j in range(1 << log_n) if sel[0][j] and sel[10][j]), "multiplication": sum(1 for v in sel[4] if v),
+                     "x^5": sum(1 for v in sel[6] if v), "constant": sum(1 for v in sel[11] if v), "lookup": sum(1 for v in sel[13] if v) if ultra else 0},
+           "selector_comms": [g1(p).hex() for p in vk["selector_comms"]], "sigma_comms": [g1(p).hex() for p in vk["sigma_comms"]],
+           "plookup_comms": {name: g1(p).hex() for name, p in vk["plookup"].items()} if ultra else None,
+           "challenges": {name: "%x" % v for name, v in out["challenges"].items()}, "proof": out["proof"].hex()}
+    return rec
+
+
 BATCH_CASES = [(0, "TurboPlonk", (25, 28, 31), 8), (1, "UltraPlonk", (36, 40), 4)]
 
 
@@ -131,6 +176,10 @@ if __name__ == "__main__":
     with open(os.path.join(HERE, "link_vectors.json"), "w") as f:
         json.dump(links, f, indent=1)
     print("wrote", len(links), "link vectors")
+    general = [build_general(*case) for case in GENERAL_CASES]
+    with open(os.path.join(HERE, "general_proof_vectors.json"), "w") as f:
+        json.dump(general, f, indent=1)
+    print("wrote", len(general), "general-circuit proof vectors:", [(v["plonk_type"], v["domain_size"], v["gates"]) for v in general])
     batches = [build_batch(*case) for case in BATCH_CASES]
     with open(os.path.join(HERE, "batch_vectors.json"), "w") as f:
         json.dump(batches, f, indent=1)

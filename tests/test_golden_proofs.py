@@ -73,6 +73,36 @@ def test_golden_proof_vectors_over_the_reference_testing_setup(pyref, mj, index)
     assert not V.verify(pc, fresh(), vk, [], bytes(bad), g, int(vec["srs_beta"], 16))
 
 
+@pytest.mark.parametrize("index", [0, 1, 2, 3])
+def test_golden_general_circuit_proof_vectors(pyref, index):
+    """tests/golden/general_proof_vectors.json: whole proofs of GENERAL circuits (non-zero public input, addition / multiplication / x^5
+    gates, copy constraints, key + range lookups) by the schoolbook prover -- regenerated identically; the restated reference verifier
+    accepts them with their public input in the pairing form, and rejects a changed public input or proof byte."""
+    import pyref_verifier as V
+    vec = load_golden("general_proof_vectors")[index]
+    gen = _generator()
+    assert (vec["curve"], vec["plonk_type"], vec["log_n"], vec["seed"]) == gen.GENERAL_CASES[index]
+    assert gen.build_general(*gen.GENERAL_CASES[index]) == vec, "tests/golden/general_proof_vectors.json is stale: run tests/golden/make_proof_golden.py"
+    g = vec["gates"]
+    assert g["addition"] and g["multiplication"] and g["x^5"] and g["constant"] and (g["lookup"] > 0) == (vec["plonk_type"] == "UltraPlonk")
+    pc = pyref.CURVES[vec["curve"]]
+    pub = [int(x, 16) for x in vec["public_input"]]
+    assert any(pub)
+    vk = golden_vk(V, pc, vec)
+    vk["num_inputs"] = len(pub)
+    proof = bytes.fromhex(vec["proof"])
+    srs_beta = int(vec["srs_beta"], 16)
+    fresh = lambda: FS.StandardTranscript(pc, b"PlonkProof")
+    assert V.verify(pc, fresh(), vk, pub, proof, None, None, open_key=V.open_key_for_testing(pc, srs_beta))
+    ch = V.compute_challenges(fresh(), vk, pub, V.deserialize_proof(pc, proof))
+    assert {name: "%x" % ch[name] for name in vec["challenges"]} == vec["challenges"]
+    wrong = pub[:3] + [(pub[3] + 1) % pc.r]
+    assert not V.verify(pc, fresh(), vk, wrong, proof, pyref.g1_gen(pc), srs_beta)
+    bad = bytearray(proof)
+    bad[-40 if vec["plookup_comms"] is None else -2] ^= 1
+    assert not V.verify(pc, fresh(), vk, pub, bytes(bad), pyref.g1_gen(pc), srs_beta)
+
+
 @pytest.mark.parametrize("index", [0, 1])
 def test_golden_link_vectors(pyref, mj, index):
     """tests/golden/link_vectors.json: two proofs on one `test_rng` stream and their LinkingProof, all by the restatements --
@@ -134,7 +164,7 @@ def test_golden_batch_vectors(pyref, mj, index):
     assert not V.verify_batch_proof(pc, fresh(), vks[::-1], pubs, blob, G, srs_beta)
 
 
-@pytest.mark.parametrize("name", ["proof_vectors", "proof_vectors_refsetup"])
+@pytest.mark.parametrize("name", ["proof_vectors", "proof_vectors_refsetup", "general_proof_vectors"])
 def test_reference_proof_fixtures_when_present(name):
     """tests/golden/ref_proof_vectors.json = `PlonkKzgSnark::{preprocess, prove}` of the reference itself on the four golden cases
     (integration/rust/src/bin/gen_fixtures.rs); ref_proof_vectors_refsetup.json = the same over the reference's OWN
@@ -148,8 +178,89 @@ def test_reference_proof_fixtures_when_present(name):
     ours = load_golden(name)
     assert len(ref) == len(ours)
     for a, b in zip(ours, ref):
-        for f in ("curve", "plonk_type", "num_gates", "domain_size", "srs_beta") + (("srs_g",) if "srs_g" in a else ()):
+        for f in ("curve", "plonk_type", "domain_size", "srs_beta") + (("srs_g",) if "srs_g" in a else ()) + (("num_gates",) if "num_gates" in a else ("log_n", "seed", "public_input")):
             assert a[f] == b[f]
         assert [int(x, 16) for x in a["k"]] == [int(x, 16) for x in b["k"]]
         assert a["selector_comms"] == b["selector_comms"] and a["sigma_comms"] == b["sigma_comms"]
         assert a["proof"] == b["proof"], "proof bytes differ from the reference's"
+
+
+# ---- the reference-made families of integration/rust/src/bin/gen_fixtures.rs (round 5): batch, link, general circuits ----------------
+@pytest.mark.parametrize("name,fields", [("batch_vectors", ("batch_proof",)), ("link_vectors", ("proofs", "link_proof"))])
+def test_reference_batch_and_link_fixtures_when_present(name, fields):
+    """tests/golden/ref_batch_vectors.json / ref_link_vectors.json = `PlonkKzgSnark::batch_prove` / `prove_with_link_hint` + `link_proofs` of
+    the reference itself on the inputs of the committed vectors: the restatements' bytes must equal them."""
+    import json
+    path = os.path.join(HERE, "golden", "ref_%s.json" % name)
+    if not os.path.exists(path):
+        pytest.skip("reference fixtures absent (integration/rust has not been run): parity unpinned")
+    ref, ours = json.load(open(path)), load_golden(name)
+    assert len(ref) == len(ours)
+    for a, b in zip(ours, ref):
+        assert a["curve"] == b["curve"] and a["gates"] == b["gates"] and a["srs_beta"] == b["srs_beta"]
+        for f in fields:
+            assert a[f] == b[f], "%s differs from the reference's" % f
+
+
+def oracle_proof_of_circuit_file(pyref, mj, blob):
+    """The schoolbook prover (oracle/pyref_snark.py) on a circuit handed over in the circuit-file format: `test_rng` draws the SRS trapdoor,
+    then the blinders.  Returns (proof bytes, public input, srs_beta)."""
+    from importlib import import_module
+    import gc
+    from conftest import fr_from_mont_limbs
+    import pyref_snark as PS
+    io = import_module("mpc-jellyfish_amd.circuit_io")
+    cf = io.read_circuit(blob)
+    pc = pyref.CURVES[cf["curve_id"]]
+    ints = lambda a: fr_from_mont_limbs(pc, a)
+    n, W = 1 << cf["log_n"], cf["num_wire_types"]
+    ultra = W == 6
+    pub = ints(cf["pub_values"])
+    pi = [0] * n
+    for row, v in zip(cf["pub_rows"], pub):
+        pi[row] = v
+    tables = {name: ints(cf["tables"][name]) for name in io.TABLES} if ultra else None
+    rng = RNG.test_rng()
+    srs_beta = RNG.fr_rand(pc, rng)
+    blind = RNG.draw_blinders(pc, rng, W, ultra)
+    out = PS.prove(pc, cf["log_n"], [ints(s) for s in cf["selectors"]], [ints(s) for s in cf["sigmas"]], ints(cf["k"]), [ints(w) for w in cf["wires"]],
+                   pi, pub, blind, srs_beta, FS.StandardTranscript(pc, b"PlonkProof"), lambda p: FS.g1_bytes(pc, p), lambda x: FS.fr_bytes(pc, x), plookup=tables)
+    gc.collect()
+    return out["proof"], pub, srs_beta, out["vk"]
+
+
+@pytest.mark.parametrize("index", [0, 2])
+def test_oracle_proves_a_circuit_file(pyref, mj, tmp_path, index):
+    """The path the reference-made general circuits take (below), exercised on the committed general vectors: write the instance in the
+    circuit-file format, read it back, prove it with the schoolbook oracle -> the committed bytes."""
+    from importlib import import_module
+    io = import_module("mpc-jellyfish_amd.circuit_io")
+    vec = load_golden("general_proof_vectors")[index]
+    gen = _generator()
+    sel, sigma, k, w, pi, pub, tables = gen.general_instance(*gen.GENERAL_CASES[index])
+    path = str(tmp_path / "c.bin")
+    io.write_circuit(path, vec["curve"], vec["log_n"], sel, sigma, k, w, pub_input=pub, tables=tables)
+    proof, pub2, beta, _ = oracle_proof_of_circuit_file(pyref, mj, open(path, "rb").read())
+    assert proof.hex() == vec["proof"] and pub2 == pub and "%x" % beta == vec["srs_beta"]
+    with pytest.raises(ValueError):
+        io.read_circuit(open(path, "rb").read()[:-8])
+
+
+def test_reference_general_circuits_when_present(pyref, mj):
+    """tests/golden/ref_general_circuits.json: GENERAL circuits built through the reference's own gadgets (public inputs, add / mul / pow5 /
+    lc gates, shared variables, range + key lookups), exported as circuit files and proved by the reference (gen_fixtures.rs `general`).
+    The schoolbook oracle on the same file must emit the reference's proof and verifying-key bytes (domains up to 2^7: larger cases are
+    left to the GPU test, tests/test_golden_proofs_gpu.py)."""
+    import json
+    path = os.path.join(HERE, "golden", "ref_general_circuits.json")
+    if not os.path.exists(path):
+        pytest.skip("reference fixtures absent (integration/rust has not been run): parity unpinned")
+    for case in json.load(open(path)):
+        if case["domain_size"] > 128:
+            continue
+        pc = pyref.CURVES[case["curve"]]
+        proof, pub, beta, vk = oracle_proof_of_circuit_file(pyref, mj, bytes.fromhex(case["circuit_file"]))
+        assert "%x" % beta == case["srs_beta"] and ["%x" % x for x in pub] == case["public_input"]
+        assert [FS.g1_bytes(pc, p).hex() for p in vk["selector_comms"]] == case["selector_comms"]
+        assert [FS.g1_bytes(pc, p).hex() for p in vk["sigma_comms"]] == case["sigma_comms"]
+        assert proof.hex() == case["proof"], "proof bytes differ from the reference's"

@@ -153,3 +153,145 @@ def test_device_prover_over_the_reference_testing_setup(gpu, mj, index):
     assert proof_bytes.hex() == vec["proof"]
     pk.release()
     ck.release()
+
+
+# ---- general circuits: oracle-made bytes for a non-zero public input, every arithmetic gate family, copy constraints, lookups --------
+def _general_case(mj, pyref, vec):
+    """The instance of one general golden vector, rebuilt from (log_n, seed) by the oracle's builder, in the product's forms."""
+    import random
+    import numpy as np
+    import pyref_circuit as PC
+    from conftest import fr_mont_limbs
+    c, pc = mj.params.CURVES[vec["curve"]], pyref.CURVES[vec["curve"]]
+    ultra = vec["plonk_type"] == "UltraPlonk"
+    rnd = random.Random(vec["seed"])
+    tabs = None
+    if ultra:
+        sel, sig, k, w, pi, tabs = PC.general_ultra_circuit(pc, vec["log_n"], rnd)
+    else:
+        sel, sig, k, w, pi = PC.general_circuit(pc, vec["log_n"], rnd)
+    assert ["%x" % x for x in pi[:4]] == vec["public_input"] and ["%x" % x for x in k] == vec["k"]
+    dom = mj.Radix2EvaluationDomain(c, vec["log_n"])
+    kw = {"plookup": {name: dom.ifft(fr_mont_limbs(c, tabs[key])) for name, key in
+                      zip(mj.plonk.PLOOKUP_TABLE_POLYS, ("range", "key", "table_dom_sep", "q_dom_sep"))}} if ultra else {}
+    sel_p, sig_p = [dom.ifft(fr_mont_limbs(c, s)) for s in sel], [dom.ifft(fr_mont_limbs(c, s)) for s in sig]
+    return c, ultra, (sel, sig, k, w, pi, tabs), sel_p, sig_p, np.stack([fr_mont_limbs(c, col) for col in w]), kw
+
+
+@pytest.mark.parametrize("index", [0, 1, 2, 3])
+def test_general_circuit_golden_proofs_from_all_three_hosts(gpu, mj, pyref, tmp_path, index):
+    """tests/golden/general_proof_vectors.json (oracle/pyref_snark.py on oracle/pyref_circuit.py's general circuits: non-zero public
+    input, add / mul / x^5 gates, copy constraints over all wires, key + range lookups): the SAME bytes -- verifying key and proof --
+    from (i) the Python mirror (primitive-level sequencing), (ii) the round-level C ABI (mzk_prover_*, through ctypes) and (iii) the
+    compiled host reading the circuit from a file (`mzk_prove <curve> file`)."""
+    import json
+    import os
+    import subprocess
+    from importlib import import_module
+    from conftest import fr_mont_limbs
+    vec = load_golden("general_proof_vectors")[index]
+    c, ultra, raw, sel_p, sig_p, wires, kw = _general_case(mj, pyref, vec)
+    sel, sig, k, w, pi, tabs = raw
+    n, W = vec["domain_size"], 6 if ultra else 5
+    pub = pi[:4]
+    g1 = lambda x: mj.snark._g1(c, x).hex()
+
+    def rng_and_key():
+        rng = mj.rng.test_rng()
+        beta = mj.rng.fr_rand(c, rng)
+        assert "%x" % beta == vec["srs_beta"]
+        return rng, beta
+
+    rng, beta = rng_and_key()
+    ck = mj.UnivariateProverParam.gen_srs_for_testing(c, beta, n + 2)
+    # (i) the Python mirror
+    mirror = mj.prover.TurboPlonkProver(c, n, sel_p, sig_p, k, ck, **kw)
+    sel_c, sig_c = mirror.vk_commitments()
+    assert [g1(x) for x in sel_c] == vec["selector_comms"] and [g1(x) for x in sig_c] == vec["sigma_comms"]
+    if ultra:
+        names = ("range_table_comm", "key_table_comm", "table_dom_sep_comm", "q_dom_sep_comm")
+        assert dict(zip(names, [g1(x) for x in mirror.plookup_vk_commitments()])) == vec["plookup_comms"]
+    blind = mj.snark.draw_blinders(c, rng, W, ultra)
+    src = mj.prover.TranscriptChallenges(mirror, pub)
+    core = mirror.prove(wires, fr_mont_limbs(c, pi), src, blind)
+    assert mj.snark.serialize_proof(c, core).hex() == vec["proof"], "Python mirror"
+    assert {name: "%x" % v for name, v in src.challenges.items()} == vec["challenges"]
+    mirror.release()
+    # (ii) the round-level C ABI
+    N = import_module("mpc-jellyfish_amd.native")
+    native = N.NativeProver(c, n, sel_p, sig_p, k, ck, **kw)
+    sel_c, sig_c = native.vk_commitments()
+    assert [g1(x) for x in sel_c] == vec["selector_comms"] and [g1(x) for x in sig_c] == vec["sigma_comms"]
+    rng, _ = rng_and_key()
+    blind = mj.snark.draw_blinders(c, rng, W, ultra)
+    core = native.prove(wires, pub, mj.prover.TranscriptChallenges(native, pub), blind)
+    assert mj.snark.serialize_proof(c, core).hex() == vec["proof"], "round-level ABI"
+    native.release()
+    ck.release()
+    # (iii) the compiled host, circuit from a file
+    io = import_module("mpc-jellyfish_amd.circuit_io")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = str(tmp_path / "general.bin")
+    io.write_circuit(path, c, vec["log_n"], sel, sig, k, w, pub_input=pub, tables=tabs)
+    out = subprocess.run([os.path.join(root, "mpc-jellyfish_amd", "mzk_prove"), str(vec["curve"]), "file", path, "0"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert got["proof_hex"] == vec["proof"], "mzk_prove file"
+    assert got["vk_hex"] == "".join(vec["selector_comms"] + vec["sigma_comms"])
+
+
+def _check_circuit_file_case(mj, tmp_path, case, i):
+    """`mzk_prove <curve> file` and the round-level C ABI on case["circuit_file"] must emit case["proof"] (and the verifying key)."""
+    import json
+    import os
+    import subprocess
+    from importlib import import_module
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    io = import_module("mpc-jellyfish_amd.circuit_io")
+    N = import_module("mpc-jellyfish_amd.native")
+    blob = bytes.fromhex(case["circuit_file"])
+    f = str(tmp_path / ("ref_%d.bin" % i))
+    open(f, "wb").write(blob)
+    out = subprocess.run([os.path.join(root, "mpc-jellyfish_amd", "mzk_prove"), str(case["curve"]), "file", f, "0"], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stderr[-2000:]
+    got = json.loads(out.stdout.strip().splitlines()[-1])
+    assert got["proof_hex"] == case["proof"], "mzk_prove file"
+    assert got["vk_hex"] == "".join(case["selector_comms"] + case["sigma_comms"])
+    cf = io.read_circuit(blob)
+    c = mj.params.CURVES[cf["curve_id"]]
+    n, W = 1 << cf["log_n"], cf["num_wire_types"]
+    dom = mj.Radix2EvaluationDomain(c, cf["log_n"])
+    kw = {"plookup": {name: dom.ifft(cf["tables"][key]) for name, key in zip(mj.plonk.PLOOKUP_TABLE_POLYS, io.TABLES)}} if W == 6 else {}
+    rng = mj.rng.test_rng()
+    ck = mj.UnivariateProverParam.gen_srs_for_testing(c, mj.rng.fr_rand(c, rng), n + 2)
+    native = N.NativeProver(c, n, [dom.ifft(s) for s in cf["selectors"]], [dom.ifft(s) for s in cf["sigmas"]], mj.params.fr_from_mont(c, cf["k"]), ck, **kw)
+    pub = mj.params.fr_from_mont(c, cf["pub_values"])
+    blind = mj.snark.draw_blinders(c, rng, W, W == 6)
+    core = native.prove(cf["wires"], (cf["pub_rows"], pub), mj.prover.TranscriptChallenges(native, pub), blind)
+    assert mj.snark.serialize_proof(c, core).hex() == case["proof"], "round-level ABI"
+    native.release()
+    ck.release()
+
+
+def test_circuit_file_path_on_the_committed_general_vectors(gpu, mj, pyref, tmp_path):
+    """The path the reference-made general circuits take (next test), exercised on the committed oracle-made vectors."""
+    from importlib import import_module
+    io = import_module("mpc-jellyfish_amd.circuit_io")
+    for i, vec in enumerate(load_golden("general_proof_vectors")):
+        c, ultra, (sel, sig, k, w, pi, tabs), *_ = _general_case(mj, pyref, vec)
+        path = str(tmp_path / ("g%d.bin" % i))
+        io.write_circuit(path, c, vec["log_n"], sel, sig, k, w, pub_input=pi[:4], tables=tabs)
+        _check_circuit_file_case(mj, tmp_path, dict(vec, circuit_file=open(path, "rb").read().hex()), i)
+
+
+def test_reference_general_circuits_on_the_device_when_present(gpu, mj, tmp_path):
+    """tests/golden/ref_general_circuits.json (gen_fixtures.rs `general`: circuits built and proved by the REFERENCE, handed over as circuit
+    files): `mzk_prove <curve> file` and the round-level C ABI on the same file must emit the reference's proof bytes."""
+    import json
+    import os
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    path = os.path.join(root, "tests", "golden", "ref_general_circuits.json")
+    if not os.path.exists(path):
+        pytest.skip("reference fixtures absent (integration/rust has not been run): parity unpinned")
+    for i, case in enumerate(json.load(open(path))):
+        _check_circuit_file_case(mj, tmp_path, case, i)

@@ -90,6 +90,42 @@ CHECKS = [
     ("relation/src/constraint_system.rs", r"pub\(crate\) wire_variables: \[Vec<Variable>; GATE_WIDTH \+ 2\],", "witness_and_wire_variables"),
     ("relation/src/constraint_system.rs", r"pub\(crate\) witness: Vec<F>,", "witness_and_wire_variables"),
     ("plonk/src/proof_system/prover.rs", r"DensePolynomial::rand\(hiding_bound, prng\)\.mul_by_vanishing_poly\(self\.domain\)", "DensePolynomial::rand(hiding_bound, prng)"),
+    # gen_fixtures round 5: batch_prove, prove_with_link_hint, link_proofs, the general circuit through the reference's gadgets and its export
+    ("plonk/src/proof_system/mod.rs", r"pub mod structs;", "proof_system::{structs::ProvingKey"),
+    ("plonk/src/proof_system/structs.rs", r"pub struct ProvingKey<E: Pairing> \{[^}]*pub commit_key: CommitKey<E>,", "&pk1.commit_key"),
+    ("plonk/src/proof_system/structs.rs", r"pub struct Proof<E: Pairing>", "mpc_plonk::proof_system::structs::Proof<E>"),
+    ("plonk/src/proof_system/snark.rs", r"pub fn batch_prove<C, R, T>\(\s*prng: &mut R,\s*circuits: &\[&C\],\s*prove_keys: &\[&ProvingKey<E>\],\s*\) -> Result<BatchProof<E>, PlonkError>",
+     "batch_prove::<_, _, StandardTranscript>(rng, &cs_refs, &pk_refs)"),
+    ("plonk/src/proof_system/snark.rs", r"pub fn prove_with_link_hint<C, R, T>\(\s*prng: &mut R,\s*circuit: &C,\s*prove_key: &ProvingKey<E>,\s*\) -> Result<\(Proof<E>, LinkingHint<E>\), PlonkError>",
+     "prove_with_link_hint::<_, _, StandardTranscript>(rng, &cs1, &pk1)"),
+    ("plonk/src/proof_system/proof_linking.rs", r"pub fn link_proofs<T: PlonkTranscript<F>>\(\s*lhs_link_hint: &LinkingHint<E>,\s*rhs_link_hint: &LinkingHint<E>,\s*group_layout: &GroupLayout,\s*commit_key: &CommitKey<E>,",
+     "link_proofs::<StandardTranscript>(&hint1, &hint2, &layout, &pk1.commit_key)"),
+    ("plonk/src/proof_system/proof_linking.rs", r"CanonicalSerialize, CanonicalDeserialize\)\]\s*pub struct LinkingProof<E: Pairing> \{[^}]*pub quotient_commitment: Commitment<E>,[^}]*pub opening_proof: UnivariateKzgProof<E>,",
+     "quotient_commitment || opening_proof"),
+    ("relation/src/lib.rs", r"pub mod proof_linking;", "proof_linking::GroupLayout"),
+    ("relation/src/proof_linking/mod.rs", r"pub fn new\(alignment: usize, offset: usize, size: usize\) -> Self", "GroupLayout::new(lay[0], lay[1], lay[2])"),
+    ("relation/src/constraint_system.rs", r"pub type Variable = usize;", "Variable"),
+    ("relation/src/traits.rs", r"fn create_public_variable\(&mut self, val: Self::Wire\) -> Result<Variable, CircuitError>", "cs.create_public_variable(Fr::from(seed))"),
+    ("relation/src/traits.rs", r"fn create_variable\(&mut self, val: Self::Wire\) -> Result<Variable, CircuitError>;", "cs.create_variable("),
+    ("relation/src/traits.rs", r"fn mul\(&mut self, a: Variable, b: Variable\) -> Result<Variable, CircuitError>", "cs.mul(s, x)"),
+    ("relation/src/traits.rs", r"fn pow5\(&mut self, x: Variable\) -> Result<Variable, CircuitError>;", "cs.pow5(m)"),
+    ("relation/src/traits.rs", r"fn lc\(\s*&mut self,\s*wires_in: &\[Variable; GATE_WIDTH\],\s*coeffs: &\[F; GATE_WIDTH\],\s*\) -> Result<Variable, CircuitError>", "cs.lc(&[s, m, p, y], &coeffs)"),
+    ("relation/src/traits.rs", r"fn add_constant\(&mut self, x: Variable, c: &F\) -> Result<Variable, CircuitError>", "cs.add_constant(t, &Fr::from("),
+    ("relation/src/gadgets/range.rs", r"pub fn enforce_in_range\(&mut self, a: Variable, bit_len: usize\) -> Result<\(\), CircuitError>", "cs.enforce_in_range(*v, range_bits)"),
+    ("relation/src/gadgets/ultraplonk/lookup_table.rs", r"pub fn create_table_and_lookup_variables\(\s*&mut self,\s*lookup_vars: &\[\(Variable, Variable, Variable\)\],\s*table_vars: &\[\(Variable, Variable\)\],",
+     "cs.create_table_and_lookup_variables(&lookups, &table)"),
+    ("relation/src/traits.rs", r"fn check_circuit_satisfiability\(&self, pub_input: &\[Self::Wire\]\) -> Result<\(\), CircuitError>;", "cs.check_circuit_satisfiability(&pub_input)"),
+    ("relation/src/traits.rs", r"fn num_wire_types\(&self\) -> usize;", "cs.num_wire_types()"),
+    ("relation/src/traits.rs", r"fn num_gates\(&self\) -> usize;", "cs.num_gates()"),
+    ("relation/src/traits.rs", r"fn compute_selector_polynomials\(&self\) -> Result<Vec<DensePolynomial<F>>, CircuitError>;", "cs.compute_selector_polynomials()"),
+    ("relation/src/traits.rs", r"fn compute_extended_permutation_polynomials\(\s*&self,\s*\) -> Result<Vec<DensePolynomial<F>>, CircuitError>;", "cs.compute_extended_permutation_polynomials()"),
+    ("relation/src/traits.rs", r"fn compute_wire_polynomials\(&self\) -> Result<Vec<DensePolynomial<F>>, CircuitError>;", "cs.compute_wire_polynomials()"),
+    ("relation/src/traits.rs", r"fn compute_range_table_polynomial\(&self\) -> Result<DensePolynomial<F>, CircuitError>", "cs.compute_range_table_polynomial()"),
+    ("relation/src/traits.rs", r"fn compute_key_table_polynomial\(&self\) -> Result<DensePolynomial<F>, CircuitError>", "cs.compute_key_table_polynomial()"),
+    ("relation/src/traits.rs", r"fn compute_table_dom_sep_polynomial\(&self\) -> Result<DensePolynomial<F>, CircuitError>", "cs.compute_table_dom_sep_polynomial()"),
+    ("relation/src/traits.rs", r"fn compute_q_dom_sep_polynomial\(&self\) -> Result<DensePolynomial<F>, CircuitError>", "cs.compute_q_dom_sep_polynomial()"),
+    # the order the circuit file relies on: q_lc, q_mul, q_hash, q_o, q_c, q_ecc, [q_lookup]; range, key, table_dom_sep, q_dom_sep
+    ("relation/src/constraint_system.rs", r"// q_lc, q_mul, q_hash, q_o, q_c, q_ecc, \[q_lookup \(if support lookup\)\]", "compute_selector_polynomials"),
     # the call sites lib.rs documents
     ("primitives/src/pcs/univariate_kzg/mod.rs", r"msm_bigint\(", "msm_bigint"),
     ("plonk/src/proof_system/prover.rs", r"fft_in_place|\.coset_fft|\.fft\(", "fft_in_place"),
