@@ -103,8 +103,8 @@ MZK_API int32_t mzk_srs_generate_lagrange_for_testing(int32_t curve_id, const ui
                                                       uint32_t n_extra, uint64_t* out_handle);
 /* The same key from the points of a registered SRS alone (no trapdoor): [L_i(beta)]g = (1/n) sum_j w^(-ij) [beta^j]g, the inverse NTT over the
  * group of its first 2^log_n points, then [beta^(n+j)]g - [beta^j]g for the n_extra tail (the SRS must hold 2^log_n + n_extra points).
- * (n / 2) log2 n scalar multiplications: 0.14 s at 2^16, 1.2 s at 2^20 (BLS12-381; BN254 half that) -- once per SRS and domain size.
- * Synchronises. */
+ * (n / 2) log2 n scalar multiplications: 0.51 s at 2^20 on BLS12-381, 0.22 s on BN254 -- once per SRS and domain size.  Set-up peak:
+ * (5n + 8) internal points of scratch (1.17 GB at 2^20 on BLS12-381), handed back before the call returns.  Synchronises. */
 MZK_API int32_t mzk_srs_lagrange_from_srs(uint64_t srs_handle, uint32_t log_n, uint32_t n_extra, uint64_t* out_handle);
 /* A new SRS handle holding the points [first, first + n_points) of a registered one (a device copy; `trim` generalised, srs.rs:77-93): a rank
  * of a multi-GPU prover keeps the range it commits over -- 1 / G of the points and of the fixed-base table, built with the window that suits
@@ -377,7 +377,10 @@ MZK_API int32_t mzk_poly_div_roots_dev(int32_t curve_id, const void* d_poly, uin
  * concatenated in rank order, into recv (world x bytes).  exchange_classes (nullable): make the class remainders of all ranks
  * resident in d_rem (n_classes x class_bytes, device; this rank has filled [first_own, first_own + n_own)); NULL = the prover pushes
  * its own classes into the peers' buffers itself (mzk_prover_set_peer_buffers, hipMemcpyPeerAsync over xGMI) and calls barrier.
- * Callbacks return 0 on success. */
+ * Callbacks return 0 on success.  FAILURE: a rank whose round fails (bad argument, MZK_ERR_WRONG_QUOTIENT_DEGREE, a HIP error) returns
+ * without entering the round's remaining collectives, so its peers would wait in all_gather / barrier for ever: the CALLER's
+ * collectives must be abortable or time out (the in-tree LocalComm has an abort flag every waiter polls; torch.distributed callers set
+ * a process-group timeout), and a non-zero return of a callback ends the round on that rank with MZK_ERR_INVALID_ARG. */
 typedef struct mzk_comm {
     void* ctx;
     int32_t rank, world;
@@ -404,7 +407,9 @@ MZK_API int32_t mzk_prover_vk_commitments(uint64_t prover, uint64_t* out_xy_mont
 /* `wire_variables` of the finalised circuit (relation/src/constraint_system.rs:1225-1247), W x n u32 (host), every entry < n_vars (checked:
  * MZK_ERR_INVALID_ARG -- the reference panics on such an index): resident circuit structure for MZK_WITNESS_*_VECTOR. */
 MZK_API int32_t mzk_prover_set_wire_variables(uint64_t prover, const uint32_t* wire_variables, uint64_t n_vars);
-#define MZK_WITNESS_DEV_WIRES 0   /* device, W x n: witness[wire_variable(i, j)] already gathered */
+#define MZK_WITNESS_DEV_WIRES 0   /* device, W x n: witness[wire_variable(i, j)] already gathered.  The prover keeps the POINTER, not a copy:
+                                   * the buffer must stay valid and unmodified until round 2 (round 2.5 for UltraPlonk) has returned --
+                                   * rounds 1.5 and 2 read the wire values again (sorted vector, permutation product) */
 #define MZK_WITNESS_HOST_WIRES 1  /* host, W x n (page-locked memory: column k + 1 crosses PCIe under the iNTT of column k) */
 #define MZK_WITNESS_HOST_VECTOR 2 /* host, n_vars witness values; gathered on the device (mzk_prover_set_wire_variables) */
 #define MZK_WITNESS_DEV_VECTOR 3  /* device, n_vars witness values */
@@ -495,7 +500,7 @@ MZK_API int32_t mzk_profile_reset(void);
  * the first such call (13 x the SRS size for 2^20 points); on != 0 (default) enables it.  Results are identical. */
 MZK_API int32_t mzk_msm_set_precompute(int32_t on);
 /* Builds the table of precomputed multiples of an SRS now (instead of lazily on its first MSM of >= 1024 pairs) and reports it:
- * window bits c, levels W = ceil(256 / c), bytes of HBM it occupies (W x n x 112 B for BLS12-381, x 80 B for BN254) and the wall
+ * window bits c, levels W = ceil(256 / c), bytes of HBM it occupies (W x n x 112 B for BLS12-381, x 72 B for BN254: 2 x 9 words of 29-bit limbs) and the wall
  * time the build took (W - 1 launches of c doublings per point, synchronised).  A fixed-base table is legitimate for KZG -- the
  * commit key never changes (primitives/src/pcs/univariate_kzg/srs.rs:77-93) -- but it is a set-up cost ark-ec's
  * VariableBaseMSM does not pay: bench.py prints it beside the headline.  All zeros when the table is disabled or did not fit:
@@ -504,7 +509,7 @@ MZK_API int32_t mzk_msm_set_precompute(int32_t on);
 MZK_API int32_t mzk_srs_precompute(uint64_t srs_handle, uint32_t* out_window_bits, uint32_t* out_levels, uint64_t* out_table_bytes,
                                    double* out_build_ms);
 /* HBM accounting (bench.py reports it per leg).  An SRS: its points (boundary form + the MSM's internal form: 96 + 112 B per point on
- * BLS12-381, 64 + 80 B on BN254) and its fixed-base table (0 until built; the reference keeps the points only: srs.rs:36-40).  A proving
+ * BLS12-381, 64 + 72 B on BN254) and its fixed-base table (0 until built; the reference keeps the points only: srs.rs:36-40).  A proving
  * key: the resident evaluations of the fixed polynomials and the per-point tables.  The device context: the shared scratch of the NTT /
  * MSM / quotient kernels (grow-only) and the buffers of the host-pointer I/O slots. */
 MZK_API int32_t mzk_srs_hbm_bytes(uint64_t srs_handle, uint64_t* out_points_bytes, uint64_t* out_table_bytes);

@@ -16,7 +16,7 @@ use ark_ff::{PrimeField, UniformRand};
 use ark_std::rand::{CryptoRng, RngCore};
 use core::ffi::c_void;
 
-use crate::{check, Mi355Error, SrsHandle};
+use crate::{check, mzk_srs_release, Mi355Error, SrsHandle};
 
 pub const MZK_WITNESS_HOST_VECTOR: i32 = 2;
 pub const MZK_ERR_WRONG_QUOTIENT_DEGREE: i32 = -9;
@@ -46,11 +46,18 @@ pub struct Mi355Prover {
     pub num_wire_types: usize,
     pub ultra: bool,
     fq_limbs: usize,
+    /// the Lagrange-basis key derived for this prover (0 = none): its points and fixed-base table live in HBM until released
+    lagrange_key: u64,
 }
 
 impl Drop for Mi355Prover {
     fn drop(&mut self) {
-        unsafe { mzk_prover_destroy(self.handle) };
+        unsafe {
+            mzk_prover_destroy(self.handle);
+            if self.lagrange_key != 0 {
+                mzk_srs_release(self.lagrange_key);
+            }
+        }
     }
 }
 
@@ -73,12 +80,18 @@ impl Mi355Prover {
                 // wire VALUES -- same group elements, mostly small scalars
                 check(mzk_srs_lagrange_from_srs(commit_key.raw(), log_n, 3, &mut lagrange))?;
             }
-            check(mzk_prover_create(curve_id, log_n, num_wire_types as u32, flat(selectors), flat(sigmas),
-                                    tables.map_or(core::ptr::null(), |t| flat(t)), 1u64 << log_n, flat(k), commit_key.raw(), lagrange,
-                                    core::ptr::null(), &mut handle))?;
-            check(mzk_prover_set_wire_variables(handle, wire_variables.as_ptr(), n_vars as u64))?;
+            let made = check(mzk_prover_create(curve_id, log_n, num_wire_types as u32, flat(selectors), flat(sigmas),
+                                               tables.map_or(core::ptr::null(), |t| flat(t)), 1u64 << log_n, flat(k), commit_key.raw(), lagrange,
+                                               core::ptr::null(), &mut handle));
+            if made.is_err() && lagrange != 0 {
+                mzk_srs_release(lagrange);                         // nothing of a failed construction stays in HBM
+            }
+            made?;
         }
-        Ok(Self { handle, num_wire_types, ultra: tables.is_some(), fq_limbs })
+        // from here on Drop releases both handles
+        let me = Self { handle, num_wire_types, ultra: tables.is_some(), fq_limbs, lagrange_key: lagrange };
+        unsafe { check(mzk_prover_set_wire_variables(handle, wire_variables.as_ptr(), n_vars as u64))? };
+        Ok(me)
     }
 
     fn points<P: ark_ec::short_weierstrass::SWCurveConfig>(&self, xy: &[u64]) -> Vec<Affine<P>>

@@ -336,13 +336,22 @@ int32_t mzk_srs_slice(uint64_t handle, uint64_t first, uint64_t n_points, uint64
     ENTER_HANDLE(handle);
     auto it = cx_->srs.find(handle);
     if (it == cx_->srs.end()) { set_error("unknown SRS handle"); return MZK_ERR_BAD_HANDLE; }
-    if (!out_handle || first + n_points > it->second.n) { set_error("slice outside the SRS"); return MZK_ERR_INVALID_ARG; }
+    if (!out_handle || first > it->second.n || n_points > it->second.n - first) { set_error("slice outside the SRS"); return MZK_ERR_INVALID_ARG; }   // (no u64 wrap)
     const Srs& src = it->second;
     Srs s{src.curve, n_points, nullptr, nullptr, nullptr, 0};
     const size_t pt = (size_t)2 * fq_words(src.curve) * 4, bytes = (size_t)n_points * pt;
     HIP_TRY(hipMalloc((void**)&s.d_xy, bytes ? bytes : 4));
-    if (bytes) HIP_TRY(hipMemcpy(s.d_xy, reinterpret_cast<const uint8_t*>(src.d_xy) + first * pt, bytes, hipMemcpyDeviceToDevice));
-    MZK_TRY(srs_build_internal(s, nullptr));
+    int32_t rc = MZK_OK;
+    if (bytes && hipMemcpy(s.d_xy, reinterpret_cast<const uint8_t*>(src.d_xy) + first * pt, bytes, hipMemcpyDeviceToDevice) != hipSuccess) {
+        set_error("hipMemcpy of the SRS slice failed");
+        rc = MZK_ERR_HIP;
+    }
+    if (rc == MZK_OK) rc = srs_build_internal(s, nullptr);
+    if (rc != MZK_OK) {                                               // nothing of a failed slice stays allocated
+        (void)hipFree(s.d_xy);
+        if (s.d_int) (void)hipFree(s.d_int);
+        return rc;
+    }
     *out_handle = handle_make(cx_->logical, cx_->next_handle++);
     cx_->srs[*out_handle] = s;
     return MZK_OK;

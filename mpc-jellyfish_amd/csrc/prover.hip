@@ -991,6 +991,12 @@ int32_t mzk_prover_create(int32_t curve_id, uint32_t log_n, uint32_t num_wire_ty
         set_error("bad argument (TurboPlonk: 5 wire types, 13 selectors; UltraPlonk: 6 wire types, 14 selectors, 4 table polynomials; coefficient vectors of at most 2^log_n)");
         return MZK_ERR_INVALID_ARG;
     }
+    // the quotient lives on the 8n-point domain: its W (n + 1) + 3 coefficients (prover.rs:916-919) must fit below 8n.  The reference sizes
+    // that domain from the degree (n = 2 with five or six wire types and n = 4 with six would take 16n); such domains are refused here
+    if ((uint64_t)num_wire_types * ((1ull << log_n) + 1) + 2 >= (8ull << log_n)) {
+        set_error("domain too small for the 8n-point quotient domain: need num_wire_types * (n + 1) + 2 < 8 n (n >= 4 for TurboPlonk, n >= 8 for UltraPlonk)");
+        return MZK_ERR_UNSUPPORTED;
+    }
     int32_t device = -1;
     MZK_TRY(mzk_get_device(&device));
     if (device < 0) { set_error("mzk_init has not been called"); return MZK_ERR_NOT_INIT; }

@@ -167,6 +167,14 @@ def test_rounds_out_of_order_and_bad_arguments(gpu, mj, pyref):
     with pytest.raises(mj.MzkError):
         N.NativeProver(c, n, sel_p, sig_p, k, small)
     small.release()
+    # domains whose quotient does not fit the 8n-point domain are refused with a message (the reference would take a 16n domain there):
+    # n = 2 with five wire types, n = 4 with six
+    z = np.zeros((14 * 4, 4), dtype=np.uint64)
+    kk = mj.params.fr_to_mont(c, [1, 2, 3, 4, 5, 6])
+    hh = C.c_uint64()
+    for lg, W in ((1, 5), (1, 6), (2, 6)):
+        assert L.mzk_prover_create(0, lg, W, p(z), p(z), p(z) if W == 6 else None, 1 << lg, p(kk), ck.handle, 0, None, C.byref(hh)) == UNSUPPORTED
+        assert b"domain too small" in L.mzk_last_error()
     native.release()
     assert L.mzk_prover_destroy(native.handle or 12345) == BAD_HANDLE
     ck.release()
