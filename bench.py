@@ -597,6 +597,19 @@ def main():
         del cs
         if ck is not pp:
             ck.release()
+        # K proofs IN FLIGHT on this one card: K host threads, each with its own device context and prover handle (every handle runs on a
+        # stream of its own, csrc/prover.hip) -- a child process, because the K contexts are configured before the library is loaded
+        try:
+            import subprocess
+            r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "prove_in_flight.py"), "--log-n", str(pl), "--in-flight", "1,2,3", "--reps", str(reps)],
+                               capture_output=True, text=True, timeout=600)
+            fl = json.loads(r.stdout.strip().splitlines()[-1])
+            prove["in_flight"] = {"proofs_per_s_1_in_flight": fl["in_flight"]["1"]["proofs_per_s"], "proofs_per_s_2_in_flight": fl["in_flight"]["2"]["proofs_per_s"],
+                                  "proofs_per_s_3_in_flight": fl["in_flight"]["3"]["proofs_per_s"], "in_flight_contexts_agree_on_proof": fl["contexts_agree_on_proof"],
+                                  "what": "tools/prove_in_flight.py: K threads x (device context + mzk_prover handle on its own stream) on ONE card, round-level C ABI "
+                                          "driven from ctypes; the host Horner tails, transcripts and launch gaps of one proof run under the kernels of the others"}
+        except Exception as e:                                  # noqa: BLE001  (secondary)
+            prove["in_flight"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
 
     # ---- secondary: the same proof's NTTs and MSMs in SHIM-ONLY mode: host pointers through the two call-site swaps of
     #      INTEGRATION.md section 2, nothing else of the Rust prover changed (tools/dropin_time.py) --------------------------------

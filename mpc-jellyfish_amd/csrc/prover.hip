@@ -6,6 +6,7 @@
 // 64-bit-limb field arithmetic (hostfp.hpp).  Transcript, rng and `Proof` assembly stay with the caller, as in snark.rs:263-431.
 #include <algorithm>
 #include <chrono>
+#include <cstdlib>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -84,7 +85,14 @@ struct ProverBase {
     bool ultra = false;
     uint64_t n = 0;
     bool profile = false;
+    // Every handle runs its rounds on a stream of its own (non-blocking): two provers of one card -- two device contexts, MZK_VIRTUAL_DEVICES,
+    // or two handles of one context -- then only meet where they share hardware, and the latency-bound tails of one proof (narrow
+    // reduction levels, host Horner, transcript) run under the kernels of the other.  MZK_PROVER_NULL_STREAM=1: the device's null
+    // stream, as until round 4 (A/B).  What the caller hands over in device memory must be complete on the null stream (or synchronised)
+    // when a round is called: round 1 makes S wait for it; every round returns with S idle as far as its outputs are concerned.
+    void* S = nullptr;
     std::map<std::string, double> timings_ms;
+    void sync_stream() { if (mzk_stream_sync(S) != MZK_OK) throw Fail{MZK_ERR_HIP}; }
     virtual ~ProverBase() {}
     virtual void vk_commitments(uint64_t* out_xy, uint64_t* out_plookup_xy) = 0;
     virtual void set_wire_variables(const uint32_t* vars, uint64_t n_vars) = 0;
@@ -145,10 +153,10 @@ struct ProverT final : ProverBase {
     struct Tick {
         ProverBase& P; std::chrono::steady_clock::time_point t0;
         explicit Tick(ProverBase& p) : P(p) { reset(); }
-        void reset() { if (P.profile) { (void)mzk_dev_sync(); t0 = std::chrono::steady_clock::now(); } }
+        void reset() { if (P.profile) { (void)mzk_stream_sync(P.S); t0 = std::chrono::steady_clock::now(); } }
         void mark(const char* name) {
             if (!P.profile) return;
-            (void)mzk_dev_sync();
+            (void)mzk_stream_sync(P.S);
             P.timings_ms[name] = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
             reset();
         }
@@ -187,8 +195,10 @@ struct ProverT final : ProverBase {
                 fail(MZK_ERR_INVALID_ARG, "Lagrange-basis key: 2^log_n + 3 points (mzk_srs_lagrange_from_srs(.., log_n, 3)), sliced like the commit key");
         }
         const int nfix = nsel + W + (ultra ? 4 : 0);
+        if (!std::getenv("MZK_PROVER_NULL_STREAM")) ck(mzk_stream_create(&S));
         fixed.alloc((size_t)nfix * n);
-        ck(mzk_dev_memset(fixed.p, 0, (size_t)nfix * n * EL, nullptr));
+        ck(mzk_dev_memset(fixed.p, 0, (size_t)nfix * n * EL, S));
+        sync_stream();                                                 // the uploads below are synchronous copies, not ordered after S
         auto up_rows = [&](int first, int cnt, const uint64_t* src) {
             if (poly_len == n) ck(mzk_dev_upload(fix(first), src, (size_t)cnt * n * EL));
             else for (int i = 0; i < cnt; i++) ck(mzk_dev_upload(fix(first + i), src + (size_t)i * poly_len * 4, poly_len * EL));
@@ -221,6 +231,7 @@ struct ProverT final : ProverBase {
         (void)mzk_dev_sync();
         if (pk) (void)mzk_plonk_pk_release(pk);
         if (copy_stream) (void)mzk_stream_destroy(copy_stream);
+        if (S) (void)mzk_stream_destroy(S);
     }
     void hbm_bytes(uint64_t* fixed_b, uint64_t* pk_b, uint64_t* ws_b) override {
         uint64_t ws = 0;
@@ -244,7 +255,7 @@ struct ProverT final : ProverBase {
             l[i] = s1 - s0;
             off[i] = (s1 > s0 ? s0 : a) - key_first;                     // (a sliced key starts at this rank's lo: a >= lo there)
         }
-        ck(mzk_msm_batch_dev(key ? key : srs, kp, p.data(), l.data(), off.data(), 1, xyz.data(), nullptr));
+        ck(mzk_msm_batch_dev(key ? key : srs, kp, p.data(), l.data(), off.data(), 1, xyz.data(), S));
         return xyz;
     }
     // the ranks' partial sums -> the commitments, identical on every rank: all-gather of k x 144 B (96 B on BN254) through host
@@ -270,7 +281,7 @@ struct ProverT final : ProverBase {
     void commit_slices(const std::vector<const void*>& slices, const std::vector<uint64_t>& lens, uint64_t* out_xy) {
         const uint32_t kp = (uint32_t)slices.size();
         std::vector<uint64_t> off(kp, lo - key_first), xyz((size_t)kp * 3 * QL);
-        ck(mzk_msm_batch_dev(srs, kp, slices.data(), lens.data(), off.data(), 1, xyz.data(), nullptr));
+        ck(mzk_msm_batch_dev(srs, kp, slices.data(), lens.data(), off.data(), 1, xyz.data(), S));
         combine_partials(xyz, out_xy);
     }
     void vk_commitments(uint64_t* out_xy, uint64_t* out_plookup_xy) override {   // set-up work: over several ranks sharded by point range like every commitment
@@ -290,7 +301,7 @@ struct ProverT final : ProverBase {
     // ---- small helpers ---------------------------------------------------------------------------------------------------------
     std::vector<Fr> evaluate(const void* d, uint64_t len, uint32_t batch_n, uint64_t stride, const Fr& x) {
         std::vector<Fr> out(batch_n);
-        ck(mzk_poly_eval_dev(CURVE, d, len, batch_n, stride, x.l, reinterpret_cast<uint64_t*>(out.data()), nullptr));
+        ck(mzk_poly_eval_dev(CURVE, d, len, batch_n, stride, x.l, reinterpret_cast<uint64_t*>(out.data()), S));
         return out;
     }
     // evaluations of one round, collected and finished together.  Over several ranks every rank evaluates its coefficient range
@@ -330,7 +341,7 @@ struct ProverT final : ProverBase {
             if (n_x == 1) xs[1] = xs[0];
             if (!scale.empty())
                 ck(mzk_poly_eval_many_dev(CURVE, (uint32_t)ptrs.size(), ptrs.data(), lens.data(), batches.data(), strides.data(), which.data(), xs[0].l,
-                                          reinterpret_cast<uint64_t*>(vals.data()), nullptr));
+                                          reinterpret_cast<uint64_t*>(vals.data()), P.S));
             if (P.world == 1) return;
             const size_t cnt = vals.size();
             for (size_t i = 0; i < cnt; i++) vals[i] = vals[i] * scale[i];
@@ -348,7 +359,7 @@ struct ProverT final : ProverBase {
         std::vector<const void*> ptrs;
         std::vector<uint64_t> lens, sc;
         for (auto& t : terms) { ptrs.push_back(t.p); lens.push_back(t.len); for (int i = 0; i < 4; i++) sc.push_back(t.s.l[i]); }
-        ck(mzk_poly_lincomb_dev(CURVE, (uint32_t)terms.size(), ptrs.data(), lens.data(), sc.data(), out, out_len, nullptr));
+        ck(mzk_poly_lincomb_dev(CURVE, (uint32_t)terms.size(), ptrs.data(), lens.data(), sc.data(), out, out_len, S));
     }
     // sum of any number of terms into `out` (one launch takes 32)
     void lincomb_many(const std::vector<Term>& terms, void* out, uint64_t out_len) {
@@ -364,7 +375,7 @@ struct ProverT final : ProverBase {
     void mask(const std::vector<int>& slab_rows, const uint64_t* blinders, uint32_t n_blind) {      // prover.rs:463-486
         std::vector<void*> ptrs;
         for (int r : slab_rows) ptrs.push_back(row(r));
-        ck(mzk_poly_mask_dev(CURVE, (uint32_t)ptrs.size(), ptrs.data(), n, n_blind, blinders, nullptr));
+        ck(mzk_poly_mask_dev(CURVE, (uint32_t)ptrs.size(), ptrs.data(), n, n_blind, blinders, S));
     }
     const void* one_dev() {                                            // the field's one (Montgomery), resident: tmp[1]
         if (!one_ready) {
@@ -377,8 +388,9 @@ struct ProverT final : ProverBase {
     // a scalar into device memory as a kernel argument (times the resident one): no host-to-device copy, hence no stream synchronisation
     void put_scalar(const Fr& v, void* d) { lincomb({{v, one_dev(), 1}}, d, 1); }
     void* rem_dev() const { return tmp.at(2); }                        // where the opening division leaves the batch polynomial's value at zeta
-    Fr download_fr(const void* d) const {
+    Fr download_fr(const void* d) {
         Fr v;
+        sync_stream();                                                 // (a synchronous copy is ordered after the null stream, not after S)
         ck(mzk_dev_download(v.l, d, EL));
         return v;
     }
@@ -397,7 +409,7 @@ struct ProverT final : ProverBase {
     }
     void public_input_row(const uint64_t* pi_rows, const uint64_t* pi, uint64_t n_pi) {
         void* d = coeff.at((size_t)W * n);
-        ck(mzk_dev_memset(d, 0, n * EL, nullptr));
+        ck(mzk_dev_memset(d, 0, n * EL, S));
         st.pi_zero = true;
         for (uint64_t i = 0; i < n_pi * 4 && st.pi_zero; i++) st.pi_zero = pi[i] == 0;
         if (st.pi_zero) return;
@@ -406,14 +418,14 @@ struct ProverT final : ProverBase {
         uint64_t* h = static_cast<uint64_t*>(stage_pi.reserve(n_pi * EL));
         std::memcpy(h, pi, n_pi * EL);
         if (!pi_rows) {
-            ck(mzk_dev_upload_async(d, h, n_pi * EL, nullptr));
+            ck(mzk_dev_upload_async(d, h, n_pi * EL, S));
         } else {
             for (uint64_t i = 0; i < n_pi; i++) {
                 if (pi_rows[i] >= n) fail(MZK_ERR_INVALID_ARG, "public-input row outside the domain");
-                ck(mzk_dev_upload_async(static_cast<uint8_t*>(d) + pi_rows[i] * EL, h + 4 * i, EL, nullptr));
+                ck(mzk_dev_upload_async(static_cast<uint8_t*>(d) + pi_rows[i] * EL, h + 4 * i, EL, S));
             }
         }
-        ck(mzk_ntt_dev(CURVE, d, n, log_n, 1, nullptr, 1, n, nullptr));      // compute_pub_input_polynomial (:1249-1259)
+        ck(mzk_ntt_dev(CURVE, d, n, log_n, 1, nullptr, 1, n, S));      // compute_pub_input_polynomial (:1249-1259)
     }
     void round1(int kind, const void* witness, uint64_t witness_len, const uint64_t* pi_rows, const uint64_t* pi, uint64_t n_pi, const uint64_t* blinders,
                 uint64_t* out) override {
@@ -422,13 +434,14 @@ struct ProverT final : ProverBase {
         stage = CREATED;
         timings_ms.clear();
         if (!witness || !blinders || !out || (n_pi && !pi)) fail(MZK_ERR_INVALID_ARG, "null pointer");
+        if (S) ck(mzk_stream_wait_stream(S, nullptr));                 // what the caller wrote on the null stream (a device-resident witness) is complete first
         public_input_row(pi_rows, pi, n_pi);
         const size_t cells = (size_t)W * n;
         if (kind == MZK_WITNESS_DEV_WIRES) {
             if (witness_len != cells) fail(MZK_ERR_INVALID_ARG, "witness_len != num_wire_types * domain size");
             st.wire_values = witness;
-            ck(mzk_dev_copy(coeff.p, witness, cells * EL, nullptr));
-            ck(mzk_ntt_dev(CURVE, coeff.p, n, log_n, 1, nullptr, W, n, nullptr));
+            ck(mzk_dev_copy(coeff.p, witness, cells * EL, S));
+            ck(mzk_ntt_dev(CURVE, coeff.p, n, log_n, 1, nullptr, W, n, S));
         } else if (kind == MZK_WITNESS_HOST_VECTOR || kind == MZK_WITNESS_DEV_VECTOR) {
             // the witness vector crosses PCIe; `witness[wire_variable(i, j)]` (constraint_system.rs:1239) is gathered on the device
             if (!vars.p) fail(MZK_ERR_STATE, "mzk_prover_set_wire_variables has not been called");
@@ -439,14 +452,14 @@ struct ProverT final : ProverBase {
             if (kind == MZK_WITNESS_HOST_VECTOR) {
                 if (wit.elems < n_vars) wit.alloc(n_vars);
                 if (!copy_stream) ck(mzk_stream_create(&copy_stream));
-                ck(mzk_stream_wait_stream(copy_stream, nullptr));                                       // the previous proof is done with `wit`
+                ck(mzk_stream_wait_stream(copy_stream, S));                                       // the previous proof is done with `wit`
                 ck(mzk_dev_upload_async(wit.p, witness, n_vars * EL, copy_stream));
-                ck(mzk_stream_wait_stream(nullptr, copy_stream));
+                ck(mzk_stream_wait_stream(S, copy_stream));
                 d_wit = wit.p;
             }
-            ck(mzk_plonk_gather_witness_dev(d_wit, n_vars, vars.p, cells, wv.p, nullptr));
-            ck(mzk_dev_copy(coeff.p, wv.p, cells * EL, nullptr));
-            ck(mzk_ntt_dev(CURVE, coeff.p, n, log_n, 1, nullptr, W, n, nullptr));
+            ck(mzk_plonk_gather_witness_dev(d_wit, n_vars, vars.p, cells, wv.p, S));
+            ck(mzk_dev_copy(coeff.p, wv.p, cells * EL, S));
+            ck(mzk_ntt_dev(CURVE, coeff.p, n, log_n, 1, nullptr, W, n, S));
         } else if (kind == MZK_WITNESS_HOST_WIRES) {
             // host-resident witness (constraint_system.rs:1225-1247 gathers it on the host): column i + 1 crosses PCIe on a copy
             // stream while column i is transformed on the null stream
@@ -454,26 +467,26 @@ struct ProverT final : ProverBase {
             if (!wv.p) wv.alloc(cells);
             if (!copy_stream) ck(mzk_stream_create(&copy_stream));
             st.wire_values = wv.p;
-            ck(mzk_stream_wait_stream(copy_stream, nullptr));                                           // the previous proof is done with `wv`
+            ck(mzk_stream_wait_stream(copy_stream, S));                                           // the previous proof is done with `wv`
             for (int i = 0; i < W; i++) {
                 ck(mzk_dev_upload_async(wv.at((size_t)i * n), static_cast<const uint8_t*>(witness) + (size_t)i * n * EL, n * EL, copy_stream));
-                ck(mzk_stream_wait_stream(nullptr, copy_stream));                                       // columns 0..i have arrived
-                ck(mzk_dev_copy(coeff.at((size_t)i * n), wv.at((size_t)i * n), n * EL, nullptr));
-                ck(mzk_ntt_dev(CURVE, coeff.at((size_t)i * n), n, log_n, 1, nullptr, 1, n, nullptr));
+                ck(mzk_stream_wait_stream(S, copy_stream));                                       // columns 0..i have arrived
+                ck(mzk_dev_copy(coeff.at((size_t)i * n), wv.at((size_t)i * n), n * EL, S));
+                ck(mzk_ntt_dev(CURVE, coeff.at((size_t)i * n), n, log_n, 1, nullptr, 1, n, S));
             }
         } else {
             fail(MZK_ERR_INVALID_ARG, "unknown witness_kind");
         }
-        for (int r = 0; r < rows; r++) ck(mzk_dev_memset(static_cast<uint8_t*>(row(r)) + n * EL, 0, 3 * EL, nullptr));
-        ck(mzk_dev_copy2d(slab.p, (n + 3) * EL, coeff.p, n * EL, n * EL, W, nullptr));
-        ck(mzk_dev_copy(row(rowPI()), coeff.at((size_t)W * n), n * EL, nullptr));
+        for (int r = 0; r < rows; r++) ck(mzk_dev_memset(static_cast<uint8_t*>(row(r)) + n * EL, 0, 3 * EL, S));
+        ck(mzk_dev_copy2d(slab.p, (n + 3) * EL, coeff.p, n * EL, n * EL, W, S));
+        ck(mzk_dev_copy(row(rowPI()), coeff.at((size_t)W * n), n * EL, S));
         { std::vector<int> rs; for (int i = 0; i < W; i++) rs.push_back(i); mask(rs, blinders, 2); }
         tick.mark("r1_ntt_mask");
         std::vector<const void*> p; std::vector<uint64_t> l;
         if (srs_lagrange) {
             // sum_i v_i [L_i(beta)]g + b_0 [Z_H(beta)]g + b_1 [beta Z_H(beta)]g: rows of n + 3 slots, the values, then the blinders
             if (!vals_ext.p) vals_ext.alloc((size_t)W * (n + 3));
-            ck(mzk_dev_copy2d(vals_ext.p, (n + 3) * EL, st.wire_values, n * EL, n * EL, W, nullptr));
+            ck(mzk_dev_copy2d(vals_ext.p, (n + 3) * EL, st.wire_values, n * EL, n * EL, W, S));
             for (int i = 0; i < W; i++)
                 for (int j = 0; j < 2; j++) put_scalar(load(blinders + (size_t)(2 * i + j) * 4), vals_ext.at((size_t)i * (n + 3) + n + j));
             for (int i = 0; i < W; i++) { p.push_back(vals_ext.at((size_t)i * (n + 3))); l.push_back(n + 2); }
@@ -491,19 +504,19 @@ struct ProverT final : ProverBase {
         Tick tick(*this);
         st.tau = load(tau);
         const int H1 = rowH1();
-        ck(mzk_plookup_sorted_vec_dev(pk, st.wire_values, st.tau.l, table.p, lookup.p, sorted.p, nullptr));
-        ck(mzk_dev_copy(hh.p, sorted.p, n * EL, nullptr));
-        ck(mzk_dev_copy(hh.at(n), sorted.at(n - 1), n * EL, nullptr));
+        ck(mzk_plookup_sorted_vec_dev(pk, st.wire_values, st.tau.l, table.p, lookup.p, sorted.p, S));
+        ck(mzk_dev_copy(hh.p, sorted.p, n * EL, S));
+        ck(mzk_dev_copy(hh.at(n), sorted.at(n - 1), n * EL, S));
         if (srs_lagrange) {
             // h_1, h_2 are committed from the sorted vector's VALUES (table entries and looked-up values: small numbers unless the circuit
             // looks up keyed tables) plus their three blinders, over the Lagrange-basis key -- as the wires in round 1
             if (!vals_ext.p) vals_ext.alloc((size_t)W * (n + 3));
-            ck(mzk_dev_copy2d(vals_ext.p, (n + 3) * EL, hh.p, n * EL, n * EL, 2, nullptr));
+            ck(mzk_dev_copy2d(vals_ext.p, (n + 3) * EL, hh.p, n * EL, n * EL, 2, S));
             for (int i = 0; i < 2; i++)
                 for (int j = 0; j < 3; j++) put_scalar(load(blinders + (size_t)(3 * i + j) * 4), vals_ext.at((size_t)i * (n + 3) + n + j));
         }
-        ck(mzk_ntt_dev(CURVE, hh.p, n, log_n, 1, nullptr, 2, n, nullptr));
-        ck(mzk_dev_copy2d(row(H1), (n + 3) * EL, hh.p, n * EL, n * EL, 2, nullptr));
+        ck(mzk_ntt_dev(CURVE, hh.p, n, log_n, 1, nullptr, 2, n, S));
+        ck(mzk_dev_copy2d(row(H1), (n + 3) * EL, hh.p, n * EL, n * EL, 2, S));
         mask({H1, H1 + 1}, blinders, 3);
         tick.mark("r1_5_sorted_vec");
         if (srs_lagrange) commit({vals_ext.p, vals_ext.at(n + 3)}, {n + 3, n + 3}, out, srs_lagrange);
@@ -516,8 +529,8 @@ struct ProverT final : ProverBase {
         need(ultra ? R1_5 : R1, R2, ultra ? "round 2 follows round 1.5" : "round 2 follows round 1");
         Tick tick(*this);
         st.beta = load(beta); st.gamma = load(gamma);
-        ck(mzk_plonk_perm_product_dev(pk, st.wire_values, st.beta.l, st.gamma.l, coeff.p, nullptr));
-        ck(mzk_dev_copy(row(rowZ()), coeff.p, n * EL, nullptr));
+        ck(mzk_plonk_perm_product_dev(pk, st.wire_values, st.beta.l, st.gamma.l, coeff.p, S));
+        ck(mzk_dev_copy(row(rowZ()), coeff.p, n * EL, S));
         mask({rowZ()}, blinders, 3);
         tick.mark("r2_product");
         commit({row(rowZ())}, {n + 3}, out);
@@ -529,8 +542,8 @@ struct ProverT final : ProverBase {
         if (!ultra) fail(MZK_ERR_UNSUPPORTED, "round 2.5 exists for UltraPlonk only");
         need(R2, R2_5, "round 2.5 follows round 2");
         Tick tick(*this);
-        ck(mzk_plookup_product_dev(pk, table.p, lookup.p, sorted.p, st.beta.l, st.gamma.l, coeff.p, nullptr));
-        ck(mzk_dev_copy(row(rowPL()), coeff.p, n * EL, nullptr));
+        ck(mzk_plookup_product_dev(pk, table.p, lookup.p, sorted.p, st.beta.l, st.gamma.l, coeff.p, S));
+        ck(mzk_dev_copy(row(rowPL()), coeff.p, n * EL, S));
         mask({rowPL()}, blinders, 3);
         tick.mark("r2_5_product");
         commit({row(rowPL())}, {n + 3}, out);
@@ -545,7 +558,7 @@ struct ProverT final : ProverBase {
         // into this class's slot of `rem` (the rows of the slab are read, not overwritten)
         if (!own.empty())
             ck(mzk_plonk_quotient_chunked_flags_dev(pk, slab.p, n + 3, n + 3, st.pi_zero ? MZK_QUOTIENT_PI_ZERO : 0u, ultra ? st.tau.l : nullptr, alpha.l,
-                                                    st.beta.l, st.gamma.l, rem.at((size_t)own[0] * n), nullptr));
+                                                    st.beta.l, st.gamma.l, rem.at((size_t)own[0] * n), S));
         if (world > 1) {
             // THE one exchange
             const uint32_t first = own.empty() ? 0u : own[0];
@@ -560,31 +573,31 @@ struct ProverT final : ProverBase {
                     for (int q = 0; q < world; q++)
                         if (q != rank)
                             ck(mzk_dev_copy_peer(static_cast<uint8_t*>(peer_rem[q]) + (size_t)own[0] * n * EL, peer_dev[q], rem.at((size_t)own[0] * n), device,
-                                                 own.size() * n * EL, nullptr));
+                                                 own.size() * n * EL, S));
                 ck(mzk_dev_sync());
                 if (comm.barrier(comm.ctx)) fail(MZK_ERR_INVALID_ARG, "mzk_comm.barrier failed");
             }
         }
         // the inverse Vandermonde per coefficient index (replicated: every rank needs the quotient's coefficients for the split)
         if (use_top) {
-            ck(mzk_plonk_quotient_top_dev(pk, slab.p, n + 3, n + 3, alpha.l, st.beta.l, st.gamma.l, top.p, nullptr, nullptr));
-            ck(mzk_plonk_quotient_combine_top_dev(CURVE, log_n, classes.data(), (uint32_t)classes.size(), rem.p, top.p, (uint32_t)W + 3, quot.p, nullptr));
+            ck(mzk_plonk_quotient_top_dev(pk, slab.p, n + 3, n + 3, alpha.l, st.beta.l, st.gamma.l, top.p, nullptr, S));
+            ck(mzk_plonk_quotient_combine_top_dev(CURVE, log_n, classes.data(), (uint32_t)classes.size(), rem.p, top.p, (uint32_t)W + 3, quot.p, S));
         } else {
-            ck(mzk_plonk_quotient_combine_classes_dev(CURVE, log_n, classes.data(), (uint32_t)classes.size(), rem.p, quot.p, nullptr));
+            ck(mzk_plonk_quotient_combine_classes_dev(CURVE, log_n, classes.data(), (uint32_t)classes.size(), rem.p, quot.p, S));
         }
     }
     // split_quotient_polynomial (prover.rs:902-960) of the 8n coefficients at `q` into this->split
     void split_quotient(const void* q, const uint64_t* b_quot) {
         const uint64_t expected = (uint64_t)W * (n + 1) + 2;                                                  // quotient_polynomial_degree
         // only what lies at and above the expected degree is scanned: its length must be exactly 1 (read after the commitments)
-        ck(mzk_poly_degree_dev(static_cast<const uint8_t*>(q) + expected * EL, m - expected, static_cast<uint64_t*>(deg.p), nullptr));
-        ck(mzk_dev_memset(split.p, 0, (size_t)W * (n + 3) * EL, nullptr));
+        ck(mzk_poly_degree_dev(static_cast<const uint8_t*>(q) + expected * EL, m - expected, static_cast<uint64_t*>(deg.p), S));
+        ck(mzk_dev_memset(split.p, 0, (size_t)W * (n + 3) * EL, S));
         st.split_len.assign(W, 0);
         Fr last = Fr::zero();
         for (int i = 0; i < W; i++) {
             const uint64_t a = (uint64_t)i * (n + 2), b = i < W - 1 ? a + n + 2 : expected + 1;
             void* p = split.at((size_t)i * (n + 3));
-            ck(mzk_dev_copy(p, static_cast<const uint8_t*>(q) + a * EL, (b - a) * EL, nullptr));
+            ck(mzk_dev_copy(p, static_cast<const uint8_t*>(q) + a * EL, (b - a) * EL, S));
             if (i < W - 1) put_scalar(load(b_quot + 4 * i), static_cast<uint8_t*>(p) + (n + 2) * EL);
             if (i > 0) lincomb({{Fr::one(), p, 1}, {neg(last), one_dev(), 1}}, p, 1);                             // t_i[0] -= b_{i-1}
             if (i < W - 1) last = load(b_quot + 4 * i);
@@ -606,6 +619,7 @@ struct ProverT final : ProverBase {
             qterms.push_back({base, p->quot.p, m});
             st.bases.push_back(base);
             base = base * (p->ultra ? a7 : a3);                         // prover.rs:661-669
+            if (p != this) ck(mzk_stream_wait_stream(S, p->S));         // its quotient was computed on its own stream
         }
         const void* q = quot.p;
         if (inst.size() > 1) {                                          // the per-instance quotients are combined after their inverse NTTs (linear maps)
@@ -625,6 +639,7 @@ struct ProverT final : ProverBase {
         // numerator the degree is right by construction and round 5 checks the identity at zeta.  (The commitments have synchronised the
         // stream; this reads 8 bytes.)
         uint64_t tail = 0;
+        sync_stream();
         ck(mzk_dev_download(&tail, deg.p, 8));
         for (ProverBase* b : inst) b->stage = R3;
         if (tail != 1) {
@@ -802,8 +817,8 @@ struct ProverT final : ProverBase {
         Fr c = Fr::one();
         for (auto& p : polys) { t.push_back({c, p.p, p.len}); c = c * v; }
         lincomb_many(t, batch.p, n + 3);
-        if (d_rem) ck(mzk_poly_div_linear_rem_dev(CURVE, batch.p, n + 3, point.l, out.p, d_rem, nullptr));   // remainder = batch(point)
-        else ck(mzk_poly_div_linear_dev(CURVE, batch.p, n + 3, point.l, out.p, nullptr));
+        if (d_rem) ck(mzk_poly_div_linear_rem_dev(CURVE, batch.p, n + 3, point.l, out.p, d_rem, S));   // remainder = batch(point)
+        else ck(mzk_poly_div_linear_dev(CURVE, batch.p, n + 3, point.l, out.p, S));
     }
     // Round 5 over several ranks.  The opening witness of a batch polynomial b at a point z is
     // w_j = sum_{i > j} b_i z^(i-j-1).  A rank needs w on its own coefficient range [lo, hi) only -- that is its MSM shard -- and
@@ -835,7 +850,7 @@ struct ProverT final : ProverBase {
         Fr e[2] = {Fr::zero(), Fr::zero()};
         for (int j = 0; j < 2; j++) {
             if (!width) continue;
-            if (cuts[j].empty()) ck(mzk_dev_memset(bufs[j], 0, width * EL, nullptr));
+            if (cuts[j].empty()) ck(mzk_dev_memset(bufs[j], 0, width * EL, S));
             else lincomb_many(cuts[j], bufs[j], width);
             e[j] = evaluate(bufs[j], width, 1, width, points[j])[0];
         }
@@ -852,7 +867,7 @@ struct ProverT final : ProverBase {
         void* outs[2] = {opening.p, shifted.p};
         for (int j = 0; j < 2 && width; j++) {
             put_scalar(carry[j], static_cast<uint8_t*>(bufs[j]) + width * EL);                                    // the carried coefficient, without a copy
-            ck(mzk_poly_div_linear_dev(CURVE, bufs[j], width + 1, points[j].l, outs[j], nullptr));               // width coefficients: w on [lo, hi)
+            ck(mzk_poly_div_linear_dev(CURVE, bufs[j], width + 1, points[j].l, outs[j], S));               // width coefficients: w on [lo, hi)
         }
         tick.mark("r5_polys");
         commit_slices({opening.p, shifted.p}, {width, width}, out);
@@ -861,7 +876,10 @@ struct ProverT final : ProverBase {
     void round5(const std::vector<ProverBase*>& inst, const uint64_t* v_p, uint64_t* out) override {
         Tick tick(*this);
         if (st.bases.size() != inst.size()) fail(MZK_ERR_STATE, "round 5 takes the instances of round 3, first instance first");
-        for (ProverBase* b : inst) static_cast<ProverT*>(b)->need(R4, R4 + 1, "round 5 follows round 4 of every instance");
+        for (ProverBase* b : inst) {
+            static_cast<ProverT*>(b)->need(R4, R4 + 1, "round 5 follows round 4 of every instance");
+            if (b != this) ck(mzk_stream_wait_stream(S, b->S));         // the other instances' polynomials are read on this stream
+        }
         const Fr v = load(v_p), zeta = st.zeta;
         std::vector<Term> terms = quotient_lin_terms(zeta);
         for (size_t i = 0; i < inst.size(); i++) {
