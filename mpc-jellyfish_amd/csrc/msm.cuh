@@ -219,6 +219,48 @@ __global__ __launch_bounds__(1024) void msm_order_scatter_kernel(const uint32_t*
     }
 }
 
+// The two-level sort's form of the ranking (round 5): msm_order_hist's key counts arrive from the sort itself (pre_fine / pre_huge_scan count
+// the keys of their buckets into keycnt), every workgroup scans the 1024 key totals of its window for itself (what msm_order_scan did in a
+// launch of its own) and reserves its ranges from a zeroed cursor array -- and, visiting every bucket's count anyway, registers the
+// over-long and heavy ones (what msm_long_find_kernel did after the accumulation; NULL desc_count: not here).  Three launches fewer per MSM.
+struct LongDesc;
+struct HeavyRun;
+__device__ __forceinline__ void msm_long_register(uint32_t w, uint32_t b, uint32_t c, uint32_t offs_t, int n_win, uint32_t cap, uint32_t desc_cap,
+                                                  LongDesc* __restrict__ desc, uint32_t* __restrict__ desc_count, uint32_t run_cap,
+                                                  HeavyRun* __restrict__ heavy_runs);
+__global__ __launch_bounds__(1024) void msm_order_place_kernel(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs, uint32_t M,
+                                                               const uint32_t* __restrict__ keycnt, uint32_t* __restrict__ keycur, uint32_t* __restrict__ order,
+                                                               int n_win, uint32_t cap, uint32_t desc_cap, LongDesc* __restrict__ desc,
+                                                               uint32_t* __restrict__ desc_count, uint32_t run_cap, HeavyRun* __restrict__ heavy_runs) {
+    __shared__ uint32_t cnt[1024];
+    __shared__ uint32_t part[1024];
+    const uint32_t w = blockIdx.y, t = threadIdx.x;
+    const uint32_t lo = blockIdx.x * MSM_ORDER_SLICE, hi = min(M, lo + MSM_ORDER_SLICE);
+    const uint32_t total = keycnt[(size_t)w * 1024 + t];
+    part[t] = total;
+    cnt[t] = 0;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) {
+        uint32_t v = t >= (uint32_t)d ? part[t - d] : 0;
+        __syncthreads();
+        part[t] += v;
+        __syncthreads();
+    }
+    const uint32_t key_start = part[t] - total;                        // exclusive start of key t in the window's order array
+    for (uint32_t b = lo + t; b < hi; b += 1024) atomicAdd(&cnt[order_key(hist[(size_t)w * M + b])], 1u);
+    __syncthreads();
+    const uint32_t mine = cnt[t];
+    __syncthreads();
+    cnt[t] = mine ? key_start + atomicAdd(&keycur[(size_t)w * 1024 + t], mine) : 0u;      // start of this slice's range for key t
+    __syncthreads();
+    for (uint32_t b = lo + t; b < hi; b += 1024) {
+        const uint32_t c = hist[(size_t)w * M + b];
+        const uint32_t pos = atomicAdd(&cnt[order_key(c)], 1u);
+        order[(size_t)w * M + pos] = b;
+        if (desc_count && c > cap) msm_long_register(w, b, c, offs[(size_t)w * M + b], n_win, cap, desc_cap, desc, desc_count, run_cap, heavy_runs);
+    }
+}
+
 template <class FQ>
 __device__ __forceinline__ Affine<Fp<FQ>> load_affine(const uint32_t* __restrict__ bases, unsigned long long idx) {
     Affine<Fp<FQ>> p;
@@ -358,8 +400,8 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(const u
                                                                           const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ order,
                                                                           uint32_t M, int n_win, uint32_t cap, uint32_t* __restrict__ long_count,
                                                                           uint32_t* __restrict__ buckets, uint8_t* __restrict__ occ) {
-    if (blockIdx.x == 0)                                       // what msm_long_find_kernel counts into: saves a fill (per window: 1 + MSM_HEAVY_COUNTERS words)
-        for (unsigned i = threadIdx.x; i < (unsigned)n_win * (1 + MSM_HEAVY_COUNTERS); i += MSM_ACC_THREADS) long_count[i] = 0u;
+    if (long_count && blockIdx.x == 0)                         // what msm_long_find_kernel counts into: saves a fill (per window: 1 + MSM_HEAVY_COUNTERS words);
+        for (unsigned i = threadIdx.x; i < (unsigned)n_win * (1 + MSM_HEAVY_COUNTERS); i += MSM_ACC_THREADS) long_count[i] = 0u;      // NULL: the sort has cleared and filled them already
     const unsigned long long t0 = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
     if (t0 >= (unsigned long long)n_win * M) return;
     const unsigned long long w = t0 / M;
@@ -391,7 +433,7 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_split_kernel(c
                                                                                 const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ order,
                                                                                 uint32_t M, int n_win, uint32_t cap, int log_split, uint32_t* __restrict__ long_count,
                                                                                 uint32_t* __restrict__ sub) {
-    if (blockIdx.x == 0)
+    if (long_count && blockIdx.x == 0)
         for (unsigned i = threadIdx.x; i < (unsigned)n_win * (1 + MSM_HEAVY_COUNTERS); i += MSM_ACC_THREADS) long_count[i] = 0u;
     const unsigned long long t1 = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
     const unsigned long long t0 = t1 >> log_split;
@@ -501,6 +543,11 @@ struct HeavyJob {
     uint32_t *h1, *h2, *h3, *buckets;
     uint8_t* occ;
     uint32_t run_cap, h1_cap, M;       // runs / level-1 partial sums per window
+    // the over-long buckets of the same MSM (round 5: their chunk sums run in the launch of the heavy level-1 sums, msm_rare_leaf_kernel)
+    const LongDesc* desc;
+    const uint32_t* desc_count;
+    uint32_t* parts;
+    uint32_t desc_cap;
 };
 struct HeavyJobs { HeavyJob j[MSM_HEAVY_JOBS]; };
 // counters of window w at heavy_count + w * MSM_HEAVY_COUNTERS: [0] level-1 runs, [1] level-B runs, [2] level-C runs, [3] parts of level 2, [4] of level 3,
@@ -525,6 +572,11 @@ __device__ __forceinline__ void msm_heavy_push(uint32_t b, uint32_t start, uint3
     runsC[atomicAdd(&cnt[2], 1u)] = HeavyRun{p3, n2, b, 0};
 }
 
+// bucket b of window w holds c > cap entries from offs_t on: descriptors of its chunks (over-long) or runs (heavy)
+__device__ __forceinline__ void msm_long_register(uint32_t w, uint32_t b, uint32_t c, uint32_t offs_t, int n_win, uint32_t cap, uint32_t desc_cap,
+                                                  LongDesc* __restrict__ desc, uint32_t* __restrict__ desc_count, uint32_t run_cap,
+                                                  HeavyRun* __restrict__ heavy_runs);
+
 __global__ __launch_bounds__(256) void msm_long_find_kernel(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs, uint32_t M, int n_win,
                                                             uint32_t cap, uint32_t desc_cap, LongDesc* __restrict__ desc,
                                                             uint32_t* __restrict__ desc_count, uint32_t run_cap, HeavyRun* __restrict__ heavy_runs) {
@@ -532,10 +584,14 @@ __global__ __launch_bounds__(256) void msm_long_find_kernel(const uint32_t* __re
     if (t >= (unsigned long long)n_win * M) return;
     const uint32_t c = hist[t];
     if (c <= cap) return;
-    const uint32_t w = (uint32_t)(t / M), b = (uint32_t)(t % M);
+    msm_long_register((uint32_t)(t / M), (uint32_t)(t % M), c, offs[t], n_win, cap, desc_cap, desc, desc_count, run_cap, heavy_runs);
+}
+__device__ __forceinline__ void msm_long_register(uint32_t w, uint32_t b, uint32_t c, uint32_t offs_t, int n_win, uint32_t cap, uint32_t desc_cap,
+                                                  LongDesc* __restrict__ desc, uint32_t* __restrict__ desc_count, uint32_t run_cap,
+                                                  HeavyRun* __restrict__ heavy_runs) {
     if (msm_is_heavy(c, cap)) {                                        // heavy: its own kernels take ALL its entries
         HeavyRun* base = heavy_runs + (size_t)w * 3 * run_cap;
-        msm_heavy_push(b, offs[t], c, run_cap, desc_count + n_win + (size_t)w * MSM_HEAVY_COUNTERS, base, base + run_cap, base + 2 * (size_t)run_cap);
+        msm_heavy_push(b, offs_t, c, run_cap, desc_count + n_win + (size_t)w * MSM_HEAVY_COUNTERS, base, base + run_cap, base + 2 * (size_t)run_cap);
         return;
     }
     const uint32_t nch = (c - cap + cap - 1) / cap;
@@ -544,7 +600,7 @@ __global__ __launch_bounds__(256) void msm_long_find_kernel(const uint32_t* __re
         if (pos + j >= desc_cap) break;                      // cannot happen: sum of (c-cap)/cap <= n/cap
         LongDesc d;
         d.bucket = b;
-        d.start = offs[t] + cap * (j + 1);
+        d.start = offs_t + cap * (j + 1);
         d.len = min(cap, c - cap * (j + 1));
         d.idx_in_run = j;
         d.run_len = nch;
@@ -571,13 +627,64 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_long_chunk_kernel(const u
     EC::store_pt(parts, (size_t)w * desc_cap + i, acc);
 }
 
+// The leaf sums of BOTH rare paths in one launch (round 5; bit-identical to the two kernels above and below, which it replaces in
+// msm.hip): workgroups [0, long_blocks) take a chunk descriptor per thread (msm_long_chunk_kernel), the others a heavy level-1 run per
+// workgroup, MSM_HEAVY_PER_THREAD entries per thread (msm_heavy_chunk_kernel).  Either way a thread sums `cnt` consecutive entries of the
+// sorted list into one partial sum: ONE loop, one call site of EC::madd.  blockIdx.y = window, blockIdx.z = MSM of the batch.
+template <class EC>
+__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_rare_leaf_kernel(HeavyJobs jobs, uint32_t long_blocks) {
+    const HeavyJob& jb = jobs.j[blockIdx.z];
+    const uint32_t w = blockIdx.y, t = threadIdx.x;
+    const bool is_long = blockIdx.x < long_blocks;
+    const uint32_t heavy_cnt = is_long ? 0u : min(jb.count[(size_t)w * MSM_HEAVY_COUNTERS], jb.run_cap);
+    const HeavyRun* runs = jb.runs + (size_t)w * 3 * jb.run_cap;
+    const uint32_t r_step = is_long ? 1u : gridDim.x - long_blocks;
+    uint32_t r = is_long ? 0u : blockIdx.x - long_blocks;
+    for (;; r += r_step) {
+        const uint32_t* list;
+        uint32_t cnt;
+        uint32_t* out;
+        size_t out_idx;
+        if (is_long) {
+            if (r) break;                                              // one descriptor per thread
+            const uint32_t i = blockIdx.x * MSM_ACC_THREADS + t;
+            if (i >= min(jb.desc_count[w], jb.desc_cap)) break;
+            const LongDesc d = jb.desc[(size_t)w * jb.desc_cap + i];
+            list = jb.sorted + (size_t)w * jb.n + d.start;
+            cnt = d.len;
+            out = jb.parts;
+            out_idx = (size_t)w * jb.desc_cap + i;
+        } else {
+            if (r >= heavy_cnt) break;
+            const HeavyRun run = runs[r];
+            const uint32_t lo = t * MSM_HEAVY_PER_THREAD;
+            if (lo >= run.n) continue;
+            list = jb.sorted + (size_t)w * jb.n + run.src + lo;
+            cnt = min(run.n, lo + MSM_HEAVY_PER_THREAD) - lo;
+            out = jb.h1;
+            out_idx = (size_t)w * jb.h1_cap + run.p1 + t;
+        }
+        typename EC::Pt acc = EC::inf();
+        for (uint32_t k = 0; k < cnt; k++) {
+            const uint32_t e = list[k];
+            acc = EC::madd(acc, EC::load_aff(jb.bases, e & 0x7fffffffu), (e >> 31) != 0);
+        }
+        EC::store_pt(out, out_idx, acc);
+    }
+}
+
 // one thread per long bucket: its run of chunk sums (at most MSM_HEAVY_RUN / cap + 1 of them: longer buckets are heavy, see above) is added
 // to the bucket one after the other -- chains of a few additions, in parallel over the runs.  (Until round 3 ONE workgroup per window
 // walked a pairwise tree over all runs: 3 - 30 ms once tens of thousands of buckets were over-long.)  ONE call site of EC::add.
 template <class EC>
-__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_long_combine_kernel(const LongDesc* __restrict__ desc, const uint32_t* __restrict__ desc_count,
-                                                                            uint32_t desc_cap, uint32_t M, const uint32_t* __restrict__ parts,
-                                                                            uint32_t* __restrict__ buckets, uint8_t* __restrict__ occ) {
+__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_long_combine_kernel(HeavyJobs jobs) {
+    const HeavyJob& jb = jobs.j[blockIdx.z];
+    const LongDesc* __restrict__ desc = jb.desc;
+    const uint32_t* __restrict__ desc_count = jb.desc_count;
+    const uint32_t desc_cap = jb.desc_cap, M = jb.M;
+    const uint32_t* __restrict__ parts = jb.parts;
+    uint32_t* __restrict__ buckets = jb.buckets;
+    uint8_t* __restrict__ occ = jb.occ;
     const uint32_t w = blockIdx.y;
     const uint32_t cnt = min(desc_count[w], desc_cap);
     const LongDesc* dw = desc + (size_t)w * desc_cap;
@@ -697,11 +804,43 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_fold_kernel(uint32_t* __r
     fold_one<EC>(buckets, occ, base + i, base + h + i);
 }
 
+// TWO levels in one launch (round 5): half sizes h (level nseg) and h / 2 (level nseg + 1).  A thread owns the items i and i + h / 2 of one
+// segment: both folds of the first level, then the second level's fold of their sums; the thread of the MAIN segment also folds the segment
+// the first level leaves behind (the main array's upper half, T_nseg: its two sources are the operands this thread has just read).
+// Nothing a thread touches is touched by another.  h even.
+template <class EC>
+__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_fold2_kernel(uint32_t* __restrict__ buckets, uint8_t* __restrict__ occ, uint32_t M, uint32_t h, int nseg, int n_win) {
+    const uint32_t q = h >> 1;
+    const unsigned long long t = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
+    const unsigned long long per_win = (unsigned long long)nseg * q;
+    if (t >= per_win * n_win) return;
+    const unsigned long long w = t / per_win, r = t % per_win;
+    const uint32_t seg = (uint32_t)(r / q), i = (uint32_t)(r % q);
+    const unsigned long long base = w * M + (seg ? (M >> seg) : 0u);
+#pragma unroll 1
+    for (int step = 0; step < 4; step++) {                              // ONE call site of the addition (instruction cache: msm_split_combine_kernel)
+        if (step == 3 && seg) break;
+        const unsigned long long ia = base + (step == 1 ? q : (step == 3 ? h : 0u)) + i;
+        const unsigned long long ib = step < 2 ? ia + h : ia + q;
+        fold_one<EC>(buckets, occ, ia, ib);
+    }
+}
+template <class EC>
+__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_fold2_quad_kernel(uint32_t* buckets, uint8_t* occ, uint32_t M, uint32_t h, int nseg, int n_win);
+
 // the last levels of the recursive halving in ONE launch: a 256-thread workgroup per
 // bucket set walks the levels with a workgroup barrier between them (each level is one EC add deep,
 // so separate launches would pay a launch gap per level for a few hundred threads of work)
+// collect (nullable): the workgroup also writes its bucket set's log_m + 1 results (what msm_collect_kernel does in a launch of its own)
 template <class EC>
-__global__ __launch_bounds__(256) void msm_fold_tail_kernel(uint32_t* __restrict__ buckets, uint8_t* __restrict__ occ, uint32_t M, int log_m, int first_lvl) {
+__device__ __forceinline__ void collect_set(const uint32_t* buckets, const uint8_t* occ, uint32_t M, int log_m, unsigned long long w, uint32_t* out, int j) {
+    const unsigned long long slot = w * M + (j ? (M >> j) : 0u);
+    typename EC::Pt p = occ[slot] ? EC::load_pt(buckets, slot) : EC::inf();
+    store_xyzz<typename EC::Field>(out, (size_t)w * (log_m + 1) + j, EC::to_boundary(p));
+}
+template <class EC>
+__global__ __launch_bounds__(256) void msm_fold_tail_kernel(uint32_t* __restrict__ buckets, uint8_t* __restrict__ occ, uint32_t M, int log_m, int first_lvl,
+                                                            uint32_t* __restrict__ collect) {
     const unsigned long long w = blockIdx.x;
     for (int lvl = first_lvl; lvl <= log_m; lvl++) {
         const uint32_t h = M >> lvl;
@@ -714,6 +853,7 @@ __global__ __launch_bounds__(256) void msm_fold_tail_kernel(uint32_t* __restrict
         __threadfence_block();
         __syncthreads();
     }
+    if (collect && (int)threadIdx.x <= log_m) collect_set<EC>(buckets, occ, M, log_m, w, collect, (int)threadIdx.x);
 }
 
 // The same levels with FOUR lanes per addition (ecx.cuh, xyzzx_add_quad): lane k of a quad loads, adds and stores coordinate k.  For
@@ -732,7 +872,7 @@ __device__ __forceinline__ void fold_one_quad(uint32_t* buckets, uint8_t* occ, u
     if (!occ[ia]) {
 #pragma unroll
         for (int i = 0; i < XN; i++) pa[i] = cb.l[i];
-        if (role == 0) occ[ia] = 1;
+        occ[ia] = 1;                                                      // every lane of the quad: each then re-reads what IT wrote (msm_fold2_quad_kernel reads it again without a barrier)
         return;
     }
     Fx<X> ca;
@@ -755,7 +895,8 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_fold_quad_kernel(uint32_t
 }
 constexpr int MSM_TAIL_QUAD_THREADS = 512;
 template <class EC>
-__global__ __launch_bounds__(MSM_TAIL_QUAD_THREADS) void msm_fold_tail_quad_kernel(uint32_t* buckets, uint8_t* occ, uint32_t M, int log_m, int first_lvl) {
+__global__ __launch_bounds__(MSM_TAIL_QUAD_THREADS) void msm_fold_tail_quad_kernel(uint32_t* buckets, uint8_t* occ, uint32_t M, int log_m, int first_lvl,
+                                                                                    uint32_t* collect) {
     const unsigned long long w = blockIdx.x;
     const uint32_t quad = threadIdx.x >> 2;
     const int role = threadIdx.x & 3;
@@ -769,6 +910,26 @@ __global__ __launch_bounds__(MSM_TAIL_QUAD_THREADS) void msm_fold_tail_quad_kern
         }
         __threadfence_block();
         __syncthreads();
+    }
+    if (collect && (int)threadIdx.x <= log_m) collect_set<EC>(buckets, occ, M, log_m, w, collect, (int)threadIdx.x);
+}
+// two levels in one launch on quads of lanes (msm_fold2_kernel's item order)
+template <class EC>
+__global__ __launch_bounds__(MSM_ACC_THREADS) void msm_fold2_quad_kernel(uint32_t* buckets, uint8_t* occ, uint32_t M, uint32_t h, int nseg, int n_win) {
+    const uint32_t q = h >> 1;
+    const unsigned long long t = ((unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x) >> 2;
+    const int role = threadIdx.x & 3;
+    const unsigned long long per_win = (unsigned long long)nseg * q;
+    if (t >= per_win * n_win) return;
+    const unsigned long long w = t / per_win, r = t % per_win;
+    const uint32_t seg = (uint32_t)(r / q), i = (uint32_t)(r % q);
+    const unsigned long long base = w * M + (seg ? (M >> seg) : 0u);
+#pragma unroll 1
+    for (int step = 0; step < 4; step++) {
+        if (step == 3 && seg) break;
+        const unsigned long long ia = base + (step == 1 ? q : (step == 3 ? h : 0u)) + i;
+        const unsigned long long ib = step < 2 ? ia + h : ia + q;
+        fold_one_quad<EC>(buckets, occ, ia, ib, role);
     }
 }
 

@@ -85,6 +85,30 @@ void write_infinity(uint32_t* out_xyz) {
     one.to_words(out_xyz); one.to_words(out_xyz + FQ::N); z.to_words(out_xyz + 2 * FQ::N);
 }
 
+// the rare paths of `n_jobs` MSMs (over-long buckets: chunk sums + their combination; heavy buckets: level-1 sums + trees A, B[, C]) -- with
+// `diet` the leaf sums of both paths share one launch (msm_rare_leaf_kernel)
+template <class EC>
+int32_t launch_rare(const HeavyJobs& jobs, unsigned n_jobs, int sets, uint32_t desc_cap, uint32_t run_cap, bool level_c, bool diet, hipStream_t st) {
+    const uint32_t long_blocks = (desc_cap + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, heavy_blocks = std::min<uint32_t>(run_cap, 2048u);
+    const dim3 hg(heavy_blocks, sets, n_jobs);
+    if (diet) {
+        hipLaunchKernelGGL((msm_rare_leaf_kernel<EC>), dim3(long_blocks + heavy_blocks, sets, n_jobs), dim3(MSM_ACC_THREADS), 0, st, jobs, long_blocks);
+    } else {
+        for (unsigned q = 0; q < n_jobs; q++) {
+            const HeavyJob& jb = jobs.j[q];
+            hipLaunchKernelGGL((msm_long_chunk_kernel<EC>), dim3((jb.desc_cap + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, sets), dim3(MSM_ACC_THREADS), 0, st,
+                               jb.bases, jb.n, jb.sorted, jb.desc, jb.desc_count, jb.desc_cap, jb.parts);
+        }
+        hipLaunchKernelGGL((msm_heavy_chunk_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, jobs);
+    }
+    hipLaunchKernelGGL((msm_long_combine_kernel<EC>), dim3(std::min<uint32_t>(long_blocks, 1024u), sets, n_jobs), dim3(MSM_ACC_THREADS), 0, st, jobs);
+    hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, jobs, 0);
+    hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, jobs, 1);
+    if (level_c) hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), dim3(64, sets, n_jobs), dim3(MSM_ACC_THREADS), 0, st, jobs, 2);
+    HIP_TRY(hipGetLastError());
+    return MZK_OK;
+}
+
 // `count` MSMs that share the window size: sort + accumulate run one after the other (they fill the
 // chip on their own), the latency-bound recursive halving runs ONCE over all bucket sets, one copy
 // brings every partial sum to the host, and the host Horner tails run there in sequence (threads only when there are many).
@@ -193,7 +217,16 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
         }
     }
     const uint32_t n_bins = (pre.c || sort2) ? std::max<uint32_t>(1u, pb.count((uint32_t)wm)) : 0u;      // (table path, one MSM: wm == M)
-    const size_t cnt_words = 2048 + (size_t)sets * 1024;                 // bin totals, bin cursors, order keys
+    // Round 5, the launch diet of the two-level sort's paths: the order keys are counted by the sort's own workgroups, ONE kernel ranks the
+    // buckets AND registers the over-long / heavy ones (msm_order_place_kernel), the leaf sums of both rare paths share a launch, the
+    // reduction halves twice per launch and its last launch also collects the results: 32 -> 21 launches per variable-base MSM of 2^20
+    // pairs, bit-identical.  MZK_MSM_LEGACY_LAUNCHES=1: the round-4 sequence (A/B).
+    static const bool legacy_launches = std::getenv("MZK_MSM_LEGACY_LAUNCHES") != nullptr;
+    const bool diet = (pre.c || sort2) && !legacy_launches;
+    const size_t cnt_words = 2048 + (size_t)sets * 1024 * (diet ? 2 : 1);  // bin totals, bin cursors, order keys (diet: and their cursors)
+    // the over-long buckets are registered inside the sort only when the sort may write this MSM's descriptors while the stream `st` still
+    // works on the previous MSM of the batch: every MSM has a slot of its own (defer_heavy), or there is no second stream
+    const bool find_in_sort = diet && (!overlap || defer_heavy);
     MZK_TRY(g_ws.pre_cnt.reserve(nb * cnt_words * 4));
     if (pre.c || sort2) {
         MZK_TRY(g_ws.pre_off.reserve(nb * 8192 * 4));                      // bin_start [n_bins + 1 <= 1025], then the huge-bin words (msm_pre.cuh)
@@ -214,7 +247,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     uint32_t* collect = g_ws.collect.as<uint32_t>();
     HeavyJobs jobs;
     std::memset(&jobs, 0, sizeof jobs);
-    uint32_t heavy_run_cap_max = 0;
+    uint32_t heavy_run_cap_max = 0, long_desc_cap_max = 0;
     bool heavy_level_c = false;
     static const int n_sort_streams = std::min(4, std::max(1, std::getenv("MZK_MSM_SORT_STREAMS") ? std::atoi(std::getenv("MZK_MSM_SORT_STREAMS")) : 2));       // (A/B switch)
     SortStreams& ss = g_sort[cur().logical];
@@ -318,14 +351,15 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 const uint32_t slice = (uint32_t)std::max<uint64_t>(16384, (records + 2047) / 2048);
                 const uint32_t slice_grid = (uint32_t)std::min<uint64_t>(PRE_SLICE_CAP, records / slice + PRE_HUGE_MAX + 1);
                 const uint32_t huge_grid = (uint32_t)std::min<uint64_t>(PRE_HUGE_MAX, records / PRE_HUGE + 1);
-                hipLaunchKernelGGL(pre_bin_scan_kernel, dim3(1), dim3(1024), 0, sst, bin_total, (int)n_bins, bin_start, bin_cursor, slice, huge);
+                hipLaunchKernelGGL(pre_bin_scan_kernel, dim3(1), dim3(1024), 0, sst, bin_total, (int)n_bins, bin_start, bin_cursor, slice, huge,
+                                   find_in_sort ? desc_count : nullptr, (uint32_t)sets * (1 + MSM_HEAVY_COUNTERS));
                 hipLaunchKernelGGL(pre_coarse_scatter_kernel, coarse_grid, dim3(PRE_CTHREADS), 0, sst, dig32, n, dstride, n_dig, (int)n_bins, pb, bstride, chunk,
                                    pre.c ? pre.tab_stride : 0ull, pre.c ? items[p].base_off : 0ull, multi, bin_cursor, coarse);
-                hipLaunchKernelGGL(pre_fine_kernel, dim3(n_bins), dim3(1024), 0, sst, bin_start, coarse, (uint32_t)wm, pb, hist, offs, sorted, huge);
-                if (records > PRE_HUGE) {                                // (no bin of a sort with at most PRE_HUGE records can be huge: four launches less for small MSMs)
-                    hipLaunchKernelGGL(pre_huge_zero_kernel, dim3(huge_grid), dim3(1024), 0, sst, huge, (uint32_t)wm, pb, hist);
+                uint32_t* keycnt_sort = diet ? cnt + 2048 : nullptr;     // [sets][1024] order keys, counted by the sort's own workgroups
+                hipLaunchKernelGGL(pre_fine_kernel, dim3(n_bins), dim3(1024), 0, sst, bin_start, coarse, (uint32_t)wm, pb, hist, offs, sorted, huge, M, keycnt_sort);
+                if (records > PRE_HUGE) {                                // (no bin of a sort with at most PRE_HUGE records can be huge: three launches less for small MSMs)
                     hipLaunchKernelGGL(pre_huge_count_kernel, dim3(slice_grid), dim3(1024), 0, sst, huge, bin_start, coarse, (uint32_t)wm, pb, slice, hist);
-                    hipLaunchKernelGGL(pre_huge_scan_kernel, dim3(huge_grid), dim3(1024), 0, sst, huge, bin_start, (uint32_t)wm, pb, hist, offs, order);
+                    hipLaunchKernelGGL(pre_huge_scan_kernel, dim3(huge_grid), dim3(1024), 0, sst, huge, bin_start, (uint32_t)wm, pb, hist, offs, order, M, keycnt_sort);
                     hipLaunchKernelGGL(pre_huge_scatter_kernel, dim3(slice_grid), dim3(1024), 0, sst, huge, bin_start, coarse, (uint32_t)wm, pb, slice, order, sorted);
                 }
             }
@@ -335,9 +369,14 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 uint32_t* keycnt = g_ws.pre_cnt.as<uint32_t>() + b * cnt_words + 2048;       // [sets][1024]
                 const unsigned slices = (M + MSM_ORDER_SLICE - 1) / MSM_ORDER_SLICE;
                 if (!pre.c && !sort2) HIP_TRY(hipMemsetAsync(keycnt, 0, (size_t)sets * 1024 * 4, sst));    // (two-level sort: zeroed with the bin totals above)
-                hipLaunchKernelGGL(msm_order_hist_kernel, dim3(slices, sets), dim3(1024), 0, sst, hist, M, keycnt);
-                hipLaunchKernelGGL(msm_order_scan_kernel, dim3(sets), dim3(1024), 0, sst, keycnt);
-                hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(slices, sets), dim3(1024), 0, sst, hist, M, keycnt, order);
+                if (diet) {
+                    hipLaunchKernelGGL(msm_order_place_kernel, dim3(slices, sets), dim3(1024), 0, sst, hist, offs, M, keycnt, keycnt + (size_t)sets * 1024, order,
+                                       sets, cap, desc_cap, desc, find_in_sort ? desc_count : nullptr, run_cap, heavy_runs);
+                } else {
+                    hipLaunchKernelGGL(msm_order_hist_kernel, dim3(slices, sets), dim3(1024), 0, sst, hist, M, keycnt);
+                    hipLaunchKernelGGL(msm_order_scan_kernel, dim3(sets), dim3(1024), 0, sst, keycnt);
+                    hipLaunchKernelGGL(msm_order_scatter_kernel, dim3(slices, sets), dim3(1024), 0, sst, hist, M, keycnt, order);
+                }
             }
             if (overlap) {
                 HIP_TRY(hipEventRecord(ss.ev_sorted[b], sst));
@@ -359,7 +398,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 if (log_split == 0) {
                     ProfScope ps("msm_accumulate", st);
                     hipLaunchKernelGGL((msm_accumulate_kernel<EC>), dim3((unsigned)((wm + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
-                                       d_bases, list_stride, offs, hist, sorted, order, M, sets, cap, desc_count, buckets, occ);
+                                       d_bases, list_stride, offs, hist, sorted, order, M, sets, cap, find_in_sort ? nullptr : desc_count, buckets, occ);
                 } else {
                     const size_t threads = wm << log_split;
                     MZK_TRY(g_ws.split.reserve(threads * EC::PT_WORDS * 4));
@@ -367,7 +406,8 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                     {
                         ProfScope ps("msm_accumulate", st);               // the dominant launch alone: what rocprofv3 --stats averages
                         hipLaunchKernelGGL((msm_accumulate_split_kernel<EC>), dim3((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)),
-                                           dim3(MSM_ACC_THREADS), 0, st, d_bases, list_stride, offs, hist, sorted, order, M, sets, cap, log_split, desc_count, sub);
+                                           dim3(MSM_ACC_THREADS), 0, st, d_bases, list_stride, offs, hist, sorted, order, M, sets, cap, log_split,
+                                           find_in_sort ? nullptr : desc_count, sub);
                     }
                     ProfScope pc("msm_split_combine", st);
                     hipLaunchKernelGGL((msm_split_combine_kernel<EC>), dim3((unsigned)((threads + 2 * MSM_ACC_THREADS - 1) / (2 * MSM_ACC_THREADS))), dim3(MSM_ACC_THREADS),
@@ -377,37 +417,25 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
             {
                 // over-long buckets (skewed scalars); no-ops for uniformly random scalars
                 ProfScope ps("msm_long", st);
-                hipLaunchKernelGGL(msm_long_find_kernel, dim3((unsigned)((wm + 255) / 256)), dim3(256), 0, st, hist, offs, M, sets, cap, desc_cap, desc, desc_count,
-                                   run_cap, heavy_runs);
-                hipLaunchKernelGGL((msm_long_chunk_kernel<EC>), dim3((desc_cap + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, sets), dim3(MSM_ACC_THREADS), 0, st,
-                                   d_bases, list_stride, sorted, desc, desc_count, desc_cap, parts);
-                hipLaunchKernelGGL((msm_long_combine_kernel<EC>), dim3(std::min<uint32_t>((desc_cap + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS, 1024u), sets),
-                                   dim3(MSM_ACC_THREADS), 0, st, desc, desc_count, desc_cap, M, parts, buckets, occ);
+                if (!find_in_sort)
+                    hipLaunchKernelGGL(msm_long_find_kernel, dim3((unsigned)((wm + 255) / 256)), dim3(256), 0, st, hist, offs, M, sets, cap, desc_cap, desc, desc_count,
+                                       run_cap, heavy_runs);
                 // heavy buckets: a workgroup per run of MSM_HEAVY_RUN entries, then workgroup trees (levels A, B; C only when a bucket can hold
                 // more than MSM_HEAVY_RUN * MSM_HEAVY_FANIN entries).  Every workgroup exits at once when there is no heavy bucket.
                 HeavyJob& jb = jobs.j[defer_heavy ? p : 0];
                 jb.bases = d_bases; jb.sorted = sorted; jb.n = list_stride; jb.runs = heavy_runs; jb.count = heavy_count;
                 jb.h1 = h1; jb.h2 = h2; jb.h3 = h3; jb.buckets = buckets; jb.occ = occ; jb.run_cap = run_cap; jb.h1_cap = h1_cap; jb.M = M;
+                jb.desc = desc; jb.desc_count = desc_count; jb.parts = parts; jb.desc_cap = desc_cap;
                 heavy_run_cap_max = std::max(heavy_run_cap_max, run_cap);
+                long_desc_cap_max = std::max(long_desc_cap_max, desc_cap);
                 heavy_level_c = heavy_level_c || n_sorted > (uint64_t)MSM_HEAVY_RUN * MSM_HEAVY_FANIN;
-                if (!defer_heavy) {
-                    const dim3 hg(std::min<uint32_t>(run_cap, 2048u), sets, 1);
-                    hipLaunchKernelGGL((msm_heavy_chunk_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, jobs);
-                    hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, jobs, 0);
-                    hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, jobs, 1);
-                    if (n_sorted > (uint64_t)MSM_HEAVY_RUN * MSM_HEAVY_FANIN)
-                        hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), dim3(64, sets, 1), dim3(MSM_ACC_THREADS), 0, st, jobs, 2);
-                }
+                if (!defer_heavy) MZK_TRY((launch_rare<EC>(jobs, 1, sets, desc_cap, run_cap, n_sorted > (uint64_t)MSM_HEAVY_RUN * MSM_HEAVY_FANIN, diet, st)));
             }
             if (overlap) HIP_TRY(hipEventRecord(ss.ev_acc[b], st));
         }
-        if (defer_heavy) {                                          // the heavy buckets of all MSMs of the batch, one launch per level
+        if (defer_heavy) {                                          // the over-long and heavy buckets of all MSMs of the batch, one launch per level
             ProfScope ps("msm_long", st);
-            const dim3 hg(std::min<uint32_t>(heavy_run_cap_max, 2048u), sets, (unsigned)passes);
-            hipLaunchKernelGGL((msm_heavy_chunk_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, jobs);
-            hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, jobs, 0);
-            hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), hg, dim3(MSM_ACC_THREADS), 0, st, jobs, 1);
-            if (heavy_level_c) hipLaunchKernelGGL((msm_heavy_reduce_kernel<EC>), dim3(64, sets, (unsigned)passes), dim3(MSM_ACC_THREADS), 0, st, jobs, 2);
+            MZK_TRY((launch_rare<EC>(jobs, (unsigned)passes, sets, long_desc_cap_max, heavy_run_cap_max, heavy_level_c, diet, st)));
         }
         {
             ProfScope ps("msm_reduce", st);
@@ -422,6 +450,21 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
             for (int lvl = 1; lvl < first_tail; lvl++) {
                 const uint32_t h = M >> lvl;
                 const size_t threads = (size_t)nw_all * lvl * h;
+                // (two levels per launch -- msm.cuh, msm_fold2_kernel -- measured SLOWER, profiles/r05_msm_launch_diet.txt: the second level's
+                // operands are the first level's results, a store -> load round trip per addition that two launches overlap across threads;
+                // MZK_MSM_FOLD2=1 switches it on for A/B)
+                static const bool fold2 = std::getenv("MZK_MSM_FOLD2") != nullptr;
+                if (fold2 && diet && lvl + 1 < first_tail && h >= 2) {
+                    const size_t t2 = (size_t)nw_all * lvl * (h >> 1);
+                    if (threads <= quad_max)
+                        hipLaunchKernelGGL((msm_fold2_quad_kernel<EC>), dim3((unsigned)((4 * t2 + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
+                                           buckets, occ, M, h, lvl, nw_all);
+                    else
+                        hipLaunchKernelGGL((msm_fold2_kernel<EC>), dim3((unsigned)((t2 + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
+                                           buckets, occ, M, h, lvl, nw_all);
+                    lvl++;
+                    continue;
+                }
                 if (threads <= quad_max)
                     hipLaunchKernelGGL((msm_fold_quad_kernel<EC>), dim3((unsigned)((4 * threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
                                        buckets, occ, M, h, lvl, nw_all);
@@ -429,11 +472,13 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                     hipLaunchKernelGGL((msm_fold_kernel<EC>), dim3((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
                                        buckets, occ, M, h, lvl, nw_all);
             }
+            uint32_t* tail_collect = diet ? collect : nullptr;          // the last launch of the halving also writes the results
             if (first_tail <= log_m) {
-                if (quad_max) hipLaunchKernelGGL((msm_fold_tail_quad_kernel<EC>), dim3(nw_all), dim3(MSM_TAIL_QUAD_THREADS), 0, st, buckets, occ, M, log_m, first_tail);
-                else hipLaunchKernelGGL((msm_fold_tail_kernel<EC>), dim3(nw_all), dim3(256), 0, st, buckets, occ, M, log_m, first_tail);
+                if (quad_max) hipLaunchKernelGGL((msm_fold_tail_quad_kernel<EC>), dim3(nw_all), dim3(MSM_TAIL_QUAD_THREADS), 0, st, buckets, occ, M, log_m, first_tail, tail_collect);
+                else hipLaunchKernelGGL((msm_fold_tail_kernel<EC>), dim3(nw_all), dim3(256), 0, st, buckets, occ, M, log_m, first_tail, tail_collect);
             }
-            hipLaunchKernelGGL((msm_collect_kernel<EC>), dim3((n_out + 63) / 64), dim3(64), 0, st, buckets, occ, M, log_m, nw_all, collect);
+            if (!tail_collect || first_tail > log_m)
+                hipLaunchKernelGGL((msm_collect_kernel<EC>), dim3((n_out + 63) / 64), dim3(64), 0, st, buckets, occ, M, log_m, nw_all, collect);
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(g_ws.h_collect, collect, out_bytes, hipMemcpyDeviceToHost, st));

@@ -110,10 +110,15 @@ constexpr uint32_t PRE_HUGE = 131072;
 constexpr int PRE_HUGE_MAX = 128;             // huge bins per sort (more: the rest stays with pre_fine_kernel -- slow, still correct)
 constexpr int PRE_SLICE_CAP = 2816;           // slice descriptors per sort
 // layout of the per-sort words at `huge` (after bin_start in the pre_off block): [0] huge bins, [1] slices, [2 ..] bins, [256 ..] slices (bin << 16 | j)
+// zero_words (nullable): n_zero words this one-workgroup launch clears on the way -- the over-long / heavy bucket counters of the MSM
+// (msm.cuh), which msm_order_place_kernel counts into later in the same sort
 __global__ __launch_bounds__(1024) void pre_bin_scan_kernel(const uint32_t* __restrict__ bin_total, int n_bins, uint32_t* __restrict__ bin_start,
-                                                            uint32_t* __restrict__ bin_cursor, uint32_t slice, uint32_t* __restrict__ huge) {
+                                                            uint32_t* __restrict__ bin_cursor, uint32_t slice, uint32_t* __restrict__ huge,
+                                                            uint32_t* __restrict__ zero_words, uint32_t n_zero) {
     __shared__ uint32_t part[1024];
     const int t = threadIdx.x;
+    if (zero_words)
+        for (uint32_t i = (uint32_t)t; i < n_zero; i += 1024) zero_words[i] = 0u;
     const uint32_t mine = t < n_bins ? bin_total[t] : 0u;
     part[t] = mine;
     if (t < 2) huge[t] = 0u;
@@ -143,13 +148,8 @@ __device__ __forceinline__ bool pre_is_huge(const uint32_t* __restrict__ huge, u
         if (huge[2 + h] == bin) return true;
     return false;
 }
-// one workgroup per slice of a huge bin: bucket histogram of the slice -> hist (zeroed by pre_huge_zero_kernel)
-__global__ __launch_bounds__(1024) void pre_huge_zero_kernel(const uint32_t* __restrict__ huge, uint32_t M, PreBins pb, uint32_t* __restrict__ hist) {
-    const uint32_t h = blockIdx.x;
-    if (h >= min(huge[0], (uint32_t)PRE_HUGE_MAX)) return;
-    const uint32_t bin = huge[2 + h], rsize = pb.size_of(bin, M), bucket0 = pb.first_bucket(bin);
-    for (uint32_t j = threadIdx.x; j < rsize; j += 1024) hist[bucket0 + j] = 0u;
-}
+// one workgroup per slice of a huge bin: bucket histogram of the slice -> hist (zeroed by the bin's own pre_fine workgroup, which leaves
+// the bin to these kernels)
 __global__ __launch_bounds__(1024) void pre_huge_count_kernel(const uint32_t* __restrict__ huge, const uint32_t* __restrict__ bin_start,
                                                               const unsigned long long* __restrict__ coarse, uint32_t M, PreBins pb, uint32_t slice,
                                                               uint32_t* __restrict__ hist) {
@@ -168,7 +168,8 @@ __global__ __launch_bounds__(1024) void pre_huge_count_kernel(const uint32_t* __
 }
 // one workgroup per huge bin: offs = bin start + exclusive scan of hist; cursor = offs (what pre_huge_scatter reserves from)
 __global__ __launch_bounds__(1024) void pre_huge_scan_kernel(const uint32_t* __restrict__ huge, const uint32_t* __restrict__ bin_start, uint32_t M, PreBins pb,
-                                                             const uint32_t* __restrict__ hist, uint32_t* __restrict__ offs, uint32_t* __restrict__ cursor) {
+                                                             const uint32_t* __restrict__ hist, uint32_t* __restrict__ offs, uint32_t* __restrict__ cursor,
+                                                             uint32_t set_size, uint32_t* __restrict__ keycnt /* nullable: [set][1024] order keys */) {
     __shared__ uint32_t part[1024];
     const uint32_t h = blockIdx.x, tid = threadIdx.x;
     if (h >= min(huge[0], (uint32_t)PRE_HUGE_MAX)) return;
@@ -185,11 +186,18 @@ __global__ __launch_bounds__(1024) void pre_huge_scan_kernel(const uint32_t* __r
         __syncthreads();
     }
     uint32_t run = start + part[tid] - sum;
+    __syncthreads();
+    part[tid] = 0u;                                                    // now the counts of the order keys (msm.cuh order_key) of this bin's buckets
+    __syncthreads();
     for (uint32_t j = tid * per; j < min(rsize, (tid + 1) * per); j++) {
+        const uint32_t c = hist[bucket0 + j];
         offs[bucket0 + j] = run;
         cursor[bucket0 + j] = run;
-        run += hist[bucket0 + j];
+        run += c;
+        if (keycnt) atomicAdd(&part[order_key(c)], 1u);
     }
+    __syncthreads();
+    if (keycnt && part[tid]) atomicAdd(&keycnt[(size_t)(bucket0 / set_size) * 1024 + tid], part[tid]);
 }
 // one workgroup per slice: counts again, reserves its range of every bucket with one global atomic, writes the entries
 __global__ __launch_bounds__(1024) void pre_huge_scatter_kernel(const uint32_t* __restrict__ huge, const uint32_t* __restrict__ bin_start,
@@ -270,7 +278,8 @@ constexpr uint32_t PRE_STAGE = 24576;        // entries staged per run (96 KiB)
 
 __global__ __launch_bounds__(1024) void pre_fine_kernel(const uint32_t* __restrict__ bin_start, const unsigned long long* __restrict__ coarse,
                                                         uint32_t M, PreBins pb, uint32_t* __restrict__ hist, uint32_t* __restrict__ offs,
-                                                        uint32_t* __restrict__ sorted, const uint32_t* __restrict__ huge) {
+                                                        uint32_t* __restrict__ sorted, const uint32_t* __restrict__ huge,
+                                                        uint32_t set_size, uint32_t* __restrict__ keycnt /* nullable: [set][1024] order keys, zeroed */) {
     __shared__ uint32_t bins[1 << PRE_FINE_LOG];          // counts, then scatter cursors (relative to the bin)
     __shared__ uint32_t loc[(1 << PRE_FINE_LOG) + 1];     // exclusive offsets of the buckets inside the bin
     __shared__ uint32_t part[1024];
@@ -279,7 +288,10 @@ __global__ __launch_bounds__(1024) void pre_fine_kernel(const uint32_t* __restri
     const uint32_t bin = blockIdx.x, tid = threadIdx.x;
     const uint32_t rsize = pb.size_of(bin, M), bucket0 = pb.first_bucket(bin);
     const uint32_t start = bin_start[bin], end = bin_start[bin + 1];
-    if (end - start > PRE_HUGE && pre_is_huge(huge, bin)) return;       // (uniform over the workgroup) sorted by pre_huge_* kernels
+    if (end - start > PRE_HUGE && pre_is_huge(huge, bin)) {             // (uniform over the workgroup) sorted by pre_huge_* kernels:
+        for (uint32_t j = tid; j < rsize; j += 1024) hist[bucket0 + j] = 0u;        // their slices count into hist
+        return;
+    }
     for (uint32_t j = tid; j < rsize; j += 1024) bins[j] = 0;
     __syncthreads();
     for (uint32_t k = start + tid; k < end; k += 4096) {
@@ -303,6 +315,9 @@ __global__ __launch_bounds__(1024) void pre_fine_kernel(const uint32_t* __restri
         __syncthreads();
     }
     uint32_t run = part[tid] - sum;                     // offset inside the bin
+    __syncthreads();
+    part[tid] = 0u;                                     // now the counts of the order keys of this bin's buckets (what msm_order_hist_kernel
+    __syncthreads();                                    // computed in a launch of its own: the ranking of the buckets by load, msm.cuh)
     for (uint32_t j = tid * per; j < min(rsize, (tid + 1) * per); j++) {
         const uint32_t c = bins[j];
         hist[bucket0 + j] = c;
@@ -310,9 +325,11 @@ __global__ __launch_bounds__(1024) void pre_fine_kernel(const uint32_t* __restri
         loc[j] = run;
         bins[j] = run;                                  // becomes the scatter cursor
         run += c;
+        if (keycnt) atomicAdd(&part[order_key(c)], 1u);
     }
     if (tid == 1023) loc[rsize] = end - start;
     __syncthreads();
+    if (keycnt && part[tid]) atomicAdd(&keycnt[(size_t)(bucket0 / set_size) * 1024 + tid], part[tid]);
     uint32_t lo = 0;                                    // uniform across the workgroup
     while (lo < rsize) {
         // the longest run of buckets [lo, hi) with at most PRE_STAGE entries; one over-long bucket forms a run of its own
