@@ -597,6 +597,20 @@ def main():
         del cs
         if ck is not pp:
             ck.release()
+        # HBM held by a prover of a DENSE witness (no Lagrange-basis key: snark.witness_is_small decides from a sample) and by the C5-shaped
+        # proof (UltraPlonk / BN254, 2^22 gates) -- child processes, so that the grow-only scratch is what THOSE proofs need
+        try:
+            import subprocess
+            hb = {}
+            for name, extra in (("dense_witness_prover", ["--log-n", str(pl), "--dense"]), ("c5_shape_ultra_bn254_2p22", ["--ultra", "--log-n", "22"])):
+                if name.startswith("c5") and pl < 20:
+                    continue                                    # (toy sizes of the contract test: skip the 2^22 proof)
+                r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "hbm_report.py")] + extra, capture_output=True, text=True, timeout=600)
+                d_ = json.loads(r.stdout.strip().splitlines()[-1])
+                hb[name] = {"hbm_total_bytes": d_["hbm_bytes"]["total"], "library_scratch": d_["hbm_bytes"]["library_scratch"], "prove_ms": d_["prove_ms"]}
+            prove["hbm_other_provers"] = hb
+        except Exception as e:                                  # noqa: BLE001  (secondary)
+            prove["hbm_other_provers"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:200])}
         # K proofs IN FLIGHT on this one card: K host threads, each with its own device context and prover handle (every handle runs on a
         # stream of its own, csrc/prover.hip) -- a child process, because the K contexts are configured before the library is loaded
         try:
@@ -969,6 +983,9 @@ def main():
                          "prove_from_host_witness_vector_ms": prove["from_host_witness_vector_ms"],
                          "kernel_launches_per_proof": prove["kernel_launches_per_proof"], "hbm_total_bytes": prove["hbm_bytes"]["total"],
                          "prove_log_n": prove["log_n"]})
+            for name_, v_ in (prove.get("hbm_other_provers") or {}).items():
+                if isinstance(v_, dict) and "hbm_total_bytes" in v_:
+                    flat["hbm_total_bytes_" + name_] = v_["hbm_total_bytes"]
             for k_, v_ in (prove.get("in_flight") or {}).items():
                 if isinstance(v_, (int, float, bool)):
                     flat["prove_" + k_] = v_

@@ -45,6 +45,7 @@ struct Workspace {
     DevBuf ntt_scratch, scalars, hist, offs, cursor, sorted, buckets, collect, io, misc, digits, long_desc, long_parts, plonk_polys, plonk_out, pre_cnt, pre_off, pre_ce, pre_cb, poly_tmp, split, link_tmp, occ;
     void* h_collect = nullptr;
     size_t h_collect_cap = 0;
+    double heavy_frac = 0.125;          // msm.hip: share of the worst case the heavy buckets' level-1 sums are sized for (grows on overflow, with a re-run)
     hipEvent_t last_use = nullptr;
     void release();
     size_t bytes();

@@ -227,11 +227,11 @@ struct LongDesc;
 struct HeavyRun;
 __device__ __forceinline__ void msm_long_register(uint32_t w, uint32_t b, uint32_t c, uint32_t offs_t, int n_win, uint32_t cap, uint32_t desc_cap,
                                                   LongDesc* __restrict__ desc, uint32_t* __restrict__ desc_count, uint32_t run_cap,
-                                                  HeavyRun* __restrict__ heavy_runs);
+                                                  uint32_t h1_cap, HeavyRun* __restrict__ heavy_runs);
 __global__ __launch_bounds__(1024) void msm_order_place_kernel(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs, uint32_t M,
                                                                const uint32_t* __restrict__ keycnt, uint32_t* __restrict__ keycur, uint32_t* __restrict__ order,
                                                                int n_win, uint32_t cap, uint32_t desc_cap, LongDesc* __restrict__ desc,
-                                                               uint32_t* __restrict__ desc_count, uint32_t run_cap, HeavyRun* __restrict__ heavy_runs) {
+                                                               uint32_t* __restrict__ desc_count, uint32_t run_cap, uint32_t h1_cap, HeavyRun* __restrict__ heavy_runs) {
     __shared__ uint32_t cnt[1024];
     __shared__ uint32_t part[1024];
     const uint32_t w = blockIdx.y, t = threadIdx.x;
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(1024) void msm_order_place_kernel(const uint32_t* _
         const uint32_t c = hist[(size_t)w * M + b];
         const uint32_t pos = atomicAdd(&cnt[order_key(c)], 1u);
         order[(size_t)w * M + pos] = b;
-        if (desc_count && c > cap) msm_long_register(w, b, c, offs[(size_t)w * M + b], n_win, cap, desc_cap, desc, desc_count, run_cap, heavy_runs);
+        if (desc_count && c > cap) msm_long_register(w, b, c, offs[(size_t)w * M + b], n_win, cap, desc_cap, desc, desc_count, run_cap, h1_cap, heavy_runs);
     }
 }
 
@@ -552,12 +552,18 @@ struct HeavyJob {
 struct HeavyJobs { HeavyJob j[MSM_HEAVY_JOBS]; };
 // counters of window w at heavy_count + w * MSM_HEAVY_COUNTERS: [0] level-1 runs, [1] level-B runs, [2] level-C runs, [3] parts of level 2, [4] of level 3,
 // [5] level-1 partial sums (one per MSM_HEAVY_PER_THREAD entries of a run)
-__device__ __forceinline__ void msm_heavy_push(uint32_t b, uint32_t start, uint32_t rem, uint32_t run_cap, uint32_t* __restrict__ cnt,
+__device__ __forceinline__ void msm_heavy_push(uint32_t b, uint32_t start, uint32_t rem, uint32_t run_cap, uint32_t h1_cap, uint32_t* __restrict__ cnt,
                                                HeavyRun* __restrict__ runs0, HeavyRun* __restrict__ runsB, HeavyRun* __restrict__ runsC) {
     const uint32_t n1 = (rem + MSM_HEAVY_RUN - 1) / MSM_HEAVY_RUN;
+    // the level-1 partial sums of this bucket: a range of the window's h1 array.  The array is sized OPTIMISTICALLY (msm.hip: a fraction of
+    // the worst case "every entry sits in a heavy bucket", remembered per device context): a bucket that does not fit registers nothing, the
+    // counter keeps counting what WOULD have been needed, and the host -- which reads the counters with the results -- grows the array and
+    // runs the group again.  Round 5: 1.33 GB of scratch for five 2^20-pair MSMs -> what their heavy buckets really hold.
+    const uint32_t need = (rem + MSM_HEAVY_PER_THREAD - 1) / MSM_HEAVY_PER_THREAD + n1;                     // (rounding slack: one per run)
+    const uint32_t p1 = atomicAdd(&cnt[5], need);
+    if (p1 + need > h1_cap) return;
     const uint32_t r0 = atomicAdd(&cnt[0], n1);
     if (r0 + n1 > run_cap) return;                                     // cannot happen: run_cap >= 2 * entries / MSM_HEAVY_RUN + 2 (a heavy bucket holds more than MSM_HEAVY_RUN entries)
-    const uint32_t p1 = atomicAdd(&cnt[5], (rem + MSM_HEAVY_PER_THREAD - 1) / MSM_HEAVY_PER_THREAD + n1);     // (rounding slack: one per run)
     constexpr uint32_t PER_RUN = MSM_HEAVY_RUN / MSM_HEAVY_PER_THREAD;
     if (n1 == 1) { runs0[r0] = HeavyRun{start, rem, b, p1}; return; }
     const uint32_t p2 = atomicAdd(&cnt[3], n1);
@@ -575,29 +581,29 @@ __device__ __forceinline__ void msm_heavy_push(uint32_t b, uint32_t start, uint3
 // bucket b of window w holds c > cap entries from offs_t on: descriptors of its chunks (over-long) or runs (heavy)
 __device__ __forceinline__ void msm_long_register(uint32_t w, uint32_t b, uint32_t c, uint32_t offs_t, int n_win, uint32_t cap, uint32_t desc_cap,
                                                   LongDesc* __restrict__ desc, uint32_t* __restrict__ desc_count, uint32_t run_cap,
-                                                  HeavyRun* __restrict__ heavy_runs);
+                                                  uint32_t h1_cap, HeavyRun* __restrict__ heavy_runs);
 
 __global__ __launch_bounds__(256) void msm_long_find_kernel(const uint32_t* __restrict__ hist, const uint32_t* __restrict__ offs, uint32_t M, int n_win,
                                                             uint32_t cap, uint32_t desc_cap, LongDesc* __restrict__ desc,
-                                                            uint32_t* __restrict__ desc_count, uint32_t run_cap, HeavyRun* __restrict__ heavy_runs) {
+                                                            uint32_t* __restrict__ desc_count, uint32_t run_cap, uint32_t h1_cap, HeavyRun* __restrict__ heavy_runs) {
     const unsigned long long t = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (unsigned long long)n_win * M) return;
     const uint32_t c = hist[t];
     if (c <= cap) return;
-    msm_long_register((uint32_t)(t / M), (uint32_t)(t % M), c, offs[t], n_win, cap, desc_cap, desc, desc_count, run_cap, heavy_runs);
+    msm_long_register((uint32_t)(t / M), (uint32_t)(t % M), c, offs[t], n_win, cap, desc_cap, desc, desc_count, run_cap, h1_cap, heavy_runs);
 }
 __device__ __forceinline__ void msm_long_register(uint32_t w, uint32_t b, uint32_t c, uint32_t offs_t, int n_win, uint32_t cap, uint32_t desc_cap,
                                                   LongDesc* __restrict__ desc, uint32_t* __restrict__ desc_count, uint32_t run_cap,
-                                                  HeavyRun* __restrict__ heavy_runs) {
+                                                  uint32_t h1_cap, HeavyRun* __restrict__ heavy_runs) {
     if (msm_is_heavy(c, cap)) {                                        // heavy: its own kernels take ALL its entries
         HeavyRun* base = heavy_runs + (size_t)w * 3 * run_cap;
-        msm_heavy_push(b, offs_t, c, run_cap, desc_count + n_win + (size_t)w * MSM_HEAVY_COUNTERS, base, base + run_cap, base + 2 * (size_t)run_cap);
+        msm_heavy_push(b, offs_t, c, run_cap, h1_cap, desc_count + n_win + (size_t)w * MSM_HEAVY_COUNTERS, base, base + run_cap, base + 2 * (size_t)run_cap);
         return;
     }
     const uint32_t nch = (c - cap + cap - 1) / cap;
     const uint32_t pos = atomicAdd(&desc_count[w], nch);
+    if (pos + nch > desc_cap) return;                        // optimistic size (msm.hip): all of the bucket's chunks or none -- the host sees desc_count > desc_cap and runs the group again
     for (uint32_t j = 0; j < nch; j++) {
-        if (pos + j >= desc_cap) break;                      // cannot happen: sum of (c-cap)/cap <= n/cap
         LongDesc d;
         d.bucket = b;
         d.start = offs_t + cap * (j + 1);

@@ -53,6 +53,7 @@ struct MsmItem {
     uint64_t base_off;           // pre path: index of this MSM's first SRS point
 };
 constexpr unsigned long long MSM_MIN_CAP = 48;
+constexpr int32_t MSM_RETRY = 1;                 // internal: msm_group_dev wants to run again (never leaves this file)
 struct PreInfo { int c = 0; uint64_t tab_stride = 0; };      // c == 0: plain path
 
 // A batch of MSMs sorts on a second stream: the sort of MSM p + 1 (memory- and LDS-bound, few registers) runs under the
@@ -149,25 +150,48 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     MZK_TRY(g_ws.hist.reserve(nb * wm * 4));
     MZK_TRY(g_ws.offs.reserve(nb * wm * 4));
     MZK_TRY(g_ws.cursor.reserve(nb * wm * 4));                           // bucket order by load
-    const uint32_t desc_cap_max = (uint32_t)(sorted_max / MSM_MIN_CAP + 1);          // cap >= MSM_MIN_CAP below
+    const uint32_t desc_cap_worst = (uint32_t)(sorted_max / MSM_MIN_CAP + 1);        // cap >= MSM_MIN_CAP below
+    uint32_t desc_cap_max = desc_cap_worst;                                          // (optimistic with a slot per MSM, like h1_cap below)
     // heavy buckets (msm.cuh): per window <= entries / MSM_HEAVY_RUN full level-1 runs plus one partial run per heavy bucket
     const uint32_t run_cap_max = (uint32_t)(2 * (sorted_max / MSM_HEAVY_RUN) + 2);
-    const uint32_t h1_cap_max = (uint32_t)(sorted_max / MSM_HEAVY_PER_THREAD + 2 * (size_t)run_cap_max + 2);       // level-1 sums: one per 16 entries (+ slack per run)
+    // level-1 sums of the heavy buckets: one per 16 entries (+ slack per run) in the WORST case, every entry in a heavy bucket -- 197 MB
+    // per 2^20-pair table-path MSM, which almost no MSM needs.  With a slot per MSM (defer_heavy, below) the arrays are sized for a share
+    // of that, remembered per device context; the counters the kernels keep say what was really needed, the host reads them with the
+    // results, and a group that overflowed runs again with a larger share (msm.cuh, msm_heavy_push).
+    auto h1_cap_of = [](uint64_t entries, uint32_t run_cap_, double frac) {
+        const uint64_t worst = entries / MSM_HEAVY_PER_THREAD + 2 * (uint64_t)run_cap_ + 2;
+        return (uint32_t)std::min<uint64_t>(worst, (uint64_t)((double)worst * frac) + 2 * (uint64_t)run_cap_ + 4096);
+    };
+    const uint32_t h1_cap_worst = h1_cap_of(sorted_max, run_cap_max, 1.0);
+    uint32_t h1_cap_max = h1_cap_worst;
     const size_t heavy_runs_bytes = (size_t)sets * 3 * run_cap_max * sizeof(HeavyRun);
     // In a batch of at most SORT_SETS (and MSM_HEAVY_JOBS) MSMs every MSM keeps its own sorted list until the end, so their heavy
     // kernels are deferred and run as ONE launch per level over all of them (msm.cuh, HeavyJobs): each MSM then needs its own
     // descriptors, counters and partial sums ("slot").
-    const size_t desc_slot_bytes = (((size_t)sets * desc_cap_max * sizeof(LongDesc) + (size_t)sets * 4 * (1 + MSM_HEAVY_COUNTERS) + 16 + heavy_runs_bytes) + 255) & ~(size_t)255;
-    const size_t parts_slot_words = (size_t)sets * desc_cap_max * EC::PT_WORDS + (size_t)sets * ((size_t)h1_cap_max + 2 * (size_t)run_cap_max) * EC::PT_WORDS;
     bool defer_heavy = passes > 1 && (size_t)passes <= nb && passes <= MSM_HEAVY_JOBS;
+    const double heavy_frac = defer_heavy ? g_ws.heavy_frac : 1.0;        // (one shared slot: its counters are overwritten MSM after MSM -- worst case there)
+    auto desc_cap_of = [](uint64_t entries, uint64_t cap_, double frac) {
+        const uint64_t worst = entries / cap_ + 1;
+        return (uint32_t)std::min<uint64_t>(worst, (uint64_t)((double)worst * frac) + 1024);
+    };
+    if (defer_heavy) { h1_cap_max = h1_cap_of(sorted_max, run_cap_max, heavy_frac); desc_cap_max = desc_cap_of(sorted_max, MSM_MIN_CAP, heavy_frac); }
+    size_t desc_slot_bytes = (((size_t)sets * desc_cap_max * sizeof(LongDesc) + (size_t)sets * 4 * (1 + MSM_HEAVY_COUNTERS) + 16 + heavy_runs_bytes) + 255) & ~(size_t)255;
+    size_t parts_slot_words = (size_t)sets * desc_cap_max * EC::PT_WORDS + (size_t)sets * ((size_t)h1_cap_max + 2 * (size_t)run_cap_max) * EC::PT_WORDS;
     // ... while the slots fit: the scratch is sized for the worst case (every entry in heavy buckets: ~3.5 x the sorted list per slot,
     // 2.3 GB for five 2^20-pair MSMs) and scales with n.  A batch whose slots would need more than what is reserved already AND more than
     // a quarter of the free HBM (batches of 2^24 pairs and up) runs its heavy kernels per MSM out of one slot instead.
     if (defer_heavy && (size_t)passes * parts_slot_words * 4 > g_ws.long_parts.cap) {
         size_t free_b = 0, total_b = 0;
         HIP_TRY(hipMemGetInfo(&free_b, &total_b));
-        if ((size_t)passes * parts_slot_words * 4 > free_b / 4) defer_heavy = false;
+        if ((size_t)passes * parts_slot_words * 4 > free_b / 4) {
+            defer_heavy = false;
+            h1_cap_max = h1_cap_worst;
+            desc_cap_max = desc_cap_worst;
+            desc_slot_bytes = (((size_t)sets * desc_cap_max * sizeof(LongDesc) + (size_t)sets * 4 * (1 + MSM_HEAVY_COUNTERS) + 16 + heavy_runs_bytes) + 255) & ~(size_t)255;
+            parts_slot_words = (size_t)sets * desc_cap_max * EC::PT_WORDS + (size_t)sets * ((size_t)h1_cap_max + 2 * (size_t)run_cap_max) * EC::PT_WORDS;
+        }
     }
+    const double h1_frac = defer_heavy ? heavy_frac : 1.0;
     const size_t slots = defer_heavy ? (size_t)passes : 1;
     MZK_TRY(g_ws.long_desc.reserve(slots * desc_slot_bytes));
     MZK_TRY(g_ws.long_parts.reserve(slots * parts_slot_words * 4));
@@ -237,13 +261,16 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     const int n_out_one = n_win * (log_m + 1);
     const int n_out = n_out_one * count;
     const size_t out_bytes = (size_t)n_out * 4 * FQ::N * 4;
+    const size_t counts_words = (size_t)sets * (1 + MSM_HEAVY_COUNTERS), host_bytes = out_bytes + (size_t)passes * counts_words * 4;   // results, then every MSM's counters
     MZK_TRY(g_ws.collect.reserve(out_bytes));
-    if (g_ws.h_collect_cap < out_bytes) {
+    if (g_ws.h_collect_cap < host_bytes) {
         if (g_ws.h_collect) HIP_TRY(hipHostFree(g_ws.h_collect));
         g_ws.h_collect = nullptr;
-        HIP_TRY(hipHostMalloc(&g_ws.h_collect, out_bytes, hipHostMallocDefault));
-        g_ws.h_collect_cap = out_bytes;
+        HIP_TRY(hipHostMalloc(&g_ws.h_collect, host_bytes, hipHostMallocDefault));
+        g_ws.h_collect_cap = host_bytes;
     }
+    std::vector<uint32_t> h1_caps(passes, 0), desc_caps(passes, 0);
+    std::vector<const uint32_t*> count_ptrs(passes, nullptr);
     uint32_t* collect = g_ws.collect.as<uint32_t>();
     HeavyJobs jobs;
     std::memset(&jobs, 0, sizeof jobs);
@@ -295,14 +322,17 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 if (extra <= 4 * peak) peak += extra;      // a very short top digit (few buckets, huge runs) is left to the chunked path
             }
             const uint32_t cap = (uint32_t)std::max<unsigned long long>(MSM_MIN_CAP, peak + 6 * (unsigned long long)std::sqrt((double)peak) + 8);
-            const uint32_t desc_cap = (uint32_t)(n_sorted / cap + 1);
+            const uint32_t desc_cap = std::min(desc_cap_max, desc_cap_of(n_sorted, cap, h1_frac));
+            desc_caps[p] = desc_cap;
             const size_t slot = defer_heavy ? (size_t)p : 0;
             LongDesc* desc = reinterpret_cast<LongDesc*>(g_ws.long_desc.as<char>() + slot * desc_slot_bytes);
             uint32_t* parts = g_ws.long_parts.as<uint32_t>() + slot * parts_slot_words;
             uint32_t* desc_count = reinterpret_cast<uint32_t*>(desc + (size_t)sets * desc_cap);        // `sets` words, then the heavy counters
             const uint32_t* heavy_count = desc_count + sets;
             const uint32_t run_cap = (uint32_t)(2 * (n_sorted / MSM_HEAVY_RUN) + 2);
-            const uint32_t h1_cap = (uint32_t)(n_sorted / MSM_HEAVY_PER_THREAD + 2 * (size_t)run_cap + 2);
+            const uint32_t h1_cap = std::min(h1_cap_max, h1_cap_of(n_sorted, run_cap, h1_frac));
+            h1_caps[p] = h1_cap;
+            count_ptrs[p] = desc_count;
             HeavyRun* heavy_runs = reinterpret_cast<HeavyRun*>(desc_count + (((size_t)sets * (1 + MSM_HEAVY_COUNTERS) + 3) & ~(size_t)3));
             uint32_t* h1 = parts + (size_t)sets * desc_cap * EC::PT_WORDS;                           // level-1 sums: one per MSM_HEAVY_PER_THREAD entries of a run
             uint32_t* h2 = h1 + (size_t)sets * h1_cap * EC::PT_WORDS;                                 // one per level-1 run
@@ -371,7 +401,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 if (!pre.c && !sort2) HIP_TRY(hipMemsetAsync(keycnt, 0, (size_t)sets * 1024 * 4, sst));    // (two-level sort: zeroed with the bin totals above)
                 if (diet) {
                     hipLaunchKernelGGL(msm_order_place_kernel, dim3(slices, sets), dim3(1024), 0, sst, hist, offs, M, keycnt, keycnt + (size_t)sets * 1024, order,
-                                       sets, cap, desc_cap, desc, find_in_sort ? desc_count : nullptr, run_cap, heavy_runs);
+                                       sets, cap, desc_cap, desc, find_in_sort ? desc_count : nullptr, run_cap, h1_cap, heavy_runs);
                 } else {
                     hipLaunchKernelGGL(msm_order_hist_kernel, dim3(slices, sets), dim3(1024), 0, sst, hist, M, keycnt);
                     hipLaunchKernelGGL(msm_order_scan_kernel, dim3(sets), dim3(1024), 0, sst, keycnt);
@@ -419,7 +449,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 ProfScope ps("msm_long", st);
                 if (!find_in_sort)
                     hipLaunchKernelGGL(msm_long_find_kernel, dim3((unsigned)((wm + 255) / 256)), dim3(256), 0, st, hist, offs, M, sets, cap, desc_cap, desc, desc_count,
-                                       run_cap, heavy_runs);
+                                       run_cap, h1_cap, heavy_runs);
                 // heavy buckets: a workgroup per run of MSM_HEAVY_RUN entries, then workgroup trees (levels A, B; C only when a bucket can hold
                 // more than MSM_HEAVY_RUN * MSM_HEAVY_FANIN entries).  Every workgroup exits at once when there is no heavy bucket.
                 HeavyJob& jb = jobs.j[defer_heavy ? p : 0];
@@ -482,9 +512,28 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
         }
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(g_ws.h_collect, collect, out_bytes, hipMemcpyDeviceToHost, st));
+        if (defer_heavy)                                             // what the heavy buckets of every MSM really needed (their slots keep the counters)
+            for (int p = 0; p < passes; p++)
+                HIP_TRY(hipMemcpyAsync(static_cast<uint8_t*>(g_ws.h_collect) + out_bytes + (size_t)p * counts_words * 4, count_ptrs[p], counts_words * 4,
+                                       hipMemcpyDeviceToHost, st));
     }
     MZK_TRY(ws_release(st));
     HIP_TRY(hipStreamSynchronize(st));
+    if (defer_heavy) {
+        const uint32_t* cw = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(g_ws.h_collect) + out_bytes);
+        double grow = 0;
+        for (int p = 0; p < passes; p++)
+            for (int w = 0; w < sets; w++) {
+                const uint32_t need = cw[(size_t)p * counts_words + sets + (size_t)w * MSM_HEAVY_COUNTERS + 5];
+                if (need > h1_caps[p]) grow = std::max(grow, (double)need / (double)h1_cap_worst);
+                const uint32_t need_desc = cw[(size_t)p * counts_words + w];                     // chunk descriptors of the over-long buckets
+                if (need_desc > desc_caps[p]) grow = std::max(grow, (double)need_desc / (double)desc_cap_worst);
+            }
+        if (grow > 0) {                                              // some heavy bucket found no room: its MSM's result is incomplete -- larger arrays, same group again
+            g_ws.heavy_frac = std::min(1.0, std::max(g_ws.heavy_frac * 2, grow * 1.25));
+            return MSM_RETRY;
+        }
+    }
     const uint32_t* h = reinterpret_cast<const uint32_t*>(g_ws.h_collect);
     const size_t per = (size_t)n_out_one * 4 * FQ::N;
     // a Horner tail is c doublings + c additions on one core, ~14 us on the table path (one bucket set): starting a thread costs more
@@ -503,6 +552,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
 }
 
 constexpr uint64_t PRE_MIN_N = 1ull << 10;       // smaller MSMs stay on the plain path
+constexpr int MSM_GROUP_MAX = 6;
 
 template <class FR, class EC>
 int32_t msm_batch_dev(const MsmItem* items, int count, int is_mont, const PreInfo& pre, const uint32_t* plain_table, size_t aff_words,
@@ -519,11 +569,19 @@ int32_t msm_batch_dev(const MsmItem* items, int count, int is_mont, const PreInf
         const bool p0 = use_pre(items[i]);
         const int c = win_of(items[i]);
         int j = i + 1;
-        while (j < count && j - i < 16 && items[j].n != 0 && items[j].n < (1ull << 27) && use_pre(items[j]) == p0 && win_of(items[j]) == c) j++;
+        // (at most 6 MSMs per group -- a round of UltraPlonk commits six wires --: every MSM of a group keeps its bucket set -- 117 MB at 2^19 buckets -- until the shared reduction; groups
+        // of 16, which only the 18 verifying-key commitments of set-up ever formed, left 1.9 GB in the grow-only scratch: round 5)
+        while (j < count && j - i < MSM_GROUP_MAX && items[j].n != 0 && items[j].n < (1ull << 27) && use_pre(items[j]) == p0 && win_of(items[j]) == c) j++;
         run.assign(items + i, items + j);
         if (!p0)
             for (auto& it : run) it.d_bases = plain_table + it.base_off * aff_words;   // plain path: pointer to the first base
-        MZK_TRY((msm_group_dev<FR, EC>(run.data(), j - i, c, is_mont, p0 ? pre : PreInfo{}, st)));
+        for (int attempt = 0;; attempt++) {                          // (MSM_RETRY: the heavy-bucket scratch was too small; it has been enlarged)
+            const int32_t rc = msm_group_dev<FR, EC>(run.data(), j - i, c, is_mont, p0 ? pre : PreInfo{}, st);
+            if (rc == MSM_RETRY && attempt < 8) continue;
+            if (rc == MSM_RETRY) { set_error("MSM heavy-bucket scratch: no fit after 8 attempts"); return MZK_ERR_UNSUPPORTED; }
+            MZK_TRY(rc);
+            break;
+        }
         i = j;
     }
     return MZK_OK;

@@ -41,6 +41,7 @@ void Workspace::release() {
     h_collect_cap = 0;
     if (last_use) (void)hipEventDestroy(last_use);
     last_use = nullptr;
+    heavy_frac = 0.125;
 }
 
 size_t Workspace::bytes() {
@@ -472,6 +473,19 @@ int32_t mzk_workspace_hbm_bytes(uint64_t* out_bytes) {
     uint64_t b = cx_->ws.bytes();
     for (auto& slot : cx_->io) b += slot.buf.cap;
     *out_bytes = b;
+    if (std::getenv("MZK_WS_DEBUG")) {                                // one line per buffer of the grow-only scratch (tools/hbm_report.py)
+        Workspace& w = cx_->ws;
+        const char* names[] = {"ntt_scratch", "scalars", "hist", "offs", "cursor", "sorted", "buckets", "collect", "io", "misc", "digits", "long_desc", "long_parts",
+                               "plonk_polys", "plonk_out", "pre_cnt", "pre_off", "pre_ce", "pre_cb", "poly_tmp", "split", "link_tmp", "occ"};
+        int i = 0;
+        for (DevBuf* d : {&w.ntt_scratch, &w.scalars, &w.hist, &w.offs, &w.cursor, &w.sorted, &w.buckets, &w.collect, &w.io, &w.misc, &w.digits, &w.long_desc,
+                          &w.long_parts, &w.plonk_polys, &w.plonk_out, &w.pre_cnt, &w.pre_off, &w.pre_ce, &w.pre_cb, &w.poly_tmp, &w.split, &w.link_tmp, &w.occ}) {
+            if (d->cap) std::fprintf(stderr, "[mzk ws] %-12s %10.1f MB\n", names[i], d->cap / 1e6);
+            i++;
+        }
+        for (auto& slot : cx_->io)
+            if (slot.buf.cap) std::fprintf(stderr, "[mzk ws] io slot      %10.1f MB\n", slot.buf.cap / 1e6);
+    }
     return MZK_OK;
 }
 

@@ -290,8 +290,8 @@ struct ProverT final : ProverBase {
         const int cnt = nsel + W + (ultra && out_plookup_xy ? 4 : 0);
         for (int i = 0; i < cnt; i++) { ptrs.push_back(fix(i)); lens.push_back(n); }
         std::vector<uint64_t> xy((size_t)cnt * PT);
-        for (int i = 0; i < cnt; i += 16) {                                      // (mzk_msm_batch_dev groups at most 16 MSMs)
-            const int k = std::min(16, cnt - i);
+        for (int i = 0; i < cnt; i += W) {                                       // W at a time, like a round's commitments: set-up does not enlarge the MSM scratch the proofs need
+            const int k = std::min(W, cnt - i);
             commit(std::vector<const void*>(ptrs.begin() + i, ptrs.begin() + i + k), std::vector<uint64_t>(lens.begin() + i, lens.begin() + i + k), &xy[(size_t)i * PT]);
         }
         std::memcpy(out_xy, xy.data(), (size_t)(nsel + W) * PT * 8);

@@ -226,7 +226,8 @@ def round5(provers, v_ch):
 
 def preprocess(commit_key: kzg.UnivariateProverParam, circuit, lagrange: bool | None = None, lagrange_ck=None) -> NativeProver:
     """snark.preprocess for the native prover: interpolate selectors, sigmas (and tables) and hand the coefficient forms over.
-    lagrange_ck: an existing Lagrange-basis key of this SRS and domain (else derived when `lagrange`: None = from 2^13 gates on)."""
+    lagrange_ck: an existing Lagrange-basis key of this SRS and domain (else derived when `lagrange`: None = from 2^13 gates on when a
+    sample of the circuit's witness shows small values, snark.witness_is_small)."""
     from . import snark
     from .domain import Radix2EvaluationDomain
     c, n = circuit.curve, circuit.n
@@ -246,7 +247,7 @@ def preprocess(commit_key: kzg.UnivariateProverParam, circuit, lagrange: bool | 
         tab_h = host(tab)
         plookup = {name: tab_h[i] for i, name in enumerate(("range_table_poly", "key_table_poly", "table_dom_sep_poly", "q_dom_sep_poly"))}
     if lagrange is None:
-        lagrange = n >= snark.LAGRANGE_MIN_DOMAIN
+        lagrange = n >= snark.LAGRANGE_MIN_DOMAIN and snark.witness_is_small(c, circuit.wire_values)
     lck = lagrange_ck if lagrange_ck is not None else (commit_key.lagrange_key(n) if lagrange else None)
     return NativeProver(c, n, list(host(sel)), list(host(sig)), circuit.k, commit_key, plookup=plookup, lagrange_ck=lck)
 

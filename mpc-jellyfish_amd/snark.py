@@ -20,7 +20,7 @@ import numpy as np
 
 from . import kzg, poly, prover as _prover, rng as _rng, transcript as _transcript
 from .domain import Radix2EvaluationDomain
-from .params import CurveParams, curve as _curve, fr_to_mont, fq_from_mont
+from .params import CurveParams, curve as _curve, fr_from_mont, fr_to_mont, fq_from_mont
 
 TURBO, ULTRA = "TurboPlonk", "UltraPlonk"
 
@@ -150,6 +150,24 @@ class HostWitness:
 
 
 LAGRANGE_MIN_DOMAIN = 1 << 13          # preprocess(lagrange=None): round 1 over the Lagrange basis from this domain size on
+LAGRANGE_SAMPLE = 2048                 # ... when a sample of the witness shows small values (below)
+
+
+def witness_is_small(curve, wire_values) -> bool:
+    """Does round 1 gain from the Lagrange-basis key?  It does when the wire VALUES are mostly small numbers (flags, counters, 64-bit
+    amounts: their high digits cost the MSM nothing); on a dense witness the key and its fixed-base table are 1.75 GB of HBM (2^20 gates,
+    BLS12-381) and 0.5 s of set-up for nothing.  Decided from LAGRANGE_SAMPLE strided values: small = below 2^64 for at
+    least half of them.  wire_values: (W, n, 4) Montgomery limbs (tensor on either side) or a HostWitness (its witness vector)."""
+    c = _curve(curve)
+    t = wire_values.witness if isinstance(wire_values, HostWitness) else wire_values
+    flat = t.reshape(-1, 4)
+    total = int(flat.shape[0])
+    if total == 0:
+        return False
+    step = max(1, total // LAGRANGE_SAMPLE)
+    sample = flat[::step][:LAGRANGE_SAMPLE].cpu().numpy().view(np.uint64)
+    small = sum(1 for v in fr_from_mont(c, sample) if v < (1 << 64))
+    return 2 * small >= sample.shape[0]
 
 
 def preprocess(commit_key: kzg.UnivariateProverParam, circuit: BenchCircuit, quotient_classes=None, quotient_gather=None,
@@ -158,7 +176,8 @@ def preprocess(commit_key: kzg.UnivariateProverParam, circuit: BenchCircuit, quo
     verifying-key commitments are produced on demand by `TurboPlonkProver.vk_commitments()`.  lagrange: also derive the commit key over
     the Lagrange basis of the gate domain from the SRS's points (kzg.UnivariateProverParam.lagrange_key) -- round 1 then commits the
     wires from their values (same commitments; single-process proving).  None: from 2^13 gates on (below, an MSM is a chain of
-    latencies and small scalars only add over-long buckets to it: 2.0 against 0.9 ms for round 1 at 2^10 gates)."""
+    latencies and small scalars only add over-long buckets to it: 2.0 against 0.9 ms for round 1 at 2^10 gates) AND only when a sample
+    of the circuit's witness shows small values (witness_is_small: a dense witness gains nothing from the key)."""
     c, n = circuit.curve, circuit.n
     if commit_key.length < n + 3:
         raise ValueError("SRS too small: need domain size + 3 powers (srs.rs:88)")          # snark.rs:535-541
@@ -179,7 +198,7 @@ def preprocess(commit_key: kzg.UnivariateProverParam, circuit: BenchCircuit, quo
     pk = _prover.TurboPlonkProver(c, n, list(host(sel)), list(host(sig)), circuit.k, commit_key, plookup=plookup,
                                   quotient_classes=quotient_classes, quotient_gather=quotient_gather, quotient_shard=quotient_shard)
     if lagrange is None:
-        lagrange = n >= LAGRANGE_MIN_DOMAIN
+        lagrange = n >= LAGRANGE_MIN_DOMAIN and witness_is_small(c, circuit.wire_values)
     if lagrange and quotient_shard is None and quotient_gather is None and commit_key.offset == 0:
         pk.lagrange_ck = commit_key.lagrange_key(n)
     return pk

@@ -184,3 +184,34 @@ def test_fused_batches_of_small_msms_against_the_oracle(gpu, mj, cref, curve_id,
         want = cref.jac_to_affine(curve_id, cref.msm(curve_id, srs[offs[k]:offs[k] + len(polys[k])], polys[k], scalars_are_mont=True, threads=4))[0]
         assert np.array_equal(cref.jac_to_affine(curve_id, jac[k])[0], want), (k, len(polys[k]), offs[k])
     pp.release()
+
+
+def test_heavy_bucket_scratch_grows_on_demand_and_the_group_runs_again(gpu, mj, cref):
+    """Round 5: the level-1 sums of heavy buckets are sized for an eighth of the worst case; a batch whose scalars put EVERY entry into heavy
+    buckets (all-equal scalars) overflows it, the library enlarges the scratch from the counters it reads with the results and runs the
+    group again (csrc/msm.hip MSM_RETRY).  Same points as the oracle, from a freshly released workspace (the share starts again there),
+    and uniform scalars afterwards leave the scratch as it is."""
+    import ctypes as C
+    c = mj.params.CURVES[0]
+    n = (1 << 17) + 5
+    bases = cref.g1_arith_bases(0, 0xbeef, 0x2b, n)
+    pp = mj.UnivariateProverParam.from_affine(0, bases)
+    pats = _patterns(mj, c, n)
+    L = mj.load()
+    ws = C.c_uint64()
+    mj.lib.check(L.mzk_workspace_release(), "mzk_workspace_release")
+    names = ["dense", "dense", "half", "dense", "few"]
+    jac = mj.msm_bigint_batch(pp, [pats[k] for k in names], scalars_are_mont=True)           # uniform: no heavy bucket, the optimistic size holds
+    want = {k: cref.jac_to_affine(0, cref.msm(0, bases, pats[k], scalars_are_mont=True, threads=8))[0] for k in set(names) | {"all_equal", "plus_minus", "small_limbs"}}
+    for i, k in enumerate(names):
+        assert np.array_equal(cref.jac_to_affine(0, jac[i])[0], want[k]), k
+    mj.lib.check(L.mzk_workspace_hbm_bytes(C.byref(ws)), "mzk_workspace_hbm_bytes")
+    before = ws.value
+    skew = ["all_equal", "plus_minus", "all_equal", "small_limbs", "all_equal"]
+    for _ in range(2):                                                                        # the second call finds the scratch large enough
+        jac = mj.msm_bigint_batch(pp, [pats[k] for k in skew], scalars_are_mont=True)
+        for i, k in enumerate(skew):
+            assert np.array_equal(cref.jac_to_affine(0, jac[i])[0], want[k]), ("skew", k)
+    mj.lib.check(L.mzk_workspace_hbm_bytes(C.byref(ws)), "mzk_workspace_hbm_bytes")
+    assert ws.value > before, "the skewed batch must have enlarged the heavy-bucket scratch"
+    pp.release()
