@@ -38,20 +38,35 @@ def sum_jacobian(curve, points: np.ndarray) -> np.ndarray:
     return out
 
 
+def gather_partials(part: np.ndarray, group=None, device=None) -> np.ndarray:
+    """The collective of one commit group: every rank's (k, 3, L) Jacobian partials -> (world, k, 3, L) on every rank.  ONE flat
+    tensor, ONE all_gather_into_tensor (RCCL: the payload in a CUDA tensor; gloo: host tensors, no copies at all) and ONE transfer back.
+    The partials are BORN on the host -- an MSM ends with its Horner tail on a CPU core (csrc/msm.hip) -- so a device-side sum of the
+    gathered points would not save a hop: over RCCL it is H2D, collective, D2H either way (k x world x 144 B); the <= 8 additions per
+    commitment run on the host in a microsecond each (mzk_g1_sum_jacobian).  tools/collective_time.py times this path."""
+    import torch
+    import torch.distributed as dist
+    world = dist.get_world_size(group)
+    flat = np.ascontiguousarray(part, dtype=np.uint64).view(np.int64).reshape(-1)
+    t = torch.from_numpy(flat)
+    if device is not None:
+        t = t.to(device, non_blocking=True)
+    out = torch.empty(world * t.numel(), dtype=t.dtype, device=t.device)
+    try:
+        dist.all_gather_into_tensor(out, t, group=group)
+    except (RuntimeError, NotImplementedError):                            # a backend without the flat form: the list form
+        parts = [torch.empty_like(t) for _ in range(world)]
+        dist.all_gather(parts, t, group=group)
+        out = torch.cat(parts)
+    return out.cpu().numpy().view(np.uint64).reshape((world,) + tuple(np.shape(part)))
+
+
 def all_gather_sum(curve, partial_xyz: np.ndarray, group=None, device=None) -> np.ndarray:
     """All-gather every rank's Jacobian partial and add them up locally ("all-reduce" of EC sums).
     With backend nccl (= RCCL) the 144-byte payload travels in a CUDA tensor; gloo uses host tensors."""
-    import torch
-    import torch.distributed as dist
     c = _curve(curve)
-    world = dist.get_world_size(group)
-    t = torch.from_numpy(np.ascontiguousarray(partial_xyz, dtype=np.uint64).view(np.int64).reshape(-1))
-    if device is not None:
-        t = t.to(device)
-    parts = [torch.empty_like(t) for _ in range(world)]
-    dist.all_gather(parts, t, group=group)
-    stacked = torch.stack(parts).cpu().numpy().view(np.uint64).reshape(world, 3, c.fq_limbs)
-    return sum_jacobian(c, stacked)
+    part = np.ascontiguousarray(partial_xyz, dtype=np.uint64).reshape(1, 3, c.fq_limbs)
+    return sum_jacobian(c, gather_partials(part, group, device)[:, 0])
 
 
 class ShardedCommitter:
@@ -108,12 +123,7 @@ class ShardedCommitter:
             slices.append(s.contiguous() if hasattr(s, "contiguous") else np.ascontiguousarray(s))
             offsets.append(lo if hi > lo else lo_r)
         part = np.ascontiguousarray(self._local(slices, offsets), dtype=np.uint64).reshape(k, 3, L)
-        t = torch.from_numpy(part.view(np.int64).reshape(-1).copy())
-        if self.device is not None:
-            t = t.to(self.device)
-        parts = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(parts, t, group=self.group)
-        stacked = torch.stack(parts).cpu().numpy().view(np.uint64).reshape(world, k, 3, L)
+        stacked = gather_partials(part, self.group, self.device)
         return np.stack([sum_jacobian(self.c, stacked[:, i]) for i in range(k)])
 
     # ---- coefficient-range mode: the pointwise stages of rounds 4 and 5 run on this rank's
@@ -162,12 +172,7 @@ class ShardedCommitter:
         sl = [s.contiguous() if hasattr(s, "contiguous") else np.ascontiguousarray(s) for s in slices]
         assert all(int(s.shape[0]) <= hi_r - lo_r for s in sl)
         part = np.ascontiguousarray(self._local(sl, [lo_r] * k), dtype=np.uint64).reshape(k, 3, L)
-        t = torch.from_numpy(part.view(np.int64).reshape(-1).copy())
-        if self.device is not None:
-            t = t.to(self.device)
-        parts = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(parts, t, group=self.group)
-        stacked = torch.stack(parts).cpu().numpy().view(np.uint64).reshape(world, k, 3, L)
+        stacked = gather_partials(part, self.group, self.device)
         return np.stack([sum_jacobian(self.c, stacked[:, i]) for i in range(k)])
 
     def release(self):

@@ -41,7 +41,14 @@ import numpy as np
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
-SMALL_COLLECTIVE_US = 40.0        # RCCL all-gather of a few hundred bytes over xGMI, incl. the device->host hop of the result
+# One small collective of a commit group = the wire + the host side of sharding.gather_partials.  The HOST side is measured
+# (tools/collective_time.py, profiles/r05_collective_time.json: tensor set-up, one transfer back, k x (G - 1) Jacobian additions through
+# mzk_g1_sum_jacobian: 36 us for k = 5 at two ranks, 51 us at four).  The WIRE cannot be measured without a multi-GPU node: the same call
+# between gloo processes over TCP loopback takes 0.7 ms at two ranks -- a figure of the test backend, not of RCCL -- so the RCCL
+# all-gather of a few hundred bytes over xGMI, device -> host hop included, stays the ASSUMED 40 us.
+RCCL_SMALL_ALLGATHER_US = 40.0
+HOST_SUMS_US = 45.0
+SMALL_COLLECTIVE_US = RCCL_SMALL_ALLGATHER_US + HOST_SUMS_US
 XGMI_GBPS = 300.0                 # all-gather receive rate per GPU: 7 links x ~45 GB/s achieved of 64 GB/s per direction (MI355X_MICROARCH.md)
 
 
@@ -230,7 +237,7 @@ def main():
     from importlib import import_module
     import_module("mpc-jellyfish_amd.lib").init(0)
     res = {"what": "predicted PlonkKzgSnark::prove time on G GPUs from single-GPU measurements of each rank's share (tools/scale_model.py)",
-           "constants": {"small_collective_us": SMALL_COLLECTIVE_US, "xgmi_allgather_GBps_per_gpu": XGMI_GBPS},
+           "constants": {"small_collective_us": SMALL_COLLECTIVE_US, "of_which_assumed_rccl_allgather_us": RCCL_SMALL_ALLGATHER_US, "of_which_measured_host_sums_us": HOST_SUMS_US, "xgmi_allgather_GBps_per_gpu": XGMI_GBPS},
            "C4_turbo_bls12_381": model(mj, mj.params.BLS12_381, "TurboPlonk", args.c4_log_n)}
     if args.c5_log_n:
         res["C5_ultra_bn254"] = model(mj, mj.params.BN254, "UltraPlonk", args.c5_log_n)
