@@ -26,6 +26,7 @@
 // This header keeps the decomposition and its shared definitions; the pass kernel and the plan tables live in
 // ntt_fx.cuh (reduced-radix field, both directions decimation-in-time, N^-1 / coset factors in the final pass).
 #pragma once
+#include <cstdlib>
 #include <hip/hip_runtime.h>
 
 #include <vector>
@@ -46,6 +47,22 @@ constexpr int NTT_MAX_LOG_R = 9;
 __device__ __forceinline__ unsigned bitrev(unsigned x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
 
 inline void ntt_choose_radices(int log_n, int* log_radix, int* n_pass) {
+    // EXPERIMENT switch (profiles/r05_ntt_two_pass.txt): MZK_NTT_RADICES="11,11" forces the pass structure of transforms whose size is
+    // the sum of the listed radices (with MZK_NTT_TILE_LOG_RT=12 for 4096-element tiles); nothing ships with it
+    if (const char* f = std::getenv("MZK_NTT_RADICES")) {
+        int r[NTT_MAX_PASSES], k = 0, sum = 0;
+        for (const char* q = f; *q && k < NTT_MAX_PASSES;) {
+            r[k] = std::atoi(q);
+            sum += r[k++];
+            while (*q && *q != ',') q++;
+            if (*q == ',') q++;
+        }
+        if (sum == log_n && k >= 1) {
+            *n_pass = k;
+            for (int i = 0; i < k; i++) log_radix[i] = r[i];
+            return;
+        }
+    }
     if (log_n <= NTT_MAX_LOG_R) {
         *n_pass = 1;
         log_radix[0] = log_n;

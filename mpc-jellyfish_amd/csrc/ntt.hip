@@ -166,7 +166,8 @@ int32_t ntt_dev(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool in
     // MZK_NTT_NO_RADIX4=1: the round-3 form everywhere (A/B).
     static const bool no_r4 = std::getenv("MZK_NTT_NO_RADIX4") != nullptr;
     const bool r4 = !no_r4 && N >= (1ull << 21);
-    const int tile_log = r4 ? 11 : NTT_TILE_LOG;
+    static const int tile_rt = std::getenv("MZK_NTT_TILE_LOG_RT") ? std::atoi(std::getenv("MZK_NTT_TILE_LOG_RT")) : 0;      // (experiment switch, see ntt.cuh)
+    const int tile_log = r4 ? (tile_rt >= 11 && tile_rt <= 12 ? tile_rt : 11) : NTT_TILE_LOG;
     for (int k = 0; k < K; k++) {
         NttxPassArgs a;
         std::memset(&a, 0, sizeof a);
