@@ -473,6 +473,7 @@ def main():
         torch.cuda.synchronize()
         prove_ms = (time.perf_counter() - t1) / reps * 1e3
         core, proof_bytes = mj.snark.prove(rng, cs, prover, profile=True)
+        proof_bytes_first = mj.snark.prove(mj.rng.test_rng(), cs, prover)[1]      # the proof of a fresh `test_rng` stream: what the other legs must reproduce
 
         def timed_proofs(circuit, k):
             for _ in range(2):
@@ -483,44 +484,51 @@ def main():
                 mj.snark.prove(rng, circuit, prover)
             torch.cuda.synchronize()
             return (time.perf_counter() - ta) / k * 1e3
-        # round 1 from the masked COEFFICIENT forms, as the reference commits (univariate_kzg/mod.rs:90-116): the same prover without its
-        # Lagrange-basis key
-        lag_key, prover.lagrange_ck = prover.lagrange_ck, None
-        coeff_ms = timed_proofs(cs, reps)
-        coeff_core, coeff_bytes = mj.snark.prove(mj.rng.test_rng(), cs, prover, profile=True)
-        prover.lagrange_ck = lag_key
+        # round 1 from the masked COEFFICIENT forms, as the reference commits (univariate_kzg/mod.rs:90-116): a second handle of the same
+        # circuit without the Lagrange-basis key
+        coeff_prover = mj.snark.preprocess(ck, cs, lagrange=False)
+        for _ in range(2):
+            mj.snark.prove(rng, cs, coeff_prover)
+        torch.cuda.synchronize()
+        ta = time.perf_counter()
+        for _ in range(reps):
+            mj.snark.prove(rng, cs, coeff_prover)
+        torch.cuda.synchronize()
+        coeff_ms = (time.perf_counter() - ta) / reps * 1e3
+        coeff_core, coeff_bytes = mj.snark.prove(mj.rng.test_rng(), cs, coeff_prover, profile=True)
         coeff_same = bool(coeff_bytes == mj.snark.prove(mj.rng.test_rng(), cs, prover)[1])
+        coeff_prover.release()
         tl = time.perf_counter()
         tmp_key = ck.lagrange_key(pn)
         lagrange_key_s = time.perf_counter() - tl
         tmp_key.release()
-        # the SAME proof through the round-level C ABI (mzk_prover_create / round1 .. round5, include/mzk.h): the rounds run inside the
-        # library, this process keeps transcript, rng and Proof -- what a Rust caller of the drop-in gets
-        from importlib import import_module
-        native = import_module("mpc-jellyfish_amd.native")
+        # `prove_ms` above IS the round-level C ABI (mzk_prover_create / round1 .. round5, include/mzk.h) driven from ctypes: since round 5
+        # the product has one implementation of the rounds (csrc/prover.hip) and snark.prove is its thin client.  Here: launches per
+        # proof, the same proof from a host-resident witness VECTOR, and what the instance holds in HBM with the library's grow-only
+        # scratch started afresh (`hbm_bytes.library_scratch` = what PROOFS of this size need, not the earlier legs' maxima)
         torch.cuda.synchronize()
-        mlib.check(L.mzk_workspace_release(), "mzk_workspace_release")    # the library's grow-only scratch starts again: `hbm_bytes.library_scratch`
-        npk = native.preprocess(prover.ck, cs, lagrange_ck=prover.lagrange_ck)     # below is what PROOFS of this size need, not the earlier legs' maxima
+        mlib.check(L.mzk_workspace_release(), "mzk_workspace_release")
+        npk = prover
         for _ in range(2):
-            native.prove(rng, cs, npk)
+            mj.snark.prove(rng, cs, npk)
         torch.cuda.synchronize()
         l0 = launch_count()
         ta = time.perf_counter()
         for _ in range(reps):
-            native.prove(rng, cs, npk)
+            mj.snark.prove(rng, cs, npk)
         torch.cuda.synchronize()
         abi_ms = (time.perf_counter() - ta) / reps * 1e3
         abi_launches = (launch_count() - l0) // reps
-        abi_core, abi_bytes = native.prove(mj.rng.test_rng(), cs, npk, profile=True)
-        abi_same = bool(abi_bytes == mj.snark.prove(mj.rng.test_rng(), cs, prover)[1])
+        abi_core, abi_bytes = mj.snark.prove(mj.rng.test_rng(), cs, npk, profile=True)
+        abi_same = bool(abi_bytes == proof_bytes_first)
         npk.set_wire_variables(cs.wire_variables.cpu().numpy(), int(cs.witness.shape[0]))
         abi_vec = mj.snark.HostWitness(cs.witness.cpu().pin_memory(), cs.wire_variables)
         for _ in range(2):
-            native.prove(rng, cs, npk, witness=abi_vec)
+            mj.snark.prove(rng, cs, npk, witness=abi_vec)
         torch.cuda.synchronize()
         ta = time.perf_counter()
         for _ in range(reps):
-            native.prove(rng, cs, npk, witness=abi_vec)
+            mj.snark.prove(rng, cs, npk, witness=abi_vec)
         torch.cuda.synchronize()
         abi_vec_ms = (time.perf_counter() - ta) / reps * 1e3
         # HBM held for this proof system instance (the reference keeps one commit key: srs.rs:36-40)
@@ -534,7 +542,6 @@ def main():
         mlib.check(L.mzk_workspace_hbm_bytes(C.byref(a_)), "mzk_workspace_hbm_bytes")
         hbm["library_scratch"] = a_.value
         hbm["total"] = sum(hbm.values())
-        npk.release()
         del abi_vec
         # (i) the witness starts in page-locked HOST memory, as the reference holds it (constraint_system.rs:1225-1247 gathers it on the
         # host): every proof uploads its 5 x n x 32 B, wire k + 1 under the iNTT of wire k (prover.py _stage_round1)
@@ -701,10 +708,11 @@ def main():
             ck = mj.UnivariateProverParam.gen_srs_for_testing(crv, beta, pn + 2)          # the same SRS on every rank
             cs = mj.snark.gen_circuit_for_bench(crv, pn, plonk_type)
             chunked = True                                                               # 8(e).3: the needed classes (6 / 7 of 8) split over the ranks
-            gather = lambda local, n_classes: mj.sharding.gather_quotient_classes(local, via_host=(backend != "nccl"), n_classes=n_classes)
-            prover = mj.snark.preprocess(ck, cs, quotient_shard=(rank, world), quotient_gather=gather)
+            # this process is ONE RANK of the library's own rounds (mzk_comm over torch.distributed: sharding.TorchComm) and keeps only its
+            # point range of the SRS (1 / N of the fixed-base table): commitments by point range, the quotient by residue class with one
+            # exchange, rounds 4-5 by coefficient range (csrc/prover.hip)
+            prover = mj.snark.preprocess(ck, cs, comm=mj.sharding.TorchComm(device=coll_dev))
             prover.vk_commitments()
-            prover.committer = mj.sharding.ShardedCommitter(crv, ck, device=coll_dev, slice_srs=True)     # every rank keeps its point range of the SRS (1 / N of the table)
             rng = mj.rng.test_rng()
             for _ in range(3):
                 mj.snark.prove(rng, cs, prover)
@@ -733,7 +741,8 @@ def main():
 
         prove_sharded = {"what": "PlonkKzgSnark::prove on the bench circuit, strong scaling: commitments sharded by point range over the ranks "
                                  "(all-gather of Jacobian partials + local EC sum, 8(e).1), quotient domain split into residue classes with one "
-                                 "all-gather (8(e).3) when the world size divides 8.  Python-orchestrated (compare with `prove` of the 1-GPU line); "
+                                 "exchange (8(e).3), rounds 4-5 by coefficient range -- the library's own rounds on every rank, mzk_comm over torch.distributed "
+                                 "(sharding.TorchComm); compare with `prove` of the 1-GPU line; "
                                  "profiles/r04_scale_model.json (tools/scale_model.py) holds the model this is to be checked against",
                          }
         try:
@@ -915,12 +924,12 @@ def main():
             pkm = mj.snark.preprocess(ckm, csm)
             blm = mj.snark.draw_blinders(curve, rngm, 5, False)
             for _ in range(2):
-                pkm.prove(csm.wire_values, csm.pub_input_values, mj.prover.TranscriptChallenges(pkm, []), blm)
+                pkm.prove(csm.wire_values, [], mj.prover.TranscriptChallenges(pkm, []), blm)
             torch.cuda.synchronize()
             t1 = time.perf_counter()
             for _ in range(gpu_reps):
                 srcm = mj.prover.TranscriptChallenges(pkm, [])
-                corem = pkm.prove(csm.wire_values, csm.pub_input_values, srcm, blm)
+                corem = pkm.prove(csm.wire_values, [], srcm, blm)
             torch.cuda.synchronize()
             gpu_ms = (time.perf_counter() - t1) / gpu_reps * 1e3
             srs_xy = ckm.powers_of_g()
@@ -937,7 +946,7 @@ def main():
                     "cpu_spent_s": cm_.get("spent_seconds"),
                     "sample": "ONE TurboPlonk proof of the 2^%d-gate bench circuit over BLS12-381 by the C restatement (oracle/cref_prover.py: ark-poly "
                               "style FFTs, ark-ec style Pippenger with its window rule, the reference's serial grand product and per-point quotient "
-                              "closure; `preprocess` work excluded) on %d threads, vs the device prover (Python-orchestrated, proving key resident) on the "
+                              "closure; `preprocess` work excluded) on %d threads, vs the device prover (round-level C ABI from ctypes, proving key resident) on the "
                               "same circuit, SRS, blinders and transcript; restatement of the ark-* algorithms, not the Rust binary" % (lg, cpu_threads)}
 
         c1 = cpu_vs_device(10, 1, 3)                                      # config C1 (BASELINE.json configs[0]): 2^10 gates, ONE CPU thread

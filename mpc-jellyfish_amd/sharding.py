@@ -1,11 +1,13 @@
-"""Multi-GPU sharding of the commit path; one process per GPU, torch.distributed.
+"""Multi-GPU sharding; one process per GPU, torch.distributed.
 
-  * independent MSMs (batch_commit, mod.rs:125-127): polynomial i goes to rank i % world -- no
-    collective on the data path; the W affine results are gathered as plain bytes at the end.
-  * one large MSM sharded by point range: rank g owns bases/scalars [g*N/G, (g+1)*N/G), computes a
-    full Pippenger over its range and emits one Jacobian partial; the partials (<= 8 x 144 B) are
-    all-gathered and summed locally on every rank (RCCL has no EC-add reduction op).
-The collective is latency-bound (<= 1152 B); link bandwidth is irrelevant.
+  * `TorchComm`: the `mzk_comm` callbacks of the round-level C ABI over a process group -- a `prover.TurboPlonkProver` created with
+    it is one rank of a sharded proof: every commitment by point range (rank g commits over its range of the SRS, a slice it may keep
+    alone: kzg.UnivariateProverParam.slice), the quotient by residue class with one exchange, rounds 4-5 by coefficient range -- the
+    decomposition lives in the library's rounds (csrc/prover.hip), this class only moves the bytes.
+  * one large MSM sharded by point range (bench.py's weak-scaling headline): rank g computes a full Pippenger over its range and
+    emits one Jacobian partial; the partials (<= 8 x 144 B) are all-gathered and summed locally on every rank (RCCL has no EC-add
+    reduction op): `all_gather_sum`, `gather_partials`.
+The collectives are latency-bound (<= 1152 B); link bandwidth matters for the one class exchange only.
 """
 from __future__ import annotations
 
@@ -69,116 +71,83 @@ def all_gather_sum(curve, partial_xyz: np.ndarray, group=None, device=None) -> n
     return sum_jacobian(c, gather_partials(part, group, device)[:, 0])
 
 
-class ShardedCommitter:
-    """`UnivariateKzgPCS::{commit, batch_commit}` (mod.rs:90-131) across the ranks of a process group.
+class TorchComm:
+    """`mzk_comm` (include/mzk.h) over torch.distributed: what makes a `prover.TurboPlonkProver` ONE RANK of a multi-process proof
+    (one process per GPU).  The library's rounds call back for (i) the small all-gathers of Jacobian partials and
+    partial evaluations (host buffers of a few hundred bytes), (ii) the one exchange of quotient-class remainders of round 3 (device
+    buffers, n x 32 B per class) and (iii) barriers.  RCCL (backend "nccl"): payloads travel in CUDA tensors, the class exchange is
+    one all_gather_into_tensor between staging tensors filled / drained by device-to-device copies; gloo (CPU rehearsal): host tensors,
+    the classes staged through host memory.  Every rank must make the same calls in the same order -- the rounds do."""
 
-    Every polynomial is sharded by point range: rank g runs ONE fused batch of k MSMs over its slice
-    [g*len/G, (g+1)*len/G) of every polynomial (base_offset = slice start into the replicated SRS and its
-    precomputed table), then the k x G Jacobian partials (144 B each) are all-gathered and summed on every rank, so
-    all ranks hold identical commitments and their transcripts stay in step.  Compared with "polynomial i on rank
-    i % G"  the load is balanced for any k and G (5 wire commitments on 8 GPUs), at the price of
-    the same one small collective.
-    `msm_batch(ck, scalars_list, base_offsets) -> (k, 3, fq_limbs)` defaults to the device path; the CPU tests inject
-    the oracle there."""
-
-    def __init__(self, curve, ck, group=None, device=None, msm_batch=None, slice_srs: bool = False):
-        """slice_srs: register this rank's point range of the SRS as an SRS of its own.  The fixed-base table's window is chosen
-        by SRS size (csrc/msm.hip srs_build_pre_t): a 2^17-point slice gets a small window and 2^15 buckets per MSM instead of the
-        full SRS's 2^19 -- at 8 GPUs the bucket reduction, not the accumulation, is what a shard's MSM costs -- and the rank
-        holds 1 / G of the table."""
-        self.c = _curve(curve)
-        self.ck, self.group, self.device = ck, group, device
-        self.msm_batch = msm_batch
-        self.slice_srs = slice_srs and ck is not None and msm_batch is None
-        self._slice = None
-
-    def _local(self, slices, offsets):
-        if self.msm_batch is not None:
-            return self.msm_batch(self.ck, slices, offsets)
-        from . import kzg
-        if self._slice is not None:
-            lo = self._slice_lo
-            return kzg.msm_bigint_batch(self._slice, slices, [o - lo for o in offsets], scalars_are_mont=True)
-        return kzg.msm_bigint_batch(self.ck, slices, offsets, scalars_are_mont=True)
-
-    def commit_jacobian(self, polys) -> np.ndarray:
-        """polys: list of (len, 4) Montgomery coefficient arrays / CUDA tensors, identical on every rank.
-        Returns (k, 3, fq_limbs) Jacobian commitments, identical on every rank."""
-        import torch
+    def __init__(self, group=None, device=None):
         import torch.distributed as dist
-        world = dist.get_world_size(self.group)
-        rank = dist.get_rank(self.group)
-        k, L = len(polys), self.c.fq_limbs
-        # ONE partition of the point indices for all polynomials -- by the SRS length when there is an SRS (so that a rank always
-        # works on the same points and can keep just those), else by the longest polynomial of the call
-        total = self.ck.length if self.ck is not None else max([int(p.shape[0]) for p in polys] + [1])
-        lo_r, hi_r = shard_range(total, rank, world)
-        if self.slice_srs and self._slice is None and hi_r > lo_r:
-            self._slice = self.ck.slice(lo_r, hi_r - lo_r)               # mzk_srs_slice: a device copy of this rank's range
-            self._slice_lo = lo_r
-        slices, offsets = [], []
-        for p in polys:
-            lo, hi = min(lo_r, int(p.shape[0])), min(hi_r, int(p.shape[0]))
-            s = p[lo:hi]
-            slices.append(s.contiguous() if hasattr(s, "contiguous") else np.ascontiguousarray(s))
-            offsets.append(lo if hi > lo else lo_r)
-        part = np.ascontiguousarray(self._local(slices, offsets), dtype=np.uint64).reshape(k, 3, L)
-        stacked = gather_partials(part, self.group, self.device)
-        return np.stack([sum_jacobian(self.c, stacked[:, i]) for i in range(k)])
+        self.group, self.device = group, device
+        self.rank, self.world = dist.get_rank(group), dist.get_world_size(group)
+        AG = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p)
+        BA = C.CFUNCTYPE(C.c_int32, C.c_void_p)
+        EX = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32)
 
-    # ---- coefficient-range mode (SURVEY.md 8(e), VERDICT r1 6b): the pointwise stages of rounds 4 and 5 run on this rank's
-    # ---- coefficient range only -- the very range its MSM shard needs -- with small exchanges of field elements
-    def world(self) -> int:
+        class Comm(C.Structure):
+            _fields_ = [("ctx", C.c_void_p), ("rank", C.c_int32), ("world", C.c_int32), ("all_gather", AG), ("barrier", BA), ("exchange_classes", EX)]
+
+        self._cb = (AG(self._all_gather), BA(self._barrier), EX(self._exchange))            # (kept alive with the struct)
+        self._struct = Comm(None, self.rank, self.world, *self._cb)
+
+    def struct_ptr(self):
+        return C.cast(C.pointer(self._struct), C.c_void_p)
+
+    def _guard(self, fn, *args) -> int:
+        try:
+            fn(*args)
+            return 0
+        except Exception as e:                                         # noqa: BLE001  (a Python exception must not cross the C boundary)
+            import sys
+            print("TorchComm callback failed: %r" % (e,), file=sys.stderr)
+            return 1
+
+    def _all_gather(self, ctx, send, nbytes, recv):
+        def run():
+            import torch
+            import torch.distributed as dist
+            t = torch.frombuffer((C.c_uint8 * nbytes).from_address(send), dtype=torch.uint8).clone() if nbytes else torch.empty(0, dtype=torch.uint8)
+            if self.device is not None:
+                t = t.to(self.device)
+            out = torch.empty(self.world * nbytes, dtype=torch.uint8, device=t.device)
+            dist.all_gather_into_tensor(out, t, group=self.group)
+            C.memmove(recv, out.cpu().numpy().ctypes.data, self.world * nbytes)
+        return self._guard(run)
+
+    def _barrier(self, ctx):
         import torch.distributed as dist
-        return dist.get_world_size(self.group)
+        return self._guard(lambda: dist.barrier(group=self.group))
 
-    def rank(self) -> int:
-        import torch.distributed as dist
-        return dist.get_rank(self.group)
-
-    def point_range(self):
-        """[lo, hi) of the SRS indices this rank commits over (the fixed partition commit_jacobian uses)."""
-        import torch.distributed as dist
-        return shard_range(self.ck.length, dist.get_rank(self.group), dist.get_world_size(self.group))
-
-    def all_gather_fr(self, values) -> list:
-        """Every rank's list of field elements (canonical ints, same count on every rank) -> [rank][i]; 32 bytes per element."""
-        import torch
-        import torch.distributed as dist
-        world = dist.get_world_size(self.group)
-        k = len(values)
-        t = torch.tensor([(int(v) >> (64 * j)) & 0xFFFFFFFFFFFFFFFF for v in values for j in range(4)], dtype=torch.uint64).view(torch.int64)
-        if self.device is not None:
-            t = t.to(self.device)
-        parts = [torch.empty_like(t) for _ in range(world)]
-        dist.all_gather(parts, t, group=self.group)
-        out = []
-        for p in parts:
-            w = p.cpu().numpy().view(np.uint64).reshape(k, 4)
-            out.append([sum(int(w[i, j]) << (64 * j) for j in range(4)) for i in range(k)])
-        return out
-
-    def commit_jacobian_slices(self, slices) -> np.ndarray:
-        """Like commit_jacobian, for polynomials of which this rank holds ONLY its coefficient range: slices[i] = coefficients
-        [lo, lo + len(slices[i])) of polynomial i, lo = point_range()[0] (an empty slice: nothing of it falls into the range)."""
-        import torch
-        import torch.distributed as dist
-        world = dist.get_world_size(self.group)
-        k, L = len(slices), self.c.fq_limbs
-        lo_r, hi_r = self.point_range()
-        if self.slice_srs and self._slice is None and hi_r > lo_r:
-            self._slice = self.ck.slice(lo_r, hi_r - lo_r)               # mzk_srs_slice: a device copy of this rank's range
-            self._slice_lo = lo_r
-        sl = [s.contiguous() if hasattr(s, "contiguous") else np.ascontiguousarray(s) for s in slices]
-        assert all(int(s.shape[0]) <= hi_r - lo_r for s in sl)
-        part = np.ascontiguousarray(self._local(sl, [lo_r] * k), dtype=np.uint64).reshape(k, 3, L)
-        stacked = gather_partials(part, self.group, self.device)
-        return np.stack([sum_jacobian(self.c, stacked[:, i]) for i in range(k)])
-
-    def release(self):
-        if self._slice is not None:
-            self._slice.release()
-            self._slice = None
+    def _exchange(self, ctx, d_rem, class_bytes, first_own, n_own, n_classes):
+        """the class remainders of all ranks resident in d_rem (n_classes x class_bytes on the device; this rank has filled
+        [first_own, first_own + n_own)): ranks own contiguous blocks of ceil(n_classes / world) classes (class_range), the last may own fewer"""
+        def run():
+            import torch
+            import torch.distributed as dist
+            L = _lib.load()
+            per = -(-n_classes // self.world)
+            on_dev = self.device is not None
+            local = torch.zeros(per * class_bytes, dtype=torch.uint8, device=self.device if on_dev else "cpu")
+            mine = C.c_void_p(d_rem + first_own * class_bytes)
+            if n_own:
+                if on_dev:
+                    _lib.check(L.mzk_dev_copy(C.c_void_p(local.data_ptr()), mine, n_own * class_bytes, None), "mzk_dev_copy")
+                    _lib.check(L.mzk_dev_sync(), "mzk_dev_sync")
+                else:
+                    _lib.check(L.mzk_dev_download(C.c_void_p(local.data_ptr()), mine, n_own * class_bytes), "mzk_dev_download")
+            out = torch.empty(self.world * per * class_bytes, dtype=torch.uint8, device=local.device)
+            dist.all_gather_into_tensor(out, local, group=self.group)
+            total = n_classes * class_bytes                              # rank order IS class order; the tail beyond n_classes is padding
+            if on_dev:
+                torch.cuda.synchronize()
+                _lib.check(L.mzk_dev_copy(C.c_void_p(d_rem), C.c_void_p(out.data_ptr()), total, None), "mzk_dev_copy")
+                _lib.check(L.mzk_dev_sync(), "mzk_dev_sync")
+            else:
+                _lib.check(L.mzk_dev_upload(C.c_void_p(d_rem), C.c_void_p(out.data_ptr()), total), "mzk_dev_upload")
+        return self._guard(run)
 
 
 def class_range(rank: int, world: int, n_classes: int = 8) -> list[int]:

@@ -170,19 +170,22 @@ def witness_is_small(curve, wire_values) -> bool:
     return 2 * small >= sample.shape[0]
 
 
-def preprocess(commit_key: kzg.UnivariateProverParam, circuit: BenchCircuit, quotient_classes=None, quotient_gather=None,
-               quotient_shard=None, lagrange: bool | None = None) -> _prover.TurboPlonkProver:
-    """snark.rs:529-617: interpolate selectors, sigmas (and Plookup tables), keep them with the commit key.  The
-    verifying-key commitments are produced on demand by `TurboPlonkProver.vk_commitments()`.  lagrange: also derive the commit key over
-    the Lagrange basis of the gate domain from the SRS's points (kzg.UnivariateProverParam.lagrange_key) -- round 1 then commits the
-    wires from their values (same commitments; single-process proving).  None: from 2^13 gates on (below, an MSM is a chain of
-    latencies and small scalars only add over-long buckets to it: 2.0 against 0.9 ms for round 1 at 2^10 gates) AND only when a sample
-    of the circuit's witness shows small values (witness_is_small: a dense witness gains nothing from the key)."""
+def preprocess(commit_key: kzg.UnivariateProverParam, circuit: BenchCircuit, lagrange: bool | None = None, lagrange_ck=None,
+               comm=None) -> _prover.TurboPlonkProver:
+    """snark.rs:529-617: interpolate selectors, sigmas (and Plookup tables) and hand the coefficient forms to the library
+    (mzk_prover_create keeps them, their evaluations on the needed residue classes and the workspace of one proof in HBM).  The
+    verifying-key commitments come on demand from `TurboPlonkProver.vk_commitments()`.
+    lagrange: also derive the commit key over the Lagrange basis of the gate domain from the SRS's points
+    (kzg.UnivariateProverParam.lagrange_key) -- round 1 then commits the wires from their VALUES (same commitments).  None: from 2^13
+    gates on (below, an MSM is a chain of latencies and small scalars only add over-long buckets to it) AND only when a sample of the
+    circuit's witness shows small values (witness_is_small: a dense witness gains nothing from the key).  lagrange_ck: an existing key.
+    comm: a sharding.TorchComm -- this process is one rank of a sharded proof and keeps only its point range of the SRS (and of the
+    Lagrange key): mzk_srs_slice."""
     c, n = circuit.curve, circuit.n
     if commit_key.length < n + 3:
         raise ValueError("SRS too small: need domain size + 3 powers (srs.rs:88)")          # snark.rs:535-541
-    if commit_key.length > n + 3:       # snark.rs:535, 561: the proving key keeps trim(srs_size) = n + 3 powers -- a view of the same registration;
-        commit_key = commit_key.trim(n + 2)   # the sharded commits partition THIS length over the ranks (sharding.ShardedCommitter)
+    if commit_key.length > n + 3:       # snark.rs:535, 561: the proving key keeps trim(srs_size) = n + 3 powers -- a view of the same registration
+        commit_key = commit_key.trim(n + 2)
     dom = Radix2EvaluationDomain(c, n.bit_length() - 1)
     sel = circuit.selector_values.clone()
     sig = circuit.sigma_values.clone()
@@ -195,12 +198,24 @@ def preprocess(commit_key: kzg.UnivariateProverParam, circuit: BenchCircuit, quo
         dom.ifft_in_place(tab)
         tab_h = host(tab)
         plookup = {name: tab_h[i] for i, name in enumerate(("range_table_poly", "key_table_poly", "table_dom_sep_poly", "q_dom_sep_poly"))}
-    pk = _prover.TurboPlonkProver(c, n, list(host(sel)), list(host(sig)), circuit.k, commit_key, plookup=plookup,
-                                  quotient_classes=quotient_classes, quotient_gather=quotient_gather, quotient_shard=quotient_shard)
     if lagrange is None:
         lagrange = n >= LAGRANGE_MIN_DOMAIN and witness_is_small(c, circuit.wire_values)
-    if lagrange and quotient_shard is None and quotient_gather is None and commit_key.offset == 0:
-        pk.lagrange_ck = commit_key.lagrange_key(n)
+    lck = lagrange_ck if lagrange_ck is not None else (commit_key.lagrange_key(n) if lagrange else None)
+    owned = []                                                   # keys this prover releases with itself
+    if comm is not None and comm.world > 1:
+        from .sharding import shard_range
+        lo, hi = shard_range(n + 3, comm.rank, comm.world)       # ONE partition of the n + 3 powers for every commitment of the proof
+        commit_key = commit_key.slice(lo, hi - lo)
+        owned.append(commit_key)
+        if lck is not None:
+            full, lck = lck, lck.slice(lo, hi - lo)
+            owned.append(lck)
+            if lagrange_ck is None:
+                full.release()                                   # derived here: only this rank's range of it stays
+    elif lagrange_ck is None and lck is not None:
+        owned.append(lck)
+    pk = _prover.TurboPlonkProver(c, n, list(host(sel)), list(host(sig)), circuit.k, commit_key, plookup=plookup, lagrange_ck=lck, comm=comm)
+    pk.owned_keys = owned
     return pk
 
 
@@ -242,24 +257,25 @@ def serialize_proof(curve, proof: _prover.ProofCore) -> bytes:
 
 
 def prove(rng: _rng.ChaChaRng, circuit: BenchCircuit, pk: _prover.TurboPlonkProver, extra_transcript_init_msg: bytes | None = None,
-          profile: bool = False):
-    """PlonkKzgSnark::prove (snark.rs:624-651): returns (ProofCore, compressed proof bytes)."""
+          profile: bool = False, witness=None):
+    """PlonkKzgSnark::prove (snark.rs:624-651) through the round-level C ABI: returns (ProofCore, compressed proof bytes).
+    witness: what to prove from instead of circuit.wire_values (a HostWitness, a host tensor ..)."""
     if (circuit.plonk_type == ULTRA) != pk.ultra:
         raise ValueError("Mismatched Plonk types between the proving key and the circuit")                       # snark.rs:249-254
     if circuit.n != pk.n:
         raise ValueError("proving key domain size %d != expected domain size %d" % (pk.n, circuit.n))           # snark.rs:233-240
     blind = draw_blinders(circuit.curve, rng, circuit.num_wire_types, pk.ultra)
     src = _prover.TranscriptChallenges(pk, circuit.public_input, extra_transcript_init_msg)
-    core = pk.prove(circuit.wire_values, circuit.pub_input_values, src, blind, profile=profile, pi_zero=not any(circuit.public_input))
+    core = pk.prove(circuit.wire_values if witness is None else witness, list(circuit.public_input), src, blind, profile=profile)
     return core, serialize_proof(circuit.curve, core)
 
 
 def prove_with_link_hint(rng: _rng.ChaChaRng, circuit: BenchCircuit, pk: _prover.TurboPlonkProver, extra_transcript_init_msg: bytes | None = None):
     """PlonkKzgSnark::prove_with_link_hint (snark.rs:81-119): the proof plus the LinkingHint -- the masked wire polynomial that
-    carries the proof-linking gates (wire PROOF_LINK_WIRE_IDX, device resident) and its commitment from round 1."""
+    carries the proof-linking gates (wire PROOF_LINK_WIRE_IDX, device resident: mzk_prover_poly_dev) and its commitment from round 1."""
     from . import linking
     core, proof_bytes = prove(rng, circuit, pk, extra_transcript_init_msg)
-    hint = linking.LinkingHint(pk.last["wire_polys"][linking.PROOF_LINK_WIRE_IDX].clone(), core.wires_poly_comms[linking.PROOF_LINK_WIRE_IDX])
+    hint = linking.LinkingHint(pk.poly_dev(linking.PROOF_LINK_WIRE_IDX), core.wires_poly_comms[linking.PROOF_LINK_WIRE_IDX])
     return core, proof_bytes, hint
 
 
@@ -295,6 +311,5 @@ def batch_prove(rng: _rng.ChaChaRng, circuits: list, pks: list, extra_transcript
         if cs.num_wire_types != W:
             raise ValueError("inconsistent plonk circuit types")
     blinds, quot = draw_batch_blinders(circuits[0].curve, rng, W, [pk.ultra for pk in pks])
-    core = _batch.batch_prove(pks, [cs.wire_values for cs in circuits], [cs.pub_input_values for cs in circuits],
-                              [cs.public_input for cs in circuits], blinds, quot, extra_transcript_init_msg)
+    core = _batch.batch_prove(pks, [cs.wire_values for cs in circuits], [list(cs.public_input) for cs in circuits], blinds, quot, extra_transcript_init_msg)
     return core, _batch.serialize_batch_proof(circuits[0].curve, core)

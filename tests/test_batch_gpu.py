@@ -6,6 +6,8 @@ import random
 import numpy as np
 import pytest
 
+import mirror_prover as MP          # the primitive-level sequencing of the rounds: test code since round 5
+
 from conftest import affine_from_limbs, build_circuit, build_ultra_circuit, fr_mont_limbs, verifying_key
 import pyref_fs as FS
 
@@ -102,11 +104,11 @@ def test_batch_prove_matches_the_restated_batch_prover(gpu, mj, pyref, curve_id,
                  "h": [[rng.randrange(r) for _ in range(3)] for _ in range(2)], "prod_lookup": [rng.randrange(r) for _ in range(3)]}
         instances.append({"selector_vals": sel, "sigma_vals": sig, "k": k, "wire_vals": w, "pi_vals": pi, "blind": blind, "plookup": tabs})
         kw = {"plookup": {name: dom.ifft(fr_mont_limbs(c, tabs[key])) for name, key in zip(mj.plonk.PLOOKUP_TABLE_POLYS, TABLES)}} if ultra else {}
-        provers.append(mj.prover.TurboPlonkProver(c, n, [dom.ifft(fr_mont_limbs(c, s)) for s in sel], [dom.ifft(fr_mont_limbs(c, s)) for s in sig], k, ck, **kw))
+        provers.append(MP.TurboPlonkProver(c, n, [dom.ifft(fr_mont_limbs(c, s)) for s in sel], [dom.ifft(fr_mont_limbs(c, s)) for s in sig], k, ck, **kw))
         blinds.append(mj.prover.Blinders(blind["wires"], blind["z"], [], blind["h"] if ultra else None, blind["prod_lookup"] if ultra else None))
     quot_blind = [rng.randrange(r) for _ in range(W - 1)]
     pubs = [inst["pi_vals"][:4] for inst in instances]
-    core = mj.batch.batch_prove(provers, [np.stack([fr_mont_limbs(c, col) for col in inst["wire_vals"]]) for inst in instances],
+    core = MP.batch_prove(provers, [np.stack([fr_mont_limbs(c, col) for col in inst["wire_vals"]]) for inst in instances],
                                 [fr_mont_limbs(c, inst["pi_vals"]) for inst in instances], pubs, blinds, quot_blind, extra_transcript_init_msg=b"batch")
     want = PP.batch_prove_core(pc, log_n, instances, core.challenges, quot_blind, srs_beta)
     assert want["divisible"] and want["quot_degree_ok"]

@@ -55,14 +55,22 @@ def test_golden_proofs_with_round_1_committed_over_the_lagrange_basis(gpu, mj, n
     else:
         srs_beta, g = mj.rng.fr_rand(c, rng), None
     ck = mj.UnivariateProverParam.gen_srs_for_testing(c, srs_beta, cs.n + 2, g=g)
+    import mirror_prover as MP
     for mode in ("from the SRS", "from beta", "off"):
-        pk = mj.snark.preprocess(ck, cs, lagrange=mode == "from the SRS")           # (None, the default: from 2^13 gates on)
-        assert (pk.lagrange_ck is not None) == (mode == "from the SRS")
-        if mode == "from beta":
-            pk.lagrange_ck = mj.UnivariateProverParam.gen_lagrange_srs_for_testing(c, srs_beta, cs.n, g=g)
-        _, proof_bytes = mj.snark.prove(_rng_after_setup(mj, c, "srs_g" in vec), cs, pk)
-        assert proof_bytes.hex() == vec["proof"], mode
+        from_beta = mj.UnivariateProverParam.gen_lagrange_srs_for_testing(c, srs_beta, cs.n, g=g) if mode == "from beta" else None
+        # the product (round-level C ABI) and the test-side sequencing of the primitives, both with the same key
+        pk = mj.snark.preprocess(ck, cs, lagrange=mode == "from the SRS", lagrange_ck=from_beta)           # (lagrange=None, the default: from 2^13 gates on)
+        assert (pk.lagrange_ck is not None) == (mode != "off")
+        mk = MP.preprocess(ck, cs, lagrange=False)
+        mk.lagrange_ck = pk.lagrange_ck
+        for name, prove, key in (("product", mj.snark.prove, pk), ("mirror", MP.prove, mk)):
+            _, proof_bytes = prove(_rng_after_setup(mj, c, "srs_g" in vec), cs, key)
+            assert proof_bytes.hex() == vec["proof"], (mode, name)
+        mk.lagrange_ck = None
+        mk.release()
         pk.release()
+        if from_beta is not None:
+            from_beta.release()
     ck.release()
 
 
@@ -205,7 +213,8 @@ def test_general_circuit_golden_proofs_from_all_three_hosts(gpu, mj, pyref, tmp_
     rng, beta = rng_and_key()
     ck = mj.UnivariateProverParam.gen_srs_for_testing(c, beta, n + 2)
     # (i) the Python mirror
-    mirror = mj.prover.TurboPlonkProver(c, n, sel_p, sig_p, k, ck, **kw)
+    import mirror_prover as MP
+    mirror = MP.TurboPlonkProver(c, n, sel_p, sig_p, k, ck, **kw)
     sel_c, sig_c = mirror.vk_commitments()
     assert [g1(x) for x in sel_c] == vec["selector_comms"] and [g1(x) for x in sig_c] == vec["sigma_comms"]
     if ultra:

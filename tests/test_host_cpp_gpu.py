@@ -221,7 +221,8 @@ def test_cpp_host_proves_a_general_circuit_from_a_file(gpu, mj, pyref, tmp_path,
     dom = mj.Radix2EvaluationDomain(c, log_n)
     kw = {"plookup": {name: dom.ifft(fr_mont_limbs(c, tabs[key])) for name, key in
                       zip(mj.plonk.PLOOKUP_TABLE_POLYS, ("range", "key", "table_dom_sep", "q_dom_sep"))}} if ultra else {}
-    mirror = mj.prover.TurboPlonkProver(c, n, [dom.ifft(fr_mont_limbs(c, s)) for s in sel], [dom.ifft(fr_mont_limbs(c, s)) for s in sig], k, ck, **kw)
+    import mirror_prover as MP
+    mirror = MP.TurboPlonkProver(c, n, [dom.ifft(fr_mont_limbs(c, s)) for s in sel], [dom.ifft(fr_mont_limbs(c, s)) for s in sig], k, ck, **kw)
     blind = mj.snark.draw_blinders(c, g, W, ultra)
     core = mirror.prove(np.stack([fr_mont_limbs(c, col) for col in w]), fr_mont_limbs(c, pi), mj.prover.TranscriptChallenges(mirror, pub), blind)
     want = mj.snark.serialize_proof(c, core)

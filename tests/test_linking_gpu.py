@@ -6,6 +6,8 @@ import random
 import numpy as np
 import pytest
 
+import mirror_prover as MP          # the primitive-level sequencing of the rounds: test code since round 5 (tests/mirror_prover.py)
+
 from conftest import affine_from_limbs, build_circuit, fr_from_mont_limbs, fr_mont_limbs, verifying_key
 import pyref_fs as FS
 
@@ -26,7 +28,7 @@ def _prove_linked(mj, pyref, curve_id, log_n, layout, shared, rng, srs_beta, ck)
     reserved = {start + i * spacing: v for i, v in enumerate(shared)}
     sel, sig, k, w, pi = build_circuit(pc, log_n, rng, reserved=reserved)
     dom = mj.Radix2EvaluationDomain(c, log_n)
-    prover = mj.prover.TurboPlonkProver(c, n, [dom.ifft(fr_mont_limbs(c, s)) for s in sel], [dom.ifft(fr_mont_limbs(c, s)) for s in sig], k, ck)
+    prover = MP.TurboPlonkProver(c, n, [dom.ifft(fr_mont_limbs(c, s)) for s in sel], [dom.ifft(fr_mont_limbs(c, s)) for s in sig], k, ck)
     blind = mj.snark.draw_blinders(c, mj.rng.ChaChaRng(bytes([log_n]) * 32, 12), 5, False)
     src = mj.prover.TranscriptChallenges(prover, pi[:4])
     core = prover.prove(np.stack([fr_mont_limbs(c, col) for col in w]), fr_mont_limbs(c, pi), src, blind)

@@ -10,6 +10,8 @@ from importlib import import_module
 import numpy as np
 import pytest
 
+import mirror_prover as MP          # the primitive-level sequencing of the rounds: test code since round 5
+
 from conftest import build_circuit, build_ultra_circuit, fr_mont_limbs, load_golden, verifying_key
 import pyref_fs as FS
 
@@ -43,7 +45,7 @@ def test_round_level_abi_on_general_circuits(gpu, mj, pyref, curve_id, ultra, lo
     sel_p, sig_p, k, wires, pi, kw = _general_instance(mj, pc, c, log_n, ultra, rng)
     srs_beta = rng.randrange(1, r)
     ck = mj.UnivariateProverParam.gen_srs_for_testing(c, srs_beta, n + 2)
-    mirror = mj.prover.TurboPlonkProver(c, n, sel_p, sig_p, k, ck, **kw)
+    mirror = MP.TurboPlonkProver(c, n, sel_p, sig_p, k, ck, **kw)
     native = N.NativeProver(c, n, sel_p, sig_p, k, ck, **kw)
     pub = pi[:4]
     assert pub[3] != 0 and not any(pi[4:])
@@ -115,9 +117,9 @@ def test_tiny_domain_keeps_the_degree_guard_of_round_3(gpu, mj):
     assert cs.n == 8
     rng = mj.rng.test_rng()
     ck = mj.UnivariateProverParam.gen_srs_for_testing(c, mj.rng.fr_rand(c, rng), cs.n + 2)
-    pk, npk = mj.snark.preprocess(ck, cs), N.preprocess(ck, cs)
+    pk, npk = MP.preprocess(ck, cs), N.preprocess(ck, cs)
     g1, g2 = mj.rng.test_rng(), mj.rng.test_rng()
-    assert N.prove(g1, cs, npk)[1] == mj.snark.prove(g2, cs, pk)[1]
+    assert N.prove(g1, cs, npk)[1] == MP.prove(g2, cs, pk)[1]
     bad = cs.wire_values.clone()
     bad[4, 3] = bad[4, 4]                                                # the output of the addition gate on row 3 takes row 4's value
     blind = mj.snark.draw_blinders(c, mj.rng.test_rng(), 6, True)
@@ -192,7 +194,7 @@ def test_bench_circuit_every_witness_kind_and_the_lagrange_key(gpu, mj, pyref, c
     rng0 = mj.rng.test_rng()
     srs_beta = mj.rng.fr_rand(c, rng0)
     ck = mj.UnivariateProverParam.gen_srs_for_testing(c, srs_beta, cs.n + 2)
-    pk = mj.snark.preprocess(ck, cs)
+    pk = MP.preprocess(ck, cs)
     npk = N.preprocess(ck, cs)
     assert (npk.lagrange_ck is not None) == (cs.n >= 1 << 13)
 
@@ -201,7 +203,7 @@ def test_bench_circuit_every_witness_kind_and_the_lagrange_key(gpu, mj, pyref, c
         mj.rng.fr_rand(c, g)
         return g
 
-    _, want = mj.snark.prove(fresh_rng(), cs, pk)
+    _, want = MP.prove(fresh_rng(), cs, pk)
     npk.set_wire_variables(cs.wire_variables.cpu().numpy().astype(np.uint32), int(cs.witness.shape[0]))
     host_vec = cs.witness.cpu().pin_memory()
     kinds = {"device wires": None, "host wires": cs.wire_values.cpu(), "host vector": mj.snark.HostWitness(host_vec, cs.wire_variables),
@@ -212,7 +214,7 @@ def test_bench_circuit_every_witness_kind_and_the_lagrange_key(gpu, mj, pyref, c
     # consecutive proofs from one rng stream agree too (the bench's usage: bench.rs:56-60)
     ga, gb = fresh_rng(), fresh_rng()
     for _ in range(3):
-        assert N.prove(ga, cs, npk)[1] == mj.snark.prove(gb, cs, pk)[1]
+        assert N.prove(ga, cs, npk)[1] == MP.prove(gb, cs, pk)[1]
     torch.cuda.synchronize()
     pk.release()
     if npk.lagrange_ck is not None:
@@ -255,13 +257,13 @@ def test_batch_prove_over_native_handles_matches_the_mirror(gpu, mj, pyref, curv
     mirrors, natives, wires_l, pis, pubs, blinds = [], [], [], [], [], []
     for _ in range(3):
         sel_p, sig_p, k, wires, pi, kw = _general_instance(mj, pc, c, log_n, ultra, rng)
-        mirrors.append(mj.prover.TurboPlonkProver(c, n, sel_p, sig_p, k, ck, **kw))
+        mirrors.append(MP.TurboPlonkProver(c, n, sel_p, sig_p, k, ck, **kw))
         natives.append(N.NativeProver(c, n, sel_p, sig_p, k, ck, **kw))
         wires_l.append(wires); pis.append(fr_mont_limbs(c, pi)); pubs.append(pi[:4])
         rnd = lambda cnt: [rng.randrange(r) for _ in range(cnt)]
         blinds.append(mj.prover.Blinders([rnd(2) for _ in range(W)], rnd(3), [], [rnd(3), rnd(3)] if ultra else None, rnd(3) if ultra else None))
     quot_blind = [rng.randrange(r) for _ in range(W - 1)]
-    want = mj.batch.batch_prove(mirrors, wires_l, pis, pubs, blinds, quot_blind, extra_transcript_init_msg=b"batch")
+    want = MP.batch_prove(mirrors, wires_l, pis, pubs, blinds, quot_blind, extra_transcript_init_msg=b"batch")
     got = N.batch_prove(natives, wires_l, pubs, blinds, quot_blind, extra_transcript_init_msg=b"batch")
     assert got.challenges == want.challenges
     assert mj.batch.serialize_batch_proof(c, got) == mj.batch.serialize_batch_proof(c, want)
@@ -284,7 +286,7 @@ def test_a_wrongly_asserted_pi_zero_trips_the_identity_at_zeta(gpu, mj, pyref):
     rng = random.Random(4242)
     sel_p, sig_p, k, wires, pi, kw = _general_instance(mj, pc, c, log_n, False, rng)
     ck = mj.UnivariateProverParam.gen_srs_for_testing(c, rng.randrange(1, c.r), n + 2)
-    mirror = mj.prover.TurboPlonkProver(c, n, sel_p, sig_p, k, ck)
+    mirror = MP.TurboPlonkProver(c, n, sel_p, sig_p, k, ck)
     blind = mj.snark.draw_blinders(c, mj.rng.test_rng(), W, False)
     pub = pi[:4]
     mirror.prove(wires, fr_mont_limbs(c, pi), mj.prover.TranscriptChallenges(mirror, pub), blind)                     # fine

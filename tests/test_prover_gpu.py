@@ -7,6 +7,8 @@ import random
 import numpy as np
 import pytest
 
+import mirror_prover as MP          # the primitive-level sequencing of the rounds: test code since round 5 (tests/mirror_prover.py)
+
 from conftest import affine_from_limbs, build_circuit, fr_from_mont_limbs, fr_mont_limbs
 
 pytestmark = pytest.mark.gpu
@@ -31,7 +33,7 @@ def test_prover_core_matches_bigint_restatement(gpu, mj, pyref, curve_id, log_n)
     sel_polys = [dom.ifft(fr_mont_limbs(c, s)) for s in sel]
     sig_polys = [dom.ifft(fr_mont_limbs(c, s)) for s in sigma_vals]
     ck = mj.UnivariateProverParam.gen_srs_for_testing(c, srs_beta, n + 2)          # n + 3 powers (srs.rs:88)
-    prover = mj.prover.TurboPlonkProver(c, n, sel_polys, sig_polys, k, ck)
+    prover = MP.TurboPlonkProver(c, n, sel_polys, sig_polys, k, ck)
     proof = prover.prove(np.stack([fr_mont_limbs(c, col) for col in w]), fr_mont_limbs(c, pi),
                          mj.prover.ProverChallenges(**ch), mj.prover.Blinders(blind["wires"], blind["z"], blind["quot"]))
     host = lambda t: fr_from_mont_limbs(c, t.cpu().numpy().view(np.uint64))
@@ -80,7 +82,7 @@ def test_prover_with_merlin_transcript(gpu, mj, pyref):
     srs_beta = rng.randrange(r)
     dom = mj.Radix2EvaluationDomain(c, log_n)
     ck = mj.UnivariateProverParam.gen_srs_for_testing(c, srs_beta, n + 2)
-    prover = mj.prover.TurboPlonkProver(c, n, [dom.ifft(fr_mont_limbs(c, s)) for s in sel], [dom.ifft(fr_mont_limbs(c, s)) for s in sigma_vals], k, ck)
+    prover = MP.TurboPlonkProver(c, n, [dom.ifft(fr_mont_limbs(c, s)) for s in sel], [dom.ifft(fr_mont_limbs(c, s)) for s in sigma_vals], k, ck)
     pub = [pi[3]]                                              # one public input (row 3)
     src = mj.prover.TranscriptChallenges(prover, pub)
     proof = prover.prove(np.stack([fr_mont_limbs(c, col) for col in w]), fr_mont_limbs(c, pi), src,

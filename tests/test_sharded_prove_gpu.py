@@ -25,14 +25,26 @@ def _worker(rank, world, port, curve_id, plonk_type, num_gates, out_dir):
         cs = mj.snark.gen_circuit_for_bench(c, num_gates, plonk_type)
         rng = mj.rng.test_rng()
         ck = mj.UnivariateProverParam.gen_srs_for_testing(c, mj.rng.fr_rand(c, rng), cs.n + 2)
+        # (i) the product: this process is one rank of the library's own rounds (mzk_comm over torch.distributed: sharding.TorchComm),
+        # keeping only its point range of the SRS
+        pk = mj.snark.preprocess(ck, cs, comm=mj.sharding.TorchComm() if world > 1 else None)
+        g1 = mj.rng.test_rng()
+        mj.rng.fr_rand(c, g1)
+        _, proof_bytes = mj.snark.prove(g1, cs, pk)
+        with open(os.path.join(out_dir, f"proof_{world}_{rank}.bin"), "wb") as f:
+            f.write(proof_bytes)
+        pk.release()
+        # (ii) the test-side sequencing of the primitives with the torch.distributed committer (tests/mirror_prover.py)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import mirror_prover as MP
         if world > 1:
             gather = lambda local, n_classes: mj.sharding.gather_quotient_classes(local, via_host=True, n_classes=n_classes)
-            pk = mj.snark.preprocess(ck, cs, quotient_shard=(rank, world), quotient_gather=gather)
-            pk.committer = mj.sharding.ShardedCommitter(c, ck)
+            mk = MP.preprocess(ck, cs, quotient_shard=(rank, world), quotient_gather=gather)
+            mk.committer = MP.ShardedCommitter(c, ck)
         else:
-            pk = mj.snark.preprocess(ck, cs)
-        _, proof_bytes = mj.snark.prove(rng, cs, pk)
-        with open(os.path.join(out_dir, f"proof_{world}_{rank}.bin"), "wb") as f:
+            mk = MP.preprocess(ck, cs)
+        _, proof_bytes = MP.prove(rng, cs, mk)
+        with open(os.path.join(out_dir, f"mirror_{world}_{rank}.bin"), "wb") as f:
             f.write(proof_bytes)
     finally:
         dist.destroy_process_group()
@@ -47,9 +59,11 @@ def test_sharded_prove_matches_single_process(gpu, tmp_path, curve_id, plonk_typ
         mp.spawn(_worker, args=(world, port + world, curve_id, plonk_type, num_gates, str(tmp_path)), nprocs=world, join=True)
     single = (tmp_path / "proof_1_0.bin").read_bytes()
     assert len(single) > 500
+    assert (tmp_path / "mirror_1_0.bin").read_bytes() == single
     for world in worlds:
         for rank in range(world):
             assert (tmp_path / f"proof_{world}_{rank}.bin").read_bytes() == single, (world, rank)
+            assert (tmp_path / f"mirror_{world}_{rank}.bin").read_bytes() == single, ("mirror", world, rank)
 
 
 @pytest.mark.parametrize("curve_id,plonk_type,num_gates,classes", [(0, "TurboPlonk", 1 << 10, list(range(8))), (1, "UltraPlonk", 1 << 9, list(range(8))),
@@ -70,15 +84,16 @@ def test_chunked_quotient_single_process(gpu, mj, curve_id, plonk_type, num_gate
     n = cs.n
     rng = mj.rng.test_rng()
     ck = mj.UnivariateProverParam.gen_srs_for_testing(c, mj.rng.fr_rand(c, rng), n + 2)
-    pk0 = mj.snark.preprocess(ck, cs, quotient_classes="whole")
-    core0, bytes0 = mj.snark.prove(mj.rng.test_rng(), cs, pk0)
+    import mirror_prover as MP
+    pk0 = MP.preprocess(ck, cs, quotient_classes="whole")
+    core0, bytes0 = MP.prove(mj.rng.test_rng(), cs, pk0)
     quot0 = pk0.last["quot"].clone()
-    pk1 = mj.snark.preprocess(ck, cs, quotient_classes=classes)
+    pk1 = MP.preprocess(ck, cs, quotient_classes=classes)
     W = 6 if plonk_type == "UltraPlonk" else 5
     if classes is None:
         assert pk1.own_classes == list(range(W))                     # W classes + the top W + 3 coefficients from the numerator (round 3)
     if classes is None or len(classes) >= W:
-        core1, bytes1 = mj.snark.prove(mj.rng.test_rng(), cs, pk1)
+        core1, bytes1 = MP.prove(mj.rng.test_rng(), cs, pk1)
         assert torch.equal(pk1.last["quot"], quot0)
         assert bytes1 == bytes0
     else:

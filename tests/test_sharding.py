@@ -7,6 +7,8 @@ import sys
 import numpy as np
 import pytest
 
+import mirror_prover as MP          # ShardedCommitter: the torch.distributed committer of the test-side prover (tests/mirror_prover.py)
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
@@ -90,7 +92,7 @@ def _committer_worker(rank, world, port, curve_id, lens, out_dir):
         bases = cref.g1_arith_bases(curve_id, 99, 5, max(lens))
         polys = [mj.params.random_fr_mont(c, n, seed=300 + i) for i, n in enumerate(lens)]
         oracle_batch = lambda ck, slices, offs: np.stack([cref.msm(curve_id, bases[o:o + len(s)], s, scalars_are_mont=True) for s, o in zip(slices, offs)])
-        com = mj.sharding.ShardedCommitter(c, None, msm_batch=oracle_batch)
+        com = MP.ShardedCommitter(c, None, msm_batch=oracle_batch)
         np.save(os.path.join(out_dir, f"commits_{rank}.npy"), com.commit_jacobian(polys))
     finally:
         dist.destroy_process_group()
@@ -205,7 +207,7 @@ def _range_worker(rank, world, port, curve_id, srs_len, poly_len, out_dir):
         r = c.r
         bases = cref.g1_arith_bases(curve_id, 31, 7, srs_len)
         oracle_batch = lambda ck, slices, offs: np.stack([cref.msm(curve_id, bases[o:o + len(s)], np.asarray(s), scalars_are_mont=True) for s, o in zip(slices, offs)])
-        com = mj.sharding.ShardedCommitter(c, _Srs(srs_len), msm_batch=oracle_batch)
+        com = MP.ShardedCommitter(c, _Srs(srs_len), msm_batch=oracle_batch)
         assert com.rank() == rank and com.world() == world
         b = mj.params.fr_from_mont(c, mj.params.random_fr_mont(c, poly_len, seed=5))       # the batch polynomial, same on every rank
         z = 0x1234567890abcdef % r

@@ -7,6 +7,8 @@ import random
 import numpy as np
 import pytest
 
+import mirror_prover as MP          # the primitive-level sequencing of the rounds: test code since round 5 (tests/mirror_prover.py)
+
 from conftest import affine_from_limbs, build_ultra_circuit, fr_from_mont_limbs, fr_mont_limbs
 
 pytestmark = pytest.mark.gpu
@@ -27,7 +29,7 @@ def _make_prover(mj, c, log_n, sel, sigma_vals, k, plookup, srs_beta):
     sig_polys = [dom.ifft(fr_mont_limbs(c, s)) for s in sigma_vals]
     tabs = {name: dom.ifft(fr_mont_limbs(c, plookup[key])) for name, key in zip(mj.plonk.PLOOKUP_TABLE_POLYS, TABLES)}
     ck = mj.UnivariateProverParam.gen_srs_for_testing(c, srs_beta, n + 2)
-    return mj.prover.TurboPlonkProver(c, n, sel_polys, sig_polys, k, ck, plookup=tabs), ck
+    return MP.TurboPlonkProver(c, n, sel_polys, sig_polys, k, ck, plookup=tabs), ck
 
 
 @pytest.mark.parametrize("curve_id,log_n", [(0, 5), (1, 6)])
