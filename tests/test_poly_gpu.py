@@ -37,9 +37,9 @@ def test_evaluate_matches_oracle(gpu, mj, cref, curve_id, n):
 
 
 @pytest.mark.parametrize("curve_id", [0, 1])
-def test_evaluate_many_matches_single_calls(gpu, mj, curve_id):
-    """mzk_poly_eval_many_dev (a round's evaluations at zeta and zeta * omega in one call) against mzk_poly_eval_dev job by job: batches,
-    shorter logical lengths, an empty job, one point only."""
+def test_evaluate_many_matches_the_oracle_and_single_calls(gpu, mj, cref, curve_id):
+    """mzk_poly_eval_many_dev (a round's evaluations at zeta and zeta * omega in one call) against Horner's rule on the C oracle -- every
+    value of every job -- and against mzk_poly_eval_dev job by job: batches, shorter logical lengths, an empty job, one point only."""
     import ctypes as C
     from mpc_jellyfish_amd import lib as mlib
     c = mj.params.CURVES[curve_id]
@@ -50,8 +50,14 @@ def test_evaluate_many_matches_single_calls(gpu, mj, curve_id):
     x0, x1 = rng.randrange(c.r), rng.randrange(c.r)
     jobs = [(a, None, 0), (b, None, 1), (d, 257, 1), (b, 0, 0), (a, 4097, 1), (d, None, 0)]
     got = mj.poly.evaluate_many(c, jobs, [x0, x1])
+    xm = [mj.params.fr_to_mont(c, [x])[0] for x in (x0, x1)]
     for (t, length, w), g in zip(jobs, got):
         assert g == mj.poly.evaluate(c, t, [x0, x1][w], length=length)
+        host = t.cpu().numpy().view(np.uint64)
+        host = host.reshape(1, -1, 4) if host.ndim == 2 else host
+        ln = host.shape[1] if length is None else length
+        want = [mj.params.fr_from_mont(c, cref.poly_eval(curve_id, row[:ln], xm[w]).reshape(1, 4))[0] if ln else 0 for row in host]
+        assert g == want, (ln, w)
     assert mj.poly.evaluate_many(c, [(b, None, 0)], [x1])[0] == mj.poly.evaluate(c, b, x1)
     L = mlib.ensure_init()
     assert L.mzk_poly_eval_many_dev(c.curve_id, 65, None, None, None, None, None, None, None, None) == -1
