@@ -41,18 +41,18 @@ sys.path.insert(0, os.path.join(ROOT, "tools"))
 import srchash  # noqa: E402  (tools/srchash.py: hash of the kernel sources a PMC pass was collected on)
 
 HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E peak 8.0 TB/s (spec)
-TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r04_traffic.json")
+TRAFFIC_JSON = os.path.join(ROOT, "profiles", "r05_traffic.json")
 VOP3_NS = 1.9                  # measured cost of one VOP3 wave-instruction per SIMD (profiles/r01_valu_ubench2.txt); 1024 SIMDs
 
 
 def _pmc(key, sources):
-    """(value, note) of one figure of the committed PMC passes (profiles/r04_traffic.json, written by tools/pmc_passes.sh +
+    """(value, note) of one figure of the committed PMC passes (profiles/r05_traffic.json, written by tools/pmc_passes.sh +
     tools/pmc_aggregate.py: PMC counters cannot be read inside the timed run).  The file carries the hash of the kernel sources
     it was collected on; when those sources have changed since, the stale number is NOT quoted: None and a note saying so."""
     try:
         d = json.load(open(TRAFFIC_JSON))
     except Exception:
-        return None, "no committed PMC pass (profiles/r04_traffic.json missing)"
+        return None, "no committed PMC pass (profiles/r05_traffic.json missing)"
     name = "msm" if sources is srchash.MSM_SOURCES else "ntt"
     want = (d.get("source_sha16") or {}).get(name)
     have = srchash.sha16(sources)

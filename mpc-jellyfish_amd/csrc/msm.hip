@@ -65,11 +65,20 @@ struct SortStreams {                                               // one set pe
     hipEvent_t ev_start = nullptr, ev_sorted[SORT_SETS] = {}, ev_acc[SORT_SETS] = {};
 };
 SortStreams g_sort[MAX_CTX];
+inline int n_sort_streams() {                                     // (A/B switch MZK_MSM_SORT_STREAMS: 1 .. 4, default 2)
+    static const int n = std::min(4, std::max(1, std::getenv("MZK_MSM_SORT_STREAMS") ? std::atoi(std::getenv("MZK_MSM_SORT_STREAMS")) : 2));
+    return n;
+}
 int32_t sort_stream_init(SortStreams& ss) {
     if (ss.stream) return MZK_OK;
     int prio_least = 0, prio_greatest = 0;                               // the short sort kernels go first whenever a slot frees up
     HIP_TRY(hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
-    for (auto& q : ss.streams) HIP_TRY(hipStreamCreateWithPriority(&q, hipStreamNonBlocking, std::getenv("MZK_MSM_SORT_PRIO_LOW") ? prio_least : prio_greatest));
+    // only as many streams as the sorts alternate between (two): HIP multiplexes a process's streams onto a handful of hardware queues
+    // (four by default) in creation order, and a stream that lands on the queue of another is serialised with it -- four sort streams
+    // created BEFORE a prover's own stream put that stream on the queue of sort stream 0: its accumulations then waited for the sorts
+    // they were meant to overlap (+5 ms per 2^20-gate proof, round 5: profiles/r05_stream_queue_aliasing.txt)
+    for (int q = 0; q < n_sort_streams(); q++)
+        HIP_TRY(hipStreamCreateWithPriority(&ss.streams[q], hipStreamNonBlocking, std::getenv("MZK_MSM_SORT_PRIO_LOW") ? prio_least : prio_greatest));
     ss.stream = ss.streams[0];
     HIP_TRY(hipEventCreateWithFlags(&ss.ev_start, hipEventDisableTiming));
     for (int i = 0; i < SORT_SETS; i++) {
@@ -276,12 +285,11 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     std::memset(&jobs, 0, sizeof jobs);
     uint32_t heavy_run_cap_max = 0, long_desc_cap_max = 0;
     bool heavy_level_c = false;
-    static const int n_sort_streams = std::min(4, std::max(1, std::getenv("MZK_MSM_SORT_STREAMS") ? std::atoi(std::getenv("MZK_MSM_SORT_STREAMS")) : 2));       // (A/B switch)
     SortStreams& ss = g_sort[cur().logical];
     if (overlap) {
         MZK_TRY(sort_stream_init(ss));
         HIP_TRY(hipEventRecord(ss.ev_start, st));                        // scalars and workspace are ready on st
-        for (int q = 0; q < n_sort_streams; q++) HIP_TRY(hipStreamWaitEvent(ss.streams[q], ss.ev_start, 0));
+        for (int q = 0; q < n_sort_streams(); q++) HIP_TRY(hipStreamWaitEvent(ss.streams[q], ss.ev_start, 0));
     }
 
     {
@@ -289,7 +297,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
         const unsigned n_ranges = M >> MSM_RANGE_LOG ? M >> MSM_RANGE_LOG : 1u;
         for (int p = 0; p < passes; p++) {
             const size_t b = overlap ? (size_t)p % nb : 0;               // this MSM's set of sort buffers
-            const hipStream_t sst = overlap ? ss.streams[p % n_sort_streams] : st;      // the stream this MSM's sort runs on
+            const hipStream_t sst = overlap ? ss.streams[p % n_sort_streams()] : st;      // the stream this MSM's sort runs on
             uint32_t* hist = g_ws.hist.as<uint32_t>() + b * wm;
             uint32_t* offs = g_ws.offs.as<uint32_t>() + b * wm;
             uint32_t* order = g_ws.cursor.as<uint32_t>() + b * wm;
@@ -858,7 +866,7 @@ void jac_to_affine_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uin
 void msm_release_streams() {
     SortStreams& ss = g_sort[cur().logical];
     if (!ss.stream) return;
-    for (auto& q : ss.streams) (void)hipStreamDestroy(q);
+    for (auto& q : ss.streams) if (q) (void)hipStreamDestroy(q);
     (void)hipEventDestroy(ss.ev_start);
     for (int i = 0; i < SORT_SETS; i++) { (void)hipEventDestroy(ss.ev_sorted[i]); (void)hipEventDestroy(ss.ev_acc[i]); }
     ss = SortStreams();

@@ -21,6 +21,8 @@ sys.path.insert(0, ROOT)
 
 def measure(log_n, ks, reps, dense=False, plonk_type="TurboPlonk", curve_id=0):
     os.environ["MZK_VIRTUAL_DEVICES"] = str(max(ks))
+    if os.environ.get("MZK_INFLIGHT_HW_QUEUES"):                          # (experiment: more hardware queues for the K x 4 streams; read by HIP at start-up)
+        os.environ["GPU_MAX_HW_QUEUES"] = os.environ["MZK_INFLIGHT_HW_QUEUES"]
     import torch
     import mpc_jellyfish_amd as mj
     from importlib import import_module
