@@ -13,6 +13,9 @@
 
 #include "../../include/mzk.h"
 
+// library-internal entry point (not in include/mzk.h, not exported): the calling thread's context hands a prover handle its stream
+extern "C" int32_t mzk_ctx_prover_stream(uint32_t k, void** out_stream);
+
 namespace mzk {
 
 void set_error(const std::string& s);
@@ -131,6 +134,7 @@ int32_t ntt_dispatch(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bo
                      const uint32_t* d_patch = nullptr, int skip_batch = -1 /* a batch entry that is not transformed */);
 void ntt_release_plans();
 void msm_release_streams();
+int32_t ctx_prover_stream(unsigned k, hipStream_t* out);      // msm.hip: a context-owned stream for a prover handle (never destroyed by the handle)
 // msm.hip
 int32_t msm_dispatch(const Srs& s, uint64_t base_offset, const uint32_t* d_scalars, uint64_t n, int is_mont, uint32_t* out, hipStream_t st);
 int32_t msm_batch_dispatch(const Srs& s, uint32_t n_polys, const uint32_t* const* d_scalars, const uint64_t* lens, const uint64_t* base_offsets,

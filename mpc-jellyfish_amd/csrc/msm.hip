@@ -62,6 +62,7 @@ constexpr int SORT_SETS = 6;                                       // sorts run 
 struct SortStreams {                                               // one set per device context
     hipStream_t stream = nullptr;                                  // (non-null once the set is initialised)
     hipStream_t streams[4] = {};                                   // sorts go round these: the ~14 short launches of a sort are a latency chain, chains side by side cost one
+    hipStream_t prover[2] = {};                                    // the streams the context's mzk_prover handles run on (created in the SAME burst: below)
     hipEvent_t ev_start = nullptr, ev_sorted[SORT_SETS] = {}, ev_acc[SORT_SETS] = {};
 };
 SortStreams g_sort[MAX_CTX];
@@ -77,8 +78,20 @@ int32_t sort_stream_init(SortStreams& ss) {
     // (four by default) in creation order, and a stream that lands on the queue of another is serialised with it -- four sort streams
     // created BEFORE a prover's own stream put that stream on the queue of sort stream 0: its accumulations then waited for the sorts
     // they were meant to overlap (+5 ms per 2^20-gate proof, round 5: profiles/r05_stream_queue_aliasing.txt)
+    // several contexts on ONE card (MZK_VIRTUAL_DEVICES: proofs in flight) cannot all have queues of their own: context j starts its burst
+    // j * MZK_STREAM_ROT queues further on (placeholder streams), which decides WHICH of its streams meet which of its neighbour's
+    static const int rot = std::getenv("MZK_STREAM_ROT") ? std::atoi(std::getenv("MZK_STREAM_ROT")) : 1;      // (measured: profiles/r05_proofs_in_flight.txt)
+    for (int q = 0; q < (cur().logical * rot) % 4; q++) {
+        hipStream_t pad = nullptr;
+        HIP_TRY(hipStreamCreateWithFlags(&pad, hipStreamNonBlocking));       // (kept: destroying it would give its place in the rotation back)
+    }
     for (int q = 0; q < n_sort_streams(); q++)
         HIP_TRY(hipStreamCreateWithPriority(&ss.streams[q], hipStreamNonBlocking, std::getenv("MZK_MSM_SORT_PRIO_LOW") ? prio_least : prio_greatest));
+    // ... and the prover streams right behind them: the runtime hands out its hardware queues round-robin in creation order, so streams
+    // created in one burst sit on DIFFERENT queues wherever the burst starts -- a handle's stream created later, on its own, shares a
+    // sort stream's queue whenever the number of streams the process made in between happens to be 2 mod 4 (measured with torch side
+    // streams and the host-pointer I/O slots: tools/stream_alias_probe.py extra_streams:k -- 42.5 / 47.6 / 43.0 ms for k = 1 / 2 / 4)
+    for (auto& q : ss.prover) HIP_TRY(hipStreamCreateWithFlags(&q, hipStreamNonBlocking));
     ss.stream = ss.streams[0];
     HIP_TRY(hipEventCreateWithFlags(&ss.ev_start, hipEventDisableTiming));
     for (int i = 0; i < SORT_SETS; i++) {
@@ -863,10 +876,19 @@ void jac_to_affine_host_dispatch(int curve, const uint64_t* xyz, uint64_t n, uin
     else jac_to_affine_host<BnFq>(xyz, n, xy);
 }
 
+// the stream handle `k` of this context runs its rounds on: one of two, made together with the sort streams (sort_stream_init)
+int32_t ctx_prover_stream(unsigned k, hipStream_t* out) {
+    SortStreams& ss = g_sort[cur().logical];
+    MZK_TRY(sort_stream_init(ss));
+    *out = ss.prover[k & 1];
+    return MZK_OK;
+}
+
 void msm_release_streams() {
     SortStreams& ss = g_sort[cur().logical];
     if (!ss.stream) return;
     for (auto& q : ss.streams) if (q) (void)hipStreamDestroy(q);
+    for (auto& q : ss.prover) if (q) (void)hipStreamDestroy(q);
     (void)hipEventDestroy(ss.ev_start);
     for (int i = 0; i < SORT_SETS; i++) { (void)hipEventDestroy(ss.ev_sorted[i]); (void)hipEventDestroy(ss.ev_acc[i]); }
     ss = SortStreams();

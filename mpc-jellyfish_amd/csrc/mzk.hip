@@ -1018,6 +1018,15 @@ int32_t mzk_stream_create(void** out_stream) {
     *out_stream = st;
     return MZK_OK;
 }
+// (internal to the library's own translation units: csrc/prover.hip) the context's stream for prover handle k
+int32_t mzk_ctx_prover_stream(uint32_t k, void** out_stream) {
+    ENTER_CUR();
+    if (!out_stream) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    hipStream_t st = nullptr;
+    MZK_TRY(ctx_prover_stream(k, &st));
+    *out_stream = st;
+    return MZK_OK;
+}
 int32_t mzk_stream_destroy(void* stream) {
     BIND_CUR();
     if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream));

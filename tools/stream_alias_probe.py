@@ -18,6 +18,14 @@ def timed(cs, pk, rng, k=6):
 rng = mj.rng.test_rng()
 ck = mj.UnivariateProverParam.gen_srs_for_testing(c, mj.rng.fr_rand(c, rng), n + 2)
 mode = sys.argv[1]
+if mode.startswith("extra_streams"):                     # a process that already holds other streams (host-pointer I/O slots, torch side streams ..)
+    sc = torch.from_numpy(mj.params.random_fr_mont(c, n, seed=1).view(np.int64)).cuda()
+    for _ in range(2): mj.msm_bigint_batch(ck, [sc] * 5, scalars_are_mont=True)      # the two sort streams exist
+    extra = [torch.cuda.Stream() for _ in range(int(mode.split(":")[1]))]
+    for st_ in extra:
+        with torch.cuda.stream(st_):
+            torch.zeros(8, device="cuda")
+    torch.cuda.synchronize()
 if mode in ("bench_then_dense", "bench_batch_then_dense"):
     if mode == "bench_batch_then_dense":
         sc = torch.from_numpy(mj.params.random_fr_mont(c, n, seed=1).view(np.int64)).cuda()
