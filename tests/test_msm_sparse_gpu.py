@@ -215,3 +215,49 @@ def test_heavy_bucket_scratch_grows_on_demand_and_the_group_runs_again(gpu, mj, 
     mj.lib.check(L.mzk_workspace_hbm_bytes(C.byref(ws)), "mzk_workspace_hbm_bytes")
     assert ws.value > before, "the skewed batch must have enlarged the heavy-bucket scratch"
     pp.release()
+
+
+_LAUNCH_AB_SCRIPT = r"""
+import hashlib, sys
+import numpy as np
+sys.path.insert(0, sys.argv[1])
+sys.path.insert(0, sys.argv[1] + "/oracle")
+sys.path.insert(0, sys.argv[1] + "/tests")
+import mpc_jellyfish_amd as mj
+import cref
+from importlib import import_module
+import_module("mpc-jellyfish_amd.lib").init(0)
+from test_msm_sparse_gpu import _patterns
+c = mj.params.CURVES[0]
+n = (1 << 16) + 3
+bases = cref.g1_arith_bases(0, 0xbeef, 0x2b, n)
+pp = mj.UnivariateProverParam.from_affine(0, bases)
+pats = _patterns(mj, c, n)
+L = mj.load()
+for table in (1, 0):
+    L.mzk_msm_set_precompute(table)
+    for k in sorted(pats):
+        print(table, k, hashlib.sha256(cref.jac_to_affine(0, mj.msm_bigint(pp, pats[k], scalars_are_mont=True)).tobytes()).hexdigest())
+    names = ["dense", "all_equal", "half", "small_limbs", "plus_minus"]
+    jac = mj.msm_bigint_batch(pp, [pats[k] for k in names], scalars_are_mont=True)
+    for i, k in enumerate(names):
+        print(table, "batch:" + k, hashlib.sha256(cref.jac_to_affine(0, jac[i]).tobytes()).hexdigest())
+"""
+
+
+def test_launch_diet_and_round_4_launch_sequence_give_the_same_points(gpu):
+    """Round 5 folded six launches of an MSM into their neighbours (csrc/msm.hip `diet`); MZK_MSM_LEGACY_LAUNCHES=1 keeps the round-4
+    sequence for A/B.  Both sequences -- each in a child process, the switch is read once -- on dense, sparse and skewed scalars, both MSM
+    paths, single calls and a batch: the same affine points (which the tests above pin to the oracle for the default)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    outs = []
+    for env in ({}, {"MZK_MSM_LEGACY_LAUNCHES": "1"}, {"MZK_MSM_FOLD2": "1"}):
+        r = subprocess.run([sys.executable, "-c", _LAUNCH_AB_SCRIPT, root], env=dict(os.environ, **env), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs.append([l for l in r.stdout.splitlines() if len(l.split()) == 3])
+    assert len(outs[0]) == 2 * (7 + 5)
+    assert outs[0] == outs[1], "launch diet vs the round-4 launch sequence"
+    assert outs[0] == outs[2], "two reduction levels per launch (off by default)"

@@ -299,3 +299,21 @@ def test_a_wrongly_asserted_pi_zero_trips_the_identity_at_zeta(gpu, mj, pyref):
         mirror.prove(wires, fr_mont_limbs(c, pi), mj.prover.TranscriptChallenges(mirror, pub), blind)
     mirror.release()
     ck.release()
+
+
+@pytest.mark.parametrize("args", [["--log-n", "12"], ["--log-n", "13", "--ultra"]])
+def test_proofs_in_flight_on_one_card_are_the_same_bytes(gpu, args):
+    """Round 5: every handle runs on a stream of its context.  tools/prove_in_flight.py --check: three host threads, three device contexts
+    on the ONE card (MZK_VIRTUAL_DEVICES), proving concurrently from identical rng streams -- every proof made while the others are in
+    flight must be the same bytes, and the same as each context's proof made alone."""
+    import json
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    r = subprocess.run([sys.executable, os.path.join(root, "tools", "prove_in_flight.py"), "--in-flight", "1,3", "--reps", "6", "--check"] + args,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stderr[-2000:]
+    d = json.loads(r.stdout.strip().splitlines()[-1])
+    assert d["contexts_agree_on_proof"] is True and d["proofs_made_concurrently_identical"] is True
+    assert d["in_flight"]["3"]["proofs_per_s"] > 0

@@ -19,7 +19,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 
 
-def measure(log_n, ks, reps, dense=False, plonk_type="TurboPlonk", curve_id=0):
+def measure(log_n, ks, reps, dense=False, plonk_type="TurboPlonk", curve_id=0, check=False):
     os.environ["MZK_VIRTUAL_DEVICES"] = str(max(ks))
     if os.environ.get("MZK_INFLIGHT_HW_QUEUES"):                          # (experiment: more hardware queues for the K x 4 streams; read by HIP at start-up)
         os.environ["GPU_MAX_HW_QUEUES"] = os.environ["MZK_INFLIGHT_HW_QUEUES"]
@@ -89,6 +89,32 @@ def measure(log_n, ks, reps, dense=False, plonk_type="TurboPlonk", curve_id=0):
             raise SystemExit("; ".join(errors))
         el = max(done) - t0
         out[k_now] = {"proofs_per_s": round(k_now * reps / el, 2), "ms_per_proof_per_prover": round(el / reps * 1e3, 2)}
+    # --check: K threads prove CONCURRENTLY from identical rng streams: every proof made while others are in flight must be the same bytes
+    concurrent_ok = None
+    if check:
+        K2 = max(ks)
+        start = threading.Barrier(K2)
+        got = [[] for _ in range(K2)]
+
+        def work_check(k):
+            try:
+                mlib.check(L.mzk_init(k), "mzk_init")
+                _, cs, pk, _ = state[k]
+                start.wait()
+                for _ in range(4):
+                    g = mj.rng.test_rng()
+                    mj.rng.fr_rand(curve, g)                              # (the SRS trapdoor was the first draw of the stream)
+                    got[k].append(hashlib.sha256(native.prove(g, cs, pk)[1]).hexdigest())
+            except Exception as e:                                        # noqa: BLE001
+                errors.append("check %d: %r" % (k, e))
+        th = [threading.Thread(target=work_check, args=(k,)) for k in range(K2)]
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        if errors:
+            raise SystemExit("; ".join(errors))
+        concurrent_ok = len({d for row in got for d in row}) == 1 and all(len(row) == 4 for row in got)
     # every context must emit the same bytes for the same rng stream
     for k in range(K):
         def one(k=k):
@@ -99,7 +125,8 @@ def measure(log_n, ks, reps, dense=False, plonk_type="TurboPlonk", curve_id=0):
         t.start()
         t.join()
     res = {"log_n": log_n, "plonk_type": plonk_type, "curve": curve.name, "dense_witness": dense, "reps_per_prover": reps,
-           "in_flight": {str(k): v for k, v in out.items()}, "contexts_agree_on_proof": len(digests) == 1}
+           "in_flight": {str(k): v for k, v in out.items()}, "contexts_agree_on_proof": len(digests) == 1,
+           "proofs_made_concurrently_identical": concurrent_ok}
     if 1 in out:
         for k, v in out.items():
             if k != 1:
@@ -124,5 +151,8 @@ if __name__ == "__main__":
     ap.add_argument("--in-flight", default="1,2,3")
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--dense", action="store_true")
+    ap.add_argument("--ultra", action="store_true", help="UltraPlonk over BN254 instead of TurboPlonk over BLS12-381")
+    ap.add_argument("--check", action="store_true", help="also: K threads prove concurrently from identical rng streams; all proofs must be the same bytes")
     a = ap.parse_args()
-    print(json.dumps(measure(a.log_n, [int(x) for x in a.in_flight.split(",")], a.reps, a.dense)))
+    print(json.dumps(measure(a.log_n, [int(x) for x in a.in_flight.split(",")], a.reps, a.dense, "UltraPlonk" if a.ultra else "TurboPlonk",
+                             1 if a.ultra else 0, a.check)))
