@@ -35,6 +35,10 @@ def test_bench_prints_one_json_line_with_the_contract_keys(gpu):
     for key in ("prove_ms", "prove_dense_witness_ms", "prove_coefficient_commit_ms", "ntt_2p22_ms", "kernel_launches_per_proof", "hbm_total_bytes"):
         assert d[key] == d["roofline"][key] and d[key] > 0, key
     assert not any(isinstance(v, (dict, list)) for k, v in cb.items() if k.startswith(("cpu_", "gpu_", "value")))
+    # round 5: proofs in flight on the one card, and what a dense-witness prover holds in HBM, as flat scalars too
+    assert d["prove_proofs_per_s_1_in_flight"] > 0 and d["prove_proofs_per_s_2_in_flight"] > 0 and d["prove_in_flight_contexts_agree_on_proof"] is True
+    assert 0 < d["hbm_total_bytes_dense_witness_prover"] and d["hbm_total_bytes"] == d["roofline"]["hbm_total_bytes"] > 0
+    assert d["roofline"]["launches_per_msm"] > 0 and d["prove"]["round_level_abi_same_proof_bytes"] is True
     assert big_keys(d), "precompute cost, variable-base leg, shim-only leg"
     assert d["prove_cpp_host"]["turbo_bls12_381"]["proof_bytes"] == d["prove"]["proof_bytes"]
     assert d["prove_cpp_host"]["ultra_bn254"]["proof_bytes"] == d["prove_ultra_bn254"]["proof_bytes"]
