@@ -663,7 +663,7 @@ def main():
     prove_replicas = None
     if not args.no_plonk and world > 1 and not os.environ.get("MZK_BENCH_NO_REPLICAS"):
         try:
-            native = import_module("mpc-jellyfish_amd.native")
+            native = mj.snark
             pn = 1 << args.plonk_log_n
             ckr = mj.UnivariateProverParam.gen_srs_for_testing(curve, beta, pn + 2)            # the same SRS, circuit and rng seed on every rank
             csr = mj.snark.gen_circuit_for_bench(curve, pn, "TurboPlonk")

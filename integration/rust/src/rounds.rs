@@ -10,7 +10,7 @@
 //! relation/src/constraint_system.rs:127, 131):
 //!     impl<F: FftField> PlonkCircuit<F> { pub fn witness_and_wire_variables(&self) -> (&[F], &[Vec<Variable>; GATE_WIDTH + 2]) }
 //! NOT COMPILED in this repository's image (no Rust toolchain); the C++ host (mpc-jellyfish_amd/host/mzk_prover.hpp) and the ctypes
-//! driver (mpc-jellyfish_amd/native.py) are the compiled / executed twins of exactly this call sequence.
+//! driver (mpc-jellyfish_amd/prover.py) are the compiled / executed twins of exactly this call sequence.
 use ark_ec::{pairing::Pairing, short_weierstrass::Affine, AffineRepr};
 use ark_ff::{PrimeField, UniformRand};
 use ark_std::rand::{CryptoRng, RngCore};

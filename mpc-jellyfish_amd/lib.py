@@ -105,7 +105,7 @@ _SIGS = {
     "mzk_workspace_release": [],
     "mzk_launch_count": [C.POINTER(C.c_uint64)],
     "mzk_poly_eval_many_dev": [C.c_int32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
-    # the prover's rounds (csrc/prover.hip); mzk_comm* travels as a void pointer (native.Comm)
+    # the prover's rounds (csrc/prover.hip); mzk_comm* travels as a void pointer (sharding.TorchComm)
     "mzk_prover_create": [C.c_int32, C.c_uint32, C.c_uint32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_void_p,
                           C.POINTER(C.c_uint64)],
     "mzk_prover_destroy": [C.c_uint64],

@@ -1,5 +1,5 @@
 """GPU: the prover's rounds behind the C ABI (mzk_prover_create / round1 .. round5, include/mzk.h; csrc/prover.hip) driven through
-ctypes (mpc-jellyfish_amd/native.py) the way a Rust caller would drive them -- transcript, rng and Proof assembly on the caller's
+ctypes (mpc-jellyfish_amd/prover.py) the way a Rust caller would drive them -- transcript, rng and Proof assembly on the caller's
 side -- on GENERAL circuits: non-zero public input, add / mul / x^5 gates, copy constraints, key and range lookups.  The bytes must
 equal the Python mirror's (prover.TurboPlonkProver, which sequences the library's primitives itself) and the golden vectors the
 oracle produced on the CPU, and the restated reference verifier (oracle/pyref_verifier.py) must accept them."""
@@ -20,7 +20,10 @@ TABLES = ("range", "key", "table_dom_sep", "q_dom_sep")
 
 
 def _native(mj):
-    return import_module("mpc-jellyfish_amd.native")
+    """the product's client of the round-level C ABI under the names these tests have used since round 4"""
+    import types
+    return types.SimpleNamespace(NativeProver=mj.prover.TurboPlonkProver, preprocess=mj.snark.preprocess, prove=mj.snark.prove,
+                                 batch_prove=mj.batch.batch_prove, round3=mj.prover.round3, round5=mj.prover.round5)
 
 
 def _general_instance(mj, pc, c, log_n, ultra, rng):

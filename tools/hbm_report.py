@@ -21,7 +21,7 @@ ap.add_argument("--dense", action="store_true")
 ap.add_argument("--ultra", action="store_true")
 a = ap.parse_args()
 mlib = import_module("mpc-jellyfish_amd.lib")
-native = import_module("mpc-jellyfish_amd.native")
+native = mj.snark                                      # (preprocess / prove: thin clients of the round-level C ABI)
 L = mlib.init(0)
 curve = mj.params.BN254 if a.ultra else mj.params.BLS12_381
 n = 1 << a.log_n

@@ -27,7 +27,7 @@ def measure(log_n, ks, reps, dense=False, plonk_type="TurboPlonk", curve_id=0, c
     import mpc_jellyfish_amd as mj
     from importlib import import_module
     mlib = import_module("mpc-jellyfish_amd.lib")
-    native = import_module("mpc-jellyfish_amd.native")
+    native = mj.snark                                      # (preprocess / prove: thin clients of the round-level C ABI)
     L = mlib.load()
     curve = mj.params.CURVES[curve_id]
     n = 1 << log_n
