@@ -286,8 +286,7 @@ MZK_API int32_t mzk_plonk_perm_product(uint64_t pk_handle, const uint64_t* wire_
  * elements of either curve, d_wire_variables = u32 variable indices (wire-major).  The index table is circuit structure -- resident
  * once per circuit -- so a host-resident witness crosses PCIe as n_vars x 32 B instead of W x n x 32 B (the bench circuit: 1 / 5).
  * An index >= n_vars yields zero and is NOT reported here (the call is asynchronous): the reference panics on such an index, so validate
- * the table once where it is registered -- mzk_prover_set_wire_variables does (MZK_ERR_INVALID_ARG), the Python mirror checks its index
- * tensor on first use.  Asynchronous; the wire iNTTs (mzk_ntt_dev) follow on the same stream. */
+ * the table once where it is registered -- mzk_prover_set_wire_variables does (MZK_ERR_INVALID_ARG).  Asynchronous; the wire iNTTs (mzk_ntt_dev) follow on the same stream. */
 MZK_API int32_t mzk_plonk_gather_witness_dev(const void* d_witness, uint64_t n_vars, const void* d_wire_variables, uint64_t count, void* d_out,
                                              void* stream);
 
@@ -366,7 +365,16 @@ MZK_API int32_t mzk_poly_div_roots_dev(int32_t curve_id, const void* d_poly, uin
  * quotient is recovered from W residue classes and the top coefficients of its numerator (mzk_plonk_quotient_top_dev), which has
  * the expected degree whatever the witness; the guard is the quotient identity at zeta, checked at the end of round 5 on a value
  * the opening's division leaves anyway: mzk_prover_round5 returns MZK_ERR_WRONG_QUOTIENT_DEGREE (the proof must be discarded).
- * Tiny domains (n <= W + 2) keep the reference's guard and round 3 returns that code. */
+ * Tiny domains (n <= W + 2) keep the reference's guard and round 3 returns that code.
+ *
+ * Streams (round 5).  A handle runs its rounds on a non-blocking stream of its device context (two per context, handed to its handles in
+ * turn; MZK_PROVER_NULL_STREAM=1: the null stream, as before).  mzk_prover_round1 makes that stream wait for everything the caller has
+ * enqueued on the NULL stream (a device-resident witness written there is complete first; work on other streams of the caller's must be
+ * synchronised by the caller); every round returns when its outputs are in host memory; mzk_prover_poly_dev's pointers are valid to read
+ * on any stream once round 5 has returned.  Two proofs on one card -- two host threads, each bound (mzk_init) to its own device context
+ * (MZK_VIRTUAL_DEVICES maps several contexts onto one GPU), or two handles of one context -- run concurrently where the hardware allows.
+ * Domains whose quotient does not fit the 8n-point domain (num_wire_types * (n + 1) + 2 >= 8 n: n = 2; n = 4 with six wire types) are
+ * refused by mzk_prover_create with MZK_ERR_UNSUPPORTED. */
 #define MZK_ERR_WRONG_QUOTIENT_DEGREE (-9) /* PlonkError::WrongQuotientPolyDegree: the witness does not satisfy the circuit */
 #define MZK_ERR_STATE (-10)                /* prover rounds called out of order */
 
