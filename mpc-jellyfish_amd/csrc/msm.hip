@@ -9,6 +9,7 @@
 
 #include "internal.hpp"
 #include "hostfp.hpp"
+#include "host_tail.hpp"
 #include "msm.cuh"
 #include "msm_pre.cuh"
 
@@ -16,35 +17,7 @@ namespace mzk {
 std::atomic<bool> g_msm_precompute{true};
 namespace {
 
-// ---- MSM ------------------------------------------------------------------------------------------
-template <class FQ>
-void host_horner(const uint32_t* pts, int n_win, int c, uint32_t* out_xyz) {
-    using F = Fp64<FQ>;
-    const int log_m = c - 1, per = log_m + 1, W4 = 4 * FQ::N;
-    auto load = [&](int w, int j) {
-        XYZZ<F> p;
-        const uint32_t* s = pts + ((size_t)w * per + j) * W4;
-        p.x = F::from_words(s); p.y = F::from_words(s + FQ::N);
-        p.zz = F::from_words(s + 2 * FQ::N); p.zzz = F::from_words(s + 3 * FQ::N);
-        return p;
-    };
-    XYZZ<F> acc = XYZZ<F>::inf();
-    for (int w = n_win - 1; w >= 0; w--) {
-        for (int k = c - 1; k >= 0; k--) {
-            if (!acc.is_inf()) acc = xyzz_dbl(acc);
-            if (k <= c - 2) {
-                XYZZ<F> t = load(w, log_m - k);          // buckets whose index has bit k set
-                if (!t.is_inf()) acc = xyzz_add(acc, t);
-            }
-        }
-        XYZZ<F> t0 = load(w, 0);                          // sum of all buckets (weights are index+1)
-        if (!t0.is_inf()) acc = xyzz_add(acc, t0);
-    }
-    F X, Y, Z;
-    xyzz_to_jacobian(acc, X, Y, Z);
-    X.to_words(out_xyz); Y.to_words(out_xyz + FQ::N); Z.to_words(out_xyz + 2 * FQ::N);
-}
-
+// ---- MSM (the host Horner tail over the device's bit-sums: host_tail.hpp) ---------------------------------------
 struct MsmItem {
     const uint32_t* d_bases;     // plain path: first base of this MSM; pre path: the precomputed table
     const uint32_t* d_scalars;
@@ -558,8 +531,8 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     const uint32_t* h = reinterpret_cast<const uint32_t*>(g_ws.h_collect);
     const size_t per = (size_t)n_out_one * 4 * FQ::N;
     // a Horner tail is c doublings + c additions on one core, ~14 us on the table path (one bucket set): starting a thread costs more
-    // than running it (measured: 5 tails on 5 fresh threads 130-250 us, in sequence 70 us).  Threads only for many-window plain-path
-    // batches (n_win tails of work each).
+    // than running it (measured: 5 tails on 5 fresh threads 130-250 us, in sequence 70 us).  The n_win sets of ONE plain-path MSM are
+    // summed side by side on the sleeping workers of host_tail.hpp (round 5); fresh threads only for many-window plain-path batches.
     if (count * n_win <= 16) {
         for (int p = 0; p < count; p++) host_horner<FQ>(h + p * per, n_win, c, items[p].out_xyz);
     } else {
