@@ -208,4 +208,43 @@ void host_horner(const uint32_t* pts, int n_win, int c, uint32_t* out_xyz) {
     host_tail_store<FQ>(acc, out_xyz);
 }
 
+// the tails of `count` MSMs of one group (every MSM: n_win sets of c bit-sums, `per_words` words apart; result p to outs[p]).
+// Single-set tails -- the five or six commits of a proof's round on the table path, ~17 us each -- run side by side on the pool, the
+// caller taking its share; a many-window MSM on its own takes the overlapped form above; batches of many-window MSMs (plain path,
+// rare) run whole tails side by side.
+template <class FQ>
+struct HostTailBatchJob {
+    const uint32_t* pts;
+    size_t per_words;
+    int n_win, c;
+    uint32_t* const* outs;
+    std::atomic<int>* ready;            // [count]
+    static void run(void* ctx, int p) {
+        auto* j = static_cast<HostTailBatchJob*>(ctx);
+        host_horner_serial<FQ>(j->pts + (size_t)p * j->per_words, j->n_win, j->c, j->outs[p]);
+        j->ready[p].store(1, std::memory_order_release);
+    }
+};
+template <class FQ>
+void host_horner_batch(const uint32_t* pts, size_t per_words, int count, int n_win, int c, uint32_t* const* outs) {
+    constexpr int MAX_COUNT = 64;
+    if (count == 1) return host_horner<FQ>(pts, n_win, c, outs[0]);
+    HostTailPool& pool = host_tail_pool();
+    std::atomic<int> ready[MAX_COUNT];
+    HostTailBatchJob<FQ> job{pts, per_words, n_win, c, outs, ready};
+    uint32_t gen = 0;
+    if (count <= MAX_COUNT && pool.size()) {
+        for (int p = 0; p < count; p++) ready[p].store(0, std::memory_order_relaxed);
+        gen = pool.try_begin(&HostTailBatchJob<FQ>::run, &job, count);
+    }
+    if (!gen) {
+        for (int p = 0; p < count; p++) host_horner_serial<FQ>(pts + (size_t)p * per_words, n_win, c, outs[p]);
+        return;
+    }
+    for (int i; (i = pool.claim(gen)) >= 0;) HostTailBatchJob<FQ>::run(&job, i);
+    for (int p = 0; p < count; p++)
+        while (!ready[p].load(std::memory_order_acquire)) HostTailPool::cpu_relax();
+    pool.end();
+}
+
 }  // namespace mzk

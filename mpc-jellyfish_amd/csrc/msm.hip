@@ -530,18 +530,12 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
     }
     const uint32_t* h = reinterpret_cast<const uint32_t*>(g_ws.h_collect);
     const size_t per = (size_t)n_out_one * 4 * FQ::N;
-    // a Horner tail is c doublings + c additions on one core, ~14 us on the table path (one bucket set): starting a thread costs more
-    // than running it (measured: 5 tails on 5 fresh threads 130-250 us, in sequence 70 us).  The n_win sets of ONE plain-path MSM are
-    // summed side by side on the sleeping workers of host_tail.hpp (round 5); fresh threads only for many-window plain-path batches.
-    if (count * n_win <= 16) {
-        for (int p = 0; p < count; p++) host_horner<FQ>(h + p * per, n_win, c, items[p].out_xyz);
-    } else {
-        const int n_thr = std::min(count, 4);
-        std::vector<std::thread> th;
-        for (int q = 0; q < n_thr; q++)
-            th.emplace_back([=] { for (int p = q; p < count; p += n_thr) host_horner<FQ>(h + p * per, n_win, c, items[p].out_xyz); });
-        for (auto& t : th) t.join();
-    }
+    // a Horner tail is c doublings + c additions on one core, ~17 us on the table path (one bucket set): starting a thread costs more
+    // than running it (measured: 5 tails on 5 fresh threads 130-250 us, in sequence 70 us) -- the tails of a group, and the bucket
+    // sets of ONE plain-path MSM, run side by side on the sleeping workers of host_tail.hpp instead (round 5)
+    std::vector<uint32_t*> outs(count);
+    for (int p = 0; p < count; p++) outs[p] = items[p].out_xyz;
+    host_horner_batch<FQ>(h, per, count, n_win, c, outs.data());
     return MZK_OK;
 }
 

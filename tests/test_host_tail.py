@@ -24,7 +24,7 @@ def test_pooled_tail_is_the_serial_point(tmp_path):
         out = subprocess.run([exe], capture_output=True, text=True, env=dict(os.environ, MZK_HOST_TAIL_THREADS=workers), timeout=300)
         assert out.returncode == 0, out.stdout + out.stderr
         lines = [ln for ln in out.stdout.splitlines() if "same point" in ln]
-        assert len(lines) == 5 and all(ln.endswith("same point: yes") for ln in lines), out.stdout
+        assert len(lines) == 8 and all(ln.endswith("same point: yes") for ln in lines), out.stdout
         assert all("(pool of %s)" % workers in ln for ln in lines), out.stdout
 
 
