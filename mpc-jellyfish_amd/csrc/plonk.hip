@@ -146,8 +146,7 @@ int32_t pk_build(PlonkPk& pk, const uint32_t* sel_coeffs, const uint32_t* sig_co
     HIP_TRY(hipMemsetAsync(pk.d_sigma_n, 0, (size_t)pk.W * n * 32, st));
     const uint64_t sl = poly_len < n ? poly_len : n;
     HIP_TRY(hipMemcpy2DAsync(pk.d_sigma_n, n * 32, sig_coeffs, poly_len * 32, sl * 32, pk.W, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL((fr_powers_mont_kernel<P>), dim3((unsigned)(((n + 15) / 16 + PLK_THREADS - 1) / PLK_THREADS)), dim3(PLK_THREADS), 0, st,
-                       to_fr_arg<P>(wn), n, pk.d_omega_n);
+    launch_powers<P>(st, &wn, 1, n, &pk.d_omega_n);
     HIP_TRY(hipGetLastError());
     MZK_TRY(ws_release(st));
     MZK_TRY(ntt_dispatch(pk.curve, pk.d_sigma_n, sl, pk.log_n, false, nullptr, pk.W, n, st));
@@ -431,7 +430,7 @@ int32_t pk_build_chunked(PlonkPk& pk, const uint32_t* sel_coeffs, const uint32_t
     HIP_TRY(hipMalloc((void**)&pk.d_omega_n, n * 32));
     HIP_TRY(hipMemsetAsync(pk.d_sigma_n, 0, (size_t)pk.W * n * 32, st));
     HIP_TRY(hipMemcpy2DAsync(pk.d_sigma_n, n * 32, sig_coeffs, poly_len * 32, sl * 32, pk.W, hipMemcpyHostToDevice, st));
-    hipLaunchKernelGGL((fr_powers_mont_kernel<P>), dim3(tg), dim3(PLK_THREADS), 0, st, to_fr_arg<P>(wn), n, pk.d_omega_n);
+    launch_powers<P>(st, &wn, 1, n, &pk.d_omega_n);
     HIP_TRY(hipGetLastError());
     MZK_TRY(ws_release(st));
     // class evaluations of the fixed polynomials: size-n coset NTTs with offset h_k, all polynomials of a class in one batch

@@ -79,18 +79,70 @@ __global__ __launch_bounds__(POLY_THREADS) void poly_eval_final_kernel(const uin
     if (threadIdx.x == 0) store_fp<P>(out + (size_t)blockIdx.x * 8, s);
 }
 
-// out[j] = w^j (Montgomery), 16 per thread
+// out[j] = w^j (Montgomery) for j < n, 16 per thread, for up to two bases in one launch (grid.y = base).
+// The host -- where a field product costs 30 ns -- sends w^(d 4^L), d = 1..3, for every base-4 digit position L of an exponent
+// as kernel arguments (PowTable: 1.3 KB per base), so a thread's first power w^(16 t) is a product of at most 12 of them (at most 6
+// up to 2^16 elements) and its 16 outputs are that times w^(4 a) times w^b: a chain of 8 dependent products where round 4's form
+// (square-and-multiply per thread, then 16 products in sequence) had up to 60 -- the table of a 2^15-coefficient polynomial 29 -> 8 us,
+// and a proof launches six of them (rounds 4 and 5), now three.
+constexpr int POW_LEVELS = 14;                 // exponents below 4^14 = 2^28
+struct PowTable { uint32_t p[POW_LEVELS][3][8]; };
+struct PowArgs {
+    PowTable t[2];
+    unsigned long long n;
+    uint32_t* out[2];
+};
 template <class P>
-__global__ __launch_bounds__(POLY_THREADS) void fr_powers_mont_kernel(FrArg w_mont, unsigned long long n, uint32_t* __restrict__ out) {
+__global__ __launch_bounds__(POLY_THREADS) void fr_powers_tab_kernel(PowArgs a) {
     using F = Fp<P>;
     const unsigned long long start = ((unsigned long long)blockIdx.x * POLY_THREADS + threadIdx.x) * 16;
-    if (start >= n) return;
-    const F w = fr_arg<P>(w_mont);
-    F x = pow_u64(w, start);
-    for (int q = 0; q < 16 && start + q < n; q++) {
-        store_fp<P>(out + (start + q) * 8, x);
-        x = x * w;
+    if (start >= a.n) return;
+    const PowTable& tb = a.t[blockIdx.y];
+    uint32_t* __restrict__ out = a.out[blockIdx.y];
+    auto entry = [&](int L, unsigned d) {
+        F r;
+#pragma unroll
+        for (int q = 0; q < 8; q++) r.l[q] = tb.p[L][d - 1][q];
+        return r;
+    };
+    F x = F::one();
+    bool have = false;
+#pragma unroll 1
+    for (int L = 2; L < POW_LEVELS; L++) {
+        const unsigned d = (unsigned)(start >> (2 * L)) & 3u;
+        if (d == 0) continue;
+        x = have ? x * entry(L, d) : entry(L, d);
+        have = true;
     }
+#pragma unroll 1
+    for (unsigned hi = 0; hi < 4; hi++) {
+        const F xa = hi ? x * entry(1, hi) : x;
+#pragma unroll 1
+        for (unsigned lo = 0; lo < 4; lo++) {
+            const unsigned long long j = start + 4 * hi + lo;
+            if (j < a.n) store_fp<P>(out + j * 8, lo ? xa * entry(0, lo) : xa);
+        }
+    }
+}
+// the launch: count = 1 or 2 bases, n powers each
+template <class P>
+inline PowTable make_pow_table(const Fp<P>& w) {
+    PowTable t;
+    Fp<P> e = w;
+    for (int L = 0; L < POW_LEVELS; L++) {
+        const Fp<P> e2 = e * e, e3 = e2 * e;
+        for (int q = 0; q < 8; q++) { t.p[L][0][q] = e.l[q]; t.p[L][1][q] = e2.l[q]; t.p[L][2][q] = e3.l[q]; }
+        e = e2 * e2;
+    }
+    return t;
+}
+template <class P>
+inline void launch_powers(hipStream_t st, const Fp<P>* w, int count, unsigned long long n, uint32_t* const* out) {
+    if (n == 0 || count <= 0) return;
+    PowArgs a;
+    for (int q = 0; q < 2; q++) { a.t[q] = make_pow_table<P>(w[q < count ? q : 0]); a.out[q] = out[q < count ? q : 0]; }
+    a.n = n;
+    hipLaunchKernelGGL((fr_powers_tab_kernel<P>), dim3((unsigned)(((n + 15) / 16 + POLY_THREADS - 1) / POLY_THREADS), (unsigned)count), dim3(POLY_THREADS), 0, st, a);
 }
 
 struct LincombArgs {

@@ -23,8 +23,7 @@ int32_t eval_run(const uint32_t* d_coeffs, uint64_t stride, uint64_t len, uint32
     uint32_t* partial = xpow + (size_t)T * 8;
     uint32_t* d_out = partial + (size_t)batch * blocks * 8;
     const uint64_t tlen = len < T ? len : T;
-    hipLaunchKernelGGL((fr_powers_mont_kernel<P>), dim3((unsigned)(((tlen + 15) / 16 + POLY_THREADS - 1) / POLY_THREADS)), dim3(POLY_THREADS), 0, st,
-                       to_fr_arg<P>(x), tlen, xpow);                 // x and y travel as kernel arguments
+    launch_powers<P>(st, &x, 1, tlen, &xpow);                        // (x's powers and y travel as kernel arguments)
     hipLaunchKernelGGL((poly_eval_partial_kernel<P>), dim3(blocks, batch), dim3(POLY_THREADS), 0, st, d_coeffs, stride, len, xpow, to_fr_arg<P>(y),
                        (unsigned long long)T, partial);
     hipLaunchKernelGGL((poly_eval_final_kernel<P>), dim3(batch), dim3(POLY_THREADS), 0, st, partial, blocks, d_out);
@@ -55,10 +54,14 @@ int32_t eval_many_run(const EvalJob* jobs, uint32_t n_jobs, const uint32_t* x_mo
     uint32_t* partial = xpow + 2 * (size_t)T * 8;
     uint32_t* d_out = partial + (size_t)total * blocks * 8;
     const uint64_t tlen = max_len < T ? max_len : T;
-    for (int q = 0; q < 2; q++)
-        if (used[q])
-            hipLaunchKernelGGL((fr_powers_mont_kernel<P>), dim3((unsigned)(((tlen + 15) / 16 + POLY_THREADS - 1) / POLY_THREADS)), dim3(POLY_THREADS), 0, st,
-                               to_fr_arg<P>(x[q]), tlen, xpow + (size_t)q * T * 8);
+    {                                                              // the power tables of the points in use: one launch
+        F bases[2];
+        uint32_t* tabs[2];
+        int nb = 0;
+        for (int q = 0; q < 2; q++)
+            if (used[q]) { bases[nb] = x[q]; tabs[nb] = xpow + (size_t)q * T * 8; nb++; }
+        launch_powers<P>(st, bases, nb, tlen, tabs);
+    }
     uint64_t at = 0;
     for (uint32_t j = 0; j < n_jobs; j++) {
         const EvalJob& jb = jobs[j];
@@ -99,10 +102,12 @@ int32_t div_run(const uint32_t* d_poly, uint64_t len, const uint32_t* z_mont, ui
     uint32_t* zinvpow = zpow + len * 8;
     uint32_t* t = zinvpow + len * 8;
     uint32_t* totals = t + len * 8;
-    const unsigned pg = (unsigned)(((len + 15) / 16 + POLY_THREADS - 1) / POLY_THREADS);
     const unsigned eg = (unsigned)((len + POLY_THREADS - 1) / POLY_THREADS);
-    hipLaunchKernelGGL((fr_powers_mont_kernel<P>), dim3(pg), dim3(POLY_THREADS), 0, st, to_fr_arg<P>(z), len, zpow);
-    hipLaunchKernelGGL((fr_powers_mont_kernel<P>), dim3(pg), dim3(POLY_THREADS), 0, st, to_fr_arg<P>(zi), len, zinvpow);
+    {
+        const F bases[2] = {z, zi};
+        uint32_t* const tabs[2] = {zpow, zinvpow};
+        launch_powers<P>(st, bases, 2, len, tabs);
+    }
     hipLaunchKernelGGL((poly_div_scale_kernel<P>), dim3(eg), dim3(POLY_THREADS), 0, st, d_poly, zpow, len, t);
     hipLaunchKernelGGL((fr_suffix_add_block_kernel<P>), dim3(n_blocks), dim3(POLY_THREADS), 0, st, t, len, totals);
     hipLaunchKernelGGL((fr_suffix_add_totals_kernel<P>), dim3(1), dim3(1024), 0, st, totals, n_blocks);
