@@ -13,6 +13,7 @@
 #include <hip/hip_runtime.h>
 
 #include "fp.cuh"
+#include "fp_inv.cuh"
 #include "fx.cuh"
 #include "poly.cuh"
 
@@ -340,7 +341,7 @@ __global__ __launch_bounds__(PLK_THREADS) void plonk_perm_terms_kernel(PermArgs 
 
 // io[j] = io[j] / den[j] for all j < n.  Thread t of T owns the elements t, t + T, t + 2T, .. (coalesced across the wave) and
 // inverts their product once (Montgomery's trick; the prefix products are parked in `pref`): 3 products per element and one
-// Fermat power (fx_inv: ~210 product-equivalents) per n / T elements.  The host picks T so that the chip has a wave per SIMD
+// inversion (fp_inv.cuh: ~70 product-equivalents; the launch lasts about as long as it on a lone wave) per n / T elements.  The host picks T so that the chip has a wave per SIMD
 // before chunks grow.  A zero denominator -- probability ~ n / r; the reference would panic on 1 / 0 -- zeroes its chunk.
 template <class P, class X>
 __global__ __launch_bounds__(PLK_THREADS) void fr_batch_div_kernel(uint32_t* __restrict__ io, const uint32_t* __restrict__ den, unsigned long long n,
@@ -355,13 +356,7 @@ __global__ __launch_bounds__(PLK_THREADS) void fr_batch_div_kernel(uint32_t* __r
         store_fp<P>(pref + j * 8, run);
         run = run * load_fp<P>(den + j * 8);
     }
-    Fp<X> rx;
-#pragma unroll
-    for (int q = 0; q < 8; q++) rx.l[q] = run.l[q];
-    const Fp<X> ix = fx_to_boundary<X>(fx_inv<X>(fx_from_boundary<X>(rx)));
-    F inv_run;
-#pragma unroll
-    for (int q = 0; q < 8; q++) inv_run.l[q] = ix.l[q];
+    F inv_run = inv_safegcd(run);                               // (fp_inv.cuh: division steps, ~17 K instructions; round 4's Fermat power on the reduced-radix product took ~74 K)
 #pragma unroll 1
     for (j -= T;; j -= T) {                                     // the elements again, last to first (j ends at t)
         const F x = inv_run * load_fp<P>(pref + j * 8);
