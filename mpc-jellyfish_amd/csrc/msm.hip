@@ -413,12 +413,23 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 int log_split = 0;
                 const unsigned long long mean = n_sorted / M;
                 static const int max_split = std::getenv("MZK_MSM_MAX_SPLIT") ? std::atoi(std::getenv("MZK_MSM_MAX_SPLIT")) : 3;   // (tuning switch)
+                // Below 2^18 buckets one thread per bucket is less than two rounds of waves (the chip holds 2^17 threads at the kernel's two
+                // waves per SIMD): the chains are exposed in full and a partial last round idles up to half the chip -- split until the grid
+                // is ~2^20 threads or chains drop to 2 adds (8 threads per bucket only up to 2^15 buckets and while chains keep 4: measured worse beyond).  Re-swept in round 5 over one
+                // MSM, pairs and fused batches of five / six (tools/msm_split_sweep.py): the round-4 rule stopped at 2^18 THREADS, which left
+                // the fused commits of a proof at one or two threads per bucket -- batch of five, BLS12-381: 2^13 pairs 0.59 -> 0.53 ms,
+                // 2^15 0.96 -> 0.85; BN254: 2^13 0.37 -> 0.32, 2^15 0.63 -> 0.48.
+                const bool few_rounds = wm < (1ull << 18);
                 while (log_split < max_split) {
                     const int nx = log_split + 1;
-                    const bool small_grid = (wm << nx) <= (1ull << 18);
-                    if (small_grid ? ((mean >> (nx + 1)) == 0 || (nx == 3 && (mean >> 5) == 0)) : ((1ull << nx) - 1) * 32 > mean) break;    // (8 threads per bucket only while their chains keep 4 adds: the 7 M extra additions outweigh shorter ones)
+                    bool stop;
+                    if (few_rounds) stop = nx < 3 ? ((wm << nx) > (1ull << 20) || (mean >> nx) < 2) : ((wm << nx) > (1ull << 18) || (mean >> 5) == 0);
+                    else stop = ((1ull << nx) - 1) * 32 > mean;               // beyond: only while the (S - 1) M extra additions stay under ~5 % of the work
+                    if (stop) break;
                     log_split = nx;
                 }
+                static const int force_split = std::getenv("MZK_MSM_FORCE_SPLIT") ? std::atoi(std::getenv("MZK_MSM_FORCE_SPLIT")) : -1;      // (tuning switch: tools/msm_split_sweep.py)
+                if (force_split >= 0 && force_split <= 3) log_split = force_split;
                 if (log_split == 0) {
                     ProfScope ps("msm_accumulate", st);
                     hipLaunchKernelGGL((msm_accumulate_kernel<EC>), dim3((unsigned)((wm + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
