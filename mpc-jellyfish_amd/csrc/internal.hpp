@@ -132,6 +132,11 @@ inline int handle_ctx(uint64_t h) { return (int)(h >> 48) - 1; }
 int32_t ntt_dispatch(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool inverse, const uint32_t* coset,
                      uint32_t batch, uint64_t stride, hipStream_t st, int scale = 0, const uint32_t* d_src = nullptr, uint64_t src_stride = 0,
                      const uint32_t* d_patch = nullptr, int skip_batch = -1 /* a batch entry that is not transformed */);
+// The same transform over n_classes different cosets in ONE launch per pass (ntt_fx.cuh nttx_pass_classes_kernel): d_data holds
+// n_classes * rows polynomials class-major, `stride` elements apart; with d_src every class reads the SAME rows of d_src (src_stride
+// apart; d_patch class-major, 4 elements per entry).  2^10 <= N, n_classes <= 8; small transforms (the radix-2 pass form).
+int32_t ntt_classes_dispatch(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool inverse, const uint32_t* const* cosets, int n_classes, uint32_t rows,
+                             uint64_t stride, hipStream_t st, int scale, const uint32_t* d_src, uint64_t src_stride, const uint32_t* d_patch, int skip_batch);
 void ntt_release_plans();
 void msm_release_streams();
 int32_t ctx_prover_stream(unsigned k, hipStream_t* out);      // msm.hip: a context-owned stream for a prover handle (never destroyed by the handle)

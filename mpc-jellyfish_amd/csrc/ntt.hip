@@ -211,7 +211,89 @@ int32_t ntt_dev(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool in
     return MZK_OK;
 }
 
+// several cosets, one launch per pass (internal.hpp ntt_classes_dispatch)
+template <class X>
+int32_t ntt_classes_dev(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool inverse, const uint32_t* const* cosets, int n_classes, uint32_t rows,
+                        uint64_t stride, hipStream_t st, int scale, const uint32_t* d_src, uint64_t src_stride, const uint32_t* d_patch, int skip_batch) {
+    const uint64_t N = 1ull << log_n;
+    const uint64_t batch = (uint64_t)rows * (uint64_t)n_classes;
+    if (log_n < 10 || log_n > X::TWO_ADICITY || log_n > 30 || n_classes < 1 || n_classes > NTTX_MAX_CLASSES || rows == 0 || batch > 65535 || stride < N ||
+        (d_src && src_stride < in_len) || (d_patch && !d_src)) {
+        set_error("ntt_classes: bad shape");
+        return MZK_ERR_INVALID_ARG;
+    }
+    if (in_len > N) in_len = N;
+    NttPlanDev* pl[NTTX_MAX_CLASSES];
+    for (int c = 0; c < n_classes; c++) MZK_TRY(get_plan<X>(curve, log_n, inverse, cosets[c], scale, &pl[c]));     // (the most recently used plans: none evicts another)
+    const int K = pl[0]->h.n_pass;
+    for (int c = 1; c < n_classes; c++)
+        if (pl[c]->h.n_pass != K || pl[c]->h.log_lb != pl[0]->h.log_lb || pl[c]->h.final_factor != pl[0]->h.final_factor || (pl[c]->d_flo != nullptr) != (pl[0]->d_flo != nullptr)) {
+            set_error("ntt_classes: the classes' plans differ in shape");
+            return MZK_ERR_UNSUPPORTED;
+        }
+    if (K < 2) { set_error("ntt_classes: single-pass transform"); return MZK_ERR_UNSUPPORTED; }
+    MZK_TRY(ws_acquire(st));
+    MZK_TRY(g_ws.ntt_scratch.reserve((size_t)batch * N * 36));
+    uint32_t* scratch = g_ws.ntt_scratch.as<uint32_t>();
+    ProfScope total("ntt_total", st);
+    int log_p = 0;
+    for (int k = 0; k < K; k++) {
+        NttxPassArgs a;
+        std::memset(&a, 0, sizeof a);
+        NttxClasses mc;
+        std::memset(&mc, 0, sizeof mc);
+        const int lr = pl[0]->h.log_radix[k];
+        a.log_n = log_n; a.log_r = lr; a.log_p = log_p; a.log_s = log_n - log_p - lr;
+        a.n_pass = K; a.is_first = k == 0; a.is_final = k == K - 1;
+        for (int q = 0; q < K; q++) a.log_radix[q] = pl[0]->h.log_radix[q];
+        a.log_lb = pl[0]->h.log_lb;
+        mc.rows = rows;
+        mc.shared_in = d_src ? 1 : 0;
+        for (int c = 0; c < n_classes; c++) {
+            mc.stage_tw[c] = pl[c]->d_stage[k];
+            mc.t_full[c] = pl[c]->d_tfull[k];
+            mc.f_lo[c] = pl[c]->d_flo;
+            mc.f_hi[c] = pl[c]->d_fhi;
+            mc.f_one[c] = pl[c]->h.final_factor ? pl[c]->d_fone : nullptr;
+        }
+        a.in_len = in_len;
+        a.n = N;
+        if (a.is_first && !d_patch)
+            while (a.skip < lr && in_len <= (N >> (a.skip + 1))) a.skip++;
+        int lc = NTT_TILE_LOG - lr;
+        if (lc < 0) lc = 0;
+        if (a.is_final) lc = lc < pl[0]->h.log_radix[0] ? lc : pl[0]->h.log_radix[0];
+        else lc = lc < a.log_s ? lc : a.log_s;
+        a.log_c = lc;
+        const bool from_data = k == 0, to_data = k == K - 1;
+        a.in = from_data ? (d_src ? const_cast<uint32_t*>(d_src) : d_data) : scratch;
+        a.in_stride = from_data ? (d_src ? src_stride : stride) : N;
+        a.patch = from_data ? d_patch : nullptr;
+        a.skip_batch = skip_batch;
+        a.in_planes = from_data ? 0 : 1;
+        a.out = to_data ? d_data : scratch;
+        a.out_stride = to_data ? stride : N;
+        a.out_planes = to_data ? 0 : 1;
+        const unsigned long long n_tiles = N >> (lr + lc);
+        const size_t tile = (size_t)1 << (lr + lc);
+        ProfScope ps("ntt_pass", st);
+        hipLaunchKernelGGL((nttx_pass_classes_kernel<X>), dim3((unsigned)n_tiles, (unsigned)batch), dim3(NTTX_THREADS), 2 * tile * 16 + tile * 4, st, a, mc);
+        HIP_TRY(hipGetLastError());
+        log_p += lr;
+    }
+    MZK_TRY(ws_release(st));
+    return MZK_OK;
+}
+
 }  // namespace
+
+int32_t ntt_classes_dispatch(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool inverse, const uint32_t* const* cosets, int n_classes, uint32_t rows,
+                             uint64_t stride, hipStream_t st, int scale, const uint32_t* d_src, uint64_t src_stride, const uint32_t* d_patch, int skip_batch) {
+    if (curve == MZK_CURVE_BLS12_381) return ntt_classes_dev<BlsFrX>(curve, d_data, in_len, log_n, inverse, cosets, n_classes, rows, stride, st, scale, d_src, src_stride, d_patch, skip_batch);
+    if (curve == MZK_CURVE_BN254) return ntt_classes_dev<BnFrX>(curve, d_data, in_len, log_n, inverse, cosets, n_classes, rows, stride, st, scale, d_src, src_stride, d_patch, skip_batch);
+    set_error("unknown curve_id");
+    return MZK_ERR_INVALID_ARG;
+}
 
 int32_t ntt_dispatch(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool inverse, const uint32_t* coset,
                      uint32_t batch, uint64_t stride, hipStream_t st, int scale, const uint32_t* d_src, uint64_t src_stride, const uint32_t* d_patch,

@@ -51,7 +51,26 @@ struct QuotientArgs {
     // Rescue / elliptic-curve / multiplication gates -- the reference's bench circuit is additions only -- skips 16 + 3 + 4 of the
     // 56 products per point and 7 of the 28 operand streams.
     uint32_t sel_zero;
+    // ---- several residue classes in one launch (grid.y = class; small circuits: plonk.hip quotient_chunked_run): class c reads the fixed
+    // tables, x_i, 1 / (n (x_i - 1)) and writes its output c * cls_fixed words on, reads the online evaluations c * cls_online words on
+    int n_cls;                // <= 1: one class, the pointers as they are
+    int zh_cls[PLK_RATIO];    // zh_class of class c
+    unsigned long long cls_fixed, cls_online;
 };
+// the pointers of class blockIdx.y
+__device__ __forceinline__ void quotient_class_shift(QuotientArgs& a) {
+    if (a.n_cls <= 1) return;
+    const unsigned c = blockIdx.y;
+    const size_t f = (size_t)c * a.cls_fixed, o = (size_t)c * a.cls_online;
+    a.sel += f; a.sig += f; a.xs += f; a.inv_den += f; a.out += f;
+    if (a.tab) a.tab += f;
+    if (a.inv_den_n) a.inv_den_n += f;
+    a.wire += o; a.z += o;
+    if (a.pi) a.pi += o;
+    if (a.h) a.h += o;
+    if (a.pl) a.pl += o;
+    a.zh_class = a.zh_cls[c];
+}
 
 template <class P>
 __device__ __forceinline__ Fp<P> arg_fp(const uint32_t (&a)[8]) {
@@ -83,6 +102,7 @@ template <class X, bool ULTRA>
 __global__ __launch_bounds__(PLK_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void plonk_quotient_kernel(QuotientArgs a) {
     using F = Fx<X>;
     constexpr int W = ULTRA ? 6 : 5;
+    quotient_class_shift(a);
     const unsigned long long i = (unsigned long long)blockIdx.x * PLK_THREADS + threadIdx.x;
     if (i >= a.m) return;
     const unsigned long long m = a.m;
@@ -142,6 +162,7 @@ __global__ __launch_bounds__(PLK_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
 template <class X>
 __global__ __launch_bounds__(PLK_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void plonk_quotient_lookup_kernel(QuotientArgs a) {
     using F = Fx<X>;
+    quotient_class_shift(a);
     const unsigned long long i = (unsigned long long)blockIdx.x * PLK_THREADS + threadIdx.x;
     if (i >= a.m) return;
     const unsigned long long m = a.m;
@@ -251,6 +272,20 @@ __global__ void plonk_fold_patch_kernel(const uint32_t* __restrict__ src, unsign
     F v = (j < in_len && j < n) ? load_fp<P>(p + j * 8) : F::zero();
     if (n + j < in_len) v = v + fr_arg<P>(c_mont) * load_fp<P>(p + (n + j) * 8);
     store_fp<P>(patch + (size_t)t * 8, v);
+}
+// ... for several classes at once (grid.y = class, patches class-major)
+struct FoldClasses { FrArg c[PLK_RATIO]; };
+template <class P>
+__global__ void plonk_fold_patch_classes_kernel(const uint32_t* __restrict__ src, unsigned long long src_stride, unsigned long long in_len, unsigned long long n, int rows,
+                                                FoldClasses cs, uint32_t* __restrict__ patch) {
+    using F = Fp<P>;
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= rows * 4) return;
+    const unsigned long long row = t / 4, j = t % 4;
+    const uint32_t* p = src + row * src_stride * 8;
+    F v = (j < in_len && j < n) ? load_fp<P>(p + j * 8) : F::zero();
+    if (n + j < in_len) v = v + fr_arg<P>(cs.c[blockIdx.y]) * load_fp<P>(p + (n + j) * 8);
+    store_fp<P>(patch + ((size_t)blockIdx.y * rows * 4 + t) * 8, v);
 }
 
 // r_k = t mod (X^n - c_k), c_k = g^n w_8^k, for s of the 8 classes k  ->  the s coefficient slabs T_q of t = sum_{q<s} X^(qn) T_q:
@@ -424,7 +459,8 @@ __global__ __launch_bounds__(1024) void fr_scan_mul_totals_kernel(uint32_t* __re
         F incl = mine;
         put(threadIdx.x, incl);
         __syncthreads();
-        for (int d = 1; d < 1024; d <<= 1) {
+        const int live = (int)min(1024u, n_blocks - c0);             // the threads beyond hold ones: a 2^15-gate product has 16 block totals, four steps instead of ten
+        for (int d = 1; d < live; d <<= 1) {
             F other = F::one();
             const bool has = (int)threadIdx.x >= d;
             if (has) other = get(threadIdx.x - d);

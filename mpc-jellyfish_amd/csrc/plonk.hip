@@ -313,6 +313,7 @@ int32_t quotient_run(const PlonkPk& pk, uint32_t* d_polys, uint64_t in_len, cons
     // -- evaluations left in the internal form x * R' of the kernels (plonk.cuh)
     MZK_TRY(ntt_dispatch(pk.curve, d_polys, in_len, log_m, false, pk.gen, pk.W + 2 + (pk.ultra ? 3 : 0), m, st, 1));
     QuotientArgs a;
+    a.n_cls = 0;
     a.sel = pk.d_fixed;
     a.sig = pk.d_fixed + (size_t)pk.nsel * m * 8;
     a.wire = d_polys;
@@ -513,9 +514,62 @@ int32_t quotient_chunked_run(const PlonkPk& pk, const uint32_t* d_polys, uint64_
                                                                            // transformed nor read
     const bool patched = in_len <= n + 4 && n >= 4;                        // p mod (X^n - c) differs from p's first n coefficients in <= 4 places
     QuotientArgs a;
+    a.n_cls = 0;
     a.m = n; a.fstride = ncl * n; a.ostride = n; a.next_off = 1;
     fill_quotient_constants<P>(a, pk, tau, alpha, beta, gamma);
     const unsigned long long fold_threads = n * (unsigned long long)rows;
+    // Small circuits: all classes in ONE launch per step (round 5).  A class's transforms are 192 workgroups at 2^15 gates and the round
+    // was a chain of 5 (6) x 5 launches, 0.64 ms of a 3.7-ms proof; with the class as a grid dimension (ntt_fx.cuh
+    // nttx_pass_classes_kernel, quotient_class_shift) it is 2 + 2 + 1 + 2 launches that fill the chip.  Needs the in-place patched form,
+    // a work buffer per class (rows x n x 32 B each: up to 2^18 gates, 280 MB) and multi-pass transforms.  MZK_QUOTIENT_NO_CLASS_BATCH=1: A/B.
+    static const bool no_class_batch = std::getenv("MZK_QUOTIENT_NO_CLASS_BATCH") != nullptr;
+    static const int class_batch_max_log = std::getenv("MZK_QUOTIENT_CLASS_BATCH_MAX_LOG") ? std::atoi(std::getenv("MZK_QUOTIENT_CLASS_BATCH_MAX_LOG")) : 18;      // (tuning switch; measured: 2^18 gates 1.97 -> 1.60 ms, 2^19 3.47 -> 3.28, 2^20 no gain for 1.1 GB more workspace)
+    if (patched && ncl > 1 && ncl <= (size_t)PLK_RATIO && pk.log_n >= 10 && pk.log_n <= class_batch_max_log && !no_class_batch) {
+        MZK_TRY(g_ws.plonk_polys.reserve(ncl * (size_t)rows * n * 32 + 64 + ncl * (size_t)rows * 4 * 32));
+        work = g_ws.plonk_polys.as<uint32_t>();
+        patch = work + (ncl * (size_t)rows * n + 2) * 8;
+        FoldClasses fc;
+        const uint32_t* cosets[PLK_RATIO];                          // (= NTTX_MAX_CLASSES of ntt_fx.cuh)
+        a.n_cls = (int)ncl;
+        for (size_t lc = 0; lc < ncl; lc++) {
+            std::memcpy(fc.c[lc].l, pk.c_cls[pk.cls[lc]], 32);
+            cosets[lc] = pk.h_cls[pk.cls[lc]];
+            a.zh_cls[lc] = pk.cls[lc];
+        }
+        hipLaunchKernelGGL((plonk_fold_patch_classes_kernel<P>), dim3((rows * 4 + 63) / 64, (unsigned)ncl), dim3(64), 0, st, d_polys, in_stride, in_len, n, rows, fc, patch);
+        HIP_TRY(hipGetLastError());
+        // every row of every class; the workgroups of a zero public-input row (row W + 1) exit at once
+        MZK_TRY(ntt_classes_dispatch(pk.curve, work, n, pk.log_n, false, cosets, (int)ncl, (uint32_t)rows, n, st, 1, d_polys, in_stride, patch, pi_zero ? pk.W + 1 : -1));
+        a.sel = pk.d_fixed;
+        a.sig = pk.d_fixed + (size_t)pk.nsel * ncl * n * 8;
+        a.tab = pk.ultra ? pk.d_fixed + (size_t)(pk.nsel + pk.W) * ncl * n * 8 : nullptr;
+        a.wire = work;
+        a.z = work + (size_t)pk.W * n * 8;
+        a.pi = pi_zero ? nullptr : work + (size_t)(pk.W + 1) * n * 8;
+        a.h = pk.ultra ? work + (size_t)(pk.W + 2) * n * 8 : nullptr;
+        a.pl = pk.ultra ? work + (size_t)(pk.W + 4) * n * 8 : nullptr;
+        a.xs = pk.d_xs;
+        a.inv_den = pk.d_inv_den;
+        a.inv_den_n = pk.ultra ? pk.d_inv_den_n : nullptr;
+        a.out = d_out;
+        a.cls_fixed = n * 8;
+        a.cls_online = (unsigned long long)rows * n * 8;
+        a.zh_class = a.zh_cls[0];
+        const dim3 grid((unsigned)((n + PLK_THREADS - 1) / PLK_THREADS), (unsigned)ncl);
+        {
+            ProfScope ps("plonk_quotient_kernel", st);
+            if (pk.ultra) {
+                hipLaunchKernelGGL((plonk_quotient_kernel<typename FxOf<P>::type, true>), grid, dim3(PLK_THREADS), 0, st, a);
+                hipLaunchKernelGGL((plonk_quotient_lookup_kernel<typename FxOf<P>::type>), grid, dim3(PLK_THREADS), 0, st, a);
+            } else {
+                hipLaunchKernelGGL((plonk_quotient_kernel<typename FxOf<P>::type, false>), grid, dim3(PLK_THREADS), 0, st, a);
+            }
+        }
+        HIP_TRY(hipGetLastError());
+        MZK_TRY(ntt_classes_dispatch(pk.curve, d_out, n, pk.log_n, true, cosets, (int)ncl, 1, n, st, 2, nullptr, 0, nullptr, -1));     // back to the boundary form
+        MZK_TRY(ws_release(st));
+        return MZK_OK;
+    }
     for (size_t lc = 0; lc < ncl; lc++) {
         const int k = pk.cls[lc];
         FrArg c_k;

@@ -234,7 +234,8 @@ __global__ __launch_bounds__(1024) void fr_suffix_add_totals_kernel(uint32_t* __
     F incl = mine;
     put(r, incl);
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) {
+    const int live = (int)((n_blocks + per - 1) / per);             // threads that own blocks (the highest r): sums from further away are zeros
+    for (int d = 1; d < live; d <<= 1) {
         F other = F::zero();
         const bool has = r >= d;
         if (has) other = get(r - d);

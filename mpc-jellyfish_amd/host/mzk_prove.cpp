@@ -28,7 +28,7 @@ struct Options {
     bool check_agree = false;     // --check-agree: every rank's proof bytes are compared (tests)
     bool slice_srs = true;        // --no-slice: with --gpus G every rank keeps the whole commit key (and its table) instead of its point range
     int lagrange = -1;            // round 1 commits the wires from their VALUES over the Lagrange-basis key derived from the SRS (same proof
-                                  // bytes): -1 = from 2^13 gates on (below, small scalars only add latency) when a sample of the witness
+                                  // bytes): -1 = from 2^18 gates on (below, the heavy-bucket paths of small scalars cost more than they save: 2^15 gates 3.93 against 3.73 ms) when a sample of the witness
                                   // shows small values (a dense witness gains nothing from the key), --lagrange = always,
                                   // --no-lagrange = never (from the masked coefficient forms, as the reference does)
 };
@@ -51,7 +51,7 @@ int run(bool ultra, uint64_t num_gates, int reps, int range_bits, const Options&
     ShardedProver<C> sp(opt.gpus);
     double circuit_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     t0 = std::chrono::steady_clock::now();
-    const bool lagrange = opt.lagrange < 0 ? (host.log_n >= 13 && host.witness_is_small()) : opt.lagrange != 0;
+    const bool lagrange = opt.lagrange < 0 ? (host.log_n >= 18 && host.witness_is_small()) : opt.lagrange != 0;
     sp.setup(host, beta_c, opt.host_witness, lagrange, opt.slice_srs);                           // SRS, circuit upload and PlonkKzgSnark::preprocess on every device
     const double preprocess_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     Proof<C> proof = sp.prove(rng, false, opt.check_agree);             // the proof whose bytes are printed (and warm-up)

@@ -149,7 +149,9 @@ class HostWitness:
     wire_variables: object
 
 
-LAGRANGE_MIN_DOMAIN = 1 << 13          # preprocess(lagrange=None): round 1 over the Lagrange basis from this domain size on
+LAGRANGE_MIN_DOMAIN = 1 << 18          # preprocess(lagrange=None): round 1 over the Lagrange basis from this domain size on (re-measured in round 5 with the
+                                       # fused small batches split over more threads: at 2^13 / 2^15 gates the coefficient-form commits are 0.28 / 0.2 ms
+                                       # FASTER than the heavy-bucket paths small values take, equal at 2^17; 2^20: 2.6 against 8.0 ms)
 LAGRANGE_SAMPLE = 2048                 # ... when a sample of the witness shows small values (below)
 
 
@@ -176,7 +178,7 @@ def preprocess(commit_key: kzg.UnivariateProverParam, circuit: BenchCircuit, lag
     (mzk_prover_create keeps them, their evaluations on the needed residue classes and the workspace of one proof in HBM).  The
     verifying-key commitments come on demand from `TurboPlonkProver.vk_commitments()`.
     lagrange: also derive the commit key over the Lagrange basis of the gate domain from the SRS's points
-    (kzg.UnivariateProverParam.lagrange_key) -- round 1 then commits the wires from their VALUES (same commitments).  None: from 2^13
+    (kzg.UnivariateProverParam.lagrange_key) -- round 1 then commits the wires from their VALUES (same commitments).  None: from 2^18
     gates on (below, an MSM is a chain of latencies and small scalars only add over-long buckets to it) AND only when a sample of the
     circuit's witness shows small values (witness_is_small: a dense witness gains nothing from the key).  lagrange_ck: an existing key.
     comm: a sharding.TorchComm -- this process is one rank of a sharded proof and keeps only its point range of the SRS (and of the

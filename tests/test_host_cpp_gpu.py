@@ -30,7 +30,7 @@ def test_cpp_host_prove_matches_python_mirror(gpu, mj, curve_id, plonk_type, num
     _, proof_bytes = mj.snark.prove(rng, cs, pk)
     assert got["log_n"] == cs.n.bit_length() - 1
     assert got["proof_hex"] == proof_bytes.hex()
-    # --lagrange (the default from 2^13 gates on) commits round 1 from the wire VALUES over the Lagrange-basis key derived from the SRS;
+    # --lagrange (the default from 2^18 gates on for small-valued witnesses) commits round 1 from the wire VALUES over the Lagrange-basis key derived from the SRS;
     # --no-lagrange from the masked coefficient forms, as the reference does: same proof
     assert got["lagrange_round1"] is True
     out = subprocess.run([BIN, str(curve_id), "ultra" if plonk_type == "UltraPlonk" else "turbo", str(num_gates), "0", str(range_bits), "--no-lagrange"],

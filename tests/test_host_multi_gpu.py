@@ -30,7 +30,7 @@ def _prove(curve_id, kind, gates, gpus, extra=(), reps="0"):
 def test_virtual_devices_emit_the_single_device_proof(gpu, curve_id, kind, gates):
     one = _prove(curve_id, kind, gates, 1)
     for g in (2, 3, 4, 8):                                   # 3: an uneven class split (2 + 2 + 1 of 5, 2 + 2 + 2 of 6); 8: ranks that own no class; 8192 gates: round 1 over the Lagrange-basis key, sharded
-        many = _prove(curve_id, kind, gates, g)              # every rank keeps only ITS point range of the commit key(s) (mzk_srs_slice): the default
+        many = _prove(curve_id, kind, gates, g, ["--lagrange"] if gates >= 8192 else ())     # every rank keeps only ITS point range of the commit key(s) (mzk_srs_slice): the default
         assert many["gpus"] == g and many["proof_hex"] == one["proof_hex"] and many["vk_hex"] == one["vk_hex"], (curve_id, kind, gates, g)
     # --no-slice: every rank holds the whole SRS (and its table) and commits over its range of it
     whole = _prove(curve_id, kind, gates, 4, ["--no-slice"])

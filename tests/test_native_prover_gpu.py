@@ -189,7 +189,7 @@ def test_rounds_out_of_order_and_bad_arguments(gpu, mj, pyref):
 def test_bench_circuit_every_witness_kind_and_the_lagrange_key(gpu, mj, pyref, curve_id, plonk_type, num_gates):
     """The reference's bench circuit (plonk/benches/bench.rs:29-46) through snark.prove (Python mirror) and native.prove: device wires,
     host wires, the witness VECTOR from host and from device memory gathered through the resident wire_variables; round 1 (and 1.5)
-    over the Lagrange-basis key from 2^13 gates on."""
+    over the Lagrange-basis key when asked for (the default asks from 2^18 gates on: snark.LAGRANGE_MIN_DOMAIN)."""
     import torch
     N = _native(mj)
     c = mj.params.CURVES[curve_id]
@@ -198,8 +198,8 @@ def test_bench_circuit_every_witness_kind_and_the_lagrange_key(gpu, mj, pyref, c
     srs_beta = mj.rng.fr_rand(c, rng0)
     ck = mj.UnivariateProverParam.gen_srs_for_testing(c, srs_beta, cs.n + 2)
     pk = MP.preprocess(ck, cs)
-    npk = N.preprocess(ck, cs)
-    assert (npk.lagrange_ck is not None) == (cs.n >= 1 << 13)
+    npk = N.preprocess(ck, cs, lagrange=True if cs.n >= 1 << 13 else None)
+    assert (npk.lagrange_ck is not None) == (cs.n >= 1 << 13) and mj.snark.LAGRANGE_MIN_DOMAIN == 1 << 18
 
     def fresh_rng():
         g = mj.rng.test_rng()
