@@ -38,6 +38,12 @@ def test_cpp_host_prove_matches_python_mirror(gpu, mj, curve_id, plonk_type, num
     assert out.returncode == 0, out.stderr[-2000:]
     plain = json.loads(out.stdout.strip().splitlines()[-1])
     assert plain["lagrange_round1"] is False and plain["proof_hex"] == got["proof_hex"]
+    # the quotient round with all residue classes in one launch per step (the default up to 2^18 gates, from 2^10 on) and class by class
+    # (round 4's sequence, MZK_QUOTIENT_NO_CLASS_BATCH=1): two launch sequences, one proof
+    out = subprocess.run([BIN, str(curve_id), "ultra" if plonk_type == "UltraPlonk" else "turbo", str(num_gates), "0", str(range_bits)],
+                         capture_output=True, text=True, timeout=600, env=dict(os.environ, MZK_QUOTIENT_NO_CLASS_BATCH="1"))
+    assert out.returncode == 0, out.stderr[-2000:]
+    assert json.loads(out.stdout.strip().splitlines()[-1])["proof_hex"] == got["proof_hex"]
     pk.release()
     ck.release()
 

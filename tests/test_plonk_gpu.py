@@ -110,7 +110,7 @@ def test_quotient_of_a_satisfied_circuit_is_a_low_degree_polynomial(gpu, mj, cre
 
 
 @pytest.mark.parametrize("curve_id", [0, 1])
-@pytest.mark.parametrize("log_n", [3, 4, 6, 9])
+@pytest.mark.parametrize("log_n", [3, 4, 6, 9, 11])             # (11: every class in one launch per step -- plonk.hip quotient_chunked_run, from 2^10 gates on)
 def test_quotient_from_one_class_fewer_and_the_top_coefficients(gpu, mj, pyref, curve_id, log_n):
     """mzk_plonk_quotient_top_dev + mzk_plonk_quotient_combine_top_dev: W classes and the W + 3 top coefficients of the numerator give the
     same 8n coefficients as the whole-domain key.  The circuit of the test above (add / mul / x^5 / ecc gates, identity permutation
