@@ -109,24 +109,34 @@ __device__ __forceinline__ FsTw tws_load(const uint32_t* __restrict__ table, uns
 }
 
 // One pass over one tile.  grid = (N / (R*C), batch), block = NTTX_THREADS.  R4: stage PAIRS in registers (below), for 2048-element tiles.
-// The batch entry and the plan's tables arrive as arguments: a plain launch passes blockIdx.y and the tables of its ONE plan
-// (nttx_pass_kernel); a launch over several cosets picks them per class (nttx_pass_classes_kernel, below).
+// The batch entry and the plan's tables come from a selector: a plain launch reads blockIdx.y and the tables of its ONE plan in the
+// argument struct at their points of use (NttxPlainSel: the code of rounds 1-4); a launch over several cosets picks them per class
+// (NttxClassSel, nttx_pass_classes_kernel below).
 //   y_in / y_out: batch entry of the input / of the output and the patch; y_row: what skip_batch is compared with
-template <class X, bool R4>
-__device__ __forceinline__ void nttx_pass_body(const NttxPassArgs& a, const unsigned y_in, const unsigned y_out, const unsigned y_row, const uint32_t* __restrict__ p_stage_tw,
-                                               const uint32_t* __restrict__ p_t_full, const uint32_t* __restrict__ p_f_lo, const uint32_t* __restrict__ p_f_hi,
-                                               const uint32_t* __restrict__ p_f_one) {
+struct NttxPlainSel {
+    const NttxPassArgs& a;
+    __device__ __forceinline__ unsigned y_in() const { return blockIdx.y; }
+    __device__ __forceinline__ unsigned y_out() const { return blockIdx.y; }
+    __device__ __forceinline__ unsigned y_row() const { return blockIdx.y; }
+    __device__ __forceinline__ const uint32_t* stage_tw() const { return a.stage_tw; }
+    __device__ __forceinline__ const uint32_t* t_full() const { return a.t_full; }
+    __device__ __forceinline__ const uint32_t* f_lo() const { return a.f_lo; }
+    __device__ __forceinline__ const uint32_t* f_hi() const { return a.f_hi; }
+    __device__ __forceinline__ const uint32_t* f_one() const { return a.f_one; }
+};
+template <class X, bool R4, class SEL>
+__device__ __forceinline__ void nttx_pass_body(const NttxPassArgs& a, const SEL sel) {
     static_assert(X::XN == 9 && X::N == 8, "256-bit scalar fields: 8 boundary words, 9 limbs of 29 bits");
     extern __shared__ int4 ldsx[];
-    if ((int)y_row == a.skip_batch) return;
+    if ((int)sel.y_row() == a.skip_batch) return;
     const int R = 1 << a.log_r, C = 1 << a.log_c, TILE = R * C;
     int4* da = ldsx;
     int4* db = da + TILE;
     int32_t* dc = reinterpret_cast<int32_t*>(db + TILE);
     const int tid = threadIdx.x;
     const unsigned long long tile = blockIdx.x;
-    const uint32_t* in = a.in + (unsigned long long)y_in * a.in_stride * (a.in_planes ? 9 : 8);
-    uint32_t* out = a.out + (unsigned long long)y_out * a.out_stride * (a.out_planes ? 9 : 8);
+    const uint32_t* in = a.in + (unsigned long long)sel.y_in() * a.in_stride * (a.in_planes ? 9 : 8);
+    uint32_t* out = a.out + (unsigned long long)sel.y_out() * a.out_stride * (a.out_planes ? 9 : 8);
 
     // ---- tile geometry (as ntt.cuh) --------------------------------------------------------------------
     const int log_r1 = a.n_pass > 1 ? a.log_radix[0] : 0;
@@ -182,7 +192,7 @@ __device__ __forceinline__ void nttx_pass_body(const NttxPassArgs& a, const unsi
         v = Fs<X>::zero(); v.l[0] = (int32_t)g;
 #else
         if (a.in_planes) v = planes_get<X>(in, a.n, g);                                  // lazy: |limbs| <= 2^30
-        else if (a.patch && g < 4) v = fs_load_packed<X>(a.patch + ((unsigned long long)y_out * 4 + g) * 8);
+        else if (a.patch && g < 4) v = fs_load_packed<X>(a.patch + ((unsigned long long)sel.y_out() * 4 + g) * 8);
         else if (a.is_first && g >= a.in_len) v = Fs<X>::zero();
         else v = fs_load_packed<X>(in + g * 8);                                        // fresh: limbs in [0, 2^29)
 #endif
@@ -216,7 +226,7 @@ __device__ __forceinline__ void nttx_pass_body(const NttxPassArgs& a, const unsi
             const Fs<X> x1 = ldss_load<X>(da, db, dc, i0 + st), x3 = ldss_load<X>(da, db, dc, i0 + 3 * st);
             if (!fresh) { x0 = fs_norm(x0); x2 = fs_norm(x2); }
             const unsigned long long k1 = a.is_first ? 0ull : (a.is_final ? i1_0 + c : k1_blk);
-            const uint32_t* tw = p_stage_tw + k1 * tw_rows * FS_TW_WORDS;
+            const uint32_t* tw = sel.stage_tw() + k1 * tw_rows * FS_TW_WORDS;
             const FsTw w1 = tws_load(tw, (unsigned long long)(half - 1 + j));
             const Fs<X> t1 = fs_mulc<X>(x1, w1), t3 = fs_mulc<X>(x3, w1);
             const Fs<X> y0 = fs_norm(fs_add(x0, t1)), y1 = fs_norm(fs_sub(x0, t1));
@@ -245,7 +255,7 @@ __device__ __forceinline__ void nttx_pass_body(const NttxPassArgs& a, const unsi
             const Fs<X> hi = ldss_load<X>(da, db, dc, hi_i);
             if (!fresh) lo = fs_norm(lo);
             const unsigned long long k1 = a.is_first ? 0ull : (a.is_final ? i1_0 + c : k1_blk);
-            const Fs<X> t = fs_mulc<X>(hi, tws_load(p_stage_tw, k1 * tw_rows + (half - 1 + j)));
+            const Fs<X> t = fs_mulc<X>(hi, tws_load(sel.stage_tw(), k1 * tw_rows + (half - 1 + j)));
             ldss_store<X>(da, db, dc, lo_i, fs_add(lo, t));
             ldss_store<X>(da, db, dc, hi_i, fs_sub(lo, t));
         }
@@ -259,7 +269,7 @@ __device__ __forceinline__ void nttx_pass_body(const NttxPassArgs& a, const unsi
         Fs<X> v = ldss_load<X>(da, db, dc, r * C + c);
         if (!a.is_final) {
             const unsigned long long g = base + ((unsigned long long)r << a.log_s) + c;
-            if (!a.is_first) v = fs_mulc<X>(v, tws_load(p_t_full, ((unsigned long long)r << a.log_s) + c0 + c));   // boundaries after pass 2
+            if (!a.is_first) v = fs_mulc<X>(v, tws_load(sel.t_full(), ((unsigned long long)r << a.log_s) + c0 + c));   // boundaries after pass 2
 #ifdef MZK_NTT_DIAG_NOIO
             if (v.l[0] == 0x7fffffff && v.l[8] == 12345) planes_put<X>(out, a.n, g, v);
 #else
@@ -268,11 +278,11 @@ __device__ __forceinline__ void nttx_pass_body(const NttxPassArgs& a, const unsi
         } else {
             const unsigned long long rev = (i1_0 + c) + (rev_rest << log_r1);
             const unsigned long long g = rev + ((unsigned long long)r << a.log_p);
-            if (p_f_lo) {
-                v = fs_mulc<X>(v, tws_load(p_f_lo, g & ((1ull << a.log_lb) - 1)));
-                v = fs_mulc<X>(v, tws_load(p_f_hi, g >> a.log_lb));
-            } else if (p_f_one) {
-                v = fs_mulc<X>(v, tws_load(p_f_one, 0));
+            if (sel.f_lo()) {
+                v = fs_mulc<X>(v, tws_load(sel.f_lo(), g & ((1ull << a.log_lb) - 1)));
+                v = fs_mulc<X>(v, tws_load(sel.f_hi(), g >> a.log_lb));
+            } else if (sel.f_one()) {
+                v = fs_mulc<X>(v, tws_load(sel.f_one(), 0));
             }
 #ifdef MZK_NTT_DIAG_NOIO
             const Fx<X> cv = fs_canonical<X>(v);
@@ -286,7 +296,7 @@ __device__ __forceinline__ void nttx_pass_body(const NttxPassArgs& a, const unsi
 
 template <class X, bool R4>
 __global__ __launch_bounds__(NTTX_THREADS) void nttx_pass_kernel(NttxPassArgs a) {
-    nttx_pass_body<X, R4>(a, blockIdx.y, blockIdx.y, blockIdx.y, a.stage_tw, a.t_full, a.f_lo, a.f_hi, a.f_one);
+    nttx_pass_body<X, R4>(a, NttxPlainSel{a});
 }
 
 // Several transforms of ONE shape over DIFFERENT cosets in one launch: the quotient round's residue classes (plonk.hip) -- at 2^15
@@ -303,10 +313,22 @@ struct NttxClasses {
     const uint32_t* f_hi[NTTX_MAX_CLASSES];
     const uint32_t* f_one[NTTX_MAX_CLASSES];
 };
+struct NttxClassSel {
+    unsigned yi, y, row;
+    const uint32_t *p_stage, *p_full, *p_lo, *p_hi, *p_one;
+    __device__ __forceinline__ unsigned y_in() const { return yi; }
+    __device__ __forceinline__ unsigned y_out() const { return y; }
+    __device__ __forceinline__ unsigned y_row() const { return row; }
+    __device__ __forceinline__ const uint32_t* stage_tw() const { return p_stage; }
+    __device__ __forceinline__ const uint32_t* t_full() const { return p_full; }
+    __device__ __forceinline__ const uint32_t* f_lo() const { return p_lo; }
+    __device__ __forceinline__ const uint32_t* f_hi() const { return p_hi; }
+    __device__ __forceinline__ const uint32_t* f_one() const { return p_one; }
+};
 template <class X>
 __global__ __launch_bounds__(NTTX_THREADS) void nttx_pass_classes_kernel(NttxPassArgs a, NttxClasses mc) {
     const unsigned y = blockIdx.y, c = y / mc.rows, row = y - c * mc.rows;
-    nttx_pass_body<X, false>(a, (a.is_first && mc.shared_in) ? row : y, y, row, mc.stage_tw[c], mc.t_full[c], mc.f_lo[c], mc.f_hi[c], mc.f_one[c]);
+    nttx_pass_body<X, false>(a, NttxClassSel{(a.is_first && mc.shared_in) ? row : y, y, row, mc.stage_tw[c], mc.t_full[c], mc.f_lo[c], mc.f_hi[c], mc.f_one[c]});
 }
 
 // ------------------------------------------------------------------------------------------------

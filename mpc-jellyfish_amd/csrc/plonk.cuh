@@ -57,19 +57,29 @@ struct QuotientArgs {
     int zh_cls[PLK_RATIO];    // zh_class of class c
     unsigned long long cls_fixed, cls_online;
 };
-// the pointers of class blockIdx.y
-__device__ __forceinline__ void quotient_class_shift(QuotientArgs& a) {
-    if (a.n_cls <= 1) return;
-    const unsigned c = blockIdx.y;
-    const size_t f = (size_t)c * a.cls_fixed, o = (size_t)c * a.cls_online;
-    a.sel += f; a.sig += f; a.xs += f; a.inv_den += f; a.out += f;
-    if (a.tab) a.tab += f;
-    if (a.inv_den_n) a.inv_den_n += f;
-    a.wire += o; a.z += o;
-    if (a.pi) a.pi += o;
-    if (a.h) a.h += o;
-    if (a.pl) a.pl += o;
-    a.zh_class = a.zh_cls[c];
+// the pointers of class blockIdx.y, as LOCAL values: the kernels leave their argument struct untouched -- a kernel that writes to its
+// by-value argument makes clang copy all of it (1 KB, with run-time-indexed arrays: zh_inv, k) into scratch memory, which cost the
+// 2^20-gate quotient round 0.8 ms when the class shift was first written that way
+struct QuotientPtrs {
+    const uint32_t *sel, *sig, *wire, *z, *pi, *xs, *inv_den, *tab, *h, *pl, *inv_den_n;
+    uint32_t* out;
+    int zh_class;
+};
+__device__ __forceinline__ QuotientPtrs quotient_class_ptrs(const QuotientArgs& a) {
+    QuotientPtrs q{a.sel, a.sig, a.wire, a.z, a.pi, a.xs, a.inv_den, a.tab, a.h, a.pl, a.inv_den_n, a.out, a.zh_class};
+    if (a.n_cls > 1) {
+        const unsigned c = blockIdx.y;
+        const size_t f = (size_t)c * a.cls_fixed, o = (size_t)c * a.cls_online;
+        q.sel += f; q.sig += f; q.xs += f; q.inv_den += f; q.out += f;
+        if (q.tab) q.tab += f;
+        if (q.inv_den_n) q.inv_den_n += f;
+        q.wire += o; q.z += o;
+        if (q.pi) q.pi += o;
+        if (q.h) q.h += o;
+        if (q.pl) q.pl += o;
+        q.zh_class = a.zh_cls[c];
+    }
+    return q;
 }
 
 template <class P>
@@ -102,7 +112,7 @@ template <class X, bool ULTRA>
 __global__ __launch_bounds__(PLK_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void plonk_quotient_kernel(QuotientArgs a) {
     using F = Fx<X>;
     constexpr int W = ULTRA ? 6 : 5;
-    quotient_class_shift(a);
+    const QuotientPtrs q = quotient_class_ptrs(a);
     const unsigned long long i = (unsigned long long)blockIdx.x * PLK_THREADS + threadIdx.x;
     if (i >= a.m) return;
     const unsigned long long m = a.m;
@@ -110,15 +120,15 @@ __global__ __launch_bounds__(PLK_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
     const unsigned long long fs = a.fstride, os = a.ostride;
     F w[W];
 #pragma unroll
-    for (int j = 0; j < W; j++) w[j] = ldx<X>(a.wire + ((size_t)j * os + i) * 8);
-    auto sel = [&](int j) { return ldx<X>(a.sel + ((size_t)j * fs + i) * 8); };
+    for (int j = 0; j < W; j++) w[j] = ldx<X>(q.wire + ((size_t)j * os + i) * 8);
+    auto sel = [&](int j) { return ldx<X>(q.sel + ((size_t)j * fs + i) * 8); };
     // ---- gate identity (prover.rs:696-708); value bounds in units of p on the right
     // Every term below is optional (sel_zero, uniform over the launch); the bounds on the right are those with all of them present.
     const uint32_t sz = a.sel_zero;
     auto has = [&](int j) { return !((sz >> j) & 1u); };
     F t = F::zero();                                                                   // q_c + pi                     2
     if (has(11)) t = sel(11);
-    if (a.pi) t = fx_add(t, ldx<X>(a.pi + i * 8));                                     // (null: the public-input polynomial is zero)
+    if (q.pi) t = fx_add(t, ldx<X>(q.pi + i * 8));                                     // (null: the public-input polynomial is zero)
 #pragma unroll
     for (int j = 0; j < 4; j++)
         if (has(j)) t = fx_add(t, fx_mul(sel(j), w[j]));                              // q_lc                         6.1, limbs < 6 * 2^29
@@ -140,20 +150,20 @@ __global__ __launch_bounds__(PLK_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
     t = fx_norm(t);
     // ---- copy constraints (prover.rs:741-758)
     const F alpha = arg_fx<X>(a.alpha), beta = arg_fx<X>(a.beta), gamma = arg_fx<X>(a.gamma);
-    const F z_x = ldx<X>(a.z + i * 8);
-    const F z_xw = ldx<X>(a.z + inext * 8);
-    const F xb = fx_mul(ldx<X>(a.xs + i * 8), beta);                                  // class M
+    const F z_x = ldx<X>(q.z + i * 8);
+    const F z_xw = ldx<X>(q.z + inext * 8);
+    const F xb = fx_mul(ldx<X>(q.xs + i * 8), beta);                                  // class M
     F acc1 = z_x, acc2 = z_xw;
 #pragma unroll
     for (int j = 0; j < W; j++) {
         const F wg = fx_add(w[j], gamma);                                             // 2, limbs < 2^30
         acc1 = fx_mul(acc1, fx_norm(fx_add(wg, fx_mul(arg_fx<X>(a.k[j]), xb))));      // factor 3.1 -> product < 1.06
-        acc2 = fx_mul(acc2, fx_norm(fx_add(wg, fx_mul(ldx<X>(a.sig + ((size_t)j * fs + i) * 8), beta))));
+        acc2 = fx_mul(acc2, fx_norm(fx_add(wg, fx_mul(ldx<X>(q.sig + ((size_t)j * fs + i) * 8), beta))));
     }
     const F t1 = fx_norm(fx_add(t, fx_mul(alpha, fx_norm(fx_sub2(acc1, acc2)))));     // acc1 - acc2 + 2p: 3.2;  t1: 16.6
-    const F t2 = fx_mul(arg_fx<X>(a.alpha2), fx_mul(fx_norm(fx_sub2(z_x, F::one())), ldx<X>(a.inv_den + i * 8)));   // z - 1 (+ 2p): 3
-    const F zh = arg_fx<X>(a.zh_inv[a.zh_class >= 0 ? a.zh_class : (int)(i % PLK_RATIO)]);
-    stx<X>(a.out + i * 8, fx_add(fx_mul(t1, zh), t2));                                // 16.6 / 2^H + 1 + 1.05 < 2.4         prover.rs:657
+    const F t2 = fx_mul(arg_fx<X>(a.alpha2), fx_mul(fx_norm(fx_sub2(z_x, F::one())), ldx<X>(q.inv_den + i * 8)));   // z - 1 (+ 2p): 3
+    const F zh = arg_fx<X>(a.zh_inv[q.zh_class >= 0 ? q.zh_class : (int)(i % PLK_RATIO)]);
+    stx<X>(q.out + i * 8, fx_add(fx_mul(t1, zh), t2));                                // 16.6 / 2^H + 1 + 1.05 < 2.4         prover.rs:657
 }
 
 // UltraPlonk, second launch: out[i] += t_lookup_1 * zh_inv + t_lookup_2 (compute_quotient_plookup_contribution,
@@ -162,14 +172,14 @@ __global__ __launch_bounds__(PLK_THREADS) __attribute__((amdgpu_waves_per_eu(3, 
 template <class X>
 __global__ __launch_bounds__(PLK_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void plonk_quotient_lookup_kernel(QuotientArgs a) {
     using F = Fx<X>;
-    quotient_class_shift(a);
+    const QuotientPtrs q = quotient_class_ptrs(a);
     const unsigned long long i = (unsigned long long)blockIdx.x * PLK_THREADS + threadIdx.x;
     if (i >= a.m) return;
     const unsigned long long m = a.m;
     const unsigned long long inext = (i + a.next_off) % m;
     const unsigned long long fs = a.fstride, os = a.ostride;
-    auto wire = [&](int j, unsigned long long at) { return ldx<X>(a.wire + ((size_t)j * os + at) * 8); };
-    auto tab = [&](int j, unsigned long long at) { return ldx<X>(a.tab + ((size_t)j * fs + at) * 8); };
+    auto wire = [&](int j, unsigned long long at) { return ldx<X>(q.wire + ((size_t)j * os + at) * 8); };
+    auto tab = [&](int j, unsigned long long at) { return ldx<X>(q.tab + ((size_t)j * fs + at) * 8); };
     const F alpha = arg_fx<X>(a.alpha), beta = arg_fx<X>(a.beta), gamma = arg_fx<X>(a.gamma);
     const F tau = arg_fx<X>(a.tau), alpha3 = arg_fx<X>(a.alpha3);
     // first + q tau (ds + tau (a0 + tau (a1 + tau a2))): every sum has two terms (value <= 2.1, limbs < 2^30): no norm needed
@@ -180,15 +190,15 @@ __global__ __launch_bounds__(PLK_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
         const F in1 = fx_norm(fx_add(ds, fx_mul(tau, in2)));
         return fx_add(first, fx_mul(qtau, in1));                                      // 2.1, limbs < 2^30
     };
-    const F qtau = fx_mul(ldx<X>(a.sel + ((size_t)13 * fs + i) * 8), tau);
-    const F qtau_next = fx_mul(ldx<X>(a.sel + ((size_t)13 * fs + inext) * 8), tau);
+    const F qtau = fx_mul(ldx<X>(q.sel + ((size_t)13 * fs + i) * 8), tau);
+    const F qtau_next = fx_mul(ldx<X>(q.sel + ((size_t)13 * fs + inext) * 8), tau);
     const F mt = merged(tab(0, i), qtau, tab(2, i), tab(1, i), wire(3, i), wire(4, i));
     const F mt_next = merged(tab(0, inext), qtau_next, tab(2, inext), tab(1, inext), wire(3, inext), wire(4, inext));
     const F ml = merged(wire(5, i), qtau, tab(3, i), wire(0, i), wire(1, i), wire(2, i));
-    const F h1 = ldx<X>(a.h + i * 8), h1n = ldx<X>(a.h + inext * 8);
-    const F h2 = ldx<X>(a.h + (os + i) * 8), h2n = ldx<X>(a.h + (os + inext) * 8);
-    const F p = ldx<X>(a.pl + i * 8), pn = ldx<X>(a.pl + inext * 8);
-    const F lag_n = ldx<X>(a.inv_den_n + i * 8), lag_1 = ldx<X>(a.inv_den + i * 8);
+    const F h1 = ldx<X>(q.h + i * 8), h1n = ldx<X>(q.h + inext * 8);
+    const F h2 = ldx<X>(q.h + (os + i) * 8), h2n = ldx<X>(q.h + (os + inext) * 8);
+    const F p = ldx<X>(q.pl + i * 8), pn = ldx<X>(q.pl + inext * 8);
+    const F lag_n = ldx<X>(q.inv_den_n + i * 8), lag_1 = ldx<X>(q.inv_den + i * 8);
     const F pm1 = fx_norm(fx_sub2(p, F::one()));                                      // p - 1 (+ 2p): 3
     // result_2 = alpha^3 (term_h + alpha (term_p1 + alpha term_p2))
     const F inner = fx_norm(fx_add(fx_mul(pm1, lag_1), fx_mul(alpha, fx_mul(pm1, lag_n))));            // 2.2
@@ -202,12 +212,12 @@ __global__ __launch_bounds__(PLK_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
     // right = p(wX) (g1 + h1 + beta h1(wX)) (g1 + h2 + beta h2(wX))
     F right = fx_mul(pn, fx_norm(fx_add(fx_add(g1, h1), fx_mul(beta, h1n))));         // factor 3.2
     right = fx_mul(right, fx_norm(fx_add(fx_add(g1, h2), fx_mul(beta, h2n))));
-    const F xm = fx_norm(fx_sub2(ldx<X>(a.xs + i * 8), arg_fx<X>(a.w_inv)));          // x - w^-1 (+ 2p): 3
+    const F xm = fx_norm(fx_sub2(ldx<X>(q.xs + i * 8), arg_fx<X>(a.w_inv)));          // x - w^-1 (+ 2p): 3
     const F term3 = fx_mul(xm, fx_norm(fx_sub2(left, right)));                        // (3.2) * 3 / 2^H + 1
     const F t1 = fx_mul(fx_sqr(alpha3), term3);
-    const F zh = arg_fx<X>(a.zh_inv[a.zh_class >= 0 ? a.zh_class : (int)(i % PLK_RATIO)]);
-    const F prev = ldx<X>(a.out + i * 8);
-    stx<X>(a.out + i * 8, fx_add(fx_add(prev, t2), fx_mul(t1, zh)));                  // 1 + 1.1 + 1.1
+    const F zh = arg_fx<X>(a.zh_inv[q.zh_class >= 0 ? q.zh_class : (int)(i % PLK_RATIO)]);
+    const F prev = ldx<X>(q.out + i * 8);
+    stx<X>(q.out + i * 8, fx_add(fx_add(prev, t2), fx_mul(t1, zh)));                  // 1 + 1.1 + 1.1
 }
 
 // xs[i] = g * w^i and inv_den[i] = 1/(n (xs[i] - 1)), 16 points per thread with one shared inversion
