@@ -8,6 +8,7 @@
 #include <cstring>
 
 #include "constants.cuh"
+#include "hostinv.hpp"
 
 namespace mzk {
 
@@ -100,7 +101,7 @@ Fp64<P> pow_u64(Fp64<P> b, uint64_t e) {
     return acc;
 }
 template <class P>
-Fp64<P> inv(const Fp64<P>& a) {                              // a^(p-2)
+Fp64<P> inv_fermat(const Fp64<P>& a) {                       // a^(p-2): the checker of the division-step inverse below, and its fallback
     uint64_t e[Fp64<P>::N];
     for (int i = 0; i < Fp64<P>::N; i++) e[i] = Fp64<P>::mod(i);
     e[0] -= 2;                                               // every modulus here is odd and > 2: no borrow beyond limb 0
@@ -111,6 +112,21 @@ Fp64<P> inv(const Fp64<P>& a) {                              // a^(p-2)
             b = b * b;
         }
     return acc;
+}
+// 1 / a for a in Montgomery form (a R -> a^-1 R), inv(0) = 0, by division steps (hostinv.hpp: ~4 us in BLS12-381's Fq where the Fermat power
+// takes ~25).  The integer inverse of the image a R is a^-1 R^-1; one Montgomery product by R^3 makes it a^-1 R.
+template <class P>
+Fp64<P> inv(const Fp64<P>& a) {
+    if (a.is_zero()) return a;
+    static const Fp64<P> r3 = [] {
+        Fp64<P> r2;
+        for (int i = 0; i < Fp64<P>::N; i++) r2.l[i] = Fp64<P>::c64(P::R2, i);
+        return r2 * r2;
+    }();
+    uint32_t x[P::N], y[P::N];
+    a.to_words(x);
+    if (!hinv::inverse_words<P>(x, y)) return inv_fermat(a);   // (the proven step cap cannot be reached: hostinv.hpp)
+    return Fp64<P>::from_words(y) * r3;
 }
 template <class P>
 std::array<uint64_t, Fp64<P>::N> canonical(const Fp64<P>& a) {   // Montgomery -> integer

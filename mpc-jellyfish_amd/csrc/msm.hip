@@ -778,7 +778,7 @@ int32_t srs_lagrange_from_points(const uint32_t* d_xy, int log_n, uint32_t n_ext
     return MZK_OK;
 }
 
-// n Jacobian points -> affine on the host (`normalize_batch`): ONE Fermat inversion for all of them (Montgomery's trick)
+// n Jacobian points -> affine on the host (`normalize_batch`): ONE inversion for all of them (Montgomery's trick)
 template <class FQ>
 void jac_to_affine_host(const uint64_t* xyz, uint64_t n, uint64_t* xy) {
     using F = Fp64<FQ>;
@@ -789,15 +789,7 @@ void jac_to_affine_host(const uint64_t* xyz, uint64_t n, uint64_t* xy) {
         const F Z = F::from_words((const uint32_t*)(xyz + i * 3 * L + 2 * L));
         pref[i + 1] = Z.is_zero() ? pref[i] : pref[i] * Z;
     }
-    F e = pref[n], acc = F::one();                 // (prod Z)^-1 by Fermat
-    uint64_t ex[L];
-    for (int i = 0; i < L; i++) ex[i] = F::mod(i);
-    ex[0] -= 2;                                   // p - 2 (p odd and > 2: no borrow)
-    for (int i = 0; i < L; i++)
-        for (int b = 0; b < 64; b++) {
-            if ((ex[i] >> b) & 1) acc = acc * e;
-            e = e * e;
-        }
+    F acc = h64::inv(pref[n]);                     // (prod Z)^-1 by division steps (hostinv.hpp; the Fermat power of rounds 1-4 took ~25 us in BLS12-381's Fq)
     for (uint64_t i = n; i-- > 0;) {
         const uint64_t* p = xyz + i * 3 * L;
         uint64_t* o = xy + i * 2 * L;
