@@ -358,10 +358,22 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 std::memset(&multi, 0, sizeof multi);
                 if (fuse) {                                              // the digits of MSM q: n_dig rows of dstride words from dig32 + q * n_dig * dstride
                     multi.count = (uint32_t)count; multi.set_stride = M;
+                    PreDigitsMulti dm;
+                    std::memset(&dm, 0, sizeof dm);
+                    unsigned long long n_max = 0;
                     for (int q = 0; q < count; q++) {
                         multi.n[q] = items[q].n; multi.base_off[q] = items[q].base_off;
-                        hipLaunchKernelGGL((pre_digits_kernel<FR>), dim3((unsigned)((items[q].n + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0, sst,
-                                           items[q].d_scalars, items[q].n, is_mont, c, n_dig, dig32 + (size_t)q * n_dig * dstride, dstride);
+                        dm.scalars[q] = items[q].d_scalars; dm.n[q] = items[q].n;
+                        n_max = std::max<unsigned long long>(n_max, items[q].n);
+                    }
+                    static const bool digits_per_msm = std::getenv("MZK_MSM_DIGITS_PER_MSM") != nullptr;      // (A/B switch: the launches of rounds 4-5)
+                    if (digits_per_msm) {
+                        for (int q = 0; q < count; q++)
+                            hipLaunchKernelGGL((pre_digits_kernel<FR>), dim3((unsigned)((items[q].n + MSM_THREADS - 1) / MSM_THREADS)), dim3(MSM_THREADS), 0, sst,
+                                               items[q].d_scalars, items[q].n, is_mont, c, n_dig, dig32 + (size_t)q * n_dig * dstride, dstride);
+                    } else if (n_max) {
+                        hipLaunchKernelGGL((pre_digits_multi_kernel<FR>), dim3((unsigned)((n_max + MSM_THREADS - 1) / MSM_THREADS), (unsigned)count), dim3(MSM_THREADS), 0, sst,
+                                           dm, is_mont, c, n_dig, dig32, dstride);
                     }
                 } else {
                     hipLaunchKernelGGL((pre_digits_kernel<FR>), dim3(gs), dim3(MSM_THREADS), 0, sst, d_scalars, n, is_mont, c, n_dig, dig32, dstride);

@@ -67,6 +67,28 @@ __global__ __launch_bounds__(MSM_THREADS) void pre_digits_kernel(const uint32_t*
     }
 }
 
+// the digits of all MSMs of a FUSED batch in one launch (blockIdx.y = MSM q: its scalars, its length, its rows of `digits`): the five or
+// six launches of a commit group were 7 us each on a corner of the chip, one after the other
+struct PreDigitsMulti {
+    const uint32_t* scalars[PRE_FUSE_MAX];
+    unsigned long long n[PRE_FUSE_MAX];
+};
+template <class FR>
+__global__ __launch_bounds__(MSM_THREADS) void pre_digits_multi_kernel(PreDigitsMulti m, int is_mont, int c, int n_win, uint32_t* __restrict__ digits,
+                                                                        unsigned long long stride) {
+    const uint32_t q = blockIdx.y;
+    const unsigned long long i = (unsigned long long)blockIdx.x * MSM_THREADS + threadIdx.x;
+    if (i >= m.n[q]) return;
+    DigitIter it;
+    load_scalar<FR>(it, m.scalars[q], i, is_mont);
+    uint32_t* out = digits + (size_t)q * n_win * stride;
+    for (int w = 0; w < n_win; w++) {
+        uint32_t mag, ng;
+        it.next(w, c, mag, ng);
+        out[(size_t)w * stride + i] = mag ? ((ng << 31) | (mag - 1)) : PRE_EMPTY;
+    }
+}
+
 // Coarse partition on the top bucket bits.  A workgroup owns PRE_CHUNK scalars (all their windows).
 //   pre_coarse_count:   bin_total[bin] += entries of this chunk in that bin          (bin_total zeroed first)
 //   pre_bin_scan:       bin_start = exclusive scan of bin_total (n_bins + 1 entries), bin_cursor = copy

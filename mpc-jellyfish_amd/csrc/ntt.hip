@@ -150,7 +150,13 @@ int32_t ntt_dev(int curve, uint32_t* d_data, uint64_t in_len, int log_n, bool in
     if (batch == 0) return MZK_OK;
     if (stride < N || batch > 65535 || (d_src && src_stride < in_len) || (d_patch && (!d_src || N < 4))) { set_error("bad batch/stride"); return MZK_ERR_INVALID_ARG; }
     if (in_len > N) in_len = N;
-    if (log_n == 0 && scale == 0) return MZK_OK;   // size-1 transform is the identity (offset^0 = 1, N^-1 = 1)
+    if (log_n == 0 && scale == 0) {
+        // size-1 transform is the identity (offset^0 = 1, N^-1 = 1) -- of the zero-padded input: an EMPTY input gives 0, not what the buffer
+        // held (found by tools/soak.py in round 5), and a separate source is copied
+        if (in_len == 0) HIP_TRY(hipMemset2DAsync(d_data, stride * 32, 0, 32, batch, st));
+        else if (d_src) HIP_TRY(hipMemcpy2DAsync(d_data, stride * 32, d_src, src_stride * 32, 32, batch, hipMemcpyDeviceToDevice, st));
+        return MZK_OK;
+    }
     if (log_n == 0) { set_error("scaled size-1 transform"); return MZK_ERR_UNSUPPORTED; }
     NttPlanDev* pl;
     MZK_TRY(get_plan<X>(curve, log_n, inverse, coset, scale, &pl));
