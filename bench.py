@@ -1010,7 +1010,9 @@ def main():
             for name, key in (("turbo_bls12_381", "prove_cpp_host_ms"), ("turbo_bls12_381_32768_gates", "prove_cpp_host_2p15_ms"),
                               ("turbo_bls12_381_1024_gates", "prove_cpp_host_2p10_ms"), ("ultra_bn254_32768_gates", "prove_cpp_host_ultra_2p15_ms")):
                 if "prove_ms" in prove_cpp.get(name, {}):
-                    flat[key] = prove_cpp[name]["prove_ms"]
+                    flat[key] = prove_cpp[name]["prove_ms"]                       # mean over the repetitions, like every figure since round 1
+                if "prove_median_ms" in prove_cpp.get(name, {}):
+                    flat[key.replace("_ms", "_median_ms")] = prove_cpp[name]["prove_median_ms"]
         if prove_replicas:
             flat.update({"prove_replicas_proofs_per_s": prove_replicas.get("proofs_per_s"), "prove_replicas_ranks_agree": prove_replicas.get("ranks_agree_on_proof")})
         vi = out["roofline"].get("valu_issue") or {}

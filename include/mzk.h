@@ -312,6 +312,13 @@ MZK_API int32_t mzk_poly_lincomb_dev(int32_t curve_id, uint32_t n_terms, const v
  * n_polys x n_blinders x 4 limbs, host (the `DensePolynomial::rand` draws, 1 <= n_blinders <= 4).  Asynchronous. */
 MZK_API int32_t mzk_poly_mask_dev(int32_t curve_id, uint32_t n_polys, void* const* d_polys, uint64_t n, uint32_t n_blinders,
                                   const uint64_t* blinders_mont, void* stream);
+/* `split_quotient_polynomial` (prover.rs:902-960) in one launch: the W (n + 1) + 3 coefficients at d_quot (the quotient's expected degree is
+ * W (n + 1) + 2, W = n_parts, 2..8) into n_parts rows of out_stride (>= n + 3) slots at d_out: row i holds the coefficients
+ * [i (n + 2), (i + 1)(n + 2)) -- the last row what is left -- plus the blinder b_i as coefficient n + 2 (rows before the last) minus
+ * b_{i-1} in the constant term (rows after the first); every other slot of a row is zeroed.  blinders_mont: (n_parts - 1) x 4 limbs, host.
+ * d_out must not overlap d_quot.  Asynchronous. */
+MZK_API int32_t mzk_poly_split_quotient_dev(int32_t curve_id, const void* d_quot, uint64_t n, uint32_t n_parts, const uint64_t* blinders_mont,
+                                            void* d_out, uint64_t out_stride, void* stream);
 /* quotient of p(X) / (X - z), len - 1 coefficients into d_out (remainder dropped, as ark-poly's `/` does at
  * prover.rs:504-506).  d_out must not alias d_poly.  Asynchronous. */
 MZK_API int32_t mzk_poly_div_linear_dev(int32_t curve_id, const void* d_poly, uint64_t len, const uint64_t* z_mont, void* d_out, void* stream);
@@ -496,6 +503,8 @@ MZK_API int32_t mzk_dev_copy(void* dst, const void* src, uint64_t bytes, void* s
 MZK_API int32_t mzk_dev_copy_peer(void* dst, int32_t dst_device, const void* src, int32_t src_device, uint64_t bytes, void* stream);
 MZK_API int32_t mzk_dev_copy2d(void* dst, uint64_t dst_pitch, const void* src, uint64_t src_pitch, uint64_t width, uint64_t height, void* stream);
 MZK_API int32_t mzk_dev_memset(void* dptr, int32_t value, uint64_t bytes, void* stream);
+/* `height` runs of `width` bytes, `pitch` bytes apart, in one launch (the tails of the rows of a coefficient slab) */
+MZK_API int32_t mzk_dev_memset2d(void* dptr, uint64_t pitch, int32_t value, uint64_t width, uint64_t height, void* stream);
 
 /* ---- measurement hooks (bench.py): HIP-event timing of the library's own kernels ---- */
 /* on != 0: every subsequent call brackets its dominant kernels with hipEvents on the launch stream. */

@@ -164,6 +164,7 @@ int32_t poly_lincomb_dispatch(int curve, uint32_t n_terms, const uint32_t* const
                               uint64_t out_len, hipStream_t st);
 int32_t poly_degree_dispatch(const uint32_t* d_poly, uint64_t len, unsigned long long* d_out, hipStream_t st);
 int32_t wire_gather_dispatch(const uint32_t* d_witness, uint64_t n_vars, const uint32_t* d_vars, uint64_t count, uint32_t* d_out, hipStream_t st);
+int32_t poly_split_quotient_dispatch(int curve, const uint32_t* d_q, uint64_t n, uint32_t W, const uint32_t* blind_mont, uint32_t* d_out, uint64_t stride, hipStream_t st);
 int32_t poly_mask_dispatch(int curve, uint32_t n_rows, uint32_t* const* d_rows, uint64_t n, uint32_t n_blind, const uint32_t* blind_mont, hipStream_t st);
 // plonk.hip
 int32_t plonk_pk_register(int curve, int log_n, int W, const uint32_t* sel, const uint32_t* sig, const uint32_t* tab /* NULL: TurboPlonk */,

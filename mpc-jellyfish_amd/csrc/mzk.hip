@@ -927,6 +927,12 @@ int32_t mzk_poly_mask_dev(int32_t curve_id, uint32_t n_polys, void* const* d_pol
     return poly_mask_dispatch(curve_id, n_polys, reinterpret_cast<uint32_t* const*>(d_polys), n, n_blinders, reinterpret_cast<const uint32_t*>(blinders_mont),
                               (hipStream_t)stream);
 }
+int32_t mzk_poly_split_quotient_dev(int32_t curve_id, const void* d_quot, uint64_t n, uint32_t n_parts, const uint64_t* blinders_mont, void* d_out, uint64_t out_stride, void* stream) {
+    ENTER_CUR();
+    if (!d_quot || !d_out || !blinders_mont) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
+    return poly_split_quotient_dispatch(curve_id, reinterpret_cast<const uint32_t*>(d_quot), n, n_parts, reinterpret_cast<const uint32_t*>(blinders_mont),
+                                        reinterpret_cast<uint32_t*>(d_out), out_stride, (hipStream_t)stream);
+}
 int32_t mzk_plonk_gather_witness_dev(const void* d_witness, uint64_t n_vars, const void* d_wire_variables, uint64_t count, void* d_out, void* stream) {
     ENTER_CUR();
     if (count && (!d_witness || !d_wire_variables || !d_out)) { set_error("null pointer"); return MZK_ERR_INVALID_ARG; }
@@ -1089,6 +1095,12 @@ int32_t mzk_dev_copy2d(void* dst, uint64_t dst_pitch, const void* src, uint64_t 
     ENTER_CUR();
     if (width && height && (!dst || !src || width > dst_pitch || width > src_pitch)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
     if (width && height) HIP_TRY(hipMemcpy2DAsync(dst, dst_pitch, src, src_pitch, width, height, hipMemcpyDeviceToDevice, (hipStream_t)stream));
+    return MZK_OK;
+}
+int32_t mzk_dev_memset2d(void* dptr, uint64_t pitch, int32_t value, uint64_t width, uint64_t height, void* stream) {
+    ENTER_CUR();
+    if (width && height && (!dptr || width > pitch)) { set_error("bad argument"); return MZK_ERR_INVALID_ARG; }
+    if (width && height) HIP_TRY(hipMemset2DAsync(dptr, pitch, value, width, height, (hipStream_t)stream));
     return MZK_OK;
 }
 int32_t mzk_dev_memset(void* dptr, int32_t value, uint64_t bytes, void* stream) {

@@ -303,6 +303,46 @@ __global__ void poly_mask_kernel(MaskArgs a) {
     store_fp<P>(p + (a.n + j) * 8, b);
 }
 
+// ---- a13: split_quotient_polynomial (plonk/src/proof_system/prover.rs:902-960) in one launch ----------------------------------------
+// The quotient's W(n + 1) + 3 coefficients into W rows of `stride` (>= n + 3) slots: row i takes the coefficients [i (n + 2), (i + 1)(n + 2))
+// (the last row: what is left up to the expected degree), row i < W - 1 gets the blinder b_i as coefficient n + 2 and row i > 0 loses
+// b_{i-1} from its constant term (:946-957); every other slot of a row is zeroed.  Two lanes per 32-byte element (16 B each) for the copy.
+constexpr int SPLIT_MAX_ROWS = 8;
+struct SplitArgs {
+    const uint32_t* q;
+    uint32_t* out;
+    unsigned long long n, stride, expected;     // expected = W (n + 1) + 2: the quotient's degree
+    int W;
+    uint32_t blind[SPLIT_MAX_ROWS - 1][8];      // Montgomery
+};
+template <class P>
+__global__ __launch_bounds__(256) void poly_split_quotient_kernel(SplitArgs a) {
+    using F = Fp<P>;
+    const unsigned long long t = (unsigned long long)blockIdx.x * 256 + threadIdx.x;
+    const unsigned int i = blockIdx.y;
+    if (t >= 2 * a.stride) return;
+    const unsigned long long j = t >> 1;
+    const unsigned long long lo = (unsigned long long)i * (a.n + 2), hi = (int)i < a.W - 1 ? lo + a.n + 2 : a.expected + 1;
+    uint4* dst = reinterpret_cast<uint4*>(a.out + ((size_t)i * a.stride + j) * 8) + (t & 1);
+    const bool edge = (j == 0 && i > 0) || (j == a.n + 2 && (int)i < a.W - 1);
+    if (!edge) {
+        *dst = lo + j < hi ? reinterpret_cast<const uint4*>(a.q + (lo + j) * 8)[t & 1] : make_uint4(0, 0, 0, 0);
+        return;
+    }
+    if (t & 1) return;                                                       // the two edge elements of a row: one lane does the field arithmetic
+    F v;
+    if (j == 0) {
+        F b;
+#pragma unroll
+        for (int k = 0; k < 8; k++) b.l[k] = a.blind[i - 1][k];
+        v = (lo < hi ? load_fp<P>(a.q + lo * 8) : F::zero()) - b;
+    } else {
+#pragma unroll
+        for (int k = 0; k < 8; k++) v.l[k] = a.blind[i][k];
+    }
+    store_fp<P>(a.out + ((size_t)i * a.stride + j) * 8, v);
+}
+
 // ---- a1: the gather of Arithmetization::compute_wire_polynomials (relation/src/constraint_system.rs:1225-1247) -----------------------
 // out[t] = witness[wire_variables[t]] for the W * n cells of the wire table: 32-byte elements, two lanes per element (16 B each),
 // so a wave reads and writes whole 128-byte lines where the indices run (the bench circuit's mostly do).  Field-independent.

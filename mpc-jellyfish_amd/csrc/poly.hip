@@ -298,4 +298,18 @@ int32_t poly_mask_dispatch(int curve, uint32_t n_rows, uint32_t* const* d_rows, 
     return MZK_OK;
 }
 
+int32_t poly_split_quotient_dispatch(int curve, const uint32_t* d_q, uint64_t n, uint32_t W, const uint32_t* blind_mont, uint32_t* d_out, uint64_t stride, hipStream_t st) {
+    if (W < 2 || W > SPLIT_MAX_ROWS || n + 5 <= W || stride < n + 3 || stride >= (1ull << 40)) { set_error("split_quotient: 2..8 parts, rows of at least n + 3 slots"); return MZK_ERR_INVALID_ARG; }
+    SplitArgs a;
+    a.q = d_q; a.out = d_out; a.n = n; a.stride = stride; a.expected = (uint64_t)W * (n + 1) + 2; a.W = (int)W;
+    std::memset(a.blind, 0, sizeof a.blind);
+    for (uint32_t i = 0; i + 1 < W; i++) std::memcpy(a.blind[i], blind_mont + (size_t)i * 8, 32);
+    const dim3 grid((unsigned)((2 * stride + 255) / 256), W);
+    if (curve == 0) hipLaunchKernelGGL((poly_split_quotient_kernel<BlsFr>), grid, dim3(256), 0, st, a);
+    else if (curve == 1) hipLaunchKernelGGL((poly_split_quotient_kernel<BnFr>), grid, dim3(256), 0, st, a);
+    else { set_error("unknown curve_id"); return MZK_ERR_INVALID_ARG; }
+    HIP_TRY(hipGetLastError());
+    return MZK_OK;
+}
+
 }  // namespace mzk

@@ -17,6 +17,7 @@
 #include <cstdlib>
 #include <memory>
 
+#include <algorithm>
 #include "mzk_prover.hpp"
 
 using namespace mzk_host;
@@ -56,14 +57,25 @@ int run(bool ultra, uint64_t num_gates, int reps, int range_bits, const Options&
     const double preprocess_s = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     Proof<C> proof = sp.prove(rng, false, opt.check_agree);             // the proof whose bytes are printed (and warm-up)
     const std::vector<uint8_t> bytes = proof.serialize_compressed();
-    double ms = 0;
+    double ms = 0, median_ms = 0, min_ms = 0, max_ms = 0;
     if (reps > 0) {
         for (int i = 0; i < 2; i++) sp.prove(rng);
         sp.sync();
+        // prove() returns the finished proof, so every repetition can be read off the clock on its own: the mean is what the figures of
+        // rounds 1-5 are; the median says what a proof takes when nothing else happens on the host (one in a few dozen takes milliseconds longer)
+        std::vector<double> each;
         t0 = std::chrono::steady_clock::now();
-        for (int i = 0; i < reps; i++) sp.prove(rng);
+        auto t1 = t0;
+        for (int i = 0; i < reps; i++) {
+            sp.prove(rng);
+            const auto t2 = std::chrono::steady_clock::now();
+            each.push_back(std::chrono::duration<double, std::milli>(t2 - t1).count());
+            t1 = t2;
+        }
         sp.sync();
         ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count() / reps;
+        std::sort(each.begin(), each.end());
+        median_ms = each[each.size() / 2]; min_ms = each.front(); max_ms = each.back();
         sp.prove(rng, true);
     }
     Prover<C>& prover = *sp.prover[0];
@@ -71,9 +83,9 @@ int run(bool ultra, uint64_t num_gates, int reps, int range_bits, const Options&
     static const char* d = "0123456789abcdef";
     for (uint8_t b : bytes) { hex.push_back(d[b >> 4]); hex.push_back(d[b & 15]); }
     std::printf("{\"curve\": %d, \"plonk_type\": \"%s\", \"num_gates\": %llu, \"log_n\": %d, \"gpus\": %d, \"host_witness\": %s, \"lagrange_round1\": %s, \"proof_bytes\": %zu, "
-                "\"prove_ms\": %.3f, \"circuit_build_s\": %.3f, \"preprocess_s\": %.3f, \"lagrange_key_s\": %.3f, \"rounds_ms\": {",
+                "\"prove_ms\": %.3f, \"prove_median_ms\": %.3f, \"prove_min_ms\": %.3f, \"prove_max_ms\": %.3f, \"circuit_build_s\": %.3f, \"preprocess_s\": %.3f, \"lagrange_key_s\": %.3f, \"rounds_ms\": {",
                 C::ID, ultra ? "UltraPlonk" : "TurboPlonk", (unsigned long long)num_gates, host.log_n, opt.gpus, opt.host_witness == 0 ? "false" : (opt.host_witness == 1 ? "\"wire table\"" : "\"witness vector\""), lagrange ? "true" : "false",
-                bytes.size(), ms, circuit_s, preprocess_s, sp.lagrange_key_s);
+                bytes.size(), ms, median_ms, min_ms, max_ms, circuit_s, preprocess_s, sp.lagrange_key_s);
     bool first = true;
     for (auto& kv : prover.timings_ms) { std::printf("%s\"%s\": %.3f", first ? "" : ", ", kv.first.c_str(), kv.second); first = false; }
     std::vector<uint8_t> vk_bytes;                                      // VerifyingKey commitments (selectors, then sigmas), compressed

@@ -70,6 +70,7 @@ _SIGS = {
     "mzk_plonk_gather_witness_dev": [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p],
     "mzk_poly_eval_dev": [C.c_int32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p],
     "mzk_poly_lincomb_dev": [C.c_int32, C.c_uint32, C.POINTER(C.c_void_p), C.POINTER(C.c_uint64), C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p],
+    "mzk_poly_split_quotient_dev": [C.c_int32, C.c_void_p, C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p],
     "mzk_poly_mask_dev": [C.c_int32, C.c_uint32, C.POINTER(C.c_void_p), C.c_uint64, C.c_uint32, C.c_void_p, C.c_void_p],
     "mzk_poly_div_linear_dev": [C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p],
     "mzk_poly_div_linear_rem_dev": [C.c_int32, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p],
@@ -89,6 +90,7 @@ _SIGS = {
     "mzk_dev_copy": [C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p],
     "mzk_dev_copy2d": [C.c_void_p, C.c_uint64, C.c_void_p, C.c_uint64, C.c_uint64, C.c_uint64, C.c_void_p],
     "mzk_dev_memset": [C.c_void_p, C.c_int32, C.c_uint64, C.c_void_p],
+    "mzk_dev_memset2d": [C.c_void_p, C.c_uint64, C.c_int32, C.c_uint64, C.c_uint64, C.c_void_p],
     "mzk_profile_enable": [C.c_int32],
     "mzk_profile_get": [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_uint64)],
     "mzk_profile_reset": [],

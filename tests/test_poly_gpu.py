@@ -157,3 +157,55 @@ def test_gather_witness_and_stream_helpers(gpu, mj):
         assert np.array_equal(out.cpu().numpy().view(np.uint64), want)
     dev = C.c_int32(-7)
     assert L.mzk_get_device(C.byref(dev)) == 0 and dev.value == 0
+
+
+@pytest.mark.parametrize("curve_id", [0, 1])
+@pytest.mark.parametrize("n,W", [(4, 5), (8, 5), (16, 6), (1000, 5), (1 << 12, 6), ((1 << 16), 5), (37, 2), (64, 8)])
+def test_split_quotient_matches_the_reference_rule(gpu, mj, curve_id, n, W):
+    """mzk_poly_split_quotient_dev (round 3's split in one launch) against `split_quotient_polynomial` restated with Python integers
+    (plonk/src/proof_system/prover.rs:902-960): slices of n + 2 coefficients, the last one what is left up to degree W (n + 1) + 2,
+    slice i < W - 1 gains b_i X^(n+2), slice i > 0 loses b_{i-1} from its constant term; everything else in a row of `stride` slots is zero --
+    whatever the rows held before."""
+    import ctypes as C
+    import torch
+    from mpc_jellyfish_amd import lib as mlib
+    c = mj.params.CURVES[curve_id]
+    rng = random.Random(n * 31 + W)
+    expected = W * (n + 1) + 2
+    qi = [rng.randrange(c.r) for _ in range(expected + 1)] + [rng.randrange(c.r) for _ in range(5)]     # (what lies beyond the degree is not read)
+    b = [rng.randrange(c.r) for _ in range(W - 1)]
+    L = mlib.ensure_init()
+    for stride in (n + 3, n + 7):
+        d_q = _dev(fr_mont_limbs(c, qi))
+        d_out = _dev(mj.params.random_fr_mont(c, W * stride, seed=9))                                  # dirty rows
+        bl = fr_mont_limbs(c, b)
+        mlib.check(L.mzk_poly_split_quotient_dev(curve_id, C.c_void_p(d_q.data_ptr()), n, W, C.c_void_p(bl.ctypes.data), C.c_void_p(d_out.data_ptr()), stride, None),
+                   "mzk_poly_split_quotient_dev")
+        torch.cuda.synchronize()
+        got = fr_from_mont_limbs(c, d_out.cpu().numpy().view(np.uint64).reshape(-1, 4))
+        for i in range(W):
+            lo, hi = i * (n + 2), ((i + 1) * (n + 2) if i < W - 1 else expected + 1)
+            want = qi[lo:hi] + [0] * (stride - (hi - lo))
+            if i < W - 1:
+                want[n + 2] = b[i]
+            if i > 0:
+                want[0] = (want[0] - b[i - 1]) % c.r
+            assert got[i * stride:(i + 1) * stride] == want, (n, W, stride, i)
+    # argument checks: too many parts, rows too short
+    assert L.mzk_poly_split_quotient_dev(curve_id, C.c_void_p(d_q.data_ptr()), n, 9, C.c_void_p(bl.ctypes.data), C.c_void_p(d_out.data_ptr()), n + 3, None) == -1
+    assert L.mzk_poly_split_quotient_dev(curve_id, C.c_void_p(d_q.data_ptr()), n, W, C.c_void_p(bl.ctypes.data), C.c_void_p(d_out.data_ptr()), n + 2, None) == -1
+
+
+def test_memset2d(gpu, mj):
+    """mzk_dev_memset2d: `height` runs of `width` bytes, `pitch` apart, nothing else touched."""
+    import ctypes as C
+    import torch
+    from mpc_jellyfish_amd import lib as mlib
+    L = mlib.ensure_init()
+    a = torch.full((7, 100), 0x55, dtype=torch.uint8, device="cuda")
+    mlib.check(L.mzk_dev_memset2d(C.c_void_p(a.data_ptr() + 90), 100, 0, 10, 7, None), "mzk_dev_memset2d")
+    torch.cuda.synchronize()
+    h = a.cpu().numpy()
+    assert (h[:, :90] == 0x55).all() and (h[:, 90:] == 0).all()
+    assert L.mzk_dev_memset2d(C.c_void_p(a.data_ptr()), 5, 0, 10, 7, None) == -1
+    assert L.mzk_dev_memset2d(None, 100, 0, 0, 7, None) == 0
