@@ -129,6 +129,8 @@ struct ProverT final : ProverBase {
     Buf fixed;                                                         // (nsel + W [+ 4]) x n coefficient forms
     Buf slab, quot, coeff, split, lin, batch, opening, shifted, hh, table, lookup, sorted, tmp, deg, rem, wv, wit, top, vals_ext, qsum, vars;
     Pinned stage_pi;
+    Pinned stage_back;                                                 // 64 B: the words a round reads back AFTER its commitments (quotient degree, batch value at zeta)
+                                                                       // are copied here asynchronously BEFORE them: no second device round trip at the end of the round
     uint64_t n_vars = 0;
     bool use_top = false;                                              // W classes + mzk_plonk_quotient_top_dev
     std::vector<uint32_t> classes, own;                                // the classes that determine the quotient; this rank's share of them
