@@ -30,17 +30,6 @@ void set_error(const std::string& s);
         }                                                                                     \
     } while (0)
 
-// Waiting for a stream the host needs the results of.  hipStreamSynchronize parks the thread and is woken by an interrupt (10-20 us after the
-// last kernel ended); with MZK_SPIN_WAIT=1 the thread polls the stream instead -- a core busy for the length of the wait, the results a few
-// microseconds earlier.  An experiment switch of round 5 (tools/ab_env.sh): off by default.
-inline hipError_t stream_wait(hipStream_t st) {
-    static const bool spin = std::getenv("MZK_SPIN_WAIT") != nullptr;
-    if (!spin) return hipStreamSynchronize(st);
-    hipError_t e;
-    while ((e = hipStreamQuery(st)) == hipErrorNotReady) __builtin_ia32_pause();
-    return e;
-}
-
 #define MZK_TRY(expr)                \
     do {                             \
         int32_t _r = (expr);         \

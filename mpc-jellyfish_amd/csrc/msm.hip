@@ -535,7 +535,7 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                                        hipMemcpyDeviceToHost, st));
     }
     MZK_TRY(ws_release(st));
-    HIP_TRY(stream_wait(st));
+    HIP_TRY(hipStreamSynchronize(st));
     if (defer_heavy) {
         const uint32_t* cw = reinterpret_cast<const uint32_t*>(static_cast<const uint8_t*>(g_ws.h_collect) + out_bytes);
         double grow = 0;

@@ -1040,7 +1040,7 @@ int32_t mzk_stream_destroy(void* stream) {
 }
 int32_t mzk_stream_sync(void* stream) {
     BIND_CUR();
-    HIP_TRY(stream_wait((hipStream_t)stream));
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return MZK_OK;
 }
 int32_t mzk_stream_wait_stream(void* waiter, void* signaller) {

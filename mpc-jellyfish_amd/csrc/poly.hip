@@ -30,7 +30,7 @@ int32_t eval_run(const uint32_t* d_coeffs, uint64_t stride, uint64_t len, uint32
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_host, d_out, (size_t)batch * 32, hipMemcpyDeviceToHost, st));
     MZK_TRY(ws_release(st));
-    HIP_TRY(stream_wait(st));
+    HIP_TRY(hipStreamSynchronize(st));
     return MZK_OK;
 }
 
@@ -77,7 +77,7 @@ int32_t eval_many_run(const EvalJob* jobs, uint32_t n_jobs, const uint32_t* x_mo
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipMemcpyAsync(out_host, d_out, (size_t)total * 32, hipMemcpyDeviceToHost, st));
     MZK_TRY(ws_release(st));
-    HIP_TRY(stream_wait(st));
+    HIP_TRY(hipStreamSynchronize(st));
     return MZK_OK;
 }
 
