@@ -427,19 +427,31 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_kernel(const u
 // Small and medium MSMs are latency bound: few buckets, each a chain of dependent mixed adds (~12 us apiece when a wave runs
 // alone).  There every bucket is split over S = 2^log_split threads -- thread s takes entries s, s + S, ... of the run -- and
 // msm_split_combine_kernel adds the S partial sums as a tree: chains S times shorter for (S - 1) M extra additions, log_split deep.
-template <class EC>
+//
+// LARGE plain-path MSMs, round 5 (last session): only the TAIL is split.  The buckets of rank < rank0 (ranks are window-major, by descending
+// load within a window: `order`) take one thread each and write their bucket directly; the buckets of rank >= rank0 -- what the launch
+// dispatches last -- are split.  With several bucket sets the last ranks are a whole window, light buckets AND heavy ones: a launch of
+// whole-bucket threads ends with the chip draining for the length of its chains (2.65-2.77 ms at 2^20 pairs), halving EVERY bucket costs an
+// addition per bucket (2.35 + 0.13 ms), splitting the last eighth of the ranks four ways 2.36 + 0.07.  (One bucket set -- the table path --
+// is ranked as a whole, so its launch ends on its lightest buckets and gains nothing: not used there.)  rank0 = 0: every bucket is split.
+// `sub` is laid out by RANK: the partial sums of the bucket of rank rank0 + r are sub[r S .. r S + S).
+// ONE_SET: one bucket set (the table path); it also gives the two paths' launches different names for the profiler.
+template <class EC, bool ONE_SET>
 __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_split_kernel(const uint32_t* __restrict__ bases, unsigned long long n,
                                                                                 const uint32_t* __restrict__ offs, const uint32_t* __restrict__ hist,
                                                                                 const uint32_t* __restrict__ sorted, const uint32_t* __restrict__ order,
                                                                                 uint32_t M, int n_win, uint32_t cap, int log_split, uint32_t* __restrict__ long_count,
-                                                                                uint32_t* __restrict__ sub) {
+                                                                                uint32_t* __restrict__ sub, unsigned long long rank0,
+                                                                                uint32_t* __restrict__ buckets, uint8_t* __restrict__ occ) {
     if (long_count && blockIdx.x == 0)
         for (unsigned i = threadIdx.x; i < (unsigned)n_win * (1 + MSM_HEAVY_COUNTERS); i += MSM_ACC_THREADS) long_count[i] = 0u;
     const unsigned long long t1 = (unsigned long long)blockIdx.x * MSM_ACC_THREADS + threadIdx.x;
-    const unsigned long long t0 = t1 >> log_split;
+    const bool whole = t1 < rank0;                                     // (rank0 is a multiple of the wave size: a wave is of one kind)
+    const unsigned long long u = whole ? 0ull : t1 - rank0;
+    const unsigned long long t0 = whole ? t1 : rank0 + (u >> log_split);
     if (t0 >= (unsigned long long)n_win * M) return;
-    const uint32_t S = 1u << log_split, part = (uint32_t)(t1 & (S - 1));
-    const unsigned long long w = t0 / M;
+    const uint32_t S = whole ? 1u : 1u << log_split, part = whole ? 0u : (uint32_t)(u & (S - 1));
+    const unsigned long long w = ONE_SET ? 0ull : t0 / M;
     const unsigned long long t = w * M + order[t0];
     const uint32_t start = offs[t];
     const uint32_t h = hist[t];
@@ -450,7 +462,13 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_accumulate_split_kernel(c
         const uint32_t e = list[k];
         acc = EC::madd(acc, EC::load_aff(bases, e & 0x7fffffffu), (e >> 31) != 0);
     }
-    EC::store_pt(sub, (t << log_split) + part, acc);
+    if (whole) {
+        const bool empty = acc.is_inf();
+        occ[t] = empty ? 0 : 1;
+        if (!empty) EC::store_pt(buckets, t, acc);
+    } else {
+        EC::store_pt(sub, u, acc);
+    }
 }
 // A workgroup takes 2 * MSM_ACC_THREADS consecutive partial sums (2 * MSM_ACC_THREADS / S whole buckets).  Level 0: every thread adds
 // one adjacent pair; level l: the first MSM_ACC_THREADS >> l threads add the pairs of the level before, which they find in LDS
@@ -479,8 +497,10 @@ __device__ __forceinline__ typename EC::Pt pt_lds_get(const uint32_t* lds, int s
     }
     return p;
 }
-template <class EC>
+// (the bucket of tail rank r is the one of rank rank0 + r: window-major `order`, as in the accumulation)
+template <class EC, bool ONE_SET>
 __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_split_combine_kernel(const uint32_t* __restrict__ sub, unsigned long long n_buckets, int log_split,
+                                                                             const uint32_t* __restrict__ order, uint32_t M, unsigned long long rank0,
                                                                              uint32_t* __restrict__ buckets, uint8_t* __restrict__ occ) {
     __shared__ uint32_t lds[MSM_ACC_THREADS * EC::PT_WORDS];
     const int tid = threadIdx.x;
@@ -503,9 +523,10 @@ __global__ __launch_bounds__(MSM_ACC_THREADS) void msm_split_combine_kernel(cons
         if (mine) {
             acc = EC::add(a, b);
             if (lvl == log_split - 1) {
+                const unsigned long long t0 = rank0 + (base >> log_split) + tid, w = ONE_SET ? 0ull : t0 / M, t = w * M + order[t0];
                 const bool empty = acc.is_inf();
-                occ[(base >> log_split) + tid] = empty ? 0 : 1;
-                if (!empty) EC::store_pt(buckets, (base >> log_split) + tid, acc);
+                occ[t] = empty ? 0 : 1;
+                if (!empty) EC::store_pt(buckets, t, acc);
             } else pt_lds_put<EC>(lds, tid, acc);
         }
     }

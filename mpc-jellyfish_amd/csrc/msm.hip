@@ -442,23 +442,42 @@ int32_t msm_group_dev(const MsmItem* items, int count, int c, int is_mont, const
                 }
                 static const int force_split = std::getenv("MZK_MSM_FORCE_SPLIT") ? std::atoi(std::getenv("MZK_MSM_FORCE_SPLIT")) : -1;      // (tuning switch: tools/msm_split_sweep.py)
                 if (force_split >= 0 && force_split <= 3) log_split = force_split;
+                // LARGE plain-path MSMs (several bucket sets, >= 2^18 buckets: several rounds of waves) that the rule above halves: whole-bucket
+                // threads for all but the last 1/8 of the ranks, four threads per bucket there (msm.cuh, msm_accumulate_split_kernel).  Headline
+                // step, same box, alternating: 3.30-3.31 against 3.33-3.37 ms (profiles/r05_d_tail_split.txt).  The table path's ONE bucket set is
+                // ranked as a whole and ends on its lightest buckets: no gain there (measured), not used.  MZK_MSM_NO_TAIL_SPLIT=1: the rule alone
+                // (A/B); MZK_MSM_TAIL_FRAC_LOG / MZK_MSM_TAIL_SPLIT: tuning switches.
+                static const bool no_tail = std::getenv("MZK_MSM_NO_TAIL_SPLIT") != nullptr;
+                static const int tail_frac_log = std::getenv("MZK_MSM_TAIL_FRAC_LOG") ? std::atoi(std::getenv("MZK_MSM_TAIL_FRAC_LOG")) : 3;
+                static const int tail_split = std::getenv("MZK_MSM_TAIL_SPLIT") ? std::atoi(std::getenv("MZK_MSM_TAIL_SPLIT")) : 2;
+                unsigned long long rank0 = 0;
+                if (!few_rounds && sets > 1 && !no_tail && force_split < 0 && log_split == 1 && mean >= 8 && tail_frac_log >= 1 && tail_frac_log <= 6 && tail_split >= 1 && tail_split <= 3) {
+                    rank0 = (wm - (wm >> tail_frac_log)) & ~(unsigned long long)(MSM_ACC_THREADS - 1);
+                    log_split = tail_split;
+                }
                 if (log_split == 0) {
                     ProfScope ps("msm_accumulate", st);
                     hipLaunchKernelGGL((msm_accumulate_kernel<EC>), dim3((unsigned)((wm + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), dim3(MSM_ACC_THREADS), 0, st,
                                        d_bases, list_stride, offs, hist, sorted, order, M, sets, cap, find_in_sort ? nullptr : desc_count, buckets, occ);
                 } else {
-                    const size_t threads = wm << log_split;
-                    MZK_TRY(g_ws.split.reserve(threads * EC::PT_WORDS * 4));
+                    const size_t n_split = (size_t)(wm - rank0), split_threads = n_split << log_split, threads = (size_t)rank0 + split_threads;
+                    MZK_TRY(g_ws.split.reserve(split_threads * EC::PT_WORDS * 4));
                     uint32_t* sub = g_ws.split.as<uint32_t>();
+                    const dim3 acc_grid((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)), cmb_grid((unsigned)((split_threads + 2 * MSM_ACC_THREADS - 1) / (2 * MSM_ACC_THREADS)));
                     {
                         ProfScope ps("msm_accumulate", st);               // the dominant launch alone: what rocprofv3 --stats averages
-                        hipLaunchKernelGGL((msm_accumulate_split_kernel<EC>), dim3((unsigned)((threads + MSM_ACC_THREADS - 1) / MSM_ACC_THREADS)),
-                                           dim3(MSM_ACC_THREADS), 0, st, d_bases, list_stride, offs, hist, sorted, order, M, sets, cap, log_split,
-                                           find_in_sort ? nullptr : desc_count, sub);
+                        if (sets == 1)
+                            hipLaunchKernelGGL((msm_accumulate_split_kernel<EC, true>), acc_grid, dim3(MSM_ACC_THREADS), 0, st, d_bases, list_stride, offs, hist, sorted, order, M, sets,
+                                               cap, log_split, find_in_sort ? nullptr : desc_count, sub, rank0, buckets, occ);
+                        else
+                            hipLaunchKernelGGL((msm_accumulate_split_kernel<EC, false>), acc_grid, dim3(MSM_ACC_THREADS), 0, st, d_bases, list_stride, offs, hist, sorted, order, M, sets,
+                                               cap, log_split, find_in_sort ? nullptr : desc_count, sub, rank0, buckets, occ);
                     }
                     ProfScope pc("msm_split_combine", st);
-                    hipLaunchKernelGGL((msm_split_combine_kernel<EC>), dim3((unsigned)((threads + 2 * MSM_ACC_THREADS - 1) / (2 * MSM_ACC_THREADS))), dim3(MSM_ACC_THREADS),
-                                       0, st, sub, (unsigned long long)wm, log_split, buckets, occ);
+                    if (sets == 1)
+                        hipLaunchKernelGGL((msm_split_combine_kernel<EC, true>), cmb_grid, dim3(MSM_ACC_THREADS), 0, st, sub, (unsigned long long)n_split, log_split, order, M, rank0, buckets, occ);
+                    else
+                        hipLaunchKernelGGL((msm_split_combine_kernel<EC, false>), cmb_grid, dim3(MSM_ACC_THREADS), 0, st, sub, (unsigned long long)n_split, log_split, order, M, rank0, buckets, occ);
                 }
             }
             {

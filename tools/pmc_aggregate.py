@@ -64,8 +64,8 @@ out = {"source": "tools/pmc_passes.sh + tools/pmc_aggregate.py: rocprofv3 --kern
        "msm_accumulate_SQ_INSTS_VALU": table[acc_name].get("SQ_INSTS_VALU"),
        "ntt_pass_kernel": ntt_name, "ntt_pass_hbm_bytes_per_launch": hbm(table[ntt_name], True),
        "ntt_pass_SQ_INSTS_VALU": table[ntt_name].get("SQ_INSTS_VALU"), "kernels": table}
-# table off: 16 windows of 2^15 buckets at 2^20 pairs -- mean load 32, so every bucket is split over several threads
-# (msm_accumulate_split_kernel + msm_split_combine_kernel); the accumulation launch is the one quoted
+# table off: 16 windows of 2^15 buckets at 2^20 pairs -- mean load 32: whole-bucket threads for the first 7/8 of the ranks, the last eighth
+# split four ways (msm_accumulate_split_kernel<EC, false> + msm_split_combine_kernel); the accumulation launch is the one quoted
 pname = next((k for k in plain if "msm_accumulate" in k), None)
 if pname:
     out.update({"msm_accumulate_plain_kernel": pname, "msm_accumulate_plain_hbm_bytes_per_launch": hbm(plain[pname], False),
