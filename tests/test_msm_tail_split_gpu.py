@@ -38,16 +38,16 @@ for curve_id, log_n in ((0, 20), (1, 21)):
     n = 1 << log_n
     c = mj.params.CURVES[curve_id]
     beta = 0x3c4d5e6f708192a3b4c5d6e7f8091a2b3c4d5e6f708192a3b4c5d6e7f8091a2b % c.r
-    pp = mj.UnivariateProverParam.gen_srs_for_testing(curve_id, beta, n - 1)
+    pp = mj.UnivariateProverParam.gen_srs_for_testing(curve_id, beta, n - 1 + 12350)
     beta_m = mj.params.fr_to_mont(c, [beta])[0]
-    dense = mj.params.random_fr_mont(c, n, seed=4100 + log_n)
-    skew = dense.copy()
+    dense = mj.params.random_fr_mont(c, n + 12345, seed=4100 + log_n)
+    skew = dense[:n].copy()
     skew[::2] = cref.fr_convert(curve_id, big(c.r - 2), True)[0]            # every second scalar equal: over-long buckets in every window
-    small = dense.copy()                                                    # the last 3/4 small counters: the high windows' buckets thin out
+    small = dense[:n].copy()                                                    # the last 3/4 small counters: the high windows' buckets thin out
     vals = np.zeros((n - n // 4, 4), dtype=np.uint64)
     vals[:, 0] = np.arange(n - n // 4, dtype=np.uint64)
     small[n // 4:] = cref.fr_convert(curve_id, vals, True)
-    for name, sc, off, m in (("dense", dense, 0, n), ("ragged", dense, 5, n - 12345), ("skew", skew, 0, n), ("small_tail", small, 0, n)):
+    for name, sc, off, m in (("dense", dense, 0, n), ("ragged", dense, 5, n + 12345), ("short", dense, 3, n - 54321), ("skew", skew, 0, n), ("small_tail", small, 0, n)):
         s = np.ascontiguousarray(sc[:m])
         t = torch.from_numpy(s.view(np.int64)).cuda()
         L.mzk_profile_reset()
@@ -76,7 +76,7 @@ def _run(env_extra):
         f = line.split()
         if f and f[0] == "CASE":
             out[(int(f[1]), f[3])] = dict(n_win=int(f[4]), n_buckets=int(f[5]), combined=int(f[6]), ok=int(f[7]), point=f[8])
-    assert len(out) == 8, r.stdout[-2000:]
+    assert len(out) == 10, r.stdout[-2000:]
     return out
 
 
@@ -85,7 +85,7 @@ def test_plain_path_large_msm_schedules_agree_with_the_oracle(gpu):
     for key, v in default.items():
         assert v["ok"] == 1, ("default schedule differs from [p(beta)]G", key)
         assert v["n_win"] > 1 and v["n_win"] * v["n_buckets"] >= 1 << 18, ("not the several-set plain path", key, v)
-        if key[1] in ("dense", "ragged"):                    # (skewed scalars may leave fewer than 32 entries per bucket: no split)
+        if key[1] in ("dense", "ragged"):                    # (fewer than 32 entries per bucket -- "short", skewed scalars -- : whole-bucket threads)
             assert v["combined"] == 1, ("the split path (and its combine launch) did not run", key)
     for switches in ({"MZK_MSM_NO_TAIL_SPLIT": "1"},                                          # every bucket halved (rounds 4-5)
                      {"MZK_MSM_FORCE_SPLIT": "0"},                                             # whole-bucket threads everywhere
