@@ -160,7 +160,10 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    cdev = dev if backend == "nccl" else torch.device("cpu")          # where collective payloads live
+    # MZK_BENCH_GLOO_CUDA=1 (rehearsal): gloo carrying CUDA tensors -- the payloads live where they live under RCCL, so the one-GPU box runs
+    # the very tensor handling of the nccl path (staging copies, device-to-device class exchange)
+    dev_payloads = backend == "nccl" or os.environ.get("MZK_BENCH_GLOO_CUDA") == "1"
+    cdev = dev if dev_payloads else torch.device("cpu")                # where collective payloads live
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if backend == "nccl":
@@ -173,7 +176,7 @@ def main():
     import ctypes as C
     mlib = import_module("mpc-jellyfish_amd.lib")
     L = mlib.init(local_rank)
-    coll_dev = dev if backend == "nccl" else None
+    coll_dev = dev if dev_payloads else None
 
     curve = mj.params.BLS12_381
     n = 1 << args.log_n

@@ -114,7 +114,8 @@ class TorchComm:
                 t = t.to(self.device)
             out = torch.empty(self.world * nbytes, dtype=torch.uint8, device=t.device)
             dist.all_gather_into_tensor(out, t, group=self.group)
-            C.memmove(recv, out.cpu().numpy().ctypes.data, self.world * nbytes)
+            host = out.cpu()                                             # (kept in a name until the memmove is done: with device payloads .cpu() makes a temporary)
+            C.memmove(recv, host.data_ptr(), self.world * nbytes)
         return self._guard(run)
 
     def _barrier(self, ctx):

@@ -60,11 +60,12 @@ def big_keys(d):
     return True
 
 
-def _two_ranks(extra_args, port):
+def _two_ranks(extra_args, port, env_extra=None):
     """port = None: `python bench.py --gpus 2` with NO launcher around it, as the driver's command line reads -- bench.py starts its
     own two workers (bench.self_launch); otherwise wrapped in torch.distributed.run, the contract's other form."""
     env = dict(os.environ, MZK_BENCH_BACKEND="gloo", MZK_BENCH_SINGLE_DEVICE="1", HSA_ENABLE_IPC_MODE_LEGACY="0")
     env.pop("WORLD_SIZE", None)
+    env.update(env_extra or {})
     launcher = [] if port is None else ["-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
                                         "--master-port", str(port)]
     cmd = [sys.executable] + launcher + [os.path.join(ROOT, "bench.py"), "--gpus", "2", "--log-n", "14", "--plonk-log-n", "10", "--ultra-sharded-log-n", "10",
@@ -78,7 +79,8 @@ def test_bench_two_ranks_rehearsal_and_watchdog(gpu):
     """The N > 1 launch of the contract, rehearsed with two ranks on the one GPU over gloo: one JSON line from rank 0 with the
     whole-job value and the sharded proofs; and with a secondary section that cannot finish in time, the watchdog still prints
     the headline line (the driver's SCALE run must never end without one)."""
-    out, lines = _two_ranks([], None)                    # no launcher: bench.py --gpus 2 launches its own workers
+    # no launcher: bench.py --gpus 2 launches its own workers; MZK_BENCH_GLOO_CUDA=1: the collectives' payloads in CUDA tensors, as under RCCL
+    out, lines = _two_ranks([], None, {"MZK_BENCH_GLOO_CUDA": "1"})
     assert out.returncode == 0, out.stderr[-3000:]
     assert len(lines) == 1, lines
     d = json.loads(lines[0])

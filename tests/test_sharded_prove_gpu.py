@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def _worker(rank, world, port, curve_id, plonk_type, num_gates, out_dir):
+def _worker(rank, world, port, curve_id, plonk_type, num_gates, out_dir, device_payloads=False):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     import torch.distributed as dist
@@ -27,13 +27,19 @@ def _worker(rank, world, port, curve_id, plonk_type, num_gates, out_dir):
         ck = mj.UnivariateProverParam.gen_srs_for_testing(c, mj.rng.fr_rand(c, rng), cs.n + 2)
         # (i) the product: this process is one rank of the library's own rounds (mzk_comm over torch.distributed: sharding.TorchComm),
         # keeping only its point range of the SRS
-        pk = mj.snark.preprocess(ck, cs, comm=mj.sharding.TorchComm() if world > 1 else None)
+        # device_payloads: the collectives' payloads in CUDA tensors, as under RCCL (staging tensors filled / drained by device-to-device
+        # copies, the class exchange device to device) -- gloo carries CUDA tensors too, so the one-GPU box rehearses that code path
+        import torch
+        comm_dev = torch.device("cuda", 0) if device_payloads else None
+        pk = mj.snark.preprocess(ck, cs, comm=mj.sharding.TorchComm(device=comm_dev) if world > 1 else None)
         g1 = mj.rng.test_rng()
         mj.rng.fr_rand(c, g1)
         _, proof_bytes = mj.snark.prove(g1, cs, pk)
         with open(os.path.join(out_dir, f"proof_{world}_{rank}.bin"), "wb") as f:
             f.write(proof_bytes)
         pk.release()
+        if device_payloads:
+            return
         # (ii) the test-side sequencing of the primitives with the torch.distributed committer (tests/mirror_prover.py)
         sys.path.insert(0, os.path.join(ROOT, "tests"))
         import mirror_prover as MP
@@ -64,6 +70,20 @@ def test_sharded_prove_matches_single_process(gpu, tmp_path, curve_id, plonk_typ
         for rank in range(world):
             assert (tmp_path / f"proof_{world}_{rank}.bin").read_bytes() == single, (world, rank)
             assert (tmp_path / f"mirror_{world}_{rank}.bin").read_bytes() == single, ("mirror", world, rank)
+
+
+@pytest.mark.parametrize("curve_id,plonk_type,num_gates,world", [(0, "TurboPlonk", 1 << 12, 2), (1, "UltraPlonk", 1 << 11, 3), (0, "TurboPlonk", 1 << 10, 5)])
+def test_sharded_prove_with_device_payloads(gpu, tmp_path, curve_id, plonk_type, num_gates, world):
+    """The library's rounds as one rank of a multi-process proof with the collectives' payloads in CUDA tensors -- the form
+    sharding.TorchComm / sharding.gather_partials take under RCCL (bench.py --gpus N): same proof bytes as the single-process run."""
+    import torch.multiprocessing as mp
+    port = 31500 + (os.getpid() + num_gates) % 2000
+    mp.spawn(_worker, args=(1, port, curve_id, plonk_type, num_gates, str(tmp_path), True), nprocs=1, join=True)
+    mp.spawn(_worker, args=(world, port + world, curve_id, plonk_type, num_gates, str(tmp_path), True), nprocs=world, join=True)
+    single = (tmp_path / "proof_1_0.bin").read_bytes()
+    assert len(single) > 500
+    for rank in range(world):
+        assert (tmp_path / f"proof_{world}_{rank}.bin").read_bytes() == single, (world, rank)
 
 
 @pytest.mark.parametrize("curve_id,plonk_type,num_gates,classes", [(0, "TurboPlonk", 1 << 10, list(range(8))), (1, "UltraPlonk", 1 << 9, list(range(8))),
