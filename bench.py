@@ -735,9 +735,10 @@ def main():
             dist.all_reduce(lo, op=dist.ReduceOp.MIN)
             dist.all_reduce(hi, op=dist.ReduceOp.MAX)
             core, _ = mj.snark.prove(rng, cs, prover, profile=True)
+            _, fresh = mj.snark.prove(mj.rng.test_rng(), cs, prover)        # from a fresh test_rng: the bytes `prove_replicas` reports (same SRS, circuit, seed)
             res = {"plonk_type": plonk_type, "curve": crv.name, "log_n": cs.n.bit_length() - 1, "chunked_quotient": chunked,
                    "prove_ms": round(float(tmax.item()), 2), "ranks_agree_on_proof": bool(lo.item() == hi.item()),
-                   "proof_bytes": len(proof_bytes), "rounds_ms_rank0": core.timings_ms}
+                   "proof_bytes": len(proof_bytes), "proof_sha16": hashlib.sha256(fresh).hexdigest()[:16], "rounds_ms_rank0": core.timings_ms}
             prover.release()
             ck.release()
             return res
@@ -750,6 +751,8 @@ def main():
                          }
         try:
             prove_sharded["turbo_bls12_381"] = sharded_prove(curve, args.plonk_log_n, "TurboPlonk")
+            if prove_replicas and "proof_sha16" in prove_replicas:            # the sharded proof IS the single-GPU proof, byte for byte
+                prove_sharded["same_proof_bytes_as_single_gpu_replicas"] = prove_sharded["turbo_bls12_381"]["proof_sha16"] == prove_replicas["proof_sha16"]
             if args.ultra_sharded_log_n:                               # config C5: UltraPlonk over BN254, 2^22 constraints
                 prove_sharded["ultra_bn254"] = sharded_prove(mj.params.BN254, args.ultra_sharded_log_n, "UltraPlonk")
         except Exception as e:                                         # noqa: BLE001  (secondary: the headline must still be printed)
@@ -1020,6 +1023,13 @@ def main():
                     flat[key.replace("_ms", "_median_ms")] = prove_cpp[name]["prove_median_ms"]
         if prove_replicas:
             flat.update({"prove_replicas_proofs_per_s": prove_replicas.get("proofs_per_s"), "prove_replicas_ranks_agree": prove_replicas.get("ranks_agree_on_proof")})
+        if prove_sharded and isinstance(prove_sharded.get("turbo_bls12_381"), dict):
+            flat.update({"prove_sharded_ms": prove_sharded["turbo_bls12_381"].get("prove_ms"),
+                         "prove_sharded_ranks_agree": prove_sharded["turbo_bls12_381"].get("ranks_agree_on_proof"),
+                         "prove_sharded_same_bytes_as_single_gpu": prove_sharded.get("same_proof_bytes_as_single_gpu_replicas")})
+        if prove_cpp_multi and "speedup" in prove_cpp_multi:
+            flat.update({"prove_cpp_host_multi_gpu_ms": prove_cpp_multi["gpus_%d" % world]["prove_ms"], "prove_cpp_host_multi_gpu_speedup": prove_cpp_multi["speedup"],
+                         "prove_cpp_host_multi_gpu_same_bytes": prove_cpp_multi.get("same_proof_bytes")})
         vi = out["roofline"].get("valu_issue") or {}
         out["roofline"].update({"valu_issue_util": vi.get("util"), "valu_issue_bound_ms": vi.get("issue_bound_ms"),
                                 "valu_wave_insts_per_launch": vi.get("wave_insts_per_launch"), "launches_per_msm": phases["kernel_launches"],

@@ -87,6 +87,7 @@ def test_bench_two_ranks_rehearsal_and_watchdog(gpu):
     assert d["n_gpus"] == 2 and d["scaling"] == "weak" and d["value"] > 0
     sh = d["prove_sharded"]
     assert "error" not in sh and sh["turbo_bls12_381"]["ranks_agree_on_proof"] and sh["ultra_bn254"]["ranks_agree_on_proof"]
+    assert sh["same_proof_bytes_as_single_gpu_replicas"] is True and d["prove_sharded_same_bytes_as_single_gpu"] is True and d["prove_sharded_ms"] > 0
     rp = d["prove_replicas"]                              # N independent provers, one per rank: proofs/s, the same proof bytes everywhere
     assert "error" not in rp and rp["ranks_agree_on_proof"] is True and rp["proofs_per_s"] > 0 and d["prove_replicas_proofs_per_s"] == rp["proofs_per_s"]
     cm = d["prove_cpp_host_multi_gpu"]                    # the compiled host driving both (virtual) devices from one process
