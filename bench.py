@@ -191,8 +191,6 @@ def main():
     scalars = mj.params.random_fr_mont(curve, n, seed=0x6d7a6b5f + rank)      # uniform in [0, r)
     d_scalars = torch.from_numpy(scalars.view(np.int64)).to(dev)
     torch.cuda.synchronize()
-    # the headline steps run with the fixed-base table OFF: nothing is precomputed per base (BASELINE configs[1], ark-ec's VariableBaseMSM)
-    L.mzk_msm_set_precompute(0)
 
     def step():
         jac = mj.msm_bigint(pp, d_scalars, scalars_are_mont=True)            # one Pippenger MSM, result on host
@@ -239,9 +237,22 @@ def main():
                   "kernel_launches": launches}
         return el, res, acc_ms / max(acc_cnt, 1), phases, mlib.msm_last_shape()
 
+    table_off_only = os.environ.get("MZK_BENCH_TABLE") == "0"   # tools/pmc_passes.sh: PMC passes of the headline kernels alone
+    # ---- secondary leg, run FIRST: the same W + K steps on the library's default path for a registered SRS (a fixed-base table of
+    #      precomputed multiples, built here explicitly and timed apart).  The two legs are independent (the switch below decides per MSM
+    #      whether the table is looked at); this one goes first because a card coming out of idle runs its first ~10 steps 5-7 % slower
+    #      (clock ramp: profiles/r05_f_warmup_ab.txt -- headline 3.48 ms after 2 warm-ups, 3.36 after 5, 3.31-3.32 after 50 or 200), and
+    #      the headline should be read at the sustained clocks a prover sees, not at the ramp.  --no-fixed-base gives the cold figure.
+    fb_raw = None
+    if not args.no_fixed_base and not table_off_only:
+        L.mzk_msm_set_precompute(1)
+        pc_bits, pc_levels, pc_bytes, pc_ms = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_double()
+        mlib.check(L.mzk_srs_precompute(pp.handle, C.byref(pc_bits), C.byref(pc_levels), C.byref(pc_bytes), C.byref(pc_ms)), "mzk_srs_precompute")
+        fb_raw = (pc_bits.value, pc_levels.value, pc_bytes.value, pc_ms.value) + tuple(timed_steps())
+    # the headline steps run with the fixed-base table OFF: nothing is precomputed per base (BASELINE configs[1], ark-ec's VariableBaseMSM)
+    L.mzk_msm_set_precompute(0)
     elapsed, result, acc_avg_ms, phases, (c_bits, n_win, n_buckets) = timed_steps()
     alg_bytes = 128.0 * n                          # N * (2*|Fq| + 32) bytes per BLS12-381 MSM
-    table_off_only = os.environ.get("MZK_BENCH_TABLE") == "0"   # tools/pmc_passes.sh: PMC passes of the headline kernels alone
 
     def msm_roofline(acc_ms, windows, pmc_prefix):
         achieved = alg_bytes / (acc_ms * 1e-3) / 1e9
@@ -275,7 +286,9 @@ def main():
                                    "library's default path for a registered SRS",
                        "curve": "bls12-381", "pairs_per_gpu": n, "window_bits": c_bits, "windows": n_win,
                        "buckets_per_window": n_buckets, "sharding": "point-range" if world > 1 else "none",
-                       "srs_gen_s": round(t_srs, 3)},
+                       "srs_gen_s": round(t_srs, 3),
+                       "leg_order": ("fixed_base leg (table build + W + K steps) ran before these W + K steps: sustained clocks"
+                                     if fb_raw is not None else "headline first (card out of idle: clock ramp inside the timed steps)")},
             "roofline": msm_roofline(acc_avg_ms, n_win, "msm_accumulate_plain"),
             "phases_ms": phases,
             "cpu_baseline": None, "fixed_base": None, "ntt": None, "plonk_round3": None, "batch_commit5": None, "prove": None,
@@ -309,17 +322,14 @@ def main():
         watchdog.daemon = True
         watchdog.start()
 
-    # ---- secondary: the same K steps on the library's default path for a registered SRS: a fixed-base table of precomputed multiples,
-    #      built here explicitly (the library would otherwise build it inside the first MSM) and timed -----
+    # ---- secondary: the fixed-base leg measured above, before the headline -----
     fixed_base = None
     L.mzk_msm_set_precompute(1)
-    if not args.no_fixed_base and not table_off_only:
-        pc_bits, pc_levels, pc_bytes, pc_ms = C.c_uint32(), C.c_uint32(), C.c_uint64(), C.c_double()
-        mlib.check(L.mzk_srs_precompute(pp.handle, C.byref(pc_bits), C.byref(pc_levels), C.byref(pc_bytes), C.byref(pc_ms)), "mzk_srs_precompute")
-        precompute = {"window_bits": pc_bits.value, "levels": pc_levels.value, "table_bytes": pc_bytes.value, "build_ms": round(pc_ms.value, 2),
+    if fb_raw is not None:
+        pcb, pcl, pcy, pcm, fb_el, fb_res, fb_acc, fb_phases, (fc, fw, fm) = fb_raw
+        precompute = {"window_bits": pcb, "levels": pcl, "table_bytes": pcy, "build_ms": round(pcm, 2),
                       "note": "fixed-base table table[w][i] = 2^(c*w) * P_i of the registered SRS, built once per SRS by pre_next_level_kernel "
                               "OUTSIDE the timed region of this leg"}
-        fb_el, fb_res, fb_acc, fb_phases, (fc, fw, fm) = timed_steps()
         if rank == 0:
             fixed_base = {"what": "the headline's steps with mzk_msm_set_precompute(1), the library default: the digits of all windows index rows of "
                                   "the table and share ONE bucket set.  Legitimate for KZG (the commit key never changes, srs.rs:77-93) and what "
