@@ -237,6 +237,34 @@ def main():
                   "kernel_launches": launches}
         return el, res, acc_ms / max(acc_cnt, 1), phases, mlib.msm_last_shape()
 
+    # With several ranks every leg holds collectives (barriers around the timed steps, the sharded proofs): if a rank fails or stalls,
+    # the others would wait for ever and no line would be printed -- a watchdog prints the headline as it stands (once it exists) and ends
+    # the process with a NON-ZERO code (a stalled section is not a success).  Started before the first leg.
+    out = None
+    emit_lock = threading.Lock()
+    state = {"printed": False}
+
+    def emit():
+        with emit_lock:
+            if rank == 0 and not state["printed"]:
+                state["printed"] = True
+                print(json.dumps(out), flush=True)
+
+    def bail():
+        if rank == 0:
+            with emit_lock:
+                if not state["printed"] and out is not None:
+                    out["prove_sharded"] = {"error": "watchdog: the secondary multi-rank section did not finish in %d s" % args.secondary_timeout}
+                    state["printed"] = True
+                    print(json.dumps(out), flush=True)
+        os._exit(3)
+
+    watchdog = None
+    if world > 1 and args.secondary_timeout > 0:
+        watchdog = threading.Timer(args.secondary_timeout, bail)
+        watchdog.daemon = True
+        watchdog.start()
+
     table_off_only = os.environ.get("MZK_BENCH_TABLE") == "0"   # tools/pmc_passes.sh: PMC passes of the headline kernels alone
     # ---- secondary leg, run FIRST: the same W + K steps on the library's default path for a registered SRS (a fixed-base table of
     #      precomputed multiples, built here explicitly and timed apart).  The two legs are independent (the switch below decides per MSM
@@ -273,7 +301,6 @@ def main():
                 "avg_launch_ms": round(acc_ms, 4), "valu_issue": valu,
                 "note": "integer-ALU bound (381-bit Montgomery mixed adds), not HBM bound: see DESIGN.md"}
 
-    out = None
     if rank == 0:
         out = {
             "metric": "msm_g1_scalar_pairs_per_s", "value": world * n * args.steps / elapsed, "unit": "pairs/s",
@@ -295,32 +322,7 @@ def main():
             "prove_dropin": None, "prove_cpp_host": None, "prove_sharded": None, "prove_replicas": None, "prove_cpp_host_multi_gpu": None, "prove_ultra_bn254": None, "link_and_batch": None,
         }
 
-    # The headline line is complete here; everything below is secondary.  With several ranks the secondary part holds collectives
-    # (the sharded proofs): if a rank fails or stalls there, the others would wait for ever and the line would never be printed --
-    # a watchdog prints the headline as it stands and ends the process with a NON-ZERO code (a stalled section is not a success).
-    emit_lock = threading.Lock()
-    state = {"printed": False}
-
-    def emit():
-        with emit_lock:
-            if rank == 0 and not state["printed"]:
-                state["printed"] = True
-                print(json.dumps(out), flush=True)
-
-    def bail():
-        if rank == 0:
-            with emit_lock:
-                if not state["printed"]:
-                    out["prove_sharded"] = {"error": "watchdog: the secondary multi-rank section did not finish in %d s" % args.secondary_timeout}
-                    state["printed"] = True
-                    print(json.dumps(out), flush=True)
-        os._exit(3)
-
-    watchdog = None
-    if world > 1 and args.secondary_timeout > 0:
-        watchdog = threading.Timer(args.secondary_timeout, bail)
-        watchdog.daemon = True
-        watchdog.start()
+    # (the watchdog of the multi-rank sections was started before the MSM legs: see `bail` above)
 
     # ---- secondary: the fixed-base leg measured above, before the headline -----
     fixed_base = None
