@@ -50,6 +50,35 @@ def test_ntt_batch_longer_than_the_pipeline_pinned_and_pageable(gpu, mj, cref):
             assert L.mzk_host_free(p) == 0
 
 
+@pytest.mark.parametrize("curve_id", [0, 1])
+def test_ntt_batch_on_the_collaborative_provers_public_polynomials(gpu, mj, cref, curve_id):
+    """the multiprover transforms its PUBLIC polynomials -- 13 selectors and 5 sigmas of n coefficients each -- onto
+    the GENERATOR coset of the 8n-point quotient domain, one `coset.fft(poly.coeffs())` per polynomial
+    (plonk/src/multiprover/proof_system/prover.rs:364-371).  The swap is ONE mzk_ntt_batch call with in_lens = n: every row against the C
+    restatement of ark-poly's transform of the zero-padded coefficients (what `fft` does with a short slice)."""
+    L = mj.load()
+    c = mj.params.BLS12_381 if curve_id == 0 else mj.params.BN254
+    n, log_m = 1 << 9, 12                                                        # quot_domain = 8n
+    M = 1 << log_m
+    g = mj.params.fr_to_mont(c, [c.fr_generator])[0]
+    polys = [mj.params.random_fr_mont(c, n, seed=700 + 31 * curve_id + i) for i in range(13 + 5)]
+    polys[3][n - 5:] = 0                                                         # a selector of lower degree: trailing zero coefficients
+    polys[7][:] = 0                                                              # an unused selector: the zero polynomial
+    bufs = []
+    for s in polys:
+        a = np.empty((M, 4), dtype=np.uint64)
+        a[:n] = s
+        a[n:] = 0x5a5a5a5a5a5a5a5a                                              # beyond in_len: ignored
+        bufs.append(a)
+    ptrs = (C.c_void_p * len(bufs))(*[b.ctypes.data for b in bufs])
+    lens = (C.c_uint64 * len(bufs))(*[n] * len(bufs))
+    assert L.mzk_ntt_batch(curve_id, len(bufs), ptrs, lens, log_m, 0, g.ctypes.data_as(C.c_void_p)) == 0, L.mzk_last_error()
+    for s, b in zip(polys, bufs):
+        padded = np.concatenate([s, np.zeros((M - n, 4), dtype=np.uint64)])
+        assert np.array_equal(b, cref.ntt(curve_id, padded, log_m, False, g, threads=2))
+    assert not bufs[7].any()
+
+
 def test_host_register_and_error_paths(gpu, mj):
     L = mj.load()
     a = np.zeros((1 << 12, 4), dtype=np.uint64)
